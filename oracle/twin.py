@@ -1,0 +1,670 @@
+"""Python twin of the CPU oracle (TEST INFRASTRUCTURE, not product code).
+
+A literal, pure-Python restatement of the reference's variant-query hot path,
+using Python's native big integers for the anagram values.  It exists to
+  (1) pin the semantics against the reference's own known-answer tests and the
+      recorded outputs in tutorial.ipynb (tests/test_twin_golden.py),
+  (2) cross-check the C oracle (oracle/anx_oracle.c) on random inputs,
+  (3) generate the committed fixtures under tests/golden/ (tests/golden/make_fixtures.py).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+Parity status: PINNED by tests/main.rs 01xx-04xx known answers and tutorial.ipynb outputs.
+"""
+from __future__ import annotations
+
+import math
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+# src/types.rs:20-30
+PRIMES = [
+    2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97,
+    101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193,
+    197, 199, 211, 223, 227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307,
+    311, 313, 317, 331, 337, 347, 349, 353, 359, 367, 373, 379, 383, 389, 397, 401, 409, 419, 421,
+    431, 433, 439, 443, 449, 457, 461, 463, 467, 479, 487, 491, 499, 503, 509, 521, 523, 541, 547,
+    557, 563, 569, 571, 577, 587, 593, 599, 601, 607, 613, 617, 619, 631, 641, 643, 647, 653, 659,
+    661, 673, 677, 683, 691, 701, 709, 719, 727, 733, 739, 743, 751, 757, 761, 769, 773, 787, 797,
+    809, 811, 821, 823, 827, 829, 839, 853, 857, 859, 863, 877, 881, 883, 887, 907, 911, 919, 929,
+    937, 941, 947, 953, 967, 971, 977, 983, 991, 997,
+]
+
+MAX_ANAGRAM_DISTANCE = 12  # src/lib.rs:43
+MAX_EDIT_DISTANCE = 12  # src/lib.rs:46
+
+# Rust's str::trim() strips chars with the Unicode White_Space property.
+_RUST_WS = set(chr(c) for c in (
+    list(range(0x09, 0x0E)) + [0x20, 0x85, 0xA0, 0x1680] + list(range(0x2000, 0x200B))
+    + [0x2028, 0x2029, 0x202F, 0x205F, 0x3000]))
+
+
+def rust_trim(s: str) -> str:
+    b, e = 0, len(s)
+    while b < e and s[b] in _RUST_WS:
+        b += 1
+    while e > b and s[e - 1] in _RUST_WS:
+        e -= 1
+    return s[b:e]
+
+
+def rust_lines(data: str) -> List[str]:
+    """BufRead::lines(): split on '\n', strip one trailing '\r'; no final empty line."""
+    parts = data.split("\n")
+    if parts and parts[-1] == "":
+        parts.pop()
+    return [p[:-1] if p.endswith("\r") else p for p in parts]
+
+
+def is_lowercase(ch: str) -> bool:
+    """char::is_lowercase (Unicode Lowercase property) == Python str.islower() on one char."""
+    return ch.islower()
+
+
+# ---------------------------------------------------------------------------------------------
+# Alphabet  (src/lib.rs:369-407)
+# ---------------------------------------------------------------------------------------------
+Alphabet = List[List[str]]
+
+
+def parse_alphabet(data: str) -> Alphabet:
+    alphabet: Alphabet = []
+    for line in rust_lines(data):
+        if line == "":
+            continue
+        fields = []
+        for x in line.split("\t"):
+            if x == "\\s":
+                fields.append(" ")
+            elif x == "\\t":
+                fields.append("\t")
+            elif x == "\\n":
+                fields.append("\n")
+            else:
+                t = rust_trim(x)
+                if t != "":
+                    fields.append(t)
+        alphabet.append(fields)
+    return alphabet
+
+
+def read_alphabet(path: str) -> Alphabet:
+    with open(path, "r", encoding="utf-8", newline="") as f:
+        return parse_alphabet(f.read())
+
+
+# src/test.rs:3-31 (values of the 27-class test alphabet)
+TEST_ALPHABET: Alphabet = [[c, c.upper()] for c in "abcdefghijklmnopqrstuvwxyz"] + [[".", ","]]
+
+
+def _encode(text: str, alphabet: Alphabet) -> List[int]:
+    """Shared scan of anahash()/normalize_to_alphabet() (src/anahash.rs:16-80).
+
+    Returns class indices; unmatched characters are reported as -1.
+    Matching is on UTF-8 byte slices; we emulate with str.startswith on code points, which is
+    equivalent because alphabet members and the text are both valid UTF-8 starting at a char boundary.
+    """
+    out: List[int] = []
+    skip = 0
+    n = len(text)
+    for pos in range(n):
+        if skip > 0:
+            skip -= 1
+            continue
+        matched = False
+        for seqnr, chars in enumerate(alphabet):
+            for element in chars:
+                if text.startswith(element, pos):
+                    out.append(seqnr)
+                    matched = True
+                    skip = len(element) - 1
+                    break
+            if matched:
+                break
+        if not matched:
+            out.append(-1)
+    return out
+
+
+def normalize_to_alphabet(text: str, alphabet: Alphabet) -> List[int]:
+    """src/anahash.rs:50-80: UNK -> alphabet.len()+1."""
+    unk = len(alphabet) + 1
+    return [c if c >= 0 else unk for c in _encode(text, alphabet)]
+
+
+def anahash(text: str, alphabet: Alphabet) -> int:
+    """src/anahash.rs:16-47: product of primes; UNK -> PRIMES[alphabet.len()]; empty = 1."""
+    h = 1
+    unk = len(alphabet)
+    for c in _encode(text, alphabet):
+        h *= PRIMES[c if c >= 0 else unk]
+    return h
+
+
+# ---------------------------------------------------------------------------------------------
+# Anahash trait (src/anahash.rs:139-261)
+# ---------------------------------------------------------------------------------------------
+def av_character(seqnr: int) -> int:
+    return PRIMES[seqnr]
+
+
+def av_insert(a: int, b: int) -> int:
+    return b if a == 0 else a * b
+
+
+def av_contains(a: int, b: int) -> bool:
+    if b > a:
+        return False
+    return a % b == 0
+
+
+def av_delete(a: int, b: int) -> Optional[int]:
+    return a // b if av_contains(a, b) else None
+
+
+def av_is_empty(a: int) -> bool:
+    return a == 1 or a == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# Iterators (src/iterators.rs)
+# ---------------------------------------------------------------------------------------------
+def deletion_iterator(value: int, alphabet_size: int):
+    """src/iterators.rs:51-70: yields (value_after_deletion, charindex), descending charindex."""
+    if value == 1:
+        return
+    for iteration in range(alphabet_size):
+        charindex = alphabet_size - iteration - 1
+        r = av_delete(value, av_character(charindex))
+        if r is not None:
+            yield (r, charindex)
+
+
+def recurse_deletion_iterator(value: int, alphabet_size: int, singlebeam: bool = False,
+                              mindepth: Optional[int] = None, maxdepth: Optional[int] = None,
+                              breadthfirst: bool = False, unique: bool = False,
+                              empty_leaves: bool = True):
+    """src/iterators.rs:95-235: yields ((value, charindex), depth)."""
+    queue = deque([((value, 0), 0)])
+    mind = 1 if mindepth is None else mindepth
+    visited = set()
+    while queue:
+        if breadthfirst:
+            node, depth = queue.popleft()
+            if unique and node[0] in visited:
+                continue
+            if maxdepth is None or depth < maxdepth:
+                for child in deletion_iterator(node[0], alphabet_size):
+                    if unique and child[0] in visited:
+                        continue
+                    queue.append((child, depth + 1))
+            if depth < mind or ((not empty_leaves) and av_is_empty(node[0])):
+                continue
+            if unique:
+                visited.add(node[0])
+            yield (node, depth)
+        else:
+            node, depth = queue.pop()
+            if maxdepth is None or depth < maxdepth:
+                if unique and node[0] in visited:
+                    continue
+                children = deletion_iterator(node[0], alphabet_size)
+                if singlebeam:
+                    for child in children:
+                        queue.append((child, depth + 1))
+                        break
+                else:
+                    children = list(children)[::-1]
+                    for child in children:
+                        if unique and child[0] in visited:
+                            continue
+                        queue.append((child, depth + 1))
+            if depth < mind or ((not empty_leaves) and av_is_empty(node[0])):
+                continue
+            if unique:
+                visited.add(node[0])
+            yield (node, depth)
+
+
+def av_iter(value: int, alphabet_size: int):
+    """src/anahash.rs:192-204."""
+    return recurse_deletion_iterator(value, alphabet_size, True, None, None, False, False, True)
+
+
+def av_iter_parents(value: int, alphabet_size: int):
+    return deletion_iterator(value, alphabet_size)
+
+
+def av_iter_recursive(value: int, alphabet_size: int, min_distance=None, max_distance=None,
+                      breadthfirst=False, allow_duplicates=True, allow_empty_leaves=True):
+    """src/anahash.rs:212-228 with SearchParams defaults :272-282."""
+    return recurse_deletion_iterator(value, alphabet_size, False, min_distance, max_distance,
+                                     breadthfirst, not allow_duplicates, allow_empty_leaves)
+
+
+def char_count(value: int, alphabet_size: int) -> int:
+    return sum(1 for _ in av_iter(value, alphabet_size))
+
+
+def alphabet_upper_bound(value: int, alphabet_size: int) -> Tuple[int, int]:
+    """src/anahash.rs:126-136."""
+    maxc, count = 0, 0
+    for (node, _depth) in av_iter(value, alphabet_size):
+        count += 1
+        if node[1] > maxc:
+            maxc = node[1]
+    return maxc, count
+
+
+# ---------------------------------------------------------------------------------------------
+# Distances (src/distance.rs)
+# ---------------------------------------------------------------------------------------------
+def levenshtein(a: Sequence[int], b: Sequence[int], max_distance: int) -> Optional[int]:
+    """src/distance.rs:7-82."""
+    a, b = list(a), list(b)
+    if a == b:
+        return 0
+    la, lb = len(a), len(b)
+    if la == 0:
+        return None if lb > max_distance else lb
+    elif la > lb:
+        if la - lb > max_distance:
+            return None
+    if lb == 0:
+        return None if la > max_distance else la
+    elif lb > la:
+        if lb - la > max_distance:
+            return None
+    cache = list(range(1, la + 1))
+    result = 0
+    for index_b, elem_b in enumerate(b):
+        result = index_b
+        distance_a = index_b
+        for index_a, elem_a in enumerate(a):
+            distance_b = distance_a if elem_a == elem_b else distance_a + 1
+            distance_a = cache[index_a]
+            if distance_a > result:
+                result = result + 1 if distance_b > result else distance_b
+            elif distance_b > distance_a:
+                result = distance_a + 1
+            else:
+                result = distance_b
+            cache[index_a] = result
+    return None if result > max_distance else result
+
+
+def damerau_levenshtein(s: Sequence[int], t: Sequence[int], max_distance: int) -> Optional[int]:
+    """src/distance.rs:101-179 (unrestricted DL, full matrix, literal)."""
+    len_s, len_t = len(s), len(t)
+    if len_s == 0:
+        return None if len_t > max_distance else len_t
+    elif len_s > len_t:
+        if len_s - len_t > max_distance:
+            return None
+    if len_t == 0:
+        return None if len_s > max_distance else len_s
+    elif len_t > len_s:
+        if len_t - len_s > max_distance:
+            return None
+    ub = len_t + len_s
+    mat = [[0] * (len_t + 2) for _ in range(len_s + 2)]
+    mat[0][0] = ub
+    for i in range(len_s + 1):
+        mat[i + 1][0] = ub
+        mat[i + 1][1] = i
+    for i in range(len_t + 1):
+        mat[0][i + 1] = ub
+        mat[1][i + 1] = i
+    char_map: Dict[int, int] = {}
+    for i0, s_char in enumerate(s):
+        db = 0
+        i = i0 + 1
+        for j0, t_char in enumerate(t):
+            j = j0 + 1
+            last = char_map.get(t_char, 0)
+            cost = 0 if s_char == t_char else 1
+            mat[i + 1][j + 1] = min(
+                mat[i + 1][j] + 1,
+                mat[i][j + 1] + 1,
+                mat[i][j] + cost,
+                mat[last][db] + (i - last - 1) + 1 + (j - db - 1),
+            )
+            if cost == 0:
+                db = j
+        char_map[s_char] = i
+    result = mat[len_s + 1][len_t + 1]
+    return None if result > max_distance else result
+
+
+def longest_common_substring_length(s1: Sequence[int], s2: Sequence[int]) -> int:
+    """src/distance.rs:181-205."""
+    lcs = 0
+    n1, n2 = len(s1), len(s2)
+    for i in range(n1):
+        for j in range(n2):
+            if s1[i] == s2[j]:
+                tmp, ti, tj = 1, i + 1, j + 1
+                while ti < n1 and tj < n2 and s1[ti] == s2[tj]:
+                    tmp += 1
+                    ti += 1
+                    tj += 1
+                if tmp > lcs:
+                    lcs = tmp
+    return lcs
+
+
+def common_prefix_length(s1: Sequence[int], s2: Sequence[int]) -> int:
+    """src/distance.rs:208-218."""
+    n = 0
+    for i in range(min(len(s1), len(s2))):
+        if s1[i] == s2[i]:
+            n += 1
+        else:
+            break
+    return n
+
+
+def common_suffix_length(s1: Sequence[int], s2: Sequence[int]) -> int:
+    """src/distance.rs:221-231."""
+    n = 0
+    for i in range(min(len(s1), len(s2))):
+        if s1[len(s1) - i - 1] == s2[len(s2) - i - 1]:
+            n += 1
+        else:
+            break
+    return n
+
+
+# ---------------------------------------------------------------------------------------------
+# Parameters (src/types.rs)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Weights:  # src/types.rs:40-73
+    ld: float = 0.5
+    lcs: float = 0.125
+    prefix: float = 0.125
+    suffix: float = 0.125
+    case: float = 0.125
+
+    def sum(self) -> float:
+        return self.ld + self.lcs + self.prefix + self.suffix + self.case
+
+
+# DistanceThreshold (src/types.rs:76-83) as a tuple: ("abs", x) | ("ratio", r) | ("ratiolimit", r, limit)
+def _f32(x: float) -> float:
+    import struct
+    return struct.unpack("f", struct.pack("f", x))[0]
+
+
+def clamp_threshold(th, length: int, absolute_max: int) -> int:
+    """src/lib.rs:982-994 / 1000-1012.  Ratio arithmetic is done in f32 like the reference."""
+    kind = th[0]
+    if kind == "ratio":
+        v = math.floor(_f32(_f32(float(length)) * _f32(th[1])))
+        return min(min(max(int(v), 0), 255), absolute_max)
+    if kind == "ratiolimit":
+        v = math.floor(_f32(_f32(float(length)) * _f32(th[1])))
+        return min(min(max(int(v), 0), 255), th[2])
+    return min(th[1], min(int(math.floor(length / 2.0)), 255))
+
+
+@dataclass
+class SearchParameters:  # src/types.rs:112-192 (query-path subset)
+    max_anagram_distance: tuple = ("abs", 3)
+    max_edit_distance: tuple = ("abs", 3)
+    max_matches: int = 20
+    score_threshold: float = 0.25
+    cutoff_threshold: float = 2.0
+    stop_at_exact_match: bool = False
+    freq_weight: float = 0.0
+
+
+def test_searchparams() -> SearchParameters:
+    """src/test.rs:48-68."""
+    return SearchParameters(("abs", 2), ("abs", 2), 10, 0.0, 0.0, False, 0.0)
+
+
+@dataclass
+class VocabValue:  # src/vocab.rs:8-29 (query-path subset)
+    text: str
+    norm: List[int]
+    frequency: int
+    indexed: bool = True
+
+
+@dataclass
+class VariantResult:  # src/types.rs:326-365
+    vocab_id: int
+    dist_score: float
+    freq_score: float
+    via: Optional[int] = None
+
+    def score(self, freq_weight: float) -> float:
+        if freq_weight == 0.0:
+            return self.dist_score
+        fw = _f32(freq_weight)
+        return (self.dist_score + (fw * self.freq_score)) / (1.0 + fw)
+
+
+@dataclass
+class Distance:  # src/types.rs:289-305
+    ld: int
+    lcs: int
+    prefixlen: int
+    suffixlen: int
+    samecase: bool
+
+
+class VariantModel:
+    """src/lib.rs:50-100, query path only (no LM, no variant lists, no confusables)."""
+
+    def __init__(self, alphabet: Alphabet, weights: Optional[Weights] = None):
+        self.alphabet = alphabet
+        self.weights = weights or Weights()
+        self.decoder: List[VocabValue] = []
+        self.encoder: Dict[str, int] = {}
+        self.have_freq = False
+        self.index: Dict[int, Tuple[List[int], int]] = {}  # anavalue -> (instances, charcount)
+        self.sortedindex: Dict[int, List[int]] = {}
+        # src/vocab.rs:145-181: ids 0,1,2 reserved, not INDEXED
+        for t in ("<bos>", "<eos>", "<unk>"):
+            self.encoder[t] = len(self.decoder)
+            self.decoder.append(VocabValue(t, [], 0, indexed=False))
+
+    def alphabet_size(self) -> int:  # src/lib.rs:163-165
+        return len(self.alphabet) + 1
+
+    def add_to_vocabulary(self, text: str, frequency: Optional[int] = None,
+                          freq_handling: str = "max") -> int:
+        """src/lib.rs:900-967 (INDEXED entries only)."""
+        frequency = 1 if frequency is None else frequency
+        vid = self.encoder.get(text)
+        if vid is not None:
+            item = self.decoder[vid]
+            if freq_handling == "sum":
+                item.frequency += frequency
+            elif freq_handling == "max":
+                item.frequency = max(item.frequency, frequency)
+            elif freq_handling == "min":
+                item.frequency = min(item.frequency, frequency)
+            else:
+                item.frequency = frequency
+            return vid
+        self.encoder[text] = len(self.decoder)
+        self.decoder.append(VocabValue(text, normalize_to_alphabet(text, self.alphabet), frequency))
+        return len(self.decoder) - 1
+
+    def read_vocabulary(self, path: str, text_column: int = 0, freq_column: Optional[int] = 1,
+                        freq_handling: str = "max") -> None:
+        """src/lib.rs:519-568."""
+        with open(path, "r", encoding="utf-8", newline="") as f:
+            data = f.read()
+        for line in rust_lines(data):
+            if line == "":
+                continue
+            fields = line.split("\t")
+            text = fields[text_column]
+            if freq_column is not None:
+                self.have_freq = True
+                frequency = int(fields[freq_column]) if freq_column < len(fields) else 1
+            else:
+                frequency = 1
+            self.add_to_vocabulary(text, frequency, freq_handling)
+
+    def build(self) -> None:
+        """src/lib.rs:192-245."""
+        self.index = {}
+        for vid, value in enumerate(self.decoder):
+            if value.indexed:
+                av = anahash(value.text, self.alphabet)
+                node = self.index.get(av)
+                if node is None:
+                    node = ([], char_count(av, self.alphabet_size()))
+                    self.index[av] = node
+                node[0].append(vid)
+        self.sortedindex = {}
+        for av, node in self.index.items():
+            self.sortedindex.setdefault(node[1], []).append(av)
+        for keys in self.sortedindex.values():
+            keys.sort()
+
+    def get_anagram_instances(self, text: str) -> List[VocabValue]:  # src/lib.rs:305-318
+        node = self.index.get(anahash(text, self.alphabet))
+        return [self.decoder[v] for v in node[0]] if node else []
+
+    def has(self, text: str) -> bool:  # src/lib.rs:331-338
+        return any(i.text == text for i in self.get_anagram_instances(text))
+
+    # -- hot path ---------------------------------------------------------------------------
+    def find_nearest_anahashes(self, focus: int, max_distance: int,
+                               stop_at_exact_match: bool = False) -> List[int]:
+        """src/lib.rs:1143-1308, literal.  Returns ascending list (BTreeSet iteration order)."""
+        nearest = set()
+        if focus in self.index:
+            nearest.add(focus)
+            if stop_at_exact_match and self.index[focus][0]:
+                return sorted(nearest)
+        focus_upper_bound, focus_charcount = alphabet_upper_bound(focus, self.alphabet_size())
+        focus_alphabet_size = focus_upper_bound + 1
+        lookups: Dict[int, List[int]] = {}
+        for distance in range(1, max_distance + 1):
+            lookups.setdefault((focus_charcount + distance) & 0xFF, []).append(focus)
+        for (node, distance) in av_iter_recursive(focus, focus_alphabet_size + 1,
+                                                  max_distance=max_distance, breadthfirst=True,
+                                                  allow_empty_leaves=False, allow_duplicates=False):
+            deletion = node[0]
+            if deletion in self.index:
+                nearest.add(deletion)
+            deletion_charcount = focus_charcount - distance
+            for search_distance in range(1, max_distance - distance + 1):
+                lookups.setdefault((deletion_charcount + search_distance) & 0xFF, []).append(deletion)
+        for search_charcount, anavalues in lookups.items():
+            bucket = self.sortedindex.get(search_charcount)
+            if bucket is not None:
+                for candidate in bucket:
+                    for av in anavalues:
+                        if av_contains(candidate, av):
+                            nearest.add(candidate)
+                            break
+        return sorted(nearest)
+
+    def gather_instances(self, nearest: List[int], querystring: List[int], query: str,
+                         max_edit_distance: int) -> List[Tuple[int, Distance]]:
+        """src/lib.rs:1311-1402."""
+        found = []
+        w = self.weights
+        for av in nearest:
+            for vocab_id in self.index[av][0]:
+                item = self.decoder[vocab_id]
+                ld = damerau_levenshtein(querystring, item.norm, max_edit_distance)
+                if ld is not None:
+                    found.append((vocab_id, Distance(
+                        ld,
+                        longest_common_substring_length(querystring, item.norm) if w.lcs > 0.0 else 0,
+                        common_prefix_length(querystring, item.norm) if w.prefix > 0.0 else 0,
+                        common_suffix_length(querystring, item.norm) if w.suffix > 0.0 else 0,
+                        (is_lowercase(item.text[0]) == is_lowercase(query[0])) if w.case > 0.0 else True,
+                    )))
+        return found
+
+    def score_and_rank(self, instances, input_length: int, max_matches: int,
+                       score_threshold: float, cutoff_threshold: float,
+                       freq_weight: float) -> List[VariantResult]:
+        """src/lib.rs:1405-1653 without confusables / variant expansion."""
+        results: List[VariantResult] = []
+        max_freq = 0.0
+        w = self.weights
+        weights_sum = w.sum()
+        assert input_length > 0
+        for vocab_id, d in instances:
+            item = self.decoder[vocab_id]
+            distance_score = 0.0 if d.ld > input_length else 1.0 - (float(d.ld) / float(input_length))
+            lcs_score = float(d.lcs) / float(input_length)
+            prefix_score = float(d.prefixlen) / float(input_length)
+            suffix_score = float(d.suffixlen) / float(input_length)
+            score = (w.ld * distance_score + w.lcs * lcs_score + w.prefix * prefix_score
+                     + w.suffix * suffix_score + (w.case if d.samecase else 0.0)) / weights_sum
+            freq_score = float(item.frequency) if self.have_freq else 1.0
+            if freq_score > max_freq:
+                max_freq = freq_score
+            if score >= score_threshold:
+                results.append(VariantResult(vocab_id, score, freq_score))
+        if max_freq > 0.0:
+            for r in results:
+                r.freq_score = r.freq_score / max_freq
+        # rank_results: stable sort with rank_cmp (src/types.rs:344-365)
+        if freq_weight > 0.0:
+            results.sort(key=lambda r: -r.score(freq_weight))
+        else:
+            results.sort(key=lambda r: (-r.dist_score, -r.freq_score))
+        if max_matches > 0 and len(results) > max_matches:
+            last_score = results[max_matches - 1].score(freq_weight)
+            cropped_score = results[max_matches].score(freq_weight)
+            if cropped_score < last_score:
+                del results[max_matches:]
+            else:
+                early_cutoff = 0
+                late_cutoff = 0
+                for i, r in enumerate(results):
+                    if r.dist_score == cropped_score and early_cutoff == 0:
+                        early_cutoff = i
+                    if r.dist_score < cropped_score:
+                        late_cutoff = i
+                        break
+                if early_cutoff > 0:
+                    del results[early_cutoff + 1:]
+                elif late_cutoff > 0:
+                    del results[late_cutoff + 1:]
+        cutoff = 0
+        bestscore = None
+        if cutoff_threshold >= 1.0:
+            for i, r in enumerate(results):
+                if bestscore is not None:
+                    if r.score(freq_weight) <= bestscore / cutoff_threshold:
+                        cutoff = i
+                        break
+                else:
+                    bestscore = r.score(freq_weight)
+        if cutoff > 0:
+            del results[cutoff:]
+        return results
+
+    def find_variants(self, text: str, params: SearchParameters, trace: Optional[dict] = None
+                      ) -> List[VariantResult]:
+        """src/lib.rs:972-1027."""
+        if not self.index:
+            return []
+        normstring = normalize_to_alphabet(text, self.alphabet)
+        av = anahash(text, self.alphabet)
+        k = clamp_threshold(params.max_anagram_distance, len(normstring), MAX_ANAGRAM_DISTANCE)
+        nearest = self.find_nearest_anahashes(av, k, params.stop_at_exact_match)
+        d = clamp_threshold(params.max_edit_distance, len(normstring), MAX_EDIT_DISTANCE)
+        variants = self.gather_instances(nearest, normstring, text, d)
+        if trace is not None:
+            trace["n_classes"] = len(nearest)
+            trace["n_pairs"] = sum(len(self.index[a][0]) for a in nearest)
+            trace["distances"] = variants
+        return self.score_and_rank(variants, len(normstring), params.max_matches,
+                                   params.score_threshold, params.cutoff_threshold,
+                                   params.freq_weight)
