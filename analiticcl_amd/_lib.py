@@ -1,0 +1,132 @@
+"""Loader + ctypes signatures for libanx.so (the C ABI declared in include/anx.h).
+
+The library is built in-tree (analiticcl_amd/libanx.so) by `python -m analiticcl_amd.build` or
+`__graft_entry__.build()`.  There is no Python/CPU fallback: if the library is missing, importing fails
+loudly; if no HIP device is present, calls that need the device raise AnxError(ANX_ENODEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libanx.so")
+
+ANX_OK, ANX_EINVAL, ANX_EIO, ANX_ENOTBUILT, ANX_ENODEVICE, ANX_ELIMIT, ANX_EEMPTY = 0, -1, -2, -3, -4, -5, -6
+ANX_NO_VIA = 0xFFFFFFFFFFFFFFFF
+
+
+class AnxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"anx error {code}: {message}")
+        self.code = code
+
+
+class Weights(C.Structure):
+    _fields_ = [("ld", C.c_double), ("lcs", C.c_double), ("prefix", C.c_double), ("suffix", C.c_double),
+                ("casew", C.c_double)]
+
+
+class Threshold(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("value", C.c_uint8), ("ratio", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [("max_anagram_distance", Threshold), ("max_edit_distance", Threshold),
+                ("max_matches", C.c_uint64), ("score_threshold", C.c_double), ("cutoff_threshold", C.c_double),
+                ("stop_at_exact_match", C.c_int32), ("freq_weight", C.c_float)]
+
+
+class VocabParams(C.Structure):
+    _fields_ = [("text_column", C.c_uint8), ("freq_column", C.c_int16), ("freq_handling", C.c_uint8),
+                ("vocab_type", C.c_uint8)]
+
+
+class Result(C.Structure):
+    _fields_ = [("vocab_id", C.c_uint64), ("dist_score", C.c_double), ("freq_score", C.c_double),
+                ("via", C.c_uint64)]
+
+
+class Pair(C.Structure):
+    _fields_ = [("query", C.c_uint32), ("vocab_id", C.c_uint32), ("ld", C.c_int16), ("lcs", C.c_uint16),
+                ("prefixlen", C.c_uint16), ("suffixlen", C.c_uint16), ("samecase", C.c_uint8), ("_pad", C.c_uint8),
+                ("score", C.c_double)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("n_pairs", C.c_uint64), ("n_class_tests", C.c_uint64),
+                ("n_results", C.c_uint64), ("n_scan_blocks", C.c_uint64), ("ms_scan", C.c_float),
+                ("ms_group", C.c_float), ("ms_score", C.c_float), ("ms_rank", C.c_float), ("ms_total", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libanx.so once. torch (if installed) is imported first so that both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -m analiticcl_amd.build` "
+                          "(there is no CPU fallback for the variant-query path)")
+    try:
+        import torch  # noqa: F401  (loads the bundled libamdhip64 first; see DESIGN.md "Process model")
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, cp, u64, sz = C.c_void_p, C.c_char_p, C.c_uint64, C.c_size_t
+    sig = {
+        "anx_last_error": (cp, []),
+        "anx_abi_version": (C.c_int, []),
+        "anx_default_weights": (None, [C.POINTER(Weights)]),
+        "anx_default_params": (None, [C.POINTER(Params)]),
+        "anx_default_vocab_params": (None, [C.POINTER(VocabParams)]),
+        "anx_model_new": (vp, [cp, C.POINTER(Weights), C.c_int]),
+        "anx_model_new_with_alphabet": (vp, [cp, C.POINTER(Weights), C.c_int]),
+        "anx_model_free": (None, [vp]),
+        "anx_model_read_vocabulary": (C.c_int, [vp, cp, C.POINTER(VocabParams)]),
+        "anx_model_add_to_vocabulary": (u64, [vp, cp, C.c_int, C.c_uint32, C.POINTER(VocabParams)]),
+        "anx_model_build": (C.c_int, [vp, C.c_int]),
+        "anx_model_to_device": (C.c_int, [vp, C.c_int]),
+        "anx_model_has": (C.c_int, [vp, cp]),
+        "anx_model_vocab_size": (u64, [vp]),
+        "anx_model_vocab_text": (cp, [vp, u64]),
+        "anx_model_vocab_frequency": (C.c_uint32, [vp, u64]),
+        "anx_model_vocab_lexindex": (C.c_uint32, [vp, u64]),
+        "anx_model_num_instances": (u64, [vp]),
+        "anx_model_num_classes": (u64, [vp]),
+        "anx_model_bucket_size": (u64, [vp, C.c_int]),
+        "anx_model_alphabet_size": (C.c_int, [vp]),
+        "anx_model_normalize": (C.c_int, [vp, cp, C.c_char_p, C.c_int]),
+        "anx_model_anahash": (C.c_int, [vp, cp, C.c_char_p, C.c_int]),
+        "anx_find_variants_batch": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(Params),
+                                              C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
+        "anx_results_free": (None, [C.POINTER(Result), C.POINTER(sz)]),
+        "anx_batch_encode": (vp, [vp, C.POINTER(cp), sz, C.POINTER(Params)]),
+        "anx_batch_run": (C.c_int, [vp, vp, vp]),
+        "anx_batch_fetch": (C.c_int, [vp, C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
+        "anx_batch_fetch_pairs": (C.c_int, [vp, C.POINTER(C.POINTER(Pair)), C.POINTER(sz)]),
+        "anx_pairs_free": (None, [C.POINTER(Pair)]),
+        "anx_batch_export_topk": (C.c_int, [vp, vp, C.c_uint32, vp]),
+        "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats)]),
+        "anx_batch_free": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED = None
+
+
+def check(rc: int):
+    if rc != 0:
+        raise AnxError(rc, lib().anx_last_error().decode("utf-8", "replace"))
+
+
+def last_error() -> str:
+    return lib().anx_last_error().decode("utf-8", "replace")

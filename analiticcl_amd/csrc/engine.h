@@ -1,0 +1,30 @@
+// engine.h -- device side of the anx engine (gfx950 only).  See DESIGN.md for the data layout.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "host_model.h"
+
+namespace anx {
+
+struct DeviceLexicon;  // HBM-resident SoA lexicon
+struct Batch;          // encoded queries + pipeline buffers + results, HBM-resident
+
+int device_count(std::string& err);
+DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& err);
+void lexicon_free(DeviceLexicon*);
+
+Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
+                    const anx_params& p, std::string& err, int* code);
+int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
+int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
+                std::string& err);
+int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_pair** out, size_t* n,
+                      std::string& err);
+int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32_t stride, void* stream,
+                      std::string& err);
+void batch_stats(const Batch* b, anx_batch_stats* s);
+void batch_free(Batch*);
+
+}  // namespace anx

@@ -1,0 +1,404 @@
+// host_model.cpp -- see host_model.h.  Host-only code (no HIP here).
+#include "host_model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <sstream>
+
+#include "unicode_tables.inc"
+
+namespace anx {
+
+// The first 168 primes (reference: PRIMES, src/types.rs:20-30); generated, not transcribed.
+static std::vector<uint32_t> make_primes() {
+  std::vector<uint32_t> p;
+  for (uint32_t n = 2; p.size() < 168; ++n) {
+    bool prime = true;
+    for (uint32_t d : p) {
+      if (d * d > n) break;
+      if (n % d == 0) { prime = false; break; }
+    }
+    if (prime) p.push_back(n);
+  }
+  return p;
+}
+static const std::vector<uint32_t>& primes() {
+  static const std::vector<uint32_t> p = make_primes();
+  return p;
+}
+
+// ---- UTF-8 / Unicode ------------------------------------------------------------------------------
+static inline int u8len(unsigned char c) {
+  return c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1;
+}
+static uint32_t u8decode(const char* s, size_t avail, int* len) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(s);
+  int l = u8len(p[0]);
+  if ((size_t)l > avail) l = 1;
+  *len = l;
+  if (l == 1) return p[0];
+  if (l == 2) return ((p[0] & 0x1Fu) << 6) | (p[1] & 0x3Fu);
+  if (l == 3) return ((p[0] & 0x0Fu) << 12) | ((p[1] & 0x3Fu) << 6) | (p[2] & 0x3Fu);
+  return ((p[0] & 0x07u) << 18) | ((p[1] & 0x3Fu) << 12) | ((p[2] & 0x3Fu) << 6) | (p[3] & 0x3Fu);
+}
+static bool in_table(const unsigned int (*r)[2], int n, uint32_t cp) {
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    int mid = (lo + hi) >> 1;
+    if (cp < r[mid][0]) hi = mid - 1;
+    else if (cp > r[mid][1]) lo = mid + 1;
+    else return true;
+  }
+  return false;
+}
+bool first_char_is_lowercase(const char* s) {
+  if (!s || !*s) return false;
+  int l;
+  return in_table(anx_uc_lower, anx_uc_lower_n, u8decode(s, strlen(s), &l));
+}
+static std::string trim_ws(const std::string& f) {  // str::trim(): Unicode White_Space
+  size_t b = 0, e = f.size();
+  while (b < e) {
+    int l;
+    uint32_t cp = u8decode(f.data() + b, e - b, &l);
+    if (!in_table(anx_uc_ws, anx_uc_ws_n, cp)) break;
+    b += (size_t)l;
+  }
+  while (e > b) {
+    size_t k = e - 1;
+    while (k > b && (static_cast<unsigned char>(f[k]) & 0xC0) == 0x80) --k;
+    int l;
+    uint32_t cp = u8decode(f.data() + k, e - k, &l);
+    if (!in_table(anx_uc_ws, anx_uc_ws_n, cp)) break;
+    e = k;
+  }
+  return f.substr(b, e - b);
+}
+static int count_chars(const std::string& s) {
+  int n = 0;
+  for (size_t i = 0; i < s.size(); i += (size_t)u8len((unsigned char)s[i])) ++n;
+  return n;
+}
+// BufRead::lines(): '\n' separated, one trailing '\r' removed, no final empty line
+static void split_lines(const std::string& data, std::vector<std::string>& out) {
+  size_t pos = 0;
+  while (pos < data.size()) {
+    size_t e = data.find('\n', pos);
+    size_t end = e == std::string::npos ? data.size() : e;
+    size_t l = end - pos;
+    if (l > 0 && data[pos + l - 1] == '\r') --l;
+    out.emplace_back(data, pos, l);
+    if (e == std::string::npos) break;
+    pos = e + 1;
+  }
+}
+static bool read_file(const char* path, std::string& out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  out = ss.str();
+  return true;
+}
+
+// ---- alphabet -----------------------------------------------------------------------------------------
+bool parse_alphabet(const std::string& tsv, Alphabet& out, std::string& err) {
+  std::vector<std::string> lines;
+  split_lines(tsv, lines);
+  for (const std::string& line : lines) {
+    if (line.empty()) continue;
+    std::vector<AlphabetMember> cls;
+    size_t pos = 0;
+    for (;;) {
+      size_t e = line.find('\t', pos);
+      std::string field = line.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+      std::string val;
+      if (field == "\\s") val = " ";
+      else if (field == "\\t") val = "\t";
+      else if (field == "\\n") val = "\n";
+      else val = trim_ws(field);
+      if (!val.empty()) cls.push_back(AlphabetMember{val, count_chars(val)});
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+    out.classes.push_back(std::move(cls));
+  }
+  if (out.size() > kMaxAlphabet) {
+    err = "alphabet has more than 166 classes (the reference's PRIMES table has 168 entries)";
+    return false;
+  }
+  return true;
+}
+
+bool Alphabet::scan(const char* text, size_t nbytes, std::vector<int16_t>& out) const {
+  out.clear();
+  int skip = 0;
+  for (size_t pos = 0; pos < nbytes; pos += (size_t)u8len((unsigned char)text[pos])) {
+    if (skip > 0) { --skip; continue; }
+    int hit = -1;
+    for (int c = 0; c < size() && hit < 0; ++c)
+      for (const AlphabetMember& m : classes[c])
+        if (pos + m.bytes.size() <= nbytes && memcmp(text + pos, m.bytes.data(), m.bytes.size()) == 0) {
+          hit = c;
+          skip = m.nchars - 1;
+          break;
+        }
+    if ((int)out.size() >= kMaxSymbols) return false;
+    out.push_back((int16_t)hit);
+  }
+  return true;
+}
+
+// ---- BigVal ---------------------------------------------------------------------------------------------
+void BigVal::mul_small(uint32_t m) {
+  uint64_t carry = 0;
+  for (uint32_t& x : w) {
+    uint64_t t = (uint64_t)x * m + carry;
+    x = (uint32_t)t;
+    carry = t >> 32;
+  }
+  if (carry) w.push_back((uint32_t)carry);
+}
+int BigVal::cmp(const BigVal& o) const {
+  if (w.size() != o.w.size()) return w.size() < o.w.size() ? -1 : 1;
+  for (size_t i = w.size(); i-- > 0;)
+    if (w[i] != o.w[i]) return w[i] < o.w[i] ? -1 : 1;
+  return 0;
+}
+std::string BigVal::to_decimal() const {
+  std::vector<uint32_t> t = w;
+  std::string digits;
+  while (!t.empty()) {
+    uint64_t rem = 0;
+    for (size_t i = t.size(); i-- > 0;) {
+      uint64_t cur = (rem << 32) | t[i];
+      t[i] = (uint32_t)(cur / 10);
+      rem = cur % 10;
+    }
+    digits.push_back((char)('0' + rem));
+    while (!t.empty() && t.back() == 0) t.pop_back();
+  }
+  if (digits.empty()) digits = "0";
+  std::reverse(digits.begin(), digits.end());
+  return digits;
+}
+
+// ---- model ------------------------------------------------------------------------------------------------
+HostModel::HostModel() {
+  anx_default_weights(&weights);
+  // init_vocab (src/vocab.rs:145-181): ids 0,1,2 reserved, VocabType::NONE
+  for (const char* t : {"<bos>", "<eos>", "<unk>"}) {
+    encoder.emplace(t, decoder.size());
+    decoder.push_back(VocabEntry{t, {}, 0, 0, 1, ANX_VOCAB_NONE});
+  }
+}
+
+bool HostModel::encode(const char* text, std::vector<uint8_t>& norm, std::vector<uint8_t>& cv) const {
+  std::vector<int16_t> codes;
+  if (!alphabet.scan(text, strlen(text), codes)) return false;
+  const int A = alphabet.size();
+  norm.resize(codes.size());
+  cv.assign((size_t)lex.nplanes > 0 ? (size_t)lex.nplanes * 4 : (size_t)((A + 1 + 3) / 4 * 4), 0);
+  for (size_t i = 0; i < codes.size(); ++i) {
+    norm[i] = (uint8_t)(codes[i] >= 0 ? codes[i] : A + 1);  // src/anahash.rs:76
+    cv[(size_t)(codes[i] >= 0 ? codes[i] : A)]++;           // src/anahash.rs:42 (prime index of UNK)
+  }
+  return true;
+}
+
+bool HostModel::anahash(const char* text, BigVal& out) const {
+  std::vector<int16_t> codes;
+  if (!alphabet.scan(text, strlen(text), codes)) return false;
+  out.set_one();
+  for (int16_t c : codes) out.mul_small(primes()[(size_t)(c >= 0 ? c : alphabet.size())]);
+  return true;
+}
+
+uint64_t HostModel::add_to_vocabulary(const char* text, bool has_freq, uint32_t freq, const anx_vocab_params& p,
+                                      uint8_t lexicon_index) {
+  const uint32_t frequency = has_freq ? freq : 1;
+  auto it = encoder.find(text);
+  if (it != encoder.end()) {
+    VocabEntry& item = decoder[it->second];
+    switch (p.freq_handling) {
+      case ANX_FREQ_SUM: item.frequency += frequency; break;
+      case ANX_FREQ_MAX: if (frequency > item.frequency) item.frequency = frequency; break;
+      case ANX_FREQ_MIN: if (frequency < item.frequency) item.frequency = frequency; break;
+      default: item.frequency = frequency; break;
+    }
+    if (it->second <= 2) item.vocabtype = ANX_VOCAB_LM;
+    else if ((item.vocabtype & ANX_VOCAB_TRANSPARENT) && !(p.vocab_type & ANX_VOCAB_TRANSPARENT))
+      item.vocabtype ^= ANX_VOCAB_TRANSPARENT;
+    item.lexindex |= 1u << lexicon_index;
+    return it->second;
+  }
+  VocabEntry e;
+  e.text = text;
+  std::vector<int16_t> codes;
+  if (alphabet.scan(text, strlen(text), codes)) {
+    e.norm.resize(codes.size());
+    for (size_t i = 0; i < codes.size(); ++i) e.norm[i] = (uint8_t)(codes[i] >= 0 ? codes[i] : alphabet.size() + 1);
+  }
+  e.frequency = frequency;
+  e.tokencount = (uint8_t)(std::count(e.text.begin(), e.text.end(), ' ') + 1);
+  e.lexindex = 1u << lexicon_index;
+  e.vocabtype = p.vocab_type;
+  encoder.emplace(e.text, decoder.size());
+  decoder.push_back(std::move(e));
+  built = false;
+  return decoder.size() - 1;
+}
+
+int HostModel::read_vocabulary(const char* path, const anx_vocab_params& p, std::string& err) {
+  std::string data;
+  if (!read_file(path, data)) { err = std::string("cannot read ") + path; return ANX_EIO; }
+  std::vector<std::string> lines;
+  split_lines(data, lines);
+  const uint8_t lexidx = (uint8_t)lexicons.size();
+  std::vector<std::string> fields;
+  for (const std::string& line : lines) {
+    if (line.empty()) continue;
+    fields.clear();
+    size_t pos = 0;
+    for (;;) {
+      size_t e = line.find('\t', pos);
+      fields.emplace_back(line, pos, e == std::string::npos ? std::string::npos : e - pos);
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+    if (p.text_column >= fields.size()) { err = "Expected text column not found"; return ANX_EINVAL; }
+    uint32_t freq = 1;
+    if (p.freq_column >= 0) {
+      if (p.vocab_type & ANX_VOCAB_INDEXED) have_freq = true;  // src/lib.rs:544-547
+      if ((size_t)p.freq_column < fields.size()) {
+        const std::string& f = fields[(size_t)p.freq_column];
+        char* endp = nullptr;
+        unsigned long long v = strtoull(f.c_str(), &endp, 10);
+        if (f.empty() || *endp || v > 0xFFFFFFFFull) { err = "frequency should be a valid integer"; return ANX_EINVAL; }
+        freq = (uint32_t)v;
+      }
+    }
+    add_to_vocabulary(fields[p.text_column].c_str(), true, freq, p, lexidx);
+  }
+  lexicons.push_back(path);
+  return ANX_OK;
+}
+
+static int pick_planes(int nsym) {  // kernel variants are instantiated for these widths
+  const int need = (nsym + 3) / 4;
+  for (int v : {8, 16, 24, 32, 42})
+    if (need <= v) return v;
+  return -1;
+}
+
+int HostModel::build_index(std::string& err) {
+  const int A = alphabet.size();
+  lex = LexiconImage();
+  lex.nsym = A + 1;
+  lex.nplanes = pick_planes(lex.nsym);
+  if (lex.nplanes < 0) { err = "alphabet too large"; return ANX_ELIMIT; }
+  const size_t cvbytes = (size_t)lex.nplanes * 4;
+  class_of_cv.clear();
+
+  struct Tmp {
+    std::string cv;
+    BigVal value;
+    int charcount;
+    std::vector<uint32_t> ids;
+  };
+  std::vector<Tmp> tmp;
+  std::unordered_map<std::string, uint32_t> seen;
+  std::vector<int16_t> codes;
+  for (size_t id = 0; id < decoder.size(); ++id) {
+    const VocabEntry& v = decoder[id];
+    if (!(v.vocabtype & ANX_VOCAB_INDEXED)) continue;
+    if (!alphabet.scan(v.text.data(), v.text.size(), codes)) continue;  // > 255 symbols: not indexable
+    std::string cv(cvbytes, '\0');
+    for (int16_t c : codes) cv[(size_t)(c >= 0 ? c : A)]++;
+    auto it = seen.find(cv);
+    if (it == seen.end()) {
+      Tmp t;
+      t.cv = cv;
+      t.value.set_one();
+      for (int16_t c : codes) t.value.mul_small(primes()[(size_t)(c >= 0 ? c : A)]);
+      t.charcount = (int)codes.size();
+      it = seen.emplace(cv, (uint32_t)tmp.size()).first;
+      tmp.push_back(std::move(t));
+    }
+    tmp[it->second].ids.push_back((uint32_t)id);  // ascending id order (src/lib.rs:215-219)
+  }
+  std::vector<uint32_t> order(tmp.size());
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (tmp[a].charcount != tmp[b].charcount) return tmp[a].charcount < tmp[b].charcount;
+    return tmp[a].value.cmp(tmp[b].value) < 0;
+  });
+
+  lex.nclasses = (uint32_t)tmp.size();
+  lex.cstride = ((lex.nclasses + 1023u) & ~1023u) + 1024u;  // + one workgroup chunk of never-matching padding
+  lex.cls_planes.assign((size_t)lex.nplanes * lex.cstride, 0xFFFFFFFFu);  // padding classes never match
+  lex.cls_len.resize(lex.nclasses);
+  lex.cls_off.assign(lex.nclasses + 1, 0);
+  lex.cls_value.resize(lex.nclasses);
+  for (int c = 0; c <= kMaxSymbols + 1; ++c) lex.bucket_begin[c] = 0;
+  for (uint32_t r = 0; r < lex.nclasses; ++r) {
+    Tmp& t = tmp[order[r]];
+    for (int p = 0; p < lex.nplanes; ++p) {
+      uint32_t wv;
+      memcpy(&wv, t.cv.data() + 4 * p, 4);
+      lex.cls_planes[(size_t)p * lex.cstride + r] = wv;
+    }
+    lex.cls_len[r] = (uint8_t)t.charcount;
+    lex.bucket_begin[t.charcount + 1]++;
+    class_of_cv.emplace(t.cv, r);
+    lex.cls_value[r] = std::move(t.value);
+    lex.cls_off[r] = lex.nentries;
+    for (uint32_t id : t.ids) {
+      const VocabEntry& v = decoder[id];
+      const uint32_t len = (uint32_t)v.norm.size();
+      lex.ent_vocab.push_back(id);
+      lex.ent_freq.push_back(v.frequency);
+      lex.ent_meta.push_back(len | (first_char_is_lowercase(v.text.c_str()) ? 0x100u : 0u));
+      lex.ent_rowoff.push_back((uint32_t)(lex.rows.size() / 16));
+      const size_t padded = std::max<size_t>(16, (len + 15) / 16 * 16);
+      const size_t base = lex.rows.size();
+      lex.rows.resize(base + padded, 0xFF);
+      if (len) memcpy(&lex.rows[base], v.norm.data(), len);
+      lex.nentries++;
+    }
+  }
+  lex.cls_off[lex.nclasses] = lex.nentries;
+  for (int c = 0; c <= kMaxSymbols; ++c) lex.bucket_begin[c + 1] += lex.bucket_begin[c];
+  built = true;
+  return ANX_OK;
+}
+
+bool HostModel::has(const char* text) const {
+  if (!built) return false;
+  std::vector<int16_t> codes;
+  if (!alphabet.scan(text, strlen(text), codes)) return false;
+  std::string cv((size_t)lex.nplanes * 4, '\0');
+  for (int16_t c : codes) cv[(size_t)(c >= 0 ? c : alphabet.size())]++;
+  auto it = class_of_cv.find(cv);
+  if (it == class_of_cv.end()) return false;
+  for (uint32_t e = lex.cls_off[it->second]; e < lex.cls_off[it->second + 1]; ++e)
+    if (decoder[lex.ent_vocab[e]].text == text) return true;
+  return false;
+}
+
+int clamp_threshold(const anx_threshold& t, int len, int absolute_max) {
+  if (t.kind == ANX_RATIO || t.kind == ANX_RATIO_WITH_LIMIT) {
+    const float v = std::floor((float)len * t.ratio);
+    const int x = v < 0.0f ? 0 : v > 255.0f ? 255 : (int)v;  // `as u8` saturates
+    const int lim = t.kind == ANX_RATIO ? absolute_max : (int)t.value;
+    return std::min(x, lim);
+  }
+  const int half = std::min(255, (int)std::floor((double)len / 2.0));
+  return std::min((int)t.value, half);
+}
+
+}  // namespace anx

@@ -1,0 +1,103 @@
+// host_model.h -- host side of the anx engine: alphabet, vocabulary, anagram-class index and the
+// SoA lexicon image that is uploaded to HBM.  Mirrors the reference's VariantModel for the query path
+// (/root/reference/src/lib.rs:50-245, 369-407, 519-568, 900-967; src/anahash.rs:16-80; src/vocab.rs).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/anx.h"
+
+namespace anx {
+
+constexpr int kMaxSymbols = 255;   // CharIndexType = u8 lengths/charcounts (src/types.rs:13)
+constexpr int kMaxAlphabet = 166;  // PRIMES has 168 entries (src/types.rs:20-30): classes + UNK + 1
+constexpr int kMaxAnagramDistance = 12;  // src/lib.rs:43
+constexpr int kMaxEditDistance = 12;     // src/lib.rs:46
+
+struct AlphabetMember {
+  std::string bytes;
+  int nchars;
+};
+
+struct Alphabet {
+  std::vector<std::vector<AlphabetMember>> classes;  // file order; first byte-prefix match wins
+  int size() const { return (int)classes.size(); }
+  // Walks `text` exactly like str::anahash / str::normalize_to_alphabet (src/anahash.rs:16-80) and
+  // returns, per consumed position, the class index or -1 for an unmatched character.
+  // Returns false if more than kMaxSymbols symbols are produced.
+  bool scan(const char* text, size_t nbytes, std::vector<int16_t>& out) const;
+};
+
+bool parse_alphabet(const std::string& tsv, Alphabet& out, std::string& err);  // src/lib.rs:369-407
+bool first_char_is_lowercase(const char* utf8);  // char::is_lowercase on text.chars().next()
+
+struct VocabEntry {  // VocabValue, src/vocab.rs:8-29
+  std::string text;
+  std::vector<uint8_t> norm;  // normalize_to_alphabet: UNK = alphabet.len()+1
+  uint32_t frequency;
+  uint32_t lexindex;
+  uint8_t tokencount;
+  uint8_t vocabtype;
+};
+
+// Little-endian arbitrary-precision unsigned integer; only what ordering anagram values needs
+// (AnaValue = product of primes, src/anahash.rs:16-47; ordering src/lib.rs:243).
+struct BigVal {
+  std::vector<uint32_t> w;
+  void set_one() { w.assign(1, 1u); }
+  void mul_small(uint32_t m);
+  int cmp(const BigVal& o) const;
+  std::string to_decimal() const;
+};
+
+// SoA image of the lexicon, in "class rank" order: classes sorted by (charcount, anagram value ascending)
+// = the order of sortedindex (src/lib.rs:222-245) and of BTreeSet<&AnaValue> iteration within a charcount;
+// entries sorted by (class rank, vocab id) = the enumeration order of gather_instances (src/lib.rs:1327-1332).
+struct LexiconImage {
+  int nsym = 0;     // alphabet.len()+1 hash symbols (UNK = alphabet.len())
+  int nplanes = 0;  // count-vector dwords per class (4 symbols per dword), padded to a kernel variant
+  uint32_t nclasses = 0, nentries = 0;
+  std::vector<uint32_t> cls_planes;     // [nplanes][cstride] packed u8 counts
+  uint32_t cstride = 0;
+  std::vector<uint8_t> cls_len;         // charcount per class
+  std::vector<uint32_t> cls_off;        // CSR class -> entries, nclasses+1
+  uint32_t bucket_begin[kMaxSymbols + 2];  // class-rank range per charcount
+  std::vector<uint32_t> ent_vocab;      // vocab id
+  std::vector<uint32_t> ent_freq;
+  std::vector<uint32_t> ent_meta;       // len | first_is_lower<<8
+  std::vector<uint32_t> ent_rowoff;     // offset of the token row in 16-byte units
+  std::vector<uint8_t> rows;            // token rows padded to 16-byte multiples with 0xFF
+  std::vector<BigVal> cls_value;        // anagram value per class (host only)
+};
+
+class HostModel {
+ public:
+  Alphabet alphabet;
+  anx_weights weights;
+  int debug = 0;
+  std::vector<VocabEntry> decoder;                       // VocabDecoder
+  std::unordered_map<std::string, uint64_t> encoder;     // VocabEncoder
+  std::vector<std::string> lexicons;
+  bool have_freq = false;
+  bool built = false;
+  LexiconImage lex;
+  std::unordered_map<std::string, uint32_t> class_of_cv;  // count vector bytes -> class rank
+
+  HostModel();
+  int alphabet_size() const { return alphabet.size() + 1; }  // src/lib.rs:163-165
+  uint64_t add_to_vocabulary(const char* text, bool has_freq, uint32_t freq, const anx_vocab_params& p,
+                             uint8_t lexicon_index);  // src/lib.rs:900-967
+  int read_vocabulary(const char* path, const anx_vocab_params& p, std::string& err);  // src/lib.rs:519-568
+  int build_index(std::string& err);  // src/lib.rs:192-245
+  bool has(const char* text) const;   // src/lib.rs:331-338
+  // encode one string: norm codes (UNK = len+1), hash-class count vector (UNK = len), symbol count
+  bool encode(const char* text, std::vector<uint8_t>& norm, std::vector<uint8_t>& cv) const;
+  bool anahash(const char* text, BigVal& out) const;
+};
+
+// threshold clamps of find_variants (src/lib.rs:982-994, 1000-1012)
+int clamp_threshold(const anx_threshold& t, int len, int absolute_max);
+
+}  // namespace anx

@@ -1,0 +1,292 @@
+"""Python mirror of analiticcl's Python API for the variant-query path, on top of the anx C ABI.
+
+Same class / method / keyword names as the reference's pyo3 binding
+(/root/reference/bindings/python/src/lib.rs:591-812, typed in /root/reference/analiticcl.pyi):
+`VariantModel`, `SearchParameters`, `Weights`, `VocabParams`; `find_variants`, `find_variants_par`.
+All scoring runs on the GPU through libanx.so; nothing is computed in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+from . import _lib as L
+
+
+def _threshold(v) -> L.Threshold:
+    """int -> Absolute, float in [0,1] -> Ratio, (float, int) -> RatioWithLimit
+    (bindings/python/src/lib.rs extract_distance_threshold; src/types.rs:85-108)."""
+    if isinstance(v, bool):
+        raise ValueError("distance threshold must be int, float or (float, int)")
+    if isinstance(v, int):
+        if not 0 <= v <= 255:
+            raise ValueError("absolute distance threshold must fit in u8")
+        return L.Threshold(0, v, 0.0)
+    if isinstance(v, float):
+        if not 0.0 <= v <= 1.0:
+            raise ValueError("ratio must be in range 0.0-1.0")
+        return L.Threshold(1, 0, v)
+    if isinstance(v, (tuple, list)) and len(v) == 2:
+        return L.Threshold(2, int(v[1]), float(v[0]))
+    raise ValueError("distance threshold must be int, float or (float, int)")
+
+
+class Weights:
+    """Weights of the score components (src/types.rs:40-73)."""
+
+    _names = ("ld", "lcs", "prefix", "suffix", "case")
+
+    def __init__(self, **kwargs):
+        self.ld, self.lcs, self.prefix, self.suffix, self.case = 0.5, 0.125, 0.125, 0.125, 0.125
+        for k, v in kwargs.items():
+            if k not in self._names:
+                raise ValueError(f"Unknown parameter for Weights: {k}")
+            setattr(self, k, float(v))
+
+    def _c(self) -> L.Weights:
+        return L.Weights(self.ld, self.lcs, self.prefix, self.suffix, self.case)
+
+    def to_dict(self) -> dict:
+        return {k: getattr(self, k) for k in self._names}
+
+    def get_ld(self): return self.ld
+    def get_lcs(self): return self.lcs
+    def get_prefix(self): return self.prefix
+    def get_suffix(self): return self.suffix
+    def get_case(self): return self.case
+    def set_ld(self, value): self.ld = float(value)
+    def set_lcs(self, value): self.lcs = float(value)
+    def set_prefix(self, value): self.prefix = float(value)
+    def set_suffix(self, value): self.suffix = float(value)
+    def set_case(self, value): self.case = float(value)
+
+
+class SearchParameters:
+    """SearchParameters (src/types.rs:112-192); defaults are the library defaults (k=3, d=3, n=20)."""
+
+    _defaults = dict(max_anagram_distance=3, max_edit_distance=3, max_matches=20, score_threshold=0.25,
+                     cutoff_threshold=2.0, stop_criterion=False, max_ngram=3, lm_order=3, max_seq=250,
+                     single_thread=False, context_weight=0.0, variantmodel_weight=3.0, lm_weight=1.0,
+                     contextrules_weight=1.0, freq_weight=0.0, consolidate_matches=True, unicodeoffsets=False)
+
+    def __init__(self, **kwargs):
+        self.__dict__.update(self._defaults)
+        for k, v in kwargs.items():
+            if k not in self._defaults:
+                raise ValueError(f"Unknown parameter for SearchParameters: {k}")
+            setattr(self, k, v)
+
+    def _c(self) -> L.Params:
+        return L.Params(_threshold(self.max_anagram_distance), _threshold(self.max_edit_distance),
+                        int(self.max_matches), float(self.score_threshold), float(self.cutoff_threshold),
+                        1 if self.stop_criterion else 0, float(self.freq_weight))
+
+    def to_dict(self) -> dict:
+        return {k: getattr(self, k) for k in self._defaults}
+
+
+for _k in SearchParameters._defaults:
+    setattr(SearchParameters, "get_" + _k, (lambda k: lambda self: getattr(self, k))(_k))
+SearchParameters.get_edit_distance = lambda self: self.max_edit_distance  # name used by analiticcl.pyi
+
+
+class VocabParams:
+    """VocabParams (src/vocab.rs:108-143)."""
+
+    _fh = {"sum": 0, "max": 1, "min": 2, "replace": 3}
+    _vt = {"NONE": 0, "INDEXED": 1, "LM": 2, "TRANSPARENT": 4}
+
+    def __init__(self, **kwargs):
+        self.text_column, self.freq_column, self.freq_handling, self.vocabtype = 0, 1, "max", "INDEXED"
+        for k, v in kwargs.items():
+            if k not in ("text_column", "freq_column", "freq_handling", "vocabtype"):
+                raise ValueError(f"Unknown parameter for VocabParams: {k}")
+            setattr(self, k, v)
+
+    def _c(self) -> L.VocabParams:
+        vt = self.vocabtype
+        vtv = vt if isinstance(vt, int) else sum(self._vt[x.strip().upper()] for x in vt.split("|"))
+        return L.VocabParams(int(self.text_column), -1 if self.freq_column is None else int(self.freq_column),
+                             self._fh[self.freq_handling.lower()], vtv)
+
+
+def _b(s) -> bytes:
+    return s if isinstance(s, bytes) else s.encode("utf-8")
+
+
+class Batch:
+    """A batch of queries encoded and resident in HBM (anx_batch_*): encode once, run many times."""
+
+    def __init__(self, model: "VariantModel", inputs: Sequence[str], params: SearchParameters):
+        self.model = model
+        self.n = len(inputs)
+        arr = (C.c_char_p * max(self.n, 1))(*[_b(t) for t in inputs])
+        cp = params._c()
+        self.h = L.lib().anx_batch_encode(model.h, arr, self.n, C.byref(cp))
+        if not self.h:
+            raise L.AnxError(L.ANX_ENODEVICE if "device" in L.last_error() else L.ANX_EINVAL, L.last_error())
+        self.freq_weight = float(params.freq_weight)
+
+    def run(self, stream: int = 0):
+        L.check(L.lib().anx_batch_run(self.model.h, self.h, C.c_void_p(stream)))
+
+    def stats(self) -> dict:
+        s = L.BatchStats()
+        L.check(L.lib().anx_batch_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in L.BatchStats._fields_}
+
+    def fetch(self) -> List[List[tuple]]:
+        """-> per query, ranked [(vocab_id, dist_score, freq_score)]"""
+        rows = C.POINTER(L.Result)()
+        offs = C.POINTER(C.c_size_t)()
+        L.check(L.lib().anx_batch_fetch(self.h, C.byref(rows), C.byref(offs)))
+        try:
+            out = []
+            for i in range(self.n):
+                out.append([(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score)
+                            for j in range(offs[i], offs[i + 1])])
+            return out
+        finally:
+            L.lib().anx_results_free(rows, offs)
+
+    def fetch_pairs(self) -> List[tuple]:
+        """-> every scored pair (query, vocab_id, ld|-1, lcs, prefixlen, suffixlen, samecase, score)"""
+        pairs = C.POINTER(L.Pair)()
+        n = C.c_size_t()
+        L.check(L.lib().anx_batch_fetch_pairs(self.h, C.byref(pairs), C.byref(n)))
+        try:
+            return [(pairs[i].query, pairs[i].vocab_id, pairs[i].ld, pairs[i].lcs, pairs[i].prefixlen,
+                     pairs[i].suffixlen, pairs[i].samecase, pairs[i].score) for i in range(n.value)]
+        finally:
+            L.lib().anx_pairs_free(pairs)
+
+    def export_topk(self, device_ptr: int, stride: int, stream: int = 0):
+        L.check(L.lib().anx_batch_export_topk(self.h, C.c_void_p(device_ptr), stride, C.c_void_p(stream)))
+
+    def free(self):
+        if getattr(self, "h", None):
+            L.lib().anx_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.free()
+
+
+class VariantModel:
+    """VariantModel (src/lib.rs:50-100) for the query path; `device` = HIP device ordinal
+    (default: $LOCAL_RANK or 0; -1 = host index only)."""
+
+    def __init__(self, alphabet_file: str, weights: Optional[Weights] = None, debug: int = 0,
+                 device: Optional[int] = None, alphabet_text: Optional[str] = None):
+        w = (weights or Weights())._c()
+        lib = L.lib()
+        if alphabet_text is not None:
+            self.h = lib.anx_model_new_with_alphabet(_b(alphabet_text), C.byref(w), debug)
+        else:
+            self.h = lib.anx_model_new(_b(alphabet_file), C.byref(w), debug)
+        if not self.h:
+            raise L.AnxError(L.ANX_EIO, L.last_error())
+        self.device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+        self.lexicons: List[str] = []
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L.lib().anx_model_free(self.h)
+            self.h = None
+
+    # -- loading -----------------------------------------------------------------------------------
+    def read_vocabulary(self, filename: str, params: Optional[VocabParams] = None):
+        p = (params or VocabParams())._c()
+        L.check(L.lib().anx_model_read_vocabulary(self.h, _b(filename), C.byref(p)))
+        self.lexicons.append(filename)
+
+    def read_lexicon(self, filename: str):
+        self.read_vocabulary(filename, VocabParams())
+
+    def add_to_vocabulary(self, text: str, frequency: Optional[int] = None, params: Optional[VocabParams] = None):
+        p = (params or VocabParams())._c()
+        return L.lib().anx_model_add_to_vocabulary(self.h, _b(text), 0 if frequency is None else 1,
+                                                   frequency or 0, C.byref(p))
+
+    def build(self):
+        L.check(L.lib().anx_model_build(self.h, self.device))
+
+    def to_device(self, device: int):
+        self.device = device
+        L.check(L.lib().anx_model_to_device(self.h, device))
+
+    # -- introspection ------------------------------------------------------------------------------
+    def __contains__(self, text: str) -> bool:
+        return bool(L.lib().anx_model_has(self.h, _b(text)))
+
+    def vocab_text(self, vocab_id: int) -> str:
+        return L.lib().anx_model_vocab_text(self.h, vocab_id).decode("utf-8")
+
+    def num_instances(self) -> int:
+        return L.lib().anx_model_num_instances(self.h)
+
+    def num_classes(self) -> int:
+        return L.lib().anx_model_num_classes(self.h)
+
+    def bucket_size(self, charcount: int) -> int:
+        return L.lib().anx_model_bucket_size(self.h, charcount)
+
+    def normalize(self, text: str) -> List[int]:
+        buf = C.create_string_buffer(256)
+        n = L.lib().anx_model_normalize(self.h, _b(text), buf, 255)
+        if n < 0:
+            L.check(n)
+        return list(buf.raw[:n])
+
+    def anahash(self, text: str) -> int:
+        buf = C.create_string_buffer(4096)
+        n = L.lib().anx_model_anahash(self.h, _b(text), buf, len(buf))
+        if n < 0:
+            L.check(n)
+        return int(buf.value)
+
+    # -- the hot path ---------------------------------------------------------------------------------
+    def encode_batch(self, inputs: Sequence[str], params: SearchParameters) -> Batch:
+        return Batch(self, inputs, params)
+
+    def find_variants_ids(self, inputs: Sequence[str], params: SearchParameters) -> List[List[tuple]]:
+        """anx_find_variants_batch: -> per input, ranked [(vocab_id, dist_score, freq_score)]"""
+        n = len(inputs)
+        arr = (C.c_char_p * max(n, 1))(*[_b(t) for t in inputs])
+        cp = params._c()
+        rows = C.POINTER(L.Result)()
+        offs = C.POINTER(C.c_size_t)()
+        L.check(L.lib().anx_find_variants_batch(self.h, arr, n, C.byref(cp), C.byref(rows), C.byref(offs)))
+        try:
+            return [[(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score) for j in range(offs[i], offs[i + 1])]
+                    for i in range(n)]
+        finally:
+            L.lib().anx_results_free(rows, offs)
+
+    def _to_dict(self, vid: int, dist: float, freq: float, freq_weight: float) -> Dict:
+        # variantresult_to_dict, bindings/python/src/lib.rs:554-588
+        fw = float(freq_weight)
+        score = dist if fw == 0.0 else (dist + fw * freq) / (1.0 + fw)
+        lexindex = L.lib().anx_model_vocab_lexindex(self.h, vid)
+        return {"text": self.vocab_text(vid), "score": score, "dist_score": dist, "freq_score": freq,
+                "lexicons": [name for i, name in enumerate(self.lexicons) if lexindex & (1 << i)]}
+
+    def find_variants(self, input: str, params: SearchParameters) -> List[dict]:
+        res = self.find_variants_ids([input], params)[0]
+        return [self._to_dict(v, d, f, params.freq_weight) for v, d, f in res]
+
+    def find_variants_par(self, input: List[str], params: SearchParameters) -> List[dict]:
+        res = self.find_variants_ids(input, params)
+        return [{"input": t, "variants": [self._to_dict(v, d, f, params.freq_weight) for v, d, f in r]}
+                for t, r in zip(input, res)]
+
+    # -- outside the hot-path scope ("next" rows) ---------------------------------
+    def find_all_matches(self, text: str, params: SearchParameters):
+        raise NotImplementedError("search mode (find_all_matches) is a 'next' row of SURVEY.md section 8(f)")
+
+    def read_variants(self, filename: str, transparent: bool = False):
+        raise NotImplementedError("variant lists are a 'next' row of SURVEY.md section 8(f)")
+
+    def read_confusablelist(self, filename: str):
+        raise NotImplementedError("confusables are a 'next' row of SURVEY.md section 8(f)")

@@ -1,0 +1,62 @@
+"""Synthetic query generator of SURVEY.md section 8(d) (bench + tests input; not part of the scored path).
+
+seed 20240601; pick a lexicon entry uniformly among entries whose length is in range; apply
+e in {0,1,2} edits (p = .2/.5/.3) drawn uniformly from {delete, insert a-z, substitute a-z, adjacent
+transpose}; reject empty / over-long results; original casing is kept.
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import random
+from typing import List, Sequence
+
+SEED = 20240601
+GOLDEN_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
+
+
+def load_lexicon_words(path: str) -> List[str]:
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt", encoding="utf-8", newline="") as f:
+        return [line.split("\t")[0] for line in f.read().split("\n") if line]
+
+
+def materialize_golden(dst_dir: str) -> dict:
+    """Decompress the golden data files (tests/golden/data) into dst_dir; returns their paths."""
+    os.makedirs(dst_dir, exist_ok=True)
+    out = {"alphabet": os.path.join(dst_dir, "simple.alphabet.tsv")}
+    with open(os.path.join(GOLDEN_DATA, "simple_alphabet.tsv"), "rb") as f, open(out["alphabet"], "wb") as g:
+        g.write(f.read())
+    for name in ("eng", "nld"):
+        out[name] = os.path.join(dst_dir, f"{name}.aspell.lexicon")
+        if not os.path.exists(out[name]):
+            with gzip.open(os.path.join(GOLDEN_DATA, f"{name}_aspell.lexicon.gz"), "rb") as f, open(out[name], "wb") as g:
+                g.write(f.read())
+    return out
+
+
+def make_queries(words: Sequence[str], n: int, max_len: int = 16, min_len: int = 1, seed: int = SEED) -> List[str]:
+    rng = random.Random(seed)
+    pool = [w for w in words if min_len <= len(w) <= max_len]
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    out: List[str] = []
+    choice, rnd, randrange = rng.choice, rng.random, rng.randrange
+    while len(out) < n:
+        cs = list(choice(pool))
+        r = rnd()
+        e = 0 if r < 0.2 else (1 if r < 0.7 else 2)
+        for _ in range(e):
+            op = randrange(4)
+            if op == 0:
+                if len(cs) > 1:
+                    del cs[randrange(len(cs))]
+            elif op == 1:
+                cs.insert(randrange(len(cs) + 1), letters[randrange(26)])
+            elif op == 2:
+                cs[randrange(len(cs))] = letters[randrange(26)]
+            elif len(cs) > 1:
+                p = randrange(len(cs) - 1)
+                cs[p], cs[p + 1] = cs[p + 1], cs[p]
+        if cs and len(cs) <= max_len:
+            out.append("".join(cs))
+    return out

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the variant-query hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): eng.aspell lexicon (119 773 entries / 108 802 anagram classes) +
+simple.alphabet, 1 M synthetic queries of length <= 16 (generator: SURVEY.md section 8(d), seed 20240601 + rank),
+CLI defaults with max-edit-distance 2 (k=3, d=2, n=10, score threshold 0.25, cutoff 2.0).
+A "step" = one pass of the device pipeline (anagram scan -> pair grouping -> DL/LCS/prefix/suffix scoring ->
+ranking) over the whole resident query batch.  Inputs are encoded and uploaded once, before the timed region.
+With N>1 every rank processes its own 1 M-query shard (weak scaling, no data-path collective) and the ranked
+fixed-stride top-k records are gathered to rank 0 over RCCL once per step.
+
+Prints ONE JSON line (rank 0).  value = scored (query,candidate) pairs per second, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD32 x 2.4 GHz (one VALU lane-op per lane per clock)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--queries", type=int, default=1_000_000)
+    ap.add_argument("--max-len", type=int, default=16)
+    ap.add_argument("--lexicon", default="eng", choices=["eng", "nld"])
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the variant-query path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import analiticcl_amd as A
+    from analiticcl_amd import synth
+
+    paths = synth.materialize_golden(os.path.join(tempfile.gettempdir(), f"anx_bench_data_{os.getuid()}_{local_rank}"))
+    model = A.VariantModel(paths["alphabet"], A.Weights(), device=local_rank)
+    model.read_lexicon(paths[args.lexicon])
+    model.build()
+    words = synth.load_lexicon_words(paths[args.lexicon])
+    queries = synth.make_queries(words, args.queries, max_len=args.max_len, seed=synth.SEED + rank)
+    params = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10,
+                                score_threshold=0.25, cutoff_threshold=2.0)
+    t_enc = time.time()
+    batch = model.encode_batch(queries, params)  # host encode + H2D, outside the timed region
+    t_enc = time.time() - t_enc
+    stride = 11  # max_matches + 1 records per query (crop tie rule can return max_matches + 1)
+    stream = torch.cuda.current_stream()
+    topk = torch.empty(args.queries * stride * 16, dtype=torch.uint8, device="cuda")
+    gathered = None
+    if world > 1 and not args.no_gather and rank == 0:
+        gathered = [torch.empty_like(topk) for _ in range(world)]
+
+    def step():
+        batch.run(stream.cuda_stream)
+        if world > 1 and not args.no_gather:
+            batch.export_topk(topk.data_ptr(), stride, stream.cuda_stream)
+            dist.gather(topk, gathered, dst=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stage_ms = {"ms_scan": 0.0, "ms_group": 0.0, "ms_score": 0.0, "ms_rank": 0.0, "ms_total": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = batch.stats()  # HIP-event times recorded by the library on the launch stream for this run
+        for k in stage_ms:
+            stage_ms[k] += st[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = batch.stats()
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(st["n_pairs"]), float(st["n_queries"]), float(st["n_class_tests"])],
+                       dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    pairs, nq, tests = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        for k in stage_ms:
+            stage_ms[k] /= max(args.steps, 1)
+        # ---- roofline of the dominant kernel (per launch, rank 0) --------------------------------------
+        lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
+        n_classes = model.num_classes()
+        scan_bytes = st["n_queries"] * 32 + st["n_pairs"] * 8 + n_classes * 32
+        score_bytes = st["n_pairs"] * (lpad + 32)
+        if stage_ms["ms_scan"] >= stage_ms["ms_score"]:
+            kname, kbytes, kms = "k_anagram_scan", scan_bytes, stage_ms["ms_scan"]
+        else:
+            kname, kbytes, kms = "k_score_pairs", score_bytes, stage_ms["ms_score"]
+        achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": kms,
+                    "algorithmic_bytes_per_launch": kbytes,
+                    "note": "integer scan/DP path: VALU-bound, far below the HBM roof (see valu_* and DESIGN.md)",
+                    "valu_scan_laneops_per_s": st["n_class_tests"] * 9.0 / (stage_ms["ms_scan"] * 1e-3)
+                    if stage_ms["ms_scan"] > 0 else 0.0,
+                    "valu_peak_laneops_per_s": VALU_PEAK_LANEOPS}
+        roofline["valu_scan_frac"] = roofline["valu_scan_laneops_per_s"] / VALU_PEAK_LANEOPS
+        # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
+        cpu = None
+        ncores = os.cpu_count() or 1
+        sample = args.cpu_sample if args.cpu_sample >= 0 else min(args.queries, 2500 * ncores)
+        if sample > 0:
+            from oracle import cwrap as O
+            om = O.OracleModel(alphabet_path=paths["alphabet"])
+            om.read_lexicon(paths[args.lexicon])
+            om.build()
+            op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
+            t = time.perf_counter()
+            rc, _res, _counts, cpairs, _ccls = om.find_variants_batch(queries[:sample], op, nthreads=ncores, stride=16)
+            dt = time.perf_counter() - t
+            cpu = {"value": cpairs / dt, "unit": "pairs/s", "cores": ncores, "kind": "port",
+                   "queries_per_s": sample / dt,
+                   "sample": f"first {sample} of the same {args.queries} queries, C oracle (oracle/anx_oracle.c), "
+                             f"OpenMP dynamic schedule, {ncores} threads, {dt:.1f} s"}
+        out = {
+            "metric": "scored (query,candidate) pairs/sec + queries/sec, 200k-lexicon, len<=16",
+            "value": pairs * args.steps / elapsed, "unit": "pairs/s",
+            "queries_per_s": nq * args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.lexicon}.aspell lexicon + simple.alphabet, {args.queries} synthetic queries "
+                                   f"len<={args.max_len} per GPU, k=3 d=2 n=10 score-threshold 0.25 cutoff 2.0 "
+                                   "(BASELINE.json configs[1])",
+                       "queries_per_gpu": args.queries, "lexicon_entries": model.num_instances(),
+                       "anagram_classes": n_classes, "pairs_per_query": pairs / nq if nq else 0.0,
+                       "class_tests_per_query": tests / nq if nq else 0.0,
+                       "parallelism": f"query-sharded x{world}" + (", RCCL gather of top-k records" if world > 1 and not args.no_gather else "")},
+            "stage_ms": stage_ms, "encode_upload_s": t_enc,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/* anx.h -- C ABI of the MI355X-native variant-scoring engine ("anx") for analiticcl.
+ *
+ * This header is the drop-in boundary for analiticcl's variant-query hot path.  The reference
+ * (proycon/analiticcl, Rust) has no FFI of its own; the functions below are what a Rust `extern "C"`
+ * block (or cgo / ctypes / N-API) binds in place of the reference's Rust methods.  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference tree).  INTEGRATION.md shows the
+ * Rust-side binding.
+ *
+ * Conventions: plain pointers and sizes only; UTF-8, NUL-terminated strings borrowed for the call;
+ * every function returning int returns 0 on success and a negative ANX_E* code on failure, with a
+ * thread-local message available from anx_last_error(); nothing aborts across the ABI.
+ * The compute path is HIP-only (gfx950): there is no CPU fallback -- calls that need the device fail
+ * with ANX_ENODEVICE when no GPU is present.
+ */
+#ifndef ANX_H
+#define ANX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANX_ABI_VERSION 1
+
+enum {
+  ANX_OK = 0,
+  ANX_EINVAL = -1,    /* bad argument */
+  ANX_EIO = -2,       /* file could not be read (reference: io::Result from the readers) */
+  ANX_ENOTBUILT = -3, /* find_variants before build() (reference prints an error and returns [], src/lib.rs:973-976) */
+  ANX_ENODEVICE = -4, /* no HIP device / HIP runtime error */
+  ANX_ELIMIT = -5,    /* input exceeds a documented limit (255 symbols per string, 166 alphabet classes) */
+  ANX_EEMPTY = -6     /* empty query (reference panics: assert!(input_length > 0), src/lib.rs:1420) */
+};
+
+typedef struct anx_model anx_model; /* VariantModel, src/lib.rs:50-100 */
+typedef struct anx_batch anx_batch; /* a batch of encoded queries + its results, resident in HBM */
+
+/* Weights, src/types.rs:40-73 (defaults .5/.125/.125/.125/.125) */
+typedef struct anx_weights {
+  double ld, lcs, prefix, suffix, casew;
+} anx_weights;
+
+/* DistanceThreshold, src/types.rs:76-83 */
+enum { ANX_ABSOLUTE = 0, ANX_RATIO = 1, ANX_RATIO_WITH_LIMIT = 2 };
+typedef struct anx_threshold {
+  uint8_t kind;
+  uint8_t value; /* Absolute(value) or the limit of RatioWithLimit(ratio, value) */
+  float ratio;
+} anx_threshold;
+
+/* SearchParameters, src/types.rs:112-192 (fields used by find_variants) */
+typedef struct anx_params {
+  anx_threshold max_anagram_distance; /* default Absolute(3) */
+  anx_threshold max_edit_distance;    /* default Absolute(3) */
+  uint64_t max_matches;               /* default 20; 0 = unlimited */
+  double score_threshold;             /* default 0.25 */
+  double cutoff_threshold;            /* default 2.0 */
+  int32_t stop_at_exact_match;        /* StopCriterion::StopAtExactMatch, src/types.rs:308-313 */
+  float freq_weight;                  /* default 0.0 */
+} anx_params;
+
+/* VocabParams, src/vocab.rs:108-131 */
+enum { ANX_FREQ_SUM = 0, ANX_FREQ_MAX = 1, ANX_FREQ_MIN = 2, ANX_FREQ_REPLACE = 3 };
+enum { ANX_VOCAB_NONE = 0, ANX_VOCAB_INDEXED = 1, ANX_VOCAB_LM = 2, ANX_VOCAB_TRANSPARENT = 4 };
+typedef struct anx_vocab_params {
+  uint8_t text_column;   /* default 0 */
+  int16_t freq_column;   /* default 1; -1 = None */
+  uint8_t freq_handling; /* default ANX_FREQ_MAX */
+  uint8_t vocab_type;    /* default ANX_VOCAB_INDEXED */
+} anx_vocab_params;
+
+/* VariantResult, src/types.rs:326-332 */
+#define ANX_NO_VIA UINT64_MAX
+typedef struct anx_result {
+  uint64_t vocab_id;
+  double dist_score;
+  double freq_score;
+  uint64_t via; /* Option<VocabId>; ANX_NO_VIA = None */
+} anx_result;
+
+/* One scored (query, candidate) pair -- the reference's Distance (src/types.rs:289-305) for every instance
+ * on which damerau_levenshtein is invoked (src/lib.rs:1343); ld = -1 where it returned None.
+ * Exposed for parity tests and the "scored pairs" metric. */
+typedef struct anx_pair {
+  uint32_t query;    /* index into the batch */
+  uint32_t vocab_id;
+  int16_t ld;
+  uint16_t lcs, prefixlen, suffixlen;
+  uint8_t samecase;
+  uint8_t _pad;
+  double score;      /* dist score (src/lib.rs:1443-1452); 0 when ld < 0 */
+} anx_pair;
+
+/* Fixed-stride ranked record for device-to-device export / RCCL gather (16 B). */
+typedef struct anx_topk_record {
+  uint32_t vocab_id; /* UINT32_MAX = empty slot */
+  float freq_score;
+  double dist_score;
+} anx_topk_record;
+
+void anx_default_weights(anx_weights *);           /* Weights::default() */
+void anx_default_params(anx_params *);             /* SearchParameters::default() */
+void anx_default_vocab_params(anx_vocab_params *); /* VocabParams::default() */
+const char *anx_last_error(void);
+int anx_abi_version(void);
+
+/* ---- model construction (host) ------------------------------------------------------------------ */
+/* VariantModel::new(alphabet_file, weights, debug), src/lib.rs:104 (+ read_alphabet :369) */
+anx_model *anx_model_new(const char *alphabet_path, const anx_weights *weights, int debug);
+/* VariantModel::new_with_alphabet, src/lib.rs:132; the alphabet is passed as the TSV text */
+anx_model *anx_model_new_with_alphabet(const char *alphabet_tsv, const anx_weights *weights, int debug);
+void anx_model_free(anx_model *);
+/* read_vocabulary(filename, &VocabParams), src/lib.rs:519 */
+int anx_model_read_vocabulary(anx_model *, const char *path, const anx_vocab_params *);
+/* add_to_vocabulary(text, Option<u32>, &VocabParams) -> VocabId, src/lib.rs:900. Returns UINT64_MAX on error. */
+uint64_t anx_model_add_to_vocabulary(anx_model *, const char *utf8, int has_frequency, uint32_t frequency,
+                                     const anx_vocab_params *);
+/* build(), src/lib.rs:192: anagram classes, sorted secondary index, then the device-resident SoA lexicon.
+ * `device` = HIP device ordinal to upload to; -1 = build the host index only (queries then fail with
+ * ANX_ENODEVICE until anx_model_to_device succeeds). */
+int anx_model_build(anx_model *, int device);
+int anx_model_to_device(anx_model *, int device);
+/* has(text), src/lib.rs:331; get_vocab(id), src/lib.rs:341 */
+int anx_model_has(const anx_model *, const char *utf8);
+uint64_t anx_model_vocab_size(const anx_model *);
+const char *anx_model_vocab_text(const anx_model *, uint64_t vocab_id);
+uint32_t anx_model_vocab_frequency(const anx_model *, uint64_t vocab_id);
+uint32_t anx_model_vocab_lexindex(const anx_model *, uint64_t vocab_id);
+/* index statistics ("Found N instances / N anagrams / N anagrams of length L", src/lib.rs:211,220,244) */
+uint64_t anx_model_num_instances(const anx_model *);
+uint64_t anx_model_num_classes(const anx_model *);
+uint64_t anx_model_bucket_size(const anx_model *, int charcount);
+int anx_model_alphabet_size(const anx_model *); /* alphabet_size(), src/lib.rs:163 (includes UNK) */
+/* normalize_to_alphabet, src/anahash.rs:50; returns length or a negative error */
+int anx_model_normalize(const anx_model *, const char *utf8, uint8_t *out, int cap);
+/* anahash, src/anahash.rs:16, as a decimal string; returns length or a negative error */
+int anx_model_anahash(const anx_model *, const char *utf8, char *out, int cap);
+
+/* ---- the hot path: find_variants --------------------------------------------------------------- */
+/* VariantModel::find_variants(&self, &str, &SearchParameters) -> Vec<VariantResult>, src/lib.rs:972,
+ * for n inputs at once (the reference's callers fan out one call per input: rayon par_iter in
+ * src/bin/analiticcl.rs:445-448, src/lib.rs:1883, bindings/python/src/lib.rs:727).
+ * Results are CSR: rows of query i are (*out_rows)[(*out_offsets)[i] .. (*out_offsets)[i+1]).
+ * Both arrays are allocated by the library; release with anx_results_free. Thread-safe for concurrent
+ * read-only use of the model. */
+int anx_find_variants_batch(const anx_model *, const char *const *utf8, size_t n, const anx_params *,
+                            anx_result **out_rows, size_t **out_offsets);
+void anx_results_free(anx_result *rows, size_t *offsets);
+
+/* ---- staged form of the same call (inputs/results resident in HBM between stages) --------------------
+ * encode : host normalisation (src/anahash.rs:16-80), threshold clamps (src/lib.rs:982-1012), length
+ *          bucketing, upload.  run: the device pipeline (candidate scan -> pair list -> scoring -> rank).
+ * fetch  : download + convert.  anx_find_variants_batch == encode + run + fetch + free. */
+anx_batch *anx_batch_encode(const anx_model *, const char *const *utf8, size_t n, const anx_params *);
+/* `stream` is a hipStream_t (NULL = the default stream). Asynchronous except for one count read-back. */
+int anx_batch_run(const anx_model *, anx_batch *, void *stream);
+int anx_batch_fetch(const anx_batch *, anx_result **out_rows, size_t **out_offsets);
+/* every scored pair of the batch (order unspecified within a query) */
+int anx_batch_fetch_pairs(const anx_batch *, anx_pair **out_pairs, size_t *out_n);
+void anx_pairs_free(anx_pair *);
+/* write fixed-stride ranked records (stride records per query, batch order) into a DEVICE buffer of
+ * n*stride*sizeof(anx_topk_record) bytes (e.g. a torch tensor) -- the payload of the multi-GPU gather */
+int anx_batch_export_topk(const anx_batch *, void *device_dst, uint32_t stride, void *stream);
+typedef struct anx_batch_stats {
+  uint64_t n_queries;
+  uint64_t n_pairs;          /* scored (query,candidate) pairs = DL invocations of the reference */
+  uint64_t n_class_tests;    /* (query,class) count-vector tests executed by the scan kernel */
+  uint64_t n_results;        /* ranked results returned */
+  uint64_t n_scan_blocks;    /* workgroups launched by the scan kernel */
+  float ms_scan, ms_group, ms_score, ms_rank, ms_total; /* HIP-event times of the last run */
+} anx_batch_stats;
+int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
+void anx_batch_free(anx_batch *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path (through the C ABI, libanx.so) against the CPU oracle and the golden vectors.
+
+Bar: bit-exact integer distances (ld, lcs, prefix, suffix, samecase), identical ranked vocab-id lists,
+scores within 1e-6 (in practice identical f64).
+"""
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import analiticcl_amd as A
+from analiticcl_amd import synth
+from oracle import cwrap as O
+
+TOL = 1e-6
+TEST_ALPHABET_TSV = "\n".join(f"{c}\t{c.upper()}" for c in "abcdefghijklmnopqrstuvwxyz") + "\n.\t,\n"
+
+
+def sp(th):
+    """oracle-style threshold tuple -> python API value"""
+    return th[1] if th[0] == "abs" else (float(th[1]) if th[0] == "ratio" else (float(th[1]), int(th[2])))
+
+
+def params_pair(k=("abs", 3), d=("abs", 3), n=20, thr=0.25, cutoff=2.0, stop=False, fw=0.0):
+    return (A.SearchParameters(max_anagram_distance=sp(k), max_edit_distance=sp(d), max_matches=n, score_threshold=thr,
+                               cutoff_threshold=cutoff, stop_criterion=stop, freq_weight=fw),
+            O.make_params(k, d, n, thr, cutoff, stop, fw))
+
+
+CLI = dict(k=("abs", 3), d=("abs", 2), n=10, thr=0.25, cutoff=2.0)  # src/bin/analiticcl.rs:805-817
+
+
+@pytest.fixture(scope="module")
+def eng(data_dir):
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    g.build()
+    o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+    o.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    o.build()
+    return g, o
+
+
+def compare_batch(g, o, queries, gp, op, check_pairs=True):
+    b = g.encode_batch(queries, gp)
+    b.run()
+    res = b.fetch()
+    stats = b.stats()
+    pairs_by_q = {}
+    if check_pairs:
+        for (q, vid, ld, lcs, pre, suf, same, _score) in b.fetch_pairs():
+            pairs_by_q.setdefault(q, []).append((vid, ld, lcs if ld >= 0 else 0, pre if ld >= 0 else 0,
+                                                 suf if ld >= 0 else 0, same if ld >= 0 else 1))
+    total_pairs = 0
+    for i, text in enumerate(queries):
+        if text == "":
+            assert res[i] == []
+            continue
+        ores, opairs, npairs, _ncls = o.find_variants(text, op, want_pairs=True, cap=1 << 17)
+        total_pairs += npairs
+        got = res[i]
+        assert [v for v, _, _ in got] == [v for v, _, _ in ores], (text, got[:5], ores[:5])
+        for (gv, gd, gf), (ov, od, of) in zip(got, ores):
+            assert abs(gd - od) <= TOL and abs(gf - of) <= TOL, (text, gv, gd, od, gf, of)
+            assert gd == od and gf == of, ("scores are expected to be identical f64", text, gd, od)
+        if check_pairs:
+            assert sorted(pairs_by_q.get(i, [])) == sorted(opairs), text
+    assert stats["n_pairs"] == total_pairs
+    b.free()
+    return stats
+
+
+def test_tutorial_outputs(eng, tutorial_outputs):
+    g, _ = eng
+    p = A.SearchParameters()
+    cases = [(c["input"], c["results"]) for c in tutorial_outputs["find_variants"]]
+    cases += [(m["input"], m["variants"]) for m in tutorial_outputs["find_all_matches"][0]["matches"]]
+    cases += [(m["input"], m["variants"]) for m in tutorial_outputs["find_all_matches"][1]["matches"]]
+    for text, exp in cases:
+        got = [[r["text"], r["score"], r["dist_score"], r["freq_score"]] for r in g.find_variants(text, p)]
+        assert got == exp, text
+    r = g.find_variants("seperate", p)[0]
+    assert r["lexicons"] and r["lexicons"][0].endswith("eng.aspell.lexicon")
+
+
+def test_twin_vectors_all_paramsets(eng, twin_vectors):
+    g, _ = eng
+    for pname, v in twin_vectors["paramsets"].items():
+        gp = A.SearchParameters(max_anagram_distance=sp(tuple(v["max_anagram_distance"])),
+                                max_edit_distance=sp(tuple(v["max_edit_distance"])), max_matches=v["max_matches"],
+                                score_threshold=v["score_threshold"], cutoff_threshold=v["cutoff_threshold"],
+                                stop_criterion=v["stop_at_exact_match"], freq_weight=v["freq_weight"])
+        cases = [c for c in twin_vectors["cases"] if c["params"] == pname]
+        b = g.encode_batch([c["input"] for c in cases], gp)
+        b.run()
+        res = b.fetch()
+        assert b.stats()["n_pairs"] == sum(c["n_pairs"] for c in cases), pname
+        for c, r in zip(cases, res):
+            got = [[g.vocab_text(v), v, ds, fs] for v, ds, fs in r]
+            assert got == c["results"], (pname, c["input"])
+        b.free()
+
+
+def test_random_queries_vs_oracle_cli_defaults(eng, data_dir):
+    g, o = eng
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    qs = synth.make_queries(words, 1500, max_len=16, seed=11)
+    gp, op = params_pair(**CLI)
+    st = compare_batch(g, o, qs, gp, op)
+    assert st["n_queries"] == 1500 and st["n_pairs"] > 10000
+
+
+@pytest.mark.parametrize("kw", [
+    dict(k=("abs", 3), d=("abs", 3), n=20),                       # library defaults
+    dict(k=("abs", 2), d=("abs", 2), n=10, thr=0.0, cutoff=0.0),  # src/test.rs:48-68
+    dict(k=("ratio", 0.3), d=("ratiolimit", 0.25, 3), n=5, thr=0.5, cutoff=0.0),
+    dict(k=("ratio", 1.0), d=("ratio", 0.5), n=3, thr=0.1, cutoff=1.0),
+    dict(k=("abs", 3), d=("abs", 3), n=20, stop=True),
+    dict(k=("abs", 2), d=("abs", 2), n=0, thr=0.0, cutoff=0.0),   # unlimited
+    dict(k=("abs", 3), d=("abs", 3), n=1),
+    dict(k=("abs", 4), d=("abs", 4), n=7, thr=0.3, cutoff=1.5),
+    dict(k=("abs", 3), d=("abs", 2), n=10, fw=0.5),               # weighted ranking (all freqs 1 here)
+])
+def test_parameter_sets_vs_oracle(eng, data_dir, kw):
+    g, o = eng
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    qs = synth.make_queries(words, 250, max_len=20, seed=5)
+    qs += ["a", "I", "Fo", "K", "xyzzyq", "it's", "O'Neil", "étude", "naïve", "b2b", "``", "  ", "e.g.", "AAAA",
+           "antidisestablishmentarianism", "pneumonoultramicroscopicsilicovolcanoconiosis", "ZZZZZZZZZZ"]
+    gp, op = params_pair(**kw)
+    compare_batch(g, o, qs, gp, op)
+
+
+def test_edge_inputs(eng):
+    g, o = eng
+    gp, op = params_pair(**CLI)
+    qs = ["", "a", "", "zzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzz", "the", "", "é", "\U0001F600x"]
+    compare_batch(g, o, qs, gp, op)
+    assert g.find_variants_ids([], gp) == []
+    assert g.find_variants_ids([""], gp) == [[]]
+
+
+def test_single_query_call_equals_batch(eng):
+    g, _ = eng
+    p = A.SearchParameters(max_edit_distance=2, max_matches=10)
+    qs = ["seperate", "recieve", "teh", "acommodate", "wich"]
+    batch = g.find_variants_ids(qs, p)
+    for q, r in zip(qs, batch):
+        assert g.find_variants_ids([q], p)[0] == r
+    par = g.find_variants_par(qs, p)
+    assert [x["input"] for x in par] == qs
+    assert [[v["text"] for v in x["variants"]] for x in par] == [[g.vocab_text(v) for v, _, _ in r] for r in batch]
+
+
+def test_export_topk_matches_fetch(eng):
+    import numpy as np
+    import torch
+    g, _ = eng
+    p = A.SearchParameters(max_edit_distance=2, max_matches=10)
+    qs = ["seperate", "", "recieve", "teh", "xyzzyq", "acommodate"]
+    b = g.encode_batch(qs, p)
+    b.run()
+    res = b.fetch()
+    stride = 11
+    buf = torch.zeros(len(qs) * stride * 16, dtype=torch.uint8, device="cuda:0")
+    b.export_topk(buf.data_ptr(), stride)
+    torch.cuda.synchronize()
+    rec = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=np.dtype([("vocab_id", "<u4"), ("freq", "<f4"), ("dist", "<f8")]))
+    rec = rec.reshape(len(qs), stride)
+    for i, r in enumerate(res):
+        if qs[i] == "":
+            continue
+        assert [int(x) for x in rec[i]["vocab_id"][:len(r)]] == [v for v, _, _ in r]
+        assert all(int(x) == 0xFFFFFFFF for x in rec[i]["vocab_id"][len(r):])
+        assert [float(x) for x in rec[i]["dist"][:len(r)]] == [d for _, d, _ in r]
+    b.free()
+
+
+def test_small_model_reference_tests():  # tests/main.rs:858-911
+    lex = ["rites", "tiers", "tires", "tries", "tyres", "rides", "brides", "dire"]
+    g = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
+    o = O.OracleModel(alphabet_text=TEST_ALPHABET_TSV)
+    for w in lex:
+        g.add_to_vocabulary(w)
+        o.add(w)
+    g.build()
+    o.build()
+    gp, op = params_pair(("abs", 2), ("abs", 2), 10, 0.0, 0.0)
+    compare_batch(g, o, ["rite", "rites", "tyre", "bride", "x", "dir"], gp, op)
+    g2 = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
+    for w in ("huis", "huls"):
+        g2.add_to_vocabulary(w)
+    g2.build()
+    r = g2.find_variants("huys", gp)
+    assert [x["text"] for x in r] == ["huis", "huls"]  # tied: order is the deterministic enumeration order
+    assert r[0]["dist_score"] == r[1]["dist_score"] and r[0]["freq_score"] == r[1]["freq_score"]
+
+
+def test_frequency_lexicon_and_weights(tmp_path):
+    """have_freq lexicon (frequency column), freq_weight > 0, zero weights (components not computed)."""
+    rng = random.Random(3)
+    base = ["house", "houses", "horse", "hose", "mouse", "moose", "louse", "hours", "hour", "our", "ours", "use",
+            "used", "user", "muse", "fuse", "ruse", "rouse", "douse", "nous", "thou", "shout", "south", "mouth"]
+    lines = [f"{w}\t{rng.randrange(0, 500)}" for w in base] + ["hause", "Hause\t7"]
+    lexfile = tmp_path / "freq.tsv"
+    lexfile.write_text("\n".join(lines) + "\n", encoding="utf-8")
+    qs = ["house", "hous", "huose", "mouse", "Hose", "ouse", "xouse", "thuo"]
+    for weights in (A.Weights(), A.Weights(lcs=0.0, prefix=0.0), A.Weights(case=0.0, suffix=0.0, ld=1.0)):
+        g = A.VariantModel("", weights, alphabet_text=TEST_ALPHABET_TSV, device=0)
+        g.read_lexicon(str(lexfile))
+        g.build()
+        o = O.OracleModel(alphabet_text=TEST_ALPHABET_TSV)
+        o.set_weights(weights.ld, weights.lcs, weights.prefix, weights.suffix, weights.case)
+        o.read_lexicon(str(lexfile))
+        o.build()
+        for kw in (dict(fw=0.0), dict(fw=0.5), dict(fw=2.0, n=3), dict(fw=1.0, n=0, thr=0.0, cutoff=0.0),
+                   dict(fw=0.25, n=2, cutoff=1.2)):
+            gp, op = params_pair(("abs", 3), ("abs", 3), kw.get("n", 20), kw.get("thr", 0.25), kw.get("cutoff", 2.0),
+                                 False, kw["fw"])
+            compare_batch(g, o, qs, gp, op)
+
+
+def test_nld_lexicon_edit_distance_3(data_dir):
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(os.path.join(data_dir, "nld.aspell.lexicon"))
+    g.build()
+    o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+    o.read_lexicon(os.path.join(data_dir, "nld.aspell.lexicon"))
+    o.build()
+    words = synth.load_lexicon_words(os.path.join(data_dir, "nld.aspell.lexicon"))
+    qs = synth.make_queries(words, 400, max_len=24, seed=23)
+    gp, op = params_pair(("abs", 3), ("abs", 3), 10, 0.25, 2.0)
+    compare_batch(g, o, qs, gp, op)
