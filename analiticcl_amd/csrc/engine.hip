@@ -36,9 +36,6 @@ struct Tile {           // TQ queries of one length against the +-k charcount wi
   uint32_t k;           // clamped anagram distance for this length
   uint32_t lq;          // query length in symbols
 };
-struct Work {           // one workgroup of k_anagram_scan
-  uint32_t tile, cbase;
-};
 
 struct DeviceLexicon {
   int device = 0;
@@ -51,6 +48,7 @@ struct DeviceLexicon {
   uint32_t* ent_freq = nullptr;
   uint32_t* ent_meta = nullptr;
   uint32_t* ent_rowoff = nullptr;
+  uint32_t* ent_order = nullptr;
   uint4* rows = nullptr;
   size_t bytes = 0;
 };
@@ -66,7 +64,6 @@ struct Batch {
   std::vector<int32_t> status;     // per original query: 0 ok, ANX_EEMPTY, ANX_ELIMIT
   size_t n_input = 0;
   std::vector<Tile> tiles;
-  std::vector<Work> work;
   uint32_t qw = 1;                 // uint4 words per query row
   uint32_t dmax = 0;
   uint64_t n_class_tests = 0;
@@ -76,7 +73,6 @@ struct Batch {
   uint32_t* q_meta = nullptr;      // len | k<<8 | d<<16 | first_is_lower<<24
   uint32_t* q_orig = nullptr;      // original index
   Tile* d_tiles = nullptr;
-  Work* d_work = nullptr;
   // device: pipeline
   uint32_t* counters = nullptr;
   uint32_t* qcount = nullptr;
@@ -116,68 +112,121 @@ struct Batch {
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant address space: s_load
 
+constexpr uint32_t SCAN_TQ = 256;       // queries per tile (= per workgroup)
+constexpr uint32_t SCAN_CHUNK = 1024;   // pair slots a wave reserves per global atomic
+constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
+
+// One workgroup owns one query tile and streams every class chunk of the tile's charcount window past it.
+// Per-query pair counts live in LDS (no global atomics); each wave appends its hits to wave-private
+// 1024-slot chunks of the flat pair list, reserved with ONE global atomic per chunk (a single contended
+// counter word sustains only ~88 M atomics/s on this chip, MI355X_MICROARCH.md "dequeue").
 template <int NP, int CPL>
-__global__ __launch_bounds__(256) void k_anagram_scan(const Tile* __restrict__ tiles, const Work* __restrict__ work,
+__global__ __launch_bounds__(256) void k_anagram_scan(const Tile* __restrict__ tiles,
                                                       const uint32_t* __restrict__ q_cv,
                                                       const uint32_t* __restrict__ planes, uint32_t cstride,
                                                       const uint8_t* __restrict__ cls_len,
                                                       const uint32_t* __restrict__ cls_off, uint2* __restrict__ raw,
                                                       uint32_t raw_cap, uint32_t* __restrict__ counters,
                                                       uint32_t* __restrict__ qcount, uint32_t* __restrict__ qexact) {
-  const Work w = work[blockIdx.x];
-  const Tile t = tiles[w.tile];
-  // Unguarded loads: the plane arrays are padded by a full workgroup chunk of 0xFF classes, and real
-  // classes beyond c1 lie outside the +-k charcount window, so they can never satisfy L1 <= k.
-  uint32_t cv[CPL][NP];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const uint32_t c = w.cbase + j * 256 + threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) cv[j][p] = planes[(size_t)p * cstride + c];
-  }
+  __shared__ uint32_t s_cnt[SCAN_TQ], s_exact[SCAN_TQ];
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t i = threadIdx.x; i < SCAN_TQ; i += 256) { s_cnt[i] = 0; s_exact[i] = 0; }
+  __syncthreads();
+  uint32_t w_base = 0, w_left = 0;  // this wave's current chunk of the pair list (wave-uniform)
   const uint32_t k = t.k;
   cptr_u32 qbase = (cptr_u32)(q_cv + (size_t)t.q0 * NP);
-  uint32_t qnext[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) qnext[p] = qbase[p];
-  for (uint32_t qi = 0; qi < t.nq; ++qi) {
-    const uint32_t q = t.q0 + qi;
-    uint32_t qreg[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) qreg[p] = qnext[p];
-    // prefetch the next query's count vector into SGPRs while this one is compared
-    cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * NP;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) qnext[p] = qv[p];
-    uint32_t dist[CPL];
-    bool any = false;
+  for (uint32_t cb = t.c0; cb < t.c1; cb += 256 * CPL) {
+    // Unguarded loads: the plane arrays are padded by a full chunk of 0xFF classes, and real classes
+    // beyond c1 lie outside the +-k charcount window, so they can never satisfy L1 <= k.
+    uint32_t cv[CPL][NP];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-      uint32_t acc = 0;
+      const uint32_t c = cb + j * 256 + threadIdx.x;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) acc = __builtin_amdgcn_sad_u8(qreg[p], cv[j][p], acc);
-      dist[j] = acc;
-      any |= acc <= k;
+      for (int p = 0; p < NP; ++p) cv[j][p] = planes[(size_t)p * cstride + c];
     }
-    if (any) {  // rare: ~0.1 % of class tests hit
+    uint32_t qnext[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) qnext[p] = qbase[p];
+    for (uint32_t qi = 0; qi < t.nq; ++qi) {
+      uint32_t qreg[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) qreg[p] = qnext[p];
+      // prefetch the next query's count vector into SGPRs while this one is compared
+      cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * NP;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) qnext[p] = qv[p];
+      uint32_t dist[CPL];
+      bool any = false;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        if (dist[j] <= k) {
-          const uint32_t c = w.cbase + j * 256 + threadIdx.x;
-          // shares at least one symbol <=> L1 < len_q + len_c (deleting all of q is never enumerated:
-          // RecurseDeletionIterator with empty_leaves=false, src/iterators.rs:177, src/lib.rs:1205)
-          if (dist[j] < t.lq + (uint32_t)cls_len[c]) {
-            const uint32_t e0 = cls_off[c], n = cls_off[c + 1] - e0;
-            const uint32_t base = atomicAdd(&counters[CTR_RAW], n);
-            atomicAdd(&qcount[q], n);
-            const uint32_t exact = dist[j] == 0 ? 0x80000000u : 0u;
-            if (exact) atomicAdd(&qexact[q], n);
-            for (uint32_t i = 0; i < n; ++i)
-              if (base + i < raw_cap) raw[base + i] = make_uint2(q, (e0 + i) | exact);
+        uint32_t acc = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc = __builtin_amdgcn_sad_u8(qreg[p], cv[j][p], acc);
+        dist[j] = acc;
+        any |= acc <= k;
+      }
+      if (__ballot(any) != 0ull) {  // wave-uniform; ~0.1 % of class tests hit
+        uint32_t e0[CPL], n[CPL], ntot = 0, nex = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          n[j] = 0;
+          e0[j] = 0;
+          if (dist[j] <= k) {
+            const uint32_t c = cb + j * 256 + threadIdx.x;
+            // shares at least one symbol <=> L1 < len_q + len_c (deleting all of q is never enumerated:
+            // RecurseDeletionIterator with empty_leaves=false, src/iterators.rs:177, src/lib.rs:1205)
+            if (dist[j] < t.lq + (uint32_t)cls_len[c]) {
+              e0[j] = cls_off[c];
+              n[j] = cls_off[c + 1] - e0[j];
+              ntot += n[j];
+              if (dist[j] == 0) nex += n[j];
+            }
           }
+        }
+        // wave-wide exclusive prefix sum of the per-lane pair counts
+        uint32_t incl = ntot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t u = __shfl_up(incl, o);
+          if (lane >= (uint32_t)o) incl += u;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        if (total) {
+          if (total > w_left) {  // wave-uniform: close the current chunk, reserve a new one
+            for (uint32_t i = lane; i < w_left; i += 64)
+              if (w_base + i < raw_cap) raw[w_base + i] = make_uint2(RAW_INVALID, 0u);
+            const uint32_t need = total > SCAN_CHUNK ? total : SCAN_CHUNK;
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&counters[CTR_RAW], need);
+            w_base = __shfl(b, 0);
+            w_left = need;
+          }
+          if (ntot) {
+            const uint32_t q = t.q0 + qi;
+            atomicAdd(&s_cnt[qi], ntot);
+            if (nex) atomicAdd(&s_exact[qi], nex);
+            uint32_t pos = w_base + incl - ntot;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+              const uint32_t exact = dist[j] == 0 ? 0x80000000u : 0u;
+              for (uint32_t i = 0; i < n[j]; ++i, ++pos)
+                if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
+            }
+          }
+          w_base += total;
+          w_left -= total;
         }
       }
     }
+  }
+  for (uint32_t i = lane; i < w_left; i += 64)
+    if (w_base + i < raw_cap) raw[w_base + i] = make_uint2(RAW_INVALID, 0u);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < t.nq; i += 256) {
+    qcount[t.q0 + i] = s_cnt[i];
+    qexact[t.q0 + i] = s_exact[i];
   }
 }
 
@@ -255,7 +304,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // K2: group the flat pair list by query (counting-sort scatter).  Order inside a query is arbitrary;
-// ranking uses a total order whose last key is the entry index (= reference enumeration order).
+// ranking uses a total order whose last key is ent_order (= reference enumeration order).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_group_pairs(const uint2* __restrict__ raw, uint32_t nraw,
                                                      const uint32_t* __restrict__ qoff,
@@ -266,6 +315,7 @@ __global__ __launch_bounds__(256) void k_group_pairs(const uint2* __restrict__ r
   if (r >= nraw) return;
   const uint2 v = raw[r];
   const uint32_t q = v.x;
+  if (q == RAW_INVALID) return;  // unused tail of a wave's chunk
   if (stop && qexact[q] > 0 && !(v.y & 0x80000000u)) return;
   const uint32_t pos = qoff[q] + atomicAdd(&qcur[q], 1u);
   pair_q[pos] = q;
@@ -438,12 +488,13 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
                                               const uint32_t* __restrict__ pair_e,
                                               const double* __restrict__ p_score,
                                               const uint32_t* __restrict__ ent_freq,
+                                              const uint32_t* __restrict__ ent_order,
                                               const uint32_t* __restrict__ qmaxfreq, RankArgs a,
                                               double* __restrict__ t_key, uint32_t* __restrict__ t_pos,
                                               uint32_t* __restrict__ r_entry, double* __restrict__ r_dist,
                                               double* __restrict__ r_freq, uint32_t* __restrict__ r_count) {
   __shared__ double s_key[4][RANK_LCAP];
-  __shared__ uint32_t s_freq[4][RANK_LCAP], s_entry[4][RANK_LCAP], s_pos[4][RANK_LCAP];
+  __shared__ uint32_t s_freq[4][RANK_LCAP], s_entry[4][RANK_LCAP], s_pos[4][RANK_LCAP], s_ord[4][RANK_LCAP];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.x * 4 + wid;
   if (q >= nq) return;
@@ -471,6 +522,7 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
       }
       if (idx < RANK_LCAP) {
         s_key[wid][idx] = key; s_freq[wid][idx] = f; s_entry[wid][idx] = e; s_pos[wid][idx] = pos;
+        s_ord[wid][idx] = ent_order[e];
       } else {
         t_key[seg0 + idx] = key; t_pos[seg0 + idx] = pos;
       }
@@ -482,17 +534,17 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
   const bool full = score_weighted || a.max_matches == 0;
   const uint32_t M = full ? n : (uint32_t)min((uint64_t)n, a.max_matches + 1);
   for (uint32_t i = lane; i < n; i += 64) {
-    double ki; uint32_t fi, ei, pi;
-    if (i < RANK_LCAP) { ki = s_key[wid][i]; fi = s_freq[wid][i]; ei = s_entry[wid][i]; pi = s_pos[wid][i]; }
-    else { ki = t_key[seg0 + i]; pi = t_pos[seg0 + i]; ei = pair_e[pi]; fi = a.have_freq ? ent_freq[ei] : 1u; }
+    double ki; uint32_t fi, ei, pi, oi;
+    if (i < RANK_LCAP) { ki = s_key[wid][i]; fi = s_freq[wid][i]; ei = s_entry[wid][i]; pi = s_pos[wid][i]; oi = s_ord[wid][i]; }
+    else { ki = t_key[seg0 + i]; pi = t_pos[seg0 + i]; ei = pair_e[pi]; fi = a.have_freq ? ent_freq[ei] : 1u; oi = ent_order[ei]; }
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; ++j) {
-      double kj; uint32_t fj, ej;
-      if (j < RANK_LCAP) { kj = s_key[wid][j]; fj = s_freq[wid][j]; ej = s_entry[wid][j]; }
-      else { kj = t_key[seg0 + j]; ej = pair_e[t_pos[seg0 + j]]; fj = a.have_freq ? ent_freq[ej] : 1u; }
+      double kj; uint32_t fj, oj;
+      if (j < RANK_LCAP) { kj = s_key[wid][j]; fj = s_freq[wid][j]; oj = s_ord[wid][j]; }
+      else { kj = t_key[seg0 + j]; const uint32_t ej = pair_e[t_pos[seg0 + j]]; fj = a.have_freq ? ent_freq[ej] : 1u; oj = ent_order[ej]; }
       bool before;
-      if (sort_weighted) before = kj > ki || (kj == ki && ej < ei);
-      else before = kj > ki || (kj == ki && (fj > fi || (fj == fi && ej < ei)));
+      if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
+      else before = kj > ki || (kj == ki && (fj > fi || (fj == fi && oj < oi)));
       rank += before;
     }
     if (rank < M) {
@@ -637,6 +689,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->ent_freq, img.ent_freq.data(), img.ent_freq.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_meta, img.ent_meta.data(), img.ent_meta.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_rowoff, img.ent_rowoff.data(), img.ent_rowoff.size(), err, &d->bytes)) ||
+      (rc = upload(&d->ent_order, img.ent_order.data(), img.ent_order.size(), err, &d->bytes)) ||
       (rc = upload(reinterpret_cast<uint8_t**>(&d->rows), img.rows.data(), img.rows.size(), err, &d->bytes))) {
     lexicon_free(d);
     return nullptr;
@@ -648,12 +701,11 @@ void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_len, (void*)d->cls_off, (void*)d->ent_vocab,
-                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->rows})
+                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->rows})
     if (p) (void)hipFree(p);
   delete d;
 }
 
-static int scan_cpl(int nplanes) { return nplanes <= 8 ? 4 : nplanes <= 16 ? 2 : 1; }
 
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
                     const anx_params& p, std::string& err, int* code) {
@@ -704,7 +756,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     b->order[i] = enc[i].orig;
   }
   // tiles + work list
-  const uint32_t TQ = 256, CPB = 256u * (uint32_t)scan_cpl(NP);
+  const uint32_t TQ = SCAN_TQ;
   for (size_t i = 0; i < nq;) {
     size_t j = i;
     while (j < nq && (h_meta[j] & 0xFFFF) == (h_meta[i] & 0xFFFF)) ++j;
@@ -713,9 +765,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     const uint32_t c0 = m.lex.bucket_begin[lo], c1 = m.lex.bucket_begin[hi + 1];
     for (size_t s = i; s < j; s += TQ) {
       Tile t{(uint32_t)s, (uint32_t)std::min<size_t>(TQ, j - s), c0, c1, k, lq};
-      const uint32_t ti = (uint32_t)b->tiles.size();
       b->tiles.push_back(t);
-      for (uint32_t cb = c0; cb < c1; cb += CPB) b->work.push_back(Work{ti, cb});
       b->n_class_tests += (uint64_t)t.nq * (c1 - c0);
     }
     i = j;
@@ -724,7 +774,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   int rc;
   if ((rc = up(&b->q_cv, h_cv.data(), h_cv.size())) || (rc = up(reinterpret_cast<uint8_t**>(&b->q_rows), h_rows.data(), h_rows.size())) ||
       (rc = up(&b->q_meta, h_meta.data(), nq)) || (rc = up(&b->q_orig, h_orig.data(), nq)) ||
-      (rc = up(&b->d_tiles, b->tiles.data(), b->tiles.size())) || (rc = up(&b->d_work, b->work.data(), b->work.size()))) {
+      (rc = up(&b->d_tiles, b->tiles.data(), b->tiles.size()))) {
     *code = rc;
     batch_free(b);
     return nullptr;
@@ -743,7 +793,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     batch_free(b);
     return nullptr;
   }
-  b->raw_cap = nq * 192 + (1u << 16);
+  b->raw_cap = nq * 192 + (size_t)b->tiles.size() * 4 * SCAN_CHUNK + (1u << 16);
   if ((rc = dalloc(&b->raw, b->raw_cap))) { *code = rc; batch_free(b); return nullptr; }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
@@ -752,8 +802,8 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
 
 template <int NP, int CPL>
 static void launch_scan(const DeviceLexicon* dl, Batch* b, hipStream_t st) {
-  hipLaunchKernelGGL((k_anagram_scan<NP, CPL>), dim3((uint32_t)b->work.size()), dim3(256), 0, st, b->d_tiles,
-                     b->d_work, b->q_cv, dl->cls_planes, dl->cstride, dl->cls_len, dl->cls_off, b->raw,
+  hipLaunchKernelGGL((k_anagram_scan<NP, CPL>), dim3((uint32_t)b->tiles.size()), dim3(256), 0, st, b->d_tiles,
+                     b->q_cv, dl->cls_planes, dl->cstride, dl->cls_len, dl->cls_off, b->raw,
                      (uint32_t)std::min<size_t>(b->raw_cap, 0xFFFFFFFFu), b->counters, b->qcount, b->qexact);
 }
 
@@ -789,11 +839,9 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   HIP_TRY(hipEventRecord(b->ev[0], st));
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(b->qcount, 0, nq * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(b->qexact, 0, nq * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(b->qcur, 0, nq * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
-    if (!b->work.empty()) {
+    if (!b->tiles.empty()) {
       switch (dl->nplanes) {
         case 8: launch_scan<8, 4>(dl, b, st); break;
         case 16: launch_scan<16, 2>(dl, b, st); break;
@@ -812,7 +860,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     if (attempt == 1) { err = "pair list overflow after regrow"; return ANX_ENODEVICE; }
     (void)hipFree(b->raw);
     b->raw = nullptr;
-    b->raw_cap = (size_t)h_counters[CTR_RAW] + 1024;
+    b->raw_cap = (size_t)h_counters[CTR_RAW] + (size_t)b->tiles.size() * 4 * SCAN_CHUNK + 1024;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->raw), b->raw_cap * sizeof(uint2)));
   }
   const uint32_t nraw = h_counters[CTR_RAW];
@@ -866,7 +914,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
   hipLaunchKernelGGL(k_rank, dim3((nq + 3) / 4), dim3(256), 0, st, nq, b->qoff, b->pair_e, b->p_score, dl->ent_freq,
-                     b->qmaxfreq, ra, b->t_key, b->t_pos, b->r_entry, b->r_dist, b->r_freq, b->r_count);
+                     dl->ent_order, b->qmaxfreq, ra, b->t_key, b->t_pos, b->r_entry, b->r_dist, b->r_freq, b->r_count);
   exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
   HIP_TRY(hipEventRecord(b->ev[4], st));
   uint32_t total_results = 0;
@@ -880,7 +928,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   s.n_pairs = P;
   s.n_class_tests = b->n_class_tests;
   s.n_results = total_results;
-  s.n_scan_blocks = b->work.size();
+  s.n_scan_blocks = b->tiles.size();
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.ms_group, b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&s.ms_score, b->ev[2], b->ev[3]);
@@ -983,7 +1031,7 @@ void batch_free(Batch* b) {
   (void)hipSetDevice(b->device);
   free_pair_buffers(b);
   for (void* p : {(void*)b->q_cv, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles,
-                  (void*)b->d_work, (void*)b->counters, (void*)b->qcount, (void*)b->qexact, (void*)b->qoff,
+                  (void*)b->counters, (void*)b->qcount, (void*)b->qexact, (void*)b->qoff,
                   (void*)b->qcur, (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->r_count,
                   (void*)b->r_off})
     if (p) (void)hipFree(p);

@@ -372,6 +372,15 @@ int HostModel::build_index(std::string& err) {
     }
   }
   lex.cls_off[lex.nclasses] = lex.nentries;
+  {  // global enumeration order of entries: classes by numeric anagram value, regardless of charcount
+    std::vector<uint32_t> byval(lex.nclasses);
+    std::iota(byval.begin(), byval.end(), 0u);
+    std::sort(byval.begin(), byval.end(), [&](uint32_t a, uint32_t b) { return lex.cls_value[a].cmp(lex.cls_value[b]) < 0; });
+    lex.ent_order.assign(lex.nentries, 0);
+    uint32_t pos = 0;
+    for (uint32_t r : byval)
+      for (uint32_t e = lex.cls_off[r]; e < lex.cls_off[r + 1]; ++e) lex.ent_order[e] = pos++;
+  }
   for (int c = 0; c <= kMaxSymbols; ++c) lex.bucket_begin[c + 1] += lex.bucket_begin[c];
   built = true;
   return ANX_OK;

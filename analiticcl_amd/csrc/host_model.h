@@ -68,6 +68,9 @@ struct LexiconImage {
   std::vector<uint32_t> ent_freq;
   std::vector<uint32_t> ent_meta;       // len | first_is_lower<<8
   std::vector<uint32_t> ent_rowoff;     // offset of the token row in 16-byte units
+  std::vector<uint32_t> ent_order;      // position in the reference's enumeration order: classes by ascending
+                                        // anagram value over ALL charcounts (BTreeSet<&AnaValue>, src/lib.rs:1148),
+                                        // then vocab id (src/lib.rs:1327-1332); last key of the ranking order
   std::vector<uint8_t> rows;            // token rows padded to 16-byte multiples with 0xFF
   std::vector<BigVal> cls_value;        // anagram value per class (host only)
 };

@@ -131,13 +131,20 @@ def main():
         # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
         cpu = None
         ncores = os.cpu_count() or 1
-        sample = args.cpu_sample if args.cpu_sample >= 0 else min(args.queries, 2500 * ncores)
-        if sample > 0:
+        if args.cpu_sample != 0:
             from oracle import cwrap as O
             om = O.OracleModel(alphabet_path=paths["alphabet"])
             om.read_lexicon(paths[args.lexicon])
             om.build()
             op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
+            if args.cpu_sample > 0:
+                sample = min(args.cpu_sample, args.queries)
+            else:  # calibrate on a short run, then size the sample for ~15 s of wall time
+                ncal = min(args.queries, 16 * ncores)
+                t = time.perf_counter()
+                om.find_variants_batch(queries[:ncal], op, nthreads=ncores, stride=16)
+                rate = ncal / max(time.perf_counter() - t, 1e-3)
+                sample = int(max(ncal, min(args.queries, rate * 15.0)))
             t = time.perf_counter()
             rc, _res, _counts, cpairs, _ccls = om.find_variants_batch(queries[:sample], op, nthreads=ncores, stride=16)
             dt = time.perf_counter() - t
