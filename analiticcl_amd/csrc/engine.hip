@@ -1,15 +1,16 @@
 // engine.hip -- the HIP (gfx950 / CDNA4) variant-query pipeline of the anx engine.
 //
 // Replaces, for a whole batch of queries at once, the reference's
-//   find_nearest_anahashes  (/root/reference/src/lib.rs:1143-1308)  -> k_anagram_scan
-//   gather_instances        (src/lib.rs:1311-1402, src/distance.rs)  -> k_group_pairs + k_score_pairs
-//   score_and_rank          (src/lib.rs:1405-1653, src/types.rs:334-365) -> k_score_pairs + k_rank
+//   find_nearest_anahashes  (/root/reference/src/lib.rs:1143-1308)  -> k_scan_bits / k_scan_sad
+//   gather_instances        (src/lib.rs:1311-1402, src/distance.rs)  -> k_score_pairs
+//   score_and_rank          (src/lib.rs:1405-1653, src/types.rs:334-365) -> k_score_pairs + k_compact + k_rank
 // Integer work only: no MFMA.  Wave = 64 lanes everywhere.  See DESIGN.md for layout and rooflines.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <type_traits>
@@ -30,19 +31,33 @@ namespace anx {
 // ------------------------------------------------------------------------------------------------
 // Device structures
 // ------------------------------------------------------------------------------------------------
-struct Tile {           // TQ queries of one length against the +-k charcount window of classes
-  uint32_t q0, nq;      // query range (queries are sorted by length)
+struct Tile {           // <= SCAN_TQ queries of one length / one multiplicity class against the +-k window
+  uint32_t q0, nq;      // query range (queries are sorted by (kernel kind, length))
   uint32_t c0, c1;      // class-rank range [c0, c1)
   uint32_t k;           // clamped anagram distance for this length
   uint32_t lq;          // query length in symbols
 };
 
+struct Work {           // one workgroup of k_scan: a tile against a segment of its class window
+  uint32_t tile, cbeg, cend, kind;  // kind 0 = SAD body, 1..NBITPLANES = bit-plane body with T = kind
+};
+
+constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
+constexpr uint32_t SCAN_TQ = 256;        // queries per tile (= per workgroup)
+constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
+constexpr uint32_t SCAN_QCAP = 512;      // deferred-hit queue entries per wave (LDS)
+constexpr uint32_t SCAN_SEG_CHUNKS = 8;  // class chunks (of 256*CPL classes) per work item
+constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t META_SKIPPED = 0xFFFFFFFFu;
+
 struct DeviceLexicon {
   int device = 0;
-  int nplanes = 0;
+  int nplanes = 0;      // count-vector dwords (SAD path)
+  int nsym = 0;
   uint32_t nclasses = 0, nentries = 0, cstride = 0, max_len = 0;
-  uint32_t* cls_planes = nullptr;
-  uint8_t* cls_len = nullptr;
+  uint32_t* cls_planes = nullptr;  // [nplanes][cstride] packed u8 counts
+  uint32_t* cls_bits = nullptr;    // [NBITPLANES][cstride] thermometer planes (bit s of plane t: count_s > t), nsym <= 32
+  uint8_t* cls_len = nullptr;      // [cstride]
   uint32_t* cls_off = nullptr;
   uint32_t* ent_vocab = nullptr;
   uint32_t* ent_freq = nullptr;
@@ -53,7 +68,7 @@ struct DeviceLexicon {
   size_t bytes = 0;
 };
 
-enum { CTR_RAW = 0, CTR_TESTS_LO = 1, CTR_TESTS_HI = 2, CTR_RESULTS = 3, CTR_N = 8 };
+enum { CTR_RAW = 0, CTR_VALID = 1, CTR_SKIPPED = 2, CTR_N = 8 };
 
 struct Batch {
   int device = 0;
@@ -64,42 +79,47 @@ struct Batch {
   std::vector<int32_t> status;     // per original query: 0 ok, ANX_EEMPTY, ANX_ELIMIT
   size_t n_input = 0;
   std::vector<Tile> tiles;
+  std::vector<Work> work;
   uint32_t qw = 1;                 // uint4 words per query row
   uint32_t dmax = 0;
   uint64_t n_class_tests = 0;
   // device: queries
   uint32_t* q_cv = nullptr;        // [nq][nplanes]
+  uint32_t* q_bits = nullptr;      // [nq][NBITPLANES]
   uint4* q_rows = nullptr;         // [nq][qw]
   uint32_t* q_meta = nullptr;      // len | k<<8 | d<<16 | first_is_lower<<24
   uint32_t* q_orig = nullptr;      // original index
   Tile* d_tiles = nullptr;
+  Work* d_work = nullptr;
   // device: pipeline
   uint32_t* counters = nullptr;
-  uint32_t* qcount = nullptr;
-  uint32_t* qexact = nullptr;
-  uint32_t* qoff = nullptr;        // nq+1
+  uint32_t* qexact = nullptr;      // per query: an exact-anagram class exists (StopAtExactMatch)
+  uint32_t* qsurv = nullptr;       // per query: pairs with score >= threshold
+  uint32_t* soff = nullptr;        // nq+1, exclusive scan of qsurv
   uint32_t* qcur = nullptr;
   uint32_t* qmaxfreq = nullptr;
   uint32_t* scan_tmp = nullptr;
-  uint2* raw = nullptr;
-  size_t raw_cap = 0;
-  uint32_t* pair_q = nullptr;
-  uint32_t* pair_e = nullptr;
-  double* p_score = nullptr;
+  uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
+  double* p_score = nullptr;       // per raw slot
   uint32_t* p_meta = nullptr;
-  uint32_t* r_entry = nullptr;
+  size_t raw_cap = 0;
+  uint32_t* c_entry = nullptr;     // survivors grouped by query
+  double* c_score = nullptr;
+  uint32_t* r_entry = nullptr;     // ranked
   double* r_dist = nullptr;
   double* r_freq = nullptr;
   double* t_key = nullptr;
-  uint32_t* t_pos = nullptr;
+  size_t surv_cap = 0;
   uint32_t* r_count = nullptr;
   uint32_t* r_off = nullptr;       // nq+1
-  size_t pair_cap = 0;
-  uint64_t n_pairs = 0, n_results = 0;
+  uint32_t n_raw = 0;
+  uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
   bool ran = false;
   hipEvent_t ev[6] = {};
   anx_batch_stats stats = {};
 };
+
+typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant address space: s_load
 
 // ------------------------------------------------------------------------------------------------
 // K1: anagram window scan.
@@ -107,38 +127,197 @@ struct Batch {
 //     { class c : L1(cv_q, cv_c) <= k, |len_c - len_q| <= k, cv_q and cv_c share a symbol }
 //   (the bigint `cand % av == 0` containment test of src/anahash.rs:165-171 is
 //   multiset inclusion, i.e. a statement about the prime-exponent = count vectors).
-//   Each lane keeps CPL classes' count vectors in VGPRs (coalesced plane loads); the tile's queries are
-//   streamed through SGPRs (wave-uniform scalar loads), 4 symbols per v_sad_u8.
+//   One workgroup owns one query tile and streams every class chunk of the tile's charcount window past
+//   it.  Each wave appends its hits to wave-private 1024-slot chunks of the flat pair list, reserved with
+//   ONE global atomic per chunk (a single contended counter word sustains only ~88 M atomics/s).
 // ------------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant address space: s_load
+struct WaveOut {
+  uint32_t base, left;  // current chunk of the pair list (wave-uniform)
+  uint32_t emitted;     // pairs appended by this wave (wave-uniform)
+};
+// Wave-wide exclusive prefix sum of ntot + chunk reservation.  Returns this lane's first slot.
+__device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane, uint2* __restrict__ raw,
+                                        uint32_t raw_cap, uint32_t* __restrict__ counters, bool* have) {
+  uint32_t incl = ntot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(incl, o);
+    if (lane >= (uint32_t)o) incl += u;
+  }
+  const uint32_t total = __shfl(incl, 63);
+  *have = total != 0;
+  if (total == 0) return 0;
+  if (total > w.left) {  // close the current chunk (mark its tail invalid), reserve a new one
+    for (uint32_t i = lane; i < w.left; i += 64)
+      if (w.base + i < raw_cap) raw[w.base + i] = make_uint2(RAW_INVALID, 0u);
+    const uint32_t need = total > SCAN_CHUNK ? total : SCAN_CHUNK;
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(&counters[CTR_RAW], need);
+    w.base = __shfl(b, 0);
+    w.left = need;
+  }
+  const uint32_t pos = w.base + incl - ntot;
+  w.base += total;
+  w.left -= total;
+  w.emitted += total;
+  return pos;
+}
+__device__ inline void wave_close(const WaveOut& w, uint32_t lane, uint2* __restrict__ raw, uint32_t raw_cap,
+                                  uint32_t* __restrict__ counters) {
+  for (uint32_t i = lane; i < w.left; i += 64)
+    if (w.base + i < raw_cap) raw[w.base + i] = make_uint2(RAW_INVALID, 0u);
+  if (lane == 0 && w.emitted) atomicAdd(&counters[CTR_VALID], w.emitted);  // one atomic per wave
+}
 
-constexpr uint32_t SCAN_TQ = 256;       // queries per tile (= per workgroup)
-constexpr uint32_t SCAN_CHUNK = 1024;   // pair slots a wave reserves per global atomic
-constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
+// ---- K1a: thermometer bit planes.  common(q,c) = sum_t popc(Q_t & C_t) is exact when every symbol of the
+// query occurs at most T times (min(a,b) only needs a's planes; class planes saturate at NBITPLANES).
+// L1 = len_q + len_c - 2 common, so  hit <=> common >= max(1, ceil((len_q + len_c - k) / 2)).
+// 2 ops per plane (v_and_b32 full rate + v_bcnt_u32_b32 accumulating) instead of 8 half-rate v_sad_u8.
+// Hits (~0.1 % of tests) are only queued in LDS inside the hot loop and expanded 64 at a time.
+struct ScanArgs {
+  const Tile* tiles;
+  const Work* work;
+  const uint32_t* q_bits;
+  const uint32_t* q_cv;
+  const uint32_t* cls_bits;
+  const uint32_t* cls_planes;
+  uint32_t cstride;
+  const uint8_t* cls_len;
+  const uint32_t* cls_off;
+  uint2* raw;
+  uint32_t raw_cap;
+  uint32_t* counters;
+  uint32_t* qexact;
+  int want_exact;
+};
 
-// One workgroup owns one query tile and streams every class chunk of the tile's charcount window past it.
-// Per-query pair counts live in LDS (no global atomics); each wave appends its hits to wave-private
-// 1024-slot chunks of the flat pair list, reserved with ONE global atomic per chunk (a single contended
-// counter word sustains only ~88 M atomics/s on this chip, MI355X_MICROARCH.md "dequeue").
+__device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount(x) in one v_bcnt_u32_b32
+  int32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
+template <int T, int CPL>
+__device__ inline void scan_bits_body(const ScanArgs& A, const Tile& t, uint32_t cbeg, uint32_t cend,
+                                      uint32_t* __restrict__ queue /* this wave's LDS queue */) {
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t* __restrict__ q_bits = A.q_bits;
+  const uint32_t* __restrict__ cls_bits = A.cls_bits;
+  const uint8_t* __restrict__ cls_len = A.cls_len;
+  const uint32_t* __restrict__ cls_off = A.cls_off;
+  uint2* __restrict__ raw = A.raw;
+  const uint32_t cstride = A.cstride, raw_cap = A.raw_cap;
+  WaveOut wo{0, 0, 0};
+  uint32_t qn = 0;  // queued hits of this wave (wave-uniform)
+  const int32_t lqk = (int32_t)t.lq - (int32_t)t.k;
+  cptr_u32 qbase = (cptr_u32)(q_bits + (size_t)t.q0 * NBITPLANES);
+
+  // expands queued (query, lane, chunk) hits: recompute the few class tests of that lane, emit pairs
+  auto drain = [&]() {
+    for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
+      const uint32_t idx = r0 + lane;
+      uint32_t e0[CPL], n[CPL], ntot = 0, exmask = 0, qi = 0;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) { e0[j] = 0; n[j] = 0; }
+      if (idx < qn) {
+        const uint32_t ent = queue[idx];
+        qi = ent & 0xFF;
+        const uint32_t ln = (ent >> 8) & 63, ch = ent >> 14;
+        const uint32_t cb = t.c0 + ch * (256 * CPL) + wid * 64 + ln;
+        uint32_t qb[T];
+#pragma unroll
+        for (int p = 0; p < T; ++p) qb[p] = q_bits[(size_t)(t.q0 + qi) * NBITPLANES + p];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const uint32_t c = cb + j * 256;
+          int32_t common = 0;
+#pragma unroll
+          for (int p = 0; p < T; ++p) common += __popc(qb[p] & cls_bits[(size_t)p * cstride + c]);
+          const int32_t l1 = (int32_t)t.lq + (int32_t)cls_len[c] - 2 * common;
+          if (l1 <= (int32_t)t.k && common >= 1) {  // common >= 1: shares a symbol (src/iterators.rs:177)
+            e0[j] = cls_off[c];
+            n[j] = cls_off[c + 1] - e0[j];
+            ntot += n[j];
+            if (l1 == 0) exmask |= 1u << j;
+          }
+        }
+      }
+      bool have;
+      uint32_t pos = wave_reserve(wo, ntot, lane, raw, raw_cap, A.counters, &have);
+      if (have && ntot) {
+        const uint32_t q = t.q0 + qi;
+        if (A.want_exact && exmask) A.qexact[q] = 1;  // benign race: every writer stores 1
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const uint32_t exact = (exmask >> j) & 1u ? 0x80000000u : 0u;
+          for (uint32_t i = 0; i < n[j]; ++i, ++pos)
+            if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
+        }
+      }
+    }
+    qn = 0;
+  };
+
+  uint32_t chunk = (cbeg - t.c0) / (256 * CPL);
+  for (uint32_t cb = cbeg; cb < cend; cb += 256 * CPL, ++chunk) {
+    // Unguarded loads: the class arrays are padded by never-matching classes (bits 0, len 255), and real
+    // classes beyond c1 lie outside the +-k charcount window, so they can never satisfy L1 <= k.
+    uint32_t cp[CPL][T];
+    int32_t negthr[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const uint32_t c = cb + j * 256 + threadIdx.x;
+#pragma unroll
+      for (int p = 0; p < T; ++p) cp[j][p] = cls_bits[(size_t)p * cstride + c];
+      const int32_t need = (lqk + (int32_t)cls_len[c] + 1) >> 1;  // ceil((lq + lc - k) / 2)
+      negthr[j] = -(need < 1 ? 1 : need);
+    }
+    uint32_t qnext[T];
+#pragma unroll
+    for (int p = 0; p < T; ++p) qnext[p] = qbase[p];
+    for (uint32_t qi = 0; qi < t.nq; ++qi) {
+      uint32_t qreg[T];
+#pragma unroll
+      for (int p = 0; p < T; ++p) qreg[p] = qnext[p];
+      // prefetch the next query's planes into SGPRs while this one is compared
+      cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * NBITPLANES;
+#pragma unroll
+      for (int p = 0; p < T; ++p) qnext[p] = qv[p];
+      int32_t best = negthr[0];
+#pragma unroll
+      for (int p = 0; p < T; ++p) best = bcnt_acc(qreg[p] & cp[0][p], best);
+#pragma unroll
+      for (int j = 1; j < CPL; ++j) {
+        int32_t acc = negthr[j];
+#pragma unroll
+        for (int p = 0; p < T; ++p) acc = bcnt_acc(qreg[p] & cp[j][p], acc);
+        best = max(best, acc);
+      }
+      const unsigned long long hitmask = __ballot(best >= 0);
+      if (hitmask) {  // wave-uniform
+        if (best >= 0) queue[qn + __popcll(hitmask & ((1ull << lane) - 1ull))] = qi | (lane << 8) | (chunk << 14);
+        qn += __popcll(hitmask);
+        if (qn > SCAN_QCAP - 64) drain();
+      }
+    }
+  }
+  drain();
+  wave_close(wo, lane, raw, raw_cap, A.counters);
+}
+
+// ---- K1b: general path (any alphabet size / any multiplicity): packed u8 count vectors, v_sad_u8.
 template <int NP, int CPL>
-__global__ __launch_bounds__(256) void k_anagram_scan(const Tile* __restrict__ tiles,
-                                                      const uint32_t* __restrict__ q_cv,
-                                                      const uint32_t* __restrict__ planes, uint32_t cstride,
-                                                      const uint8_t* __restrict__ cls_len,
-                                                      const uint32_t* __restrict__ cls_off, uint2* __restrict__ raw,
-                                                      uint32_t raw_cap, uint32_t* __restrict__ counters,
-                                                      uint32_t* __restrict__ qcount, uint32_t* __restrict__ qexact) {
-  __shared__ uint32_t s_cnt[SCAN_TQ], s_exact[SCAN_TQ];
-  const Tile t = tiles[blockIdx.x];
+__device__ inline void scan_sad_body(const ScanArgs& A, const Tile& t, uint32_t cbeg, uint32_t cend) {
   const uint32_t lane = threadIdx.x & 63;
-  for (uint32_t i = threadIdx.x; i < SCAN_TQ; i += 256) { s_cnt[i] = 0; s_exact[i] = 0; }
-  __syncthreads();
-  uint32_t w_base = 0, w_left = 0;  // this wave's current chunk of the pair list (wave-uniform)
+  const uint32_t* __restrict__ planes = A.cls_planes;
+  const uint8_t* __restrict__ cls_len = A.cls_len;
+  const uint32_t* __restrict__ cls_off = A.cls_off;
+  uint2* __restrict__ raw = A.raw;
+  const uint32_t cstride = A.cstride, raw_cap = A.raw_cap;
+  WaveOut wo{0, 0, 0};
   const uint32_t k = t.k;
-  cptr_u32 qbase = (cptr_u32)(q_cv + (size_t)t.q0 * NP);
-  for (uint32_t cb = t.c0; cb < t.c1; cb += 256 * CPL) {
-    // Unguarded loads: the plane arrays are padded by a full chunk of 0xFF classes, and real classes
-    // beyond c1 lie outside the +-k charcount window, so they can never satisfy L1 <= k.
+  cptr_u32 qbase = (cptr_u32)(A.q_cv + (size_t)t.q0 * NP);
+  for (uint32_t cb = cbeg; cb < cend; cb += 256 * CPL) {
     uint32_t cv[CPL][NP];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -153,7 +332,6 @@ __global__ __launch_bounds__(256) void k_anagram_scan(const Tile* __restrict__ t
       uint32_t qreg[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) qreg[p] = qnext[p];
-      // prefetch the next query's count vector into SGPRs while this one is compared
       cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * NP;
 #pragma unroll
       for (int p = 0; p < NP; ++p) qnext[p] = qv[p];
@@ -167,73 +345,59 @@ __global__ __launch_bounds__(256) void k_anagram_scan(const Tile* __restrict__ t
         dist[j] = acc;
         any |= acc <= k;
       }
-      if (__ballot(any) != 0ull) {  // wave-uniform; ~0.1 % of class tests hit
-        uint32_t e0[CPL], n[CPL], ntot = 0, nex = 0;
+      if (__ballot(any) != 0ull) {  // wave-uniform
+        uint32_t e0[CPL], n[CPL], ntot = 0, exmask = 0;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           n[j] = 0;
           e0[j] = 0;
           if (dist[j] <= k) {
             const uint32_t c = cb + j * 256 + threadIdx.x;
-            // shares at least one symbol <=> L1 < len_q + len_c (deleting all of q is never enumerated:
-            // RecurseDeletionIterator with empty_leaves=false, src/iterators.rs:177, src/lib.rs:1205)
+            // shares at least one symbol <=> L1 < len_q + len_c (src/iterators.rs:177, src/lib.rs:1205)
             if (dist[j] < t.lq + (uint32_t)cls_len[c]) {
               e0[j] = cls_off[c];
               n[j] = cls_off[c + 1] - e0[j];
               ntot += n[j];
-              if (dist[j] == 0) nex += n[j];
+              if (dist[j] == 0) exmask |= 1u << j;
             }
           }
         }
-        // wave-wide exclusive prefix sum of the per-lane pair counts
-        uint32_t incl = ntot;
+        bool have;
+        uint32_t pos = wave_reserve(wo, ntot, lane, raw, raw_cap, A.counters, &have);
+        if (have && ntot) {
+          const uint32_t q = t.q0 + qi;
+          if (A.want_exact && exmask) A.qexact[q] = 1;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint32_t u = __shfl_up(incl, o);
-          if (lane >= (uint32_t)o) incl += u;
-        }
-        const uint32_t total = __shfl(incl, 63);
-        if (total) {
-          if (total > w_left) {  // wave-uniform: close the current chunk, reserve a new one
-            for (uint32_t i = lane; i < w_left; i += 64)
-              if (w_base + i < raw_cap) raw[w_base + i] = make_uint2(RAW_INVALID, 0u);
-            const uint32_t need = total > SCAN_CHUNK ? total : SCAN_CHUNK;
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&counters[CTR_RAW], need);
-            w_base = __shfl(b, 0);
-            w_left = need;
+          for (int j = 0; j < CPL; ++j) {
+            const uint32_t exact = (exmask >> j) & 1u ? 0x80000000u : 0u;
+            for (uint32_t i = 0; i < n[j]; ++i, ++pos)
+              if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
           }
-          if (ntot) {
-            const uint32_t q = t.q0 + qi;
-            atomicAdd(&s_cnt[qi], ntot);
-            if (nex) atomicAdd(&s_exact[qi], nex);
-            uint32_t pos = w_base + incl - ntot;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-              const uint32_t exact = dist[j] == 0 ? 0x80000000u : 0u;
-              for (uint32_t i = 0; i < n[j]; ++i, ++pos)
-                if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
-            }
-          }
-          w_base += total;
-          w_left -= total;
         }
       }
     }
   }
-  for (uint32_t i = lane; i < w_left; i += 64)
-    if (w_base + i < raw_cap) raw[w_base + i] = make_uint2(RAW_INVALID, 0u);
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < t.nq; i += 256) {
-    qcount[t.q0 + i] = s_cnt[i];
-    qexact[t.q0 + i] = s_exact[i];
-  }
+  wave_close(wo, lane, raw, raw_cap, A.counters);
 }
 
-// StopCriterion::StopAtExactMatch (src/lib.rs:1164-1173): only the exact class survives.
-__global__ void k_stop_fixup(uint32_t n, uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qexact) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && qexact[i] > 0) qcount[i] = qexact[i];
+constexpr int BITS_CPL[NBITPLANES + 1] = {0, 8, 8, 6, 4};  // classes per lane of the T-plane variants
+template <int NP> struct SadCpl { static constexpr int v = NP <= 8 ? 4 : NP <= 16 ? 2 : 1; };
+
+// One launch for the whole batch: every workgroup takes one (tile, class segment) work item; the item's
+// kind (wave-uniform, workgroup-uniform) selects the comparison body.  Items are ordered by decreasing cost.
+template <int NP>
+__global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
+  __shared__ uint32_t s_queue[4][SCAN_QCAP];
+  const Work w = A.work[blockIdx.x];
+  const Tile t = A.tiles[w.tile];
+  uint32_t* queue = s_queue[threadIdx.x >> 6];
+  switch (w.kind) {
+    case 1: scan_bits_body<1, BITS_CPL[1]>(A, t, w.cbeg, w.cend, queue); break;
+    case 2: scan_bits_body<2, BITS_CPL[2]>(A, t, w.cbeg, w.cend, queue); break;
+    case 3: scan_bits_body<3, BITS_CPL[3]>(A, t, w.cbeg, w.cend, queue); break;
+    case 4: scan_bits_body<4, BITS_CPL[4]>(A, t, w.cbeg, w.cend, queue); break;
+    default: scan_sad_body<NP, SadCpl<NP>::v>(A, t, w.cbeg, w.cend); break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,27 +467,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: group the flat pair list by query (counting-sort scatter).  Order inside a query is arbitrary;
-// ranking uses a total order whose last key is ent_order (= reference enumeration order).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_group_pairs(const uint2* __restrict__ raw, uint32_t nraw,
-                                                     const uint32_t* __restrict__ qoff,
-                                                     const uint32_t* __restrict__ qexact, int stop,
-                                                     uint32_t* __restrict__ qcur, uint32_t* __restrict__ pair_q,
-                                                     uint32_t* __restrict__ pair_e) {
-  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= nraw) return;
-  const uint2 v = raw[r];
-  const uint32_t q = v.x;
-  if (q == RAW_INVALID) return;  // unused tail of a wave's chunk
-  if (stop && qexact[q] > 0 && !(v.y & 0x80000000u)) return;
-  const uint32_t pos = qoff[q] + atomicAdd(&qcur[q], 1u);
-  pair_q[pos] = q;
-  pair_e[pos] = v.y & 0x7FFFFFFFu;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3: score one (query, candidate) pair per lane.
+// K3: score one (query, candidate) pair per lane, straight off the flat pair list.
 //   damerau_levenshtein (src/distance.rs:101-179) in its band-limited saturating form:
 //   cells with |i-j| > d are d+1, every value saturates at d+1, the transposition term only looks back
 //   d rows / d columns (farther ones cost > d).  Identical to the reference for every outcome <= d.
@@ -333,146 +477,177 @@ __global__ __launch_bounds__(256) void k_group_pairs(const uint2* __restrict__ r
 // ------------------------------------------------------------------------------------------------
 struct ScoreArgs {
   double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
-  int have_freq;
+  double score_threshold;
+  int have_freq, stop;
   uint32_t lqp, lcp;   // bytes reserved per lane for the query / candidate row (multiples of 16)
   uint32_t stride;     // bytes per lane (odd number of dwords: conflict-free ds access)
   uint32_t qw;
 };
 #define PAIR_NONE 0x7Fu
 
-__global__ void k_score_pairs(uint32_t P, const uint32_t* __restrict__ pair_q, const uint32_t* __restrict__ pair_e,
+__global__ void k_score_pairs(uint32_t nraw, const uint2* __restrict__ raw, const uint32_t* __restrict__ qexact,
                               const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
                               const uint32_t* __restrict__ ent_meta, const uint32_t* __restrict__ ent_rowoff,
                               const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
                               double* __restrict__ p_score, uint32_t* __restrict__ p_meta,
-                              uint32_t* __restrict__ qmaxfreq) {
+                              uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv,
+                              uint32_t* __restrict__ counters) {
   extern __shared__ uint32_t lds32[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  uint8_t* S = reinterpret_cast<uint8_t*>(lds32) + (size_t)threadIdx.x * a.stride;
-  uint8_t* T = S + a.lqp;
-  uint8_t* R = T + a.lcp;
-  const uint32_t q = pair_q[p], e = pair_e[p];
-  const uint32_t qm = q_meta[q], em = ent_meta[e];
-  const int lq = qm & 0xFF, d = (qm >> 16) & 0xFF, lc = em & 0xFF;
-  const int diff = lq > lc ? lq - lc : lc - lq;
-  uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0;
-  uint32_t samecase = 1;
-  double score = __builtin_nan("");
-  if (diff <= d) {  // src/distance.rs:109-130 (both lengths > 0 here)
-    {
-      uint32_t* S32 = reinterpret_cast<uint32_t*>(S);
-      const uint4* qr = q_rows + (size_t)q * a.qw;
-      for (int wq = 0; wq * 16 < lq; ++wq) {
-        const uint4 v = qr[wq];
-        S32[wq * 4 + 0] = v.x; S32[wq * 4 + 1] = v.y; S32[wq * 4 + 2] = v.z; S32[wq * 4 + 3] = v.w;
-      }
-      uint32_t* T32 = reinterpret_cast<uint32_t*>(T);
-      const uint4* cr = rows + ent_rowoff[e];
-      for (int wc = 0; wc * 16 < lc; ++wc) {
-        const uint4 v = cr[wc];
-        T32[wc * 4 + 0] = v.x; T32[wc * 4 + 1] = v.y; T32[wc * 4 + 2] = v.z; T32[wc * 4 + 3] = v.w;
-      }
-    }
-    // ---- banded unrestricted Damerau-Levenshtein --------------------------------------------------
-    const int cap = d + 1, W = 2 * d + 3, NR = d + 2;
-    // row i is stored at R[(i % NR) * W + col], col = j - i + d + 1 in [1, 2d+1]; cols 0 and 2d+2 are guards
-    for (int col = 0; col < W; ++col) {
-      const int j = col - d - 1;
-      R[col] = (uint8_t)((j >= 0 && j <= lc && col >= 1 && col <= 2 * d + 1) ? (j < cap ? j : cap) : cap);
-    }
-    for (int i = 1; i <= lq; ++i) {
-      uint8_t* cur = R + (i % NR) * W;
-      const uint8_t* prev = R + ((i - 1) % NR) * W;
-      const uint32_t sc = S[i - 1];
-      int db = 0;
-      cur[0] = (uint8_t)cap;
-      for (int col = 1; col <= 2 * d + 1; ++col) {
-        const int j = i + col - d - 1;
-        uint32_t v;
-        if (j < 0 || j > lc) v = cap;
-        else if (j == 0) v = i < cap ? i : cap;
-        else {
-          const uint32_t tc = T[j - 1];
-          const uint32_t cost = sc != tc;
-          v = min(min((uint32_t)cur[col - 1] + 1u, (uint32_t)prev[col + 1] + 1u), (uint32_t)prev[col] + cost);
-          if (db > 0) {
-            // l = last row i' < i with s[i'-1] == t[j-1] (char_map, src/distance.rs:146,154,170), looking
-            // back at most d rows: farther rows make the term exceed d
-            for (int back = 0; back < d; ++back) {
-              const int l = i - 1 - back;
-              if (l < 1) break;
-              if (S[l - 1] == tc) {
-                const int colx = db - l + d + 1;  // column of D[l-1][db-1] in row l-1
-                if (colx >= 1 && colx <= 2 * d + 1) {
-                  const uint32_t tv = (uint32_t)R[((l - 1) % NR) * W + colx] + (uint32_t)(i - l - 1) + 1u +
-                                      (uint32_t)(j - db - 1);  // src/distance.rs:161
-                  v = min(v, tv);
+  bool stop_skipped = false;
+  if (p < nraw) {
+    const uint2 rp = raw[p];
+    const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+    // unused chunk tail, or (StopAtExactMatch, src/lib.rs:1164-1173) a non-exact class of a query that has one
+    const bool skip = q == RAW_INVALID || (a.stop && !(rp.y & 0x80000000u) && qexact[q] != 0);
+    uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
+    double score = __builtin_nan("");
+    stop_skipped = skip && q != RAW_INVALID;
+    if (!skip) {
+      uint8_t* S = reinterpret_cast<uint8_t*>(lds32) + (size_t)threadIdx.x * a.stride;
+      uint8_t* T = S + a.lqp;
+      uint8_t* R = T + a.lcp;
+      const uint32_t qm = q_meta[q], em = ent_meta[e];
+      const int lq = qm & 0xFF, d = (qm >> 16) & 0xFF, lc = em & 0xFF;
+      const int diff = lq > lc ? lq - lc : lc - lq;
+      if (diff <= d) {  // src/distance.rs:109-130 (both lengths > 0 here)
+        {
+          uint32_t* S32 = reinterpret_cast<uint32_t*>(S);
+          const uint4* qr = q_rows + (size_t)q * a.qw;
+          for (int wq = 0; wq * 16 < lq; ++wq) {
+            const uint4 v = qr[wq];
+            S32[wq * 4 + 0] = v.x; S32[wq * 4 + 1] = v.y; S32[wq * 4 + 2] = v.z; S32[wq * 4 + 3] = v.w;
+          }
+          uint32_t* T32 = reinterpret_cast<uint32_t*>(T);
+          const uint4* cr = rows + ent_rowoff[e];
+          for (int wc = 0; wc * 16 < lc; ++wc) {
+            const uint4 v = cr[wc];
+            T32[wc * 4 + 0] = v.x; T32[wc * 4 + 1] = v.y; T32[wc * 4 + 2] = v.z; T32[wc * 4 + 3] = v.w;
+          }
+        }
+        // ---- banded unrestricted Damerau-Levenshtein ------------------------------------------------
+        const int cap = d + 1, W = 2 * d + 3, NR = d + 2;
+        // row i is stored at R[(i % NR) * W + col], col = j - i + d + 1 in [1, 2d+1]; cols 0, 2d+2 are guards
+        for (int col = 0; col < W; ++col) {
+          const int j = col - d - 1;
+          R[col] = (uint8_t)((j >= 0 && j <= lc && col >= 1 && col <= 2 * d + 1) ? (j < cap ? j : cap) : cap);
+        }
+        for (int i = 1; i <= lq; ++i) {
+          uint8_t* cur = R + (i % NR) * W;
+          const uint8_t* prev = R + ((i - 1) % NR) * W;
+          const uint32_t sc = S[i - 1];
+          int db = 0;
+          cur[0] = (uint8_t)cap;
+          for (int col = 1; col <= 2 * d + 1; ++col) {
+            const int j = i + col - d - 1;
+            uint32_t v;
+            if (j < 0 || j > lc) v = cap;
+            else if (j == 0) v = i < cap ? i : cap;
+            else {
+              const uint32_t tc = T[j - 1];
+              const uint32_t cost = sc != tc;
+              v = min(min((uint32_t)cur[col - 1] + 1u, (uint32_t)prev[col + 1] + 1u), (uint32_t)prev[col] + cost);
+              if (db > 0) {
+                // l = last row i' < i with s[i'-1] == t[j-1] (char_map, src/distance.rs:146,154,170), looking
+                // back at most d rows: farther rows make the term exceed d
+                for (int back = 0; back < d; ++back) {
+                  const int l = i - 1 - back;
+                  if (l < 1) break;
+                  if (S[l - 1] == tc) {
+                    const int colx = db - l + d + 1;  // column of D[l-1][db-1] in row l-1
+                    if (colx >= 1 && colx <= 2 * d + 1) {
+                      const uint32_t tv = (uint32_t)R[((l - 1) % NR) * W + colx] + (uint32_t)(i - l - 1) + 1u +
+                                          (uint32_t)(j - db - 1);  // src/distance.rs:161
+                      v = min(v, tv);
+                    }
+                    break;
+                  }
                 }
-                break;
+              }
+              v = min(v, (uint32_t)cap);
+              if (cost == 0) db = j;  // src/distance.rs:165-167
+            }
+            cur[col] = (uint8_t)v;
+          }
+          cur[2 * d + 2] = (uint8_t)cap;
+        }
+        const uint32_t res = R[(lq % NR) * W + (lc - lq + d + 1)];
+        if (res <= (uint32_t)d) {  // src/distance.rs:173-178
+          ld = res;
+          if (a.w_lcs > 0.0) {  // src/lib.rs:1352-1356; diagonal walk == the reference's naive scan
+            uint32_t best = 0;
+            for (int delta = -(lq - 1); delta <= lc - 1; ++delta) {
+              const int i0 = delta < 0 ? -delta : 0;
+              const int i1 = min(lq, lc - delta);
+              if ((uint32_t)(i1 - i0) <= best) continue;
+              uint32_t run = 0;
+              for (int i = i0; i < i1; ++i) {
+                run = S[i] == T[i + delta] ? run + 1 : 0;
+                best = max(best, run);
               }
             }
+            lcs = best;
           }
-          v = min(v, (uint32_t)cap);
-          if (cost == 0) db = j;  // src/distance.rs:165-167
-        }
-        cur[col] = (uint8_t)v;
-      }
-      cur[2 * d + 2] = (uint8_t)cap;
-    }
-    const uint32_t res = R[(lq % NR) * W + (lc - lq + d + 1)];
-    if (res <= (uint32_t)d) {  // src/distance.rs:173-178
-      ld = res;
-      if (a.w_lcs > 0.0) {  // src/lib.rs:1352-1356; diagonal walk == the reference's naive scan
-        uint32_t best = 0;
-        for (int delta = -(lq - 1); delta <= lc - 1; ++delta) {
-          const int i0 = delta < 0 ? -delta : 0;
-          const int i1 = min(lq, lc - delta);
-          if ((uint32_t)(i1 - i0) <= best) continue;
-          uint32_t run = 0;
-          for (int i = i0; i < i1; ++i) {
-            run = S[i] == T[i + delta] ? run + 1 : 0;
-            best = max(best, run);
+          const int m = min(lq, lc);
+          if (a.w_prefix > 0.0) {
+            int n = 0;
+            while (n < m && S[n] == T[n]) ++n;
+            pre = n;
           }
+          if (a.w_suffix > 0.0) {
+            int n = 0;
+            while (n < m && S[lq - 1 - n] == T[lc - 1 - n]) ++n;
+            suf = n;
+          }
+          if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
+          const double L = (double)lq;
+          const double distance_score = (int)ld > lq ? 0.0 : 1.0 - ((double)ld / L);
+          const double lcs_score = (double)lcs / L;
+          const double prefix_score = (double)pre / L;
+          const double suffix_score = (double)suf / L;
+          score = (a.w_ld * distance_score + a.w_lcs * lcs_score + a.w_prefix * prefix_score +
+                   a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0)) /
+                  a.w_sum;
+          // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
+          atomicMax(&qmaxfreq[q], a.have_freq ? ent_freq[e] : 1u);
+          if (score >= a.score_threshold) atomicAdd(&qsurv[q], 1u);  // src/lib.rs:1475
         }
-        lcs = best;
       }
-      const int m = min(lq, lc);
-      if (a.w_prefix > 0.0) {
-        int n = 0;
-        while (n < m && S[n] == T[n]) ++n;
-        pre = n;
-      }
-      if (a.w_suffix > 0.0) {
-        int n = 0;
-        while (n < m && S[lq - 1 - n] == T[lc - 1 - n]) ++n;
-        suf = n;
-      }
-      if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
-      const double L = (double)lq;
-      const double distance_score = (int)ld > lq ? 0.0 : 1.0 - ((double)ld / L);
-      const double lcs_score = (double)lcs / L;
-      const double prefix_score = (double)pre / L;
-      const double suffix_score = (double)suf / L;
-      score = (a.w_ld * distance_score + a.w_lcs * lcs_score + a.w_prefix * prefix_score +
-               a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0)) /
-              a.w_sum;
-      // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
-      if (a.have_freq) atomicMax(&qmaxfreq[q], ent_freq[e]);
-      else atomicMax(&qmaxfreq[q], 1u);
     }
+    p_score[p] = score;
+    p_meta[p] = skip ? META_SKIPPED : (ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24));
   }
-  p_score[p] = score;
-  p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+  // scored pairs (= damerau_levenshtein invocations of the reference) = pairs emitted by the scan minus the
+  // ones StopAtExactMatch drops here; only that (rare) mode pays an atomic
+  if (a.stop) {
+    const unsigned long long m = __ballot(stop_skipped);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[CTR_SKIPPED], (uint32_t)__popcll(m));
+  }
+}
+
+// K3b: gather the survivors (score >= threshold) into per-query segments.  Order inside a query is
+// arbitrary; ranking uses a total order whose last key is ent_order (= reference enumeration order).
+__global__ __launch_bounds__(256) void k_compact(uint32_t nraw, const uint2* __restrict__ raw,
+                                                 const double* __restrict__ p_score, double thr,
+                                                 const uint32_t* __restrict__ soff, uint32_t* __restrict__ qcur,
+                                                 uint32_t* __restrict__ c_entry, double* __restrict__ c_score) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= nraw) return;
+  const double s = p_score[r];
+  if (!(s >= thr)) return;  // NaN = pruned / skipped
+  const uint2 v = raw[r];
+  const uint32_t pos = soff[v.x] + atomicAdd(&qcur[v.x], 1u);
+  c_entry[pos] = v.y & 0x7FFFFFFFu;
+  c_score[pos] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: rank.  One wave per query.  score threshold (src/lib.rs:1475), freq normalisation (:1521-1525),
-// stable sort by rank_cmp (src/types.rs:344-365) realised as a total order with the entry index as last
-// key, crop with the tie rule (:1536-1589), cutoff (:1598-1622).
+// K4: rank.  One wave per query over its survivors.  freq normalisation (src/lib.rs:1521-1525),
+// stable sort by rank_cmp (src/types.rs:344-365) realised as a total order with ent_order as last key,
+// crop with the tie rule (:1536-1589), cutoff (:1598-1622).
 // ------------------------------------------------------------------------------------------------
 struct RankArgs {
-  double score_threshold, cutoff_threshold;
+  double cutoff_threshold;
   uint64_t max_matches;
   float freq_weight;
   int have_freq;
@@ -484,64 +659,55 @@ __device__ inline double result_score(double dist, double freq, float fw) {  // 
   return (dist + ((double)fw * freq)) / (1.0 + (double)fw);
 }
 
-__global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __restrict__ qoff,
-                                              const uint32_t* __restrict__ pair_e,
-                                              const double* __restrict__ p_score,
+__global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __restrict__ soff,
+                                              const uint32_t* __restrict__ c_entry,
+                                              const double* __restrict__ c_score,
                                               const uint32_t* __restrict__ ent_freq,
                                               const uint32_t* __restrict__ ent_order,
                                               const uint32_t* __restrict__ qmaxfreq, RankArgs a,
-                                              double* __restrict__ t_key, uint32_t* __restrict__ t_pos,
-                                              uint32_t* __restrict__ r_entry, double* __restrict__ r_dist,
-                                              double* __restrict__ r_freq, uint32_t* __restrict__ r_count) {
+                                              double* __restrict__ t_key, uint32_t* __restrict__ r_entry,
+                                              double* __restrict__ r_dist, double* __restrict__ r_freq,
+                                              uint32_t* __restrict__ r_count) {
   __shared__ double s_key[4][RANK_LCAP];
-  __shared__ uint32_t s_freq[4][RANK_LCAP], s_entry[4][RANK_LCAP], s_pos[4][RANK_LCAP], s_ord[4][RANK_LCAP];
+  __shared__ uint32_t s_freq[4][RANK_LCAP], s_ord[4][RANK_LCAP];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.x * 4 + wid;
   if (q >= nq) return;
-  const uint32_t seg0 = qoff[q], seg1 = qoff[q + 1];
+  const uint32_t seg0 = soff[q], n = soff[q + 1] - seg0;
+  if (n == 0) {
+    if (lane == 0) r_count[q] = 0;
+    return;
+  }
   const uint32_t maxf = qmaxfreq[q];
   const double max_freq = a.have_freq ? (double)maxf : (maxf ? 1.0 : 0.0);
   const bool sort_weighted = a.freq_weight > 0.0f;    // rank_cmp's branch
   const bool score_weighted = a.freq_weight != 0.0f;  // score()'s branch
-  // ---- compact the survivors (score >= threshold) ---------------------------------------------------
-  uint32_t n = 0;
-  for (uint32_t base = seg0; base < seg1; base += 64) {
-    const uint32_t pos = base + lane;
-    double sc = __builtin_nan("");
-    if (pos < seg1) sc = p_score[pos];
-    const bool keep = sc >= a.score_threshold;  // NaN (pruned by DL) compares false
-    const unsigned long long mask = __ballot(keep);
-    if (keep) {
-      const uint32_t idx = n + __popcll(mask & ((1ull << lane) - 1ull));
-      const uint32_t e = pair_e[pos];
-      const uint32_t f = a.have_freq ? ent_freq[e] : 1u;
-      double key = sc;
-      if (sort_weighted) {
-        const double fs = max_freq > 0.0 ? (double)f / max_freq : (double)f;
-        key = result_score(sc, fs, a.freq_weight);
-      }
-      if (idx < RANK_LCAP) {
-        s_key[wid][idx] = key; s_freq[wid][idx] = f; s_entry[wid][idx] = e; s_pos[wid][idx] = pos;
-        s_ord[wid][idx] = ent_order[e];
-      } else {
-        t_key[seg0 + idx] = key; t_pos[seg0 + idx] = pos;
-      }
+  // ---- sort keys ------------------------------------------------------------------------------------
+  for (uint32_t i = lane; i < n; i += 64) {
+    const uint32_t e = c_entry[seg0 + i];
+    const uint32_t f = a.have_freq ? ent_freq[e] : 1u;
+    double key = c_score[seg0 + i];
+    if (sort_weighted) {
+      const double fs = max_freq > 0.0 ? (double)f / max_freq : (double)f;
+      key = result_score(key, fs, a.freq_weight);
     }
-    n += __popcll(mask);
+    if (i < RANK_LCAP) { s_key[wid][i] = key; s_freq[wid][i] = f; s_ord[wid][i] = ent_order[e]; }
+    else t_key[seg0 + i] = key;
   }
-  if (n > RANK_LCAP) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // ---- rank by counting -------------------------------------------------------------------------------
   const bool full = score_weighted || a.max_matches == 0;
   const uint32_t M = full ? n : (uint32_t)min((uint64_t)n, a.max_matches + 1);
   for (uint32_t i = lane; i < n; i += 64) {
-    double ki; uint32_t fi, ei, pi, oi;
-    if (i < RANK_LCAP) { ki = s_key[wid][i]; fi = s_freq[wid][i]; ei = s_entry[wid][i]; pi = s_pos[wid][i]; oi = s_ord[wid][i]; }
-    else { ki = t_key[seg0 + i]; pi = t_pos[seg0 + i]; ei = pair_e[pi]; fi = a.have_freq ? ent_freq[ei] : 1u; oi = ent_order[ei]; }
+    double ki; uint32_t fi, oi;
+    const uint32_t ei = c_entry[seg0 + i];
+    if (i < RANK_LCAP) { ki = s_key[wid][i]; fi = s_freq[wid][i]; oi = s_ord[wid][i]; }
+    else { ki = t_key[seg0 + i]; fi = a.have_freq ? ent_freq[ei] : 1u; oi = ent_order[ei]; }
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; ++j) {
       double kj; uint32_t fj, oj;
       if (j < RANK_LCAP) { kj = s_key[wid][j]; fj = s_freq[wid][j]; oj = s_ord[wid][j]; }
-      else { kj = t_key[seg0 + j]; const uint32_t ej = pair_e[t_pos[seg0 + j]]; fj = a.have_freq ? ent_freq[ej] : 1u; oj = ent_order[ej]; }
+      else { kj = t_key[seg0 + j]; const uint32_t ej = c_entry[seg0 + j]; fj = a.have_freq ? ent_freq[ej] : 1u; oj = ent_order[ej]; }
       bool before;
       if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
       else before = kj > ki || (kj == ki && (fj > fi || (fj == fi && oj < oi)));
@@ -549,7 +715,7 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
     }
     if (rank < M) {
       r_entry[seg0 + rank] = ei;
-      r_dist[seg0 + rank] = p_score[pi];
+      r_dist[seg0 + rank] = c_score[seg0 + i];
       r_freq[seg0 + rank] = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
     }
   }
@@ -596,7 +762,7 @@ struct DevRow {
   uint32_t vocab_id, query;
   double dist_score, freq_score;
 };
-__global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* __restrict__ qoff,
+__global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* __restrict__ soff,
                                                    const uint32_t* __restrict__ r_off,
                                                    const uint32_t* __restrict__ r_count,
                                                    const uint32_t* __restrict__ r_entry,
@@ -606,7 +772,7 @@ __global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* 
                                                    const uint32_t* __restrict__ q_orig, DevRow* __restrict__ out) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
-  const uint32_t n = r_count[q], src = qoff[q], dst = r_off[q];
+  const uint32_t n = r_count[q], src = soff[q], dst = r_off[q];
   for (uint32_t i = 0; i < n; ++i) {
     DevRow r;
     r.vocab_id = ent_vocab[r_entry[src + i]];
@@ -616,7 +782,7 @@ __global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* 
     out[dst + i] = r;
   }
 }
-__global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t stride, const uint32_t* __restrict__ qoff,
+__global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t stride, const uint32_t* __restrict__ soff,
                                                      const uint32_t* __restrict__ r_count,
                                                      const uint32_t* __restrict__ r_entry,
                                                      const double* __restrict__ r_dist,
@@ -632,7 +798,7 @@ __global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t strid
   r.freq_score = 0.0f;
   r.dist_score = 0.0;
   if (i < r_count[q]) {
-    const uint32_t src = qoff[q] + i;
+    const uint32_t src = soff[q] + i;
     r.vocab_id = ent_vocab[r_entry[src]];
     r.freq_score = (float)r_freq[src];
     r.dist_score = r_dist[src];
@@ -661,6 +827,11 @@ static int upload(T** dst, const void* src, size_t count, std::string& err, size
   if (total) *total += bytes;
   return ANX_OK;
 }
+template <typename T>
+static int dalloc(T** dst, size_t count, std::string& err) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(count * sizeof(T), 16)));
+  return ANX_OK;
+}
 
 DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& err) {
   int n = device_count(err);
@@ -673,6 +844,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   DeviceLexicon* d = new DeviceLexicon();
   d->device = device;
   d->nplanes = img.nplanes;
+  d->nsym = img.nsym;
   d->nclasses = img.nclasses;
   d->nentries = img.nentries;
   d->cstride = img.cstride;
@@ -683,6 +855,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
   if ((rc = upload(&d->cls_planes, img.cls_planes.data(), img.cls_planes.size(), err, &d->bytes)) ||
+      (rc = upload(&d->cls_bits, img.cls_bits.data(), img.cls_bits.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_len, img.cls_len.data(), img.cls_len.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_vocab, img.ent_vocab.data(), img.ent_vocab.size(), err, &d->bytes)) ||
@@ -700,12 +873,16 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_len, (void*)d->cls_off, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->rows})
     if (p) (void)hipFree(p);
   delete d;
 }
 
+static int scan_mode() {  // ANX_SCAN=sad forces the general count-vector kernel (A/B testing)
+  const char* e = getenv("ANX_SCAN");
+  return (e && strcmp(e, "sad") == 0) ? 1 : 0;
+}
 
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
                     const anx_params& p, std::string& err, int* code) {
@@ -718,10 +895,12 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   b->n_input = n;
   b->status.assign(n, 0);
   const int NP = dl->nplanes;
+  const bool bits_ok = dl->nsym <= 32 && !scan_mode();
   struct Enc {
     std::vector<uint8_t> norm, cv;
     uint32_t orig;
     uint32_t meta;
+    uint32_t kind;  // 0 = SAD kernel, 1..NBITPLANES = bit-plane kernel with T = kind planes
   };
   std::vector<Enc> enc;
   enc.reserve(n);
@@ -736,75 +915,82 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     const int d = clamp_threshold(p.max_edit_distance, len, kMaxEditDistance);
     e.meta = (uint32_t)len | ((uint32_t)k << 8) | ((uint32_t)d << 16) |
              (first_char_is_lowercase(utf8[i]) ? 1u << 24 : 0u);
+    uint32_t maxcount = 0;
+    for (uint8_t c : e.cv) maxcount = std::max<uint32_t>(maxcount, c);
+    e.kind = (bits_ok && maxcount <= (uint32_t)NBITPLANES) ? maxcount : 0;
     maxlen = std::max(maxlen, e.norm.size());
     b->dmax = std::max<uint32_t>(b->dmax, (uint32_t)d);
     enc.push_back(std::move(e));
   }
-  // length-bucketed order (stable): queries of one length share k, d and the class window
-  std::stable_sort(enc.begin(), enc.end(), [](const Enc& x, const Enc& y) { return (x.meta & 0xFF) < (y.meta & 0xFF); });
+  // (kernel kind, length)-bucketed order (stable): queries of one bucket share k, d and the class window
+  std::stable_sort(enc.begin(), enc.end(), [](const Enc& x, const Enc& y) {
+    if (x.kind != y.kind) return x.kind < y.kind;
+    return (x.meta & 0xFF) < (y.meta & 0xFF);
+  });
   const size_t nq = enc.size();
   b->nq = nq;
   b->qw = (uint32_t)((maxlen + 15) / 16);
-  std::vector<uint32_t> h_cv(nq * (size_t)NP, 0), h_meta(nq), h_orig(nq);
+  std::vector<uint32_t> h_cv(nq * (size_t)NP, 0), h_bits(nq * (size_t)NBITPLANES, 0), h_meta(nq), h_orig(nq);
   std::vector<uint8_t> h_rows(nq * (size_t)b->qw * 16, 0xFE);
   b->order.resize(nq);
   for (size_t i = 0; i < nq; ++i) {
     memcpy(&h_cv[i * (size_t)NP], enc[i].cv.data(), std::min(enc[i].cv.size(), (size_t)NP * 4));
+    for (size_t s = 0; s < enc[i].cv.size() && s < 32; ++s)
+      for (uint32_t tp = 0; tp < (uint32_t)NBITPLANES; ++tp)
+        if (enc[i].cv[s] > tp) h_bits[i * NBITPLANES + tp] |= 1u << s;
     memcpy(&h_rows[i * (size_t)b->qw * 16], enc[i].norm.data(), enc[i].norm.size());
     h_meta[i] = enc[i].meta;
     h_orig[i] = enc[i].orig;
     b->order[i] = enc[i].orig;
   }
-  // tiles + work list
-  const uint32_t TQ = SCAN_TQ;
+  // tiles (<= SCAN_TQ queries of one kind and length) and work items (tile x class segment)
+  const int sad_cpl = NP <= 8 ? 4 : NP <= 16 ? 2 : 1;
   for (size_t i = 0; i < nq;) {
     size_t j = i;
-    while (j < nq && (h_meta[j] & 0xFFFF) == (h_meta[i] & 0xFFFF)) ++j;
-    const uint32_t lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
+    while (j < nq && enc[j].kind == enc[i].kind && (h_meta[j] & 0xFF) == (h_meta[i] & 0xFF)) ++j;
+    const uint32_t kind = enc[i].kind, lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     const uint32_t c0 = m.lex.bucket_begin[lo], c1 = m.lex.bucket_begin[hi + 1];
-    for (size_t s = i; s < j; s += TQ) {
-      Tile t{(uint32_t)s, (uint32_t)std::min<size_t>(TQ, j - s), c0, c1, k, lq};
+    const uint32_t cpl = kind == 0 ? (uint32_t)sad_cpl : (uint32_t)BITS_CPL[kind];
+    const uint32_t seg = 256u * cpl * SCAN_SEG_CHUNKS;
+    for (size_t s = i; s < j; s += SCAN_TQ) {
+      Tile t{(uint32_t)s, (uint32_t)std::min<size_t>(SCAN_TQ, j - s), c0, c1, k, lq};
+      const uint32_t ti = (uint32_t)b->tiles.size();
       b->tiles.push_back(t);
+      for (uint32_t cb = c0; cb < c1; cb += seg) b->work.push_back(Work{ti, cb, std::min(c1, cb + seg), kind});
       b->n_class_tests += (uint64_t)t.nq * (c1 - c0);
     }
     i = j;
   }
-  auto up = [&](auto** dst, const void* src, size_t count) { return upload(dst, src, count, err, nullptr); };
+  {  // longest-processing-time-first order: cost ~ queries x classes x per-test cost of the kind
+    static const uint32_t kcost[NBITPLANES + 1] = {36, 9, 15, 22, 28};
+    const std::vector<Tile>& tl = b->tiles;
+    std::stable_sort(b->work.begin(), b->work.end(), [&](const Work& x, const Work& y) {
+      return (uint64_t)tl[x.tile].nq * (x.cend - x.cbeg) * kcost[x.kind] > (uint64_t)tl[y.tile].nq * (y.cend - y.cbeg) * kcost[y.kind];
+    });
+  }
   int rc;
-  if ((rc = up(&b->q_cv, h_cv.data(), h_cv.size())) || (rc = up(reinterpret_cast<uint8_t**>(&b->q_rows), h_rows.data(), h_rows.size())) ||
-      (rc = up(&b->q_meta, h_meta.data(), nq)) || (rc = up(&b->q_orig, h_orig.data(), nq)) ||
-      (rc = up(&b->d_tiles, b->tiles.data(), b->tiles.size()))) {
+  if ((rc = upload(&b->q_cv, h_cv.data(), h_cv.size(), err, nullptr)) ||
+      (rc = upload(&b->q_bits, h_bits.data(), h_bits.size(), err, nullptr)) ||
+      (rc = upload(reinterpret_cast<uint8_t**>(&b->q_rows), h_rows.data(), h_rows.size(), err, nullptr)) ||
+      (rc = upload(&b->q_meta, h_meta.data(), nq, err, nullptr)) || (rc = upload(&b->q_orig, h_orig.data(), nq, err, nullptr)) ||
+      (rc = upload(&b->d_tiles, b->tiles.data(), b->tiles.size(), err, nullptr)) ||
+      (rc = upload(&b->d_work, b->work.data(), b->work.size(), err, nullptr))) {
     *code = rc;
     batch_free(b);
     return nullptr;
   }
-  auto dalloc = [&](auto** dst, size_t count) -> int {
-    using TT = std::remove_pointer_t<std::remove_pointer_t<decltype(dst)>>;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(count * sizeof(TT), 16));
-    if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return ANX_ENODEVICE; }
-    return ANX_OK;
-  };
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N)) || (rc = dalloc(&b->qcount, nq)) || (rc = dalloc(&b->qexact, nq)) ||
-      (rc = dalloc(&b->qoff, nq + 1)) || (rc = dalloc(&b->qcur, nq)) || (rc = dalloc(&b->qmaxfreq, nq)) ||
-      (rc = dalloc(&b->scan_tmp, nblk)) || (rc = dalloc(&b->r_count, nq)) || (rc = dalloc(&b->r_off, nq + 1))) {
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->qexact, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+      (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
+      (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
     batch_free(b);
     return nullptr;
   }
-  b->raw_cap = nq * 192 + (size_t)b->tiles.size() * 4 * SCAN_CHUNK + (1u << 16);
-  if ((rc = dalloc(&b->raw, b->raw_cap))) { *code = rc; batch_free(b); return nullptr; }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
   return b;
-}
-
-template <int NP, int CPL>
-static void launch_scan(const DeviceLexicon* dl, Batch* b, hipStream_t st) {
-  hipLaunchKernelGGL((k_anagram_scan<NP, CPL>), dim3((uint32_t)b->tiles.size()), dim3(256), 0, st, b->d_tiles,
-                     b->q_cv, dl->cls_planes, dl->cstride, dl->cls_len, dl->cls_off, b->raw,
-                     (uint32_t)std::min<size_t>(b->raw_cap, 0xFFFFFFFFu), b->counters, b->qcount, b->qexact);
 }
 
 static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, hipStream_t st) {
@@ -816,13 +1002,35 @@ static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_
   return 0;
 }
 
-static void free_pair_buffers(Batch* b) {
-  for (void* p : {(void*)b->pair_q, (void*)b->pair_e, (void*)b->p_score, (void*)b->p_meta, (void*)b->r_entry,
-                  (void*)b->r_dist, (void*)b->r_freq, (void*)b->t_key, (void*)b->t_pos})
+template <int NP>
+static void launch_scan(const ScanArgs& A, uint32_t nwork, hipStream_t st) {
+  hipLaunchKernelGGL((k_scan<NP>), dim3(nwork), dim3(256), 0, st, A);
+}
+
+static int ensure_raw(Batch* b, size_t cap, std::string& err) {
+  if (cap <= b->raw_cap) return ANX_OK;
+  for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta})
     if (p) (void)hipFree(p);
-  b->pair_q = b->pair_e = b->p_meta = b->r_entry = b->t_pos = nullptr;
-  b->p_score = b->r_dist = b->r_freq = b->t_key = nullptr;
-  b->pair_cap = 0;
+  b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->raw_cap = 0;
+  int rc;
+  if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err))) return rc;
+  b->raw_cap = cap;
+  return ANX_OK;
+}
+static int ensure_surv(Batch* b, size_t cap, std::string& err) {
+  if (cap <= b->surv_cap) return ANX_OK;
+  for (void* p : {(void*)b->c_entry, (void*)b->c_score, (void*)b->r_entry, (void*)b->r_dist, (void*)b->r_freq,
+                  (void*)b->t_key})
+    if (p) (void)hipFree(p);
+  b->c_entry = b->r_entry = nullptr;
+  b->c_score = b->r_dist = b->r_freq = b->t_key = nullptr;
+  b->surv_cap = 0;
+  int rc;
+  if ((rc = dalloc(&b->c_entry, cap, err)) || (rc = dalloc(&b->c_score, cap, err)) || (rc = dalloc(&b->r_entry, cap, err)) ||
+      (rc = dalloc(&b->r_dist, cap, err)) || (rc = dalloc(&b->r_freq, cap, err)) || (rc = dalloc(&b->t_key, cap, err)))
+    return rc;
+  b->surv_cap = cap;
+  return ANX_OK;
 }
 
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
@@ -831,65 +1039,56 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint32_t nq = (uint32_t)b->nq;
   b->ran = false;
-  b->n_pairs = b->n_results = 0;
+  b->n_pairs = b->n_results = b->n_surv = 0;
+  b->n_raw = 0;
   if (nq == 0) { b->ran = true; return ANX_OK; }
   const int stop = b->params.stop_at_exact_match ? 1 : 0;
+  int rc;
+  if (b->raw_cap == 0 &&
+      (rc = ensure_raw(b, nq * (size_t)160 + (size_t)b->work.size() * 4 * SCAN_CHUNK + (1u << 16), err)))
+    return rc;
   uint32_t h_counters[CTR_N];
-  uint32_t total_pairs = 0;
   HIP_TRY(hipEventRecord(b->ev[0], st));
+  // ---- scan ------------------------------------------------------------------------------------------
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(b->qcur, 0, nq * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
-    if (!b->tiles.empty()) {
+    if (stop) HIP_TRY(hipMemsetAsync(b->qexact, 0, nq * sizeof(uint32_t), st));
+    if (!b->work.empty()) {
+      ScanArgs A;
+      A.tiles = b->d_tiles; A.work = b->d_work; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
+      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cstride = dl->cstride;
+      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.raw = b->raw;
+      A.raw_cap = (uint32_t)std::min<size_t>(b->raw_cap, 0xFFFFFFFFu);
+      A.counters = b->counters; A.qexact = b->qexact; A.want_exact = stop;
+      const uint32_t nwork = (uint32_t)b->work.size();
       switch (dl->nplanes) {
-        case 8: launch_scan<8, 4>(dl, b, st); break;
-        case 16: launch_scan<16, 2>(dl, b, st); break;
-        case 24: launch_scan<24, 1>(dl, b, st); break;
-        case 32: launch_scan<32, 1>(dl, b, st); break;
-        default: launch_scan<42, 1>(dl, b, st); break;
+        case 8: launch_scan<8>(A, nwork, st); break;
+        case 16: launch_scan<16>(A, nwork, st); break;
+        case 24: launch_scan<24>(A, nwork, st); break;
+        case 32: launch_scan<32>(A, nwork, st); break;
+        default: launch_scan<42>(A, nwork, st); break;
       }
     }
-    if (stop) hipLaunchKernelGGL(k_stop_fixup, dim3((nq + 255) / 256), dim3(256), 0, st, nq, b->qcount, b->qexact);
-    if (attempt == 0) HIP_TRY(hipEventRecord(b->ev[1], st));
-    exclusive_scan(b->qcount, nq, b->qoff, b->scan_tmp, st);
     HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&total_pairs, b->qoff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if ((size_t)h_counters[CTR_RAW] <= b->raw_cap) break;
     if (attempt == 1) { err = "pair list overflow after regrow"; return ANX_ENODEVICE; }
-    (void)hipFree(b->raw);
-    b->raw = nullptr;
-    b->raw_cap = (size_t)h_counters[CTR_RAW] + (size_t)b->tiles.size() * 4 * SCAN_CHUNK + 1024;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->raw), b->raw_cap * sizeof(uint2)));
+    if ((rc = ensure_raw(b, (size_t)h_counters[CTR_RAW] + (size_t)b->work.size() * 4 * SCAN_CHUNK + 1024, err))) return rc;
   }
+  HIP_TRY(hipEventRecord(b->ev[1], st));
   const uint32_t nraw = h_counters[CTR_RAW];
-  const uint32_t P = total_pairs;
-  b->n_pairs = P;
-  if ((size_t)P > b->pair_cap) {
-    free_pair_buffers(b);
-    const size_t cap = (size_t)P + (P >> 3) + 1024;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->pair_q), cap * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->pair_e), cap * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->p_score), cap * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->p_meta), cap * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->r_entry), cap * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->r_dist), cap * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->r_freq), cap * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->t_key), cap * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->t_pos), cap * 4));
-    b->pair_cap = cap;
-  }
-  if (nraw)
-    hipLaunchKernelGGL(k_group_pairs, dim3((nraw + 255) / 256), dim3(256), 0, st, b->raw, nraw, b->qoff, b->qexact,
-                       stop, b->qcur, b->pair_q, b->pair_e);
-  HIP_TRY(hipEventRecord(b->ev[2], st));
-  // ---- score ---------------------------------------------------------------------------------------------
+  b->n_raw = nraw;
+  // ---- score -----------------------------------------------------------------------------------------
+  HIP_TRY(hipMemsetAsync(b->qsurv, 0, nq * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(b->qcur, 0, nq * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
   ScoreArgs sa;
   sa.w_ld = m.weights.ld; sa.w_lcs = m.weights.lcs; sa.w_prefix = m.weights.prefix; sa.w_suffix = m.weights.suffix;
   sa.w_case = m.weights.casew;
   sa.w_sum = m.weights.ld + m.weights.lcs + m.weights.prefix + m.weights.suffix + m.weights.casew;  // src/types.rs:69-73
+  sa.score_threshold = b->params.score_threshold;
   sa.have_freq = m.have_freq ? 1 : 0;
+  sa.stop = stop;
   sa.lqp = b->qw * 16;
   sa.lcp = (dl->max_len + 15) / 16 * 16;
   const uint32_t d = b->dmax;
@@ -901,20 +1100,32 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   uint32_t threads = 256;
   while (threads > 64 && (size_t)threads * sa.stride > 64 * 1024) threads >>= 1;
   if ((size_t)threads * sa.stride > 64 * 1024) { err = "per-lane scoring state exceeds the LDS budget"; return ANX_ELIMIT; }
-  if (P)
-    hipLaunchKernelGGL(k_score_pairs, dim3((P + threads - 1) / threads), dim3(threads), threads * sa.stride, st, P,
-                       b->pair_q, b->pair_e, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows,
-                       dl->ent_freq, sa, b->p_score, b->p_meta, b->qmaxfreq);
+  if (nraw)
+    hipLaunchKernelGGL(k_score_pairs, dim3((nraw + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nraw,
+                       b->raw, b->qexact, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
+                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->counters);
+  HIP_TRY(hipEventRecord(b->ev[2], st));
+  // ---- compact survivors -----------------------------------------------------------------------------
+  exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
+  uint32_t total_surv = 0;
+  HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  b->n_pairs = (uint64_t)h_counters[CTR_VALID] - h_counters[CTR_SKIPPED];
+  b->n_surv = total_surv;
+  if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
+  if (nraw)
+    hipLaunchKernelGGL(k_compact, dim3((nraw + 255) / 256), dim3(256), 0, st, nraw, b->raw, b->p_score,
+                       b->params.score_threshold, b->soff, b->qcur, b->c_entry, b->c_score);
   HIP_TRY(hipEventRecord(b->ev[3], st));
-  // ---- rank ----------------------------------------------------------------------------------------------
+  // ---- rank ------------------------------------------------------------------------------------------
   RankArgs ra;
-  ra.score_threshold = b->params.score_threshold;
   ra.cutoff_threshold = b->params.cutoff_threshold;
   ra.max_matches = b->params.max_matches;
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
-  hipLaunchKernelGGL(k_rank, dim3((nq + 3) / 4), dim3(256), 0, st, nq, b->qoff, b->pair_e, b->p_score, dl->ent_freq,
-                     dl->ent_order, b->qmaxfreq, ra, b->t_key, b->t_pos, b->r_entry, b->r_dist, b->r_freq, b->r_count);
+  hipLaunchKernelGGL(k_rank, dim3((nq + 3) / 4), dim3(256), 0, st, nq, b->soff, b->c_entry, b->c_score, dl->ent_freq,
+                     dl->ent_order, b->qmaxfreq, ra, b->t_key, b->r_entry, b->r_dist, b->r_freq, b->r_count);
   exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
   HIP_TRY(hipEventRecord(b->ev[4], st));
   uint32_t total_results = 0;
@@ -925,13 +1136,13 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   b->ran = true;
   anx_batch_stats& s = b->stats;
   s.n_queries = nq;
-  s.n_pairs = P;
+  s.n_pairs = b->n_pairs;
   s.n_class_tests = b->n_class_tests;
   s.n_results = total_results;
-  s.n_scan_blocks = b->tiles.size();
+  s.n_scan_blocks = b->work.size();
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
-  (void)hipEventElapsedTime(&s.ms_group, b->ev[1], b->ev[2]);
-  (void)hipEventElapsedTime(&s.ms_score, b->ev[2], b->ev[3]);
+  (void)hipEventElapsedTime(&s.ms_score, b->ev[1], b->ev[2]);
+  (void)hipEventElapsedTime(&s.ms_group, b->ev[2], b->ev[3]);
   (void)hipEventElapsedTime(&s.ms_rank, b->ev[3], b->ev[4]);
   (void)hipEventElapsedTime(&s.ms_total, b->ev[0], b->ev[4]);
   return ANX_OK;
@@ -949,7 +1160,7 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
   if (b->nq && b->n_results) {
     DevRow* d_rows = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), b->n_results * sizeof(DevRow)));
-    hipLaunchKernelGGL(k_pack_rows, dim3(((uint32_t)b->nq + 255) / 256), dim3(256), 0, 0, (uint32_t)b->nq, b->qoff,
+    hipLaunchKernelGGL(k_pack_rows, dim3(((uint32_t)b->nq + 255) / 256), dim3(256), 0, 0, (uint32_t)b->nq, b->soff,
                        b->r_off, b->r_count, b->r_entry, b->r_dist, b->r_freq, dl->ent_vocab, b->q_orig, d_rows);
     std::vector<DevRow> h(b->n_results);
     std::vector<uint32_t> h_cnt(b->nq);
@@ -979,21 +1190,23 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
   (void)m;
   if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
   HIP_TRY(hipSetDevice(b->device));
-  const size_t P = b->n_pairs;
-  anx_pair* res = static_cast<anx_pair*>(malloc(std::max<size_t>(1, P) * sizeof(anx_pair)));
+  const size_t R = b->n_raw;
+  anx_pair* res = static_cast<anx_pair*>(malloc(std::max<size_t>(1, (size_t)b->n_pairs) * sizeof(anx_pair)));
   if (!res) { err = "out of memory"; return ANX_EINVAL; }
-  if (P) {
-    std::vector<uint32_t> pq(P), pe(P), pm(P), ev(dl->nentries);
-    std::vector<double> ps(P);
-    HIP_TRY(hipMemcpy(pq.data(), b->pair_q, P * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pe.data(), b->pair_e, P * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pm.data(), b->p_meta, P * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ps.data(), b->p_score, P * 8, hipMemcpyDeviceToHost));
+  size_t w = 0;
+  if (R) {
+    std::vector<uint2> pr(R);
+    std::vector<uint32_t> pm(R), ev(dl->nentries);
+    std::vector<double> ps(R);
+    HIP_TRY(hipMemcpy(pr.data(), b->raw, R * sizeof(uint2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pm.data(), b->p_meta, R * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ps.data(), b->p_score, R * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ev.data(), dl->ent_vocab, (size_t)dl->nentries * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < P; ++i) {
-      anx_pair& r = res[i];
-      r.query = b->order[pq[i]];
-      r.vocab_id = ev[pe[i]];
+    for (size_t i = 0; i < R; ++i) {
+      if (pm[i] == META_SKIPPED || w >= b->n_pairs) continue;
+      anx_pair& r = res[w++];
+      r.query = b->order[pr[i].x];
+      r.vocab_id = ev[pr[i].y & 0x7FFFFFFFu];
       const uint32_t ld = pm[i] & 0x7F;
       r.ld = ld == PAIR_NONE ? (int16_t)-1 : (int16_t)ld;
       r.samecase = (pm[i] >> 7) & 1;
@@ -1005,7 +1218,7 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
     }
   }
   *out = res;
-  *n = P;
+  *n = w;
   return ANX_OK;
 }
 
@@ -1017,7 +1230,7 @@ int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32
   const uint64_t total = (uint64_t)b->nq * stride;
   if (total)
     hipLaunchKernelGGL(k_export_topk, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), (uint32_t)b->nq, stride, b->qoff, b->r_count,
+                       reinterpret_cast<hipStream_t>(stream), (uint32_t)b->nq, stride, b->soff, b->r_count,
                        b->r_entry, b->r_dist, b->r_freq, dl->ent_vocab, b->q_orig,
                        static_cast<anx_topk_record*>(dst));
   HIP_TRY(hipGetLastError());
@@ -1029,11 +1242,11 @@ void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 void batch_free(Batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  free_pair_buffers(b);
-  for (void* p : {(void*)b->q_cv, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles,
-                  (void*)b->counters, (void*)b->qcount, (void*)b->qexact, (void*)b->qoff,
-                  (void*)b->qcur, (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->r_count,
-                  (void*)b->r_off})
+  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->d_work,
+                  (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
+                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta,
+                  (void*)b->c_entry, (void*)b->c_score, (void*)b->r_entry, (void*)b->r_dist, (void*)b->r_freq,
+                  (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) (void)hipFree(p);
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);

@@ -339,9 +339,10 @@ int HostModel::build_index(std::string& err) {
   });
 
   lex.nclasses = (uint32_t)tmp.size();
-  lex.cstride = ((lex.nclasses + 1023u) & ~1023u) + 1024u;  // + one workgroup chunk of never-matching padding
+  lex.cstride = ((lex.nclasses + 2047u) & ~2047u) + 2048u;  // + one workgroup chunk (<= 2048) of never-matching padding
   lex.cls_planes.assign((size_t)lex.nplanes * lex.cstride, 0xFFFFFFFFu);  // padding classes never match
-  lex.cls_len.resize(lex.nclasses);
+  lex.cls_len.assign(lex.cstride, 255);
+  lex.cls_bits.assign((size_t)4 * lex.cstride, 0u);
   lex.cls_off.assign(lex.nclasses + 1, 0);
   lex.cls_value.resize(lex.nclasses);
   for (int c = 0; c <= kMaxSymbols + 1; ++c) lex.bucket_begin[c] = 0;
@@ -353,6 +354,10 @@ int HostModel::build_index(std::string& err) {
       lex.cls_planes[(size_t)p * lex.cstride + r] = wv;
     }
     lex.cls_len[r] = (uint8_t)t.charcount;
+    if (lex.nsym <= 32)
+      for (int sidx = 0; sidx < lex.nsym; ++sidx)
+        for (int tp = 0; tp < 4; ++tp)
+          if ((uint8_t)t.cv[(size_t)sidx] > tp) lex.cls_bits[(size_t)tp * lex.cstride + r] |= 1u << sidx;
     lex.bucket_begin[t.charcount + 1]++;
     class_of_cv.emplace(t.cv, r);
     lex.cls_value[r] = std::move(t.value);

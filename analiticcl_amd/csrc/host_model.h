@@ -61,7 +61,8 @@ struct LexiconImage {
   uint32_t nclasses = 0, nentries = 0;
   std::vector<uint32_t> cls_planes;     // [nplanes][cstride] packed u8 counts
   uint32_t cstride = 0;
-  std::vector<uint8_t> cls_len;         // charcount per class
+  std::vector<uint32_t> cls_bits;       // [4][cstride] thermometer planes: bit s of plane t = (count_s > t); nsym <= 32 only
+  std::vector<uint8_t> cls_len;         // [cstride] charcount per class (padding classes: 255)
   std::vector<uint32_t> cls_off;        // CSR class -> entries, nclasses+1
   uint32_t bucket_begin[kMaxSymbols + 2];  // class-rank range per charcount
   std::vector<uint32_t> ent_vocab;      // vocab id
