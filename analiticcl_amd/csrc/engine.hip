@@ -132,12 +132,16 @@ typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant
 //   ONE global atomic per chunk (a single contended counter word sustains only ~88 M atomics/s).
 // ------------------------------------------------------------------------------------------------
 struct WaveOut {
-  uint32_t base, left;  // current chunk of the pair list (wave-uniform)
+  uint32_t base, left;  // unused part of the current chunk of the pair list (wave-uniform)
   uint32_t emitted;     // pairs appended by this wave (wave-uniform)
+  uint32_t nbase;       // chunk reserved by the last wave_reserve when the appended run spills over
+  uint32_t split;       // run indices < split go to [base..), the rest to [nbase..)
 };
-// Wave-wide exclusive prefix sum of ntot + chunk reservation.  Returns this lane's first slot.
-__device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane, uint2* __restrict__ raw,
-                                        uint32_t raw_cap, uint32_t* __restrict__ counters, bool* have) {
+// Wave-wide exclusive prefix sum of ntot + chunk reservation.  Returns this lane's first index g in the
+// wave's appended run; wave_slot(g) maps run indices to pair-list slots.  A run that does not fit in the
+// rest of the current chunk fills it up and continues in a freshly reserved chunk (ONE global atomic).
+__device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane, uint32_t* __restrict__ counters,
+                                        uint32_t* total_out) {
   uint32_t incl = ntot;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -145,22 +149,31 @@ __device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane
     if (lane >= (uint32_t)o) incl += u;
   }
   const uint32_t total = __shfl(incl, 63);
-  *have = total != 0;
-  if (total == 0) return 0;
-  if (total > w.left) {  // close the current chunk (mark its tail invalid), reserve a new one
-    for (uint32_t i = lane; i < w.left; i += 64)
-      if (w.base + i < raw_cap) raw[w.base + i] = make_uint2(RAW_INVALID, 0u);
-    const uint32_t need = total > SCAN_CHUNK ? total : SCAN_CHUNK;
+  *total_out = total;
+  w.split = w.left;
+  if (total > w.left) {
+    const uint32_t rest = total - w.left;
+    const uint32_t need = rest > SCAN_CHUNK ? rest : SCAN_CHUNK;
     uint32_t b = 0;
     if (lane == 0) b = atomicAdd(&counters[CTR_RAW], need);
-    w.base = __shfl(b, 0);
-    w.left = need;
+    w.nbase = __shfl(b, 0);
   }
-  const uint32_t pos = w.base + incl - ntot;
-  w.base += total;
-  w.left -= total;
+  return incl - ntot;
+}
+__device__ inline uint32_t wave_slot(const WaveOut& w, uint32_t g) {
+  return g < w.split ? w.base + g : w.nbase + (g - w.split);
+}
+__device__ inline void wave_commit(WaveOut& w, uint32_t total) {
+  if (total > w.left) {
+    const uint32_t rest = total - w.left;
+    const uint32_t need = rest > SCAN_CHUNK ? rest : SCAN_CHUNK;
+    w.base = w.nbase + rest;
+    w.left = need - rest;
+  } else {
+    w.base += total;
+    w.left -= total;
+  }
   w.emitted += total;
-  return pos;
 }
 __device__ inline void wave_close(const WaveOut& w, uint32_t lane, uint2* __restrict__ raw, uint32_t raw_cap,
                                   uint32_t* __restrict__ counters) {
@@ -207,7 +220,7 @@ __device__ inline void scan_bits_body(const ScanArgs& A, const Tile& t, uint32_t
   const uint32_t* __restrict__ cls_off = A.cls_off;
   uint2* __restrict__ raw = A.raw;
   const uint32_t cstride = A.cstride, raw_cap = A.raw_cap;
-  WaveOut wo{0, 0, 0};
+  WaveOut wo{0, 0, 0, 0, 0};
   uint32_t qn = 0;  // queued hits of this wave (wave-uniform)
   const int32_t lqk = (int32_t)t.lq - (int32_t)t.k;
   cptr_u32 qbase = (cptr_u32)(q_bits + (size_t)t.q0 * NBITPLANES);
@@ -242,18 +255,21 @@ __device__ inline void scan_bits_body(const ScanArgs& A, const Tile& t, uint32_t
           }
         }
       }
-      bool have;
-      uint32_t pos = wave_reserve(wo, ntot, lane, raw, raw_cap, A.counters, &have);
-      if (have && ntot) {
+      uint32_t total;
+      uint32_t g = wave_reserve(wo, ntot, lane, A.counters, &total);
+      if (ntot) {
         const uint32_t q = t.q0 + qi;
         if (A.want_exact && exmask) A.qexact[q] = 1;  // benign race: every writer stores 1
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           const uint32_t exact = (exmask >> j) & 1u ? 0x80000000u : 0u;
-          for (uint32_t i = 0; i < n[j]; ++i, ++pos)
+          for (uint32_t i = 0; i < n[j]; ++i, ++g) {
+            const uint32_t pos = wave_slot(wo, g);
             if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
+          }
         }
       }
+      wave_commit(wo, total);
     }
     qn = 0;
   };
@@ -314,7 +330,7 @@ __device__ inline void scan_sad_body(const ScanArgs& A, const Tile& t, uint32_t 
   const uint32_t* __restrict__ cls_off = A.cls_off;
   uint2* __restrict__ raw = A.raw;
   const uint32_t cstride = A.cstride, raw_cap = A.raw_cap;
-  WaveOut wo{0, 0, 0};
+  WaveOut wo{0, 0, 0, 0, 0};
   const uint32_t k = t.k;
   cptr_u32 qbase = (cptr_u32)(A.q_cv + (size_t)t.q0 * NP);
   for (uint32_t cb = cbeg; cb < cend; cb += 256 * CPL) {
@@ -362,18 +378,21 @@ __device__ inline void scan_sad_body(const ScanArgs& A, const Tile& t, uint32_t 
             }
           }
         }
-        bool have;
-        uint32_t pos = wave_reserve(wo, ntot, lane, raw, raw_cap, A.counters, &have);
-        if (have && ntot) {
+        uint32_t total;
+        uint32_t g = wave_reserve(wo, ntot, lane, A.counters, &total);
+        if (ntot) {
           const uint32_t q = t.q0 + qi;
           if (A.want_exact && exmask) A.qexact[q] = 1;
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
             const uint32_t exact = (exmask >> j) & 1u ? 0x80000000u : 0u;
-            for (uint32_t i = 0; i < n[j]; ++i, ++pos)
+            for (uint32_t i = 0; i < n[j]; ++i, ++g) {
+              const uint32_t pos = wave_slot(wo, g);
               if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
+            }
           }
         }
+        wave_commit(wo, total);
       }
     }
   }
