@@ -83,6 +83,7 @@ struct Batch {
   uint32_t qw = 1;                 // uint4 words per query row
   uint32_t dmax = 0;
   uint64_t n_class_tests = 0;
+  uint64_t n_tests_kind[NBITPLANES + 1] = {};
   // device: queries
   uint32_t* q_cv = nullptr;        // [nq][nplanes]
   uint32_t* q_bits = nullptr;      // [nq][NBITPLANES]
@@ -978,6 +979,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
       b->tiles.push_back(t);
       for (uint32_t cb = c0; cb < c1; cb += seg) b->work.push_back(Work{ti, cb, std::min(c1, cb + seg), kind});
       b->n_class_tests += (uint64_t)t.nq * (c1 - c0);
+      b->n_tests_kind[kind] += (uint64_t)t.nq * (c1 - c0);
     }
     i = j;
   }
@@ -1159,6 +1161,9 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   s.n_class_tests = b->n_class_tests;
   s.n_results = total_results;
   s.n_scan_blocks = b->work.size();
+  for (int i = 0; i <= NBITPLANES; ++i) s.n_tests_kind[i] = b->n_tests_kind[i];
+  s.n_pair_slots = nraw;
+  s.n_survivors = total_surv;
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.ms_score, b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&s.ms_group, b->ev[2], b->ev[3]);

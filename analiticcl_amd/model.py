@@ -134,7 +134,7 @@ class Batch:
     def stats(self) -> dict:
         s = L.BatchStats()
         L.check(L.lib().anx_batch_get_stats(self.h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in L.BatchStats._fields_}
+        return {k: (list(getattr(s, k)) if k == "n_tests_kind" else getattr(s, k)) for k, _ in L.BatchStats._fields_}
 
     def fetch(self) -> List[List[tuple]]:
         """-> per query, ranked [(vocab_id, dist_score, freq_score)]"""

@@ -167,6 +167,9 @@ typedef struct anx_batch_stats {
   uint64_t n_class_tests;    /* (query,class) count-vector tests executed by the scan kernel */
   uint64_t n_results;        /* ranked results returned */
   uint64_t n_scan_blocks;    /* workgroups launched by the scan kernel */
+  uint64_t n_tests_kind[5];  /* class tests by scan body: [0] v_sad_u8 count vectors, [T] T thermometer bit planes */
+  uint64_t n_pair_slots;     /* pair-list slots written (scored pairs + unused chunk tails) */
+  uint64_t n_survivors;      /* pairs with score >= score_threshold */
   float ms_scan, ms_group, ms_score, ms_rank, ms_total; /* HIP-event times of the last run */
 } anx_batch_stats;
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
