@@ -103,6 +103,8 @@ struct Batch {
   uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
   double* p_score = nullptr;       // per raw slot
   uint32_t* p_meta = nullptr;
+  uint32_t* sel = nullptr;         // indices of the pair-list slots that passed the prefilter
+  uint32_t* blockcount = nullptr;  // per 256-slot block: selected slots (+ scan scratch)
   size_t raw_cap = 0;
   uint32_t* c_entry = nullptr;     // survivors grouped by query
   double* c_score = nullptr;
@@ -300,6 +302,8 @@ __device__ inline void scan_bits_body(const ScanArgs& A, const Tile& t, uint32_t
       cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * NBITPLANES;
 #pragma unroll
       for (int p = 0; p < T; ++p) qnext[p] = qv[p];
+      // acc_j = common_j - threshold_j; a class hits iff acc_j >= 0.  The sign bits are combined with
+      // full-rate v_and_b32 (sign(best) == 1 iff every acc_j is negative) instead of half-rate v_max_i32.
       int32_t best = negthr[0];
 #pragma unroll
       for (int p = 0; p < T; ++p) best = bcnt_acc(qreg[p] & cp[0][p], best);
@@ -308,7 +312,7 @@ __device__ inline void scan_bits_body(const ScanArgs& A, const Tile& t, uint32_t
         int32_t acc = negthr[j];
 #pragma unroll
         for (int p = 0; p < T; ++p) acc = bcnt_acc(qreg[p] & cp[j][p], acc);
-        best = max(best, acc);
+        best &= acc;
       }
       const unsigned long long hitmask = __ballot(best >= 0);
       if (hitmask) {  // wave-uniform
@@ -495,35 +499,155 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t* __restrict_
 //   longest_common_substring_length / common_prefix_length / common_suffix_length: src/distance.rs:181-231.
 //   Score: src/lib.rs:1433-1452 (f64, same association, no FMA contraction).
 // ------------------------------------------------------------------------------------------------
-struct ScoreArgs {
-  double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
-  double score_threshold;
-  int have_freq, stop;
-  uint32_t lqp, lcp;   // bytes reserved per lane for the query / candidate row (multiples of 16)
-  uint32_t stride;     // bytes per lane (odd number of dwords: conflict-free ds access)
-  uint32_t qw;
-};
+// ------------------------------------------------------------------------------------------------
+// K2: prefilter + selection.  A necessary condition for damerau_levenshtein(q, c) <= d (src/distance.rs:101-179):
+// every optimal edit script matches all but <= d symbols of q (and of c) to an EQUAL symbol of the other string
+// at an offset within +-d (each unmatched symbol costs one deletion/insertion/substitution; transposed symbols
+// are equal symbols within the offset bound).  So count the positions of q that have no equal symbol of c in
+// [i-d, i+d] (and vice versa); more than d of them => the reference returns None.  Pure register SWAR over the
+// two 16-byte rows (7 byte-shifts with v_alignbyte_b32, zero-byte detection), no LDS, no DP.  On config 2 it
+// rejects ~2/3 of the pairs; the banded DP then runs only on the selected third.  Strings longer than 16
+// symbols or d > 3 are passed through unfiltered.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t META_PENDING = 0xFFFFFFFEu;  // selected for k_score_pairs
 #define PAIR_NONE 0x7Fu
 
-__global__ void k_score_pairs(uint32_t nraw, const uint2* __restrict__ raw, const uint32_t* __restrict__ qexact,
-                              const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
-                              const uint32_t* __restrict__ ent_meta, const uint32_t* __restrict__ ent_rowoff,
-                              const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
-                              double* __restrict__ p_score, uint32_t* __restrict__ p_meta,
-                              uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv,
-                              uint32_t* __restrict__ counters) {
-  extern __shared__ uint32_t lds32[];
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool stop_skipped = false;
+__device__ inline uint32_t nonzero_bytes(uint32_t x) {  // bit 7 of every byte that is non-zero
+  return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+}
+__device__ inline uint32_t len_mask(int len, int k) {  // 0x80 in every byte position (4k..4k+3) below len
+  const int n = len - 4 * k;
+  return n >= 4 ? 0x80808080u : n <= 0 ? 0u : (0x80808080u & ((1u << (8 * n)) - 1u));
+}
+
+template <int DELTA>
+__device__ inline void filter_shift(const uint32_t (&q)[4], const uint32_t (&c)[6], bool enabled, uint32_t (&nmA)[4],
+                                    uint32_t (&nmB)[4]) {
+  uint32_t nz[6];
+  nz[0] = 0xFFFFFFFFu;
+  nz[5] = 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t cs;  // bytes C[4k + DELTA ..]
+    if (DELTA == 0) cs = c[k + 1];
+    else if (DELTA > 0) cs = __builtin_amdgcn_alignbyte(c[k + 2], c[k + 1], DELTA);
+    else cs = __builtin_amdgcn_alignbyte(c[k + 1], c[k], 4 + DELTA);
+    const uint32_t v = nonzero_bytes(q[k] ^ cs);  // bit7 set where q[i] != c[i + DELTA]
+    nz[k + 1] = enabled ? v : 0xFFFFFFFFu;
+    nmA[k] &= nz[k + 1];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // the same comparisons seen from c: position j pairs with i = j - DELTA
+    uint32_t b;
+    if (DELTA == 0) b = nz[k + 1];
+    else if (DELTA > 0) b = __builtin_amdgcn_alignbyte(nz[k + 1], nz[k], 4 - DELTA);
+    else b = __builtin_amdgcn_alignbyte(nz[k + 2], nz[k + 1], -DELTA);
+    nmB[k] &= b;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_prefilter(uint32_t nraw, const uint2* __restrict__ raw,
+                                                   const uint32_t* __restrict__ qexact, int stop, int enable,
+                                                   const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
+                                                   uint32_t qw, const uint32_t* __restrict__ ent_meta,
+                                                   const uint32_t* __restrict__ ent_rowoff, const uint4* __restrict__ rows,
+                                                   double* __restrict__ p_score, uint32_t* __restrict__ p_meta,
+                                                   uint32_t* __restrict__ blockcount, uint32_t* __restrict__ counters) {
+  __shared__ uint32_t s_cnt[4];
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  bool selected = false, stop_skipped = false;
+  int d = 0, lq = 0, lc = 0;
+  uint32_t q4[4] = {0, 0, 0, 0}, c6[6] = {0xFFFFFFFFu, 0, 0, 0, 0, 0xFFFFFFFFu};
+  bool filt = false;
   if (p < nraw) {
     const uint2 rp = raw[p];
     const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
     // unused chunk tail, or (StopAtExactMatch, src/lib.rs:1164-1173) a non-exact class of a query that has one
-    const bool skip = q == RAW_INVALID || (a.stop && !(rp.y & 0x80000000u) && qexact[q] != 0);
-    uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
-    double score = __builtin_nan("");
+    const bool skip = q == RAW_INVALID || (stop && !(rp.y & 0x80000000u) && qexact[q] != 0);
     stop_skipped = skip && q != RAW_INVALID;
     if (!skip) {
+      const uint32_t qm = q_meta[q], em = ent_meta[e];
+      lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
+      const int diff = lq > lc ? lq - lc : lc - lq;
+      selected = diff <= d;  // src/distance.rs:109-130
+      filt = selected && enable && d <= 3 && lq <= 16 && lc <= 16;
+      if (filt) {
+        const uint4 Q = q_rows[(size_t)q * qw];
+        const uint4 C = rows[ent_rowoff[e]];
+        q4[0] = Q.x; q4[1] = Q.y; q4[2] = Q.z; q4[3] = Q.w;
+        c6[1] = C.x; c6[2] = C.y; c6[3] = C.z; c6[4] = C.w;
+      }
+    }
+    p_score[p] = __builtin_nan("");
+    if (skip) p_meta[p] = META_SKIPPED;
+  }
+  if (__any(filt)) {  // wave-uniform
+    uint32_t nmA[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t nmB[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    filter_shift<0>(q4, c6, true, nmA, nmB);
+    if (__any(filt && d >= 1)) { filter_shift<1>(q4, c6, d >= 1, nmA, nmB); filter_shift<-1>(q4, c6, d >= 1, nmA, nmB); }
+    if (__any(filt && d >= 2)) { filter_shift<2>(q4, c6, d >= 2, nmA, nmB); filter_shift<-2>(q4, c6, d >= 2, nmA, nmB); }
+    if (__any(filt && d >= 3)) { filter_shift<3>(q4, c6, d >= 3, nmA, nmB); filter_shift<-3>(q4, c6, d >= 3, nmA, nmB); }
+    int unA = 0, unB = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unA += __popc(nmA[k] & len_mask(lq, k));
+      unB += __popc(nmB[k] & len_mask(lc, k));
+    }
+    if (filt && (unA > d || unB > d)) selected = false;
+  }
+  if (p < nraw && !stop_skipped && raw[p].x != RAW_INVALID)
+    p_meta[p] = selected ? META_PENDING : (PAIR_NONE | (1u << 7));  // rejected: ld = None, samecase = true
+  const unsigned long long m = __ballot(selected);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) blockcount[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops; only that mode pays an atomic
+  if (stop) {
+    const unsigned long long ms = __ballot(stop_skipped);
+    if ((threadIdx.x & 63) == 0 && ms) atomicAdd(&counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
+  }
+}
+
+// K2b: selected slots -> dense index list (block offsets from the exclusive scan of blockcount)
+__global__ __launch_bounds__(256) void k_select(uint32_t nraw, const uint32_t* __restrict__ p_meta,
+                                                const uint32_t* __restrict__ blockoff, uint32_t* __restrict__ sel) {
+  __shared__ uint32_t s_cnt[4];
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const bool selected = p < nraw && p_meta[p] == META_PENDING;
+  const unsigned long long m = __ballot(selected);
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wid] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t base = blockoff[blockIdx.x];
+  for (uint32_t i = 0; i < wid; ++i) base += s_cnt[i];
+  if (selected) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+}
+
+struct ScoreArgs {
+  double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
+  double score_threshold;
+  int have_freq;
+  uint32_t lqp, lcp;   // bytes reserved per lane for the query / candidate row (multiples of 16)
+  uint32_t stride;     // bytes per lane (odd number of dwords: conflict-free ds access)
+  uint32_t qw;
+};
+
+__global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, const uint2* __restrict__ raw,
+                              const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
+                              const uint32_t* __restrict__ ent_meta, const uint32_t* __restrict__ ent_rowoff,
+                              const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
+                              double* __restrict__ p_score, uint32_t* __restrict__ p_meta,
+                              uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv) {
+  extern __shared__ uint32_t lds32[];
+  const uint32_t i_sel = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i_sel < nsel) {
+    const uint32_t p = sel[i_sel];
+    const uint2 rp = raw[p];
+    const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+    uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
+    double score = __builtin_nan("");
+    {
       uint8_t* S = reinterpret_cast<uint8_t*>(lds32) + (size_t)threadIdx.x * a.stride;
       uint8_t* T = S + a.lqp;
       uint8_t* R = T + a.lcp;
@@ -635,26 +759,22 @@ __global__ void k_score_pairs(uint32_t nraw, const uint2* __restrict__ raw, cons
       }
     }
     p_score[p] = score;
-    p_meta[p] = skip ? META_SKIPPED : (ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24));
-  }
-  // scored pairs (= damerau_levenshtein invocations of the reference) = pairs emitted by the scan minus the
-  // ones StopAtExactMatch drops here; only that (rare) mode pays an atomic
-  if (a.stop) {
-    const unsigned long long m = __ballot(stop_skipped);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[CTR_SKIPPED], (uint32_t)__popcll(m));
+    p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
 }
 
 // K3b: gather the survivors (score >= threshold) into per-query segments.  Order inside a query is
 // arbitrary; ranking uses a total order whose last key is ent_order (= reference enumeration order).
-__global__ __launch_bounds__(256) void k_compact(uint32_t nraw, const uint2* __restrict__ raw,
-                                                 const double* __restrict__ p_score, double thr,
-                                                 const uint32_t* __restrict__ soff, uint32_t* __restrict__ qcur,
-                                                 uint32_t* __restrict__ c_entry, double* __restrict__ c_score) {
-  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= nraw) return;
+__global__ __launch_bounds__(256) void k_compact(uint32_t nsel, const uint32_t* __restrict__ sel,
+                                                 const uint2* __restrict__ raw, const double* __restrict__ p_score,
+                                                 double thr, const uint32_t* __restrict__ soff,
+                                                 uint32_t* __restrict__ qcur, uint32_t* __restrict__ c_entry,
+                                                 double* __restrict__ c_score) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nsel) return;
+  const uint32_t r = sel[i];
   const double s = p_score[r];
-  if (!(s >= thr)) return;  // NaN = pruned / skipped
+  if (!(s >= thr)) return;  // NaN = pruned
   const uint2 v = raw[r];
   const uint32_t pos = soff[v.x] + atomicAdd(&qcur[v.x], 1u);
   c_entry[pos] = v.y & 0x7FFFFFFFu;
@@ -1030,11 +1150,13 @@ static void launch_scan(const ScanArgs& A, uint32_t nwork, hipStream_t st) {
 
 static int ensure_raw(Batch* b, size_t cap, std::string& err) {
   if (cap <= b->raw_cap) return ANX_OK;
-  for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta})
+  for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->sel, (void*)b->blockcount})
     if (p) (void)hipFree(p);
-  b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->raw_cap = 0;
+  b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->sel = nullptr; b->blockcount = nullptr; b->raw_cap = 0;
   int rc;
-  if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err))) return rc;
+  const size_t nblk = cap / 256 + 2;
+  if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err)) ||
+      (rc = dalloc(&b->sel, cap, err)) || (rc = dalloc(&b->blockcount, 2 * nblk + nblk / SCAN_TILE + 16, err))) return rc;
   b->raw_cap = cap;
   return ANX_OK;
 }
@@ -1109,7 +1231,6 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   sa.w_sum = m.weights.ld + m.weights.lcs + m.weights.prefix + m.weights.suffix + m.weights.casew;  // src/types.rs:69-73
   sa.score_threshold = b->params.score_threshold;
   sa.have_freq = m.have_freq ? 1 : 0;
-  sa.stop = stop;
   sa.lqp = b->qw * 16;
   sa.lcp = (dl->max_len + 15) / 16 * 16;
   const uint32_t d = b->dmax;
@@ -1121,10 +1242,25 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   uint32_t threads = 256;
   while (threads > 64 && (size_t)threads * sa.stride > 64 * 1024) threads >>= 1;
   if ((size_t)threads * sa.stride > 64 * 1024) { err = "per-lane scoring state exceeds the LDS budget"; return ANX_ELIMIT; }
-  if (nraw)
-    hipLaunchKernelGGL(k_score_pairs, dim3((nraw + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nraw,
-                       b->raw, b->qexact, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
-                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->counters);
+  // prefilter + selection (ANX_PREFILTER=0 disables the filter: every length-compatible pair goes to the DP)
+  uint32_t nsel = 0;
+  if (nraw) {
+    static const int enable_filter = []() { const char* e = getenv("ANX_PREFILTER"); return (e && e[0] == '0') ? 0 : 1; }();
+    const uint32_t nblk = (nraw + 255) / 256;
+    uint32_t* blockoff = b->blockcount + nblk + 1;
+    uint32_t* tmp = blockoff + nblk + 1;
+    hipLaunchKernelGGL(k_prefilter, dim3(nblk), dim3(256), 0, st, nraw, b->raw, b->qexact, stop, enable_filter, b->q_meta,
+                       b->q_rows, b->qw, dl->ent_meta, dl->ent_rowoff, dl->rows, b->p_score, b->p_meta, b->blockcount,
+                       b->counters);
+    exclusive_scan(b->blockcount, nblk, blockoff, tmp, st);
+    HIP_TRY(hipMemcpyAsync(&nsel, blockoff + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_select, dim3(nblk), dim3(256), 0, st, nraw, b->p_meta, blockoff, b->sel);
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (nsel)
+    hipLaunchKernelGGL(k_score_pairs, dim3((nsel + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nsel,
+                       b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
+                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv);
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors -----------------------------------------------------------------------------
   exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
@@ -1135,8 +1271,8 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   b->n_pairs = (uint64_t)h_counters[CTR_VALID] - h_counters[CTR_SKIPPED];
   b->n_surv = total_surv;
   if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
-  if (nraw)
-    hipLaunchKernelGGL(k_compact, dim3((nraw + 255) / 256), dim3(256), 0, st, nraw, b->raw, b->p_score,
+  if (nsel)
+    hipLaunchKernelGGL(k_compact, dim3((nsel + 255) / 256), dim3(256), 0, st, nsel, b->sel, b->raw, b->p_score,
                        b->params.score_threshold, b->soff, b->qcur, b->c_entry, b->c_score);
   HIP_TRY(hipEventRecord(b->ev[3], st));
   // ---- rank ------------------------------------------------------------------------------------------
@@ -1268,7 +1404,7 @@ void batch_free(Batch* b) {
   (void)hipSetDevice(b->device);
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->d_work,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
-                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta,
+                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->sel, (void*)b->blockcount,
                   (void*)b->c_entry, (void*)b->c_score, (void*)b->r_entry, (void*)b->r_dist, (void*)b->r_freq,
                   (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) (void)hipFree(p);

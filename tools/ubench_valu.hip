@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed) {
       if (OP == 13) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
       if (OP == 14) asm volatile("v_cmp_le_u32 vcc, %0, %1" :: "v"(a[i]), "v"(x) : "vcc");
       if (OP == 15) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+      if (OP == 16) asm volatile("v_and_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]), "=&v"(f[i]) : "s"(seed), "v"(y));
+      if (OP == 17) asm volatile("v_and_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]), "=&v"(f[i]) : "v"(x), "v"(y));
+      if (OP == 18) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+      if (OP == 19) asm volatile("v_max_i32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
     }
   }
   uint32_t r = 0;
@@ -75,5 +79,9 @@ int main() {
   run<12>("v_pk_add_u16", 1, d);
   run<14>("v_cmp_le_u32", 1, d);
   run<15>("v_dot4_u32_u8", 1, d);
+  run<18>("v_and_b32 (sgpr src)", 1, d);
+  run<19>("v_max_i32", 1, d);
+  run<16>("and(sgpr)+bcnt pair", 2, d);
+  run<17>("and(vgpr)+bcnt pair", 2, d);
   return 0;
 }
