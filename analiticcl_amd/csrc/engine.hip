@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <type_traits>
 
 #include "engine.h"
@@ -1036,59 +1037,107 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   b->status.assign(n, 0);
   const int NP = dl->nplanes;
   const bool bits_ok = dl->nsym <= 32 && !scan_mode();
+  // ---- host encoding, threaded: normalisation (src/anahash.rs:50-80), count vector, threshold clamps -------
   struct Enc {
-    std::vector<uint8_t> norm, cv;
-    uint32_t orig;
-    uint32_t meta;
-    uint32_t kind;  // 0 = SAD kernel, 1..NBITPLANES = bit-plane kernel with T = kind planes
+    uint32_t meta;   // len | k<<8 | d<<16 | first_is_lower<<24 ; 0 = not encodable
+    uint32_t key;    // kind*256 + len : bucket for the counting sort
+    uint32_t off;    // offset of the norm string in its thread's arena
+    uint16_t thread;
   };
-  std::vector<Enc> enc;
-  enc.reserve(n);
-  size_t maxlen = 1;
-  for (size_t i = 0; i < n; ++i) {
-    Enc e;
-    e.orig = (uint32_t)i;
-    if (!utf8[i] || !m.encode(utf8[i], e.norm, e.cv)) { b->status[i] = ANX_ELIMIT; continue; }
-    if (e.norm.empty()) { b->status[i] = ANX_EEMPTY; continue; }
-    const int len = (int)e.norm.size();
-    const int k = clamp_threshold(p.max_anagram_distance, len, kMaxAnagramDistance);
-    const int d = clamp_threshold(p.max_edit_distance, len, kMaxEditDistance);
-    e.meta = (uint32_t)len | ((uint32_t)k << 8) | ((uint32_t)d << 16) |
-             (first_char_is_lowercase(utf8[i]) ? 1u << 24 : 0u);
-    uint32_t maxcount = 0;
-    for (uint8_t c : e.cv) maxcount = std::max<uint32_t>(maxcount, c);
-    e.kind = (bits_ok && maxcount <= (uint32_t)NBITPLANES) ? maxcount : 0;
-    maxlen = std::max(maxlen, e.norm.size());
-    b->dmax = std::max<uint32_t>(b->dmax, (uint32_t)d);
-    enc.push_back(std::move(e));
+  std::vector<Enc> enc(n);
+  unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  if (n < 4096) nthreads = 1;
+  std::vector<std::vector<uint8_t>> arena(nthreads);
+  const int A = m.alphabet.size();
+  const size_t cvbytes = (size_t)NP * 4;
+  std::vector<uint8_t> cv_all(n * cvbytes, 0);
+  auto encode_range = [&](unsigned tid, size_t lo, size_t hi) {
+    std::vector<uint8_t>& ar = arena[tid];
+    ar.reserve((hi - lo) * 12);
+    int16_t codes[kMaxSymbols];
+    for (size_t i = lo; i < hi; ++i) {
+      Enc& e = enc[i];
+      e.meta = 0; e.key = 0; e.off = 0; e.thread = (uint16_t)tid;
+      const int len = utf8[i] ? m.alphabet.scan_into(utf8[i], strlen(utf8[i]), codes, kMaxSymbols) : -1;
+      if (len < 0) { b->status[i] = ANX_ELIMIT; continue; }
+      if (len == 0) { b->status[i] = ANX_EEMPTY; continue; }
+      uint8_t* cv = &cv_all[i * cvbytes];
+      e.off = (uint32_t)ar.size();
+      uint32_t maxcount = 0;
+      for (int s = 0; s < len; ++s) {
+        ar.push_back((uint8_t)(codes[s] >= 0 ? codes[s] : A + 1));                     // src/anahash.rs:76
+        const uint8_t c = ++cv[(size_t)(codes[s] >= 0 ? codes[s] : A)];                // src/anahash.rs:42
+        maxcount = std::max<uint32_t>(maxcount, c);
+      }
+      const int k = clamp_threshold(p.max_anagram_distance, len, kMaxAnagramDistance);
+      const int d = clamp_threshold(p.max_edit_distance, len, kMaxEditDistance);
+      e.meta = (uint32_t)len | ((uint32_t)k << 8) | ((uint32_t)d << 16) |
+               (first_char_is_lowercase(utf8[i]) ? 1u << 24 : 0u);
+      const uint32_t kind = (bits_ok && maxcount <= (uint32_t)NBITPLANES) ? maxcount : 0;
+      e.key = kind * 256 + (uint32_t)len;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; ++t) {
+      const size_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+      if (nthreads == 1) encode_range(0, lo, hi);
+      else th.emplace_back(encode_range, t, lo, hi);
+    }
+    for (auto& x : th) x.join();
   }
-  // (kernel kind, length)-bucketed order (stable): queries of one bucket share k, d and the class window
-  std::stable_sort(enc.begin(), enc.end(), [](const Enc& x, const Enc& y) {
-    if (x.kind != y.kind) return x.kind < y.kind;
-    return (x.meta & 0xFF) < (y.meta & 0xFF);
-  });
-  const size_t nq = enc.size();
+  // (kernel kind, length)-bucketed order, stable (counting sort): a bucket shares k, d and the class window
+  constexpr uint32_t NKEYS = (NBITPLANES + 1) * 256;
+  std::vector<size_t> kstart(NKEYS + 1, 0);
+  size_t maxlen = 1;
+  for (size_t i = 0; i < n; ++i)
+    if (enc[i].meta) {
+      kstart[enc[i].key + 1]++;
+      maxlen = std::max<size_t>(maxlen, enc[i].meta & 0xFF);
+      b->dmax = std::max<uint32_t>(b->dmax, (enc[i].meta >> 16) & 0xFF);
+    }
+  for (uint32_t kx = 0; kx < NKEYS; ++kx) kstart[kx + 1] += kstart[kx];
+  const size_t nq = kstart[NKEYS];
   b->nq = nq;
   b->qw = (uint32_t)((maxlen + 15) / 16);
-  std::vector<uint32_t> h_cv(nq * (size_t)NP, 0), h_bits(nq * (size_t)NBITPLANES, 0), h_meta(nq), h_orig(nq);
+  std::vector<uint32_t> h_cv(nq * (size_t)NP, 0), h_bits(nq * (size_t)NBITPLANES, 0), h_meta(nq), h_orig(nq), h_kind(nq);
   std::vector<uint8_t> h_rows(nq * (size_t)b->qw * 16, 0xFE);
   b->order.resize(nq);
-  for (size_t i = 0; i < nq; ++i) {
-    memcpy(&h_cv[i * (size_t)NP], enc[i].cv.data(), std::min(enc[i].cv.size(), (size_t)NP * 4));
-    for (size_t s = 0; s < enc[i].cv.size() && s < 32; ++s)
-      for (uint32_t tp = 0; tp < (uint32_t)NBITPLANES; ++tp)
-        if (enc[i].cv[s] > tp) h_bits[i * NBITPLANES + tp] |= 1u << s;
-    memcpy(&h_rows[i * (size_t)b->qw * 16], enc[i].norm.data(), enc[i].norm.size());
-    h_meta[i] = enc[i].meta;
-    h_orig[i] = enc[i].orig;
-    b->order[i] = enc[i].orig;
+  {
+    std::vector<size_t> cursor(kstart.begin(), kstart.end() - 1);
+    for (size_t i = 0; i < n; ++i)
+      if (enc[i].meta) b->order[cursor[enc[i].key]++] = (uint32_t)i;
+  }
+  auto fill_range = [&](size_t lo, size_t hi) {
+    for (size_t s = lo; s < hi; ++s) {
+      const size_t i = b->order[s];
+      const Enc& e = enc[i];
+      const uint8_t* cv = &cv_all[i * cvbytes];
+      memcpy(&h_cv[s * (size_t)NP], cv, cvbytes);
+      for (size_t sym = 0; sym < cvbytes && sym < 32; ++sym)
+        for (uint32_t tp = 0; tp < (uint32_t)NBITPLANES; ++tp)
+          if (cv[sym] > tp) h_bits[s * NBITPLANES + tp] |= 1u << sym;
+      memcpy(&h_rows[s * (size_t)b->qw * 16], &arena[e.thread][e.off], e.meta & 0xFF);
+      h_meta[s] = e.meta;
+      h_orig[s] = (uint32_t)i;
+      h_kind[s] = e.key >> 8;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; ++t) {
+      const size_t lo = nq * t / nthreads, hi = nq * (t + 1) / nthreads;
+      if (nthreads == 1) fill_range(lo, hi);
+      else th.emplace_back(fill_range, lo, hi);
+    }
+    for (auto& x : th) x.join();
   }
   // tiles (<= SCAN_TQ queries of one kind and length) and work items (tile x class segment)
   const int sad_cpl = NP <= 8 ? 4 : NP <= 16 ? 2 : 1;
   for (size_t i = 0; i < nq;) {
     size_t j = i;
-    while (j < nq && enc[j].kind == enc[i].kind && (h_meta[j] & 0xFF) == (h_meta[i] & 0xFF)) ++j;
-    const uint32_t kind = enc[i].kind, lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
+    while (j < nq && h_kind[j] == h_kind[i] && (h_meta[j] & 0xFF) == (h_meta[i] & 0xFF)) ++j;
+    const uint32_t kind = h_kind[i], lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     const uint32_t c0 = m.lex.bucket_begin[lo], c1 = m.lex.bucket_begin[hi + 1];
     const uint32_t cpl = kind == 0 ? (uint32_t)sad_cpl : (uint32_t)BITS_CPL[kind];

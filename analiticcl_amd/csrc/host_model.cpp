@@ -131,25 +131,43 @@ bool parse_alphabet(const std::string& tsv, Alphabet& out, std::string& err) {
     err = "alphabet has more than 166 classes (the reference's PRIMES table has 168 entries)";
     return false;
   }
+  out.index();
   return true;
 }
 
-bool Alphabet::scan(const char* text, size_t nbytes, std::vector<int16_t>& out) const {
-  out.clear();
-  int skip = 0;
+void Alphabet::index() {
+  for (auto& v : by_first) v.clear();
+  for (int c = 0; c < size(); ++c)
+    for (const AlphabetMember& m : classes[c])
+      if (!m.bytes.empty()) by_first[(unsigned char)m.bytes[0]].push_back(Cand{(int16_t)c, &m});
+}
+
+// Same result as trying every class and member in file order at each position (src/anahash.rs:25-39): only
+// members starting with the byte at `pos` can match, and by_first keeps them in file order.
+int Alphabet::scan_into(const char* text, size_t nbytes, int16_t* out, int cap) const {
+  int n = 0, skip = 0;
   for (size_t pos = 0; pos < nbytes; pos += (size_t)u8len((unsigned char)text[pos])) {
     if (skip > 0) { --skip; continue; }
     int hit = -1;
-    for (int c = 0; c < size() && hit < 0; ++c)
-      for (const AlphabetMember& m : classes[c])
-        if (pos + m.bytes.size() <= nbytes && memcmp(text + pos, m.bytes.data(), m.bytes.size()) == 0) {
-          hit = c;
-          skip = m.nchars - 1;
-          break;
-        }
-    if ((int)out.size() >= kMaxSymbols) return false;
-    out.push_back((int16_t)hit);
+    for (const Cand& cd : by_first[(unsigned char)text[pos]]) {
+      const AlphabetMember& m = *cd.m;
+      if (pos + m.bytes.size() <= nbytes && memcmp(text + pos, m.bytes.data(), m.bytes.size()) == 0) {
+        hit = cd.cls;
+        skip = m.nchars - 1;
+        break;
+      }
+    }
+    if (n >= cap) return -1;
+    out[n++] = (int16_t)hit;
   }
+  return n;
+}
+
+bool Alphabet::scan(const char* text, size_t nbytes, std::vector<int16_t>& out) const {
+  int16_t buf[kMaxSymbols];
+  const int n = scan_into(text, nbytes, buf, kMaxSymbols);
+  if (n < 0) { out.clear(); return false; }
+  out.assign(buf, buf + n);
   return true;
 }
 

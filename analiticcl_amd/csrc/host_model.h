@@ -24,10 +24,16 @@ struct AlphabetMember {
 struct Alphabet {
   std::vector<std::vector<AlphabetMember>> classes;  // file order; first byte-prefix match wins
   int size() const { return (int)classes.size(); }
+  // members whose first byte is b, in (class, member) file order: the scan only has to try these
+  struct Cand { int16_t cls; const AlphabetMember* m; };
+  std::vector<Cand> by_first[256];
+  void index();  // (re)builds by_first; called by parse_alphabet
   // Walks `text` exactly like str::anahash / str::normalize_to_alphabet (src/anahash.rs:16-80) and
   // returns, per consumed position, the class index or -1 for an unmatched character.
   // Returns false if more than kMaxSymbols symbols are produced.
   bool scan(const char* text, size_t nbytes, std::vector<int16_t>& out) const;
+  // allocation-free variant: writes into out[cap], returns the symbol count or -1 if it exceeds cap
+  int scan_into(const char* text, size_t nbytes, int16_t* out, int cap) const;
 };
 
 bool parse_alphabet(const std::string& tsv, Alphabet& out, std::string& err);  // src/lib.rs:369-407

@@ -150,6 +150,24 @@ class Batch:
         finally:
             L.lib().anx_results_free(rows, offs)
 
+    def fetch_arrays(self):
+        """-> (offsets[n+1], vocab_id[R], dist_score[R], freq_score[R]) as numpy arrays (CSR, batch order)"""
+        import numpy as np
+        rows = C.POINTER(L.Result)()
+        offs = C.POINTER(C.c_size_t)()
+        L.check(L.lib().anx_batch_fetch(self.h, C.byref(rows), C.byref(offs)))
+        try:
+            off = np.ctypeslib.as_array(offs, shape=(self.n + 1,)).astype(np.int64)
+            total = int(off[-1])
+            if total == 0:
+                z = np.zeros(0)
+                return off, z.astype(np.uint64), z, z
+            dt = np.dtype([("vocab_id", "<u8"), ("dist", "<f8"), ("freq", "<f8"), ("via", "<u8")])
+            a = np.frombuffer((C.c_char * (total * 32)).from_address(C.addressof(rows.contents)), dtype=dt).copy()
+            return off, a["vocab_id"], a["dist"], a["freq"]
+        finally:
+            L.lib().anx_results_free(rows, offs)
+
     def fetch_pairs(self) -> List[tuple]:
         """-> every scored pair (query, vocab_id, ld|-1, lcs, prefixlen, suffixlen, samecase, score)"""
         pairs = C.POINTER(L.Pair)()

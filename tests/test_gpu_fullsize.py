@@ -1,0 +1,102 @@
+"""Full-size run of BASELINE.json configs[1] (eng.aspell, 1 M synthetic queries len<=16, k=3 d=2 n=10) checked through
+size-independent properties + an oracle spot check (the oracle cannot finish 1 M queries in seconds)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import analiticcl_amd as A
+from analiticcl_amd import synth
+from oracle import cwrap as O
+
+N = 1_000_000
+
+
+def _checksum(off, vid, dist, freq):
+    h = np.uint64(1469598103934665603)
+    parts = (off.astype(np.uint64), vid.astype(np.uint64), dist.view(np.uint64), freq.view(np.uint64))
+    acc = np.uint64(0)
+    for i, p in enumerate(parts):
+        w = (np.arange(p.size, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(i + 1)) | np.uint64(1)
+        acc ^= np.bitwise_xor.reduce(p * w) if p.size else np.uint64(0)
+    return int(acc ^ h)
+
+
+@pytest.fixture(scope="module")
+def setup(data_dir):
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    g.build()
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    qs = synth.make_queries(words, N, max_len=16, seed=synth.SEED)
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    b = g.encode_batch(qs, p)
+    b.run()
+    return g, words, qs, p, b, b.fetch_arrays(), b.stats()
+
+
+def test_idempotent_and_counts(setup):
+    g, words, qs, p, b, (off, vid, dist, freq), st = setup
+    assert st["n_queries"] == N and off.size == N + 1
+    assert 80 * N < st["n_pairs"] < 130 * N      # ~100 scored pairs per query on this workload
+    assert st["n_results"] == off[-1]
+    c1 = _checksum(off, vid, dist, freq)
+    b.run()
+    off2, vid2, dist2, freq2 = b.fetch_arrays()
+    assert b.stats()["n_pairs"] == st["n_pairs"]
+    assert _checksum(off2, vid2, dist2, freq2) == c1   # pair-list order differs run to run, results must not
+
+
+def test_ranked_and_bounded(setup):
+    _g, _w, _qs, _p, _b, (off, vid, dist, freq), _st = setup
+    cnt = np.diff(off)
+    assert cnt.max() <= 11 and cnt.min() >= 0            # max_matches + 1 (tie rule), src/lib.rs:1536-1589
+    inner = np.ones(dist.size, dtype=bool)
+    inner[off[:-1][cnt > 0]] = False                     # first row of each query
+    assert np.all(dist[1:][inner[1:]] <= dist[:-1][inner[1:]])   # descending inside every query
+    assert np.all((dist >= 0.25) & (dist <= 1.0)) and np.all(freq == 1.0)
+    first = off[:-1][cnt > 0]
+    best = np.zeros(N)
+    best[cnt > 0] = dist[first]
+    # cutoff 2.0 (src/lib.rs:1598-1622): nothing at or below best/2 survives
+    assert np.all(dist > np.repeat(best, cnt) / 2.0 - 1e-15)
+
+
+def test_exact_words_rank_first(setup):
+    g, words, qs, _p, _b, (off, vid, dist, _freq), _st = setup
+    lex = set(words)
+    idx = [i for i in range(0, N, 97) if qs[i] in lex][:3000]
+    assert len(idx) > 1000
+    for i in idx:
+        assert off[i + 1] > off[i] and dist[off[i]] == 1.0
+        # case variants normalise identically ("MB's" / "Mb's"): the word itself is among the score-1.0 rows
+        top = [g.vocab_text(int(vid[j])) for j in range(off[i], off[i + 1]) if dist[j] == 1.0]
+        assert qs[i] in top, (qs[i], top)
+
+
+def test_shards_equal_whole(setup):
+    """The multi-GPU split: any contiguous slice run on its own returns the same rows."""
+    g, _w, qs, p, _b, (off, vid, dist, freq), _st = setup
+    for lo, hi in ((0, 50_000), (499_990, 560_000)):
+        b2 = g.encode_batch(qs[lo:hi], p)
+        b2.run()
+        o2, v2, d2, f2 = b2.fetch_arrays()
+        b2.free()
+        assert np.array_equal(o2, off[lo:hi + 1] - off[lo])
+        sl = slice(off[lo], off[hi])
+        assert np.array_equal(v2, vid[sl]) and np.array_equal(d2, dist[sl]) and np.array_equal(f2, freq[sl])
+
+
+def test_oracle_spot_check(setup, data_dir):
+    g, _w, qs, _p, _b, (off, vid, dist, freq), _st = setup
+    o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+    o.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    o.build()
+    op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
+    rng = np.random.default_rng(5)
+    for i in rng.choice(N, 1500, replace=False):
+        exp = o.find_variants(qs[i], op)
+        got = [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
+        assert got == exp, qs[i]
