@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--max-len", type=int, default=16)
     ap.add_argument("--lexicon", default="eng", choices=["eng", "nld"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--anagram-distance", type=int, default=3)
+    ap.add_argument("--edit-distance", type=int, default=2)
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
 
@@ -60,25 +62,39 @@ def main():
     model.build()
     words = synth.load_lexicon_words(paths[args.lexicon])
     queries = synth.make_queries(words, args.queries, max_len=args.max_len, seed=synth.SEED + rank)
-    params = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10,
+    params = A.SearchParameters(max_anagram_distance=args.anagram_distance, max_edit_distance=args.edit_distance, max_matches=10,
                                 score_threshold=0.25, cutoff_threshold=2.0)
     t_enc = time.time()
     batch = model.encode_batch(queries, params)  # host encode + H2D, outside the timed region
     t_enc = time.time() - t_enc
     stride = 11  # max_matches + 1 records per query (crop tie rule can return max_matches + 1)
     stream = torch.cuda.current_stream()
-    topk = torch.empty(args.queries * stride * 16, dtype=torch.uint8, device="cuda")
-    gathered = None
-    if world > 1 and not args.no_gather and rank == 0:
-        gathered = [torch.empty_like(topk) for _ in range(world)]
+    do_gather = world > 1 and not args.no_gather
+    # The only exchange of the path: fixed-stride top-k records -> rank 0 (RCCL gather over xGMI).  Double-buffered
+    # and asynchronous, so the gather of step i overlaps the scan/score kernels of step i+1.
+    topk = [torch.empty(args.queries * stride * 16, dtype=torch.uint8, device="cuda") for _ in range(2 if do_gather else 0)]
+    gathered = [[torch.empty_like(topk[0]) for _ in range(world)] if rank == 0 else None for _ in range(2)] if do_gather else None
+    pending = [None, None]
+    step_no = [0]
 
     def step():
         batch.run(stream.cuda_stream)
-        if world > 1 and not args.no_gather:
-            batch.export_topk(topk.data_ptr(), stride, stream.cuda_stream)
-            dist.gather(topk, gathered, dst=0)
+        if do_gather:
+            i = step_no[0] & 1
+            if pending[i] is not None:
+                pending[i].wait()          # the stream waits for the gather that last used this buffer
+            batch.export_topk(topk[i].data_ptr(), stride, stream.cuda_stream)
+            pending[i] = dist.gather(topk[i], gathered[i], dst=0, async_op=True)
+            step_no[0] += 1
+
+    def drain():
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     def barrier():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -122,13 +138,20 @@ def main():
             kname, kbytes, kms = "k_score_pairs", score_bytes, stage_ms["ms_score"]
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         # secondary, the bound that actually binds k_scan: VALU issue.  Measured issue costs on gfx950
-        # (tools/ubench_valu.hip): v_and_b32 2.2, v_bcnt_u32_b32 4.1, v_max_i32 2.2, v_sad_u8 4.3 cycles per
-        # wave-instruction per SIMD -> cycles per 64 class tests: T planes 6.3*T+2.2, SAD body 8*4.3+2.2.
+        # (tools/ubench_valu.hip): v_and_b32 + v_bcnt_u32_b32 pair 6.65, v_and_b32 (vgpr) 2.26, v_sad_u8 4.3 cycles per
+        # wave-instruction per SIMD -> cycles per 64 class tests: T planes 6.65*T+2.26, SAD body 8*4.3+2.26.
         kinds = st["n_tests_kind"]
-        issue_cycles = (kinds[0] * (8 * 4.3 + 2.2) + sum(kinds[t] * (6.3 * t + 2.2) for t in range(1, 5))) / 64.0
+        issue_cycles = (kinds[0] * (8 * 4.3 + 2.26) + sum(kinds[t] * (6.65 * t + 2.26) for t in range(1, 5))) / 64.0
         valu_floor_ms = issue_cycles / (1024 * 2.4e9) * 1e3
+        traffic = None  # HBM bytes per launch of that kernel from the committed PMC passes (same workload only)
+        try:
+            if (args.lexicon, args.max_len, args.anagram_distance, args.edit_distance, args.queries) == ("eng", 16, 3, 2, 1_000_000):
+                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["kernels"][kname]["traffic_bytes"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": kms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": kms,
                     "algorithmic_bytes_per_launch": kbytes,
                     "note": "integer scan/DP path: VALU-issue-bound, far below the HBM roof (DESIGN.md section 5)",
                     "scan_valu_issue_floor_ms": valu_floor_ms,
@@ -143,7 +166,7 @@ def main():
             om = O.OracleModel(alphabet_path=paths["alphabet"])
             om.read_lexicon(paths[args.lexicon])
             om.build()
-            op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
+            op = O.make_params(("abs", args.anagram_distance), ("abs", args.edit_distance), 10, 0.25, 2.0)
             if args.cpu_sample > 0:
                 sample = min(args.cpu_sample, args.queries)
             else:  # calibrate on a short run, then size the sample for ~15 s of wall time
@@ -167,8 +190,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.lexicon}.aspell lexicon + simple.alphabet, {args.queries} synthetic queries "
-                                   f"len<={args.max_len} per GPU, k=3 d=2 n=10 score-threshold 0.25 cutoff 2.0 "
-                                   "(BASELINE.json configs[1])",
+                                   f"len<={args.max_len} per GPU, k={args.anagram_distance} d={args.edit_distance} n=10 score-threshold 0.25 cutoff 2.0"
+                                   + (" (BASELINE.json configs[1])" if (args.lexicon, args.max_len, args.anagram_distance, args.edit_distance, args.queries) == ("eng", 16, 3, 2, 1_000_000) else ""),
                        "queries_per_gpu": args.queries, "lexicon_entries": model.num_instances(),
                        "anagram_classes": n_classes, "pairs_per_query": pairs / nq if nq else 0.0,
                        "class_tests_per_query": tests / nq if nq else 0.0,
