@@ -102,8 +102,9 @@ struct Batch {
   uint32_t* qmaxfreq = nullptr;
   uint32_t* scan_tmp = nullptr;
   uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
-  double* p_score = nullptr;       // per raw slot
-  uint32_t* p_meta = nullptr;
+  double* p_score = nullptr;       // per selected slot (dense, selection order)
+  uint32_t* s_meta = nullptr;      // per selected slot: ld | samecase<<7 | lcs<<8 | prefix<<16 | suffix<<24
+  uint32_t* p_meta = nullptr;      // per raw slot: skipped / rejected / pending(selected)
   uint32_t* sel = nullptr;         // indices of the pair-list slots that passed the prefilter
   uint32_t* blockcount = nullptr;  // per 256-slot block: selected slots (+ scan scratch)
   size_t raw_cap = 0;
@@ -116,7 +117,7 @@ struct Batch {
   size_t surv_cap = 0;
   uint32_t* r_count = nullptr;
   uint32_t* r_off = nullptr;       // nq+1
-  uint32_t n_raw = 0;
+  uint32_t n_raw = 0, n_sel = 0;
   uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
   bool ran = false;
   hipEvent_t ev[6] = {};
@@ -552,8 +553,8 @@ __global__ __launch_bounds__(256) void k_prefilter(uint32_t nraw, const uint2* _
                                                    const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
                                                    uint32_t qw, const uint32_t* __restrict__ ent_meta,
                                                    const uint32_t* __restrict__ ent_rowoff, const uint4* __restrict__ rows,
-                                                   double* __restrict__ p_score, uint32_t* __restrict__ p_meta,
-                                                   uint32_t* __restrict__ blockcount, uint32_t* __restrict__ counters) {
+                                                   uint32_t* __restrict__ p_meta, uint32_t* __restrict__ blockcount,
+                                                   uint32_t* __restrict__ counters) {
   __shared__ uint32_t s_cnt[4];
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   bool selected = false, stop_skipped = false;
@@ -579,7 +580,6 @@ __global__ __launch_bounds__(256) void k_prefilter(uint32_t nraw, const uint2* _
         c6[1] = C.x; c6[2] = C.y; c6[3] = C.z; c6[4] = C.w;
       }
     }
-    p_score[p] = __builtin_nan("");
     if (skip) p_meta[p] = META_SKIPPED;
   }
   if (__any(filt)) {  // wave-uniform
@@ -638,7 +638,7 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
                               const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
                               const uint32_t* __restrict__ ent_meta, const uint32_t* __restrict__ ent_rowoff,
                               const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
-                              double* __restrict__ p_score, uint32_t* __restrict__ p_meta,
+                              double* __restrict__ s_score, uint32_t* __restrict__ s_meta,
                               uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv) {
   extern __shared__ uint32_t lds32[];
   const uint32_t i_sel = blockIdx.x * blockDim.x + threadIdx.x;
@@ -759,24 +759,23 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
         }
       }
     }
-    p_score[p] = score;
-    p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+    s_score[i_sel] = score;  // dense, in selection order (coalesced)
+    s_meta[i_sel] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
 }
 
 // K3b: gather the survivors (score >= threshold) into per-query segments.  Order inside a query is
 // arbitrary; ranking uses a total order whose last key is ent_order (= reference enumeration order).
 __global__ __launch_bounds__(256) void k_compact(uint32_t nsel, const uint32_t* __restrict__ sel,
-                                                 const uint2* __restrict__ raw, const double* __restrict__ p_score,
+                                                 const uint2* __restrict__ raw, const double* __restrict__ s_score,
                                                  double thr, const uint32_t* __restrict__ soff,
                                                  uint32_t* __restrict__ qcur, uint32_t* __restrict__ c_entry,
                                                  double* __restrict__ c_score) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nsel) return;
-  const uint32_t r = sel[i];
-  const double s = p_score[r];
+  const double s = s_score[i];
   if (!(s >= thr)) return;  // NaN = pruned
-  const uint2 v = raw[r];
+  const uint2 v = raw[sel[i]];
   const uint32_t pos = soff[v.x] + atomicAdd(&qcur[v.x], 1u);
   c_entry[pos] = v.y & 0x7FFFFFFFu;
   c_score[pos] = s;
@@ -1199,13 +1198,13 @@ static void launch_scan(const ScanArgs& A, uint32_t nwork, hipStream_t st) {
 
 static int ensure_raw(Batch* b, size_t cap, std::string& err) {
   if (cap <= b->raw_cap) return ANX_OK;
-  for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->sel, (void*)b->blockcount})
+  for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount})
     if (p) (void)hipFree(p);
-  b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->sel = nullptr; b->blockcount = nullptr; b->raw_cap = 0;
+  b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->s_meta = nullptr; b->sel = nullptr; b->blockcount = nullptr; b->raw_cap = 0;
   int rc;
   const size_t nblk = cap / 256 + 2;
   if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err)) ||
-      (rc = dalloc(&b->sel, cap, err)) || (rc = dalloc(&b->blockcount, 2 * nblk + nblk / SCAN_TILE + 16, err))) return rc;
+      (rc = dalloc(&b->s_meta, cap, err)) || (rc = dalloc(&b->sel, cap, err)) || (rc = dalloc(&b->blockcount, 2 * nblk + nblk / SCAN_TILE + 16, err))) return rc;
   b->raw_cap = cap;
   return ANX_OK;
 }
@@ -1299,17 +1298,17 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     uint32_t* blockoff = b->blockcount + nblk + 1;
     uint32_t* tmp = blockoff + nblk + 1;
     hipLaunchKernelGGL(k_prefilter, dim3(nblk), dim3(256), 0, st, nraw, b->raw, b->qexact, stop, enable_filter, b->q_meta,
-                       b->q_rows, b->qw, dl->ent_meta, dl->ent_rowoff, dl->rows, b->p_score, b->p_meta, b->blockcount,
-                       b->counters);
+                       b->q_rows, b->qw, dl->ent_meta, dl->ent_rowoff, dl->rows, b->p_meta, b->blockcount, b->counters);
     exclusive_scan(b->blockcount, nblk, blockoff, tmp, st);
     HIP_TRY(hipMemcpyAsync(&nsel, blockoff + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(k_select, dim3(nblk), dim3(256), 0, st, nraw, b->p_meta, blockoff, b->sel);
     HIP_TRY(hipStreamSynchronize(st));
   }
+  b->n_sel = nsel;
   if (nsel)
     hipLaunchKernelGGL(k_score_pairs, dim3((nsel + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nsel,
                        b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
-                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv);
+                       b->p_score, b->s_meta, b->qmaxfreq, b->qsurv);
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors -----------------------------------------------------------------------------
   exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
@@ -1404,13 +1403,20 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
   if (!res) { err = "out of memory"; return ANX_EINVAL; }
   size_t w = 0;
   if (R) {
+    const size_t S = b->n_sel;
     std::vector<uint2> pr(R);
-    std::vector<uint32_t> pm(R), ev(dl->nentries);
-    std::vector<double> ps(R);
+    std::vector<uint32_t> pm(R), ev(dl->nentries), sm(std::max<size_t>(S, 1)), sl(std::max<size_t>(S, 1));
+    std::vector<double> ps(std::max<size_t>(S, 1));
     HIP_TRY(hipMemcpy(pr.data(), b->raw, R * sizeof(uint2), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pm.data(), b->p_meta, R * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ps.data(), b->p_score, R * 8, hipMemcpyDeviceToHost));
+    if (S) {
+      HIP_TRY(hipMemcpy(ps.data(), b->p_score, S * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(sm.data(), b->s_meta, S * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(sl.data(), b->sel, S * 4, hipMemcpyDeviceToHost));
+    }
     HIP_TRY(hipMemcpy(ev.data(), dl->ent_vocab, (size_t)dl->nentries * 4, hipMemcpyDeviceToHost));
+    std::vector<double> score_of(R, 0.0);
+    for (size_t i = 0; i < S; ++i) { pm[sl[i]] = sm[i]; score_of[sl[i]] = ps[i]; }  // selected slots: DP results
     for (size_t i = 0; i < R; ++i) {
       if (pm[i] == META_SKIPPED || w >= b->n_pairs) continue;
       anx_pair& r = res[w++];
@@ -1423,7 +1429,7 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
       r.prefixlen = (pm[i] >> 16) & 0xFF;
       r.suffixlen = (pm[i] >> 24) & 0xFF;
       r._pad = 0;
-      r.score = ld == PAIR_NONE ? 0.0 : ps[i];
+      r.score = ld == PAIR_NONE ? 0.0 : score_of[i];
     }
   }
   *out = res;
@@ -1453,7 +1459,7 @@ void batch_free(Batch* b) {
   (void)hipSetDevice(b->device);
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->d_work,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
-                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->sel, (void*)b->blockcount,
+                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
                   (void*)b->c_entry, (void*)b->c_score, (void*)b->r_entry, (void*)b->r_dist, (void*)b->r_freq,
                   (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) (void)hipFree(p);

@@ -285,6 +285,9 @@ struct orc_model {
   uint64_t ctabcap;
   uint32_t *bucket[256]; /* sortedindex: class idx ascending by value */
   uint32_t nbucket[256];
+  uint32_t *bflat[256];  /* the same values stored contiguously (stride bstride[c] limbs) for the containment scan */
+  uint8_t *bflat_n[256];
+  uint32_t bstride[256];
   uint64_t ninstances;
 };
 
@@ -412,7 +415,7 @@ void orc_model_free(orc_model *m) {
   for (uint64_t i = 0; i < m->ncls; i++) { free(m->cls[i].w); free(m->cls[i].inst); }
   free(m->cls);
   free(m->ctab);
-  for (int i = 0; i < 256; i++) free(m->bucket[i]);
+  for (int i = 0; i < 256; i++) { free(m->bucket[i]); free(m->bflat[i]); free(m->bflat_n[i]); }
   free(m);
 }
 void orc_set_weights(orc_model *m, double ld, double lcs, double prefix, double suffix, double casew) {
@@ -627,8 +630,22 @@ void orc_build(orc_model *m) {
     m->bucket[c][m->nbucket[c]++] = (uint32_t)i;
   }
   g_sort_model = m;
-  for (int c = 0; c < 256; c++)
-    if (m->nbucket[c]) qsort(m->bucket[c], m->nbucket[c], sizeof(uint32_t), cmp_cls);
+  for (int c = 0; c < 256; c++) {
+    free(m->bflat[c]); free(m->bflat_n[c]);
+    m->bflat[c] = NULL; m->bflat_n[c] = NULL; m->bstride[c] = 0;
+    if (!m->nbucket[c]) continue;
+    qsort(m->bucket[c], m->nbucket[c], sizeof(uint32_t), cmp_cls);
+    uint32_t stride = 1;
+    for (uint32_t i = 0; i < m->nbucket[c]; i++) if (m->cls[m->bucket[c][i]].n > stride) stride = m->cls[m->bucket[c][i]].n;
+    m->bstride[c] = stride;
+    m->bflat[c] = calloc((size_t)m->nbucket[c] * stride, 4);
+    m->bflat_n[c] = malloc(m->nbucket[c]);
+    for (uint32_t i = 0; i < m->nbucket[c]; i++) {
+      const klass *k = &m->cls[m->bucket[c][i]];
+      memcpy(m->bflat[c] + (size_t)i * stride, k->w, (size_t)k->n * 4);
+      m->bflat_n[c][i] = (uint8_t)k->n;
+    }
+  }
 }
 uint64_t orc_n_classes(const orc_model *m) { return m->ncls; }
 uint64_t orc_n_instances(const orc_model *m) { return m->ninstances; }
@@ -1043,10 +1060,12 @@ static void find_nearest(const orc_model *m, const big *focus, int max_distance,
   rdi_free(&it);
   for (int cc = 0; cc < 256; cc++) { /* :1268-1281 the containment scan */
     if (!lookups[cc].n) continue;
+    const uint32_t stride = m->bstride[cc];
     for (uint32_t bi = 0; bi < m->nbucket[cc]; bi++) {
-      const klass *cand = &m->cls[m->bucket[cc][bi]];
+      const uint32_t *cw = m->bflat[cc] + (size_t)bi * stride;
+      const int cn = m->bflat_n[cc][bi];
       for (size_t a = 0; a < lookups[cc].n; a++)
-        if (av_contains(cand->w, cand->n, lookups[cc].a[a].w, lookups[cc].a[a].n)) {
+        if (av_contains(cw, cn, lookups[cc].a[a].w, lookups[cc].a[a].n)) {
           u32vec_push(nearest, m->bucket[cc][bi]);
           break;
         }
