@@ -93,6 +93,24 @@ uint64_t anx_model_add_to_vocabulary(anx_model* m, const char* utf8, int has_fre
   if (p) vp = *p;
   return m->host.add_to_vocabulary(utf8, has_frequency != 0, frequency, vp, (uint8_t)m->host.lexicons.size());
 }
+int anx_model_add_variant(anx_model* m, uint64_t ref_id, const char* variant, double score, int has_frequency,
+                          uint32_t frequency, const anx_vocab_params* p) {
+  if (!m || !variant) return fail(ANX_EINVAL, "NULL argument");
+  anx_vocab_params vp;
+  anx_default_vocab_params(&vp);
+  if (p) vp = *p;
+  int rc = m->host.add_variant(ref_id, variant, score, has_frequency != 0, frequency, vp, (uint8_t)m->host.lexicons.size());
+  return rc < 0 ? fail(rc, "invalid reference id") : rc;
+}
+int anx_model_read_variants(anx_model* m, const char* path, const anx_vocab_params* p, int transparent) {
+  if (!m || !path) return fail(ANX_EINVAL, "NULL argument");
+  anx_vocab_params vp;
+  anx_default_vocab_params(&vp);
+  if (p) vp = *p;
+  std::string err;
+  int rc = m->host.read_variants(path, vp, transparent != 0, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
 int anx_model_to_device(anx_model* m, int device) {
   if (!m) return fail(ANX_EINVAL, "NULL model");
   if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() first");

@@ -65,6 +65,11 @@ struct DeviceLexicon {
   uint32_t* ent_meta = nullptr;
   uint32_t* ent_rowoff = nullptr;
   uint32_t* ent_order = nullptr;
+  uint32_t* ent_var_off = nullptr;     // CSR entry -> VariantOf references (variant lists, src/lib.rs:1677-1727)
+  uint32_t* var_target = nullptr;      // vocab id of the reference item
+  uint32_t* var_target_freq = nullptr;
+  double* var_score = nullptr;
+  int any_variants = 0;
   uint4* rows = nullptr;
   size_t bytes = 0;
 };
@@ -108,9 +113,14 @@ struct Batch {
   uint32_t* sel = nullptr;         // indices of the pair-list slots that passed the prefilter
   uint32_t* blockcount = nullptr;  // per 256-slot block: selected slots (+ scan scratch)
   size_t raw_cap = 0;
-  uint32_t* c_entry = nullptr;     // survivors grouped by query
+  uint32_t* c_vocab = nullptr;     // result rows grouped by query (survivors, expanded by variant lists)
   double* c_score = nullptr;
-  uint32_t* r_entry = nullptr;     // ranked
+  uint32_t* c_freq = nullptr;      // absolute frequency of the row
+  uint32_t* c_via = nullptr;       // vocab id of the variant the row was reached through, 0xFFFFFFFF = none
+  uint64_t* c_ord = nullptr;       // enumeration-order key: ent_order << 20 | position inside the expansion
+  uint32_t* qexpand = nullptr;     // per query: some DL survivor has variant references (has_expandable_variants)
+  uint32_t* r_entry = nullptr;     // ranked: vocab id
+  uint32_t* r_via = nullptr;
   double* r_dist = nullptr;
   double* r_freq = nullptr;
   double* t_key = nullptr;
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(256) void k_select(uint32_t nraw, const uint32_t* _
 struct ScoreArgs {
   double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
   double score_threshold;
-  int have_freq;
+  int have_freq, any_variants;
   uint32_t lqp, lcp;   // bytes reserved per lane for the query / candidate row (multiples of 16)
   uint32_t stride;     // bytes per lane (odd number of dwords: conflict-free ds access)
   uint32_t qw;
@@ -638,8 +648,9 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
                               const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
                               const uint32_t* __restrict__ ent_meta, const uint32_t* __restrict__ ent_rowoff,
                               const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
-                              double* __restrict__ s_score, uint32_t* __restrict__ s_meta,
-                              uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv) {
+                              const uint32_t* __restrict__ ent_var_off, double* __restrict__ s_score,
+                              uint32_t* __restrict__ s_meta, uint32_t* __restrict__ qmaxfreq,
+                              uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand) {
   extern __shared__ uint32_t lds32[];
   const uint32_t i_sel = blockIdx.x * blockDim.x + threadIdx.x;
   if (i_sel < nsel) {
@@ -755,7 +766,12 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
                   a.w_sum;
           // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
           atomicMax(&qmaxfreq[q], a.have_freq ? ent_freq[e] : 1u);
-          if (score >= a.score_threshold) atomicAdd(&qsurv[q], 1u);  // src/lib.rs:1475
+          uint32_t nrows = 1;
+          if (a.any_variants) {  // variant lists loaded (src/lib.rs:1464-1466, 1510, 1677-1727)
+            if (em & 0x200u) qexpand[q] = 1;  // benign race: every writer stores 1
+            nrows = (ent_var_off[e + 1] - ent_var_off[e]) + ((em & 0x400u) ? 0u : 1u);  // transparent: references only
+          }
+          if (score >= a.score_threshold && nrows) atomicAdd(&qsurv[q], nrows);  // src/lib.rs:1475
         }
       }
     }
@@ -764,21 +780,60 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
   }
 }
 
-// K3b: gather the survivors (score >= threshold) into per-query segments.  Order inside a query is
-// arbitrary; ranking uses a total order whose last key is ent_order (= reference enumeration order).
+// K3b: gather the survivors (score >= threshold) into per-query segments of result rows.  With variant lists a
+// survivor contributes one row per VariantOf reference (expand_variants, src/lib.rs:1677-1727: score * variant
+// score, min(reference frequency, own frequency), via = itself) and itself unless it is TRANSPARENT.
+// Order inside a query is arbitrary; ranking uses a total order whose last key is c_ord (= reference order).
+struct CompactArgs {
+  double thr;
+  int have_freq, any_variants;
+};
 __global__ __launch_bounds__(256) void k_compact(uint32_t nsel, const uint32_t* __restrict__ sel,
                                                  const uint2* __restrict__ raw, const double* __restrict__ s_score,
-                                                 double thr, const uint32_t* __restrict__ soff,
-                                                 uint32_t* __restrict__ qcur, uint32_t* __restrict__ c_entry,
-                                                 double* __restrict__ c_score) {
+                                                 CompactArgs a, const uint32_t* __restrict__ soff,
+                                                 uint32_t* __restrict__ qcur, const uint32_t* __restrict__ ent_vocab,
+                                                 const uint32_t* __restrict__ ent_freq,
+                                                 const uint32_t* __restrict__ ent_order,
+                                                 const uint32_t* __restrict__ ent_meta,
+                                                 const uint32_t* __restrict__ ent_var_off,
+                                                 const uint32_t* __restrict__ var_target,
+                                                 const uint32_t* __restrict__ var_target_freq,
+                                                 const double* __restrict__ var_score, uint32_t* __restrict__ c_vocab,
+                                                 double* __restrict__ c_score, uint32_t* __restrict__ c_freq,
+                                                 uint32_t* __restrict__ c_via, uint64_t* __restrict__ c_ord) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nsel) return;
   const double s = s_score[i];
-  if (!(s >= thr)) return;  // NaN = pruned
+  if (!(s >= a.thr)) return;  // NaN = pruned
   const uint2 v = raw[sel[i]];
-  const uint32_t pos = soff[v.x] + atomicAdd(&qcur[v.x], 1u);
-  c_entry[pos] = v.y & 0x7FFFFFFFu;
-  c_score[pos] = s;
+  const uint32_t e = v.y & 0x7FFFFFFFu, q = v.x;
+  const uint32_t f = a.have_freq ? ent_freq[e] : 1u;
+  const uint64_t ord = (uint64_t)ent_order[e] << 20;
+  uint32_t v0 = 0, v1 = 0, self = 1;
+  if (a.any_variants) {
+    v0 = ent_var_off[e];
+    v1 = ent_var_off[e + 1];
+    self = (ent_meta[e] & 0x400u) ? 0u : 1u;
+  }
+  const uint32_t nrows = (v1 - v0) + self;
+  if (!nrows) return;
+  uint32_t pos = soff[q] + atomicAdd(&qcur[q], nrows);
+  const uint32_t vid = ent_vocab[e];
+  for (uint32_t j = v0; j < v1; ++j, ++pos) {  // references first, then the item itself (src/lib.rs:1689-1717)
+    const uint32_t tf = var_target_freq[j];
+    c_vocab[pos] = var_target[j];
+    c_score[pos] = s * var_score[j];
+    c_freq[pos] = a.have_freq ? (tf < f ? tf : f) : (tf < 1u ? tf : 1u);  // min(target frequency, own freq_score)
+    c_via[pos] = vid;
+    c_ord[pos] = ord | (uint64_t)(j - v0);
+  }
+  if (self) {
+    c_vocab[pos] = vid;
+    c_score[pos] = s;
+    c_freq[pos] = f;
+    if (a.any_variants) c_via[pos] = 0xFFFFFFFFu;  // without variant lists k_rank never reads c_via
+    c_ord[pos] = ord | (uint64_t)(v1 - v0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -790,7 +845,7 @@ struct RankArgs {
   double cutoff_threshold;
   uint64_t max_matches;
   float freq_weight;
-  int have_freq;
+  int have_freq, any_variants;
 };
 constexpr int RANK_LCAP = 256;
 
@@ -800,16 +855,19 @@ __device__ inline double result_score(double dist, double freq, float fw) {  // 
 }
 
 __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __restrict__ soff,
-                                              const uint32_t* __restrict__ c_entry,
+                                              const uint32_t* __restrict__ c_vocab,
                                               const double* __restrict__ c_score,
-                                              const uint32_t* __restrict__ ent_freq,
-                                              const uint32_t* __restrict__ ent_order,
-                                              const uint32_t* __restrict__ qmaxfreq, RankArgs a,
-                                              double* __restrict__ t_key, uint32_t* __restrict__ r_entry,
-                                              double* __restrict__ r_dist, double* __restrict__ r_freq,
-                                              uint32_t* __restrict__ r_count) {
+                                              const uint32_t* __restrict__ c_freq,
+                                              const uint32_t* __restrict__ c_via,
+                                              const uint64_t* __restrict__ c_ord,
+                                              const uint32_t* __restrict__ qmaxfreq,
+                                              const uint32_t* __restrict__ qexpand, RankArgs a,
+                                              double* __restrict__ t_key, uint32_t* __restrict__ r_vocab,
+                                              uint32_t* __restrict__ r_via, double* __restrict__ r_dist,
+                                              double* __restrict__ r_freq, uint32_t* __restrict__ r_count) {
   __shared__ double s_key[4][RANK_LCAP];
-  __shared__ uint32_t s_freq[4][RANK_LCAP], s_ord[4][RANK_LCAP];
+  __shared__ unsigned long long s_ord[4][RANK_LCAP];
+  __shared__ uint32_t s_freq[4][RANK_LCAP];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.x * 4 + wid;
   if (q >= nq) return;
@@ -819,53 +877,66 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
     return;
   }
   const uint32_t maxf = qmaxfreq[q];
+  // expanded rows never raise max_freq: their frequency is a min() with the expanding item's (src/lib.rs:1512-1517)
   const double max_freq = a.have_freq ? (double)maxf : (maxf ? 1.0 : 0.0);
   const bool sort_weighted = a.freq_weight > 0.0f;    // rank_cmp's branch
   const bool score_weighted = a.freq_weight != 0.0f;  // score()'s branch
+  const bool expanded = a.any_variants && qexpand[q] != 0;  // has_expandable_variants
   // ---- sort keys ------------------------------------------------------------------------------------
   for (uint32_t i = lane; i < n; i += 64) {
-    const uint32_t e = c_entry[seg0 + i];
-    const uint32_t f = a.have_freq ? ent_freq[e] : 1u;
+    const uint32_t f = c_freq[seg0 + i];
     double key = c_score[seg0 + i];
     if (sort_weighted) {
       const double fs = max_freq > 0.0 ? (double)f / max_freq : (double)f;
       key = result_score(key, fs, a.freq_weight);
     }
-    if (i < RANK_LCAP) { s_key[wid][i] = key; s_freq[wid][i] = f; s_ord[wid][i] = ent_order[e]; }
+    if (i < RANK_LCAP) { s_key[wid][i] = key; s_freq[wid][i] = f; s_ord[wid][i] = c_ord[seg0 + i]; }
     else t_key[seg0 + i] = key;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // ---- rank by counting -------------------------------------------------------------------------------
-  const bool full = score_weighted || a.max_matches == 0;
+  const bool full = score_weighted || a.max_matches == 0 || expanded;
   const uint32_t M = full ? n : (uint32_t)min((uint64_t)n, a.max_matches + 1);
   for (uint32_t i = lane; i < n; i += 64) {
-    double ki; uint32_t fi, oi;
-    const uint32_t ei = c_entry[seg0 + i];
+    double ki; uint32_t fi; unsigned long long oi;
     if (i < RANK_LCAP) { ki = s_key[wid][i]; fi = s_freq[wid][i]; oi = s_ord[wid][i]; }
-    else { ki = t_key[seg0 + i]; fi = a.have_freq ? ent_freq[ei] : 1u; oi = ent_order[ei]; }
+    else { ki = t_key[seg0 + i]; fi = c_freq[seg0 + i]; oi = c_ord[seg0 + i]; }
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; ++j) {
-      double kj; uint32_t fj, oj;
+      double kj; uint32_t fj; unsigned long long oj;
       if (j < RANK_LCAP) { kj = s_key[wid][j]; fj = s_freq[wid][j]; oj = s_ord[wid][j]; }
-      else { kj = t_key[seg0 + j]; const uint32_t ej = c_entry[seg0 + j]; fj = a.have_freq ? ent_freq[ej] : 1u; oj = ent_order[ej]; }
+      else { kj = t_key[seg0 + j]; fj = c_freq[seg0 + j]; oj = c_ord[seg0 + j]; }
       bool before;
       if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
       else before = kj > ki || (kj == ki && (fj > fi || (fj == fi && oj < oi)));
       rank += before;
     }
     if (rank < M) {
-      r_entry[seg0 + rank] = ei;
+      r_vocab[seg0 + rank] = c_vocab[seg0 + i];
+      r_via[seg0 + rank] = a.any_variants ? c_via[seg0 + i] : 0xFFFFFFFFu;
       r_dist[seg0 + rank] = c_score[seg0 + i];
       r_freq[seg0 + rank] = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  // ---- crop + cutoff, literally, by one lane ---------------------------------------------------------
+  // ---- dedup + crop + cutoff, literally, by one lane ---------------------------------------------------
   if (lane == 0) {
     const float fw = a.freq_weight;
-    const double* rd = r_dist + seg0;
-    const double* rf = r_freq + seg0;
-    uint32_t len = n;
+    double* rd = r_dist + seg0;
+    double* rf = r_freq + seg0;
+    uint32_t len = n, avail = M;
+    if (expanded) {  // results.dedup_by_key(|x| x.vocab_id): consecutive duplicates, first kept (src/lib.rs:1530-1533)
+      uint32_t* rv = r_vocab + seg0;
+      uint32_t* rvia = r_via + seg0;
+      uint32_t w = 0;
+      for (uint32_t i = 0; i < n; ++i)
+        if (w == 0 || rv[w - 1] != rv[i]) {
+          rv[w] = rv[i]; rvia[w] = rvia[i]; rd[w] = rd[i]; rf[w] = rf[i];
+          ++w;
+        }
+      len = w;
+      avail = w;
+    }
     const uint64_t mm = a.max_matches;
     if (mm > 0 && (uint64_t)len > mm) {
       const double last = result_score(rd[mm - 1], rf[mm - 1], fw);
@@ -873,7 +944,7 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
       if (cropped < last) len = (uint32_t)mm;
       else {
         uint32_t early = 0, late = 0;
-        for (uint32_t i = 0; i < M; ++i) {
+        for (uint32_t i = 0; i < avail; ++i) {
           if (rd[i] == cropped && early == 0) early = i;
           if (rd[i] < cropped) { late = i; break; }
         }
@@ -899,24 +970,23 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
 
 // dense result rows (device) for download / gather
 struct DevRow {
-  uint32_t vocab_id, query;
+  uint32_t vocab_id, via;
   double dist_score, freq_score;
 };
 __global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* __restrict__ soff,
                                                    const uint32_t* __restrict__ r_off,
                                                    const uint32_t* __restrict__ r_count,
-                                                   const uint32_t* __restrict__ r_entry,
+                                                   const uint32_t* __restrict__ r_vocab,
+                                                   const uint32_t* __restrict__ r_via,
                                                    const double* __restrict__ r_dist,
-                                                   const double* __restrict__ r_freq,
-                                                   const uint32_t* __restrict__ ent_vocab,
-                                                   const uint32_t* __restrict__ q_orig, DevRow* __restrict__ out) {
+                                                   const double* __restrict__ r_freq, DevRow* __restrict__ out) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   const uint32_t n = r_count[q], src = soff[q], dst = r_off[q];
   for (uint32_t i = 0; i < n; ++i) {
     DevRow r;
-    r.vocab_id = ent_vocab[r_entry[src + i]];
-    r.query = q_orig[q];
+    r.vocab_id = r_vocab[src + i];
+    r.via = r_via[src + i];
     r.dist_score = r_dist[src + i];
     r.freq_score = r_freq[src + i];
     out[dst + i] = r;
@@ -924,10 +994,9 @@ __global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* 
 }
 __global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t stride, const uint32_t* __restrict__ soff,
                                                      const uint32_t* __restrict__ r_count,
-                                                     const uint32_t* __restrict__ r_entry,
+                                                     const uint32_t* __restrict__ r_vocab,
                                                      const double* __restrict__ r_dist,
                                                      const double* __restrict__ r_freq,
-                                                     const uint32_t* __restrict__ ent_vocab,
                                                      const uint32_t* __restrict__ q_orig,
                                                      anx_topk_record* __restrict__ out) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -939,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t strid
   r.dist_score = 0.0;
   if (i < r_count[q]) {
     const uint32_t src = soff[q] + i;
-    r.vocab_id = ent_vocab[r_entry[src]];
+    r.vocab_id = r_vocab[src];
     r.freq_score = (float)r_freq[src];
     r.dist_score = r_dist[src];
   }
@@ -988,6 +1057,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   d->nclasses = img.nclasses;
   d->nentries = img.nentries;
   d->cstride = img.cstride;
+  d->any_variants = img.any_variants ? 1 : 0;
   uint32_t maxlen = 1;
   for (uint32_t m : img.ent_meta) maxlen = std::max(maxlen, m & 0xFFu);
   d->max_len = maxlen;
@@ -1003,6 +1073,10 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->ent_meta, img.ent_meta.data(), img.ent_meta.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_rowoff, img.ent_rowoff.data(), img.ent_rowoff.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_order, img.ent_order.data(), img.ent_order.size(), err, &d->bytes)) ||
+      (rc = upload(&d->ent_var_off, img.ent_var_off.data(), img.ent_var_off.size(), err, &d->bytes)) ||
+      (rc = upload(&d->var_target, img.var_target.data(), img.var_target.size(), err, &d->bytes)) ||
+      (rc = upload(&d->var_target_freq, img.var_target_freq.data(), img.var_target_freq.size(), err, &d->bytes)) ||
+      (rc = upload(&d->var_score, img.var_score.data(), img.var_score.size(), err, &d->bytes)) ||
       (rc = upload(reinterpret_cast<uint8_t**>(&d->rows), img.rows.data(), img.rows.size(), err, &d->bytes))) {
     lexicon_free(d);
     return nullptr;
@@ -1014,7 +1088,8 @@ void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->ent_vocab,
-                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->rows})
+                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_var_off,
+                  (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) (void)hipFree(p);
   delete d;
 }
@@ -1170,7 +1245,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     return nullptr;
   }
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->qexact, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->qexact, nq, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
@@ -1210,15 +1285,18 @@ static int ensure_raw(Batch* b, size_t cap, std::string& err) {
 }
 static int ensure_surv(Batch* b, size_t cap, std::string& err) {
   if (cap <= b->surv_cap) return ANX_OK;
-  for (void* p : {(void*)b->c_entry, (void*)b->c_score, (void*)b->r_entry, (void*)b->r_dist, (void*)b->r_freq,
-                  (void*)b->t_key})
+  for (void* p : {(void*)b->c_vocab, (void*)b->c_score, (void*)b->c_freq, (void*)b->c_via, (void*)b->c_ord,
+                  (void*)b->r_entry, (void*)b->r_via, (void*)b->r_dist, (void*)b->r_freq, (void*)b->t_key})
     if (p) (void)hipFree(p);
-  b->c_entry = b->r_entry = nullptr;
+  b->c_vocab = b->c_freq = b->c_via = b->r_entry = b->r_via = nullptr;
+  b->c_ord = nullptr;
   b->c_score = b->r_dist = b->r_freq = b->t_key = nullptr;
   b->surv_cap = 0;
   int rc;
-  if ((rc = dalloc(&b->c_entry, cap, err)) || (rc = dalloc(&b->c_score, cap, err)) || (rc = dalloc(&b->r_entry, cap, err)) ||
-      (rc = dalloc(&b->r_dist, cap, err)) || (rc = dalloc(&b->r_freq, cap, err)) || (rc = dalloc(&b->t_key, cap, err)))
+  if ((rc = dalloc(&b->c_vocab, cap, err)) || (rc = dalloc(&b->c_score, cap, err)) || (rc = dalloc(&b->c_freq, cap, err)) ||
+      (rc = dalloc(&b->c_via, cap, err)) || (rc = dalloc(&b->c_ord, cap, err)) || (rc = dalloc(&b->r_entry, cap, err)) ||
+      (rc = dalloc(&b->r_via, cap, err)) || (rc = dalloc(&b->r_dist, cap, err)) || (rc = dalloc(&b->r_freq, cap, err)) ||
+      (rc = dalloc(&b->t_key, cap, err)))
     return rc;
   b->surv_cap = cap;
   return ANX_OK;
@@ -1273,12 +1351,14 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   HIP_TRY(hipMemsetAsync(b->qsurv, 0, nq * sizeof(uint32_t), st));
   HIP_TRY(hipMemsetAsync(b->qcur, 0, nq * sizeof(uint32_t), st));
   HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
+  if (dl->any_variants) HIP_TRY(hipMemsetAsync(b->qexpand, 0, nq * sizeof(uint32_t), st));
   ScoreArgs sa;
   sa.w_ld = m.weights.ld; sa.w_lcs = m.weights.lcs; sa.w_prefix = m.weights.prefix; sa.w_suffix = m.weights.suffix;
   sa.w_case = m.weights.casew;
   sa.w_sum = m.weights.ld + m.weights.lcs + m.weights.prefix + m.weights.suffix + m.weights.casew;  // src/types.rs:69-73
   sa.score_threshold = b->params.score_threshold;
   sa.have_freq = m.have_freq ? 1 : 0;
+  sa.any_variants = dl->any_variants;
   sa.lqp = b->qw * 16;
   sa.lcp = (dl->max_len + 15) / 16 * 16;
   const uint32_t d = b->dmax;
@@ -1308,7 +1388,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   if (nsel)
     hipLaunchKernelGGL(k_score_pairs, dim3((nsel + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nsel,
                        b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
-                       b->p_score, b->s_meta, b->qmaxfreq, b->qsurv);
+                       dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand);
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors -----------------------------------------------------------------------------
   exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
@@ -1319,9 +1399,13 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   b->n_pairs = (uint64_t)h_counters[CTR_VALID] - h_counters[CTR_SKIPPED];
   b->n_surv = total_surv;
   if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
-  if (nsel)
-    hipLaunchKernelGGL(k_compact, dim3((nsel + 255) / 256), dim3(256), 0, st, nsel, b->sel, b->raw, b->p_score,
-                       b->params.score_threshold, b->soff, b->qcur, b->c_entry, b->c_score);
+  if (nsel) {
+    CompactArgs ca{b->params.score_threshold, m.have_freq ? 1 : 0, dl->any_variants};
+    hipLaunchKernelGGL(k_compact, dim3((nsel + 255) / 256), dim3(256), 0, st, nsel, b->sel, b->raw, b->p_score, ca,
+                       b->soff, b->qcur, dl->ent_vocab, dl->ent_freq, dl->ent_order, dl->ent_meta, dl->ent_var_off,
+                       dl->var_target, dl->var_target_freq, dl->var_score, b->c_vocab, b->c_score, b->c_freq, b->c_via,
+                       b->c_ord);
+  }
   HIP_TRY(hipEventRecord(b->ev[3], st));
   // ---- rank ------------------------------------------------------------------------------------------
   RankArgs ra;
@@ -1329,8 +1413,10 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   ra.max_matches = b->params.max_matches;
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
-  hipLaunchKernelGGL(k_rank, dim3((nq + 3) / 4), dim3(256), 0, st, nq, b->soff, b->c_entry, b->c_score, dl->ent_freq,
-                     dl->ent_order, b->qmaxfreq, ra, b->t_key, b->r_entry, b->r_dist, b->r_freq, b->r_count);
+  ra.any_variants = dl->any_variants;
+  hipLaunchKernelGGL(k_rank, dim3((nq + 3) / 4), dim3(256), 0, st, nq, b->soff, b->c_vocab, b->c_score, b->c_freq,
+                     b->c_via, b->c_ord, b->qmaxfreq, b->qexpand, ra, b->t_key, b->r_entry, b->r_via, b->r_dist,
+                     b->r_freq, b->r_count);
   exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
   HIP_TRY(hipEventRecord(b->ev[4], st));
   uint32_t total_results = 0;
@@ -1359,6 +1445,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err) {
   (void)m;
+  (void)dl;
   if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
   HIP_TRY(hipSetDevice(b->device));
   const size_t n = b->n_input;
@@ -1369,7 +1456,7 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
     DevRow* d_rows = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), b->n_results * sizeof(DevRow)));
     hipLaunchKernelGGL(k_pack_rows, dim3(((uint32_t)b->nq + 255) / 256), dim3(256), 0, 0, (uint32_t)b->nq, b->soff,
-                       b->r_off, b->r_count, b->r_entry, b->r_dist, b->r_freq, dl->ent_vocab, b->q_orig, d_rows);
+                       b->r_off, b->r_count, b->r_entry, b->r_via, b->r_dist, b->r_freq, d_rows);
     std::vector<DevRow> h(b->n_results);
     std::vector<uint32_t> h_cnt(b->nq);
     HIP_TRY(hipMemcpy(h.data(), d_rows, b->n_results * sizeof(DevRow), hipMemcpyDeviceToHost));
@@ -1384,7 +1471,7 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
         out[dst].vocab_id = h[src].vocab_id;
         out[dst].dist_score = h[src].dist_score;
         out[dst].freq_score = h[src].freq_score;
-        out[dst].via = ANX_NO_VIA;
+        out[dst].via = h[src].via == 0xFFFFFFFFu ? ANX_NO_VIA : (uint64_t)h[src].via;
       }
     }
   }
@@ -1439,6 +1526,7 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
 
 int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32_t stride, void* stream,
                       std::string& err) {
+  (void)dl;
   if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
   if (!dst || stride == 0) { err = "bad export arguments"; return ANX_EINVAL; }
   HIP_TRY(hipSetDevice(b->device));
@@ -1446,8 +1534,7 @@ int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32
   if (total)
     hipLaunchKernelGGL(k_export_topk, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), (uint32_t)b->nq, stride, b->soff, b->r_count,
-                       b->r_entry, b->r_dist, b->r_freq, dl->ent_vocab, b->q_orig,
-                       static_cast<anx_topk_record*>(dst));
+                       b->r_entry, b->r_dist, b->r_freq, b->q_orig, static_cast<anx_topk_record*>(dst));
   HIP_TRY(hipGetLastError());
   return ANX_OK;
 }
@@ -1460,8 +1547,8 @@ void batch_free(Batch* b) {
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->d_work,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
-                  (void*)b->c_entry, (void*)b->c_score, (void*)b->r_entry, (void*)b->r_dist, (void*)b->r_freq,
-                  (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
+                  (void*)b->c_vocab, (void*)b->c_score, (void*)b->c_freq, (void*)b->c_via, (void*)b->c_ord, (void*)b->qexpand,
+                  (void*)b->r_entry, (void*)b->r_via, (void*)b->r_dist, (void*)b->r_freq, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) (void)hipFree(p);
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);

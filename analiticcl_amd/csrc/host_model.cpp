@@ -211,7 +211,13 @@ HostModel::HostModel() {
   // init_vocab (src/vocab.rs:145-181): ids 0,1,2 reserved, VocabType::NONE
   for (const char* t : {"<bos>", "<eos>", "<unk>"}) {
     encoder.emplace(t, decoder.size());
-    decoder.push_back(VocabEntry{t, {}, 0, 0, 1, ANX_VOCAB_NONE});
+    VocabEntry e;
+    e.text = t;
+    e.frequency = 0;
+    e.lexindex = 0;
+    e.tokencount = 1;
+    e.vocabtype = ANX_VOCAB_NONE;
+    decoder.push_back(std::move(e));
   }
 }
 
@@ -306,6 +312,87 @@ int HostModel::read_vocabulary(const char* path, const anx_vocab_params& p, std:
   return ANX_OK;
 }
 
+int HostModel::add_variant(uint64_t ref_id, const char* variant, double score, bool has_freq, uint32_t freq,
+                           const anx_vocab_params& p, uint8_t lexicon_index) {
+  if (ref_id >= decoder.size()) return ANX_EINVAL;
+  const uint64_t variantid = add_to_vocabulary(variant, has_freq, freq, p, lexicon_index);
+  if (variantid == ref_id) return 0;
+  built = false;
+  {  // link reference to variant: only the first mention counts
+    VocabEntry& r = decoder[ref_id];
+    bool dup = false;
+    for (const VariantRef& x : r.variants) dup |= !x.variant_of && x.id == variantid;
+    if (!dup) r.variants.push_back(VariantRef{false, variantid, score});
+    r.has_variants = true;
+  }
+  {  // link variant to reference; the reference compares the stored id with `variantid` (src/lib.rs:502-505)
+    VocabEntry& v = decoder[variantid];
+    bool dup = false;
+    for (const VariantRef& x : v.variants) dup |= x.variant_of && x.id == variantid;
+    if (!dup) v.variants.push_back(VariantRef{true, ref_id, score});
+    v.has_variants = true;
+  }
+  return 1;
+}
+
+int HostModel::read_variants(const char* path, const anx_vocab_params& p0, bool transparent, std::string& err) {
+  std::string data;
+  if (!read_file(path, data)) { err = std::string("cannot read ") + path; return ANX_EIO; }
+  std::vector<std::string> lines;
+  split_lines(data, lines);
+  const uint8_t lexidx = (uint8_t)lexicons.size();
+  anx_vocab_params p = p0, tp = p0;
+  if (transparent) tp.vocab_type |= ANX_VOCAB_TRANSPARENT;
+  int has_freq = -1;  // Option<bool>: autodetected on the first line (src/lib.rs:812-830)
+  auto parse_u32 = [](const std::string& f, uint32_t& out) {
+    if (f.empty() || f[0] == '-' ) return false;
+    char* endp = nullptr;
+    unsigned long long v = strtoull(f.c_str() + (f[0] == '+' ? 1 : 0), &endp, 10);
+    if (*endp || v > 0xFFFFFFFFull) return false;
+    out = (uint32_t)v;
+    return true;
+  };
+  std::vector<std::string> fields;
+  size_t linenr = 0;
+  for (const std::string& line : lines) {
+    ++linenr;
+    if (line.empty()) continue;
+    fields.clear();
+    size_t pos = 0;
+    for (;;) {
+      size_t e = line.find('\t', pos);
+      fields.emplace_back(line, pos, e == std::string::npos ? std::string::npos : e - pos);
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+    bool havef = false;
+    uint32_t freq = 0;
+    if (has_freq < 0) {
+      if (fields.size() >= 2 && (fields.size() - 2) % 3 == 0) {
+        if (parse_u32(fields[1], freq)) { has_freq = 1; havef = true; }
+      } else has_freq = 0;
+    } else if (has_freq == 1) {
+      if (fields.size() < 2 || !parse_u32(fields[1], freq)) {
+        err = "Frequency must be an integer (line " + std::to_string(linenr) + ", column 2)";
+        return ANX_EINVAL;
+      }
+      havef = true;
+    }
+    const uint64_t ref_id = add_to_vocabulary(fields[0].c_str(), havef, freq, p, lexidx);
+    const size_t step = has_freq == 1 ? 3 : 2;
+    for (size_t i = has_freq == 1 ? 2 : 1; i + step - 1 < fields.size(); i += step) {
+      char* endp = nullptr;
+      const double score = strtod(fields[i + 1].c_str(), &endp);
+      if (fields[i + 1].empty() || *endp) { err = "Variant scores must be a floating point value (line " + std::to_string(linenr) + ")"; return ANX_EINVAL; }
+      uint32_t vf = 0;
+      if (has_freq == 1 && !parse_u32(fields[i + 2], vf)) { err = "Variant frequency must be an integer (line " + std::to_string(linenr) + ")"; return ANX_EINVAL; }
+      add_variant(ref_id, fields[i].c_str(), score, has_freq == 1, vf, transparent ? tp : p, lexidx);
+    }
+  }
+  lexicons.push_back(path);
+  return ANX_OK;
+}
+
 static int pick_planes(int nsym) {  // kernel variants are instantiated for these widths
   const int need = (nsym + 3) / 4;
   for (int v : {8, 16, 24, 32, 42})
@@ -385,7 +472,16 @@ int HostModel::build_index(std::string& err) {
       const uint32_t len = (uint32_t)v.norm.size();
       lex.ent_vocab.push_back(id);
       lex.ent_freq.push_back(v.frequency);
-      lex.ent_meta.push_back(len | (first_char_is_lowercase(v.text.c_str()) ? 0x100u : 0u));
+      lex.ent_meta.push_back(len | (first_char_is_lowercase(v.text.c_str()) ? 0x100u : 0u) |
+                             (v.has_variants ? 0x200u : 0u) | ((v.vocabtype & ANX_VOCAB_TRANSPARENT) ? 0x400u : 0u));
+      lex.ent_var_off.push_back((uint32_t)lex.var_target.size());
+      for (const VariantRef& vr : v.variants)
+        if (vr.variant_of) {  // expand_variants only follows VariantOf (src/lib.rs:1690-1711)
+          lex.var_target.push_back((uint32_t)vr.id);
+          lex.var_target_freq.push_back(decoder[vr.id].frequency);
+          lex.var_score.push_back(vr.score);
+        }
+      if (v.has_variants) lex.any_variants = true;
       lex.ent_rowoff.push_back((uint32_t)(lex.rows.size() / 16));
       const size_t padded = std::max<size_t>(16, (len + 15) / 16 * 16);
       const size_t base = lex.rows.size();
@@ -395,6 +491,7 @@ int HostModel::build_index(std::string& err) {
     }
   }
   lex.cls_off[lex.nclasses] = lex.nentries;
+  lex.ent_var_off.push_back((uint32_t)lex.var_target.size());
   {  // global enumeration order of entries: classes by numeric anagram value, regardless of charcount
     std::vector<uint32_t> byval(lex.nclasses);
     std::iota(byval.begin(), byval.end(), 0u);

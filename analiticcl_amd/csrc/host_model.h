@@ -39,6 +39,12 @@ struct Alphabet {
 bool parse_alphabet(const std::string& tsv, Alphabet& out, std::string& err);  // src/lib.rs:369-407
 bool first_char_is_lowercase(const char* utf8);  // char::is_lowercase on text.chars().next()
 
+struct VariantRef {  // VariantReference, src/types.rs:315-324
+  bool variant_of;  // true = VariantOf((id, score)), false = ReferenceFor((id, score))
+  uint64_t id;
+  double score;
+};
+
 struct VocabEntry {  // VocabValue, src/vocab.rs:8-29
   std::string text;
   std::vector<uint8_t> norm;  // normalize_to_alphabet: UNK = alphabet.len()+1
@@ -46,6 +52,8 @@ struct VocabEntry {  // VocabValue, src/vocab.rs:8-29
   uint32_t lexindex;
   uint8_t tokencount;
   uint8_t vocabtype;
+  bool has_variants = false;         // variants.is_some()
+  std::vector<VariantRef> variants;  // src/vocab.rs:23-26
 };
 
 // Little-endian arbitrary-precision unsigned integer; only what ordering anagram values needs
@@ -73,7 +81,12 @@ struct LexiconImage {
   uint32_t bucket_begin[kMaxSymbols + 2];  // class-rank range per charcount
   std::vector<uint32_t> ent_vocab;      // vocab id
   std::vector<uint32_t> ent_freq;
-  std::vector<uint32_t> ent_meta;       // len | first_is_lower<<8
+  std::vector<uint32_t> ent_meta;       // len | first_is_lower<<8 | has_variants<<9 | transparent<<10
+  std::vector<uint32_t> ent_var_off;    // CSR entry -> its VariantOf references (nentries+1)
+  std::vector<uint32_t> var_target;     // vocab id of the reference item
+  std::vector<uint32_t> var_target_freq;
+  std::vector<double> var_score;
+  bool any_variants = false;
   std::vector<uint32_t> ent_rowoff;     // offset of the token row in 16-byte units
   std::vector<uint32_t> ent_order;      // position in the reference's enumeration order: classes by ascending
                                         // anagram value over ALL charcounts (BTreeSet<&AnaValue>, src/lib.rs:1148),
@@ -100,6 +113,9 @@ class HostModel {
   uint64_t add_to_vocabulary(const char* text, bool has_freq, uint32_t freq, const anx_vocab_params& p,
                              uint8_t lexicon_index);  // src/lib.rs:900-967
   int read_vocabulary(const char* path, const anx_vocab_params& p, std::string& err);  // src/lib.rs:519-568
+  int add_variant(uint64_t ref_id, const char* variant, double score, bool has_freq, uint32_t freq,
+                  const anx_vocab_params& p, uint8_t lexicon_index);  // src/lib.rs:460-514
+  int read_variants(const char* path, const anx_vocab_params& p, bool transparent, std::string& err);  // :772-897
   int build_index(std::string& err);  // src/lib.rs:192-245
   bool has(const char* text) const;   // src/lib.rs:331-338
   // encode one string: norm codes (UNK = len+1), hash-class count vector (UNK = len), symbol count

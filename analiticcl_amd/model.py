@@ -227,6 +227,23 @@ class VariantModel:
         return L.lib().anx_model_add_to_vocabulary(self.h, _b(text), 0 if frequency is None else 1,
                                                    frequency or 0, C.byref(p))
 
+    def add_variant(self, ref_id: int, variant: str, score: float, frequency: Optional[int] = None,
+                    params: Optional[VocabParams] = None) -> bool:
+        """add_variant (src/lib.rs:460): link `variant` to the reference item `ref_id` with a score"""
+        p = (params or VocabParams())._c()
+        rc = L.lib().anx_model_add_variant(self.h, ref_id, _b(variant), float(score), 0 if frequency is None else 1,
+                                           frequency or 0, C.byref(p))
+        if rc < 0:
+            L.check(rc)
+        return bool(rc)
+
+    def read_variants(self, filename: str, transparent: bool = False):
+        """Load a weighted variant list; transparent=True for error lists whose items are never returned themselves
+        (bindings/python/src/lib.rs:671-681)"""
+        p = VocabParams()._c()
+        L.check(L.lib().anx_model_read_variants(self.h, _b(filename), C.byref(p), 1 if transparent else 0))
+        self.lexicons.append(filename)
+
     def build(self):
         L.check(L.lib().anx_model_build(self.h, self.device))
 
@@ -268,8 +285,9 @@ class VariantModel:
     def encode_batch(self, inputs: Sequence[str], params: SearchParameters) -> Batch:
         return Batch(self, inputs, params)
 
-    def find_variants_ids(self, inputs: Sequence[str], params: SearchParameters) -> List[List[tuple]]:
-        """anx_find_variants_batch: -> per input, ranked [(vocab_id, dist_score, freq_score)]"""
+    def find_variants_ids(self, inputs: Sequence[str], params: SearchParameters, with_via: bool = False
+                          ) -> List[List[tuple]]:
+        """anx_find_variants_batch: -> per input, ranked [(vocab_id, dist_score, freq_score[, via | None])]"""
         n = len(inputs)
         arr = (C.c_char_p * max(n, 1))(*[_b(t) for t in inputs])
         cp = params._c()
@@ -277,34 +295,38 @@ class VariantModel:
         offs = C.POINTER(C.c_size_t)()
         L.check(L.lib().anx_find_variants_batch(self.h, arr, n, C.byref(cp), C.byref(rows), C.byref(offs)))
         try:
+            if with_via:
+                return [[(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score,
+                          None if rows[j].via == L.ANX_NO_VIA else rows[j].via) for j in range(offs[i], offs[i + 1])]
+                        for i in range(n)]
             return [[(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score) for j in range(offs[i], offs[i + 1])]
                     for i in range(n)]
         finally:
             L.lib().anx_results_free(rows, offs)
 
-    def _to_dict(self, vid: int, dist: float, freq: float, freq_weight: float) -> Dict:
+    def _to_dict(self, vid: int, dist: float, freq: float, freq_weight: float, via: Optional[int] = None) -> Dict:
         # variantresult_to_dict, bindings/python/src/lib.rs:554-588
         fw = float(freq_weight)
         score = dist if fw == 0.0 else (dist + fw * freq) / (1.0 + fw)
         lexindex = L.lib().anx_model_vocab_lexindex(self.h, vid)
-        return {"text": self.vocab_text(vid), "score": score, "dist_score": dist, "freq_score": freq,
-                "lexicons": [name for i, name in enumerate(self.lexicons) if lexindex & (1 << i)]}
+        d = {"text": self.vocab_text(vid), "score": score, "dist_score": dist, "freq_score": freq}
+        if via is not None:
+            d["via"] = self.vocab_text(via)
+        d["lexicons"] = [name for i, name in enumerate(self.lexicons) if lexindex & (1 << i)]
+        return d
 
     def find_variants(self, input: str, params: SearchParameters) -> List[dict]:
-        res = self.find_variants_ids([input], params)[0]
-        return [self._to_dict(v, d, f, params.freq_weight) for v, d, f in res]
+        res = self.find_variants_ids([input], params, with_via=True)[0]
+        return [self._to_dict(v, d, f, params.freq_weight, via) for v, d, f, via in res]
 
     def find_variants_par(self, input: List[str], params: SearchParameters) -> List[dict]:
-        res = self.find_variants_ids(input, params)
-        return [{"input": t, "variants": [self._to_dict(v, d, f, params.freq_weight) for v, d, f in r]}
+        res = self.find_variants_ids(input, params, with_via=True)
+        return [{"input": t, "variants": [self._to_dict(v, d, f, params.freq_weight, via) for v, d, f, via in r]}
                 for t, r in zip(input, res)]
 
     # -- outside the hot-path scope ("next" rows) ---------------------------------
     def find_all_matches(self, text: str, params: SearchParameters):
         raise NotImplementedError("search mode (find_all_matches) is a 'next' row of SURVEY.md section 8(f)")
-
-    def read_variants(self, filename: str, transparent: bool = False):
-        raise NotImplementedError("variant lists are a 'next' row of SURVEY.md section 8(f)")
 
     def read_confusablelist(self, filename: str):
         raise NotImplementedError("confusables are a 'next' row of SURVEY.md section 8(f)")

@@ -115,6 +115,12 @@ int anx_model_read_vocabulary(anx_model *, const char *path, const anx_vocab_par
 /* add_to_vocabulary(text, Option<u32>, &VocabParams) -> VocabId, src/lib.rs:900. Returns UINT64_MAX on error. */
 uint64_t anx_model_add_to_vocabulary(anx_model *, const char *utf8, int has_frequency, uint32_t frequency,
                                      const anx_vocab_params *);
+/* add_variant(ref_id, variant, score, Option<u32>, &VocabParams) -> bool, src/lib.rs:460 (+ add_variant_by_id :478).
+ * Returns 1 if linked, 0 if variant == reference, negative on error. */
+int anx_model_add_variant(anx_model *, uint64_t ref_id, const char *variant_utf8, double score, int has_frequency,
+                          uint32_t frequency, const anx_vocab_params *);
+/* read_variants(filename, Some(&VocabParams), transparent), src/lib.rs:772: weighted variant / error lists */
+int anx_model_read_variants(anx_model *, const char *path, const anx_vocab_params *, int transparent);
 /* build(), src/lib.rs:192: anagram classes, sorted secondary index, then the device-resident SoA lexicon.
  * `device` = HIP device ordinal to upload to; -1 = build the host index only (queries then fail with
  * ANX_ENODEVICE until anx_model_to_device succeeds). */

@@ -254,12 +254,21 @@ typedef struct {
   int n;
 } aclass;
 
+typedef struct { /* VariantReference, src/types.rs:315-324 */
+  uint8_t variant_of; /* 1 = VariantOf, 0 = ReferenceFor */
+  uint64_t id;
+  double score;
+} varref;
 typedef struct {
   char *text;
   uint8_t *norm;
   uint16_t normlen;
   uint32_t freq;
   uint8_t indexed;
+  uint8_t transparent;
+  uint8_t has_variants; /* variants.is_some() */
+  varref *variants;
+  uint32_t nvariants;
 } vocab;
 
 typedef struct {
@@ -409,7 +418,7 @@ void orc_model_free(orc_model *m) {
     free(m->alpha[i].m);
   }
   free(m->alpha);
-  for (uint64_t i = 0; i < m->nvoc; i++) { free(m->voc[i].text); free(m->voc[i].norm); }
+  for (uint64_t i = 0; i < m->nvoc; i++) { free(m->voc[i].text); free(m->voc[i].norm); free(m->voc[i].variants); }
   free(m->voc);
   free(m->enc);
   for (uint64_t i = 0; i < m->ncls; i++) { free(m->cls[i].w); free(m->cls[i].inst); }
@@ -511,17 +520,94 @@ static uint64_t vocab_push(orc_model *m, const char *text, uint32_t freq, int in
   v->normlen = (uint16_t)n;
   v->freq = freq;
   v->indexed = (uint8_t)indexed;
+  v->transparent = 0;
+  v->has_variants = 0;
+  v->variants = NULL;
+  v->nvariants = 0;
   enc_insert(m, m->nvoc);
   return m->nvoc++;
 }
-uint64_t orc_add(orc_model *m, const char *text, int has_freq, uint32_t freq) {
+static uint64_t add_vocab(orc_model *m, const char *text, int has_freq, uint32_t freq, int transparent) {
   uint32_t f = has_freq ? freq : 1;
   int64_t id = enc_find(m, text);
   if (id >= 0) { /* FrequencyHandling::Max (VocabParams::default, src/vocab.rs:121-131) */
     if (f > m->voc[id].freq) m->voc[id].freq = f;
+    if (id > 2 && m->voc[id].transparent && !transparent) m->voc[id].transparent = 0; /* src/lib.rs:935-940 */
     return (uint64_t)id;
   }
-  return vocab_push(m, text, f, 1);
+  uint64_t nid = vocab_push(m, text, f, 1);
+  m->voc[nid].transparent = (uint8_t)(transparent != 0);
+  return nid;
+}
+uint64_t orc_add(orc_model *m, const char *text, int has_freq, uint32_t freq) { return add_vocab(m, text, has_freq, freq, 0); }
+static void push_varref(vocab *v, int variant_of, uint64_t id, double score) {
+  v->variants = realloc(v->variants, (size_t)(v->nvariants + 1) * sizeof(varref));
+  v->variants[v->nvariants].variant_of = (uint8_t)variant_of;
+  v->variants[v->nvariants].id = id;
+  v->variants[v->nvariants].score = score;
+  v->nvariants++;
+  v->has_variants = 1;
+}
+/* add_variant + add_variant_by_id (src/lib.rs:460-514), including the reference's duplicate checks as written
+ * (the VariantOf side compares the stored reference id with `variantid`) */
+int orc_add_variant(orc_model *m, uint64_t ref_id, const char *variant, double score, int has_freq, uint32_t freq,
+                    int transparent) {
+  uint64_t variantid = add_vocab(m, variant, has_freq, freq, transparent);
+  if (variantid == ref_id) return 0;
+  vocab *r = &m->voc[ref_id];
+  int dup = 0;
+  for (uint32_t i = 0; i < r->nvariants; i++)
+    if (!r->variants[i].variant_of && r->variants[i].id == variantid) dup = 1;
+  if (!dup) push_varref(r, 0, variantid, score);
+  vocab *v = &m->voc[variantid];
+  dup = 0;
+  for (uint32_t i = 0; i < v->nvariants; i++)
+    if (v->variants[i].variant_of && v->variants[i].id == variantid) dup = 1;
+  if (!dup) push_varref(v, 1, ref_id, score);
+  return 1;
+}
+int orc_read_variants(orc_model *m, const char *path, int transparent) {
+  char *d = slurp(path);
+  if (!d) { set_err("cannot read variant list"); return -1; }
+  int has_freq = -1; /* None */
+  char *p = d;
+  while (*p) {
+    char *e = strchr(p, '\n');
+    if (e) *e = 0;
+    size_t len = strlen(p);
+    if (len > 0 && p[len - 1] == '\r') p[--len] = 0;
+    if (len > 0) {
+      char *fields[4096];
+      int nf = 0;
+      for (char *f = p; f && nf < 4096;) {
+        fields[nf++] = f;
+        char *tab = strchr(f, '\t');
+        if (tab) { *tab = 0; f = tab + 1; } else f = NULL;
+      }
+      int havef = 0;
+      uint32_t freq = 0;
+      if (has_freq < 0) {
+        if (nf >= 2 && (nf - 2) % 3 == 0) {
+          char *endp;
+          unsigned long long v = strtoull(fields[1], &endp, 10);
+          if (fields[1][0] && !*endp && fields[1][0] != '-' && fields[1][0] != '+' && v <= 0xFFFFFFFFull) {
+            has_freq = 1; havef = 1; freq = (uint32_t)v;
+          }
+        } else has_freq = 0;
+      } else if (has_freq == 1) { havef = 1; freq = (uint32_t)strtoul(fields[1], NULL, 10); }
+      uint64_t ref_id = add_vocab(m, fields[0], havef, freq, 0);
+      if (has_freq == 1) {
+        for (int i = 2; i + 2 < nf; i += 3)
+          orc_add_variant(m, ref_id, fields[i], strtod(fields[i + 1], NULL), 1, (uint32_t)strtoul(fields[i + 2], NULL, 10), transparent);
+      } else {
+        for (int i = 1; i + 1 < nf; i += 2) orc_add_variant(m, ref_id, fields[i], strtod(fields[i + 1], NULL), 0, 0, transparent);
+      }
+    }
+    if (!e) break;
+    p = e + 1;
+  }
+  free(d);
+  return 0;
 }
 /* src/lib.rs:519-568 with VocabParams::default(): text column 0, freq column 1 (missing -> "1") */
 int orc_read_lexicon(orc_model *m, const char *path) {
@@ -1156,6 +1242,7 @@ int orc_find_variants(const orc_model *m, const char *text, const orc_params *p,
   orc_result *res = NULL;
   size_t nres = 0, capres = 0;
   double max_freq = 0.0;
+  int has_expandable = 0;
   double weights_sum = m->w_ld + m->w_lcs + m->w_prefix + m->w_suffix + m->w_case; /* src/types.rs:69-73 */
   for (size_t a = 0; a < nearest.n; a++) {
     const klass *kl = &m->cls[nearest.a[a]];
@@ -1191,21 +1278,55 @@ int orc_find_variants(const orc_model *m, const char *text, const orc_params *p,
                      weights_sum; /* :1443-1452 */
       double freq_score = m->have_freq ? (double)v->freq : 1.0; /* :1454-1459 */
       if (freq_score > max_freq) max_freq = freq_score;
+      if (v->has_variants) has_expandable = 1; /* :1464-1466 */
       if (score >= p->score_threshold) { /* :1475 */
         if (nres == capres) { capres = capres ? capres * 2 : 64; res = realloc(res, capres * sizeof *res); }
         res[nres].vocab_id = vid;
         res[nres].dist_score = score;
         res[nres].freq_score = freq_score;
+        res[nres].via = UINT64_MAX;
         nres++;
       }
     }
   }
   free(nearest.a);
   if (n_pairs) *n_pairs = np;
+  if (has_expandable) { /* expand_variants :1510-1518, :1677-1727 */
+    orc_result *ex = NULL;
+    size_t nex = 0, capex = 0;
+    for (size_t i = 0; i < nres; i++) {
+      const vocab *it = &m->voc[res[i].vocab_id];
+      for (uint32_t j = 0; j < it->nvariants; j++) {
+        if (!it->variants[j].variant_of) continue;
+        if (nex == capex) { capex = capex ? capex * 2 : 64; ex = realloc(ex, capex * sizeof *ex); }
+        double tf = (double)m->voc[it->variants[j].id].freq;
+        ex[nex].vocab_id = it->variants[j].id;
+        ex[nex].dist_score = res[i].dist_score * it->variants[j].score;
+        ex[nex].freq_score = tf < res[i].freq_score ? tf : res[i].freq_score;
+        ex[nex].via = res[i].vocab_id;
+        nex++;
+      }
+      if (!it->transparent) {
+        if (nex == capex) { capex = capex ? capex * 2 : 64; ex = realloc(ex, capex * sizeof *ex); }
+        ex[nex++] = res[i];
+      }
+    }
+    free(res);
+    res = ex;
+    nres = nex;
+    for (size_t i = 0; i < nres; i++)
+      if (res[i].freq_score > max_freq) max_freq = res[i].freq_score;
+  }
   if (max_freq > 0.0) /* :1521-1525 */
     for (size_t i = 0; i < nres; i++) res[i].freq_score = res[i].freq_score / max_freq;
   float fw = p->freq_weight;
   stable_sort(res, nres, fw); /* :1528 */
+  if (has_expandable) { /* dedup_by_key(vocab_id): consecutive duplicates, first kept :1530-1533 */
+    size_t w = 0;
+    for (size_t i = 0; i < nres; i++)
+      if (w == 0 || res[w - 1].vocab_id != res[i].vocab_id) res[w++] = res[i];
+    nres = w;
+  }
   size_t mm = (size_t)p->max_matches;
   if (mm > 0 && nres > mm) { /* :1536-1589 */
     double last_score = vr_score(&res[mm - 1], fw), cropped_score = vr_score(&res[mm], fw);

@@ -29,11 +29,12 @@ typedef struct {
   float freq_weight;
 } orc_params;
 
-/* VariantResult, src/types.rs:326-332 (via is never set on this path) */
+/* VariantResult, src/types.rs:326-332 */
 typedef struct {
   uint64_t vocab_id;
   double dist_score;
   double freq_score;
+  uint64_t via; /* Option<VocabId>: UINT64_MAX = None (set by expand_variants, src/lib.rs:1677-1727) */
 } orc_result;
 
 /* One scored (query, candidate) pair: the Distance of src/types.rs:289-305 for every instance on which
@@ -54,6 +55,11 @@ int orc_alphabet_len(const orc_model *);
 uint64_t orc_add(orc_model *, const char *text, int has_freq, uint32_t freq);
 /* read_vocabulary(path, VocabParams::default()) -- sets have_freq */
 int orc_read_lexicon(orc_model *, const char *path);
+/* add_variant(ref_id, variant, score, freq, params[+TRANSPARENT]) src/lib.rs:460-514; returns 1 if linked */
+int orc_add_variant(orc_model *, uint64_t ref_id, const char *variant, double score, int has_freq, uint32_t freq,
+                    int transparent);
+/* read_variants(path, Some(&VocabParams::default()), transparent) src/lib.rs:772-897 */
+int orc_read_variants(orc_model *, const char *path, int transparent);
 void orc_build(orc_model *);
 uint64_t orc_vocab_size(const orc_model *);
 const char *orc_vocab_text(const orc_model *, uint64_t id);

@@ -25,7 +25,7 @@ class Params(C.Structure):
 
 
 class Result(C.Structure):
-    _fields_ = [("vocab_id", C.c_uint64), ("dist_score", C.c_double), ("freq_score", C.c_double)]
+    _fields_ = [("vocab_id", C.c_uint64), ("dist_score", C.c_double), ("freq_score", C.c_double), ("via", C.c_uint64)]
 
 
 class Pair(C.Structure):
@@ -59,6 +59,8 @@ def lib():
         L.orc_add.restype = C.c_uint64
         L.orc_add.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint32]
         L.orc_read_lexicon.argtypes = [vp, C.c_char_p]
+        L.orc_add_variant.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_double, C.c_int, C.c_uint32, C.c_int]
+        L.orc_read_variants.argtypes = [vp, C.c_char_p, C.c_int]
         L.orc_build.argtypes = [vp]
         L.orc_vocab_size.restype = C.c_uint64
         L.orc_vocab_size.argtypes = [vp]
@@ -136,6 +138,14 @@ class OracleModel:
         if lib().orc_read_lexicon(self.h, _b(path)) != 0:
             raise RuntimeError(lib().orc_last_error().decode())
 
+    def add_variant(self, ref_id: int, variant: str, score: float, freq: Optional[int] = None, transparent: bool = False):
+        return bool(lib().orc_add_variant(self.h, ref_id, _b(variant), score, 0 if freq is None else 1, freq or 0,
+                                          int(transparent)))
+
+    def read_variants(self, path: str, transparent: bool = False):
+        if lib().orc_read_variants(self.h, _b(path), int(transparent)) != 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+
     def build(self):
         lib().orc_build(self.h)
 
@@ -204,6 +214,16 @@ class OracleModel:
         if n < 0:
             raise RuntimeError("find_nearest overflow")
         return [int(x) for x in buf.value.decode().split("\n")[:n]]
+
+    def find_variants_via(self, text, params: Params, cap: int = 1 << 14):
+        """-> [(vocab_id, dist_score, freq_score, via | None)]"""
+        res = (Result * cap)()
+        npairs, ncls = C.c_int(0), C.c_int(0)
+        n = lib().orc_find_variants(self.h, _b(text), C.byref(params), res, cap, None, C.byref(npairs), C.byref(ncls))
+        if n < 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return [(res[i].vocab_id, res[i].dist_score, res[i].freq_score,
+                 None if res[i].via == 0xFFFFFFFFFFFFFFFF else res[i].via) for i in range(n)]
 
     def find_variants(self, text, params: Params, want_pairs: bool = False, cap: int = 1 << 16):
         res = (Result * cap)()

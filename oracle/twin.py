@@ -431,6 +431,9 @@ class VocabValue:  # src/vocab.rs:8-29 (query-path subset)
     norm: List[int]
     frequency: int
     indexed: bool = True
+    transparent: bool = False
+    # Option<Vec<VariantReference>> (src/types.rs:315-324): ("ref_for" | "variant_of", vocab_id, score)
+    variants: Optional[List[Tuple[str, int, float]]] = None
 
 
 @dataclass
@@ -476,12 +479,14 @@ class VariantModel:
         return len(self.alphabet) + 1
 
     def add_to_vocabulary(self, text: str, frequency: Optional[int] = None,
-                          freq_handling: str = "max") -> int:
+                          freq_handling: str = "max", transparent: bool = False) -> int:
         """src/lib.rs:900-967 (INDEXED entries only)."""
         frequency = 1 if frequency is None else frequency
         vid = self.encoder.get(text)
         if vid is not None:
             item = self.decoder[vid]
+            if item.transparent and not transparent and vid > 2:
+                item.transparent = False  # src/lib.rs:935-940
             if freq_handling == "sum":
                 item.frequency += frequency
             elif freq_handling == "max":
@@ -492,8 +497,75 @@ class VariantModel:
                 item.frequency = frequency
             return vid
         self.encoder[text] = len(self.decoder)
-        self.decoder.append(VocabValue(text, normalize_to_alphabet(text, self.alphabet), frequency))
+        self.decoder.append(VocabValue(text, normalize_to_alphabet(text, self.alphabet), frequency,
+                                       transparent=transparent))
         return len(self.decoder) - 1
+
+    def add_variant(self, ref_id: int, variant: str, score: float, freq: Optional[int] = None,
+                    transparent: bool = False) -> bool:
+        """src/lib.rs:460-514."""
+        variantid = self.add_to_vocabulary(variant, freq, transparent=transparent)
+        if variantid == ref_id:
+            return False
+        ref = self.decoder[ref_id]
+        if ref.variants is None:
+            ref.variants = [("ref_for", variantid, score)]
+        elif not any(k == "ref_for" and y == variantid for k, y, _ in ref.variants):
+            ref.variants.append(("ref_for", variantid, score))
+        var = self.decoder[variantid]
+        if var.variants is None:
+            var.variants = [("variant_of", ref_id, score)]
+        elif not any(k == "variant_of" and y == variantid for k, y, _ in var.variants):  # sic: compares with variantid
+            var.variants.append(("variant_of", ref_id, score))
+        return True
+
+    def read_variants(self, path: str, transparent: bool = False) -> None:
+        """src/lib.rs:772-897 with VocabParams::default()."""
+        with open(path, "r", encoding="utf-8", newline="") as f:
+            data = f.read()
+        has_freq = None
+        for line in rust_lines(data):
+            if line == "":
+                continue
+            fields = line.split("\t")
+            freq = None
+            if has_freq is None:
+                if (len(fields) - 2) % 3 == 0:
+                    try:
+                        freq = int(fields[1])
+                        if freq < 0:
+                            raise ValueError
+                        has_freq = True
+                    except ValueError:
+                        freq = None
+                else:
+                    has_freq = False
+            elif has_freq:
+                freq = int(fields[1])
+            ref_id = self.add_to_vocabulary(fields[0], freq)
+            if has_freq:
+                rest = fields[2:]
+                for i in range(0, len(rest) - 2, 3):
+                    self.add_variant(ref_id, rest[i], float(rest[i + 1]), int(rest[i + 2]), transparent)
+            else:
+                rest = fields[1:]
+                for i in range(0, len(rest) - 1, 2):
+                    self.add_variant(ref_id, rest[i], float(rest[i + 1]), None, transparent)
+
+    def expand_variants(self, results: List["VariantResult"]) -> List["VariantResult"]:
+        """src/lib.rs:1677-1727."""
+        out = []
+        for r in results:
+            item = self.decoder[r.vocab_id]
+            if item.variants is not None:
+                for kind, target, vscore in item.variants:
+                    if kind == "variant_of":
+                        tf = float(self.decoder[target].frequency)
+                        out.append(VariantResult(target, r.dist_score * vscore,
+                                                 tf if tf < r.freq_score else r.freq_score, r.vocab_id))
+            if not item.transparent:
+                out.append(r)
+        return out
 
     def read_vocabulary(self, path: str, text_column: int = 0, freq_column: Optional[int] = 1,
                         freq_handling: str = "max") -> None:
@@ -594,6 +666,7 @@ class VariantModel:
         """src/lib.rs:1405-1653 without confusables / variant expansion."""
         results: List[VariantResult] = []
         max_freq = 0.0
+        has_expandable_variants = False
         w = self.weights
         weights_sum = w.sum()
         assert input_length > 0
@@ -608,8 +681,15 @@ class VariantModel:
             freq_score = float(item.frequency) if self.have_freq else 1.0
             if freq_score > max_freq:
                 max_freq = freq_score
+            if item.variants is not None:
+                has_expandable_variants = True  # src/lib.rs:1464-1466
             if score >= score_threshold:
                 results.append(VariantResult(vocab_id, score, freq_score))
+        if has_expandable_variants:  # src/lib.rs:1510-1518
+            results = self.expand_variants(results)
+            for r in results:
+                if r.freq_score > max_freq:
+                    max_freq = r.freq_score
         if max_freq > 0.0:
             for r in results:
                 r.freq_score = r.freq_score / max_freq
@@ -618,6 +698,12 @@ class VariantModel:
             results.sort(key=lambda r: -r.score(freq_weight))
         else:
             results.sort(key=lambda r: (-r.dist_score, -r.freq_score))
+        if has_expandable_variants:  # Vec::dedup_by_key: consecutive duplicates only (src/lib.rs:1530-1533)
+            ded = []
+            for r in results:
+                if not ded or ded[-1].vocab_id != r.vocab_id:
+                    ded.append(r)
+            results = ded
         if max_matches > 0 and len(results) > max_matches:
             last_score = results[max_matches - 1].score(freq_weight)
             cropped_score = results[max_matches].score(freq_weight)

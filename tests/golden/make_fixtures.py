@@ -78,6 +78,20 @@ def extract_tutorial():
                 "matches": [{"input": r["input"], "begin": r["offset"]["begin"], "end": r["offset"]["end"],
                              "variants": [[v["text"], v["score"], v["dist_score"], v["freq_score"]]
                                           for v in r["variants"]]}]})
+    # cells 27-32: model2 built from a one-line transparent variant list; recorded outputs of cells 29 and 32
+    out["variant_list"] = {"source": "tutorial.ipynb cells 27-32 (recorded outputs)",
+                           "file_content": "separate\tseperate\t1.0\tseprate\t1.0\n", "transparent": True,
+                           "params": {"max_anagram_distance": 2, "max_edit_distance": 2, "max_matches": 1}, "cases": []}
+    for cell in nb["cells"]:
+        if cell["cell_type"] != "code":
+            continue
+        src = "".join(cell["source"])
+        m = re.match(r'variants = model2\.find_variants\("(\w+)"', src)
+        if m:
+            text = "".join("".join(o.get("text", "")) for o in cell.get("outputs", []))
+            rows = [ast.literal_eval(line) for line in text.strip().split("\n") if line]
+            out["variant_list"]["cases"].append({"input": m.group(1), "results": [
+                [r["text"], r["score"], r["dist_score"], r["freq_score"], r.get("via")] for r in rows]})
     return out
 
 

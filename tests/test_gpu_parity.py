@@ -233,3 +233,54 @@ def test_nld_lexicon_edit_distance_3(data_dir):
     qs = synth.make_queries(words, 400, max_len=24, seed=23)
     gp, op = params_pair(("abs", 3), ("abs", 3), 10, 0.25, 2.0)
     compare_batch(g, o, qs, gp, op)
+
+
+# ---- variant lists / transparent entries ------------------------------------
+def test_variant_list_reference_vectors(data_dir, tutorial_outputs, tmp_path):
+    """tests/main.rs:1484-1510 (test0801) and tutorial.ipynb cells 27-32 through the HIP path."""
+    g = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
+    vid = g.add_to_vocabulary("afgescheid")
+    g.add_variant(vid, "afghescheydt", 1.0, None, A.VocabParams(vocabtype="INDEXED|TRANSPARENT"))
+    g.build()
+    p = A.SearchParameters(max_anagram_distance=2, max_edit_distance=2, max_matches=10, score_threshold=0.0,
+                           cutoff_threshold=0.0)
+    r = g.find_variants("afgheschaydt", p)
+    assert [(x["text"], x["via"]) for x in r] == [("afgescheid", "afghescheydt")]
+    vl = tutorial_outputs["variant_list"]
+    f = tmp_path / "example.variantlist.tsv"
+    f.write_text(vl["file_content"], encoding="utf-8")
+    g2 = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g2.read_variants(str(f), transparent=True)
+    g2.build()
+    p2 = A.SearchParameters(**vl["params"])
+    for case in vl["cases"]:
+        got = [[x["text"], x["score"], x["dist_score"], x["freq_score"], x.get("via")] for x in g2.find_variants(case["input"], p2)]
+        assert got == case["results"]
+        assert g2.find_variants(case["input"], p2)[0]["lexicons"] == [str(f)]
+
+
+def test_variant_lists_vs_oracle(tmp_path):
+    from tests.test_variants_cpu import make_variant_file
+    rng = random.Random(99)
+    lexfile = tmp_path / "freq.tsv"
+    lexfile.write_text("\n".join(f"{w}\t{rng.randrange(0, 60)}" for w in
+                                 ["house", "mousse", "hoes", "horse", "hours", "shout", "south", "use"]) + "\n")
+    queries = ["house", "hause", "mose", "huose", "shuot", "ours", "hsoe", "xyz", "mouse", "hoose", "rous", "us"]
+    for trial in range(8):
+        with_freq, transparent, with_lex = trial % 2 == 1, trial % 3 != 0, trial >= 4
+        f = str(tmp_path / f"v{trial}.tsv")
+        make_variant_file(f, rng, with_freq)
+        g = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
+        o = O.OracleModel(alphabet_text=TEST_ALPHABET_TSV)
+        if with_lex:  # have_freq = true (src/lib.rs:544-547)
+            g.read_lexicon(str(lexfile))
+            o.read_lexicon(str(lexfile))
+        g.read_variants(f, transparent)
+        o.read_variants(f, transparent)
+        g.build()
+        o.build()
+        for n, thr, cutoff, fw in ((10, 0.0, 0.0, 0.0), (2, 0.3, 2.0, 0.0), (0, 0.0, 0.0, 0.0), (3, 0.2, 0.0, 0.7), (1, 0.25, 2.0, 0.0)):
+            gp, op = params_pair(("abs", 3), ("abs", 3), n, thr, cutoff, False, fw)
+            got = g.find_variants_ids(queries, gp, with_via=True)
+            for q, r in zip(queries, got):
+                assert r == o.find_variants_via(q, op), (trial, q, n, fw)
