@@ -60,3 +60,34 @@ def make_queries(words: Sequence[str], n: int, max_len: int = 16, min_len: int =
         if cs and len(cs) <= max_len:
             out.append("".join(cs))
     return out
+
+
+def make_lexicon(words: Sequence[str], n: int, min_len: int = 4, max_len: int = 32, seed: int = SEED) -> List[str]:
+    """BASELINE.json configs[3]: the given words plus seeded order-2 Markov-chain words (trained on them) up to n
+    distinct entries; lengths min_len..max_len."""
+    rng = random.Random(seed)
+    trans: dict = {}
+    for w in words:
+        lw = "^^" + w.lower() + "$"
+        for i in range(len(lw) - 2):
+            trans.setdefault(lw[i:i + 2], []).append(lw[i + 2])
+    out = list(dict.fromkeys(w for w in words if len(w) <= max_len))
+    seen = set(out)
+    while len(out) < n:
+        target = rng.randrange(min_len, max_len + 1)
+        cs, ctx = [], "^^"
+        while len(cs) < target:
+            nxt = rng.choice(trans.get(ctx) or "$")
+            if nxt == "$":
+                if len(cs) >= min_len and rng.random() < 0.5:
+                    break
+                ctx = "^^" if not cs else ctx[1] + rng.choice("aeiou")
+                cs.append(ctx[1])
+                continue
+            cs.append(nxt)
+            ctx = ctx[1] + nxt
+        w = "".join(cs)
+        if len(w) >= min_len and w not in seen:
+            seen.add(w)
+            out.append(w)
+    return out[:n]

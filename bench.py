@@ -161,7 +161,7 @@ def main():
         # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
         cpu = None
         ncores = os.cpu_count() or 1
-        if args.cpu_sample != 0:
+        if args.cpu_sample != 0 and world == 1:  # reported at N=1 only
             from oracle import cwrap as O
             om = O.OracleModel(alphabet_path=paths["alphabet"])
             om.read_lexicon(paths[args.lexicon])

@@ -284,3 +284,25 @@ def test_variant_lists_vs_oracle(tmp_path):
             got = g.find_variants_ids(queries, gp, with_via=True)
             for q, r in zip(queries, got):
                 assert r == o.find_variants_via(q, op), (trial, q, n, fw)
+
+
+def test_large_synthetic_lexicon_long_strings(data_dir, tmp_path):
+    """Towards BASELINE.json configs[3]: eng.aspell + Markov-chain words (400 k entries, len 4-32), queries len 4-32:
+    more classes per window, two-uint4 rows, the prefilter's pass-through for strings > 16 symbols."""
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    lex = synth.make_lexicon(words, 400_000, seed=7)
+    f = tmp_path / "synth.lexicon"
+    f.write_text("\n".join(lex) + "\n", encoding="utf-8")
+    alphabet = os.path.join(data_dir, "simple.alphabet.tsv")
+    g = A.VariantModel(alphabet, A.Weights(), device=0)
+    g.read_lexicon(str(f))
+    g.build()
+    o = O.OracleModel(alphabet_path=alphabet)
+    o.read_lexicon(str(f))
+    o.build()
+    assert g.num_classes() == o.n_classes() and g.num_instances() == o.n_instances()
+    qs = synth.make_queries(lex, 300, max_len=32, min_len=4, seed=3)
+    gp, op = params_pair(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
+    compare_batch(g, o, qs, gp, op)
+    gp, op = params_pair(("ratio", 0.2), ("ratio", 0.15), 5, 0.3, 0.0)
+    compare_batch(g, o, qs[:120], gp, op)
