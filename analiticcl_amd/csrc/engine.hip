@@ -47,7 +47,7 @@ constexpr int NBITPLANES = 4;            // thermometer planes stored per class 
 constexpr uint32_t SCAN_TQ = 256;        // queries per tile (= per workgroup)
 constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
 constexpr uint32_t SCAN_QCAP = 512;      // deferred-hit queue entries per wave (LDS)
-constexpr uint32_t SCAN_SEG_CHUNKS = 8;  // class chunks (of 256*CPL classes) per work item
+constexpr uint32_t SCAN_SEG_CHUNKS = 16; // class chunks (of 256*CPL classes) per work item (measured: 8 -> 10.0 ms, 16 -> 9.7 ms)
 constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t META_SKIPPED = 0xFFFFFFFFu;
 
@@ -847,7 +847,8 @@ struct RankArgs {
   float freq_weight;
   int have_freq, any_variants;
 };
-constexpr int RANK_LCAP = 256;
+constexpr int RANK_G = 64;      // lanes per query (measured on config 2: 64 -> 1.43 ms, 16 -> 2.16 ms: mixed list lengths diverge)
+constexpr int RANK_LCAP = 256;  // rows per query staged in LDS; longer lists spill to t_key / global reads
 
 __device__ inline double result_score(double dist, double freq, float fw) {  // src/types.rs:335-341
   if (fw == 0.0f) return dist;
@@ -865,46 +866,50 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
                                               double* __restrict__ t_key, uint32_t* __restrict__ r_vocab,
                                               uint32_t* __restrict__ r_via, double* __restrict__ r_dist,
                                               double* __restrict__ r_freq, uint32_t* __restrict__ r_count) {
-  __shared__ double s_key[4][RANK_LCAP];
-  __shared__ unsigned long long s_ord[4][RANK_LCAP];
-  __shared__ uint32_t s_freq[4][RANK_LCAP];
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t q = blockIdx.x * 4 + wid;
-  if (q >= nq) return;
-  const uint32_t seg0 = soff[q], n = soff[q + 1] - seg0;
-  if (n == 0) {
-    if (lane == 0) r_count[q] = 0;
-    return;
+  constexpr int NG = 256 / RANK_G;
+  __shared__ double s_key[NG][RANK_LCAP];
+  __shared__ unsigned long long s_ord[NG][RANK_LCAP];
+  __shared__ uint32_t s_freq[NG][RANK_LCAP];
+  __shared__ double s_sdist[NG][RANK_G], s_sfreq[NG][RANK_G];  // the first RANK_G ranked rows (parallel crop/cutoff)
+  const int grp = threadIdx.x / RANK_G, gl = threadIdx.x % RANK_G;
+  const int gshift = (threadIdx.x & 63) / RANK_G * RANK_G;  // this group's first lane inside its wave
+  const unsigned long long gmask = RANK_G >= 64 ? ~0ull : ((1ull << (RANK_G & 63)) - 1ull);
+  const uint32_t q = blockIdx.x * NG + grp;
+  uint32_t seg0 = 0, n = 0;
+  if (q < nq) {
+    seg0 = soff[q];
+    n = soff[q + 1] - seg0;
+    if (n == 0 && gl == 0) r_count[q] = 0;
   }
-  const uint32_t maxf = qmaxfreq[q];
+  const uint32_t maxf = n ? qmaxfreq[q] : 0;
   // expanded rows never raise max_freq: their frequency is a min() with the expanding item's (src/lib.rs:1512-1517)
   const double max_freq = a.have_freq ? (double)maxf : (maxf ? 1.0 : 0.0);
   const bool sort_weighted = a.freq_weight > 0.0f;    // rank_cmp's branch
   const bool score_weighted = a.freq_weight != 0.0f;  // score()'s branch
-  const bool expanded = a.any_variants && qexpand[q] != 0;  // has_expandable_variants
+  const bool expanded = n && a.any_variants && qexpand[q] != 0;  // has_expandable_variants
   // ---- sort keys ------------------------------------------------------------------------------------
-  for (uint32_t i = lane; i < n; i += 64) {
+  for (uint32_t i = gl; i < n; i += RANK_G) {
     const uint32_t f = c_freq[seg0 + i];
     double key = c_score[seg0 + i];
     if (sort_weighted) {
       const double fs = max_freq > 0.0 ? (double)f / max_freq : (double)f;
       key = result_score(key, fs, a.freq_weight);
     }
-    if (i < RANK_LCAP) { s_key[wid][i] = key; s_freq[wid][i] = f; s_ord[wid][i] = c_ord[seg0 + i]; }
+    if (i < RANK_LCAP) { s_key[grp][i] = key; s_freq[grp][i] = f; s_ord[grp][i] = c_ord[seg0 + i]; }
     else t_key[seg0 + i] = key;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // ---- rank by counting -------------------------------------------------------------------------------
   const bool full = score_weighted || a.max_matches == 0 || expanded;
   const uint32_t M = full ? n : (uint32_t)min((uint64_t)n, a.max_matches + 1);
-  for (uint32_t i = lane; i < n; i += 64) {
+  for (uint32_t i = gl; i < n; i += RANK_G) {
     double ki; uint32_t fi; unsigned long long oi;
-    if (i < RANK_LCAP) { ki = s_key[wid][i]; fi = s_freq[wid][i]; oi = s_ord[wid][i]; }
+    if (i < RANK_LCAP) { ki = s_key[grp][i]; fi = s_freq[grp][i]; oi = s_ord[grp][i]; }
     else { ki = t_key[seg0 + i]; fi = c_freq[seg0 + i]; oi = c_ord[seg0 + i]; }
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; ++j) {
       double kj; uint32_t fj; unsigned long long oj;
-      if (j < RANK_LCAP) { kj = s_key[wid][j]; fj = s_freq[wid][j]; oj = s_ord[wid][j]; }
+      if (j < RANK_LCAP) { kj = s_key[grp][j]; fj = s_freq[grp][j]; oj = s_ord[grp][j]; }
       else { kj = t_key[seg0 + j]; fj = c_freq[seg0 + j]; oj = c_ord[seg0 + j]; }
       bool before;
       if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
@@ -912,15 +917,51 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
       rank += before;
     }
     if (rank < M) {
+      const double dd = c_score[seg0 + i], ff = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
       r_vocab[seg0 + rank] = c_vocab[seg0 + i];
       r_via[seg0 + rank] = a.any_variants ? c_via[seg0 + i] : 0xFFFFFFFFu;
-      r_dist[seg0 + rank] = c_score[seg0 + i];
-      r_freq[seg0 + rank] = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
+      r_dist[seg0 + rank] = dd;
+      r_freq[seg0 + rank] = ff;
+      if (rank < RANK_G) { s_sdist[grp][rank] = dd; s_sfreq[grp][rank] = ff; }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  // ---- dedup + crop + cutoff, literally, by one lane ---------------------------------------------------
-  if (lane == 0) {
+  const bool parallel_tail = n && !expanded && M <= (uint32_t)RANK_G;
+  {
+    // ---- crop + cutoff, group-parallel (same rules as the serial code below; lane i holds ranked row i) --
+    const float fw = a.freq_weight;
+    const bool have = parallel_tail && (uint32_t)gl < M;
+    const double di = have ? s_sdist[grp][gl] : 0.0;
+    const double si = have ? result_score(di, s_sfreq[grp][gl], fw) : 0.0;
+    uint32_t len = n;
+    const uint64_t mm = a.max_matches;
+    const bool crop = parallel_tail && mm > 0 && (uint64_t)n > mm;
+    double last = 0.0, cropped = 0.0;
+    if (crop) {
+      last = result_score(s_sdist[grp][mm - 1], s_sfreq[grp][mm - 1], fw);
+      cropped = result_score(s_sdist[grp][mm], s_sfreq[grp][mm], fw);
+    }
+    // wave-wide ballots (every lane participates), sliced per group
+    const unsigned long long lt = (__ballot(have && crop && di < cropped) >> gshift) & gmask;
+    const uint32_t stop_at = lt ? (uint32_t)__ffsll((long long)lt) - 1 : (uint32_t)RANK_G;  // the loop breaks at the first smaller row
+    const unsigned long long eq = (__ballot(have && crop && gl >= 1 && (uint32_t)gl <= stop_at && di == cropped) >> gshift) & gmask;
+    if (crop) {
+      if (cropped < last) len = (uint32_t)mm;
+      else {
+        const uint32_t early = eq ? (uint32_t)__ffsll((long long)eq) - 1 : 0;
+        const uint32_t late = lt ? stop_at : 0;
+        if (early > 0) len = early + 1;
+        else if (late > 0) len = late + 1;
+      }
+    }
+    const bool docut = parallel_tail && a.cutoff_threshold >= 1.0;
+    const double best = docut ? result_score(s_sdist[grp][0], s_sfreq[grp][0], fw) : 0.0;
+    const unsigned long long cut = (__ballot(have && docut && gl >= 1 && (uint32_t)gl < len && si <= best / a.cutoff_threshold) >> gshift) & gmask;
+    if (cut) len = (uint32_t)__ffsll((long long)cut) - 1;
+    if (parallel_tail && gl == 0) r_count[q] = len;
+  }
+  // ---- general case: dedup + crop + cutoff, literally, by one lane -------------------------------------
+  if (n && !parallel_tail && gl == 0) {
     const float fw = a.freq_weight;
     double* rd = r_dist + seg0;
     double* rf = r_freq + seg0;
@@ -1215,7 +1256,8 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     const uint32_t c0 = m.lex.bucket_begin[lo], c1 = m.lex.bucket_begin[hi + 1];
     const uint32_t cpl = kind == 0 ? (uint32_t)sad_cpl : (uint32_t)BITS_CPL[kind];
-    const uint32_t seg = 256u * cpl * SCAN_SEG_CHUNKS;
+    static const uint32_t seg_chunks = []() { const char* e = getenv("ANX_SEG_CHUNKS"); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : SCAN_SEG_CHUNKS; }();
+    const uint32_t seg = 256u * cpl * seg_chunks;
     for (size_t s = i; s < j; s += SCAN_TQ) {
       Tile t{(uint32_t)s, (uint32_t)std::min<size_t>(SCAN_TQ, j - s), c0, c1, k, lq};
       const uint32_t ti = (uint32_t)b->tiles.size();
@@ -1414,7 +1456,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
   ra.any_variants = dl->any_variants;
-  hipLaunchKernelGGL(k_rank, dim3((nq + 3) / 4), dim3(256), 0, st, nq, b->soff, b->c_vocab, b->c_score, b->c_freq,
+  hipLaunchKernelGGL(k_rank, dim3((nq + 256 / RANK_G - 1) / (256 / RANK_G)), dim3(256), 0, st, nq, b->soff, b->c_vocab, b->c_score, b->c_freq,
                      b->c_via, b->c_ord, b->qmaxfreq, b->qexpand, ra, b->t_key, b->r_entry, b->r_via, b->r_dist,
                      b->r_freq, b->r_count);
   exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
