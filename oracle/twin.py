@@ -754,3 +754,353 @@ class VariantModel:
         return self.score_and_rank(variants, len(normstring), params.max_matches,
                                    params.score_threshold, params.cutoff_threshold,
                                    params.freq_weight)
+
+
+# =============================================================================================================
+# Search mode: find_all_matches and what it needs.  Host-side logic in the
+# reference; the hot path is called once per n-gram segment (src/lib.rs:1864-1899).
+# Offsets are UTF-8 byte offsets like the reference's (unicodeoffsets remaps at the end).
+# =============================================================================================================
+import numpy as _np
+
+TRANSITION_SMOOTHING_LOGPROB = _np.float32(-13.815510557964274)  # src/search.rs:4
+BOS, EOS, UNK = 0, 1, 2  # src/vocab.rs:145-147
+
+
+@dataclass
+class SearchParams(SearchParameters):  # the search-mode fields of SearchParameters (src/types.rs:132-168)
+    max_ngram: int = 3
+    max_seq: int = 250
+    lm_weight: float = 1.0
+    variantmodel_weight: float = 3.0
+    contextrules_weight: float = 1.0
+    unicodeoffsets: bool = False
+
+
+def test_searchparams_search() -> "SearchParams":
+    """src/test.rs:48-68 (max_ngram 2)."""
+    return SearchParams(("abs", 2), ("abs", 2), 10, 0.0, 0.0, False, 0.0, max_ngram=2)
+
+
+@dataclass
+class Match:  # src/search.rs:40-68
+    text: str
+    begin: int
+    end: int
+    variants: Optional[List[VariantResult]] = None
+    selected: Optional[int] = None
+    n: int = 0
+
+
+def is_alphabetic(ch: str) -> bool:
+    """char::is_alphabetic. Python's isalpha() covers the L* categories; Rust's Alphabetic additionally has Nl and
+    Other_Alphabetic -- irrelevant for the pinned tests, documented as a limit."""
+    return ch.isalpha()
+
+
+def _byte_offsets(text: str) -> List[int]:
+    """code point index -> UTF-8 byte offset (len+1 entries)"""
+    out, b = [], 0
+    for ch in text:
+        out.append(b)
+        b += len(ch.encode("utf-8"))
+    out.append(b)
+    return out
+
+
+def find_boundaries(text: str) -> List[Match]:
+    """src/search.rs:190-233."""
+    bo = _byte_offsets(text)
+    boundaries: List[Match] = []
+    begin = None
+    for i, c in enumerate(text):
+        if begin is not None:
+            if is_alphabetic(c):
+                boundaries.append(Match(text[begin:i], bo[begin], bo[i]))
+                begin = None
+        elif not is_alphabetic(c):
+            begin = i
+    if begin is not None:
+        boundaries.append(Match(text[begin:], bo[begin], bo[len(text)]))
+    else:
+        boundaries.append(Match("", bo[len(text)], bo[len(text)]))
+    return boundaries
+
+
+def classify_boundaries(boundaries: List[Match]) -> List[str]:
+    """src/search.rs:238-258; `boundary.text.len() > 1` is a BYTE length."""
+    out = []
+    for i, b in enumerate(boundaries):
+        if i == len(boundaries) - 1:
+            out.append("hard")
+        elif len(b.text.encode("utf-8")) > 1:
+            out.append("hard")
+        elif b.text in ("'", "-", "_"):
+            out.append("weak")
+        else:
+            out.append("normal")
+    return out
+
+
+def _slice_bytes(text: str, bo: List[int], b0: int, b1: int) -> str:
+    i0, i1 = bo.index(b0), bo.index(b1)
+    return text[i0:i1]
+
+
+def internal_boundaries(m: Match, boundaries: List[Match]) -> List[Match]:
+    """src/search.rs:103-120 (including its behaviour for exactly one internal boundary: empty slice)."""
+    begin, end = None, 0
+    for i, b in enumerate(boundaries):
+        if b.begin > m.begin and b.end < m.end:
+            if begin is None:
+                begin = i
+            else:
+                end = i + 1
+    if begin is None or begin >= end:
+        return []
+    return boundaries[begin:end]
+
+
+def find_match_ngrams(text: str, boundaries: List[Match], order: int, begin: int, end: Optional[int]) -> List[Match]:
+    """src/search.rs:262-313 (byte offsets)."""
+    bo = _byte_offsets(text)
+    ngrams: List[Match] = []
+    end = bo[-1] if end is None else end
+    i = 0
+    while i + order - 1 < len(boundaries):
+        boundary = boundaries[i + order - 1]
+        if boundary.begin > end:
+            break
+        mt = _slice_bytes(text, bo, begin, boundary.begin) if boundary.begin >= begin else ""
+        if mt != "" and mt != " ":
+            ngrams.append(Match(mt, begin, boundary.begin, n=order))
+        begin = boundaries[i].end
+        i += 1
+    if begin < end:
+        mt = _slice_bytes(text, bo, begin, end)
+        if mt != "" and mt != " ":
+            ng = Match(mt, begin, end, n=order)
+            if len(internal_boundaries(ng, boundaries)) == order:
+                ngrams.append(ng)
+    return ngrams
+
+
+def redundant_match(candidate: Match, matches: List[Match]) -> bool:
+    """src/search.rs:317-336."""
+    for ref in matches:
+        if ref.n == 1:
+            if ref.begin >= candidate.begin and ref.end <= candidate.end:
+                if ref.variants is not None:
+                    if not ref.variants or ref.variants[0].dist_score < 1.0:
+                        return False
+                else:
+                    return False
+        else:
+            break
+    return True
+
+
+class SearchModel(VariantModel):
+    """VariantModel + language-model vocabulary + find_all_matches (no context rules)."""
+
+    def __init__(self, alphabet, weights=None):
+        super().__init__(alphabet, weights)
+        self.ngrams: Dict[tuple, int] = {}
+        self.have_lm = False
+        self.lm_ids: List[int] = []
+
+    def add_lm(self, text: str, frequency: Optional[int] = None) -> int:
+        """add_to_vocabulary(text, freq, VocabParams{vocab_type: LM}) (src/lib.rs:900-967)."""
+        frequency = 1 if frequency is None else frequency
+        vid = self.encoder.get(text)
+        if vid is not None:
+            item = self.decoder[vid]
+            item.frequency = max(item.frequency, frequency)
+            if vid not in self.lm_ids and vid > 2:
+                pass  # the reference keeps the first vocab type; BOS/EOS/UNK become LM by definition
+            return vid
+        self.encoder[text] = len(self.decoder)
+        self.decoder.append(VocabValue(text, normalize_to_alphabet(text, self.alphabet), frequency, indexed=False))
+        self.lm_ids.append(len(self.decoder) - 1)
+        return len(self.decoder) - 1
+
+    def _into_ngram(self, vid: int) -> Optional[tuple]:
+        """src/lib.rs:2688-2729 with use_unk = true; None for > 5 tokens."""
+        text = self.decoder[vid].text
+        tokencount = text.count(" ") + 1
+        if tokencount > 5:
+            return None
+        return tuple(self.encoder.get(tok, UNK) for tok in text.split(" "))
+
+    def build(self) -> None:
+        super().build()
+        self.ngrams = {}
+        for vid in self.lm_ids:  # src/lib.rs:252-277
+            ng = self._into_ngram(vid)
+            if ng is not None:
+                self.ngrams[ng] = self.ngrams.get(ng, 0) + self.decoder[vid].frequency
+        self.have_lm = bool(self.ngrams)
+
+    # -- LM ------------------------------------------------------------------------------------------------
+    def lm_score_tokens(self, tokens: List[Optional[int]]) -> Tuple[float, float]:
+        """src/lib.rs:2632-2674: f32 logprob, f64 perplexity."""
+        logprob = _np.float32(0.0)
+        n = 0
+        for i in range(1, len(tokens)):
+            a, b = tokens[i - 1], tokens[i]
+            if a is not None and b is not None:
+                priorcount = self.ngrams.get((a,), 1)
+                joint = self.ngrams.get((a, b))
+                if joint is not None:
+                    if priorcount < joint:
+                        logprob = _np.float32(logprob + _np.log(_np.float32(joint)))
+                    else:
+                        logprob = _np.float32(logprob + _np.log(_np.float32(joint) / _np.float32(priorcount)))
+                else:
+                    logprob = _np.float32(logprob + TRANSITION_SMOOTHING_LOGPROB)
+            else:
+                logprob = _np.float32(logprob + TRANSITION_SMOOTHING_LOGPROB)
+            n += 1
+        return float(logprob), -1.0 / float(n) * float(logprob)
+
+    def lm_score(self, symbols, boundaries: List[Match]) -> Tuple[float, float]:
+        """src/lib.rs:2580-2629. symbols: list of (vocab_id, match_index, variant_index, boundary_index)."""
+        tokens: List[Optional[int]] = [BOS]
+        for vocab_id, _mi, _vi, bidx in symbols:
+            nb = boundaries[bidx]
+            if vocab_id == 0:
+                tokens.append(None)
+            else:
+                ng = self._into_ngram(vocab_id)
+                if ng is not None:
+                    tokens.extend(ng)
+            bt = rust_trim(nb.text)
+            if bt != "":
+                bid = self.encoder.get(bt)
+                if bid is not None:
+                    ng = self._into_ngram(bid)
+                    if ng is not None:
+                        tokens.extend(ng)
+                else:
+                    tokens.append(None)
+        tokens.append(EOS)
+        return self.lm_score_tokens(tokens)
+
+    # -- lattice -------------------------------------------------------------------------------------------
+    def most_likely_sequence(self, matches: List[Match], boundaries: List[Match], begin_offset: int,
+                             end_offset: int, params: "SearchParams") -> List[Match]:
+        """src/lib.rs:2088-2495 without context rules.  The reference decodes with rustfst
+        shortest_path(nshortest = max_seq); here: exact k-best over the boundary DAG.  Order among equal-cost
+        paths is rustfst-internal in the reference and NOT pinned (documented)."""
+        f32 = _np.float32
+        nstates = len(boundaries) + 1  # state 0 = start, state i+1 = boundary i
+        finals = [i + 1 for i, b in enumerate(boundaries) if b.begin == end_offset or b.end == end_offset]
+        assert finals, "no final state found"
+        arcs: List[List[tuple]] = [[] for _ in range(nstates)]  # per source state: (cost, dst, symbol or None)
+        symbols = [None]  # output symbols: (vocab_id, match_index, variant_index, boundary_index)
+        for mi, m in enumerate(matches):
+            prevb = nextb = None
+            for i, b in enumerate(boundaries):
+                if m.begin == b.end:
+                    prevb = i
+                elif m.end == b.begin:
+                    nextb = i
+            assert nextb is not None
+            n = nextb - prevb if prevb is not None else nextb + 1
+            src = prevb + 1 if prevb is not None else 0
+            dst = nextb + 1
+            if m.variants:
+                for vi, vr in enumerate(m.variants):
+                    symbols.append((vr.vocab_id, mi, vi, nextb))
+                    cost = f32(f32(n) + f32(f32(1.0) - f32(vr.score(params.freq_weight))))
+                    arcs[src].append((cost, dst, len(symbols) - 1))
+            elif n == 1:
+                symbols.append((0, mi, None, nextb))
+                arcs[src].append((f32(f32(n) + f32(1.0)), dst, len(symbols) - 1))
+        for i in range(len(boundaries)):  # failsafe epsilon transitions
+            arcs[i].append((f32(100.0), i + 1, None))
+        if len(symbols) == 1:
+            return matches
+        # k-best paths into every state (states are topologically ordered by index)
+        K = params.max_seq
+        best: List[List[tuple]] = [[] for _ in range(nstates)]  # (cost, symbol list)
+        best[0] = [(f32(0.0), ())]
+        for s in range(nstates):
+            if not best[s]:
+                continue
+            best[s].sort(key=lambda t: float(t[0]))
+            best[s] = best[s][:K]
+            for cost, dst, sym in arcs[s]:
+                for c0, syms in best[s]:
+                    best[dst].append((f32(c0 + cost), syms + ((sym,) if sym is not None else ())))
+        paths: List[tuple] = []
+        for fstate in finals:
+            paths.extend(best[fstate])
+        paths.sort(key=lambda t: float(t[0]))
+        paths = paths[:K]
+        # rerank (src/lib.rs:2318-2425)
+        seqs = []
+        best_ppl, best_cost = 999999.0, f32((len(boundaries) - 1) * 2.0)
+        use_lm = self.have_lm and params.lm_weight > 0.0
+        for cost, syms in paths:
+            osyms = [symbols[s] for s in syms]
+            logprob, ppl = (0.0, 0.0)
+            if use_lm:
+                logprob, ppl = self.lm_score(osyms, boundaries)
+                best_ppl = min(best_ppl, ppl)
+            if cost < best_cost:
+                best_cost = cost
+            seqs.append((cost, osyms, ppl))
+        best_score, best_seq = -99999999.0, None
+        for cost, osyms, ppl in seqs:
+            norm_lm = math.log(best_ppl / ppl) if use_lm else 0.0
+            norm_var = math.log(float(best_cost) / float(cost))
+            if not use_lm:
+                score = norm_var
+            else:
+                lw, vw, cw = float(f32(params.lm_weight)), float(f32(params.variantmodel_weight)), float(f32(params.contextrules_weight))
+                score = (lw * norm_lm + vw * norm_var + cw * 0.0) / (lw + vw + cw)
+            if score > best_score or best_seq is None:
+                best_score, best_seq = score, osyms
+        out = []
+        for vocab_id, mi, vi, _b in best_seq:
+            m = matches[mi]
+            out.append(Match(m.text, m.begin, m.end, m.variants, vi, m.n))
+        return out
+
+    def find_all_matches(self, text: str, params: "SearchParams") -> List[Match]:
+        """src/lib.rs:1790-1957."""
+        matches: List[Match] = []
+        if text == "" or not self.index:
+            return matches
+        boundaries = find_boundaries(text)
+        strengths = classify_boundaries(boundaries)
+        bo = _byte_offsets(text)
+        begin, begin_index = 0, 0
+        for i, (strength, boundary) in enumerate(zip(strengths, boundaries)):
+            if strength == "hard" and boundary.begin != begin:
+                bslice = boundaries[begin_index:i + 1]
+                batch: List[Match] = []
+                for order in range(1, params.max_ngram + 1):
+                    cur = find_match_ngrams(text, bslice, order, begin, boundary.begin)
+                    for seg in cur:
+                        if order == 1 or not redundant_match(seg, batch):
+                            seg.variants = self.find_variants(seg.text, params)
+                    batch.extend(cur)
+                if params.max_ngram > 1 or self.have_lm:
+                    matches.extend(self.most_likely_sequence(batch, bslice, begin, boundary.begin, params))
+                else:
+                    for m in batch:
+                        m.selected = 0
+                    matches.extend(batch)
+                begin = boundary.end
+                begin_index = i + 1
+        if params.unicodeoffsets:  # remap_offsets_to_unicodepoints (src/search.rs:527-546)
+            for m in matches:
+                m.begin, m.end = bo.index(m.begin), bo.index(m.end)
+        return matches
+
+    def match_to_str(self, m: Match) -> str:  # src/lib.rs:2757-2763
+        if m.selected is not None and m.variants:
+            return self.decoder[m.variants[m.selected].vocab_id].text
+        return m.text
