@@ -47,6 +47,16 @@ class Result(C.Structure):
                 ("via", C.c_uint64)]
 
 
+class SearchParams(C.Structure):
+    _fields_ = [("base", Params), ("max_ngram", C.c_uint32), ("max_seq", C.c_uint32), ("lm_weight", C.c_float),
+                ("variantmodel_weight", C.c_float), ("contextrules_weight", C.c_float), ("unicodeoffsets", C.c_int32)]
+
+
+class Match(C.Structure):
+    _fields_ = [("begin", C.c_size_t), ("end", C.c_size_t), ("n", C.c_uint32), ("selected", C.c_int32),
+                ("var_begin", C.c_size_t), ("var_end", C.c_size_t)]
+
+
 class Pair(C.Structure):
     _fields_ = [("query", C.c_uint32), ("vocab_id", C.c_uint32), ("ld", C.c_int16), ("lcs", C.c_uint16),
                 ("prefixlen", C.c_uint16), ("suffixlen", C.c_uint16), ("samecase", C.c_uint8), ("_pad", C.c_uint8),
@@ -106,6 +116,11 @@ def lib():
         "anx_find_variants_batch": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(Params),
                                               C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
         "anx_results_free": (None, [C.POINTER(Result), C.POINTER(sz)]),
+        "anx_default_search_params": (None, [C.POINTER(SearchParams)]),
+        "anx_find_all_matches_batch": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(SearchParams),
+                                                 C.POINTER(C.POINTER(Match)), C.POINTER(C.POINTER(sz)),
+                                                 C.POINTER(C.POINTER(Result)), C.POINTER(sz)]),
+        "anx_matches_free": (None, [C.POINTER(Match), C.POINTER(sz), C.POINTER(Result)]),
         "anx_batch_encode": (vp, [vp, C.POINTER(cp), sz, C.POINTER(Params)]),
         "anx_batch_run": (C.c_int, [vp, vp, vp]),
         "anx_batch_fetch": (C.c_int, [vp, C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),

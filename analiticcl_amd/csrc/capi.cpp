@@ -25,6 +25,9 @@ static int fail(int code, const std::string& msg) {
   return code;
 }
 
+const anx::HostModel& anx_host_of(const anx_model* m) { return m->host; }
+int anx_fail(int code, const std::string& msg) { return fail(code, msg); }
+
 extern "C" {
 
 const char* anx_last_error(void) { return g_err.c_str(); }

@@ -60,6 +60,10 @@ bool first_char_is_lowercase(const char* s) {
   int l;
   return in_table(anx_uc_lower, anx_uc_lower_n, u8decode(s, strlen(s), &l));
 }
+bool is_alphabetic_cp(uint32_t cp) { return in_table(anx_uc_alpha, anx_uc_alpha_n, cp); }
+uint32_t utf8_decode_at(const char* s, size_t avail, int* len) { return u8decode(s, avail, len); }
+static std::string trim_ws(const std::string& f);
+std::string trim_whitespace(const std::string& s) { return trim_ws(s); }
 static std::string trim_ws(const std::string& f) {  // str::trim(): Unicode White_Space
   size_t b = 0, e = f.size();
   while (b < e) {
@@ -502,8 +506,38 @@ int HostModel::build_index(std::string& err) {
       for (uint32_t e = lex.cls_off[r]; e < lex.cls_off[r + 1]; ++e) lex.ent_order[e] = pos++;
   }
   for (int c = 0; c <= kMaxSymbols; ++c) lex.bucket_begin[c + 1] += lex.bucket_begin[c];
+  build_lm();
   built = true;
   return ANX_OK;
+}
+
+// into_ngram (src/lib.rs:2688-2729) with encode_token(use_unk = true): unknown parts become UNK (2)
+bool HostModel::into_ngram(uint64_t vocab_id, std::vector<uint64_t>& out) const {
+  out.clear();
+  if (vocab_id >= decoder.size()) return false;
+  const std::string& text = decoder[vocab_id].text;
+  const size_t tokencount = (size_t)std::count(text.begin(), text.end(), ' ') + 1;
+  if (tokencount > 5) return false;  // "Can only deal with n-grams up to order 5"
+  size_t pos = 0;
+  for (;;) {
+    const size_t e = text.find(' ', pos);
+    const std::string tok = text.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+    auto it = encoder.find(tok);
+    out.push_back(it == encoder.end() ? 2 : it->second);
+    if (e == std::string::npos) break;
+    pos = e + 1;
+  }
+  return true;
+}
+std::string HostModel::ngram_key(const uint64_t* ids, size_t n) {
+  return std::string(reinterpret_cast<const char*>(ids), n * sizeof(uint64_t));
+}
+void HostModel::build_lm() {
+  ngrams.clear();
+  std::vector<uint64_t> ng;
+  for (size_t id = 0; id < decoder.size(); ++id)
+    if ((decoder[id].vocabtype & ANX_VOCAB_LM) && into_ngram(id, ng)) ngrams[ngram_key(ng.data(), ng.size())] += decoder[id].frequency;
+  have_lm = !ngrams.empty();
 }
 
 bool HostModel::has(const char* text) const {

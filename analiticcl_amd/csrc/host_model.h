@@ -38,6 +38,9 @@ struct Alphabet {
 
 bool parse_alphabet(const std::string& tsv, Alphabet& out, std::string& err);  // src/lib.rs:369-407
 bool first_char_is_lowercase(const char* utf8);  // char::is_lowercase on text.chars().next()
+bool is_alphabetic_cp(uint32_t cp);              // char::is_alphabetic (L* + Nl; see oracle/gen_unicode.py)
+uint32_t utf8_decode_at(const char* s, size_t avail, int* len);
+std::string trim_whitespace(const std::string& s);  // str::trim()
 
 struct VariantRef {  // VariantReference, src/types.rs:315-324
   bool variant_of;  // true = VariantOf((id, score)), false = ReferenceFor((id, score))
@@ -105,6 +108,8 @@ class HostModel {
   std::vector<std::string> lexicons;
   bool have_freq = false;
   bool built = false;
+  bool have_lm = false;
+  std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
   LexiconImage lex;
   std::unordered_map<std::string, uint32_t> class_of_cv;  // count vector bytes -> class rank
 
@@ -121,6 +126,10 @@ class HostModel {
   // encode one string: norm codes (UNK = len+1), hash-class count vector (UNK = len), symbol count
   bool encode(const char* text, std::vector<uint8_t>& norm, std::vector<uint8_t>& cv) const;
   bool anahash(const char* text, BigVal& out) const;
+  // language model (src/lib.rs:247-296, 2632-2729)
+  bool into_ngram(uint64_t vocab_id, std::vector<uint64_t>& out) const;
+  static std::string ngram_key(const uint64_t* ids, size_t n);
+  void build_lm();
 };
 
 // threshold clamps of find_variants (src/lib.rs:982-994, 1000-1012)

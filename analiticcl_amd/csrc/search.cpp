@@ -1,0 +1,393 @@
+// search.cpp -- search mode: the caller of the hot path.
+// Host-side restatement of VariantModel::find_all_matches (/root/reference/src/lib.rs:1790-1957), the text
+// segmentation of src/search.rs:190-336 and the sequence decoding of src/lib.rs:2088-2495 (without context rules),
+// re-organised so that ALL segments of one n-gram order -- over every hard-boundary stretch of every input text --
+// go to the device as ONE anx_find_variants_batch call (the reference calls find_variants once per segment from a
+// rayon par_iter, src/lib.rs:1883-1899).  Order n depends on the unigram results through redundant_match, so the
+// orders are processed one after another.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_model.h"
+
+extern "C" {
+int anx_find_variants_batch(const anx_model*, const char* const*, size_t, const anx_params*, anx_result**, size_t**);
+void anx_results_free(anx_result*, size_t*);
+}
+const anx::HostModel& anx_host_of(const anx_model* m);  // capi.cpp
+int anx_fail(int code, const std::string& msg);         // capi.cpp
+
+namespace {
+
+using anx::HostModel;
+
+struct Span {  // Match without variants (boundaries, segments); byte offsets into the text
+  Span(size_t b, size_t e) : begin(b), end(e) {}
+  size_t begin, end;
+  uint32_t n = 0;
+  int64_t var_slot = -1;  // index into the per-order result table (-1: no lookup done => variants = None)
+  std::vector<anx_result> variants;
+  bool has_variants = false;  // Some(vec) vs None
+  int selected = -1;
+};
+
+// find_boundaries (src/search.rs:190-233)
+void find_boundaries(const char* text, size_t len, std::vector<Span>& out) {
+  bool open = false;
+  size_t b = 0;
+  for (size_t i = 0; i < len;) {
+    int l;
+    const uint32_t cp = anx::utf8_decode_at(text + i, len - i, &l);
+    const bool alpha = anx::is_alphabetic_cp(cp);
+    if (open) {
+      if (alpha) { out.push_back(Span{b, i}); open = false; }
+    } else if (!alpha) { b = i; open = true; }
+    i += (size_t)l;
+  }
+  if (open) out.push_back(Span{b, len});
+  else out.push_back(Span{len, len});
+}
+enum Strength { WEAK, NORMAL, HARD };
+// classify_boundaries (src/search.rs:238-258): byte length > 1 => Hard
+Strength classify(const char* text, const std::vector<Span>& bs, size_t i) {
+  if (i == bs.size() - 1) return HARD;
+  const size_t l = bs[i].end - bs[i].begin;
+  if (l > 1) return HARD;
+  if (l == 1 && (text[bs[i].begin] == '\'' || text[bs[i].begin] == '-' || text[bs[i].begin] == '_')) return WEAK;
+  return NORMAL;
+}
+// Match::internal_boundaries (src/search.rs:103-120), with its single-boundary behaviour
+size_t count_internal(const Span& m, const Span* bs, size_t nb) {
+  long begin = -1;
+  size_t end = 0;
+  for (size_t i = 0; i < nb; ++i)
+    if (bs[i].begin > m.begin && bs[i].end < m.end) {
+      if (begin < 0) begin = (long)i;
+      else end = i + 1;
+    }
+  if (begin < 0 || (size_t)begin >= end) return 0;
+  return end - (size_t)begin;
+}
+// find_match_ngrams (src/search.rs:262-313)
+void find_match_ngrams(const char* text, const Span* bs, size_t nb, uint32_t order, size_t begin, size_t end,
+                       std::vector<Span>& out) {
+  size_t i = 0;
+  while (i + order - 1 < nb) {
+    const Span& boundary = bs[i + order - 1];
+    if (boundary.begin > end) break;
+    if (boundary.begin > begin && !(boundary.begin - begin == 1 && text[begin] == ' ')) {
+      Span s{begin, boundary.begin};
+      s.n = order;
+      out.push_back(s);
+    }
+    begin = bs[i].end;
+    ++i;
+  }
+  if (begin < end && !(end - begin == 1 && text[begin] == ' ')) {
+    Span s{begin, end};
+    s.n = order;
+    if (count_internal(s, bs, nb) == order) out.push_back(s);
+  }
+}
+// redundant_match (src/search.rs:317-336)
+bool redundant_match(const Span& cand, const std::vector<Span>& matches) {
+  for (const Span& r : matches) {
+    if (r.n != 1) break;
+    if (r.begin >= cand.begin && r.end <= cand.end) {
+      if (!r.has_variants) return false;
+      if (r.variants.empty() || r.variants[0].dist_score < 1.0) return false;
+    }
+  }
+  return true;
+}
+double vr_score(const anx_result& r, float fw) {  // src/types.rs:335-341
+  if (fw == 0.0f) return r.dist_score;
+  return (r.dist_score + ((double)fw * r.freq_score)) / (1.0 + (double)fw);
+}
+
+struct OutSym {  // OutputSymbol, src/search.rs:133-150
+  uint64_t vocab_id;
+  size_t match_index;
+  int variant_index;
+  size_t boundary_index;
+};
+
+// lm_score_tokens (src/lib.rs:2632-2674): f32 log-probability, f64 perplexity; token -1 = out of vocabulary
+void lm_score_tokens(const HostModel& m, const std::vector<int64_t>& tokens, float* logprob_out, double* ppl_out) {
+  const float SMOOTH = -13.815510557964274f;  // src/search.rs:4
+  float logprob = 0.0f;
+  size_t n = 0;
+  for (size_t i = 1; i < tokens.size(); ++i) {
+    if (tokens[i - 1] >= 0 && tokens[i] >= 0) {
+      const uint64_t bg[2] = {(uint64_t)tokens[i - 1], (uint64_t)tokens[i]};
+      auto pit = m.ngrams.find(HostModel::ngram_key(bg, 1));
+      const uint32_t priorcount = pit == m.ngrams.end() ? 1u : pit->second;
+      auto jit = m.ngrams.find(HostModel::ngram_key(bg, 2));
+      if (jit != m.ngrams.end()) {
+        if (priorcount < jit->second) logprob += logf((float)jit->second);
+        else logprob += logf((float)jit->second / (float)priorcount);
+      } else logprob += SMOOTH;
+    } else logprob += SMOOTH;
+    ++n;
+  }
+  *logprob_out = logprob;
+  *ppl_out = -1.0 / (double)n * (double)logprob;
+}
+// lm_score (src/lib.rs:2580-2629)
+void lm_score(const HostModel& m, const char* text, const std::vector<OutSym>& seq, const Span* bs, float* lp, double* ppl) {
+  std::vector<int64_t> tokens;
+  std::vector<uint64_t> ng;
+  tokens.push_back(0);  // BOS
+  for (const OutSym& o : seq) {
+    if (o.vocab_id == 0) tokens.push_back(-1);
+    else if (m.into_ngram(o.vocab_id, ng))
+      for (uint64_t t : ng) tokens.push_back((int64_t)t);
+    const Span& nb = bs[o.boundary_index];
+    const std::string bt = anx::trim_whitespace(std::string(text + nb.begin, nb.end - nb.begin));
+    if (!bt.empty()) {
+      auto it = m.encoder.find(bt);
+      if (it != m.encoder.end()) {
+        if (m.into_ngram(it->second, ng))
+          for (uint64_t t : ng) tokens.push_back((int64_t)t);
+      } else tokens.push_back(-1);
+    }
+  }
+  tokens.push_back(1);  // EOS
+  lm_score_tokens(m, tokens, lp, ppl);
+}
+
+// most_likely_sequence (src/lib.rs:2088-2495) without context rules.  The reference decodes with rustfst's
+// shortest_path(nshortest = max_seq) over a lattice whose states are the boundaries; this is the exact k-best over the
+// same DAG.  The order among equal-cost paths is rustfst-internal in the reference and is not pinned.
+void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span>& matches, const Span* bs, size_t nb,
+                          size_t end_offset, const anx_search_params& p, std::vector<Span>& out) {
+  struct Arc { float cost; size_t dst; long sym; };
+  const size_t nstates = nb + 1;
+  std::vector<std::vector<Arc>> arcs(nstates);
+  std::vector<OutSym> symbols(1);
+  std::vector<size_t> finals;
+  for (size_t i = 0; i < nb; ++i)
+    if (bs[i].begin == end_offset || bs[i].end == end_offset) finals.push_back(i + 1);
+  for (size_t mi = 0; mi < matches.size(); ++mi) {
+    const Span& mt = matches[mi];
+    long prevb = -1, nextb = -1;
+    for (size_t i = 0; i < nb; ++i) {
+      if (mt.begin == bs[i].end) prevb = (long)i;
+      else if (mt.end == bs[i].begin) nextb = (long)i;
+    }
+    if (nextb < 0) continue;  // "next boundary must exist"
+    const long n = prevb >= 0 ? nextb - prevb : nextb + 1;
+    const size_t src = prevb >= 0 ? (size_t)prevb + 1 : 0, dst = (size_t)nextb + 1;
+    if (mt.has_variants && !mt.variants.empty()) {
+      for (size_t vi = 0; vi < mt.variants.size(); ++vi) {
+        symbols.push_back(OutSym{mt.variants[vi].vocab_id, mi, (int)vi, (size_t)nextb});
+        const float cost = (float)n + (1.0f - (float)vr_score(mt.variants[vi], p.base.freq_weight));
+        arcs[src].push_back(Arc{cost, dst, (long)symbols.size() - 1});
+      }
+    } else if (n == 1) {
+      symbols.push_back(OutSym{0, mi, -1, (size_t)nextb});
+      arcs[src].push_back(Arc{(float)n + 1.0f, dst, (long)symbols.size() - 1});
+    }
+  }
+  for (size_t i = 0; i < nb; ++i) arcs[i].push_back(Arc{100.0f, i + 1, -1});  // failsafe epsilon transitions
+  if (symbols.size() == 1 || finals.empty()) { out.insert(out.end(), matches.begin(), matches.end()); return; }
+  // k-best paths into every state, kept as back-pointers (source state, rank there, symbol); states are in
+  // topological order by index, so best[s] is final (sorted, cut to K) before it is expanded.
+  struct Node { float cost; uint32_t ps, pr; long sym; };
+  const size_t K = std::max<uint32_t>(1, p.max_seq);
+  std::vector<std::vector<Node>> best(nstates);
+  best[0].push_back(Node{0.0f, UINT32_MAX, 0, -1});  // the start node
+  auto by_cost = [](const Node& a, const Node& b) { return a.cost < b.cost; };
+  for (size_t s = 0; s < nstates; ++s) {
+    if (best[s].empty()) continue;
+    std::stable_sort(best[s].begin(), best[s].end(), by_cost);
+    if (best[s].size() > K) best[s].resize(K);
+    for (const Arc& a : arcs[s])
+      for (size_t r = 0; r < best[s].size(); ++r)
+        best[a.dst].push_back(Node{best[s][r].cost + a.cost, (uint32_t)s, (uint32_t)r, a.sym});
+  }
+  struct Path { float cost; std::vector<long> syms; };
+  std::vector<Node> ends;
+  for (size_t f : finals) ends.insert(ends.end(), best[f].begin(), best[f].end());
+  std::stable_sort(ends.begin(), ends.end(), by_cost);
+  if (ends.size() > K) ends.resize(K);
+  std::vector<Path> paths(ends.size());
+  for (size_t i = 0; i < ends.size(); ++i) {
+    paths[i].cost = ends[i].cost;
+    for (Node cur = ends[i]; cur.ps != UINT32_MAX; cur = best[cur.ps][cur.pr])
+      if (cur.sym >= 0) paths[i].syms.push_back(cur.sym);
+    std::reverse(paths[i].syms.begin(), paths[i].syms.end());
+  }
+  // rerank (src/lib.rs:2318-2425)
+  const bool use_lm = m.have_lm && p.lm_weight > 0.0f;
+  double best_ppl = 999999.0;
+  float best_cost = (float)(nb - 1) * 2.0f;
+  std::vector<double> ppls(paths.size(), 0.0);
+  std::vector<OutSym> seq;
+  for (size_t i = 0; i < paths.size(); ++i) {
+    if (use_lm) {
+      seq.clear();
+      for (long sy : paths[i].syms) seq.push_back(symbols[(size_t)sy]);
+      float lp;
+      lm_score(m, text, seq, bs, &lp, &ppls[i]);
+      if (ppls[i] < best_ppl) best_ppl = ppls[i];
+    }
+    if (paths[i].cost < best_cost) best_cost = paths[i].cost;
+  }
+  double best_score = -99999999.0;
+  long best_i = -1;
+  for (size_t i = 0; i < paths.size(); ++i) {
+    const double norm_lm = use_lm ? std::log(best_ppl / ppls[i]) : 0.0;
+    const double norm_var = std::log((double)best_cost / (double)paths[i].cost);
+    double score;
+    if (!use_lm) score = norm_var;
+    else
+      score = ((double)p.lm_weight * norm_lm + (double)p.variantmodel_weight * norm_var + (double)p.contextrules_weight * 0.0) /
+              ((double)p.lm_weight + (double)p.variantmodel_weight + (double)p.contextrules_weight);
+    if (score > best_score || best_i < 0) { best_score = score; best_i = (long)i; }
+  }
+  for (long sy : paths[(size_t)best_i].syms) {
+    const OutSym& o = symbols[(size_t)sy];
+    Span r = matches[o.match_index];
+    r.selected = o.variant_index;
+    out.push_back(std::move(r));
+  }
+}
+
+struct Stretch {  // one hard-boundary "batch" of the reference (src/lib.rs:1821-1940)
+  size_t text_index, begin, end, b0, b1;  // boundaries [b0, b1)
+  std::vector<Span> matches;
+};
+
+}  // namespace
+
+extern "C" {
+
+void anx_default_search_params(anx_search_params* p) {  // src/types.rs:170-192
+  anx_default_params(&p->base);
+  p->max_ngram = 3;
+  p->max_seq = 250;
+  p->lm_weight = 1.0f;
+  p->variantmodel_weight = 3.0f;
+  p->contextrules_weight = 1.0f;
+  p->unicodeoffsets = 0;
+}
+
+int anx_find_all_matches_batch(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp,
+                               anx_match** out_matches, size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows) {
+  if (!model || (!texts && n) || !sp || !out_matches || !out_offsets || !out_rows || !out_n_rows)
+    return anx_fail(ANX_EINVAL, "NULL argument");
+  const HostModel& m = anx_host_of(model);
+  if (!m.built || m.lex.nclasses == 0)  // src/lib.rs:1801-1805 (the reference eprintln!s and returns no matches)
+    return anx_fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_all_matches()");
+  std::vector<std::vector<Span>> bounds(n);
+  std::vector<Stretch> stretches;
+  for (size_t t = 0; t < n; ++t) {
+    const char* text = texts[t];
+    const size_t len = text ? strlen(text) : 0;
+    if (!len) continue;
+    find_boundaries(text, len, bounds[t]);
+    size_t begin = 0, begin_index = 0;
+    for (size_t i = 0; i < bounds[t].size(); ++i)
+      if (classify(text, bounds[t], i) == HARD && bounds[t][i].begin != begin) {
+        stretches.push_back(Stretch{t, begin, bounds[t][i].begin, begin_index, i + 1, {}});
+        begin = bounds[t][i].end;
+        begin_index = i + 1;
+      }
+  }
+  // one device batch per n-gram order
+  for (uint32_t order = 1; order <= sp->max_ngram; ++order) {
+    std::vector<std::vector<Span>> cur(stretches.size());
+    std::vector<std::string> seg_text;
+    std::vector<std::pair<size_t, size_t>> seg_ref;  // (stretch, index in cur[stretch])
+    for (size_t si = 0; si < stretches.size(); ++si) {
+      Stretch& st = stretches[si];
+      const char* text = texts[st.text_index];
+      find_match_ngrams(text, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, cur[si]);
+      for (size_t k = 0; k < cur[si].size(); ++k)
+        if (order == 1 || !redundant_match(cur[si][k], st.matches)) {
+          seg_text.emplace_back(text + cur[si][k].begin, cur[si][k].end - cur[si][k].begin);
+          seg_ref.emplace_back(si, k);
+        }
+    }
+    if (!seg_text.empty()) {
+      std::vector<const char*> ptrs(seg_text.size());
+      for (size_t i = 0; i < seg_text.size(); ++i) ptrs[i] = seg_text[i].c_str();
+      anx_result* rows = nullptr;
+      size_t* offs = nullptr;
+      const int rc = anx_find_variants_batch(model, ptrs.data(), ptrs.size(), &sp->base, &rows, &offs);
+      if (rc != ANX_OK) return rc;
+      for (size_t i = 0; i < seg_ref.size(); ++i) {
+        Span& s = cur[seg_ref[i].first][seg_ref[i].second];
+        s.has_variants = true;
+        s.variants.assign(rows + offs[i], rows + offs[i + 1]);
+      }
+      anx_results_free(rows, offs);
+    }
+    for (size_t si = 0; si < stretches.size(); ++si)
+      stretches[si].matches.insert(stretches[si].matches.end(), cur[si].begin(), cur[si].end());
+  }
+  // consolidate per stretch
+  std::vector<std::vector<Span>> per_text(n);
+  for (Stretch& st : stretches) {
+    std::vector<Span>& dst = per_text[st.text_index];
+    if (sp->max_ngram > 1 || m.have_lm) {
+      most_likely_sequence(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end,
+                           *sp, dst);
+    } else {
+      for (Span& s : st.matches) { s.selected = 0; dst.push_back(std::move(s)); }
+    }
+  }
+  size_t total = 0, total_rows = 0;
+  for (auto& v : per_text) { total += v.size(); for (auto& s : v) total_rows += s.variants.size(); }
+  anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, total) * sizeof(anx_match)));
+  size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
+  anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, total_rows) * sizeof(anx_result)));
+  if (!om || !oo || !orows) { free(om); free(oo); free(orows); return anx_fail(ANX_EINVAL, "out of memory"); }
+  size_t w = 0, rw = 0;
+  for (size_t t = 0; t < n; ++t) {
+    oo[t] = w;
+    std::vector<size_t> cpmap;  // byte offset -> code point index (remap_offsets_to_unicodepoints, src/search.rs:527-546)
+    if (sp->unicodeoffsets && texts[t]) {
+      const size_t len = strlen(texts[t]);
+      cpmap.assign(len + 1, 0);
+      size_t cp = 0;
+      for (size_t i = 0; i < len;) {
+        int l;
+        anx::utf8_decode_at(texts[t] + i, len - i, &l);
+        for (int k = 0; k < l && i + (size_t)k < len; ++k) cpmap[i + (size_t)k] = cp;
+        i += (size_t)l;
+        ++cp;
+      }
+      cpmap[len] = cp;
+    }
+    for (const Span& s : per_text[t]) {
+      anx_match& o = om[w++];
+      o.begin = cpmap.empty() ? s.begin : cpmap[s.begin];
+      o.end = cpmap.empty() ? s.end : cpmap[s.end];
+      o.n = s.n;
+      o.selected = (s.has_variants && !s.variants.empty()) ? s.selected : -1;
+      o.var_begin = rw;
+      for (const anx_result& r : s.variants) orows[rw++] = r;
+      o.var_end = rw;
+    }
+  }
+  oo[n] = w;
+  *out_matches = om;
+  *out_offsets = oo;
+  *out_rows = orows;
+  *out_n_rows = rw;
+  return ANX_OK;
+}
+
+void anx_matches_free(anx_match* matches, size_t* offsets, anx_result* rows) {
+  free(matches);
+  free(offsets);
+  free(rows);
+}
+
+}  // extern "C"

@@ -82,6 +82,11 @@ class SearchParameters:
                         int(self.max_matches), float(self.score_threshold), float(self.cutoff_threshold),
                         1 if self.stop_criterion else 0, float(self.freq_weight))
 
+    def _c_search(self) -> L.SearchParams:
+        return L.SearchParams(self._c(), int(self.max_ngram), int(self.max_seq), float(self.lm_weight),
+                              float(self.variantmodel_weight), float(self.contextrules_weight),
+                              1 if self.unicodeoffsets else 0)
+
     def to_dict(self) -> dict:
         return {k: getattr(self, k) for k in self._defaults}
 
@@ -324,9 +329,49 @@ class VariantModel:
         return [{"input": t, "variants": [self._to_dict(v, d, f, params.freq_weight, via) for v, d, f, via in r]}
                 for t, r in zip(input, res)]
 
-    # -- outside the hot-path scope ("next" rows) ---------------------------------
-    def find_all_matches(self, text: str, params: SearchParameters):
-        raise NotImplementedError("search mode (find_all_matches) is a 'next' row of SURVEY.md section 8(f)")
+    # -- search mode: the caller of the hot path ---------------------------
+    def find_all_matches_ids(self, texts: Sequence[str], params: SearchParameters) -> List[List[dict]]:
+        """anx_find_all_matches_batch over many texts: every segment of one n-gram order, over all texts, is one
+        device batch. Per text: [{begin, end, n, selected, variants: [(vocab_id, dist, freq, via|None)]}]."""
+        n = len(texts)
+        enc = [_b(t) for t in texts]
+        arr = (C.c_char_p * max(n, 1))(*enc)
+        sp = params._c_search()
+        ms, offs, rows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)()
+        nrows = C.c_size_t(0)
+        L.check(L.lib().anx_find_all_matches_batch(self.h, arr, n, C.byref(sp), C.byref(ms), C.byref(offs),
+                                                   C.byref(rows), C.byref(nrows)))
+        try:
+            out = []
+            for i in range(n):
+                cur = []
+                for j in range(offs[i], offs[i + 1]):
+                    m = ms[j]
+                    cur.append({"begin": m.begin, "end": m.end, "n": m.n,
+                                "selected": None if m.selected < 0 else m.selected,
+                                "variants": [(rows[r].vocab_id, rows[r].dist_score, rows[r].freq_score,
+                                              None if rows[r].via == L.ANX_NO_VIA else rows[r].via)
+                                             for r in range(m.var_begin, m.var_end)]})
+                out.append(cur)
+            return out
+        finally:
+            L.lib().anx_matches_free(ms, offs, rows)
+
+    def find_all_matches(self, text: str, params: SearchParameters) -> List[dict]:
+        """find_all_matches of the pyo3 binding (bindings/python/src/lib.rs:752-805): the selected variant first."""
+        res = self.find_all_matches_ids([text], params)[0]
+        raw = _b(text)
+        out = []
+        for m in res:
+            inp = text[m["begin"]:m["end"]] if params.unicodeoffsets else raw[m["begin"]:m["end"]].decode("utf-8")
+            order = list(range(len(m["variants"])))
+            if m["selected"] is not None and m["selected"] < len(order):
+                order.remove(m["selected"])
+                order.insert(0, m["selected"])
+            out.append({"input": inp, "offset": {"begin": m["begin"], "end": m["end"]},
+                        "variants": [self._to_dict(*m["variants"][k][:3], params.freq_weight, m["variants"][k][3])
+                                     for k in order]})
+        return out
 
     def read_confusablelist(self, filename: str):
         raise NotImplementedError("confusables are a 'next' row of SURVEY.md section 8(f)")

@@ -181,6 +181,33 @@ typedef struct anx_batch_stats {
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
 void anx_batch_free(anx_batch *);
 
+/* ---- search mode: the main caller of the hot path -------------------------------
+ * VariantModel::find_all_matches(&self, text, &SearchParameters) -> Vec<Match>, src/lib.rs:1790, for n texts at once.
+ * Host side: boundaries / n-gram windows / redundancy filter (src/search.rs:190-336), lattice decoding and bigram-LM
+ * rerank (src/lib.rs:2088-2495, 2580-2674; context rules are not implemented).  Device side: every segment of one
+ * n-gram order, over all texts, is ONE anx_find_variants_batch call. */
+typedef struct anx_search_params {
+  anx_params base;
+  uint8_t max_ngram;          /* default 3 */
+  uint32_t max_seq;           /* default 250: candidate sequences taken to the rerank stage */
+  float lm_weight;            /* default 1.0 */
+  float variantmodel_weight;  /* default 3.0 */
+  float contextrules_weight;  /* default 1.0 (enters the normalisation only) */
+  int32_t unicodeoffsets;     /* offsets in code points instead of UTF-8 bytes */
+} anx_search_params;
+/* Match, src/search.rs:40-68 */
+typedef struct anx_match {
+  uint64_t begin, end;        /* offset of the matched text in its input text */
+  uint32_t n;                 /* tokens (boundaries) spanned */
+  int32_t selected;           /* index of the chosen variant, -1 = none (out-of-vocabulary, copied from the input) */
+  uint64_t var_begin, var_end; /* its ranked variants: rows [var_begin, var_end) of the row array */
+} anx_match;
+void anx_default_search_params(anx_search_params *);
+/* matches of text i are (*out_matches)[(*out_offsets)[i] .. (*out_offsets)[i+1]); release with anx_matches_free */
+int anx_find_all_matches_batch(const anx_model *, const char *const *utf8_texts, size_t n, const anx_search_params *,
+                               anx_match **out_matches, size_t **out_offsets, anx_result **out_rows, size_t *out_n_rows);
+void anx_matches_free(anx_match *matches, size_t *offsets, anx_result *rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -900,6 +900,11 @@ def redundant_match(candidate: Match, matches: List[Match]) -> bool:
     return True
 
 
+def _ln(x: float) -> float:
+    """f64::ln: ln(0) = -inf instead of Python's ValueError."""
+    return -math.inf if x == 0.0 else math.log(x)
+
+
 class SearchModel(VariantModel):
     """VariantModel + language-model vocabulary + find_all_matches (no context rules)."""
 
@@ -1053,8 +1058,10 @@ class SearchModel(VariantModel):
             seqs.append((cost, osyms, ppl))
         best_score, best_seq = -99999999.0, None
         for cost, osyms, ppl in seqs:
-            norm_lm = math.log(best_ppl / ppl) if use_lm else 0.0
-            norm_var = math.log(float(best_cost) / float(cost))
+            norm_lm = _ln(best_ppl / ppl) if use_lm else 0.0
+            # a stretch with ONE boundary leaves best_cost at 0.0 (src/lib.rs:2320): ln(0) = -inf for every path, and
+            # the first path the FST yields wins (src/lib.rs:2419); here that is the cheapest one
+            norm_var = _ln(float(best_cost) / float(cost))
             if not use_lm:
                 score = norm_var
             else:

@@ -1,0 +1,198 @@
+"""GPU parity for search mode (anx_find_all_matches_batch): the product's C++ search
+driver over the HIP variant-query path against (1) the reference's own 07xx tests (/root/reference/tests/main.rs,
+values transcribed), (2) the tutorial's recorded find_all_matches outputs and (3) the oracle twin on random texts.
+
+For (3) the twin's segmentation / lattice / LM code runs unchanged; only its per-segment find_variants is served by the
+C oracle (same results as the twin, tests/test_oracle_c.py) so that hundreds of segments finish in seconds."""
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import analiticcl_amd as A
+from analiticcl_amd import synth
+from oracle import cwrap as O
+from oracle import twin as T
+
+TEST_ALPHABET_TSV = "\n".join(f"{c}\t{c.upper()}" for c in "abcdefghijklmnopqrstuvwxyz") + "\n.\t,\n"
+LM = A.VocabParams(vocabtype="LM")
+
+
+def sparams(**kw):  # src/test.rs:48-68
+    d = dict(max_anagram_distance=2, max_edit_distance=2, max_matches=10, score_threshold=0.0, cutoff_threshold=0.0,
+             max_ngram=2)
+    d.update(kw)
+    return A.SearchParameters(**d)
+
+
+def small(words, lm=(), freq=None):
+    g = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
+    for w in words:
+        g.add_to_vocabulary(w, freq)
+    for t, f in lm:
+        g.add_to_vocabulary(t, f, LM)
+    g.build()
+    return g
+
+
+def lm_model(extra_words=(), extra_lm=()):
+    return small(("I", "think", "sink", "you", "are", "right") + tuple(extra_words) + ("are right",),
+                 (("<bos> I", 2), ("I think", 2), ("I sink", 1), ("you are", 2), ("right <eos>", 2)) + tuple(extra_lm), 2)
+
+
+def best(matches):
+    return [(m["input"], m["variants"][0]["text"] if m["variants"] else m["input"]) for m in matches]
+
+
+def test0701_unigram_only():  # tests/main.rs:1121-1141
+    g = small(("I", "think", "sink", "you", "are", "right"))
+    r = g.find_all_matches("I tink you are rihgt", sparams(max_ngram=1))
+    assert best(r) == [("I", "I"), ("tink", "think"), ("you", "you"), ("are", "are"), ("rihgt", "right")]
+
+
+def test0702_0705_lm():  # tests/main.rs:1144-1424
+    g = lm_model()
+    exp = [("I", "I"), ("tink", "think"), ("you", "you"), ("are rihgt", "are right")]
+    r = g.find_all_matches("I tink you are rihgt", sparams())
+    assert best(r) == exp and (r[1]["offset"]["begin"], r[1]["offset"]["end"]) == (2, 6)
+    r = g.find_all_matches("I tink you are\nrihgt", sparams())
+    assert best(r) == exp[:3] + [("are\nrihgt", "are right")]
+    assert best(g.find_all_matches("I tink you are rihgt", sparams(lm_weight=0.0))) == exp
+    g2 = lm_model(("am", "sure"), (("I am", 2), ("sure <eos>", 2)))
+    r = g2.find_all_matches("I tink you are rihgt\n\nI am sur", sparams())
+    assert best(r) == exp + [("I", "I"), ("am", "am"), ("sur", "sure")]
+
+
+def test0706_0707_offsets():  # tests/main.rs:1427-1481
+    g = small(("I", "think", "you", "are", "right"))
+    r = g.find_all_matches("I thиnk you are righт", sparams(max_ngram=1, unicodeoffsets=True))
+    assert [m["input"] for m in r] == ["I", "thиnk", "you", "are", "righт"]
+    assert (r[1]["offset"]["begin"], r[1]["offset"]["end"]) == (2, 7)
+    assert best(r)[1][1] == "think" and best(r)[4][1] == "right"
+    r = g.find_all_matches("I thиnk you are rihgt", sparams(max_ngram=1))
+    assert (r[1]["offset"]["begin"], r[1]["offset"]["end"]) == (2, 8) and best(r)[4][1] == "right"
+
+
+def test_empty_and_unbuilt():
+    g = small(("a",))
+    assert g.find_all_matches("", sparams()) == []
+    assert g.find_all_matches("   ", sparams()) == []
+    assert g.find_all_matches_ids([], sparams()) == []
+
+
+@pytest.fixture(scope="module")
+def eng(data_dir):
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    g.build()
+    return g
+
+
+def test_tutorial_find_all_matches(eng, tutorial_outputs):
+    """tutorial.ipynb cells 22 and 24 (recorded outputs of the reference)."""
+    p = A.SearchParameters(unicodeoffsets=True)
+    case = tutorial_outputs["find_all_matches"][0]
+    r = eng.find_all_matches(case["input"], p)
+    assert [(m["input"], m["offset"]["begin"], m["offset"]["end"]) for m in r] == \
+        [(c["input"], c["begin"], c["end"]) for c in case["matches"]]
+    for m, c in zip(r, case["matches"]):
+        assert [[v["text"], v["score"], v["dist_score"], v["freq_score"]] for v in m["variants"]] == c["variants"]
+    case = tutorial_outputs["find_all_matches"][1]
+    m = eng.find_all_matches(case["input"], p)[case["only_match_index"]]
+    c = case["matches"][0]
+    assert (m["input"], m["offset"]["begin"], m["offset"]["end"]) == (c["input"], c["begin"], c["end"])
+    assert [[v["text"], v["score"], v["dist_score"], v["freq_score"]] for v in m["variants"]] == c["variants"]
+
+
+class TwinOverOracle(T.SearchModel):
+    """The twin's search mode with find_variants answered by the C oracle (ids are aligned: both number the
+    vocabulary in insertion order after BOS/EOS/UNK)."""
+
+    def attach(self, orc):
+        self.orc = orc
+
+    def find_variants(self, text, params, trace=None):
+        cp = O.make_params(params.max_anagram_distance, params.max_edit_distance, params.max_matches,
+                           params.score_threshold, params.cutoff_threshold, params.stop_at_exact_match,
+                           params.freq_weight)
+        return [T.VariantResult(v, d, f, via) for v, d, f, via in self.orc.find_variants_via(text, cp)]
+
+
+def random_texts(words, phrases, n, seed):
+    rng = random.Random(seed)
+    qs = synth.make_queries(words, n * 9, max_len=14, seed=seed)
+    ps = synth.make_queries(phrases, n * 3, max_len=24, seed=seed + 1)
+    for i in range(0, len(qs), 4):
+        qs[i] = ps[i // 4 % len(ps)]
+    seps = [" "] * 12 + [", ", ". ", "\n", "-", "'", "; ", " (", ") ", "\n\n", "  ", " é ", ": \""]
+    texts, k = [], 0
+    for _ in range(n):
+        nw = rng.randrange(1, 9)
+        t = ""
+        for j in range(nw):
+            t += qs[k]
+            k += 1
+            if j + 1 < nw or rng.random() < 0.3:
+                t += rng.choice(seps)
+        texts.append(t)
+    return texts
+
+
+@pytest.mark.parametrize("with_lm", [False, True])
+def test_random_texts_vs_twin(with_lm):
+    """Markov-free small world: 3000 lexicon words (+ a bigram LM over them when with_lm), 200 random texts, the whole
+    batch in ONE anx_find_all_matches_batch call; every Match field must equal the twin's."""
+    words = [w for w in synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz")) if w.isascii() and w.isalpha()][::37][:3000]
+    rng = random.Random(11)
+    tw = TwinOverOracle(T.TEST_ALPHABET)
+    orc = O.OracleModel(alphabet_text=TEST_ALPHABET_TSV)
+    g = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
+    for w in words:
+        f = rng.randrange(1, 50)
+        tw.add_to_vocabulary(w, f)
+        orc.add(w, f)
+        g.add_to_vocabulary(w, f)
+    phrases = []
+    for _ in range(300):  # indexed multi-word entries, so that bigram / trigram segments do find variants
+        ph = " ".join(rng.choice(words[:400]) for _ in range(rng.choice((2, 2, 3))))
+        if len(ph) <= 22 and ph not in phrases:
+            phrases.append(ph)
+            f = rng.randrange(1, 50)
+            tw.add_to_vocabulary(ph, f)
+            orc.add(ph, f)
+            g.add_to_vocabulary(ph, f)
+    if with_lm:
+        for _ in range(4000):
+            a, b = rng.choice(words[:400]), rng.choice(words[:400])
+            f = rng.randrange(1, 9)
+            tw.add_lm(f"{a} {b}", f)
+            g.add_to_vocabulary(f"{a} {b}", f, LM)
+        for w in words[:50]:
+            tw.add_lm(f"<bos> {w}", 3)
+            g.add_to_vocabulary(f"<bos> {w}", 3, LM)
+    tw.build()
+    orc.build()
+    g.build()
+    tw.attach(orc)
+    texts = random_texts(words[:400] if with_lm else words, phrases, 200, 5 + int(with_lm))
+    gp = A.SearchParameters(max_anagram_distance=2, max_edit_distance=2, max_matches=6, score_threshold=0.3,
+                            cutoff_threshold=0.0, max_ngram=3, max_seq=40)
+    tp = T.SearchParams(("abs", 2), ("abs", 2), 6, 0.3, 0.0, False, 0.0, max_ngram=3, max_seq=40)
+    got = g.find_all_matches_ids(texts, gp)
+    n_multi = 0
+    for text, gm in zip(texts, got):
+        exp = tw.find_all_matches(text, tp)
+        raw = text.encode()
+        assert [(raw[m["begin"]:m["end"]].decode(), m["begin"], m["end"]) for m in gm] == \
+            [(e.text, e.begin, e.end) for e in exp], text
+        for m, e in zip(gm, exp):
+            ev = e.variants or []
+            assert [v[0] for v in m["variants"]] == [v.vocab_id for v in ev], (text, e.text)
+            for v, w in zip(m["variants"], ev):
+                assert abs(v[1] - w.dist_score) < 1e-6 and abs(v[2] - w.freq_score) < 1e-6
+            if ev:
+                assert m["selected"] == e.selected, (text, e.text)
+            n_multi += e.n > 1
+    assert n_multi > 0  # the lattice did pick some bigram/trigram segments
