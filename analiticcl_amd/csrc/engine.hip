@@ -32,22 +32,22 @@ namespace anx {
 // ------------------------------------------------------------------------------------------------
 // Device structures
 // ------------------------------------------------------------------------------------------------
-struct Tile {           // <= SCAN_TQ queries of one length / one multiplicity class against the +-k window
-  uint32_t q0, nq;      // query range (queries are sorted by (kernel kind, length))
-  uint32_t c0, c1;      // class-rank range [c0, c1)
+struct Tile {           // <= SCAN_TQ queries of one scan kind, one length and one signature
+  uint32_t q0, nq;      // query range (queries are sorted by (scan kind, length, signature))
+  uint32_t s0, s1;      // signature range [s0, s1) of the +-k charcount window
   uint32_t k;           // clamped anagram distance for this length
   uint32_t lq;          // query length in symbols
-};
-
-struct Work {           // one workgroup of k_scan: a tile against a segment of its class window
-  uint32_t tile, cbeg, cend, kind;  // kind 0 = SAD body, 1..NBITPLANES = bit-plane body with T = kind
+  uint32_t sig_lo, sig_hi;  // the tile's signature (per-group symbol counts, one byte each)
+  uint32_t kind;        // 0 = SAD body, 1..NBITPLANES = bit-plane body with T = kind
 };
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
-constexpr uint32_t SCAN_TQ = 256;        // queries per tile (= per workgroup)
+constexpr uint32_t SCAN_TQ = 32;         // queries per tile (= per wave); 5 bits of a hit-queue entry
 constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
 constexpr uint32_t SCAN_QCAP = 512;      // deferred-hit queue entries per wave (LDS)
-constexpr uint32_t SCAN_SEG_CHUNKS = 16; // class chunks (of 256*CPL classes) per work item (measured: 8 -> 10.0 ms, 16 -> 9.7 ms)
+constexpr uint32_t SCAN_CIDBITS = 27;    // class id bits of a hit-queue entry (class | query-in-tile << 27)
+constexpr uint32_t SCAN_REGIONS = 64;     // pair-list regions with one reservation counter each
+constexpr uint32_t RC_STRIDE = 32;        // uint32 words per region counter block (128 B)
 constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t META_SKIPPED = 0xFFFFFFFFu;
 
@@ -60,6 +60,9 @@ struct DeviceLexicon {
   uint32_t* cls_bits = nullptr;    // [NBITPLANES][cstride] thermometer planes (bit s of plane t: count_s > t), nsym <= 32
   uint8_t* cls_len = nullptr;      // [cstride]
   uint32_t* cls_off = nullptr;
+  uint32_t* sig_lo = nullptr;      // [nsig_pad] signature table (see LexiconImage)
+  uint32_t* sig_hi = nullptr;
+  uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint32_t* ent_vocab = nullptr;
   uint32_t* ent_freq = nullptr;
   uint32_t* ent_meta = nullptr;
@@ -74,7 +77,7 @@ struct DeviceLexicon {
   size_t bytes = 0;
 };
 
-enum { CTR_RAW = 0, CTR_VALID = 1, CTR_SKIPPED = 2, CTR_N = 8 };
+enum { CTR_SKIPPED = 2, CTR_N = 8 };
 
 struct Batch {
   int device = 0;
@@ -84,8 +87,7 @@ struct Batch {
   std::vector<uint32_t> order;     // sorted position -> original index
   std::vector<int32_t> status;     // per original query: 0 ok, ANX_EEMPTY, ANX_ELIMIT
   size_t n_input = 0;
-  std::vector<Tile> tiles;
-  std::vector<Work> work;
+  std::vector<Tile> tiles;         // in launch order (decreasing cost)
   uint32_t qw = 1;                 // uint4 words per query row
   uint32_t dmax = 0;
   uint64_t n_class_tests = 0;
@@ -97,9 +99,11 @@ struct Batch {
   uint32_t* q_meta = nullptr;      // len | k<<8 | d<<16 | first_is_lower<<24
   uint32_t* q_orig = nullptr;      // original index
   Tile* d_tiles = nullptr;
-  Work* d_work = nullptr;
   // device: pipeline
   uint32_t* counters = nullptr;
+  uint32_t* rctr = nullptr;        // [SCAN_REGIONS][RC_STRIDE] per-region reservation / statistics counters
+  uint32_t region_shift = 0;       // log2(slots per region); raw_cap = SCAN_REGIONS << region_shift
+  uint32_t region_fill[SCAN_REGIONS] = {};  // host copy of rctr[r][RC_RAW] after the last run
   uint32_t* qexact = nullptr;      // per query: an exact-anagram class exists (StopAtExactMatch)
   uint32_t* qsurv = nullptr;       // per query: pairs with score >= threshold
   uint32_t* soff = nullptr;        // nq+1, exclusive scan of qsurv
@@ -137,26 +141,38 @@ struct Batch {
 typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant address space: s_load
 
 // ------------------------------------------------------------------------------------------------
-// K1: anagram window scan.
+// K1: signature-pruned anagram scan.
 //   Spec: the set returned by find_nearest_anahashes (src/lib.rs:1143-1308) equals
 //     { class c : L1(cv_q, cv_c) <= k, |len_c - len_q| <= k, cv_q and cv_c share a symbol }
 //   (the bigint `cand % av == 0` containment test of src/anahash.rs:165-171 is
 //   multiset inclusion, i.e. a statement about the prime-exponent = count vectors).
-//   One workgroup owns one query tile and streams every class chunk of the tile's charcount window past
-//   it.  Each wave appends its hits to wave-private 1024-slot chunks of the flat pair list, reserved with
-//   ONE global atomic per chunk (a single contended counter word sustains only ~88 M atomics/s).
+//   Pruning: sig(x) = per-group sums of the count vector (LexiconImage::sym_group); summing is a contraction of
+//   L1, so L1(sig_q, sig_c) > k excludes c.  Queries are sorted by (kind, length, signature) and a tile holds
+//   <= 32 queries of ONE signature; classes are stored in (charcount, signature) order, one run per signature.
+//   One WAVE owns one tile: it tests the tile's signature against the signature table of the +-k charcount
+//   window (64 signatures per step, 2 v_sad_u8 each), copies the class ids of the compatible runs to an LDS stage
+//   and, whenever 64*CPL classes are staged, compares them (lane = class, gathered planes in registers) with
+//   every query of the tile (query planes in SGPRs through s_load).  On eng.aspell k<=3 this leaves 4.6 k of the
+//   68 k class tests per query that the plain charcount window needs.
+//   Hits (1-2 % of the remaining tests) go to an LDS queue as (class, query) and are expanded 64 at a time into
+//   wave-private 256-slot chunks of the pair list.  The pair list is split into SCAN_REGIONS regions with one
+//   reservation counter each (128 B apart): a single contended counter word sustains only ~88 M atomics/s, which
+//   at ~1.5 ms per million queries would be the bottleneck.
 // ------------------------------------------------------------------------------------------------
+enum { RC_RAW = 0, RC_VALID = 1, RC_TESTS = 4 /* u64 per scan kind at 4 + 2*kind */ };
+
 struct WaveOut {
   uint32_t base, left;  // unused part of the current chunk of the pair list (wave-uniform)
   uint32_t emitted;     // pairs appended by this wave (wave-uniform)
   uint32_t nbase;       // chunk reserved by the last wave_reserve when the appended run spills over
   uint32_t split;       // run indices < split go to [base..), the rest to [nbase..)
+  uint32_t rbase, rend; // this wave's region of the pair list: slots [rbase, rend)
+  uint32_t* ctr;        // the region's counter block
 };
 // Wave-wide exclusive prefix sum of ntot + chunk reservation.  Returns this lane's first index g in the
 // wave's appended run; wave_slot(g) maps run indices to pair-list slots.  A run that does not fit in the
-// rest of the current chunk fills it up and continues in a freshly reserved chunk (ONE global atomic).
-__device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane, uint32_t* __restrict__ counters,
-                                        uint32_t* total_out) {
+// rest of the current chunk fills it up and continues in a freshly reserved chunk (ONE atomic).
+__device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane, uint32_t* total_out) {
   uint32_t incl = ntot;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -170,8 +186,8 @@ __device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane
     const uint32_t rest = total - w.left;
     const uint32_t need = rest > SCAN_CHUNK ? rest : SCAN_CHUNK;
     uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(&counters[CTR_RAW], need);
-    w.nbase = __shfl(b, 0);
+    if (lane == 0) b = atomicAdd(&w.ctr[RC_RAW], need);
+    w.nbase = w.rbase + __shfl(b, 0);
   }
   return incl - ntot;
 }
@@ -190,31 +206,29 @@ __device__ inline void wave_commit(WaveOut& w, uint32_t total) {
   }
   w.emitted += total;
 }
-__device__ inline void wave_close(const WaveOut& w, uint32_t lane, uint2* __restrict__ raw, uint32_t raw_cap,
-                                  uint32_t* __restrict__ counters) {
+__device__ inline void wave_close(const WaveOut& w, uint32_t lane, uint2* __restrict__ raw) {
   for (uint32_t i = lane; i < w.left; i += 64)
-    if (w.base + i < raw_cap) raw[w.base + i] = make_uint2(RAW_INVALID, 0u);
-  if (lane == 0 && w.emitted) atomicAdd(&counters[CTR_VALID], w.emitted);  // one atomic per wave
+    if (w.base + i < w.rend) raw[w.base + i] = make_uint2(RAW_INVALID, 0u);
+  if (lane == 0 && w.emitted) atomicAdd(&w.ctr[RC_VALID], w.emitted);  // one atomic per wave
 }
 
-// ---- K1a: thermometer bit planes.  common(q,c) = sum_t popc(Q_t & C_t) is exact when every symbol of the
-// query occurs at most T times (min(a,b) only needs a's planes; class planes saturate at NBITPLANES).
-// L1 = len_q + len_c - 2 common, so  hit <=> common >= max(1, ceil((len_q + len_c - k) / 2)).
-// 2 ops per plane (v_and_b32 full rate + v_bcnt_u32_b32 accumulating) instead of 8 half-rate v_sad_u8.
-// Hits (~0.1 % of tests) are only queued in LDS inside the hot loop and expanded 64 at a time.
 struct ScanArgs {
   const Tile* tiles;
-  const Work* work;
+  uint32_t ntiles;
   const uint32_t* q_bits;
   const uint32_t* q_cv;
   const uint32_t* cls_bits;
   const uint32_t* cls_planes;
   uint32_t cstride;
+  uint32_t pad_class;   // a never-matching padding class (bits 0, counts 0xFF, len 255)
   const uint8_t* cls_len;
   const uint32_t* cls_off;
+  const uint32_t* sig_lo;
+  const uint32_t* sig_hi;
+  const uint32_t* sig_cbeg;
   uint2* raw;
-  uint32_t raw_cap;
-  uint32_t* counters;
+  uint32_t region_cap;  // pair-list slots per region
+  uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
   uint32_t* qexact;
   int want_exact;
 };
@@ -225,214 +239,180 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
   return r;
 }
 
-template <int T, int CPL>
-__device__ inline void scan_bits_body(const ScanArgs& A, const Tile& t, uint32_t cbeg, uint32_t cend,
-                                      uint32_t* __restrict__ queue /* this wave's LDS queue */) {
-  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const uint32_t* __restrict__ q_bits = A.q_bits;
-  const uint32_t* __restrict__ cls_bits = A.cls_bits;
+// T >= 1: thermometer bit planes.  common(q,c) = sum_t popc(Q_t & C_t) is exact when every symbol of the query
+//   occurs at most T times (min(a,b) only needs a's planes; class planes saturate at NBITPLANES).
+//   L1 = len_q + len_c - 2 common, so  hit <=> common >= max(1, ceil((len_q + len_c - k) / 2))   (>= 1: the
+//   classes share a symbol, src/iterators.rs:177).  2 ops per plane: v_and_b32 + accumulating v_bcnt_u32_b32.
+// T == 0: general path (any alphabet size / multiplicity): packed u8 count vectors, NP x v_sad_u8;
+//   hit <=> L1 <= k and L1 < len_q + len_c.
+template <int T, int NP>
+__device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage,
+                                 uint32_t* __restrict__ queue) {
+  constexpr bool BITS = T > 0;
+  constexpr int CPL = BITS ? 4 : (NP <= 8 ? 4 : NP <= 16 ? 2 : 1);  // classes per lane
+  constexpr int W = BITS ? T : NP;                                   // dwords compared per class
+  constexpr int QSTRIDE = BITS ? NBITPLANES : NP;
+  constexpr uint32_t CHUNK = 64u * CPL;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t* __restrict__ cls_words = BITS ? A.cls_bits : A.cls_planes;
   const uint8_t* __restrict__ cls_len = A.cls_len;
   const uint32_t* __restrict__ cls_off = A.cls_off;
   uint2* __restrict__ raw = A.raw;
-  const uint32_t cstride = A.cstride, raw_cap = A.raw_cap;
-  WaveOut wo{0, 0, 0, 0, 0};
-  uint32_t qn = 0;  // queued hits of this wave (wave-uniform)
-  const int32_t lqk = (int32_t)t.lq - (int32_t)t.k;
-  cptr_u32 qbase = (cptr_u32)(q_bits + (size_t)t.q0 * NBITPLANES);
+  const uint32_t cstride = A.cstride;
+  const uint32_t region = item % SCAN_REGIONS;
+  WaveOut wo{0, 0, 0, 0, 0, region * A.region_cap, (region + 1) * A.region_cap, A.rctr + region * RC_STRIDE};
+  uint32_t qn = 0;       // queued hits (wave-uniform)
+  uint32_t ns = 0;       // staged class ids (wave-uniform)
+  uint32_t nchunks = 0;
+  cptr_u32 qbase = (cptr_u32)((BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE);
 
-  // expands queued (query, lane, chunk) hits: recompute the few class tests of that lane, emit pairs
+  // expands queued (class, query) hits into (query, entry) pairs
   auto drain = [&]() {
     for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
       const uint32_t idx = r0 + lane;
-      uint32_t e0[CPL], n[CPL], ntot = 0, exmask = 0, qi = 0;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) { e0[j] = 0; n[j] = 0; }
+      uint32_t e0 = 0, n = 0, q = 0, exact = 0;
       if (idx < qn) {
         const uint32_t ent = queue[idx];
-        qi = ent & 0xFF;
-        const uint32_t ln = (ent >> 8) & 63, ch = ent >> 14;
-        const uint32_t cb = t.c0 + ch * (256 * CPL) + wid * 64 + ln;
-        uint32_t qb[T];
-#pragma unroll
-        for (int p = 0; p < T; ++p) qb[p] = q_bits[(size_t)(t.q0 + qi) * NBITPLANES + p];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          const uint32_t c = cb + j * 256;
-          int32_t common = 0;
-#pragma unroll
-          for (int p = 0; p < T; ++p) common += __popc(qb[p] & cls_bits[(size_t)p * cstride + c]);
-          const int32_t l1 = (int32_t)t.lq + (int32_t)cls_len[c] - 2 * common;
-          if (l1 <= (int32_t)t.k && common >= 1) {  // common >= 1: shares a symbol (src/iterators.rs:177)
-            e0[j] = cls_off[c];
-            n[j] = cls_off[c + 1] - e0[j];
-            ntot += n[j];
-            if (l1 == 0) exmask |= 1u << j;
+        const uint32_t cid = ent & ((1u << SCAN_CIDBITS) - 1u);
+        q = t.q0 + (ent >> SCAN_CIDBITS);
+        e0 = cls_off[cid];
+        n = cls_off[cid + 1] - e0;
+        if (A.want_exact && cls_len[cid] == t.lq) {  // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
+          bool same = true;
+          for (int p = 0; p < NP; ++p) same &= A.cls_planes[(size_t)p * cstride + cid] == A.q_cv[(size_t)q * NP + p];
+          if (same) {
+            exact = 0x80000000u;
+            A.qexact[q] = 1;  // benign race: every writer stores 1
           }
         }
       }
       uint32_t total;
-      uint32_t g = wave_reserve(wo, ntot, lane, A.counters, &total);
-      if (ntot) {
-        const uint32_t q = t.q0 + qi;
-        if (A.want_exact && exmask) A.qexact[q] = 1;  // benign race: every writer stores 1
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          const uint32_t exact = (exmask >> j) & 1u ? 0x80000000u : 0u;
-          for (uint32_t i = 0; i < n[j]; ++i, ++g) {
-            const uint32_t pos = wave_slot(wo, g);
-            if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
-          }
-        }
+      uint32_t g = wave_reserve(wo, n, lane, &total);
+      for (uint32_t i = 0; i < n; ++i, ++g) {
+        const uint32_t pos = wave_slot(wo, g);
+        if (pos < wo.rend) raw[pos] = make_uint2(q, (e0 + i) | exact);
       }
       wave_commit(wo, total);
     }
     qn = 0;
   };
 
-  uint32_t chunk = (cbeg - t.c0) / (256 * CPL);
-  for (uint32_t cb = cbeg; cb < cend; cb += 256 * CPL, ++chunk) {
-    // Unguarded loads: the class arrays are padded by never-matching classes (bits 0, len 255), and real
-    // classes beyond c1 lie outside the +-k charcount window, so they can never satisfy L1 <= k.
-    uint32_t cp[CPL][T];
-    int32_t negthr[CPL];
+  // compares the first CHUNK staged classes (padded with the never-matching class) with every query of the tile
+  auto process = [&]() {
+    uint32_t cid[CPL], cw[CPL][W];
+    int32_t thr[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-      const uint32_t c = cb + j * 256 + threadIdx.x;
+      const uint32_t idx = (uint32_t)j * 64u + lane;
+      cid[j] = idx < ns ? stage[idx] : A.pad_class;
 #pragma unroll
-      for (int p = 0; p < T; ++p) cp[j][p] = cls_bits[(size_t)p * cstride + c];
-      const int32_t need = (lqk + (int32_t)cls_len[c] + 1) >> 1;  // ceil((lq + lc - k) / 2)
-      negthr[j] = -(need < 1 ? 1 : need);
-    }
-    uint32_t qnext[T];
-#pragma unroll
-    for (int p = 0; p < T; ++p) qnext[p] = qbase[p];
-    for (uint32_t qi = 0; qi < t.nq; ++qi) {
-      uint32_t qreg[T];
-#pragma unroll
-      for (int p = 0; p < T; ++p) qreg[p] = qnext[p];
-      // prefetch the next query's planes into SGPRs while this one is compared
-      cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * NBITPLANES;
-#pragma unroll
-      for (int p = 0; p < T; ++p) qnext[p] = qv[p];
-      // acc_j = common_j - threshold_j; a class hits iff acc_j >= 0.  The sign bits are combined with
-      // full-rate v_and_b32 (sign(best) == 1 iff every acc_j is negative) instead of half-rate v_max_i32.
-      int32_t best = negthr[0];
-#pragma unroll
-      for (int p = 0; p < T; ++p) best = bcnt_acc(qreg[p] & cp[0][p], best);
-#pragma unroll
-      for (int j = 1; j < CPL; ++j) {
-        int32_t acc = negthr[j];
-#pragma unroll
-        for (int p = 0; p < T; ++p) acc = bcnt_acc(qreg[p] & cp[j][p], acc);
-        best &= acc;
-      }
-      const unsigned long long hitmask = __ballot(best >= 0);
-      if (hitmask) {  // wave-uniform
-        if (best >= 0) queue[qn + __popcll(hitmask & ((1ull << lane) - 1ull))] = qi | (lane << 8) | (chunk << 14);
-        qn += __popcll(hitmask);
-        if (qn > SCAN_QCAP - 64) drain();
+      for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
+      const int32_t lc = (int32_t)cls_len[cid[j]];
+      if (BITS) {
+        const int32_t need = ((int32_t)t.lq - (int32_t)t.k + lc + 1) >> 1;  // ceil((lq + lc - k) / 2)
+        thr[j] = -(need < 1 ? 1 : need);
+      } else {
+        const int32_t share = (int32_t)t.lq + lc - 1;  // L1 < lq + lc: shares a symbol (src/iterators.rs:177, src/lib.rs:1205)
+        thr[j] = share < (int32_t)t.k ? share : (int32_t)t.k;
       }
     }
-  }
-  drain();
-  wave_close(wo, lane, raw, raw_cap, A.counters);
-}
-
-// ---- K1b: general path (any alphabet size / any multiplicity): packed u8 count vectors, v_sad_u8.
-template <int NP, int CPL>
-__device__ inline void scan_sad_body(const ScanArgs& A, const Tile& t, uint32_t cbeg, uint32_t cend) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t* __restrict__ planes = A.cls_planes;
-  const uint8_t* __restrict__ cls_len = A.cls_len;
-  const uint32_t* __restrict__ cls_off = A.cls_off;
-  uint2* __restrict__ raw = A.raw;
-  const uint32_t cstride = A.cstride, raw_cap = A.raw_cap;
-  WaveOut wo{0, 0, 0, 0, 0};
-  const uint32_t k = t.k;
-  cptr_u32 qbase = (cptr_u32)(A.q_cv + (size_t)t.q0 * NP);
-  for (uint32_t cb = cbeg; cb < cend; cb += 256 * CPL) {
-    uint32_t cv[CPL][NP];
+    uint32_t qnext[W];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const uint32_t c = cb + j * 256 + threadIdx.x;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) cv[j][p] = planes[(size_t)p * cstride + c];
-    }
-    uint32_t qnext[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) qnext[p] = qbase[p];
+    for (int p = 0; p < W; ++p) qnext[p] = qbase[p];
     for (uint32_t qi = 0; qi < t.nq; ++qi) {
-      uint32_t qreg[NP];
+      uint32_t qreg[W];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) qreg[p] = qnext[p];
-      cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * NP;
+      for (int p = 0; p < W; ++p) qreg[p] = qnext[p];
+      // prefetch the next query's words into SGPRs while this one is compared
+      cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * QSTRIDE;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) qnext[p] = qv[p];
-      uint32_t dist[CPL];
-      bool any = false;
+      for (int p = 0; p < W; ++p) qnext[p] = qv[p];
+      const uint32_t qtag = qi << SCAN_CIDBITS;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        uint32_t acc = 0;
+        bool hit;
+        if (BITS) {
+          int32_t acc = thr[j];  // common - threshold
 #pragma unroll
-        for (int p = 0; p < NP; ++p) acc = __builtin_amdgcn_sad_u8(qreg[p], cv[j][p], acc);
-        dist[j] = acc;
-        any |= acc <= k;
+          for (int p = 0; p < W; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
+          hit = acc >= 0;
+        } else {
+          uint32_t acc = 0;
+#pragma unroll
+          for (int p = 0; p < W; ++p) acc = __builtin_amdgcn_sad_u8(qreg[p], cw[j][p], acc);
+          hit = (int32_t)acc <= thr[j];
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {  // wave-uniform
+          if (hit) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cid[j] | qtag;
+          qn += (uint32_t)__popcll(m);
+        }
       }
-      if (__ballot(any) != 0ull) {  // wave-uniform
-        uint32_t e0[CPL], n[CPL], ntot = 0, exmask = 0;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          n[j] = 0;
-          e0[j] = 0;
-          if (dist[j] <= k) {
-            const uint32_t c = cb + j * 256 + threadIdx.x;
-            // shares at least one symbol <=> L1 < len_q + len_c (src/iterators.rs:177, src/lib.rs:1205)
-            if (dist[j] < t.lq + (uint32_t)cls_len[c]) {
-              e0[j] = cls_off[c];
-              n[j] = cls_off[c + 1] - e0[j];
-              ntot += n[j];
-              if (dist[j] == 0) exmask |= 1u << j;
-            }
-          }
+      if (qn > SCAN_QCAP - CHUNK) drain();
+    }
+    ++nchunks;
+  };
+
+  for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
+    const uint32_t s = sb + lane;  // the tables are padded to whole steps with never-matching signatures
+    const uint32_t d = __builtin_amdgcn_sad_u8(A.sig_lo[s], t.sig_lo, __builtin_amdgcn_sad_u8(A.sig_hi[s], t.sig_hi, 0u));
+    const bool ok = s < t.s1 && d <= t.k;
+    unsigned long long m = __ballot(ok);
+    if (!m) continue;
+    uint32_t cb = 0, n = 0;
+    if (ok) {
+      cb = A.sig_cbeg[s];
+      n = A.sig_cbeg[s + 1] - cb;
+    }
+    while (m) {  // scalar loop over the compatible signatures of this step
+      const int i = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      uint32_t cbi = (uint32_t)__builtin_amdgcn_readlane((int)cb, i), ni = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
+      while (ni) {
+        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 64 ids
+        if (lane < take) stage[ns + lane] = cbi + lane;
+        ns += take;
+        cbi += take;
+        ni -= take;
+        if (ns >= CHUNK) {
+          process();
+          const uint32_t rem = ns - CHUNK;
+          uint32_t v = 0;
+          if (lane < rem) v = stage[CHUNK + lane];
+          if (lane < rem) stage[lane] = v;
+          ns = rem;
         }
-        uint32_t total;
-        uint32_t g = wave_reserve(wo, ntot, lane, A.counters, &total);
-        if (ntot) {
-          const uint32_t q = t.q0 + qi;
-          if (A.want_exact && exmask) A.qexact[q] = 1;
-#pragma unroll
-          for (int j = 0; j < CPL; ++j) {
-            const uint32_t exact = (exmask >> j) & 1u ? 0x80000000u : 0u;
-            for (uint32_t i = 0; i < n[j]; ++i, ++g) {
-              const uint32_t pos = wave_slot(wo, g);
-              if (pos < raw_cap) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
-            }
-          }
-        }
-        wave_commit(wo, total);
       }
     }
   }
-  wave_close(wo, lane, raw, raw_cap, A.counters);
+  if (ns) process();
+  drain();
+  wave_close(wo, lane, raw);
+  if (lane == 0 && nchunks)
+    atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * T), (unsigned long long)nchunks * CHUNK * t.nq);
 }
 
-constexpr int BITS_CPL[NBITPLANES + 1] = {0, 8, 8, 6, 4};  // classes per lane of the T-plane variants
-template <int NP> struct SadCpl { static constexpr int v = NP <= 8 ? 4 : NP <= 16 ? 2 : 1; };
-
-// One launch for the whole batch: every workgroup takes one (tile, class segment) work item; the item's
-// kind (wave-uniform, workgroup-uniform) selects the comparison body.  Items are ordered by decreasing cost.
+// One launch for the whole batch: every wave takes one tile; the tile's kind (wave-uniform) selects the comparison
+// body.  Tiles are ordered by decreasing cost.
+constexpr uint32_t SCAN_STAGE = 64 * 4 + 64;
 template <int NP>
 __global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
   __shared__ uint32_t s_queue[4][SCAN_QCAP];
-  const Work w = A.work[blockIdx.x];
-  const Tile t = A.tiles[w.tile];
-  uint32_t* queue = s_queue[threadIdx.x >> 6];
-  switch (w.kind) {
-    case 1: scan_bits_body<1, BITS_CPL[1]>(A, t, w.cbeg, w.cend, queue); break;
-    case 2: scan_bits_body<2, BITS_CPL[2]>(A, t, w.cbeg, w.cend, queue); break;
-    case 3: scan_bits_body<3, BITS_CPL[3]>(A, t, w.cbeg, w.cend, queue); break;
-    case 4: scan_bits_body<4, BITS_CPL[4]>(A, t, w.cbeg, w.cend, queue); break;
-    default: scan_sad_body<NP, SadCpl<NP>::v>(A, t, w.cbeg, w.cend); break;
+  __shared__ uint32_t s_stage[4][SCAN_STAGE];
+  const uint32_t wid = threadIdx.x >> 6;
+  const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wid));
+  if (item >= A.ntiles) return;
+  const cptr_u32 tp = (cptr_u32)(A.tiles + item);
+  Tile t;
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8];
+  uint32_t* queue = s_queue[wid];
+  uint32_t* stage = s_stage[wid];
+  switch (t.kind) {
+    case 1: scan_tile<1, NP>(A, t, item, stage, queue); break;
+    case 2: scan_tile<2, NP>(A, t, item, stage, queue); break;
+    case 3: scan_tile<3, NP>(A, t, item, stage, queue); break;
+    case 4: scan_tile<4, NP>(A, t, item, stage, queue); break;
+    default: scan_tile<0, NP>(A, t, item, stage, queue); break;
   }
 }
 
@@ -558,7 +538,10 @@ __device__ inline void filter_shift(const uint32_t (&q)[4], const uint32_t (&c)[
   }
 }
 
-__global__ __launch_bounds__(256) void k_prefilter(uint32_t nraw, const uint2* __restrict__ raw,
+// The pair list is SCAN_REGIONS regions of 1 << region_shift slots; region r holds rctr[r][RC_RAW] slots.  The
+// per-slot kernels run on a (blocks of the fullest region) x (regions) grid.
+
+__global__ __launch_bounds__(256) void k_prefilter(uint32_t region_shift, const uint32_t* __restrict__ rctr, const uint2* __restrict__ raw,
                                                    const uint32_t* __restrict__ qexact, int stop, int enable,
                                                    const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
                                                    uint32_t qw, const uint32_t* __restrict__ ent_meta,
@@ -566,12 +549,18 @@ __global__ __launch_bounds__(256) void k_prefilter(uint32_t nraw, const uint2* _
                                                    uint32_t* __restrict__ p_meta, uint32_t* __restrict__ blockcount,
                                                    uint32_t* __restrict__ counters) {
   __shared__ uint32_t s_cnt[4];
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t fill = rctr[blockIdx.y * RC_STRIDE + RC_RAW], bidx = blockIdx.y * gridDim.x + blockIdx.x;
+  if (blockIdx.x * 256 >= fill) {  // block-uniform: the whole block lies beyond its region's fill
+    if (threadIdx.x == 0) blockcount[bidx] = 0;
+    return;
+  }
+  const uint32_t p = (blockIdx.y << region_shift) + blockIdx.x * 256 + threadIdx.x;
+  const bool live = blockIdx.x * 256 + threadIdx.x < fill;
   bool selected = false, stop_skipped = false;
   int d = 0, lq = 0, lc = 0;
   uint32_t q4[4] = {0, 0, 0, 0}, c6[6] = {0xFFFFFFFFu, 0, 0, 0, 0, 0xFFFFFFFFu};
   bool filt = false;
-  if (p < nraw) {
+  if (live) {
     const uint2 rp = raw[p];
     const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
     // unused chunk tail, or (StopAtExactMatch, src/lib.rs:1164-1173) a non-exact class of a query that has one
@@ -607,12 +596,12 @@ __global__ __launch_bounds__(256) void k_prefilter(uint32_t nraw, const uint2* _
     }
     if (filt && (unA > d || unB > d)) selected = false;
   }
-  if (p < nraw && !stop_skipped && raw[p].x != RAW_INVALID)
+  if (live && !stop_skipped && raw[p].x != RAW_INVALID)
     p_meta[p] = selected ? META_PENDING : (PAIR_NONE | (1u << 7));  // rejected: ld = None, samecase = true
   const unsigned long long m = __ballot(selected);
   if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
   __syncthreads();
-  if (threadIdx.x == 0) blockcount[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (threadIdx.x == 0) blockcount[bidx] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
   // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops; only that mode pays an atomic
   if (stop) {
     const unsigned long long ms = __ballot(stop_skipped);
@@ -621,16 +610,19 @@ __global__ __launch_bounds__(256) void k_prefilter(uint32_t nraw, const uint2* _
 }
 
 // K2b: selected slots -> dense index list (block offsets from the exclusive scan of blockcount)
-__global__ __launch_bounds__(256) void k_select(uint32_t nraw, const uint32_t* __restrict__ p_meta,
+__global__ __launch_bounds__(256) void k_select(uint32_t region_shift, const uint32_t* __restrict__ rctr,
+                                                const uint32_t* __restrict__ p_meta,
                                                 const uint32_t* __restrict__ blockoff, uint32_t* __restrict__ sel) {
   __shared__ uint32_t s_cnt[4];
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-  const bool selected = p < nraw && p_meta[p] == META_PENDING;
+  const uint32_t fill = rctr[blockIdx.y * RC_STRIDE + RC_RAW];
+  if (blockIdx.x * 256 >= fill) return;  // block-uniform
+  const uint32_t p = (blockIdx.y << region_shift) + blockIdx.x * 256 + threadIdx.x;
+  const bool selected = blockIdx.x * 256 + threadIdx.x < fill && p_meta[p] == META_PENDING;
   const unsigned long long m = __ballot(selected);
   const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) s_cnt[wid] = (uint32_t)__popcll(m);
   __syncthreads();
-  uint32_t base = blockoff[blockIdx.x];
+  uint32_t base = blockoff[blockIdx.y * gridDim.x + blockIdx.x];
   for (uint32_t i = 0; i < wid; ++i) base += s_cnt[i];
   if (selected) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
 }
@@ -1109,6 +1101,9 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->cls_bits, img.cls_bits.data(), img.cls_bits.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_len, img.cls_len.data(), img.cls_len.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sig_lo, img.sig_lo.data(), img.sig_lo.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sig_hi, img.sig_hi.data(), img.sig_hi.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sig_cbeg, img.sig_cbeg.data(), img.sig_cbeg.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_vocab, img.ent_vocab.data(), img.ent_vocab.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_freq, img.ent_freq.data(), img.ent_freq.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_meta, img.ent_meta.data(), img.ent_meta.size(), err, &d->bytes)) ||
@@ -1128,7 +1123,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->sig_lo, (void*)d->sig_hi, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) (void)hipFree(p);
@@ -1158,6 +1153,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     uint32_t key;    // kind*256 + len : bucket for the counting sort
     uint32_t off;    // offset of the norm string in its thread's arena
     uint16_t thread;
+    uint64_t sig;    // per-group symbol counts (LexiconImage::sym_group)
   };
   std::vector<Enc> enc(n);
   unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
@@ -1172,7 +1168,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     int16_t codes[kMaxSymbols];
     for (size_t i = lo; i < hi; ++i) {
       Enc& e = enc[i];
-      e.meta = 0; e.key = 0; e.off = 0; e.thread = (uint16_t)tid;
+      e.meta = 0; e.key = 0; e.off = 0; e.thread = (uint16_t)tid; e.sig = 0;
       const int len = utf8[i] ? m.alphabet.scan_into(utf8[i], strlen(utf8[i]), codes, kMaxSymbols) : -1;
       if (len < 0) { b->status[i] = ANX_ELIMIT; continue; }
       if (len == 0) { b->status[i] = ANX_EEMPTY; continue; }
@@ -1190,6 +1186,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
                (first_char_is_lowercase(utf8[i]) ? 1u << 24 : 0u);
       const uint32_t kind = (bits_ok && maxcount <= (uint32_t)NBITPLANES) ? maxcount : 0;
       e.key = kind * 256 + (uint32_t)len;
+      e.sig = signature_of(cv, cvbytes, m.lex.sym_group);
     }
   };
   {
@@ -1216,12 +1213,26 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   b->nq = nq;
   b->qw = (uint32_t)((maxlen + 15) / 16);
   std::vector<uint32_t> h_cv(nq * (size_t)NP, 0), h_bits(nq * (size_t)NBITPLANES, 0), h_meta(nq), h_orig(nq), h_kind(nq);
+  std::vector<uint64_t> h_sig(nq);
   std::vector<uint8_t> h_rows(nq * (size_t)b->qw * 16, 0xFE);
   b->order.resize(nq);
   {
     std::vector<size_t> cursor(kstart.begin(), kstart.end() - 1);
     for (size_t i = 0; i < n; ++i)
       if (enc[i].meta) b->order[cursor[enc[i].key]++] = (uint32_t)i;
+  }
+  {  // inside a (kind, length) bucket: by signature, stable; buckets are independent -> threads take them round-robin
+    auto sort_buckets = [&](unsigned tid) {
+      for (uint32_t kx = tid; kx < NKEYS; kx += nthreads)
+        if (kstart[kx + 1] - kstart[kx] > 1)
+          std::stable_sort(b->order.begin() + (ptrdiff_t)kstart[kx], b->order.begin() + (ptrdiff_t)kstart[kx + 1],
+                           [&](uint32_t x, uint32_t y) { return enc[x].sig < enc[y].sig; });
+    };
+    std::vector<std::thread> th;
+    if (nthreads == 1) sort_buckets(0);
+    else
+      for (unsigned t = 0; t < nthreads; ++t) th.emplace_back(sort_buckets, t);
+    for (auto& x : th) x.join();
   }
   auto fill_range = [&](size_t lo, size_t hi) {
     for (size_t s = lo; s < hi; ++s) {
@@ -1236,6 +1247,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
       h_meta[s] = e.meta;
       h_orig[s] = (uint32_t)i;
       h_kind[s] = e.key >> 8;
+      h_sig[s] = e.sig;
     }
   };
   {
@@ -1247,47 +1259,34 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     }
     for (auto& x : th) x.join();
   }
-  // tiles (<= SCAN_TQ queries of one kind and length) and work items (tile x class segment)
-  const int sad_cpl = NP <= 8 ? 4 : NP <= 16 ? 2 : 1;
+  // tiles: <= SCAN_TQ queries of one kind, length and signature; one wave of k_scan each
   for (size_t i = 0; i < nq;) {
     size_t j = i;
-    while (j < nq && h_kind[j] == h_kind[i] && (h_meta[j] & 0xFF) == (h_meta[i] & 0xFF)) ++j;
+    while (j < nq && h_kind[j] == h_kind[i] && (h_meta[j] & 0xFF) == (h_meta[i] & 0xFF) && h_sig[j] == h_sig[i]) ++j;
     const uint32_t kind = h_kind[i], lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
-    const uint32_t c0 = m.lex.bucket_begin[lo], c1 = m.lex.bucket_begin[hi + 1];
-    const uint32_t cpl = kind == 0 ? (uint32_t)sad_cpl : (uint32_t)BITS_CPL[kind];
-    static const uint32_t seg_chunks = []() { const char* e = getenv("ANX_SEG_CHUNKS"); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : SCAN_SEG_CHUNKS; }();
-    const uint32_t seg = 256u * cpl * seg_chunks;
-    for (size_t s = i; s < j; s += SCAN_TQ) {
-      Tile t{(uint32_t)s, (uint32_t)std::min<size_t>(SCAN_TQ, j - s), c0, c1, k, lq};
-      const uint32_t ti = (uint32_t)b->tiles.size();
-      b->tiles.push_back(t);
-      for (uint32_t cb = c0; cb < c1; cb += seg) b->work.push_back(Work{ti, cb, std::min(c1, cb + seg), kind});
-      b->n_class_tests += (uint64_t)t.nq * (c1 - c0);
-      b->n_tests_kind[kind] += (uint64_t)t.nq * (c1 - c0);
-    }
+    const uint32_t s0 = m.lex.siglen_begin[lo], s1 = m.lex.siglen_begin[hi + 1];
+    for (size_t s = i; s < j; s += SCAN_TQ)
+      b->tiles.push_back(Tile{(uint32_t)s, (uint32_t)std::min<size_t>(SCAN_TQ, j - s), s0, s1, k, lq, (uint32_t)h_sig[i],
+                              (uint32_t)(h_sig[i] >> 32), kind});
     i = j;
   }
-  {  // longest-processing-time-first order: cost ~ queries x classes x per-test cost of the kind
-    static const uint32_t kcost[NBITPLANES + 1] = {36, 9, 15, 22, 28};
-    const std::vector<Tile>& tl = b->tiles;
-    std::stable_sort(b->work.begin(), b->work.end(), [&](const Work& x, const Work& y) {
-      return (uint64_t)tl[x.tile].nq * (x.cend - x.cbeg) * kcost[x.kind] > (uint64_t)tl[y.tile].nq * (y.cend - y.cbeg) * kcost[y.kind];
-    });
-  }
+  // longest-processing-time-first: cost ~ queries (the compatible classes per query vary little inside a length)
+  std::stable_sort(b->tiles.begin(), b->tiles.end(), [](const Tile& x, const Tile& y) {
+    return (uint64_t)x.nq * (x.s1 - x.s0 + 64) > (uint64_t)y.nq * (y.s1 - y.s0 + 64);
+  });
   int rc;
   if ((rc = upload(&b->q_cv, h_cv.data(), h_cv.size(), err, nullptr)) ||
       (rc = upload(&b->q_bits, h_bits.data(), h_bits.size(), err, nullptr)) ||
       (rc = upload(reinterpret_cast<uint8_t**>(&b->q_rows), h_rows.data(), h_rows.size(), err, nullptr)) ||
       (rc = upload(&b->q_meta, h_meta.data(), nq, err, nullptr)) || (rc = upload(&b->q_orig, h_orig.data(), nq, err, nullptr)) ||
-      (rc = upload(&b->d_tiles, b->tiles.data(), b->tiles.size(), err, nullptr)) ||
-      (rc = upload(&b->d_work, b->work.data(), b->work.size(), err, nullptr))) {
+      (rc = upload(&b->d_tiles, b->tiles.data(), b->tiles.size(), err, nullptr))) {
     *code = rc;
     batch_free(b);
     return nullptr;
   }
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->qexact, nq, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->qexact, nq, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
@@ -1309,11 +1308,15 @@ static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_
 }
 
 template <int NP>
-static void launch_scan(const ScanArgs& A, uint32_t nwork, hipStream_t st) {
-  hipLaunchKernelGGL((k_scan<NP>), dim3(nwork), dim3(256), 0, st, A);
+static void launch_scan(const ScanArgs& A, uint32_t nblocks, hipStream_t st) {
+  hipLaunchKernelGGL((k_scan<NP>), dim3(nblocks), dim3(256), 0, st, A);
 }
 
-static int ensure_raw(Batch* b, size_t cap, std::string& err) {
+static int ensure_raw(Batch* b, size_t slots_per_region, std::string& err) {
+  uint32_t shift = 10;
+  while (((size_t)1 << shift) < slots_per_region) ++shift;
+  if (shift > 25) { err = "pair list exceeds 2^31 slots: split the batch"; return ANX_ELIMIT; }
+  const size_t cap = (size_t)SCAN_REGIONS << shift;
   if (cap <= b->raw_cap) return ANX_OK;
   for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount})
     if (p) (void)hipFree(p);
@@ -1323,6 +1326,7 @@ static int ensure_raw(Batch* b, size_t cap, std::string& err) {
   if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err)) ||
       (rc = dalloc(&b->s_meta, cap, err)) || (rc = dalloc(&b->sel, cap, err)) || (rc = dalloc(&b->blockcount, 2 * nblk + nblk / SCAN_TILE + 16, err))) return rc;
   b->raw_cap = cap;
+  b->region_shift = shift;
   return ANX_OK;
 }
 static int ensure_surv(Batch* b, size_t cap, std::string& err) {
@@ -1355,39 +1359,57 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   if (nq == 0) { b->ran = true; return ANX_OK; }
   const int stop = b->params.stop_at_exact_match ? 1 : 0;
   int rc;
-  if (b->raw_cap == 0 &&
-      (rc = ensure_raw(b, nq * (size_t)160 + (size_t)b->work.size() * 4 * SCAN_CHUNK + (1u << 16), err)))
+  if (b->raw_cap == 0 && (rc = ensure_raw(b, (nq * (size_t)140 + b->tiles.size() * SCAN_CHUNK) / SCAN_REGIONS + 4096, err)))
     return rc;
   uint32_t h_counters[CTR_N];
+  std::vector<uint32_t> h_rctr(SCAN_REGIONS * RC_STRIDE);
   HIP_TRY(hipEventRecord(b->ev[0], st));
   // ---- scan ------------------------------------------------------------------------------------------
+  uint32_t maxfill = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(b->rctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
     if (stop) HIP_TRY(hipMemsetAsync(b->qexact, 0, nq * sizeof(uint32_t), st));
-    if (!b->work.empty()) {
+    if (!b->tiles.empty()) {
       ScanArgs A;
-      A.tiles = b->d_tiles; A.work = b->d_work; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
-      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cstride = dl->cstride;
-      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.raw = b->raw;
-      A.raw_cap = (uint32_t)std::min<size_t>(b->raw_cap, 0xFFFFFFFFu);
-      A.counters = b->counters; A.qexact = b->qexact; A.want_exact = stop;
-      const uint32_t nwork = (uint32_t)b->work.size();
+      A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
+      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
+      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig_lo = dl->sig_lo; A.sig_hi = dl->sig_hi; A.sig_cbeg = dl->sig_cbeg;
+      A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
+      const uint32_t nblocks = (A.ntiles + 3) / 4;
       switch (dl->nplanes) {
-        case 8: launch_scan<8>(A, nwork, st); break;
-        case 16: launch_scan<16>(A, nwork, st); break;
-        case 24: launch_scan<24>(A, nwork, st); break;
-        case 32: launch_scan<32>(A, nwork, st); break;
-        default: launch_scan<42>(A, nwork, st); break;
+        case 8: launch_scan<8>(A, nblocks, st); break;
+        case 16: launch_scan<16>(A, nblocks, st); break;
+        case 24: launch_scan<24>(A, nblocks, st); break;
+        case 32: launch_scan<32>(A, nblocks, st); break;
+        default: launch_scan<42>(A, nblocks, st); break;
       }
     }
-    HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->rctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if ((size_t)h_counters[CTR_RAW] <= b->raw_cap) break;
+    maxfill = 0;
+    for (uint32_t r = 0; r < SCAN_REGIONS; ++r) maxfill = std::max(maxfill, h_rctr[r * RC_STRIDE + RC_RAW]);
+    if (maxfill <= (1u << b->region_shift)) break;
     if (attempt == 1) { err = "pair list overflow after regrow"; return ANX_ENODEVICE; }
-    if ((rc = ensure_raw(b, (size_t)h_counters[CTR_RAW] + (size_t)b->work.size() * 4 * SCAN_CHUNK + 1024, err))) return rc;
+    if ((rc = ensure_raw(b, (size_t)maxfill + (maxfill >> 3) + 4096, err))) return rc;
   }
   HIP_TRY(hipEventRecord(b->ev[1], st));
-  const uint32_t nraw = h_counters[CTR_RAW];
+  uint64_t n_valid = 0, n_slots = 0;
+  b->n_class_tests = 0;
+  for (int i = 0; i <= NBITPLANES; ++i) b->n_tests_kind[i] = 0;
+  for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
+    const uint32_t* c = &h_rctr[r * RC_STRIDE];
+    b->region_fill[r] = c[RC_RAW];
+    n_slots += c[RC_RAW];
+    n_valid += c[RC_VALID];
+    for (int i = 0; i <= NBITPLANES; ++i) {
+      uint64_t v;
+      memcpy(&v, c + RC_TESTS + 2 * i, sizeof v);
+      b->n_tests_kind[i] += v;
+      b->n_class_tests += v;
+    }
+  }
+  const uint32_t nraw = maxfill ? (uint32_t)(SCAN_REGIONS << b->region_shift) : 0;  // slot space (regions are sparse)
   b->n_raw = nraw;
   // ---- score -----------------------------------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(b->qsurv, 0, nq * sizeof(uint32_t), st));
@@ -1416,14 +1438,14 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   uint32_t nsel = 0;
   if (nraw) {
     static const int enable_filter = []() { const char* e = getenv("ANX_PREFILTER"); return (e && e[0] == '0') ? 0 : 1; }();
-    const uint32_t nblk = (nraw + 255) / 256;
+    const uint32_t gx = (maxfill + 255) / 256, nblk = gx * SCAN_REGIONS;
     uint32_t* blockoff = b->blockcount + nblk + 1;
     uint32_t* tmp = blockoff + nblk + 1;
-    hipLaunchKernelGGL(k_prefilter, dim3(nblk), dim3(256), 0, st, nraw, b->raw, b->qexact, stop, enable_filter, b->q_meta,
+    hipLaunchKernelGGL(k_prefilter, dim3(gx, SCAN_REGIONS), dim3(256), 0, st, b->region_shift, b->rctr, b->raw, b->qexact, stop, enable_filter, b->q_meta,
                        b->q_rows, b->qw, dl->ent_meta, dl->ent_rowoff, dl->rows, b->p_meta, b->blockcount, b->counters);
     exclusive_scan(b->blockcount, nblk, blockoff, tmp, st);
     HIP_TRY(hipMemcpyAsync(&nsel, blockoff + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_select, dim3(nblk), dim3(256), 0, st, nraw, b->p_meta, blockoff, b->sel);
+    hipLaunchKernelGGL(k_select, dim3(gx, SCAN_REGIONS), dim3(256), 0, st, b->region_shift, b->rctr, b->p_meta, blockoff, b->sel);
     HIP_TRY(hipStreamSynchronize(st));
   }
   b->n_sel = nsel;
@@ -1438,7 +1460,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  b->n_pairs = (uint64_t)h_counters[CTR_VALID] - h_counters[CTR_SKIPPED];
+  b->n_pairs = n_valid - h_counters[CTR_SKIPPED];
   b->n_surv = total_surv;
   if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
   if (nsel) {
@@ -1472,9 +1494,9 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   s.n_pairs = b->n_pairs;
   s.n_class_tests = b->n_class_tests;
   s.n_results = total_results;
-  s.n_scan_blocks = b->work.size();
+  s.n_scan_blocks = b->tiles.size();
   for (int i = 0; i <= NBITPLANES; ++i) s.n_tests_kind[i] = b->n_tests_kind[i];
-  s.n_pair_slots = nraw;
+  s.n_pair_slots = n_slots;
   s.n_survivors = total_surv;
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.ms_score, b->ev[1], b->ev[2]);
@@ -1547,6 +1569,7 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
     std::vector<double> score_of(R, 0.0);
     for (size_t i = 0; i < S; ++i) { pm[sl[i]] = sm[i]; score_of[sl[i]] = ps[i]; }  // selected slots: DP results
     for (size_t i = 0; i < R; ++i) {
+      if ((i & (((size_t)1 << b->region_shift) - 1)) >= b->region_fill[i >> b->region_shift]) continue;  // beyond the region's fill
       if (pm[i] == META_SKIPPED || w >= b->n_pairs) continue;
       anx_pair& r = res[w++];
       r.query = b->order[pr[i].x];
@@ -1586,7 +1609,7 @@ void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 void batch_free(Batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->d_work,
+  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
                   (void*)b->c_vocab, (void*)b->c_score, (void*)b->c_freq, (void*)b->c_via, (void*)b->c_ord, (void*)b->qexpand,

@@ -404,6 +404,16 @@ static int pick_planes(int nsym) {  // kernel variants are instantiated for thes
   return -1;
 }
 
+uint64_t signature_of(const uint8_t* cv, size_t n, const std::vector<uint8_t>& sym_group) {
+  uint8_t g[8] = {};
+  for (size_t sl = 0; sl < n; ++sl) g[sym_group[sl]] = (uint8_t)(g[sym_group[sl]] + cv[sl]);
+  // bytes 0-3 -> sig_lo, 4-7 -> sig_hi: the packing only has to agree between classes and queries (v_sad_u8 is
+  // bytewise) and the sort order only has to make equal signatures adjacent
+  uint64_t s = 0;
+  for (int i = 0; i < 8; ++i) s |= (uint64_t)g[i] << (8 * i);
+  return s;
+}
+
 int HostModel::build_index(std::string& err) {
   const int A = alphabet.size();
   lex = LexiconImage();
@@ -440,10 +450,31 @@ int HostModel::build_index(std::string& err) {
     }
     tmp[it->second].ids.push_back((uint32_t)id);  // ascending id order (src/lib.rs:215-219)
   }
+  {  // symbol groups of the signature: slots by decreasing total count, each to the currently lightest group
+    std::vector<uint64_t> slot_freq(cvbytes, 0);
+    for (const Tmp& t : tmp)
+      for (size_t sl = 0; sl < cvbytes; ++sl) slot_freq[sl] += (uint8_t)t.cv[sl];
+    std::vector<uint32_t> slots(cvbytes);
+    std::iota(slots.begin(), slots.end(), 0u);
+    std::stable_sort(slots.begin(), slots.end(), [&](uint32_t a, uint32_t b) { return slot_freq[a] > slot_freq[b]; });
+    static const int ngroups = []() { const char* e = getenv("ANX_SIG_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : kSigGroups; }();
+    uint64_t weight[8] = {};
+    lex.sym_group.assign(cvbytes, 0);
+    for (uint32_t sl : slots) {
+      int g = 0;
+      for (int i = 1; i < ngroups; ++i)
+        if (weight[i] < weight[g]) g = i;
+      lex.sym_group[sl] = (uint8_t)g;
+      weight[g] += slot_freq[sl];
+    }
+  }
+  std::vector<uint64_t> sig(tmp.size());
+  for (size_t i = 0; i < tmp.size(); ++i) sig[i] = signature_of(reinterpret_cast<const uint8_t*>(tmp[i].cv.data()), cvbytes, lex.sym_group);
   std::vector<uint32_t> order(tmp.size());
   std::iota(order.begin(), order.end(), 0u);
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
     if (tmp[a].charcount != tmp[b].charcount) return tmp[a].charcount < tmp[b].charcount;
+    if (sig[a] != sig[b]) return sig[a] < sig[b];
     return tmp[a].value.cmp(tmp[b].value) < 0;
   });
 
@@ -454,9 +485,15 @@ int HostModel::build_index(std::string& err) {
   lex.cls_bits.assign((size_t)4 * lex.cstride, 0u);
   lex.cls_off.assign(lex.nclasses + 1, 0);
   lex.cls_value.resize(lex.nclasses);
-  for (int c = 0; c <= kMaxSymbols + 1; ++c) lex.bucket_begin[c] = 0;
+  for (int c = 0; c <= kMaxSymbols + 1; ++c) lex.bucket_begin[c] = lex.siglen_begin[c] = 0;
   for (uint32_t r = 0; r < lex.nclasses; ++r) {
     Tmp& t = tmp[order[r]];
+    if (r == 0 || sig[order[r]] != sig[order[r - 1]] || t.charcount != tmp[order[r - 1]].charcount) {
+      lex.sig_lo.push_back((uint32_t)sig[order[r]]);
+      lex.sig_hi.push_back((uint32_t)(sig[order[r]] >> 32));
+      lex.sig_cbeg.push_back(r);
+      lex.siglen_begin[t.charcount + 1]++;
+    }
     for (int p = 0; p < lex.nplanes; ++p) {
       uint32_t wv;
       memcpy(&wv, t.cv.data() + 4 * p, 4);
@@ -506,6 +543,12 @@ int HostModel::build_index(std::string& err) {
       for (uint32_t e = lex.cls_off[r]; e < lex.cls_off[r + 1]; ++e) lex.ent_order[e] = pos++;
   }
   for (int c = 0; c <= kMaxSymbols; ++c) lex.bucket_begin[c + 1] += lex.bucket_begin[c];
+  for (int c = 0; c <= kMaxSymbols; ++c) lex.siglen_begin[c + 1] += lex.siglen_begin[c];
+  lex.nsigs = (uint32_t)lex.sig_lo.size();
+  const size_t nsig_pad = ((size_t)lex.nsigs + 63) / 64 * 64 + 64;  // the scan reads whole 64-signature steps
+  lex.sig_lo.resize(nsig_pad, 0xFFFFFFFFu);
+  lex.sig_hi.resize(nsig_pad, 0xFFFFFFFFu);
+  lex.sig_cbeg.resize(nsig_pad + 1, lex.nclasses);
   build_lm();
   built = true;
   return ANX_OK;
