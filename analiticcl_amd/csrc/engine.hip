@@ -42,14 +42,16 @@ struct Tile {           // <= SCAN_TQ queries of one scan kind, one length and o
 };
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
-constexpr uint32_t SCAN_TQ = 32;         // queries per tile (= per wave); 5 bits of a hit-queue entry
+constexpr uint32_t SCAN_TQ = 32;         // queries per tile (= per wave): one bit each in a lane's hit mask
 constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
-constexpr uint32_t SCAN_QCAP = 512;      // deferred-hit queue entries per wave (LDS)
-constexpr uint32_t SCAN_CIDBITS = 27;    // class id bits of a hit-queue entry (class | query-in-tile << 27)
 constexpr uint32_t SCAN_REGIONS = 64;     // pair-list regions with one reservation counter each
 constexpr uint32_t RC_STRIDE = 32;        // uint32 words per region counter block (128 B)
 constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t META_SKIPPED = 0xFFFFFFFFu;
+
+struct EntRec {   // per-entry attributes k_compact needs, one 16-B gather
+  uint32_t vocab, freq, order, meta;
+};
 
 struct DeviceLexicon {
   int device = 0;
@@ -68,6 +70,7 @@ struct DeviceLexicon {
   uint32_t* ent_meta = nullptr;
   uint32_t* ent_rowoff = nullptr;
   uint32_t* ent_order = nullptr;
+  EntRec* ent_rec = nullptr;           // {vocab, freq, order, meta} per entry
   uint32_t* ent_var_off = nullptr;     // CSR entry -> VariantOf references (variant lists, src/lib.rs:1677-1727)
   uint32_t* var_target = nullptr;      // vocab id of the reference item
   uint32_t* var_target_freq = nullptr;
@@ -78,6 +81,17 @@ struct DeviceLexicon {
 };
 
 enum { CTR_SKIPPED = 2, CTR_N = 8 };
+
+struct SurvRow {  // one candidate result row of a query (k_compact -> k_rank); 32 B, written / read as two 16-B words
+  double score;            // dist_score (times the variant score for expanded rows)
+  unsigned long long ord;  // enumeration-order key: ent_order << 20 | position inside the expansion
+  uint32_t vocab, freq;    // vocab id, absolute frequency of the row
+  uint32_t via, pad;       // vocab id of the variant the row was reached through, 0xFFFFFFFF = none
+};
+struct DevRow {   // one ranked result row (device) for download / gather
+  uint32_t vocab_id, via;
+  double dist_score, freq_score;
+};
 
 struct Batch {
   int device = 0;
@@ -117,16 +131,9 @@ struct Batch {
   uint32_t* sel = nullptr;         // indices of the pair-list slots that passed the prefilter
   uint32_t* blockcount = nullptr;  // per 256-slot block: selected slots (+ scan scratch)
   size_t raw_cap = 0;
-  uint32_t* c_vocab = nullptr;     // result rows grouped by query (survivors, expanded by variant lists)
-  double* c_score = nullptr;
-  uint32_t* c_freq = nullptr;      // absolute frequency of the row
-  uint32_t* c_via = nullptr;       // vocab id of the variant the row was reached through, 0xFFFFFFFF = none
-  uint64_t* c_ord = nullptr;       // enumeration-order key: ent_order << 20 | position inside the expansion
+  SurvRow* c_rows = nullptr;       // candidate result rows grouped by query (survivors, expanded by variant lists)
   uint32_t* qexpand = nullptr;     // per query: some DL survivor has variant references (has_expandable_variants)
-  uint32_t* r_entry = nullptr;     // ranked: vocab id
-  uint32_t* r_via = nullptr;
-  double* r_dist = nullptr;
-  double* r_freq = nullptr;
+  DevRow* r_rows = nullptr;        // ranked rows, per query at soff[q] .. soff[q] + r_count[q]
   double* t_key = nullptr;
   size_t surv_cap = 0;
   uint32_t* r_count = nullptr;
@@ -152,9 +159,10 @@ typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant
 //   One WAVE owns one tile: it tests the tile's signature against the signature table of the +-k charcount
 //   window (64 signatures per step, 2 v_sad_u8 each), copies the class ids of the compatible runs to an LDS stage
 //   and, whenever 64*CPL classes are staged, compares them (lane = class, gathered planes in registers) with
-//   every query of the tile (query planes in SGPRs through s_load).  On eng.aspell k<=3 this leaves 4.6 k of the
+//   every query of the tile (query planes broadcast from LDS).  On eng.aspell k<=3 this leaves 4.6 k of the
 //   68 k class tests per query that the plain charcount window needs.
-//   Hits (1-2 % of the remaining tests) go to an LDS queue as (class, query) and are expanded 64 at a time into
+//   The query loop is branch-free: every lane keeps one hit bit per (class, query) in registers; after the loop
+//   the hits of the chunk (1-2 % of the remaining tests) are expanded through the class -> entries CSR into
 //   wave-private 256-slot chunks of the pair list.  The pair list is split into SCAN_REGIONS regions with one
 //   reservation counter each (128 B apart): a single contended counter word sustains only ~88 M atomics/s, which
 //   at ~1.5 ms per million queries would be the bottleneck.
@@ -231,6 +239,7 @@ struct ScanArgs {
   uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
   uint32_t* qexact;
   int want_exact;
+  int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
 };
 
 __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount(x) in one v_bcnt_u32_b32
@@ -247,7 +256,7 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
 //   hit <=> L1 <= k and L1 < len_q + len_c.
 template <int T, int NP>
 __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage,
-                                 uint32_t* __restrict__ queue) {
+                                 uint32_t* __restrict__ qlds) {
   constexpr bool BITS = T > 0;
   constexpr int CPL = BITS ? 4 : (NP <= 8 ? 4 : NP <= 16 ? 2 : 1);  // classes per lane
   constexpr int W = BITS ? T : NP;                                   // dwords compared per class
@@ -261,45 +270,19 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   const uint32_t cstride = A.cstride;
   const uint32_t region = item % SCAN_REGIONS;
   WaveOut wo{0, 0, 0, 0, 0, region * A.region_cap, (region + 1) * A.region_cap, A.rctr + region * RC_STRIDE};
-  uint32_t qn = 0;       // queued hits (wave-uniform)
-  uint32_t ns = 0;       // staged class ids (wave-uniform)
+  uint32_t ns = 0;  // staged class ids (wave-uniform)
   uint32_t nchunks = 0;
-  cptr_u32 qbase = (cptr_u32)((BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE);
+  {  // the tile's query words -> LDS: the comparison loop reads them back as broadcasts into VGPRs
+    const uint32_t* __restrict__ src = (BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE;
+    for (uint32_t i = lane; i < t.nq * QSTRIDE; i += 64) qlds[i] = src[i];
+  }
 
-  // expands queued (class, query) hits into (query, entry) pairs
-  auto drain = [&]() {
-    for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
-      const uint32_t idx = r0 + lane;
-      uint32_t e0 = 0, n = 0, q = 0, exact = 0;
-      if (idx < qn) {
-        const uint32_t ent = queue[idx];
-        const uint32_t cid = ent & ((1u << SCAN_CIDBITS) - 1u);
-        q = t.q0 + (ent >> SCAN_CIDBITS);
-        e0 = cls_off[cid];
-        n = cls_off[cid + 1] - e0;
-        if (A.want_exact && cls_len[cid] == t.lq) {  // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
-          bool same = true;
-          for (int p = 0; p < NP; ++p) same &= A.cls_planes[(size_t)p * cstride + cid] == A.q_cv[(size_t)q * NP + p];
-          if (same) {
-            exact = 0x80000000u;
-            A.qexact[q] = 1;  // benign race: every writer stores 1
-          }
-        }
-      }
-      uint32_t total;
-      uint32_t g = wave_reserve(wo, n, lane, &total);
-      for (uint32_t i = 0; i < n; ++i, ++g) {
-        const uint32_t pos = wave_slot(wo, g);
-        if (pos < wo.rend) raw[pos] = make_uint2(q, (e0 + i) | exact);
-      }
-      wave_commit(wo, total);
-    }
-    qn = 0;
-  };
-
-  // compares the first CHUNK staged classes (padded with the never-matching class) with every query of the tile
+  // compares the first CHUNK staged classes (padded with the never-matching class) with every query of the tile;
+  // bit (nq-1-qi) of hm[j] = query qi hits class j of this lane.  Branch-free inside the query loop.
   auto process = [&]() {
-    uint32_t cid[CPL], cw[CPL][W];
+    ++nchunks;
+    if (A.dbg & 2) return;
+    uint32_t cid[CPL], cw[CPL][W], e0[CPL], ne[CPL], hm[CPL];
     int32_t thr[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -308,6 +291,9 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 #pragma unroll
       for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
       const int32_t lc = (int32_t)cls_len[cid[j]];
+      e0[j] = cls_off[cid[j]];
+      ne[j] = cls_off[cid[j] + 1] - e0[j];
+      hm[j] = 0;
       if (BITS) {
         const int32_t need = ((int32_t)t.lq - (int32_t)t.k + lc + 1) >> 1;  // ceil((lq + lc - k) / 2)
         thr[j] = -(need < 1 ? 1 : need);
@@ -316,18 +302,11 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         thr[j] = share < (int32_t)t.k ? share : (int32_t)t.k;
       }
     }
-    uint32_t qnext[W];
-#pragma unroll
-    for (int p = 0; p < W; ++p) qnext[p] = qbase[p];
-    for (uint32_t qi = 0; qi < t.nq; ++qi) {
+    const uint32_t nqi = (A.dbg & 1) ? 1u : t.nq;
+    for (uint32_t qi = 0; qi < nqi; ++qi) {
       uint32_t qreg[W];
 #pragma unroll
-      for (int p = 0; p < W; ++p) qreg[p] = qnext[p];
-      // prefetch the next query's words into SGPRs while this one is compared
-      cptr_u32 qv = qbase + (size_t)(qi + 1 < t.nq ? qi + 1 : qi) * QSTRIDE;
-#pragma unroll
-      for (int p = 0; p < W; ++p) qnext[p] = qv[p];
-      const uint32_t qtag = qi << SCAN_CIDBITS;
+      for (int p = 0; p < W; ++p) qreg[p] = qlds[qi * QSTRIDE + p];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         bool hit;
@@ -342,15 +321,39 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
           for (int p = 0; p < W; ++p) acc = __builtin_amdgcn_sad_u8(qreg[p], cw[j][p], acc);
           hit = (int32_t)acc <= thr[j];
         }
-        const unsigned long long m = __ballot(hit);
-        if (m) {  // wave-uniform
-          if (hit) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cid[j] | qtag;
-          qn += (uint32_t)__popcll(m);
+        hm[j] = (hm[j] << 1) | (hit ? 1u : 0u);
+      }
+    }
+    // expand the hits of this chunk into (query, entry) pairs
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cnt += (uint32_t)__popc(hm[j]) * ne[j];
+    if (__ballot(cnt != 0) == 0ull) return;  // wave-uniform
+    uint32_t total;
+    uint32_t g = wave_reserve(wo, cnt, lane, &total);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      uint32_t m = hm[j];
+      while (m) {
+        const uint32_t bit = 31u - (uint32_t)__clz((int)m);
+        m &= ~(1u << bit);
+        const uint32_t q = t.q0 + (nqi - 1u - bit);
+        uint32_t exact = 0;
+        if (A.want_exact && cls_len[cid[j]] == t.lq) {  // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
+          bool same = true;
+          for (int p = 0; p < NP; ++p) same &= A.cls_planes[(size_t)p * cstride + cid[j]] == A.q_cv[(size_t)q * NP + p];
+          if (same) {
+            exact = 0x80000000u;
+            A.qexact[q] = 1;  // benign race: every writer stores 1
+          }
+        }
+        for (uint32_t i = 0; i < ne[j]; ++i, ++g) {
+          const uint32_t pos = wave_slot(wo, g);
+          if (pos < wo.rend) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
         }
       }
-      if (qn > SCAN_QCAP - CHUNK) drain();
     }
-    ++nchunks;
+    wave_commit(wo, total);
   };
 
   for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
@@ -358,7 +361,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     const uint32_t d = __builtin_amdgcn_sad_u8(A.sig_lo[s], t.sig_lo, __builtin_amdgcn_sad_u8(A.sig_hi[s], t.sig_hi, 0u));
     const bool ok = s < t.s1 && d <= t.k;
     unsigned long long m = __ballot(ok);
-    if (!m) continue;
+    if (!m || (A.dbg & 4)) continue;
     uint32_t cb = 0, n = 0;
     if (ok) {
       cb = A.sig_cbeg[s];
@@ -386,7 +389,6 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     }
   }
   if (ns) process();
-  drain();
   wave_close(wo, lane, raw);
   if (lane == 0 && nchunks)
     atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * T), (unsigned long long)nchunks * CHUNK * t.nq);
@@ -397,7 +399,8 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 constexpr uint32_t SCAN_STAGE = 64 * 4 + 64;
 template <int NP>
 __global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
-  __shared__ uint32_t s_queue[4][SCAN_QCAP];
+  constexpr int QWORDS = SCAN_TQ * (NP > NBITPLANES ? NP : NBITPLANES);
+  __shared__ uint32_t s_qlds[4][QWORDS];
   __shared__ uint32_t s_stage[4][SCAN_STAGE];
   const uint32_t wid = threadIdx.x >> 6;
   const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wid));
@@ -405,14 +408,14 @@ __global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
   t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8];
-  uint32_t* queue = s_queue[wid];
+  uint32_t* qlds = s_qlds[wid];
   uint32_t* stage = s_stage[wid];
   switch (t.kind) {
-    case 1: scan_tile<1, NP>(A, t, item, stage, queue); break;
-    case 2: scan_tile<2, NP>(A, t, item, stage, queue); break;
-    case 3: scan_tile<3, NP>(A, t, item, stage, queue); break;
-    case 4: scan_tile<4, NP>(A, t, item, stage, queue); break;
-    default: scan_tile<0, NP>(A, t, item, stage, queue); break;
+    case 1: scan_tile<1, NP>(A, t, item, stage, qlds); break;
+    case 2: scan_tile<2, NP>(A, t, item, stage, qlds); break;
+    case 3: scan_tile<3, NP>(A, t, item, stage, qlds); break;
+    case 4: scan_tile<4, NP>(A, t, item, stage, qlds); break;
+    default: scan_tile<0, NP>(A, t, item, stage, qlds); break;
   }
 }
 
@@ -783,49 +786,36 @@ struct CompactArgs {
 __global__ __launch_bounds__(256) void k_compact(uint32_t nsel, const uint32_t* __restrict__ sel,
                                                  const uint2* __restrict__ raw, const double* __restrict__ s_score,
                                                  CompactArgs a, const uint32_t* __restrict__ soff,
-                                                 uint32_t* __restrict__ qcur, const uint32_t* __restrict__ ent_vocab,
-                                                 const uint32_t* __restrict__ ent_freq,
-                                                 const uint32_t* __restrict__ ent_order,
-                                                 const uint32_t* __restrict__ ent_meta,
+                                                 uint32_t* __restrict__ qcur, const EntRec* __restrict__ ent_rec,
                                                  const uint32_t* __restrict__ ent_var_off,
                                                  const uint32_t* __restrict__ var_target,
                                                  const uint32_t* __restrict__ var_target_freq,
-                                                 const double* __restrict__ var_score, uint32_t* __restrict__ c_vocab,
-                                                 double* __restrict__ c_score, uint32_t* __restrict__ c_freq,
-                                                 uint32_t* __restrict__ c_via, uint64_t* __restrict__ c_ord) {
+                                                 const double* __restrict__ var_score, SurvRow* __restrict__ c_rows) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nsel) return;
   const double s = s_score[i];
   if (!(s >= a.thr)) return;  // NaN = pruned
   const uint2 v = raw[sel[i]];
   const uint32_t e = v.y & 0x7FFFFFFFu, q = v.x;
-  const uint32_t f = a.have_freq ? ent_freq[e] : 1u;
-  const uint64_t ord = (uint64_t)ent_order[e] << 20;
+  const EntRec er = ent_rec[e];
+  const uint32_t f = a.have_freq ? er.freq : 1u;
+  const unsigned long long ord = (unsigned long long)er.order << 20;
   uint32_t v0 = 0, v1 = 0, self = 1;
   if (a.any_variants) {
     v0 = ent_var_off[e];
     v1 = ent_var_off[e + 1];
-    self = (ent_meta[e] & 0x400u) ? 0u : 1u;
+    self = (er.meta & 0x400u) ? 0u : 1u;
   }
   const uint32_t nrows = (v1 - v0) + self;
   if (!nrows) return;
   uint32_t pos = soff[q] + atomicAdd(&qcur[q], nrows);
-  const uint32_t vid = ent_vocab[e];
   for (uint32_t j = v0; j < v1; ++j, ++pos) {  // references first, then the item itself (src/lib.rs:1689-1717)
     const uint32_t tf = var_target_freq[j];
-    c_vocab[pos] = var_target[j];
-    c_score[pos] = s * var_score[j];
-    c_freq[pos] = a.have_freq ? (tf < f ? tf : f) : (tf < 1u ? tf : 1u);  // min(target frequency, own freq_score)
-    c_via[pos] = vid;
-    c_ord[pos] = ord | (uint64_t)(j - v0);
+    // min(target frequency, own freq_score)
+    c_rows[pos] = SurvRow{s * var_score[j], ord | (unsigned long long)(j - v0), var_target[j],
+                          a.have_freq ? (tf < f ? tf : f) : (tf < 1u ? tf : 1u), er.vocab, 0u};
   }
-  if (self) {
-    c_vocab[pos] = vid;
-    c_score[pos] = s;
-    c_freq[pos] = f;
-    if (a.any_variants) c_via[pos] = 0xFFFFFFFFu;  // without variant lists k_rank never reads c_via
-    c_ord[pos] = ord | (uint64_t)(v1 - v0);
-  }
+  if (self) c_rows[pos] = SurvRow{s, ord | (unsigned long long)(v1 - v0), er.vocab, f, 0xFFFFFFFFu, 0u};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -840,7 +830,7 @@ struct RankArgs {
   int have_freq, any_variants;
 };
 constexpr int RANK_G = 64;      // lanes per query (measured on config 2: 64 -> 1.43 ms, 16 -> 2.16 ms: mixed list lengths diverge)
-constexpr int RANK_LCAP = 256;  // rows per query staged in LDS; longer lists spill to t_key / global reads
+constexpr int RANK_LCAP = 128;  // rows per query staged in LDS; longer lists spill to t_key / global reads
 
 __device__ inline double result_score(double dist, double freq, float fw) {  // src/types.rs:335-341
   if (fw == 0.0f) return dist;
@@ -848,16 +838,11 @@ __device__ inline double result_score(double dist, double freq, float fw) {  // 
 }
 
 __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __restrict__ soff,
-                                              const uint32_t* __restrict__ c_vocab,
-                                              const double* __restrict__ c_score,
-                                              const uint32_t* __restrict__ c_freq,
-                                              const uint32_t* __restrict__ c_via,
-                                              const uint64_t* __restrict__ c_ord,
+                                              const SurvRow* __restrict__ c_rows,
                                               const uint32_t* __restrict__ qmaxfreq,
                                               const uint32_t* __restrict__ qexpand, RankArgs a,
-                                              double* __restrict__ t_key, uint32_t* __restrict__ r_vocab,
-                                              uint32_t* __restrict__ r_via, double* __restrict__ r_dist,
-                                              double* __restrict__ r_freq, uint32_t* __restrict__ r_count) {
+                                              double* __restrict__ t_key, DevRow* __restrict__ r_rows,
+                                              uint32_t* __restrict__ r_count) {
   constexpr int NG = 256 / RANK_G;
   __shared__ double s_key[NG][RANK_LCAP];
   __shared__ unsigned long long s_ord[NG][RANK_LCAP];
@@ -867,27 +852,30 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
   const int gshift = (threadIdx.x & 63) / RANK_G * RANK_G;  // this group's first lane inside its wave
   const unsigned long long gmask = RANK_G >= 64 ? ~0ull : ((1ull << (RANK_G & 63)) - 1ull);
   const uint32_t q = blockIdx.x * NG + grp;
-  uint32_t seg0 = 0, n = 0;
+  uint32_t seg0 = 0, n = 0, maxf = 0, qex = 0;
   if (q < nq) {
     seg0 = soff[q];
     n = soff[q + 1] - seg0;
+    maxf = qmaxfreq[q];                      // independent loads issued together with soff
+    if (a.any_variants) qex = qexpand[q];
     if (n == 0 && gl == 0) r_count[q] = 0;
   }
-  const uint32_t maxf = n ? qmaxfreq[q] : 0;
   // expanded rows never raise max_freq: their frequency is a min() with the expanding item's (src/lib.rs:1512-1517)
   const double max_freq = a.have_freq ? (double)maxf : (maxf ? 1.0 : 0.0);
   const bool sort_weighted = a.freq_weight > 0.0f;    // rank_cmp's branch
   const bool score_weighted = a.freq_weight != 0.0f;  // score()'s branch
-  const bool expanded = n && a.any_variants && qexpand[q] != 0;  // has_expandable_variants
+  const bool expanded = n && a.any_variants && qex != 0;  // has_expandable_variants
   // ---- sort keys ------------------------------------------------------------------------------------
+  SurvRow mine{0.0, 0ull, 0u, 0u, 0u, 0u};  // row gl stays in registers (most lists are shorter than the group)
   for (uint32_t i = gl; i < n; i += RANK_G) {
-    const uint32_t f = c_freq[seg0 + i];
-    double key = c_score[seg0 + i];
+    const SurvRow r = c_rows[seg0 + i];
+    if (i == (uint32_t)gl) mine = r;
+    double key = r.score;
     if (sort_weighted) {
-      const double fs = max_freq > 0.0 ? (double)f / max_freq : (double)f;
+      const double fs = max_freq > 0.0 ? (double)r.freq / max_freq : (double)r.freq;
       key = result_score(key, fs, a.freq_weight);
     }
-    if (i < RANK_LCAP) { s_key[grp][i] = key; s_freq[grp][i] = f; s_ord[grp][i] = c_ord[seg0 + i]; }
+    if (i < RANK_LCAP) { s_key[grp][i] = key; s_freq[grp][i] = r.freq; s_ord[grp][i] = r.ord; }
     else t_key[seg0 + i] = key;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -897,24 +885,22 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
   for (uint32_t i = gl; i < n; i += RANK_G) {
     double ki; uint32_t fi; unsigned long long oi;
     if (i < RANK_LCAP) { ki = s_key[grp][i]; fi = s_freq[grp][i]; oi = s_ord[grp][i]; }
-    else { ki = t_key[seg0 + i]; fi = c_freq[seg0 + i]; oi = c_ord[seg0 + i]; }
+    else { ki = t_key[seg0 + i]; fi = c_rows[seg0 + i].freq; oi = c_rows[seg0 + i].ord; }
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; ++j) {
       double kj; uint32_t fj; unsigned long long oj;
       if (j < RANK_LCAP) { kj = s_key[grp][j]; fj = s_freq[grp][j]; oj = s_ord[grp][j]; }
-      else { kj = t_key[seg0 + j]; fj = c_freq[seg0 + j]; oj = c_ord[seg0 + j]; }
+      else { kj = t_key[seg0 + j]; fj = c_rows[seg0 + j].freq; oj = c_rows[seg0 + j].ord; }
       bool before;
       if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
       else before = kj > ki || (kj == ki && (fj > fi || (fj == fi && oj < oi)));
       rank += before;
     }
     if (rank < M) {
-      const double dd = c_score[seg0 + i], ff = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
-      r_vocab[seg0 + rank] = c_vocab[seg0 + i];
-      r_via[seg0 + rank] = a.any_variants ? c_via[seg0 + i] : 0xFFFFFFFFu;
-      r_dist[seg0 + rank] = dd;
-      r_freq[seg0 + rank] = ff;
-      if (rank < RANK_G) { s_sdist[grp][rank] = dd; s_sfreq[grp][rank] = ff; }
+      const SurvRow r = i == (uint32_t)gl ? mine : c_rows[seg0 + i];
+      const double ff = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
+      r_rows[seg0 + rank] = DevRow{r.vocab, a.any_variants ? r.via : 0xFFFFFFFFu, r.score, ff};
+      if (rank < RANK_G) { s_sdist[grp][rank] = r.score; s_sfreq[grp][rank] = ff; }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -955,16 +941,13 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
   // ---- general case: dedup + crop + cutoff, literally, by one lane -------------------------------------
   if (n && !parallel_tail && gl == 0) {
     const float fw = a.freq_weight;
-    double* rd = r_dist + seg0;
-    double* rf = r_freq + seg0;
+    DevRow* rr = r_rows + seg0;
     uint32_t len = n, avail = M;
     if (expanded) {  // results.dedup_by_key(|x| x.vocab_id): consecutive duplicates, first kept (src/lib.rs:1530-1533)
-      uint32_t* rv = r_vocab + seg0;
-      uint32_t* rvia = r_via + seg0;
       uint32_t w = 0;
       for (uint32_t i = 0; i < n; ++i)
-        if (w == 0 || rv[w - 1] != rv[i]) {
-          rv[w] = rv[i]; rvia[w] = rvia[i]; rd[w] = rd[i]; rf[w] = rf[i];
+        if (w == 0 || rr[w - 1].vocab_id != rr[i].vocab_id) {
+          rr[w] = rr[i];
           ++w;
         }
       len = w;
@@ -972,14 +955,14 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
     }
     const uint64_t mm = a.max_matches;
     if (mm > 0 && (uint64_t)len > mm) {
-      const double last = result_score(rd[mm - 1], rf[mm - 1], fw);
-      const double cropped = result_score(rd[mm], rf[mm], fw);
+      const double last = result_score(rr[mm - 1].dist_score, rr[mm - 1].freq_score, fw);
+      const double cropped = result_score(rr[mm].dist_score, rr[mm].freq_score, fw);
       if (cropped < last) len = (uint32_t)mm;
       else {
         uint32_t early = 0, late = 0;
         for (uint32_t i = 0; i < avail; ++i) {
-          if (rd[i] == cropped && early == 0) early = i;
-          if (rd[i] < cropped) { late = i; break; }
+          if (rr[i].dist_score == cropped && early == 0) early = i;
+          if (rr[i].dist_score < cropped) { late = i; break; }
         }
         if (early > 0) len = early + 1;
         else if (late > 0) len = late + 1;
@@ -990,10 +973,10 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
       bool have = false;
       double best = 0.0;
       for (uint32_t i = 0; i < len; ++i) {
-        const double s = result_score(rd[i], rf[i], fw);
+        const double sc = result_score(rr[i].dist_score, rr[i].freq_score, fw);
         if (have) {
-          if (s <= best / a.cutoff_threshold) { cutoff = i; break; }
-        } else { best = s; have = true; }
+          if (sc <= best / a.cutoff_threshold) { cutoff = i; break; }
+        } else { best = sc; have = true; }
       }
     }
     if (cutoff > 0) len = cutoff;
@@ -1002,34 +985,18 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
 }
 
 // dense result rows (device) for download / gather
-struct DevRow {
-  uint32_t vocab_id, via;
-  double dist_score, freq_score;
-};
 __global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* __restrict__ soff,
                                                    const uint32_t* __restrict__ r_off,
                                                    const uint32_t* __restrict__ r_count,
-                                                   const uint32_t* __restrict__ r_vocab,
-                                                   const uint32_t* __restrict__ r_via,
-                                                   const double* __restrict__ r_dist,
-                                                   const double* __restrict__ r_freq, DevRow* __restrict__ out) {
+                                                   const DevRow* __restrict__ r_rows, DevRow* __restrict__ out) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   const uint32_t n = r_count[q], src = soff[q], dst = r_off[q];
-  for (uint32_t i = 0; i < n; ++i) {
-    DevRow r;
-    r.vocab_id = r_vocab[src + i];
-    r.via = r_via[src + i];
-    r.dist_score = r_dist[src + i];
-    r.freq_score = r_freq[src + i];
-    out[dst + i] = r;
-  }
+  for (uint32_t i = 0; i < n; ++i) out[dst + i] = r_rows[src + i];
 }
 __global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t stride, const uint32_t* __restrict__ soff,
                                                      const uint32_t* __restrict__ r_count,
-                                                     const uint32_t* __restrict__ r_vocab,
-                                                     const double* __restrict__ r_dist,
-                                                     const double* __restrict__ r_freq,
+                                                     const DevRow* __restrict__ r_rows,
                                                      const uint32_t* __restrict__ q_orig,
                                                      anx_topk_record* __restrict__ out) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1040,10 +1007,10 @@ __global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t strid
   r.freq_score = 0.0f;
   r.dist_score = 0.0;
   if (i < r_count[q]) {
-    const uint32_t src = soff[q] + i;
-    r.vocab_id = r_vocab[src];
-    r.freq_score = (float)r_freq[src];
-    r.dist_score = r_dist[src];
+    const DevRow d = r_rows[soff[q] + i];
+    r.vocab_id = d.vocab_id;
+    r.freq_score = (float)d.freq_score;
+    r.dist_score = d.dist_score;
   }
   out[(size_t)q_orig[q] * stride + i] = r;
 }
@@ -1095,6 +1062,8 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   for (uint32_t m : img.ent_meta) maxlen = std::max(maxlen, m & 0xFFu);
   d->max_len = maxlen;
   int rc = ANX_OK;
+  std::vector<EntRec> rec(img.ent_vocab.size());
+  for (size_t e = 0; e < rec.size(); ++e) rec[e] = EntRec{img.ent_vocab[e], img.ent_freq[e], img.ent_order[e], img.ent_meta[e]};
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
   if ((rc = upload(&d->cls_planes, img.cls_planes.data(), img.cls_planes.size(), err, &d->bytes)) ||
@@ -1109,6 +1078,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->ent_meta, img.ent_meta.data(), img.ent_meta.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_rowoff, img.ent_rowoff.data(), img.ent_rowoff.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_order, img.ent_order.data(), img.ent_order.size(), err, &d->bytes)) ||
+      (rc = upload(&d->ent_rec, rec.data(), rec.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_var_off, img.ent_var_off.data(), img.ent_var_off.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_target, img.var_target.data(), img.var_target.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_target_freq, img.var_target_freq.data(), img.var_target_freq.size(), err, &d->bytes)) ||
@@ -1124,7 +1094,7 @@ void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->sig_lo, (void*)d->sig_hi, (void*)d->sig_cbeg, (void*)d->ent_vocab,
-                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_var_off,
+                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) (void)hipFree(p);
   delete d;
@@ -1331,19 +1301,14 @@ static int ensure_raw(Batch* b, size_t slots_per_region, std::string& err) {
 }
 static int ensure_surv(Batch* b, size_t cap, std::string& err) {
   if (cap <= b->surv_cap) return ANX_OK;
-  for (void* p : {(void*)b->c_vocab, (void*)b->c_score, (void*)b->c_freq, (void*)b->c_via, (void*)b->c_ord,
-                  (void*)b->r_entry, (void*)b->r_via, (void*)b->r_dist, (void*)b->r_freq, (void*)b->t_key})
+  for (void* p : {(void*)b->c_rows, (void*)b->r_rows, (void*)b->t_key})
     if (p) (void)hipFree(p);
-  b->c_vocab = b->c_freq = b->c_via = b->r_entry = b->r_via = nullptr;
-  b->c_ord = nullptr;
-  b->c_score = b->r_dist = b->r_freq = b->t_key = nullptr;
+  b->c_rows = nullptr;
+  b->r_rows = nullptr;
+  b->t_key = nullptr;
   b->surv_cap = 0;
   int rc;
-  if ((rc = dalloc(&b->c_vocab, cap, err)) || (rc = dalloc(&b->c_score, cap, err)) || (rc = dalloc(&b->c_freq, cap, err)) ||
-      (rc = dalloc(&b->c_via, cap, err)) || (rc = dalloc(&b->c_ord, cap, err)) || (rc = dalloc(&b->r_entry, cap, err)) ||
-      (rc = dalloc(&b->r_via, cap, err)) || (rc = dalloc(&b->r_dist, cap, err)) || (rc = dalloc(&b->r_freq, cap, err)) ||
-      (rc = dalloc(&b->t_key, cap, err)))
-    return rc;
+  if ((rc = dalloc(&b->c_rows, cap, err)) || (rc = dalloc(&b->r_rows, cap, err)) || (rc = dalloc(&b->t_key, cap, err))) return rc;
   b->surv_cap = cap;
   return ANX_OK;
 }
@@ -1376,6 +1341,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
       A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig_lo = dl->sig_lo; A.sig_hi = dl->sig_hi; A.sig_cbeg = dl->sig_cbeg;
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
+      { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
       const uint32_t nblocks = (A.ntiles + 3) / 4;
       switch (dl->nplanes) {
         case 8: launch_scan<8>(A, nblocks, st); break;
@@ -1466,9 +1432,8 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   if (nsel) {
     CompactArgs ca{b->params.score_threshold, m.have_freq ? 1 : 0, dl->any_variants};
     hipLaunchKernelGGL(k_compact, dim3((nsel + 255) / 256), dim3(256), 0, st, nsel, b->sel, b->raw, b->p_score, ca,
-                       b->soff, b->qcur, dl->ent_vocab, dl->ent_freq, dl->ent_order, dl->ent_meta, dl->ent_var_off,
-                       dl->var_target, dl->var_target_freq, dl->var_score, b->c_vocab, b->c_score, b->c_freq, b->c_via,
-                       b->c_ord);
+                       b->soff, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target, dl->var_target_freq, dl->var_score,
+                       b->c_rows);
   }
   HIP_TRY(hipEventRecord(b->ev[3], st));
   // ---- rank ------------------------------------------------------------------------------------------
@@ -1478,9 +1443,8 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
   ra.any_variants = dl->any_variants;
-  hipLaunchKernelGGL(k_rank, dim3((nq + 256 / RANK_G - 1) / (256 / RANK_G)), dim3(256), 0, st, nq, b->soff, b->c_vocab, b->c_score, b->c_freq,
-                     b->c_via, b->c_ord, b->qmaxfreq, b->qexpand, ra, b->t_key, b->r_entry, b->r_via, b->r_dist,
-                     b->r_freq, b->r_count);
+  hipLaunchKernelGGL(k_rank, dim3((nq + 256 / RANK_G - 1) / (256 / RANK_G)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
+                     b->qexpand, ra, b->t_key, b->r_rows, b->r_count);
   exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
   HIP_TRY(hipEventRecord(b->ev[4], st));
   uint32_t total_results = 0;
@@ -1520,7 +1484,7 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
     DevRow* d_rows = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), b->n_results * sizeof(DevRow)));
     hipLaunchKernelGGL(k_pack_rows, dim3(((uint32_t)b->nq + 255) / 256), dim3(256), 0, 0, (uint32_t)b->nq, b->soff,
-                       b->r_off, b->r_count, b->r_entry, b->r_via, b->r_dist, b->r_freq, d_rows);
+                       b->r_off, b->r_count, b->r_rows, d_rows);
     std::vector<DevRow> h(b->n_results);
     std::vector<uint32_t> h_cnt(b->nq);
     HIP_TRY(hipMemcpy(h.data(), d_rows, b->n_results * sizeof(DevRow), hipMemcpyDeviceToHost));
@@ -1599,7 +1563,7 @@ int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32
   if (total)
     hipLaunchKernelGGL(k_export_topk, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), (uint32_t)b->nq, stride, b->soff, b->r_count,
-                       b->r_entry, b->r_dist, b->r_freq, b->q_orig, static_cast<anx_topk_record*>(dst));
+                       b->r_rows, b->q_orig, static_cast<anx_topk_record*>(dst));
   HIP_TRY(hipGetLastError());
   return ANX_OK;
 }
@@ -1612,8 +1576,7 @@ void batch_free(Batch* b) {
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
-                  (void*)b->c_vocab, (void*)b->c_score, (void*)b->c_freq, (void*)b->c_via, (void*)b->c_ord, (void*)b->qexpand,
-                  (void*)b->r_entry, (void*)b->r_via, (void*)b->r_dist, (void*)b->r_freq, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
+                  (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) (void)hipFree(p);
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);
