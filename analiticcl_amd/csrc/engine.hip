@@ -42,7 +42,7 @@ struct Tile {           // <= SCAN_TQ queries of one scan kind, one length and o
 };
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
-constexpr uint32_t SCAN_TQ = 32;         // queries per tile (= per wave): one bit each in a lane's hit mask
+constexpr uint32_t SCAN_TQ = 64;         // queries per tile (= per wave), compared in passes of 32 (one hit-mask bit each)
 constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
 constexpr uint32_t SCAN_REGIONS = 64;     // pair-list regions with one reservation counter each
 constexpr uint32_t RC_STRIDE = 32;        // uint32 words per region counter block (128 B)
@@ -101,7 +101,8 @@ struct Batch {
   std::vector<uint32_t> order;     // sorted position -> original index
   std::vector<int32_t> status;     // per original query: 0 ok, ANX_EEMPTY, ANX_ELIMIT
   size_t n_input = 0;
-  std::vector<Tile> tiles;         // in launch order (decreasing cost)
+  std::vector<Tile> tiles;         // in launch order: bit-plane kinds, then the SAD kind; each by decreasing cost
+  uint32_t n_sad_tiles = 0;
   uint32_t qw = 1;                 // uint4 words per query row
   uint32_t dmax = 0;
   uint64_t n_class_tests = 0;
@@ -118,7 +119,7 @@ struct Batch {
   uint32_t* rctr = nullptr;        // [SCAN_REGIONS][RC_STRIDE] per-region reservation / statistics counters
   uint32_t region_shift = 0;       // log2(slots per region); raw_cap = SCAN_REGIONS << region_shift
   uint32_t region_fill[SCAN_REGIONS] = {};  // host copy of rctr[r][RC_RAW] after the last run
-  uint32_t* qexact = nullptr;      // per query: an exact-anagram class exists (StopAtExactMatch)
+  uint32_t* qexact = nullptr;      // per query: its exact-anagram class, 0xFFFFFFFF = none (StopAtExactMatch; host lookup)
   uint32_t* qsurv = nullptr;       // per query: pairs with score >= threshold
   uint32_t* soff = nullptr;        // nq+1, exclusive scan of qsurv
   uint32_t* qcur = nullptr;
@@ -237,7 +238,7 @@ struct ScanArgs {
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
   uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
-  uint32_t* qexact;
+  const uint32_t* qexact;  // per query: class id of its exact anagram class (0xFFFFFFFF = none); stop mode only
   int want_exact;
   int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
 };
@@ -277,12 +278,13 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     for (uint32_t i = lane; i < t.nq * QSTRIDE; i += 64) qlds[i] = src[i];
   }
 
-  // compares the first CHUNK staged classes (padded with the never-matching class) with every query of the tile;
-  // bit (nq-1-qi) of hm[j] = query qi hits class j of this lane.  Branch-free inside the query loop.
+  // compares the first CHUNK staged classes (padded with the never-matching class) with every query of the tile, 32
+  // queries per pass; bit (npass-1-qi) of hm[j] = query qi of the pass hits class j of this lane.  The query loop is
+  // branch-free: 2 ops per plane + ONE v_alignbit_b32 per test (it shifts the sign bit of acc = "miss" into the mask).
   auto process = [&]() {
     ++nchunks;
     if (A.dbg & 2) return;
-    uint32_t cid[CPL], cw[CPL][W], e0[CPL], ne[CPL], hm[CPL];
+    uint32_t cid[CPL], cw[CPL][W];
     int32_t thr[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -291,9 +293,6 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 #pragma unroll
       for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
       const int32_t lc = (int32_t)cls_len[cid[j]];
-      e0[j] = cls_off[cid[j]];
-      ne[j] = cls_off[cid[j] + 1] - e0[j];
-      hm[j] = 0;
       if (BITS) {
         const int32_t need = ((int32_t)t.lq - (int32_t)t.k + lc + 1) >> 1;  // ceil((lq + lc - k) / 2)
         thr[j] = -(need < 1 ? 1 : need);
@@ -302,58 +301,70 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         thr[j] = share < (int32_t)t.k ? share : (int32_t)t.k;
       }
     }
-    const uint32_t nqi = (A.dbg & 1) ? 1u : t.nq;
-    for (uint32_t qi = 0; qi < nqi; ++qi) {
-      uint32_t qreg[W];
+    for (uint32_t qb = 0; qb < t.nq; qb += 32) {
+      const uint32_t npass = (A.dbg & 1) ? 1u : (t.nq - qb < 32u ? t.nq - qb : 32u);
+      uint32_t hm[CPL];
 #pragma unroll
-      for (int p = 0; p < W; ++p) qreg[p] = qlds[qi * QSTRIDE + p];
+      for (int j = 0; j < CPL; ++j) hm[j] = 0xFFFFFFFFu;  // miss bits
+      for (uint32_t qi = 0; qi < npass; ++qi) {
+        uint32_t qreg[W];
+#pragma unroll
+        for (int p = 0; p < W; ++p) qreg[p] = qlds[(qb + qi) * QSTRIDE + p];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          int32_t acc;
+          if (BITS) {
+            acc = thr[j];  // common - threshold: negative = miss
+#pragma unroll
+            for (int p = 0; p < W; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
+          } else {
+            uint32_t sad = 0;
+#pragma unroll
+            for (int p = 0; p < W; ++p) sad = __builtin_amdgcn_sad_u8(qreg[p], cw[j][p], sad);
+            acc = thr[j] - (int32_t)sad;  // threshold - L1: negative = miss
+          }
+          hm[j] = __builtin_amdgcn_alignbit(hm[j], (uint32_t)acc, 31);  // (hm << 1) | sign(acc)
+        }
+      }
+      // expand the hits of this pass into (query, entry) pairs
+      const uint32_t valid = npass >= 32u ? 0xFFFFFFFFu : ((1u << npass) - 1u);
+      uint32_t any = 0;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        bool hit;
-        if (BITS) {
-          int32_t acc = thr[j];  // common - threshold
-#pragma unroll
-          for (int p = 0; p < W; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
-          hit = acc >= 0;
-        } else {
-          uint32_t acc = 0;
-#pragma unroll
-          for (int p = 0; p < W; ++p) acc = __builtin_amdgcn_sad_u8(qreg[p], cw[j][p], acc);
-          hit = (int32_t)acc <= thr[j];
-        }
-        hm[j] = (hm[j] << 1) | (hit ? 1u : 0u);
+        hm[j] = ~hm[j] & valid;
+        any |= hm[j];
       }
-    }
-    // expand the hits of this chunk into (query, entry) pairs
-    uint32_t cnt = 0;
+      if (__ballot(any != 0) == 0ull) continue;  // wave-uniform
+      uint32_t e0[CPL], ne[CPL], cnt = 0;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) cnt += (uint32_t)__popc(hm[j]) * ne[j];
-    if (__ballot(cnt != 0) == 0ull) return;  // wave-uniform
-    uint32_t total;
-    uint32_t g = wave_reserve(wo, cnt, lane, &total);
+      for (int j = 0; j < CPL; ++j) {
+        e0[j] = 0;
+        ne[j] = 0;
+        if (hm[j]) {
+          e0[j] = cls_off[cid[j]];
+          ne[j] = cls_off[cid[j] + 1] - e0[j];
+          cnt += (uint32_t)__popc(hm[j]) * ne[j];
+        }
+      }
+      uint32_t total;
+      uint32_t g = wave_reserve(wo, cnt, lane, &total);
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      uint32_t m = hm[j];
-      while (m) {
-        const uint32_t bit = 31u - (uint32_t)__clz((int)m);
-        m &= ~(1u << bit);
-        const uint32_t q = t.q0 + (nqi - 1u - bit);
-        uint32_t exact = 0;
-        if (A.want_exact && cls_len[cid[j]] == t.lq) {  // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
-          bool same = true;
-          for (int p = 0; p < NP; ++p) same &= A.cls_planes[(size_t)p * cstride + cid[j]] == A.q_cv[(size_t)q * NP + p];
-          if (same) {
-            exact = 0x80000000u;
-            A.qexact[q] = 1;  // benign race: every writer stores 1
+      for (int j = 0; j < CPL; ++j) {
+        uint32_t m = hm[j];
+        while (m) {
+          const uint32_t bit = 31u - (uint32_t)__clz((int)m);
+          m &= ~(1u << bit);
+          const uint32_t q = t.q0 + qb + (npass - 1u - bit);
+          // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
+          const uint32_t exact = (A.want_exact && A.qexact[q] == cid[j]) ? 0x80000000u : 0u;
+          for (uint32_t i = 0; i < ne[j]; ++i, ++g) {
+            const uint32_t pos = wave_slot(wo, g);
+            if (pos < wo.rend) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
           }
         }
-        for (uint32_t i = 0; i < ne[j]; ++i, ++g) {
-          const uint32_t pos = wave_slot(wo, g);
-          if (pos < wo.rend) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
-        }
       }
+      wave_commit(wo, total);
     }
-    wave_commit(wo, total);
   };
 
   for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
@@ -394,12 +405,13 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * T), (unsigned long long)nchunks * CHUNK * t.nq);
 }
 
-// One launch for the whole batch: every wave takes one tile; the tile's kind (wave-uniform) selects the comparison
-// body.  Tiles are ordered by decreasing cost.
+// Every wave takes one tile; tiles are ordered by decreasing cost.  The bit-plane tiles (wave-uniform switch over
+// T) and the count-vector tiles run as two launches so that the rarely used wide SAD body does not set the register
+// budget (= occupancy) of the common one.
 constexpr uint32_t SCAN_STAGE = 64 * 4 + 64;
-template <int NP>
+template <int NP, bool BITS>
 __global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
-  constexpr int QWORDS = SCAN_TQ * (NP > NBITPLANES ? NP : NBITPLANES);
+  constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
   __shared__ uint32_t s_stage[4][SCAN_STAGE];
   const uint32_t wid = threadIdx.x >> 6;
@@ -410,12 +422,15 @@ __global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
   t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8];
   uint32_t* qlds = s_qlds[wid];
   uint32_t* stage = s_stage[wid];
-  switch (t.kind) {
-    case 1: scan_tile<1, NP>(A, t, item, stage, qlds); break;
-    case 2: scan_tile<2, NP>(A, t, item, stage, qlds); break;
-    case 3: scan_tile<3, NP>(A, t, item, stage, qlds); break;
-    case 4: scan_tile<4, NP>(A, t, item, stage, qlds); break;
-    default: scan_tile<0, NP>(A, t, item, stage, qlds); break;
+  if (BITS) {
+    switch (t.kind) {
+      case 1: scan_tile<1, NP>(A, t, item, stage, qlds); break;
+      case 2: scan_tile<2, NP>(A, t, item, stage, qlds); break;
+      case 3: scan_tile<3, NP>(A, t, item, stage, qlds); break;
+      default: scan_tile<4, NP>(A, t, item, stage, qlds); break;
+    }
+  } else {
+    scan_tile<0, NP>(A, t, item, stage, qlds);
   }
 }
 
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(256) void k_prefilter(uint32_t region_shift, const 
     const uint2 rp = raw[p];
     const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
     // unused chunk tail, or (StopAtExactMatch, src/lib.rs:1164-1173) a non-exact class of a query that has one
-    const bool skip = q == RAW_INVALID || (stop && !(rp.y & 0x80000000u) && qexact[q] != 0);
+    const bool skip = q == RAW_INVALID || (stop && !(rp.y & 0x80000000u) && qexact[q] != 0xFFFFFFFFu);
     stop_skipped = skip && q != RAW_INVALID;
     if (!skip) {
       const uint32_t qm = q_meta[q], em = ent_meta[e];
@@ -1236,17 +1251,40 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     const uint32_t kind = h_kind[i], lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     const uint32_t s0 = m.lex.siglen_begin[lo], s1 = m.lex.siglen_begin[hi + 1];
-    for (size_t s = i; s < j; s += SCAN_TQ)
-      b->tiles.push_back(Tile{(uint32_t)s, (uint32_t)std::min<size_t>(SCAN_TQ, j - s), s0, s1, k, lq, (uint32_t)h_sig[i],
+    static const uint32_t tq = []() { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }();
+    for (size_t s = i; s < j; s += tq)
+      b->tiles.push_back(Tile{(uint32_t)s, (uint32_t)std::min<size_t>(tq, j - s), s0, s1, k, lq, (uint32_t)h_sig[i],
                               (uint32_t)(h_sig[i] >> 32), kind});
     i = j;
   }
   // longest-processing-time-first: cost ~ queries (the compatible classes per query vary little inside a length)
+  // bit-plane tiles first, the SAD tiles (kind 0) after them: two launches
   std::stable_sort(b->tiles.begin(), b->tiles.end(), [](const Tile& x, const Tile& y) {
+    if ((x.kind == 0) != (y.kind == 0)) return y.kind == 0;
     return (uint64_t)x.nq * (x.s1 - x.s0 + 64) > (uint64_t)y.nq * (y.s1 - y.s0 + 64);
   });
+  for (const Tile& t : b->tiles) b->n_sad_tiles += t.kind == 0;
+  std::vector<uint32_t> h_xcls(nq, 0xFFFFFFFFu);
+  if (p.stop_at_exact_match) {  // the exact anagram class of every query (the index lookup of src/lib.rs:1164-1173)
+    auto lookup_range = [&](size_t lo, size_t hi) {
+      std::string key(cvbytes, '\0');
+      for (size_t s = lo; s < hi; ++s) {
+        memcpy(&key[0], &cv_all[(size_t)b->order[s] * cvbytes], cvbytes);
+        auto it = m.class_of_cv.find(key);
+        if (it != m.class_of_cv.end()) h_xcls[s] = it->second;
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; ++t) {
+      const size_t lo = nq * t / nthreads, hi = nq * (t + 1) / nthreads;
+      if (nthreads == 1) lookup_range(lo, hi);
+      else th.emplace_back(lookup_range, lo, hi);
+    }
+    for (auto& x : th) x.join();
+  }
   int rc;
-  if ((rc = upload(&b->q_cv, h_cv.data(), h_cv.size(), err, nullptr)) ||
+  if ((rc = upload(&b->qexact, h_xcls.data(), nq, err, nullptr)) ||
+      (rc = upload(&b->q_cv, h_cv.data(), h_cv.size(), err, nullptr)) ||
       (rc = upload(&b->q_bits, h_bits.data(), h_bits.size(), err, nullptr)) ||
       (rc = upload(reinterpret_cast<uint8_t**>(&b->q_rows), h_rows.data(), h_rows.size(), err, nullptr)) ||
       (rc = upload(&b->q_meta, h_meta.data(), nq, err, nullptr)) || (rc = upload(&b->q_orig, h_orig.data(), nq, err, nullptr)) ||
@@ -1256,7 +1294,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     return nullptr;
   }
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->qexact, nq, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
@@ -1278,8 +1316,16 @@ static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_
 }
 
 template <int NP>
-static void launch_scan(const ScanArgs& A, uint32_t nblocks, hipStream_t st) {
-  hipLaunchKernelGGL((k_scan<NP>), dim3(nblocks), dim3(256), 0, st, A);
+static void launch_scan(ScanArgs A, uint32_t nbits, uint32_t nsad, hipStream_t st) {  // tiles: [bit-plane kinds | SAD kind]
+  if (nbits) {
+    A.ntiles = nbits;
+    hipLaunchKernelGGL((k_scan<NP, true>), dim3((nbits + 3) / 4), dim3(256), 0, st, A);
+  }
+  if (nsad) {
+    A.tiles += nbits;
+    A.ntiles = nsad;
+    hipLaunchKernelGGL((k_scan<NP, false>), dim3((nsad + 3) / 4), dim3(256), 0, st, A);
+  }
 }
 
 static int ensure_raw(Batch* b, size_t slots_per_region, std::string& err) {
@@ -1334,7 +1380,6 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(b->rctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
-    if (stop) HIP_TRY(hipMemsetAsync(b->qexact, 0, nq * sizeof(uint32_t), st));
     if (!b->tiles.empty()) {
       ScanArgs A;
       A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
@@ -1342,13 +1387,13 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig_lo = dl->sig_lo; A.sig_hi = dl->sig_hi; A.sig_cbeg = dl->sig_cbeg;
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
       { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
-      const uint32_t nblocks = (A.ntiles + 3) / 4;
+      const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
       switch (dl->nplanes) {
-        case 8: launch_scan<8>(A, nblocks, st); break;
-        case 16: launch_scan<16>(A, nblocks, st); break;
-        case 24: launch_scan<24>(A, nblocks, st); break;
-        case 32: launch_scan<32>(A, nblocks, st); break;
-        default: launch_scan<42>(A, nblocks, st); break;
+        case 8: launch_scan<8>(A, nbits, nsad, st); break;
+        case 16: launch_scan<16>(A, nbits, nsad, st); break;
+        case 24: launch_scan<24>(A, nbits, nsad, st); break;
+        case 32: launch_scan<32>(A, nbits, nsad, st); break;
+        default: launch_scan<42>(A, nbits, nsad, st); break;
       }
     }
     HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->rctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
