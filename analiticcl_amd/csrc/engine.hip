@@ -410,7 +410,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 // budget (= occupancy) of the common one.
 constexpr uint32_t SCAN_STAGE = 64 * 4 + 64;
 template <int NP, bool BITS>
-__global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
+__device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
   __shared__ uint32_t s_stage[4][SCAN_STAGE];
@@ -433,6 +433,12 @@ __global__ __launch_bounds__(256) void k_scan(ScanArgs A) {
     scan_tile<0, NP>(A, t, item, stage, qlds);
   }
 }
+// <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
+// 64 with spills -> 2.60 ms)
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scan_bits(ScanArgs A) { scan_wave<NP, true>(A); }
+template <int NP>
+__global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false>(A); }
 
 // ------------------------------------------------------------------------------------------------
 // Exclusive prefix sum (u32), three small kernels.  out has n+1 entries.
@@ -646,6 +652,7 @@ __global__ __launch_bounds__(256) void k_select(uint32_t region_shift, const uin
 }
 
 struct ScoreArgs {
+  int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL
   double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
   double score_threshold;
   int have_freq, any_variants;
@@ -654,16 +661,237 @@ struct ScoreArgs {
   uint32_t qw;
 };
 
+// The part of gather_instances / score_and_rank that follows a successful Damerau-Levenshtein (ld <= d):
+// LCS, prefix, suffix, case (src/lib.rs:1352-1377), the f64 score (:1433-1452), max_freq and the survivor count.
+__device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, int lc, uint32_t ld, uint32_t qm, uint32_t em,
+                                    uint32_t q, uint32_t e, const ScoreArgs& a, const uint32_t* __restrict__ ent_freq,
+                                    const uint32_t* __restrict__ ent_var_off, uint32_t* __restrict__ qmaxfreq,
+                                    uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, uint32_t& lcs,
+                                    uint32_t& pre, uint32_t& suf, uint32_t& samecase) {
+  if (a.w_lcs > 0.0 && !(a.dbg & 1)) {  // src/lib.rs:1352-1356; diagonal walk == the reference's naive scan
+    uint32_t best = 0;
+    for (int delta = -(lq - 1); delta <= lc - 1; ++delta) {
+      const int i0 = delta < 0 ? -delta : 0;
+      const int i1 = min(lq, lc - delta);
+      if ((uint32_t)(i1 - i0) <= best) continue;
+      uint32_t run = 0;
+      for (int i = i0; i < i1; ++i) {
+        run = S[i] == T[i + delta] ? run + 1 : 0;
+        best = max(best, run);
+      }
+    }
+    lcs = best;
+  }
+  const int m = min(lq, lc);
+  if (a.w_prefix > 0.0) {
+    int n = 0;
+    while (n < m && S[n] == T[n]) ++n;
+    pre = n;
+  }
+  if (a.w_suffix > 0.0) {
+    int n = 0;
+    while (n < m && S[lq - 1 - n] == T[lc - 1 - n]) ++n;
+    suf = n;
+  }
+  if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
+  const double L = (double)lq;
+  const double distance_score = (int)ld > lq ? 0.0 : 1.0 - ((double)ld / L);
+  const double lcs_score = (double)lcs / L;
+  const double prefix_score = (double)pre / L;
+  const double suffix_score = (double)suf / L;
+  const double score = (a.w_ld * distance_score + a.w_lcs * lcs_score + a.w_prefix * prefix_score +
+           a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0)) /
+          a.w_sum;
+  // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
+  atomicMax(&qmaxfreq[q], a.have_freq ? ent_freq[e] : 1u);
+  uint32_t nrows = 1;
+  if (a.any_variants) {  // variant lists loaded (src/lib.rs:1464-1466, 1510, 1677-1727)
+    if (em & 0x200u) qexpand[q] = 1;  // benign race: every writer stores 1
+    nrows = (ent_var_off[e + 1] - ent_var_off[e]) + ((em & 0x400u) ? 0u : 1u);  // transparent: references only
+  }
+  if (score >= a.score_threshold && nrows) atomicAdd(&qsurv[q], nrows);  // src/lib.rs:1475
+  return score;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 fast path: pairs with both strings <= 16 symbols and d <= 3 (every pair of BASELINE configs 1-2).
+// The banded unrestricted Damerau-Levenshtein runs entirely in registers: both strings are 4 dwords, the row loop
+// is fully unrolled (row number, band column and matrix column are compile-time constants, lanes whose query is
+// shorter are masked), band rows live in a ring of D+2 register rows, and values are NOT saturated: every cell is
+// >= the true distance and exact along any path of cost <= D, cells outside the band read as D+1 (their true value
+// is >= D+1, so everything derived from them is > D), which gives the same outcome for every result <= d
+// (SURVEY.md appendix A.3).  The transposition term of src/distance.rs:157-162 in band form: with
+// l = i-1-a the last earlier row whose symbol equals t[j-1] and db = j-1-b the last earlier column of this row
+// that matches s[i-1], T = D[l-1][db-1] + a + b + 1, only needed for a + b <= D - 1.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SCORE_DEFER = 0xFFFFFFFDu;  // s_meta marker: pair left to the general k_score_pairs
+
+__device__ inline uint32_t byte_of(const uint32_t (&w)[4], int idx) { return (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; }
+
+template <int D>
+__device__ inline uint32_t dl_band16(const uint32_t (&S)[4], const uint32_t (&T)[4], int lq, int lc, int lqmax) {
+  constexpr int BW = 2 * D + 1, NR = D + 2;
+  constexpr uint32_t CAP = D + 1;
+  uint32_t row[NR][BW];
+  // T padded with D+1 never-matching bytes in front: the band window of row i is bytes [i, i+2D] of tp
+  uint32_t tp[7];
+  {
+    constexpr int SH = D + 1;  // 2..4 bytes
+    const uint32_t fill = 0xFFFFFFFFu;
+    if (SH == 4) { tp[0] = fill; tp[1] = T[0]; tp[2] = T[1]; tp[3] = T[2]; tp[4] = T[3]; tp[5] = fill; tp[6] = fill; }
+    else {
+      tp[0] = __builtin_amdgcn_alignbyte(T[0], fill, 4 - SH);
+      tp[1] = __builtin_amdgcn_alignbyte(T[1], T[0], 4 - SH);
+      tp[2] = __builtin_amdgcn_alignbyte(T[2], T[1], 4 - SH);
+      tp[3] = __builtin_amdgcn_alignbyte(T[3], T[2], 4 - SH);
+      tp[4] = __builtin_amdgcn_alignbyte(fill, T[3], 4 - SH);
+      tp[5] = fill;
+      tp[6] = fill;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < BW; ++c) row[r][c] = CAP;
+#pragma unroll
+  for (int c = 0; c < BW; ++c) row[0][c] = c - D >= 0 ? (uint32_t)(c - D) : CAP;
+#pragma unroll
+  for (int i = 1; i <= 16; ++i) {
+    if (i <= lqmax) {    // wave-uniform
+      if (i <= lq) {     // lanes with shorter queries keep their last row
+        const uint32_t sc = byte_of(S, i - 1);
+        const uint32_t wlo = __builtin_amdgcn_alignbyte(tp[(i >> 2) + 1], tp[i >> 2], i & 3);
+        const uint32_t whi = __builtin_amdgcn_alignbyte(tp[(i >> 2) + 2], tp[(i >> 2) + 1], i & 3);
+        uint32_t (&cur)[BW] = row[i % NR];
+        const uint32_t (&prev)[BW] = row[(i - 1) % NR];
+        bool mt[BW];
+        uint32_t nv[BW];
+#pragma unroll
+        for (int c = 0; c < BW; ++c) {
+          const int j = i + c - D;
+          mt[c] = false;
+          nv[c] = CAP;
+          if (j == 0) nv[c] = (uint32_t)i;
+          else if (j >= 1 && j <= 16) {
+            const uint32_t tc = ((c < 4 ? wlo : whi) >> (8 * (c & 3))) & 0xFFu;
+            mt[c] = sc == tc;
+            const uint32_t up = c + 1 < BW ? prev[c + 1] : CAP;
+            const uint32_t left = c > 0 ? nv[c - 1] : CAP;
+            uint32_t v = min(min(left, up) + 1u, prev[c] + (mt[c] ? 0u : 1u));
+            // transposition
+            bool eqs[D], any_eqs = false, any_mt = false;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+              eqs[a] = i - 2 - a >= 0 ? byte_of(S, i - 2 - a >= 0 ? i - 2 - a : 0) == tc : false;
+              any_eqs |= eqs[a];
+            }
+#pragma unroll
+            for (int b = 0; b < D; ++b)
+              if (c - 1 - b >= 0) any_mt |= mt[c - 1 - b];
+            if (__builtin_amdgcn_ballot_w64(any_eqs && any_mt)) {  // wave-uniform: some lane has a transposition candidate
+              bool a_open = true;  // no closer row matched yet
+#pragma unroll
+              for (int a = 0; a < D; ++a) {
+                if (i - 2 - a < 0) break;
+                bool b_open = true;  // no closer column matched yet
+#pragma unroll
+                for (int b = 0; a + b < D; ++b) {
+                  const int cb = c - 1 - b, x = c + a - b;
+                  if (cb < 0 || j - 1 - b < 1) break;
+                  if (x >= 0 && x < BW) {
+                    const bool cond = a_open && eqs[a] && b_open && mt[cb];
+                    const uint32_t tv = row[(i - 2 - a) % NR][x] + (uint32_t)(a + b + 1);
+                    v = cond ? min(v, tv) : v;
+                  }
+                  b_open = b_open && !mt[cb];
+                }
+                a_open = a_open && !eqs[a];
+              }
+            }
+            nv[c] = v;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < BW; ++c) cur[c] = nv[c];
+      }
+    }
+  }
+  // D[lq][lc]: ring row lq % NR, band column lc - lq + D
+  uint32_t res = CAP;
+  const int rsel = lq % NR, csel = lc - lq + D;
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < BW; ++c) res = (rsel == r && csel == c) ? row[r][c] : res;
+  return res;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_score_fast(uint32_t nsel, const uint32_t* __restrict__ sel,
+                                                    const uint2* __restrict__ raw, const uint32_t* __restrict__ q_meta,
+                                                    const uint4* __restrict__ q_rows, const uint32_t* __restrict__ ent_meta,
+                                                    const uint32_t* __restrict__ ent_rowoff, const uint4* __restrict__ rows,
+                                                    const uint32_t* __restrict__ ent_freq, ScoreArgs a,
+                                                    const uint32_t* __restrict__ ent_var_off, double* __restrict__ s_score,
+                                                    uint32_t* __restrict__ s_meta, uint32_t* __restrict__ qmaxfreq,
+                                                    uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand) {
+  __shared__ uint32_t s_str[256 * 9];  // per lane: query row (4 dwords) + candidate row (4) for the byte-wise tail; odd stride
+  const uint32_t i_sel = blockIdx.x * 256 + threadIdx.x;
+  const bool active = i_sel < nsel;
+  uint32_t q = 0, e = 0, qm = 0, em = 0;
+  int lq = 0, lc = 0, d = 0;
+  uint32_t S[4] = {0, 0, 0, 0}, T[4] = {0, 0, 0, 0};
+  bool fast = false;
+  if (active) {
+    const uint2 rp = raw[sel[i_sel]];
+    q = rp.x;
+    e = rp.y & 0x7FFFFFFFu;
+    qm = q_meta[q];
+    em = ent_meta[e];
+    lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
+    fast = lq <= 16 && lc <= 16 && d <= D;
+    if (fast) {
+      const uint4 Q = q_rows[(size_t)q * a.qw];
+      const uint4 C = rows[ent_rowoff[e]];
+      S[0] = Q.x; S[1] = Q.y; S[2] = Q.z; S[3] = Q.w;
+      T[0] = C.x; T[1] = C.y; T[2] = C.z; T[3] = C.w;
+    }
+  }
+  int lqmax = fast ? lq : 0;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) lqmax = max(lqmax, __shfl_xor(lqmax, o));
+  lqmax = __builtin_amdgcn_readfirstlane(lqmax);
+  const uint32_t res = dl_band16<D>(S, T, fast ? lq : 0, lc, lqmax);
+  if (!active) return;
+  if (!fast) {  // long strings or d > D: the general kernel scores this pair
+    s_meta[i_sel] = SCORE_DEFER;
+    return;
+  }
+  uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
+  double score = __builtin_nan("");
+  const int diff = lq > lc ? lq - lc : lc - lq;
+  if (diff <= d && res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:109-130, 173-178
+    uint32_t* mine = s_str + threadIdx.x * 9;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mine[w] = S[w]; mine[4 + w] = T[w]; }
+    ld = res;
+    score = score_tail(reinterpret_cast<const uint8_t*>(mine), reinterpret_cast<const uint8_t*>(mine + 4), lq, lc, ld, qm, em,
+                       q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase);
+  }
+  s_score[i_sel] = score;
+  s_meta[i_sel] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+}
+
 __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, const uint2* __restrict__ raw,
                               const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
                               const uint32_t* __restrict__ ent_meta, const uint32_t* __restrict__ ent_rowoff,
                               const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
                               const uint32_t* __restrict__ ent_var_off, double* __restrict__ s_score,
                               uint32_t* __restrict__ s_meta, uint32_t* __restrict__ qmaxfreq,
-                              uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand) {
+                              uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, int only_deferred) {
   extern __shared__ uint32_t lds32[];
   const uint32_t i_sel = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i_sel < nsel) {
+  if (i_sel < nsel && (!only_deferred || s_meta[i_sel] == SCORE_DEFER)) {
     const uint32_t p = sel[i_sel];
     const uint2 rp = raw[p];
     const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
@@ -738,50 +966,9 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
           cur[2 * d + 2] = (uint8_t)cap;
         }
         const uint32_t res = R[(lq % NR) * W + (lc - lq + d + 1)];
-        if (res <= (uint32_t)d) {  // src/distance.rs:173-178
+        if (res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:173-178
           ld = res;
-          if (a.w_lcs > 0.0) {  // src/lib.rs:1352-1356; diagonal walk == the reference's naive scan
-            uint32_t best = 0;
-            for (int delta = -(lq - 1); delta <= lc - 1; ++delta) {
-              const int i0 = delta < 0 ? -delta : 0;
-              const int i1 = min(lq, lc - delta);
-              if ((uint32_t)(i1 - i0) <= best) continue;
-              uint32_t run = 0;
-              for (int i = i0; i < i1; ++i) {
-                run = S[i] == T[i + delta] ? run + 1 : 0;
-                best = max(best, run);
-              }
-            }
-            lcs = best;
-          }
-          const int m = min(lq, lc);
-          if (a.w_prefix > 0.0) {
-            int n = 0;
-            while (n < m && S[n] == T[n]) ++n;
-            pre = n;
-          }
-          if (a.w_suffix > 0.0) {
-            int n = 0;
-            while (n < m && S[lq - 1 - n] == T[lc - 1 - n]) ++n;
-            suf = n;
-          }
-          if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
-          const double L = (double)lq;
-          const double distance_score = (int)ld > lq ? 0.0 : 1.0 - ((double)ld / L);
-          const double lcs_score = (double)lcs / L;
-          const double prefix_score = (double)pre / L;
-          const double suffix_score = (double)suf / L;
-          score = (a.w_ld * distance_score + a.w_lcs * lcs_score + a.w_prefix * prefix_score +
-                   a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0)) /
-                  a.w_sum;
-          // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
-          atomicMax(&qmaxfreq[q], a.have_freq ? ent_freq[e] : 1u);
-          uint32_t nrows = 1;
-          if (a.any_variants) {  // variant lists loaded (src/lib.rs:1464-1466, 1510, 1677-1727)
-            if (em & 0x200u) qexpand[q] = 1;  // benign race: every writer stores 1
-            nrows = (ent_var_off[e + 1] - ent_var_off[e]) + ((em & 0x400u) ? 0u : 1u);  // transparent: references only
-          }
-          if (score >= a.score_threshold && nrows) atomicAdd(&qsurv[q], nrows);  // src/lib.rs:1475
+          score = score_tail(S, T, lq, lc, ld, qm, em, q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase);
         }
       }
     }
@@ -1319,12 +1506,12 @@ template <int NP>
 static void launch_scan(ScanArgs A, uint32_t nbits, uint32_t nsad, hipStream_t st) {  // tiles: [bit-plane kinds | SAD kind]
   if (nbits) {
     A.ntiles = nbits;
-    hipLaunchKernelGGL((k_scan<NP, true>), dim3((nbits + 3) / 4), dim3(256), 0, st, A);
+    hipLaunchKernelGGL((k_scan_bits<NP>), dim3((nbits + 3) / 4), dim3(256), 0, st, A);
   }
   if (nsad) {
     A.tiles += nbits;
     A.ntiles = nsad;
-    hipLaunchKernelGGL((k_scan<NP, false>), dim3((nsad + 3) / 4), dim3(256), 0, st, A);
+    hipLaunchKernelGGL((k_scan_sad<NP>), dim3((nsad + 3) / 4), dim3(256), 0, st, A);
   }
 }
 
@@ -1428,6 +1615,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
   if (dl->any_variants) HIP_TRY(hipMemsetAsync(b->qexpand, 0, nq * sizeof(uint32_t), st));
   ScoreArgs sa;
+  { static const int dbg = []() { const char* e = getenv("ANX_SCORE_DBG"); return e ? atoi(e) : 0; }(); sa.dbg = dbg; }
   sa.w_ld = m.weights.ld; sa.w_lcs = m.weights.lcs; sa.w_prefix = m.weights.prefix; sa.w_suffix = m.weights.suffix;
   sa.w_case = m.weights.casew;
   sa.w_sum = m.weights.ld + m.weights.lcs + m.weights.prefix + m.weights.suffix + m.weights.casew;  // src/types.rs:69-73
@@ -1460,10 +1648,22 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     HIP_TRY(hipStreamSynchronize(st));
   }
   b->n_sel = nsel;
-  if (nsel)
-    hipLaunchKernelGGL(k_score_pairs, dim3((nsel + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nsel,
-                       b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
-                       dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand);
+  if (nsel) {
+    // register-resident fast path for pairs of <= 16 symbols with d <= 3; the general kernel takes the rest
+    static const int enable_fast = []() { const char* e = getenv("ANX_SCORE_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int fastD = (enable_fast && d >= 1 && d <= 3) ? (int)d : 0;
+    const dim3 fgrid((nsel + 255) / 256);
+#define ANX_FAST_ARGS nsel, b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa, \
+                      dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand
+    if (fastD == 1) hipLaunchKernelGGL(k_score_fast<1>, fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
+    else if (fastD == 2) hipLaunchKernelGGL(k_score_fast<2>, fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
+    else if (fastD == 3) hipLaunchKernelGGL(k_score_fast<3>, fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
+#undef ANX_FAST_ARGS
+    if (!fastD || b->qw > 1 || dl->max_len > 16)
+      hipLaunchKernelGGL(k_score_pairs, dim3((nsel + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nsel,
+                         b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
+                         dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand, fastD ? 1 : 0);
+  }
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors -----------------------------------------------------------------------------
   exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
