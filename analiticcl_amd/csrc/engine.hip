@@ -88,6 +88,10 @@ struct SurvRow {  // one candidate result row of a query (k_compact -> k_rank); 
   uint32_t vocab, freq;    // vocab id, absolute frequency of the row
   uint32_t via, pad;       // vocab id of the variant the row was reached through, 0xFFFFFFFF = none
 };
+struct SurvRec {   // one scored pair that passed the score threshold (k_score_* -> k_compact), appended per wave
+  uint32_t q, e;
+  double score;
+};
 struct DevRow {   // one ranked result row (device) for download / gather
   uint32_t vocab_id, via;
   double dist_score, freq_score;
@@ -132,6 +136,9 @@ struct Batch {
   uint32_t* sel = nullptr;         // indices of the pair-list slots that passed the prefilter
   uint32_t* blockcount = nullptr;  // per 256-slot block: selected slots (+ scan scratch)
   size_t raw_cap = 0;
+  SurvRec* surv = nullptr;         // survivor records in SCAN_REGIONS regions of surv_region_cap (order arbitrary)
+  uint32_t* sctr = nullptr;        // [SCAN_REGIONS][RC_STRIDE] fill of every survivor region
+  size_t surv_region_cap = 0;
   SurvRow* c_rows = nullptr;       // candidate result rows grouped by query (survivors, expanded by variant lists)
   uint32_t* qexpand = nullptr;     // per query: some DL survivor has variant references (has_expandable_variants)
   DevRow* r_rows = nullptr;        // ranked rows, per query at soff[q] .. soff[q] + r_count[q]
@@ -661,13 +668,30 @@ struct ScoreArgs {
   uint32_t qw;
 };
 
+// Appends the wave's survivors to the survivor list: one atomic per wave on the counter of region (block % regions).
+struct SurvOut {
+  SurvRec* list;
+  uint32_t* ctr;          // [SCAN_REGIONS][RC_STRIDE]
+  uint32_t region_cap;
+};
+__device__ inline void surv_append(const SurvOut& o, bool keep, uint32_t q, uint32_t e, double score) {
+  const unsigned long long km = __ballot(keep);
+  if (!km) return;  // wave-uniform
+  const uint32_t lane = threadIdx.x & 63, region = blockIdx.x % SCAN_REGIONS;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__ffsll((long long)km) - 1u) base = atomicAdd(&o.ctr[region * RC_STRIDE], (uint32_t)__popcll(km));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)km) - 1);
+  const uint32_t pos = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+  if (keep && pos < o.region_cap) o.list[(size_t)region * o.region_cap + pos] = SurvRec{q, e, score};
+}
+
 // The part of gather_instances / score_and_rank that follows a successful Damerau-Levenshtein (ld <= d):
 // LCS, prefix, suffix, case (src/lib.rs:1352-1377), the f64 score (:1433-1452), max_freq and the survivor count.
 __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, int lc, uint32_t ld, uint32_t qm, uint32_t em,
                                     uint32_t q, uint32_t e, const ScoreArgs& a, const uint32_t* __restrict__ ent_freq,
                                     const uint32_t* __restrict__ ent_var_off, uint32_t* __restrict__ qmaxfreq,
                                     uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, uint32_t& lcs,
-                                    uint32_t& pre, uint32_t& suf, uint32_t& samecase) {
+                                    uint32_t& pre, uint32_t& suf, uint32_t& samecase, bool& keep) {
   if (a.w_lcs > 0.0 && !(a.dbg & 1)) {  // src/lib.rs:1352-1356; diagonal walk == the reference's naive scan
     uint32_t best = 0;
     for (int delta = -(lq - 1); delta <= lc - 1; ++delta) {
@@ -709,7 +733,8 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
     if (em & 0x200u) qexpand[q] = 1;  // benign race: every writer stores 1
     nrows = (ent_var_off[e + 1] - ent_var_off[e]) + ((em & 0x400u) ? 0u : 1u);  // transparent: references only
   }
-  if (score >= a.score_threshold && nrows) atomicAdd(&qsurv[q], nrows);  // src/lib.rs:1475
+  keep = score >= a.score_threshold && nrows;  // src/lib.rs:1475
+  if (keep) atomicAdd(&qsurv[q], nrows);
   return score;
 }
 
@@ -834,7 +859,7 @@ __global__ __launch_bounds__(256) void k_score_fast(uint32_t nsel, const uint32_
                                                     const uint32_t* __restrict__ ent_freq, ScoreArgs a,
                                                     const uint32_t* __restrict__ ent_var_off, double* __restrict__ s_score,
                                                     uint32_t* __restrict__ s_meta, uint32_t* __restrict__ qmaxfreq,
-                                                    uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand) {
+                                                    uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, SurvOut so) {
   __shared__ uint32_t s_str[256 * 9];  // per lane: query row (4 dwords) + candidate row (4) for the byte-wise tail; odd stride
   const uint32_t i_sel = blockIdx.x * 256 + threadIdx.x;
   const bool active = i_sel < nsel;
@@ -862,21 +887,23 @@ __global__ __launch_bounds__(256) void k_score_fast(uint32_t nsel, const uint32_
   for (int o = 32; o; o >>= 1) lqmax = max(lqmax, __shfl_xor(lqmax, o));
   lqmax = __builtin_amdgcn_readfirstlane(lqmax);
   const uint32_t res = dl_band16<D>(S, T, fast ? lq : 0, lc, lqmax);
-  if (!active) return;
-  if (!fast) {  // long strings or d > D: the general kernel scores this pair
-    s_meta[i_sel] = SCORE_DEFER;
-    return;
-  }
   uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
   double score = __builtin_nan("");
+  bool keep = false;
   const int diff = lq > lc ? lq - lc : lc - lq;
-  if (diff <= d && res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:109-130, 173-178
+  if (fast && diff <= d && res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:109-130, 173-178
     uint32_t* mine = s_str + threadIdx.x * 9;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { mine[w] = S[w]; mine[4 + w] = T[w]; }
     ld = res;
     score = score_tail(reinterpret_cast<const uint8_t*>(mine), reinterpret_cast<const uint8_t*>(mine + 4), lq, lc, ld, qm, em,
-                       q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase);
+                       q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase, keep);
+  }
+  surv_append(so, keep, q, e, score);
+  if (!active) return;
+  if (!fast) {  // long strings or d > D: the general kernel scores this pair
+    s_meta[i_sel] = SCORE_DEFER;
+    return;
   }
   s_score[i_sel] = score;
   s_meta[i_sel] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
@@ -888,9 +915,12 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
                               const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
                               const uint32_t* __restrict__ ent_var_off, double* __restrict__ s_score,
                               uint32_t* __restrict__ s_meta, uint32_t* __restrict__ qmaxfreq,
-                              uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, int only_deferred) {
+                              uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, int only_deferred, SurvOut so) {
   extern __shared__ uint32_t lds32[];
   const uint32_t i_sel = blockIdx.x * blockDim.x + threadIdx.x;
+  bool keep = false;
+  uint32_t kq = 0, ke = 0;
+  double kscore = 0.0;
   if (i_sel < nsel && (!only_deferred || s_meta[i_sel] == SCORE_DEFER)) {
     const uint32_t p = sel[i_sel];
     const uint2 rp = raw[p];
@@ -968,13 +998,15 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
         const uint32_t res = R[(lq % NR) * W + (lc - lq + d + 1)];
         if (res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:173-178
           ld = res;
-          score = score_tail(S, T, lq, lc, ld, qm, em, q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase);
+          score = score_tail(S, T, lq, lc, ld, qm, em, q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase, keep);
+          kq = q; ke = e; kscore = score;
         }
       }
     }
     s_score[i_sel] = score;  // dense, in selection order (coalesced)
     s_meta[i_sel] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
+  surv_append(so, keep, kq, ke, kscore);
 }
 
 // K3b: gather the survivors (score >= threshold) into per-query segments of result rows.  With variant lists a
@@ -982,23 +1014,20 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
 // score, min(reference frequency, own frequency), via = itself) and itself unless it is TRANSPARENT.
 // Order inside a query is arbitrary; ranking uses a total order whose last key is c_ord (= reference order).
 struct CompactArgs {
-  double thr;
   int have_freq, any_variants;
 };
-__global__ __launch_bounds__(256) void k_compact(uint32_t nsel, const uint32_t* __restrict__ sel,
-                                                 const uint2* __restrict__ raw, const double* __restrict__ s_score,
-                                                 CompactArgs a, const uint32_t* __restrict__ soff,
+__global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ surv, const uint32_t* __restrict__ sctr,
+                                                 uint32_t region_cap, CompactArgs a, const uint32_t* __restrict__ soff,
                                                  uint32_t* __restrict__ qcur, const EntRec* __restrict__ ent_rec,
                                                  const uint32_t* __restrict__ ent_var_off,
                                                  const uint32_t* __restrict__ var_target,
                                                  const uint32_t* __restrict__ var_target_freq,
                                                  const double* __restrict__ var_score, SurvRow* __restrict__ c_rows) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nsel) return;
-  const double s = s_score[i];
-  if (!(s >= a.thr)) return;  // NaN = pruned
-  const uint2 v = raw[sel[i]];
-  const uint32_t e = v.y & 0x7FFFFFFFu, q = v.x;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // grid: (blocks of the fullest region) x (regions)
+  if (i >= sctr[blockIdx.y * RC_STRIDE]) return;
+  const SurvRec sr = surv[(size_t)blockIdx.y * region_cap + i];
+  const double s = sr.score;
+  const uint32_t e = sr.e, q = sr.q;
   const EntRec er = ent_rec[e];
   const uint32_t f = a.have_freq ? er.freq : 1u;
   const unsigned long long ord = (unsigned long long)er.order << 20;
@@ -1009,7 +1038,6 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t nsel, const uint32_t* 
     self = (er.meta & 0x400u) ? 0u : 1u;
   }
   const uint32_t nrows = (v1 - v0) + self;
-  if (!nrows) return;
   uint32_t pos = soff[q] + atomicAdd(&qcur[q], nrows);
   for (uint32_t j = v0; j < v1; ++j, ++pos) {  // references first, then the item itself (src/lib.rs:1689-1717)
     const uint32_t tf = var_target_freq[j];
@@ -1031,37 +1059,24 @@ struct RankArgs {
   float freq_weight;
   int have_freq, any_variants;
 };
-constexpr int RANK_G = 64;      // lanes per query (measured on config 2: 64 -> 1.43 ms, 16 -> 2.16 ms: mixed list lengths diverge)
-constexpr int RANK_LCAP = 128;  // rows per query staged in LDS; longer lists spill to t_key / global reads
+constexpr int RANK_LCAP = 128;  // rows per query staged in LDS by the 64-lane path; longer lists spill to t_key / global reads
 
 __device__ inline double result_score(double dist, double freq, float fw) {  // src/types.rs:335-341
   if (fw == 0.0f) return dist;
   return (dist + ((double)fw * freq)) / (1.0 + (double)fw);
 }
 
-__global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __restrict__ soff,
-                                              const SurvRow* __restrict__ c_rows,
-                                              const uint32_t* __restrict__ qmaxfreq,
-                                              const uint32_t* __restrict__ qexpand, RankArgs a,
-                                              double* __restrict__ t_key, DevRow* __restrict__ r_rows,
-                                              uint32_t* __restrict__ r_count) {
-  constexpr int NG = 256 / RANK_G;
-  __shared__ double s_key[NG][RANK_LCAP];
-  __shared__ unsigned long long s_ord[NG][RANK_LCAP];
-  __shared__ uint32_t s_freq[NG][RANK_LCAP];
-  __shared__ double s_sdist[NG][RANK_G], s_sfreq[NG][RANK_G];  // the first RANK_G ranked rows (parallel crop/cutoff)
-  const int grp = threadIdx.x / RANK_G, gl = threadIdx.x % RANK_G;
-  const int gshift = (threadIdx.x & 63) / RANK_G * RANK_G;  // this group's first lane inside its wave
-  const unsigned long long gmask = RANK_G >= 64 ? ~0ull : ((1ull << (RANK_G & 63)) - 1ull);
-  const uint32_t q = blockIdx.x * NG + grp;
-  uint32_t seg0 = 0, n = 0, maxf = 0, qex = 0;
-  if (q < nq) {
-    seg0 = soff[q];
-    n = soff[q + 1] - seg0;
-    maxf = qmaxfreq[q];                      // independent loads issued together with soff
-    if (a.any_variants) qex = qexpand[q];
-    if (n == 0 && gl == 0) r_count[q] = 0;
-  }
+// One group of G lanes ranks one query, every candidate row taking part (rows beyond LCAP through t_key / global
+// reads).  Every lane of the wave calls this (ballots are wave-wide, sliced per group).
+template <int G, int LCAP>
+__device__ inline void rank_query_all(uint32_t q, bool valid, int gl, int gshift, double* __restrict__ s_key,
+                                  unsigned long long* __restrict__ s_ord, uint32_t* __restrict__ s_freq,
+                                  double* __restrict__ s_sdist, double* __restrict__ s_sfreq, uint32_t seg0, uint32_t n,
+                                  uint32_t maxf, uint32_t qex, const SurvRow* __restrict__ c_rows, const RankArgs& a,
+                                  double* __restrict__ t_key, DevRow* __restrict__ r_rows, uint32_t* __restrict__ r_count) {
+  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  if (!valid) n = 0;
+  if (valid && n == 0 && gl == 0) r_count[q] = 0;
   // expanded rows never raise max_freq: their frequency is a min() with the expanding item's (src/lib.rs:1512-1517)
   const double max_freq = a.have_freq ? (double)maxf : (maxf ? 1.0 : 0.0);
   const bool sort_weighted = a.freq_weight > 0.0f;    // rank_cmp's branch
@@ -1069,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
   const bool expanded = n && a.any_variants && qex != 0;  // has_expandable_variants
   // ---- sort keys ------------------------------------------------------------------------------------
   SurvRow mine{0.0, 0ull, 0u, 0u, 0u, 0u};  // row gl stays in registers (most lists are shorter than the group)
-  for (uint32_t i = gl; i < n; i += RANK_G) {
+  for (uint32_t i = gl; i < n; i += G) {
     const SurvRow r = c_rows[seg0 + i];
     if (i == (uint32_t)gl) mine = r;
     double key = r.score;
@@ -1077,21 +1092,21 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
       const double fs = max_freq > 0.0 ? (double)r.freq / max_freq : (double)r.freq;
       key = result_score(key, fs, a.freq_weight);
     }
-    if (i < RANK_LCAP) { s_key[grp][i] = key; s_freq[grp][i] = r.freq; s_ord[grp][i] = r.ord; }
+    if (i < (uint32_t)LCAP) { s_key[i] = key; s_freq[i] = r.freq; s_ord[i] = r.ord; }
     else t_key[seg0 + i] = key;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // ---- rank by counting -------------------------------------------------------------------------------
   const bool full = score_weighted || a.max_matches == 0 || expanded;
   const uint32_t M = full ? n : (uint32_t)min((uint64_t)n, a.max_matches + 1);
-  for (uint32_t i = gl; i < n; i += RANK_G) {
+  for (uint32_t i = gl; i < n; i += G) {
     double ki; uint32_t fi; unsigned long long oi;
-    if (i < RANK_LCAP) { ki = s_key[grp][i]; fi = s_freq[grp][i]; oi = s_ord[grp][i]; }
+    if (i < (uint32_t)LCAP) { ki = s_key[i]; fi = s_freq[i]; oi = s_ord[i]; }
     else { ki = t_key[seg0 + i]; fi = c_rows[seg0 + i].freq; oi = c_rows[seg0 + i].ord; }
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; ++j) {
       double kj; uint32_t fj; unsigned long long oj;
-      if (j < RANK_LCAP) { kj = s_key[grp][j]; fj = s_freq[grp][j]; oj = s_ord[grp][j]; }
+      if (j < (uint32_t)LCAP) { kj = s_key[j]; fj = s_freq[j]; oj = s_ord[j]; }
       else { kj = t_key[seg0 + j]; fj = c_rows[seg0 + j].freq; oj = c_rows[seg0 + j].ord; }
       bool before;
       if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
@@ -1102,28 +1117,28 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
       const SurvRow r = i == (uint32_t)gl ? mine : c_rows[seg0 + i];
       const double ff = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
       r_rows[seg0 + rank] = DevRow{r.vocab, a.any_variants ? r.via : 0xFFFFFFFFu, r.score, ff};
-      if (rank < RANK_G) { s_sdist[grp][rank] = r.score; s_sfreq[grp][rank] = ff; }
+      if (rank < (uint32_t)G) { s_sdist[rank] = r.score; s_sfreq[rank] = ff; }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  const bool parallel_tail = n && !expanded && M <= (uint32_t)RANK_G;
+  const bool parallel_tail = n && !expanded && M <= (uint32_t)G;
   {
     // ---- crop + cutoff, group-parallel (same rules as the serial code below; lane i holds ranked row i) --
     const float fw = a.freq_weight;
     const bool have = parallel_tail && (uint32_t)gl < M;
-    const double di = have ? s_sdist[grp][gl] : 0.0;
-    const double si = have ? result_score(di, s_sfreq[grp][gl], fw) : 0.0;
+    const double di = have ? s_sdist[gl] : 0.0;
+    const double si = have ? result_score(di, s_sfreq[gl], fw) : 0.0;
     uint32_t len = n;
     const uint64_t mm = a.max_matches;
     const bool crop = parallel_tail && mm > 0 && (uint64_t)n > mm;
     double last = 0.0, cropped = 0.0;
     if (crop) {
-      last = result_score(s_sdist[grp][mm - 1], s_sfreq[grp][mm - 1], fw);
-      cropped = result_score(s_sdist[grp][mm], s_sfreq[grp][mm], fw);
+      last = result_score(s_sdist[mm - 1], s_sfreq[mm - 1], fw);
+      cropped = result_score(s_sdist[mm], s_sfreq[mm], fw);
     }
     // wave-wide ballots (every lane participates), sliced per group
     const unsigned long long lt = (__ballot(have && crop && di < cropped) >> gshift) & gmask;
-    const uint32_t stop_at = lt ? (uint32_t)__ffsll((long long)lt) - 1 : (uint32_t)RANK_G;  // the loop breaks at the first smaller row
+    const uint32_t stop_at = lt ? (uint32_t)__ffsll((long long)lt) - 1 : (uint32_t)G;  // the loop breaks at the first smaller row
     const unsigned long long eq = (__ballot(have && crop && gl >= 1 && (uint32_t)gl <= stop_at && di == cropped) >> gshift) & gmask;
     if (crop) {
       if (cropped < last) len = (uint32_t)mm;
@@ -1135,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
       }
     }
     const bool docut = parallel_tail && a.cutoff_threshold >= 1.0;
-    const double best = docut ? result_score(s_sdist[grp][0], s_sfreq[grp][0], fw) : 0.0;
+    const double best = docut ? result_score(s_sdist[0], s_sfreq[0], fw) : 0.0;
     const unsigned long long cut = (__ballot(have && docut && gl >= 1 && (uint32_t)gl < len && si <= best / a.cutoff_threshold) >> gshift) & gmask;
     if (cut) len = (uint32_t)__ffsll((long long)cut) - 1;
     if (parallel_tail && gl == 0) r_count[q] = len;
@@ -1183,6 +1198,219 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
     }
     if (cutoff > 0) len = cutoff;
     r_count[q] = len;
+  }
+}
+
+// Same result, but rows that the cutoff rule (src/lib.rs:1598-1622) is certain to drop are discarded BEFORE the
+// O(n^2) rank-by-counting.  The list is sorted by the very key the cutoff tests, so every row with
+// key <= best / cutoff_threshold (and key < best) lies behind the first such row and is cut; the crop rule
+// (:1536-1589) only ever looks at rows before that point or yields a length beyond it (then the cutoff wins).
+// On config 2 the survivors per query are heavy-tailed (mean 10, 2 % above 64 carry half of sum n^2) and most of a
+// long list is below half the best score.  nloop: wave-uniform upper bound of n (ballot count must match).
+template <int G, int LCAP>
+__device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, uint32_t nloop, double* __restrict__ s_key,
+                                  unsigned long long* __restrict__ s_ord, uint32_t* __restrict__ s_freq,
+                                  uint16_t* __restrict__ s_src, double* __restrict__ s_sdist, double* __restrict__ s_sfreq,
+                                  uint32_t seg0, uint32_t n, uint32_t maxf, uint32_t qex,
+                                  const SurvRow* __restrict__ c_rows, const RankArgs& a, double* __restrict__ t_key,
+                                  DevRow* __restrict__ r_rows, uint32_t* __restrict__ r_count) {
+  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  if (!valid) n = 0;
+  const double max_freq = a.have_freq ? (double)maxf : (maxf ? 1.0 : 0.0);
+  const bool sort_weighted = a.freq_weight > 0.0f;    // rank_cmp's branch
+  const bool score_weighted = a.freq_weight != 0.0f;  // score()'s branch
+  const bool expanded = n && a.any_variants && qex != 0;  // has_expandable_variants
+  const bool prune = a.cutoff_threshold >= 1.0 && !expanded && (!score_weighted || sort_weighted) && n <= 0xFFFFu;
+  auto key_of = [&](const SurvRow& r) {
+    if (!sort_weighted) return r.score;
+    const double fs = max_freq > 0.0 ? (double)r.freq / max_freq : (double)r.freq;
+    return result_score(r.score, fs, a.freq_weight);
+  };
+  // ---- best key of the group ----------------------------------------------------------------------------
+  SurvRow mine{0.0, 0ull, 0u, 0u, 0u, 0u};
+  double best = -1.0;
+  for (uint32_t i = gl; i < n; i += G) {
+    const SurvRow r = c_rows[seg0 + i];
+    if (i == (uint32_t)gl) mine = r;
+    best = fmax(best, key_of(r));
+  }
+#pragma unroll
+  for (int o = G / 2; o; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+  const double thr = best / a.cutoff_threshold;
+  // ---- keep the rows the cutoff cannot drop, compacted into LDS -------------------------------------------
+  uint32_t kept = 0;  // group-uniform
+  for (uint32_t base = 0; base < nloop; base += G) {
+    const uint32_t i = base + (uint32_t)gl;
+    SurvRow r = mine;
+    if (base && i < n) r = c_rows[seg0 + i];
+    const double key = key_of(r);
+    const bool keep = i < n && !(prune && key <= thr && key < best);
+    const unsigned long long m = (__ballot(keep) >> gshift) & gmask;
+    const uint32_t pos = kept + (uint32_t)__popcll(m & ((1ull << gl) - 1ull));
+    if (keep && pos < (uint32_t)LCAP) { s_key[pos] = key; s_freq[pos] = r.freq; s_ord[pos] = r.ord; s_src[pos] = (uint16_t)i; }
+    kept += (uint32_t)__popcll(m);
+  }
+  if (kept > (uint32_t)LCAP) {  // group-uniform; only the 64-lane path can get here (wave-uniform there)
+    rank_query_all<G, LCAP>(q, valid, gl, gshift, s_key, s_ord, s_freq, s_sdist, s_sfreq, seg0, n, maxf, qex, c_rows, a, t_key,
+                            r_rows, r_count);
+    return;
+  }
+  n = kept;
+  if (valid && n == 0 && gl == 0) r_count[q] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  // ---- rank by counting -------------------------------------------------------------------------------
+  const bool full = score_weighted || a.max_matches == 0 || expanded;
+  const uint32_t M = full ? n : (uint32_t)min((uint64_t)n, a.max_matches + 1);
+  for (uint32_t i = gl; i < n; i += G) {
+    const double ki = s_key[i];
+    const uint32_t fi = s_freq[i];
+    const unsigned long long oi = s_ord[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+      const double kj = s_key[j];
+      const uint32_t fj = s_freq[j];
+      const unsigned long long oj = s_ord[j];
+      bool before;
+      if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
+      else before = kj > ki || (kj == ki && (fj > fi || (fj == fi && oj < oi)));
+      rank += before;
+    }
+    if (rank < M) {
+      const SurvRow r = c_rows[seg0 + s_src[i]];
+      const double ff = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
+      r_rows[seg0 + rank] = DevRow{r.vocab, a.any_variants ? r.via : 0xFFFFFFFFu, r.score, ff};
+      if (rank < (uint32_t)G) { s_sdist[rank] = r.score; s_sfreq[rank] = ff; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  const bool parallel_tail = n && !expanded && M <= (uint32_t)G;
+  {
+    // ---- crop + cutoff, group-parallel (same rules as the serial code below; lane i holds ranked row i) --
+    const float fw = a.freq_weight;
+    const bool have = parallel_tail && (uint32_t)gl < M;
+    const double di = have ? s_sdist[gl] : 0.0;
+    const double si = have ? result_score(di, s_sfreq[gl], fw) : 0.0;
+    uint32_t len = n;
+    const uint64_t mm = a.max_matches;
+    const bool crop = parallel_tail && mm > 0 && (uint64_t)n > mm;
+    double last = 0.0, cropped = 0.0;
+    if (crop) {
+      last = result_score(s_sdist[mm - 1], s_sfreq[mm - 1], fw);
+      cropped = result_score(s_sdist[mm], s_sfreq[mm], fw);
+    }
+    // wave-wide ballots (every lane participates), sliced per group
+    const unsigned long long lt = (__ballot(have && crop && di < cropped) >> gshift) & gmask;
+    const uint32_t stop_at = lt ? (uint32_t)__ffsll((long long)lt) - 1 : (uint32_t)G;  // the loop breaks at the first smaller row
+    const unsigned long long eq = (__ballot(have && crop && gl >= 1 && (uint32_t)gl <= stop_at && di == cropped) >> gshift) & gmask;
+    if (crop) {
+      if (cropped < last) len = (uint32_t)mm;
+      else {
+        const uint32_t early = eq ? (uint32_t)__ffsll((long long)eq) - 1 : 0;
+        const uint32_t late = lt ? stop_at : 0;
+        if (early > 0) len = early + 1;
+        else if (late > 0) len = late + 1;
+      }
+    }
+    const bool docut = parallel_tail && a.cutoff_threshold >= 1.0;
+    const double best = docut ? result_score(s_sdist[0], s_sfreq[0], fw) : 0.0;
+    const unsigned long long cut = (__ballot(have && docut && gl >= 1 && (uint32_t)gl < len && si <= best / a.cutoff_threshold) >> gshift) & gmask;
+    if (cut) len = (uint32_t)__ffsll((long long)cut) - 1;
+    if (parallel_tail && gl == 0) r_count[q] = len;
+  }
+  // ---- general case: dedup + crop + cutoff, literally, by one lane -------------------------------------
+  if (n && !parallel_tail && gl == 0) {
+    const float fw = a.freq_weight;
+    DevRow* rr = r_rows + seg0;
+    uint32_t len = n, avail = M;
+    if (expanded) {  // results.dedup_by_key(|x| x.vocab_id): consecutive duplicates, first kept (src/lib.rs:1530-1533)
+      uint32_t w = 0;
+      for (uint32_t i = 0; i < n; ++i)
+        if (w == 0 || rr[w - 1].vocab_id != rr[i].vocab_id) {
+          rr[w] = rr[i];
+          ++w;
+        }
+      len = w;
+      avail = w;
+    }
+    const uint64_t mm = a.max_matches;
+    if (mm > 0 && (uint64_t)len > mm) {
+      const double last = result_score(rr[mm - 1].dist_score, rr[mm - 1].freq_score, fw);
+      const double cropped = result_score(rr[mm].dist_score, rr[mm].freq_score, fw);
+      if (cropped < last) len = (uint32_t)mm;
+      else {
+        uint32_t early = 0, late = 0;
+        for (uint32_t i = 0; i < avail; ++i) {
+          if (rr[i].dist_score == cropped && early == 0) early = i;
+          if (rr[i].dist_score < cropped) { late = i; break; }
+        }
+        if (early > 0) len = early + 1;
+        else if (late > 0) len = late + 1;
+      }
+    }
+    uint32_t cutoff = 0;
+    if (a.cutoff_threshold >= 1.0) {
+      bool have = false;
+      double best = 0.0;
+      for (uint32_t i = 0; i < len; ++i) {
+        const double sc = result_score(rr[i].dist_score, rr[i].freq_score, fw);
+        if (have) {
+          if (sc <= best / a.cutoff_threshold) { cutoff = i; break; }
+        } else { best = sc; have = true; }
+      }
+    }
+    if (cutoff > 0) len = cutoff;
+    r_count[q] = len;
+  }
+}
+
+// A wave owns 4 consecutive queries.  If none of them has more than 16 candidate rows (the common case: ~10 per
+// query on config 2) the four are ranked side by side by 16 lanes each; otherwise one after the other by the whole
+// wave (lists up to RANK_LCAP rows in LDS, longer ones through t_key).  1M one-query waves were latency-bound.
+constexpr int RANK_QPW = 4;                                    // queries per wave
+constexpr int RANK_WAVE_BYTES = RANK_LCAP * 22 + 64 * 16;      // LDS per wave: keys, order keys, freqs, source rows + ranked heads
+__global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __restrict__ soff,
+                                              const SurvRow* __restrict__ c_rows,
+                                              const uint32_t* __restrict__ qmaxfreq,
+                                              const uint32_t* __restrict__ qexpand, RankArgs a,
+                                              double* __restrict__ t_key, DevRow* __restrict__ r_rows,
+                                              uint32_t* __restrict__ r_count) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_raw[4 * RANK_WAVE_BYTES];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint8_t* wl = s_raw + wid * RANK_WAVE_BYTES;
+  const uint32_t qbase = (blockIdx.x * 4 + wid) * RANK_QPW;
+  // lanes 0..3 fetch the four segments; everybody reads them back with shuffles
+  uint32_t my_seg0 = 0, my_n = 0, my_maxf = 0, my_qex = 0;
+  if (lane < RANK_QPW && qbase + lane < nq) {
+    my_seg0 = soff[qbase + lane];
+    my_n = soff[qbase + lane + 1] - my_seg0;
+    my_maxf = qmaxfreq[qbase + lane];
+    if (a.any_variants) my_qex = qexpand[qbase + lane];
+  }
+  uint32_t nmax = my_n;
+  nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, 1));
+  nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, 2));
+  nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+  if (nmax <= 16) {
+    const int grp = lane >> 4, gl = lane & 15;
+    // per group: 16 keys (8 B), 16 order keys (8 B), 16 freqs (4 B), 16 source rows (2 B), 16 + 16 ranked heads (8 B) = 608 B
+    uint8_t* gb = wl + grp * 608;
+    rank_query<16, 16>(qbase + grp, qbase + grp < nq, gl, grp * 16, 16u, reinterpret_cast<double*>(gb),
+                       reinterpret_cast<unsigned long long*>(gb + 128), reinterpret_cast<uint32_t*>(gb + 256),
+                       reinterpret_cast<uint16_t*>(gb + 320), reinterpret_cast<double*>(gb + 352), reinterpret_cast<double*>(gb + 480),
+                       (uint32_t)__shfl((int)my_seg0, grp), (uint32_t)__shfl((int)my_n, grp), (uint32_t)__shfl((int)my_maxf, grp),
+                       (uint32_t)__shfl((int)my_qex, grp), c_rows, a, t_key, r_rows, r_count);
+  } else {
+    for (int k = 0; k < RANK_QPW; ++k) {
+      if (qbase + k >= nq) break;  // wave-uniform
+      const uint32_t nk = (uint32_t)__builtin_amdgcn_readlane((int)my_n, k);
+      rank_query<64, RANK_LCAP>(qbase + k, true, lane, 0, nk, reinterpret_cast<double*>(wl),
+                                reinterpret_cast<unsigned long long*>(wl + RANK_LCAP * 8),
+                                reinterpret_cast<uint32_t*>(wl + RANK_LCAP * 16), reinterpret_cast<uint16_t*>(wl + RANK_LCAP * 20),
+                                reinterpret_cast<double*>(wl + RANK_LCAP * 22), reinterpret_cast<double*>(wl + RANK_LCAP * 22 + 512),
+                                (uint32_t)__shfl((int)my_seg0, k), nk, (uint32_t)__shfl((int)my_maxf, k), (uint32_t)__shfl((int)my_qex, k),
+                                c_rows, a, t_key, r_rows, r_count);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
   }
 }
 
@@ -1481,7 +1709,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     return nullptr;
   }
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
@@ -1648,13 +1876,26 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     HIP_TRY(hipStreamSynchronize(st));
   }
   b->n_sel = nsel;
+  SurvOut so{nullptr, b->sctr, 0};
   if (nsel) {
+    // survivor records: region r takes the survivors of blocks r, r + 64, ... of either score kernel; a block scores <= 256 pairs
+    const size_t need = 2 * ((((size_t)nsel + 255) / 256 + SCAN_REGIONS - 1) / SCAN_REGIONS + 1) * 256;
+    if (need > b->surv_region_cap) {
+      if (b->surv) (void)hipFree(b->surv);
+      b->surv = nullptr;
+      b->surv_region_cap = 0;
+      if ((rc = dalloc(&b->surv, need * SCAN_REGIONS, err))) return rc;
+      b->surv_region_cap = need;
+    }
+    so.list = b->surv;
+    so.region_cap = (uint32_t)b->surv_region_cap;
+    HIP_TRY(hipMemsetAsync(b->sctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
     // register-resident fast path for pairs of <= 16 symbols with d <= 3; the general kernel takes the rest
     static const int enable_fast = []() { const char* e = getenv("ANX_SCORE_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
     const int fastD = (enable_fast && d >= 1 && d <= 3) ? (int)d : 0;
     const dim3 fgrid((nsel + 255) / 256);
 #define ANX_FAST_ARGS nsel, b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa, \
-                      dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand
+                      dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand, so
     if (fastD == 1) hipLaunchKernelGGL(k_score_fast<1>, fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
     else if (fastD == 2) hipLaunchKernelGGL(k_score_fast<2>, fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
     else if (fastD == 3) hipLaunchKernelGGL(k_score_fast<3>, fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
@@ -1662,7 +1903,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     if (!fastD || b->qw > 1 || dl->max_len > 16)
       hipLaunchKernelGGL(k_score_pairs, dim3((nsel + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nsel,
                          b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
-                         dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand, fastD ? 1 : 0);
+                         dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand, fastD ? 1 : 0, so);
   }
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors -----------------------------------------------------------------------------
@@ -1670,15 +1911,20 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   uint32_t total_surv = 0;
   HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
+  if (nsel) HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->sctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   b->n_pairs = n_valid - h_counters[CTR_SKIPPED];
   b->n_surv = total_surv;
   if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
-  if (nsel) {
-    CompactArgs ca{b->params.score_threshold, m.have_freq ? 1 : 0, dl->any_variants};
-    hipLaunchKernelGGL(k_compact, dim3((nsel + 255) / 256), dim3(256), 0, st, nsel, b->sel, b->raw, b->p_score, ca,
-                       b->soff, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target, dl->var_target_freq, dl->var_score,
-                       b->c_rows);
+  uint32_t surv_fill = 0;
+  if (nsel)
+    for (uint32_t r = 0; r < SCAN_REGIONS; ++r) surv_fill = std::max(surv_fill, h_rctr[r * RC_STRIDE]);
+  if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
+  if (surv_fill) {
+    CompactArgs ca{m.have_freq ? 1 : 0, dl->any_variants};
+    hipLaunchKernelGGL(k_compact, dim3((surv_fill + 255) / 256, SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
+                       (uint32_t)b->surv_region_cap, ca, b->soff, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
+                       dl->var_target_freq, dl->var_score, b->c_rows);
   }
   HIP_TRY(hipEventRecord(b->ev[3], st));
   // ---- rank ------------------------------------------------------------------------------------------
@@ -1688,7 +1934,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
   ra.any_variants = dl->any_variants;
-  hipLaunchKernelGGL(k_rank, dim3((nq + 256 / RANK_G - 1) / (256 / RANK_G)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
+  hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
                      b->qexpand, ra, b->t_key, b->r_rows, b->r_count);
   exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
   HIP_TRY(hipEventRecord(b->ev[4], st));
@@ -1818,7 +2064,7 @@ void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 void batch_free(Batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr,
+  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
