@@ -62,8 +62,7 @@ struct DeviceLexicon {
   uint32_t* cls_bits = nullptr;    // [NBITPLANES][cstride] thermometer planes (bit s of plane t: count_s > t), nsym <= 32
   uint8_t* cls_len = nullptr;      // [cstride]
   uint32_t* cls_off = nullptr;
-  uint32_t* sig_lo = nullptr;      // [nsig_pad] signature table (see LexiconImage)
-  uint32_t* sig_hi = nullptr;
+  uint2* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage), lo/hi interleaved
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint32_t* ent_vocab = nullptr;
   uint32_t* ent_freq = nullptr;
@@ -239,8 +238,7 @@ struct ScanArgs {
   uint32_t pad_class;   // a never-matching padding class (bits 0, counts 0xFF, len 255)
   const uint8_t* cls_len;
   const uint32_t* cls_off;
-  const uint32_t* sig_lo;
-  const uint32_t* sig_hi;
+  const uint2* sig;         // signature table: (groups 0-3, groups 4-7) packed as bytes
   const uint32_t* sig_cbeg;
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
@@ -374,10 +372,13 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     }
   };
 
-  for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
-    const uint32_t s = sb + lane;  // the tables are padded to whole steps with never-matching signatures
-    const uint32_t d = __builtin_amdgcn_sad_u8(A.sig_lo[s], t.sig_lo, __builtin_amdgcn_sad_u8(A.sig_hi[s], t.sig_hi, 0u));
-    const bool ok = s < t.s1 && d <= t.k;
+  // No bounds test on s: signatures outside [s0, s1) belong to other charcounts, so their L1 distance to the tile's
+  // signature is at least the length difference > k, and the table is padded with never-matching entries.
+  const uint2* __restrict__ sigp = A.sig + t.s0 + lane;
+  for (uint32_t sb = t.s0; sb < t.s1; sb += 64, sigp += 64) {
+    const uint32_t s = sb + lane;
+    const uint2 sg = *sigp;
+    const bool ok = __builtin_amdgcn_sad_u8(sg.x, t.sig_lo, __builtin_amdgcn_sad_u8(sg.y, t.sig_hi, 0u)) <= t.k;
     unsigned long long m = __ballot(ok);
     if (!m || (A.dbg & 4)) continue;
     uint32_t cb = 0, n = 0;
@@ -390,8 +391,8 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       m &= m - 1;
       uint32_t cbi = (uint32_t)__builtin_amdgcn_readlane((int)cb, i), ni = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
       while (ni) {
-        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 64 ids
-        if (lane < take) stage[ns + lane] = cbi + lane;
+        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 128 ids
+        stage[ns + lane] = cbi + lane;              // all 64 lanes write; only the first `take` ids count
         ns += take;
         cbi += take;
         ni -= take;
@@ -415,7 +416,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 // Every wave takes one tile; tiles are ordered by decreasing cost.  The bit-plane tiles (wave-uniform switch over
 // T) and the count-vector tiles run as two launches so that the rarely used wide SAD body does not set the register
 // budget (= occupancy) of the common one.
-constexpr uint32_t SCAN_STAGE = 64 * 4 + 64;
+constexpr uint32_t SCAN_STAGE = 64 * 4 + 128;
 template <int NP, bool BITS>
 __device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
@@ -1494,14 +1495,15 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   int rc = ANX_OK;
   std::vector<EntRec> rec(img.ent_vocab.size());
   for (size_t e = 0; e < rec.size(); ++e) rec[e] = EntRec{img.ent_vocab[e], img.ent_freq[e], img.ent_order[e], img.ent_meta[e]};
+  std::vector<uint2> sig2(img.sig_lo.size());
+  for (size_t i = 0; i < sig2.size(); ++i) sig2[i] = make_uint2(img.sig_lo[i], img.sig_hi[i]);
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
   if ((rc = upload(&d->cls_planes, img.cls_planes.data(), img.cls_planes.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_bits, img.cls_bits.data(), img.cls_bits.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_len, img.cls_len.data(), img.cls_len.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
-      (rc = upload(&d->sig_lo, img.sig_lo.data(), img.sig_lo.size(), err, &d->bytes)) ||
-      (rc = upload(&d->sig_hi, img.sig_hi.data(), img.sig_hi.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sig, sig2.data(), sig2.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_cbeg, img.sig_cbeg.data(), img.sig_cbeg.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_vocab, img.ent_vocab.data(), img.ent_vocab.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_freq, img.ent_freq.data(), img.ent_freq.size(), err, &d->bytes)) ||
@@ -1523,7 +1525,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->sig_lo, (void*)d->sig_hi, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) (void)hipFree(p);
@@ -1799,7 +1801,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       ScanArgs A;
       A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
       A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
-      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig_lo = dl->sig_lo; A.sig_hi = dl->sig_hi; A.sig_cbeg = dl->sig_cbeg;
+      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_cbeg = dl->sig_cbeg;
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
       { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
       const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
