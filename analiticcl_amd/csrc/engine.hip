@@ -135,6 +135,7 @@ struct Batch {
   uint32_t* sel = nullptr;         // indices of the pair-list slots that passed the prefilter
   uint32_t* blockcount = nullptr;  // per 256-slot block: selected slots (+ scan scratch)
   size_t raw_cap = 0;
+  double* quot = nullptr;          // table of IEEE quotients x / L (ScoreArgs::quot)
   SurvRec* surv = nullptr;         // survivor records in SCAN_REGIONS regions of surv_region_cap (order arbitrary)
   uint32_t* sctr = nullptr;        // [SCAN_REGIONS][RC_STRIDE] fill of every survivor region
   size_t surv_region_cap = 0;
@@ -149,6 +150,7 @@ struct Batch {
   uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
   bool ran = false;
   hipEvent_t ev[6] = {};
+  hipEvent_t ev_scan0 = nullptr;   // just before the scan kernels (after the counter memsets)
   anx_batch_stats stats = {};
 };
 
@@ -660,6 +662,7 @@ __global__ __launch_bounds__(256) void k_select(uint32_t region_shift, const uin
 }
 
 struct ScoreArgs {
+  const double* quot;  // [33][33] quot[x*33+L] = (double)x / (double)L computed on the host, or nullptr
   int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL
   double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
   double score_threshold;
@@ -693,17 +696,26 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
                                     const uint32_t* __restrict__ ent_var_off, uint32_t* __restrict__ qmaxfreq,
                                     uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, uint32_t& lcs,
                                     uint32_t& pre, uint32_t& suf, uint32_t& samecase, bool& keep) {
-  if (a.w_lcs > 0.0 && !(a.dbg & 1)) {  // src/lib.rs:1352-1356; diagonal walk == the reference's naive scan
+  if (a.w_lcs > 0.0 && !(a.dbg & 1)) {
+    // longest common substring (src/lib.rs:1352-1356, src/distance.rs:181-205) = longest run of equal symbols on
+    // any diagonal.  Diagonals are visited from the main one outwards (0, +1, -1, +2, ...): the overlap of a diagonal
+    // only shrinks with |delta|, so the walk stops as soon as neither side can beat the best run found so far.
     uint32_t best = 0;
-    for (int delta = -(lq - 1); delta <= lc - 1; ++delta) {
-      const int i0 = delta < 0 ? -delta : 0;
-      const int i1 = min(lq, lc - delta);
-      if ((uint32_t)(i1 - i0) <= best) continue;
-      uint32_t run = 0;
-      for (int i = i0; i < i1; ++i) {
-        run = S[i] == T[i + delta] ? run + 1 : 0;
-        best = max(best, run);
+    for (int r = 0; r < max(lq, lc); ++r) {
+      bool open = false;
+      for (int side = 0; side < (r ? 2 : 1); ++side) {
+        const int delta = side ? -r : r;
+        const int i0 = delta < 0 ? -delta : 0;
+        const int i1 = min(lq, lc - delta);
+        if (i1 - i0 <= (int)best) continue;
+        open = true;
+        uint32_t run = 0;
+        for (int i = i0; i < i1; ++i) {
+          run = S[i] == T[i + delta] ? run + 1 : 0;
+          best = max(best, run);
+        }
       }
+      if (!open) break;
     }
     lcs = best;
   }
@@ -719,14 +731,17 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
     suf = n;
   }
   if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
+  // x / L for integers x <= L <= 32 comes from a table of host-computed IEEE quotients (identical bits, no f64 divide)
   const double L = (double)lq;
-  const double distance_score = (int)ld > lq ? 0.0 : 1.0 - ((double)ld / L);
-  const double lcs_score = (double)lcs / L;
-  const double prefix_score = (double)pre / L;
-  const double suffix_score = (double)suf / L;
-  const double score = (a.w_ld * distance_score + a.w_lcs * lcs_score + a.w_prefix * prefix_score +
-           a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0)) /
-          a.w_sum;
+  const bool tab = a.quot && lq <= 32;
+  auto over_L = [&](uint32_t x) { return (tab && x <= 32u) ? a.quot[x * 33u + (uint32_t)lq] : (double)x / L; };
+  const double distance_score = (int)ld > lq ? 0.0 : 1.0 - over_L(ld);
+  const double lcs_score = over_L(lcs);
+  const double prefix_score = over_L(pre);
+  const double suffix_score = over_L(suf);
+  const double num = a.w_ld * distance_score + a.w_lcs * lcs_score + a.w_prefix * prefix_score +
+                     a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0);
+  const double score = a.w_sum == 1.0 ? num : num / a.w_sum;  // x / 1.0 == x
   // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
   atomicMax(&qmaxfreq[q], a.have_freq ? ent_freq[e] : 1u);
   uint32_t nrows = 1;
@@ -1711,15 +1726,25 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     return nullptr;
   }
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
     batch_free(b);
     return nullptr;
   }
+  {
+    std::vector<double> quot(33 * 33, 0.0);
+    for (int x = 0; x <= 32; ++x)
+      for (int L = 1; L <= 32; ++L) {
+        volatile double num = (double)x, den = (double)L;  // a real division at run time, as the reference does
+        quot[(size_t)x * 33 + L] = num / den;
+      }
+    if (hipMemcpy(b->quot, quot.data(), quot.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
+  }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
+  if (hipEventCreate(&b->ev_scan0) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
   return b;
 }
 
@@ -1733,11 +1758,13 @@ static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_
 }
 
 template <int NP>
-static void launch_scan(ScanArgs A, uint32_t nbits, uint32_t nsad, hipStream_t st) {  // tiles: [bit-plane kinds | SAD kind]
+static void launch_scan(ScanArgs A, uint32_t nbits, uint32_t nsad, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {  // tiles: [bit-plane kinds | SAD kind]
+  (void)hipEventRecord(e0, st);  // e0 .. e1 = k_scan_bits alone (anx_batch_stats.ms_scan_kernel)
   if (nbits) {
     A.ntiles = nbits;
     hipLaunchKernelGGL((k_scan_bits<NP>), dim3((nbits + 3) / 4), dim3(256), 0, st, A);
   }
+  (void)hipEventRecord(e1, st);
   if (nsad) {
     A.tiles += nbits;
     A.ntiles = nsad;
@@ -1797,6 +1824,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(b->rctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
+    if (b->tiles.empty()) { HIP_TRY(hipEventRecord(b->ev_scan0, st)); HIP_TRY(hipEventRecord(b->ev[5], st)); }
     if (!b->tiles.empty()) {
       ScanArgs A;
       A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
@@ -1806,11 +1834,11 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
       const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
       switch (dl->nplanes) {
-        case 8: launch_scan<8>(A, nbits, nsad, st); break;
-        case 16: launch_scan<16>(A, nbits, nsad, st); break;
-        case 24: launch_scan<24>(A, nbits, nsad, st); break;
-        case 32: launch_scan<32>(A, nbits, nsad, st); break;
-        default: launch_scan<42>(A, nbits, nsad, st); break;
+        case 8: launch_scan<8>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+        case 16: launch_scan<16>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+        case 24: launch_scan<24>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+        case 32: launch_scan<32>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+        default: launch_scan<42>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
       }
     }
     HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->rctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1846,6 +1874,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   if (dl->any_variants) HIP_TRY(hipMemsetAsync(b->qexpand, 0, nq * sizeof(uint32_t), st));
   ScoreArgs sa;
   { static const int dbg = []() { const char* e = getenv("ANX_SCORE_DBG"); return e ? atoi(e) : 0; }(); sa.dbg = dbg; }
+  sa.quot = b->quot;
   sa.w_ld = m.weights.ld; sa.w_lcs = m.weights.lcs; sa.w_prefix = m.weights.prefix; sa.w_suffix = m.weights.suffix;
   sa.w_case = m.weights.casew;
   sa.w_sum = m.weights.ld + m.weights.lcs + m.weights.prefix + m.weights.suffix + m.weights.casew;  // src/types.rs:69-73
@@ -1955,11 +1984,13 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   for (int i = 0; i <= NBITPLANES; ++i) s.n_tests_kind[i] = b->n_tests_kind[i];
   s.n_pair_slots = n_slots;
   s.n_survivors = total_surv;
+  s.n_selected = nsel;
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.ms_score, b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&s.ms_group, b->ev[2], b->ev[3]);
   (void)hipEventElapsedTime(&s.ms_rank, b->ev[3], b->ev[4]);
   (void)hipEventElapsedTime(&s.ms_total, b->ev[0], b->ev[4]);
+  (void)hipEventElapsedTime(&s.ms_scan_kernel, b->ev_scan0, b->ev[5]);
   return ANX_OK;
 }
 
@@ -2066,13 +2097,14 @@ void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 void batch_free(Batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv,
+  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) (void)hipFree(p);
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);
+  if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
   delete b;
 }
 

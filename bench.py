@@ -104,12 +104,14 @@ def main():
         step()
     barrier()
     stage_ms = {"ms_scan": 0.0, "ms_group": 0.0, "ms_score": 0.0, "ms_rank": 0.0, "ms_total": 0.0}
+    sum_scan_kernel_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         st = batch.stats()  # HIP-event times recorded by the library on the launch stream for this run
         for k in stage_ms:
             stage_ms[k] += st[k]
+        sum_scan_kernel_ms += st["ms_scan_kernel"]
     barrier()
     elapsed = time.perf_counter() - t0
     st = batch.stats()
@@ -126,22 +128,21 @@ def main():
         for k in stage_ms:
             stage_ms[k] /= max(args.steps, 1)
         # ---- roofline of the dominant kernel (per launch, rank 0) --------------------------------------
-        # Algorithmic bytes: scan = queries*16 (bit planes) + classes*17 (planes + len, once per
-        # launch) + pairs*8 (pair list out); score = pairs*(Lpad+32).
+        # The dominant kernel is k_scan_bits (profiles/r01_final_kernel_trace.md).  Its algorithmic bytes per launch
+        # (DESIGN.md section 5): query planes 16 B/query + tile descriptors 36 B/tile + signature table 12 B/signature +
+        # class planes, length and CSR offsets 21 B/class (each once per launch) + pair list out 8 B/pair.
+        # SURVEY.md section 8(d)'s whole-path figure, pairs*(Lpad+32) + queries*208, is reported next to it as "pipeline".
         lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
         n_classes = model.num_classes()
-        scan_bytes = st["n_queries"] * 16 + n_classes * 17 + st["n_pairs"] * 8
-        score_bytes = st["n_pairs"] * (lpad + 32)
-        if stage_ms["ms_scan"] >= stage_ms["ms_score"]:
-            kname, kbytes, kms = "k_scan", scan_bytes, stage_ms["ms_scan"]
-        else:
-            kname, kbytes, kms = "k_score_pairs", score_bytes, stage_ms["ms_score"]
+        scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 36 + n_classes * (21 + 12) + st["n_pairs"] * 8
+        kname, kbytes, kms = "k_scan_bits", scan_bytes, sum_scan_kernel_ms / max(args.steps, 1)
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        # secondary, the bound that actually binds k_scan: VALU issue.  Measured issue costs on gfx950
-        # (tools/ubench_valu.hip): v_and_b32 + v_bcnt_u32_b32 pair 6.65, v_and_b32 (vgpr) 2.26, v_sad_u8 4.3 cycles per
-        # wave-instruction per SIMD -> cycles per 64 class tests: T planes 6.65*T+2.26, SAD body 8*4.3+2.26.
+        pipeline_bytes = st["n_pairs"] * (lpad + 32) + st["n_queries"] * 208
+        pipeline_gbs = pipeline_bytes / (stage_ms["ms_total"] * 1e-3) / 1e9 if stage_ms["ms_total"] > 0 else 0.0
+        # the bound that actually binds the scan: VALU issue.  Per 256 class tests of T planes the inner loop issues
+        # T*4 v_and_b32 (2.2 cycles, tools/ubench_valu.hip) + T*4 v_bcnt_u32_b32 (4.3) + 4 v_alignbit_b32 (4.3) + 1 ds_read.
         kinds = st["n_tests_kind"]
-        issue_cycles = (kinds[0] * (8 * 4.3 + 2.26) + sum(kinds[t] * (6.65 * t + 2.26) for t in range(1, 5))) / 64.0
+        issue_cycles = (kinds[0] * (8 * 4.3 + 4.3) * 4 + sum(kinds[t] * (t * 4 * 6.5 + 4 * 4.3) for t in range(1, 5))) / 256.0
         valu_floor_ms = issue_cycles / (1024 * 2.4e9) * 1e3
         traffic = None  # HBM bytes per launch of that kernel from the committed PMC passes (same workload only)
         try:
@@ -153,10 +154,12 @@ def main():
         roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": kms,
                     "algorithmic_bytes_per_launch": kbytes,
-                    "note": "integer scan/DP path: VALU-issue-bound, far below the HBM roof (DESIGN.md section 5)",
+                    "note": "integer scan path: VALU-issue-bound, far below the HBM roof (DESIGN.md section 5)",
+                    "pipeline_algorithmic_bytes": pipeline_bytes, "pipeline_gbs": pipeline_gbs,
+                    "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
                     "scan_valu_issue_floor_ms": valu_floor_ms,
-                    "scan_valu_issue_frac": valu_floor_ms / stage_ms["ms_scan"] if stage_ms["ms_scan"] > 0 else 0.0,
-                    "scan_class_tests_per_s": st["n_class_tests"] / (stage_ms["ms_scan"] * 1e-3) if stage_ms["ms_scan"] > 0 else 0.0,
+                    "scan_valu_issue_frac": valu_floor_ms / kms if kms > 0 else 0.0,
+                    "scan_class_tests_per_s": st["n_class_tests"] / (kms * 1e-3) if kms > 0 else 0.0,
                     "scan_tests_by_planes": kinds}
         # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
         cpu = None
@@ -197,7 +200,7 @@ def main():
                        "class_tests_per_query": tests / nq if nq else 0.0,
                        "parallelism": f"query-sharded x{world}" + (", RCCL gather of top-k records" if world > 1 and not args.no_gather else "")},
             "stage_ms": {"scan": stage_ms["ms_scan"], "score": stage_ms["ms_score"], "compact": stage_ms["ms_group"], "rank": stage_ms["ms_rank"], "total": stage_ms["ms_total"]},
-            "pair_slots": st["n_pair_slots"], "survivors": st["n_survivors"], "results": st["n_results"], "encode_upload_s": t_enc,
+            "pair_slots": st["n_pair_slots"], "dl_pairs": st["n_selected"], "survivors": st["n_survivors"], "results": st["n_results"], "encode_upload_s": t_enc,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -172,11 +172,13 @@ typedef struct anx_batch_stats {
   uint64_t n_pairs;          /* scored (query,candidate) pairs = DL invocations of the reference */
   uint64_t n_class_tests;    /* (query,class) count-vector tests executed by the scan kernel */
   uint64_t n_results;        /* ranked results returned */
-  uint64_t n_scan_blocks;    /* workgroups launched by the scan kernel */
+  uint64_t n_scan_blocks;    /* query tiles (= waves) of the scan kernels */
   uint64_t n_tests_kind[5];  /* class tests by scan body: [0] v_sad_u8 count vectors, [T] T thermometer bit planes */
   uint64_t n_pair_slots;     /* pair-list slots written (scored pairs + unused chunk tails) */
   uint64_t n_survivors;      /* pairs with score >= score_threshold */
-  float ms_scan, ms_group, ms_score, ms_rank, ms_total; /* HIP-event times of the last run */
+  float ms_scan, ms_group, ms_score, ms_rank, ms_total; /* HIP-event times of the last run (stages incl. read-backs) */
+  float ms_scan_kernel;      /* HIP events directly around the k_scan_bits launch (the dominant kernel) */
+  uint64_t n_selected;       /* pairs that passed the prefilter and went through the DL kernels */
 } anx_batch_stats;
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
 void anx_batch_free(anx_batch *);
