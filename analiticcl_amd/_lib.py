@@ -101,6 +101,10 @@ def lib():
         "anx_model_add_to_vocabulary": (u64, [vp, cp, C.c_int, C.c_uint32, C.POINTER(VocabParams)]),
         "anx_model_add_variant": (C.c_int, [vp, u64, cp, C.c_double, C.c_int, C.c_uint32, C.POINTER(VocabParams)]),
         "anx_model_read_variants": (C.c_int, [vp, cp, C.POINTER(VocabParams), C.c_int]),
+        "anx_model_add_to_confusables": (C.c_int, [vp, cp, C.c_double]),
+        "anx_model_read_confusablelist": (C.c_int, [vp, cp]),
+        "anx_model_set_confusables_before_pruning": (None, [vp]),
+        "anx_edit_script": (C.c_int, [cp, cp, C.c_char_p, C.c_int]),
         "anx_model_build": (C.c_int, [vp, C.c_int]),
         "anx_model_to_device": (C.c_int, [vp, C.c_int]),
         "anx_model_has": (C.c_int, [vp, cp]),

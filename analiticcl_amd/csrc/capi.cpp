@@ -6,6 +6,8 @@
 #include <string>
 
 #include "engine.h"
+#include <algorithm>
+
 #include "host_model.h"
 
 struct anx_model {
@@ -15,6 +17,11 @@ struct anx_model {
 struct anx_batch {
   const anx_model* model = nullptr;
   anx::Batch* b = nullptr;
+  // confusables loaded: the device ranks without the cutoff (late) or without crop and cutoff (early); the host
+  // rescoring in anx_batch_fetch needs the caller's parameters and the input texts
+  bool rescore = false;
+  anx_params params;
+  std::vector<std::string> inputs;
 };
 
 static thread_local std::string g_err;
@@ -27,6 +34,60 @@ static int fail(int code, const std::string& msg) {
 
 const anx::HostModel& anx_host_of(const anx_model* m) { return m->host; }
 int anx_fail(int code, const std::string& msg) { return fail(code, msg); }
+
+
+// Confusable rescoring of the ranked lists (src/lib.rs:1505-1508 early, :1591-1595 late) followed by the steps the device
+// left out: [early: crop, :1536-1589] and the cutoff (:1598-1622).  rows are compacted in place, offs rewritten.
+static double vr_score(const anx_result& r, float fw) {  // src/types.rs:335-341
+  if (fw == 0.0f) return r.dist_score;
+  return (r.dist_score + ((double)fw * r.freq_score)) / (1.0 + (double)fw);
+}
+static void rescore_with_confusables(const anx::HostModel& m, const std::vector<std::string>& inputs, const anx_params& p,
+                                     anx_result* rows, size_t* offs) {
+  const float fw = p.freq_weight;
+  const bool early = m.confusables_before_pruning;
+  size_t w = 0, prev_end = 0;
+  for (size_t i = 0; i < inputs.size(); ++i) {
+    const size_t b0 = prev_end, e0 = offs[i + 1];
+    prev_end = e0;
+    std::vector<anx_result> v(rows + b0, rows + e0);
+    // the weight belongs to the matched item: the variant itself for rows reached through a variant list
+    for (anx_result& r : v) r.dist_score *= m.confusable_weight(inputs[i], r.via != ANX_NO_VIA ? r.via : r.vocab_id);
+    std::stable_sort(v.begin(), v.end(), [&](const anx_result& a, const anx_result& b) {  // rank_cmp, src/types.rs:344-365
+      if (fw > 0.0f) return vr_score(a, fw) > vr_score(b, fw);
+      if (a.dist_score != b.dist_score) return a.dist_score > b.dist_score;
+      return a.freq_score > b.freq_score;
+    });
+    size_t len = v.size();
+    if (early && p.max_matches > 0 && len > p.max_matches) {  // crop with the tie rule
+      const size_t mm = (size_t)p.max_matches;
+      const double last = vr_score(v[mm - 1], fw), cropped = vr_score(v[mm], fw);
+      if (cropped < last) len = mm;
+      else {
+        size_t early_cut = 0, late_cut = 0;
+        for (size_t k = 0; k < v.size(); ++k) {
+          if (v[k].dist_score == cropped && early_cut == 0) early_cut = k;
+          if (v[k].dist_score < cropped) { late_cut = k; break; }
+        }
+        if (early_cut > 0) len = early_cut + 1;
+        else if (late_cut > 0) len = late_cut + 1;
+      }
+    }
+    if (p.cutoff_threshold >= 1.0) {
+      bool have = false;
+      double best = 0.0;
+      for (size_t k = 0; k < len; ++k) {
+        const double s = vr_score(v[k], fw);
+        if (have) {
+          if (s <= best / p.cutoff_threshold) { len = k; break; }
+        } else { best = s; have = true; }
+      }
+    }
+    offs[i] = w;
+    for (size_t k = 0; k < len; ++k) rows[w++] = v[k];
+  }
+  offs[inputs.size()] = w;
+}
 
 extern "C" {
 
@@ -169,16 +230,51 @@ int anx_model_anahash(const anx_model* m, const char* utf8, char* out, int cap) 
   return (int)s.size();
 }
 
+int anx_model_add_to_confusables(anx_model* m, const char* editscript, double weight) {
+  if (!m || !editscript) return fail(ANX_EINVAL, "NULL argument");
+  std::string err;
+  const int rc = m->host.add_to_confusables(editscript, weight, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
+int anx_model_read_confusablelist(anx_model* m, const char* path) {
+  if (!m || !path) return fail(ANX_EINVAL, "NULL argument");
+  std::string err;
+  const int rc = m->host.read_confusablelist(path, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
+void anx_model_set_confusables_before_pruning(anx_model* m) {
+  if (m) m->host.confusables_before_pruning = true;
+}
+int anx_edit_script(const char* source, const char* target, char* out, int cap) {
+  if (!source || !target || !out) return fail(ANX_EINVAL, "NULL argument");
+  const std::string s = anx::edit_script_string(source, target);
+  if ((int)s.size() + 1 > cap) return fail(ANX_EINVAL, "buffer too small");
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
 anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p) {
   if (!m || (!utf8 && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
   if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_variants()"); return nullptr; }
   std::string err;
   int code = ANX_OK;
-  anx::Batch* b = anx::batch_encode(m->host, m->dev, utf8, n, *p, err, &code);
+  anx_params dp = *p;
+  const bool rescore = !m->host.confusables.empty();
+  if (rescore) {
+    dp.cutoff_threshold = 0.0;                               // the cutoff follows the late rescoring (src/lib.rs:1591-1622)
+    if (m->host.confusables_before_pruning) dp.max_matches = 0;  // early: crop after rescoring as well (src/lib.rs:1505-1589)
+  }
+  anx::Batch* b = anx::batch_encode(m->host, m->dev, utf8, n, dp, err, &code);
   if (!b) { fail(code ? code : ANX_ENODEVICE, err); return nullptr; }
   anx_batch* h = new anx_batch();
   h->model = m;
   h->b = b;
+  h->rescore = rescore;
+  h->params = *p;
+  if (rescore) {
+    h->inputs.reserve(n);
+    for (size_t i = 0; i < n; ++i) h->inputs.emplace_back(utf8[i] ? utf8[i] : "");
+  }
   return h;
 }
 int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
@@ -191,7 +287,9 @@ int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   if (!b || !rows || !offs) return fail(ANX_EINVAL, "NULL argument");
   std::string err;
   int rc = anx::batch_fetch(b->model->host, b->model->dev, b->b, rows, offs, err);
-  return rc ? fail(rc, err) : ANX_OK;
+  if (rc) return fail(rc, err);
+  if (b->rescore) rescore_with_confusables(b->model->host, b->inputs, b->params, *rows, *offs);
+  return ANX_OK;
 }
 int anx_batch_fetch_pairs(const anx_batch* b, anx_pair** out, size_t* n) {
   if (!b || !out || !n) return fail(ANX_EINVAL, "NULL argument");
@@ -202,6 +300,7 @@ int anx_batch_fetch_pairs(const anx_batch* b, anx_pair** out, size_t* n) {
 void anx_pairs_free(anx_pair* p) { free(p); }
 int anx_batch_export_topk(const anx_batch* b, void* dst, uint32_t stride, void* stream) {
   if (!b) return fail(ANX_EINVAL, "NULL batch");
+  if (b->rescore) return fail(ANX_EINVAL, "confusables are loaded: results are rescored on the host, use anx_batch_fetch");
   std::string err;
   int rc = anx::batch_export_topk(b->model->dev, b->b, dst, stride, stream, err);
   return rc ? fail(rc, err) : ANX_OK;

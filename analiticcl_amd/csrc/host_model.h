@@ -110,6 +110,14 @@ constexpr int kSigGroups = 6;  // measured on eng.aspell k<=3: 6 groups -> 4.6 k
                                // charcount window (8 -> 1.9 k, but 2.5x more signatures and 3x more query tiles)
 uint64_t signature_of(const uint8_t* cv, size_t n, const std::vector<uint8_t>& sym_group);
 
+struct Confusable {  // src/confusables.rs:5-11; one edit-script pattern with '|' options per instruction
+  std::vector<char> ops;                               // '=', '+', '-'
+  std::vector<std::vector<std::u32string>> options;
+  double weight = 1.0;
+  bool strictbegin = false, strictend = false;
+};
+std::string edit_script_string(const std::string& source, const std::string& target);  // sesdiff notation, for tests
+
 class HostModel {
  public:
   Alphabet alphabet;
@@ -120,6 +128,11 @@ class HostModel {
   std::vector<std::string> lexicons;
   bool have_freq = false;
   bool built = false;
+  std::vector<Confusable> confusables;
+  bool confusables_before_pruning = false;             // set_confusables_before_pruning (src/lib.rs:157)
+  int add_to_confusables(const std::string& script, double weight, std::string& err);
+  int read_confusablelist(const std::string& path, std::string& err);
+  double confusable_weight(const std::string& input, uint64_t candidate) const;
   bool have_lm = false;
   std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
   LexiconImage lex;

@@ -120,6 +120,13 @@ def _b(s) -> bytes:
     return s if isinstance(s, bytes) else s.encode("utf-8")
 
 
+def edit_script(source: str, target: str) -> str:
+    """sesdiff::shortest_edit_script(source, target) in sesdiff notation (anx_edit_script)."""
+    buf = C.create_string_buffer(4 * (len(_b(source)) + len(_b(target))) + 64)
+    L.check(min(0, L.lib().anx_edit_script(_b(source), _b(target), buf, len(buf))))
+    return buf.value.decode("utf-8")
+
+
 class Batch:
     """A batch of queries encoded and resident in HBM (anx_batch_*): encode once, run many times."""
 
@@ -373,5 +380,12 @@ class VariantModel:
                                      for k in order]})
         return out
 
+    # -- confusables: host-side rescoring of the ranked lists ---------------
     def read_confusablelist(self, filename: str):
-        raise NotImplementedError("confusables are a 'next' row of SURVEY.md section 8(f)")
+        L.check(L.lib().anx_model_read_confusablelist(self.h, _b(filename)))
+
+    def add_to_confusables(self, editscript: str, weight: float):
+        L.check(L.lib().anx_model_add_to_confusables(self.h, _b(editscript), float(weight)))
+
+    def set_confusables_before_pruning(self):
+        L.lib().anx_model_set_confusables_before_pruning(self.h)

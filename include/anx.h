@@ -183,6 +183,18 @@ typedef struct anx_batch_stats {
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
 void anx_batch_free(anx_batch *);
 
+/* ---- confusables --------------------------------------------------------------
+ * add_to_confusables / read_confusablelist / set_confusables_before_pruning: src/lib.rs:446-458, :409-443, :157-159.
+ * Patterns are sesdiff edit scripts ("-[y]+[i]", "=[c|k]-[y]+[i]", "^...", "...$"; src/confusables.rs:13-44).  With
+ * confusables loaded the ranked lists are rescored on the host after the device run (late, src/lib.rs:1591-1595, or
+ * before the crop when set_confusables_before_pruning was called, :1505-1508); anx_batch_export_topk is then refused.
+ * The edit script restates sesdiff 0.3.1 / dissimilar (diff-match-patch): parity unpinned beyond tests/main.rs:914-1020. */
+int anx_model_add_to_confusables(anx_model *, const char *editscript, double weight);
+int anx_model_read_confusablelist(anx_model *, const char *path);
+void anx_model_set_confusables_before_pruning(anx_model *);
+/* shortest_edit_script(source, target, false, false, false) in sesdiff notation, e.g. "=[hu]-[y]+[i]=[s]" */
+int anx_edit_script(const char *source, const char *target, char *out, int cap);
+
 /* ---- search mode: the main caller of the hot path -------------------------------
  * VariantModel::find_all_matches(&self, text, &SearchParameters) -> Vec<Match>, src/lib.rs:1790, for n texts at once.
  * Host side: boundaries / n-gram windows / redundancy filter (src/search.rs:190-336), lattice decoding and bigram-LM

@@ -660,10 +660,44 @@ class VariantModel:
                     )))
         return found
 
+    # -- confusables (src/lib.rs:409-458, 1656-1663, 1733-1756; src/confusables.rs) -------------------------------
+    def add_to_confusables(self, editscript: str, weight: float) -> None:
+        from oracle.sesdiff_twin import Confusable
+        if not hasattr(self, "confusables"):
+            self.confusables, self.confusables_before_pruning = [], False
+        self.confusables.append(Confusable(editscript, weight))
+
+    def read_confusablelist(self, filename: str) -> None:
+        with open(filename, encoding="utf-8", newline="") as f:
+            for line in rust_lines(f.read()):
+                if line != "":
+                    fields = line.split("\t")
+                    self.add_to_confusables(fields[0], float(fields[1]) if len(fields) >= 2 else 1.0)
+
+    def set_confusables_before_pruning(self) -> None:
+        if not hasattr(self, "confusables"):
+            self.confusables = []
+        self.confusables_before_pruning = True
+
+    def compute_confusable_weight(self, input: str, candidate: int) -> float:
+        from oracle.sesdiff_twin import shortest_edit_script
+        weight = 1.0
+        script = shortest_edit_script(input, self.decoder[candidate].text)
+        for c in self.confusables:
+            if c.found_in(script):
+                weight *= c.weight
+        return weight
+
+    def rescore_confusables(self, results, input: str) -> None:
+        for r in results:
+            r.dist_score *= self.compute_confusable_weight(input, r.vocab_id)
+
     def score_and_rank(self, instances, input_length: int, max_matches: int,
                        score_threshold: float, cutoff_threshold: float,
-                       freq_weight: float) -> List[VariantResult]:
-        """src/lib.rs:1405-1653 without confusables / variant expansion."""
+                       freq_weight: float, input: Optional[str] = None) -> List[VariantResult]:
+        """src/lib.rs:1405-1653."""
+        confusables = getattr(self, "confusables", [])
+        early = getattr(self, "confusables_before_pruning", False)
         results: List[VariantResult] = []
         max_freq = 0.0
         has_expandable_variants = False
@@ -685,6 +719,8 @@ class VariantModel:
                 has_expandable_variants = True  # src/lib.rs:1464-1466
             if score >= score_threshold:
                 results.append(VariantResult(vocab_id, score, freq_score))
+        if confusables and early:  # src/lib.rs:1505-1508
+            self.rescore_confusables(results, input)
         if has_expandable_variants:  # src/lib.rs:1510-1518
             results = self.expand_variants(results)
             for r in results:
@@ -694,10 +730,12 @@ class VariantModel:
             for r in results:
                 r.freq_score = r.freq_score / max_freq
         # rank_results: stable sort with rank_cmp (src/types.rs:344-365)
-        if freq_weight > 0.0:
-            results.sort(key=lambda r: -r.score(freq_weight))
-        else:
-            results.sort(key=lambda r: (-r.dist_score, -r.freq_score))
+        def rank_results(rs):
+            if freq_weight > 0.0:
+                rs.sort(key=lambda r: -r.score(freq_weight))
+            else:
+                rs.sort(key=lambda r: (-r.dist_score, -r.freq_score))
+        rank_results(results)
         if has_expandable_variants:  # Vec::dedup_by_key: consecutive duplicates only (src/lib.rs:1530-1533)
             ded = []
             for r in results:
@@ -722,6 +760,9 @@ class VariantModel:
                     del results[early_cutoff + 1:]
                 elif late_cutoff > 0:
                     del results[late_cutoff + 1:]
+        if confusables and not early:  # late rescoring, the default (src/lib.rs:1591-1595)
+            self.rescore_confusables(results, input)
+            rank_results(results)
         cutoff = 0
         bestscore = None
         if cutoff_threshold >= 1.0:
@@ -753,7 +794,7 @@ class VariantModel:
             trace["distances"] = variants
         return self.score_and_rank(variants, len(normstring), params.max_matches,
                                    params.score_threshold, params.cutoff_threshold,
-                                   params.freq_weight)
+                                   params.freq_weight, text)
 
 
 # =============================================================================================================

@@ -1,0 +1,87 @@
+"""Confusables in the oracle twin: the reference's tests 0501-0504 (/root/reference/tests/main.rs:914-1020, values
+transcribed) and the published diff-match-patch behaviour the edit scripts are restated from (oracle/sesdiff_twin.py).
+Parity beyond the four reference tests is UNPINNED (sesdiff / dissimilar are not vendored in the reference tree)."""
+from oracle import twin as T
+from oracle.sesdiff_twin import Confusable, script_to_str, shortest_edit_script
+
+A = T.TEST_ALPHABET
+
+
+def test0501_confusable_found_in():
+    c = Confusable("-[y]+[i]", 1.1)
+    assert c.found_in(shortest_edit_script("huys", "huis"))
+    assert not c.found_in(shortest_edit_script("huys", "huls"))
+
+
+def _model(script):
+    m = T.VariantModel(A)
+    for w in ("huis", "huls"):
+        m.add_to_vocabulary(w)
+    m.add_to_confusables(script, 1.1)
+    m.build()
+    return m
+
+
+def test0502_0503_confusable_boosts_huis():
+    m = _model("-[y]+[i]")
+    for q in ("huys", "Huys"):
+        r = m.find_variants(q, T.test_searchparams())
+        assert [m.decoder[x.vocab_id].text for x in r] == ["huis", "huls"]
+        assert r[0].dist_score > r[1].dist_score
+
+
+def test0504_confusable_nomatch():
+    m = _model("-[y]+[p]")
+    r = m.find_variants("Huys", T.test_searchparams())
+    assert len(r) == 2 and r[0].dist_score == r[1].dist_score
+
+
+def test_edit_scripts_known_shapes():
+    """diff-match-patch as published: prefix/suffix trimming, bisect, semantic clean-up (kitten/sitting is its
+    documented example: the one-letter equality between two edits is absorbed), edge preference of lossless shifts."""
+    assert script_to_str(shortest_edit_script("huys", "huis")) == "=[hu]-[y]+[i]=[s]"
+    assert script_to_str(shortest_edit_script("separate", "seperate")) == "=[sep]-[a]+[e]=[rate]"
+    assert script_to_str(shortest_edit_script("kitten", "sitting")) == "-[k]+[s]=[itt]-[en]+[ing]"
+    assert script_to_str(shortest_edit_script("aab", "ab")) == "-[a]=[ab]"
+    assert script_to_str(shortest_edit_script("", "abc")) == "+[abc]"
+    assert script_to_str(shortest_edit_script("abc", "abc")) == "=[abc]"
+
+
+def test_pattern_syntax():
+    c = Confusable("^=[c|k]-[y]+[i]$", 0.9)
+    assert c.strictbegin and c.strictend and c.instructions == [("=", ["c", "k"]), ("-", ["y"]), ("+", ["i"])]
+    assert Confusable("=[c|k]-[y]+[i]", 1.1).found_in(shortest_edit_script("cylinder", "cilinder"))
+    assert not Confusable("=[c|k]-[y]+[i]", 1.1).found_in(shortest_edit_script("huys", "huis"))
+    assert Confusable("-[y]+[i]$", 1.1).found_in(shortest_edit_script("hay", "hai"))
+    assert not Confusable("-[y]+[i]$", 1.1).found_in(shortest_edit_script("huys", "huis"))
+
+
+def test_product_edit_scripts_equal_twin(data_dir):
+    """The product's host-side diff (csrc/confusables.cpp, anx_edit_script: no GPU involved) against the twin's on
+    4000 (misspelling, word) pairs of the eng lexicon plus hand-picked shapes.  Both restate the same published
+    algorithm independently (C++ / Python); this pins them to each other, not to the reference (see module doc)."""
+    import os
+    import random
+    import analiticcl_amd as A
+    from analiticcl_amd import synth
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    rng = random.Random(5)
+    qs = synth.make_queries(words, 4000, max_len=20, seed=9)
+    pairs = [(q, rng.choice(words)) if i % 4 == 0 else (q, min(rng.sample(words, 40), key=lambda w: abs(len(w) - len(q)) + sum(a != b for a, b in zip(w, q))))
+             for i, q in enumerate(qs)]
+    pairs += [("kitten", "sitting"), ("aab", "ab"), ("", "abc"), ("abc", ""), ("abc", "abc"), ("abXcd", "efXgh"),
+              ("the cat sat", "the hat sits"), ("étude", "etude"), ("naïve", "naive"), ("abcabcabc", "abXabXabc"),
+              ("mississippi", "misisipi"), ("a b  c", "a  b c")]
+    for a, b in pairs:
+        assert A.edit_script(a, b) == script_to_str(shortest_edit_script(a, b)), (a, b)
+
+
+def test_product_pattern_errors():
+    import pytest
+    import analiticcl_amd as A
+    m = A.VariantModel("", alphabet_text="a\nb\n")
+    with pytest.raises(A.AnxError):
+        m.add_to_confusables("y>i", 1.1)
+    with pytest.raises(A.AnxError):
+        m.add_to_confusables("-[]", 1.1)
+    m.add_to_confusables("^=[c|k]-[y]+[i]$", 0.9)
