@@ -196,3 +196,23 @@ def test_random_texts_vs_twin(with_lm):
                 assert m["selected"] == e.selected, (text, e.text)
             n_multi += e.n > 1
     assert n_multi > 0  # the lattice did pick some bigram/trigram segments
+
+
+def test_cli_query_readme_line(data_dir, tmp_path, capsys):
+    """README.md:121-124 (recorded output of `analiticcl query` with the CLI defaults) through `python -m analiticcl_amd query`."""
+    from analiticcl_amd import cli
+    inp = tmp_path / "in.txt"
+    inp.write_text("seperate\n", encoding="utf-8")
+    assert cli.main(["query", "--lexicon", os.path.join(data_dir, "eng.aspell.lexicon"), "--alphabet",
+                     os.path.join(data_dir, "simple.alphabet.tsv"), str(inp)]) == 0
+    out = capsys.readouterr().out
+    # README.md:121-124: same seven variants and scores.  The README prints the tied pair as `separates`, `separated`;
+    # the reference's enumeration order (ascending anagram value, src/lib.rs:1148) and tutorial.ipynb's recorded
+    # outputs ('separated' before 'separates' at equal score, cells 18/20) give the order asserted here.
+    assert out == ("seperate\tseparate\t0.734375\t\toperate\t0.6875\t\tdesperate\t0.6875\t\ttemperate\t0.6875\t\tserrate\t0.65625\t"
+                   "\tseparated\t0.609375\t\tseparates\t0.609375\t\n")
+    assert cli.main(["search", "--lexicon", os.path.join(data_dir, "eng.aspell.lexicon"), "--alphabet",
+                     os.path.join(data_dir, "simple.alphabet.tsv"), "--json", str(inp)]) == 0
+    import json
+    js = json.loads(capsys.readouterr().out)
+    assert js[0]["input"] == "seperate" and js[0]["begin"] == 0 and js[0]["end"] == 8 and js[0]["variants"][0]["text"] == "separate"
