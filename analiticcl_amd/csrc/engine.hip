@@ -1253,14 +1253,57 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
 #pragma unroll
   for (int o = G / 2; o; o >>= 1) best = fmax(best, __shfl_xor(best, o));
   const double thr = best / a.cutoff_threshold;
-  // ---- keep the rows the cutoff cannot drop, compacted into LDS -------------------------------------------
+  // ---- long lists, only max_matches + 1 ranks wanted: tau = the (max_matches+1)-th largest key, by quickselect ----
+  // A row with key < tau has at least max_matches+1 rows before it, so it can neither be returned nor influence the
+  // crop / cutoff rules (they only look at the first max_matches+1 ranked rows).  Counting is ballot + popcount over
+  // the wave; the pivot is the first surviving key strictly inside the current bracket (the list is unsorted, so
+  // that is a random pivot).  Needed for d = 3 / long words, where the cutoff rule prunes little (config 3: 1 % of
+  // the queries have more than 128 rows and carry 40 % of sum n^2).
+  double tau = -1.0;  // keys are >= 0
+  if (G == 64 && n > 32 && !(score_weighted || a.max_matches == 0 || expanded)) {
+    const uint32_t want = (uint32_t)a.max_matches + 1u;
+    double lo = -1.0, hi = __builtin_inf();
+    for (int round = 0; round < 96; ++round) {
+      double pivot = 0.0;
+      bool found = false;
+      for (uint32_t base = 0; base < n && !found; base += G) {  // n is wave-uniform in the 64-lane path
+        const uint32_t i = base + (uint32_t)gl;
+        SurvRow r = mine;
+        if (base && i < n) r = c_rows[seg0 + i];
+        const double key = key_of(r);
+        const bool inr = i < n && !(prune && key <= thr && key < best) && key > lo && key < hi;
+        const unsigned long long m = __ballot(inr);
+        if (m) {
+          const int src = (round & 1) ? 63 - __clzll((long long)m) : __ffsll((long long)m) - 1;  // alternate ends
+          pivot = __shfl(key, src);
+          found = true;
+        }
+      }
+      if (!found) break;  // nothing strictly inside the bracket
+      uint32_t cgt = 0, cge = 0;
+      for (uint32_t base = 0; base < n; base += G) {
+        const uint32_t i = base + (uint32_t)gl;
+        SurvRow r = mine;
+        if (base && i < n) r = c_rows[seg0 + i];
+        const double key = key_of(r);
+        const bool pa = i < n && !(prune && key <= thr && key < best);
+        cgt += (uint32_t)__popcll(__ballot(pa && key > pivot));
+        cge += (uint32_t)__popcll(__ballot(pa && key >= pivot));
+      }
+      if (cgt < want && want <= cge) { tau = pivot; break; }
+      if (cgt >= want) lo = pivot;
+      else hi = pivot;
+    }
+    // tau, if it exists, always lies strictly inside (lo, hi): an empty bracket means fewer than `want` rows -> keep all
+  }
+  // ---- keep the rows neither rule can drop, compacted into LDS --------------------------------------------
   uint32_t kept = 0;  // group-uniform
   for (uint32_t base = 0; base < nloop; base += G) {
     const uint32_t i = base + (uint32_t)gl;
     SurvRow r = mine;
     if (base && i < n) r = c_rows[seg0 + i];
     const double key = key_of(r);
-    const bool keep = i < n && !(prune && key <= thr && key < best);
+    const bool keep = i < n && !(prune && key <= thr && key < best) && key >= tau;
     const unsigned long long m = (__ballot(keep) >> gshift) & gmask;
     const uint32_t pos = kept + (uint32_t)__popcll(m & ((1ull << gl) - 1ull));
     if (keep && pos < (uint32_t)LCAP) { s_key[pos] = key; s_freq[pos] = r.freq; s_ord[pos] = r.ord; s_src[pos] = (uint16_t)i; }
