@@ -127,6 +127,7 @@ def lib():
                                                  C.POINTER(C.POINTER(Result)), C.POINTER(sz)]),
         "anx_matches_free": (None, [C.POINTER(Match), C.POINTER(sz), C.POINTER(Result)]),
         "anx_batch_encode": (vp, [vp, C.POINTER(cp), sz, C.POINTER(Params)]),
+        "anx_batch_encode_packed": (vp, [vp, C.c_char_p, sz, sz, C.POINTER(Params)]),
         "anx_batch_run": (C.c_int, [vp, vp, vp]),
         "anx_batch_fetch": (C.c_int, [vp, C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
         "anx_batch_fetch_pairs": (C.c_int, [vp, C.POINTER(C.POINTER(Pair)), C.POINTER(sz)]),

@@ -277,6 +277,21 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
   }
   return h;
 }
+anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t blob_len, size_t n, const anx_params* p) {
+  if (!m || (!blob && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
+  if (n && (blob_len == 0 || blob[blob_len - 1] != '\0')) { fail(ANX_EINVAL, "packed inputs must end with a NUL byte"); return nullptr; }
+  std::vector<const char*> ptrs;
+  ptrs.reserve(n);
+  const char* cur = blob;
+  const char* end = blob + blob_len;
+  while (ptrs.size() < n && cur < end) {
+    ptrs.push_back(cur);
+    const void* z = memchr(cur, 0, (size_t)(end - cur));
+    cur = static_cast<const char*>(z) + 1;
+  }
+  if (ptrs.size() != n) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); return nullptr; }
+  return anx_batch_encode(m, ptrs.data(), n, p);
+}
 int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
   if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");
   std::string err;

@@ -8,10 +8,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <numeric>
 #include <thread>
 #include <type_traits>
@@ -1546,17 +1550,97 @@ int device_count(std::string& err) {
   return n;
 }
 
+// Device memory pool.  A batch needs several GB of scratch (pair list, per-slot arrays, survivor rows); hipMalloc /
+// hipFree of that size cost 100-300 ms per call, far more than the 6 ms the kernels take for a million queries, and
+// search mode issues one batch per n-gram order.  Freed blocks are kept per device and handed out again (best fit,
+// at most 2x the request); lexicon_free() of the last lexicon on a device returns them to the driver.
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;        // size -> block
+  std::unordered_map<void*, size_t> size_of;       // every live or cached block of this pool
+  size_t cached = 0;
+  int lexicons = 0;
+};
+constexpr size_t POOL_CACHE_LIMIT = (size_t)96 << 30;  // bytes kept per device (MI355X: 288 GB HBM)
+DevPool& pool_of(int device) {
+  static DevPool pools[64];
+  return pools[device >= 0 && device < 64 ? device : 0];
+}
+hipError_t pool_malloc(void** p, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevPool& pl = pool_of(dev);
+  bytes = (bytes + 255) & ~(size_t)255;
+  {
+    std::lock_guard<std::mutex> g(pl.mu);
+    auto it = pl.free_blocks.lower_bound(bytes);
+    if (it != pl.free_blocks.end() && it->first <= 2 * bytes + (1u << 20)) {
+      *p = it->second;
+      pl.cached -= it->first;
+      pl.free_blocks.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {  // out of memory: give the cache back and retry once
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> g(pl.mu);
+      for (auto& kv : pl.free_blocks) { drop.push_back(kv.second); pl.size_of.erase(kv.second); }
+      pl.free_blocks.clear();
+      pl.cached = 0;
+    }
+    for (void* d : drop) (void)hipFree(d);
+    (void)hipGetLastError();
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> g(pl.mu);
+  pl.size_of[*p] = bytes;
+  return hipSuccess;
+}
+void pool_free(void* p) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevPool& pl = pool_of(dev);
+  {
+    std::lock_guard<std::mutex> g(pl.mu);
+    auto it = pl.size_of.find(p);
+    if (it != pl.size_of.end() && pl.cached + it->second <= POOL_CACHE_LIMIT) {
+      pl.free_blocks.emplace(it->second, p);
+      pl.cached += it->second;
+      return;
+    }
+    if (it != pl.size_of.end()) pl.size_of.erase(it);
+  }
+  (void)hipFree(p);
+}
+void pool_trim(int device) {
+  DevPool& pl = pool_of(device);
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(pl.mu);
+    for (auto& kv : pl.free_blocks) { drop.push_back(kv.second); pl.size_of.erase(kv.second); }
+    pl.free_blocks.clear();
+    pl.cached = 0;
+  }
+  for (void* d : drop) (void)hipFree(d);
+}
+}  // namespace
+
 template <typename T>
 static int upload(T** dst, const void* src, size_t count, std::string& err, size_t* total) {
   const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes));
+  HIP_TRY(pool_malloc(reinterpret_cast<void**>(dst), bytes));
   if (count) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
   if (total) *total += bytes;
   return ANX_OK;
 }
 template <typename T>
 static int dalloc(T** dst, size_t count, std::string& err) {
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(count * sizeof(T), 16)));
+  HIP_TRY(pool_malloc(reinterpret_cast<void**>(dst), std::max<size_t>(count * sizeof(T), 16)));
   return ANX_OK;
 }
 
@@ -1570,6 +1654,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; }
   DeviceLexicon* d = new DeviceLexicon();
   d->device = device;
+  { DevPool& pl = pool_of(device); std::lock_guard<std::mutex> g(pl.mu); ++pl.lexicons; }
   d->nplanes = img.nplanes;
   d->nsym = img.nsym;
   d->nclasses = img.nclasses;
@@ -1615,7 +1700,10 @@ void lexicon_free(DeviceLexicon* d) {
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p);
+  bool last;
+  { DevPool& pl = pool_of(d->device); std::lock_guard<std::mutex> g(pl.mu); last = --pl.lexicons <= 0; }
+  if (last) pool_trim(d->device);  // the last model of this device: hand the cached blocks back to the driver
   delete d;
 }
 
@@ -1629,6 +1717,10 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   *code = ANX_OK;
   if (!dl) { err = "model is not resident on a device (no HIP device / anx_model_to_device not called)"; *code = ANX_ENODEVICE; return nullptr; }
   if (hipSetDevice(dl->device) != hipSuccess) { err = "hipSetDevice failed"; *code = ANX_ENODEVICE; return nullptr; }
+  static const bool timing = getenv("ANX_ENCODE_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = tnow();
+  auto lap = [&](const char* what) { if (timing) { const double t = tnow(); fprintf(stderr, "[anx encode] %-28s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
   Batch* b = new Batch();
   b->device = dl->device;
   b->params = p;
@@ -1687,6 +1779,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     }
     for (auto& x : th) x.join();
   }
+  lap("normalise + count vectors");
   // (kernel kind, length)-bucketed order, stable (counting sort): a bucket shares k, d and the class window
   constexpr uint32_t NKEYS = (NBITPLANES + 1) * 256;
   std::vector<size_t> kstart(NKEYS + 1, 0);
@@ -1710,6 +1803,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     for (size_t i = 0; i < n; ++i)
       if (enc[i].meta) b->order[cursor[enc[i].key]++] = (uint32_t)i;
   }
+  lap("counting sort");
   {  // inside a (kind, length) bucket: by signature, stable; buckets are independent -> threads take them round-robin
     auto sort_buckets = [&](unsigned tid) {
       for (uint32_t kx = tid; kx < NKEYS; kx += nthreads)
@@ -1723,6 +1817,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
       for (unsigned t = 0; t < nthreads; ++t) th.emplace_back(sort_buckets, t);
     for (auto& x : th) x.join();
   }
+  lap("signature sort");
   auto fill_range = [&](size_t lo, size_t hi) {
     for (size_t s = lo; s < hi; ++s) {
       const size_t i = b->order[s];
@@ -1748,6 +1843,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     }
     for (auto& x : th) x.join();
   }
+  lap("fill device images");
   // tiles: <= SCAN_TQ queries of one kind, length and signature; one wave of k_scan each
   for (size_t i = 0; i < nq;) {
     size_t j = i;
@@ -1768,6 +1864,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     return (uint64_t)x.nq * (x.s1 - x.s0 + 64) > (uint64_t)y.nq * (y.s1 - y.s0 + 64);
   });
   for (const Tile& t : b->tiles) b->n_sad_tiles += t.kind == 0;
+  lap("tiles + LPT order");
   std::vector<uint32_t> h_xcls(nq, 0xFFFFFFFFu);
   if (p.stop_at_exact_match) {  // the exact anagram class of every query (the index lookup of src/lib.rs:1164-1173)
     auto lookup_range = [&](size_t lo, size_t hi) {
@@ -1797,6 +1894,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     batch_free(b);
     return nullptr;
   }
+  lap("uploads");
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
   if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
@@ -1817,6 +1915,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
   if (hipEventCreate(&b->ev_scan0) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
+  lap("device allocations");
   return b;
 }
 
@@ -1851,7 +1950,7 @@ static int ensure_raw(Batch* b, size_t slots_per_region, std::string& err) {
   const size_t cap = (size_t)SCAN_REGIONS << shift;
   if (cap <= b->raw_cap) return ANX_OK;
   for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount})
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p);
   b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->s_meta = nullptr; b->sel = nullptr; b->blockcount = nullptr; b->raw_cap = 0;
   int rc;
   const size_t nblk = cap / 256 + 2;
@@ -1864,7 +1963,7 @@ static int ensure_raw(Batch* b, size_t slots_per_region, std::string& err) {
 static int ensure_surv(Batch* b, size_t cap, std::string& err) {
   if (cap <= b->surv_cap) return ANX_OK;
   for (void* p : {(void*)b->c_rows, (void*)b->r_rows, (void*)b->t_key})
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p);
   b->c_rows = nullptr;
   b->r_rows = nullptr;
   b->t_key = nullptr;
@@ -1984,7 +2083,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     // survivor records: region r takes the survivors of blocks r, r + 64, ... of either score kernel; a block scores <= 256 pairs
     const size_t need = 2 * ((((size_t)nsel + 255) / 256 + SCAN_REGIONS - 1) / SCAN_REGIONS + 1) * 256;
     if (need > b->surv_region_cap) {
-      if (b->surv) (void)hipFree(b->surv);
+      if (b->surv) pool_free(b->surv);
       b->surv = nullptr;
       b->surv_region_cap = 0;
       if ((rc = dalloc(&b->surv, need * SCAN_REGIONS, err))) return rc;
@@ -2087,14 +2186,14 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
   if (!off || !out) { free(off); free(out); err = "out of memory"; return ANX_EINVAL; }
   if (b->nq && b->n_results) {
     DevRow* d_rows = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), b->n_results * sizeof(DevRow)));
+    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_rows), b->n_results * sizeof(DevRow)));
     hipLaunchKernelGGL(k_pack_rows, dim3(((uint32_t)b->nq + 255) / 256), dim3(256), 0, 0, (uint32_t)b->nq, b->soff,
                        b->r_off, b->r_count, b->r_rows, d_rows);
     std::vector<DevRow> h(b->n_results);
     std::vector<uint32_t> h_cnt(b->nq);
     HIP_TRY(hipMemcpy(h.data(), d_rows, b->n_results * sizeof(DevRow), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_cnt.data(), b->r_count, b->nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    (void)hipFree(d_rows);
+    pool_free(d_rows);
     for (size_t s = 0; s < b->nq; ++s) off[b->order[s] + 1] = h_cnt[s];
     for (size_t i = 0; i < n; ++i) off[i + 1] += off[i];
     size_t src = 0;
@@ -2182,7 +2281,7 @@ void batch_free(Batch* b) {
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p);
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);

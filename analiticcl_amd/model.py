@@ -120,6 +120,20 @@ def _b(s) -> bytes:
     return s if isinstance(s, bytes) else s.encode("utf-8")
 
 
+def _pack(inputs: Sequence) -> bytes:
+    """n inputs -> one buffer, each terminated by a NUL byte; an input with an embedded NUL is cut there, exactly as the
+    char* entry points would."""
+    if not len(inputs):
+        return b""
+    try:
+        blob = ("\0".join(inputs) + "\0").encode("utf-8")          # all str: one join, one encode
+    except TypeError:
+        blob = b"\0".join(_b(t) for t in inputs) + b"\0"
+    if blob.count(b"\0") != len(inputs):
+        blob = b"\0".join(_b(t).split(b"\0", 1)[0] for t in inputs) + b"\0"
+    return blob
+
+
 def edit_script(source: str, target: str) -> str:
     """sesdiff::shortest_edit_script(source, target) in sesdiff notation (anx_edit_script)."""
     buf = C.create_string_buffer(4 * (len(_b(source)) + len(_b(target))) + 64)
@@ -133,9 +147,10 @@ class Batch:
     def __init__(self, model: "VariantModel", inputs: Sequence[str], params: SearchParameters):
         self.model = model
         self.n = len(inputs)
-        arr = (C.c_char_p * max(self.n, 1))(*[_b(t) for t in inputs])
         cp = params._c()
-        self.h = L.lib().anx_batch_encode(model.h, arr, self.n, C.byref(cp))
+        # one NUL-terminated buffer instead of a pointer array (anx_batch_encode_packed)
+        blob = _pack(inputs)
+        self.h = L.lib().anx_batch_encode_packed(model.h, blob, len(blob), self.n, C.byref(cp))
         if not self.h:
             raise L.AnxError(L.ANX_ENODEVICE if "device" in L.last_error() else L.ANX_EINVAL, L.last_error())
         self.freq_weight = float(params.freq_weight)
