@@ -577,9 +577,15 @@ std::string HostModel::ngram_key(const uint64_t* ids, size_t n) {
 }
 void HostModel::build_lm() {
   ngrams.clear();
+  unigrams.clear();
+  bigrams.clear();
   std::vector<uint64_t> ng;
   for (size_t id = 0; id < decoder.size(); ++id)
-    if ((decoder[id].vocabtype & ANX_VOCAB_LM) && into_ngram(id, ng)) ngrams[ngram_key(ng.data(), ng.size())] += decoder[id].frequency;
+    if ((decoder[id].vocabtype & ANX_VOCAB_LM) && into_ngram(id, ng)) {
+      ngrams[ngram_key(ng.data(), ng.size())] += decoder[id].frequency;
+      if (ng.size() == 1) unigrams[ng[0]] += decoder[id].frequency;
+      else if (ng.size() == 2) bigrams[(ng[0] << 32) | (ng[1] & 0xFFFFFFFFull)] += decoder[id].frequency;
+    }
   have_lm = !ngrams.empty();
 }
 

@@ -135,6 +135,7 @@ class HostModel {
   double confusable_weight(const std::string& input, uint64_t candidate) const;
   bool have_lm = false;
   std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
+  std::unordered_map<uint64_t, uint32_t> unigrams, bigrams;  // the two orders lm_score_tokens looks up (id, id1 << 32 | id2)
   LexiconImage lex;
   std::unordered_map<std::string, uint32_t> class_of_cv;  // count vector bytes -> class rank
 

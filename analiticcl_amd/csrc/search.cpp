@@ -6,7 +6,11 @@
 // rayon par_iter, src/lib.rs:1883-1899).  Order n depends on the unigram results through redundant_match, so the
 // orders are processed one after another.
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -124,10 +128,10 @@ void lm_score_tokens(const HostModel& m, const std::vector<int64_t>& tokens, flo
   for (size_t i = 1; i < tokens.size(); ++i) {
     if (tokens[i - 1] >= 0 && tokens[i] >= 0) {
       const uint64_t bg[2] = {(uint64_t)tokens[i - 1], (uint64_t)tokens[i]};
-      auto pit = m.ngrams.find(HostModel::ngram_key(bg, 1));
-      const uint32_t priorcount = pit == m.ngrams.end() ? 1u : pit->second;
-      auto jit = m.ngrams.find(HostModel::ngram_key(bg, 2));
-      if (jit != m.ngrams.end()) {
+      auto pit = m.unigrams.find(bg[0]);
+      const uint32_t priorcount = pit == m.unigrams.end() ? 1u : pit->second;
+      auto jit = m.bigrams.find((bg[0] << 32) | (bg[1] & 0xFFFFFFFFull));
+      if (jit != m.bigrams.end()) {
         if (priorcount < jit->second) logprob += logf((float)jit->second);
         else logprob += logf((float)jit->second / (float)priorcount);
       } else logprob += SMOOTH;
@@ -281,6 +285,10 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
                                anx_match** out_matches, size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows) {
   if (!model || (!texts && n) || !sp || !out_matches || !out_offsets || !out_rows || !out_n_rows)
     return anx_fail(ANX_EINVAL, "NULL argument");
+  static const bool timing = getenv("ANX_SEARCH_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = tnow();
+  auto lap = [&](const char* what) { if (timing) { const double t = tnow(); fprintf(stderr, "[anx search] %-28s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
   const HostModel& m = anx_host_of(model);
   if (!m.built || m.lex.nclasses == 0)  // src/lib.rs:1801-1805 (the reference eprintln!s and returns no matches)
     return anx_fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_all_matches()");
@@ -299,6 +307,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         begin_index = i + 1;
       }
   }
+  lap("boundaries");
   // one device batch per n-gram order
   for (uint32_t order = 1; order <= sp->max_ngram; ++order) {
     std::vector<std::vector<Span>> cur(stretches.size());
@@ -331,17 +340,46 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     for (size_t si = 0; si < stretches.size(); ++si)
       stretches[si].matches.insert(stretches[si].matches.end(), cur[si].begin(), cur[si].end());
   }
-  // consolidate per stretch
-  std::vector<std::vector<Span>> per_text(n);
-  for (Stretch& st : stretches) {
-    std::vector<Span>& dst = per_text[st.text_index];
-    if (sp->max_ngram > 1 || m.have_lm) {
-      most_likely_sequence(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end,
-                           *sp, dst);
-    } else {
-      for (Span& s : st.matches) { s.selected = 0; dst.push_back(std::move(s)); }
+  lap("segments + device batches");
+  // consolidate per stretch: the lattices are independent -> host threads (the reference: rayon over the segments and a
+  // sequential loop over the stretches, src/lib.rs:1821-1940)
+  std::vector<std::vector<Span>> decoded(stretches.size());
+  {
+    auto work = [&](size_t lo, size_t hi) {
+      for (size_t si = lo; si < hi; ++si) {
+        Stretch& st = stretches[si];
+        if (sp->max_ngram > 1 || m.have_lm)
+          most_likely_sequence(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end,
+                               *sp, decoded[si]);
+        else
+          for (Span& s : st.matches) { s.selected = 0; decoded[si].push_back(std::move(s)); }
+      }
+    };
+    unsigned nthreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (stretches.size() < 64) nthreads = 1;
+    if (nthreads == 1) work(0, stretches.size());
+    else {
+      // interleaved chunks: neighbouring stretches have similar cost
+      std::vector<std::thread> th;
+      const size_t chunk = 16;
+      std::atomic<size_t> next{0};
+      for (unsigned t = 0; t < nthreads; ++t)
+        th.emplace_back([&]() {
+          for (;;) {
+            const size_t lo = next.fetch_add(chunk);
+            if (lo >= stretches.size()) break;
+            work(lo, std::min(stretches.size(), lo + chunk));
+          }
+        });
+      for (auto& x : th) x.join();
     }
   }
+  std::vector<std::vector<Span>> per_text(n);
+  for (size_t si = 0; si < stretches.size(); ++si) {
+    std::vector<Span>& dst = per_text[stretches[si].text_index];
+    for (Span& s : decoded[si]) dst.push_back(std::move(s));
+  }
+  lap("lattice + LM");
   size_t total = 0, total_rows = 0;
   for (auto& v : per_text) { total += v.size(); for (auto& s : v) total_rows += s.variants.size(); }
   anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, total) * sizeof(anx_match)));
@@ -377,6 +415,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     }
   }
   oo[n] = w;
+  lap("output");
   *out_matches = om;
   *out_offsets = oo;
   *out_rows = orows;

@@ -1,0 +1,48 @@
+"""Search-mode throughput (BASELINE config 5 shape, scaled): sentences of 5-25 sampled + perturbed lexicon words,
+max_ngram 3, bigram LM counts from the same sampler.  usage: search_bench.py [MB of text]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import analiticcl_amd as A
+from analiticcl_amd import synth
+
+mb = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+d = synth.materialize_golden("/tmp/anxdata")
+words = synth.load_lexicon_words(d["eng"])
+rng = random.Random(7)
+m = A.VariantModel(d["alphabet"], A.Weights(), device=0)
+m.read_lexicon(d["eng"])
+LM = A.VocabParams(vocabtype="LM")
+common = [w for w in words if w.isalpha()][::23][:5000]
+for _ in range(20000):
+    a, b = rng.choice(common), rng.choice(common)
+    m.add_to_vocabulary(f"{a} {b}", rng.randrange(1, 20), LM)
+for w in common[:500]:
+    m.add_to_vocabulary(f"<bos> {w}", 5, LM)
+m.build()
+pert = synth.make_queries(common, int(mb * 1e6 / 7) + 100, max_len=16, seed=3)
+texts, cur, size, k = [], [], 0, 0
+while size < mb * 1e6:
+    n = rng.randrange(5, 26)
+    sent = " ".join(pert[k:k + n]) + rng.choice([". ", "\n", ", ", "\n\n"])
+    k += n
+    cur.append(sent)
+    if len(cur) == 8:
+        texts.append("".join(cur)); size += len(texts[-1]); cur = []
+p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, max_ngram=3)
+import ctypes as C
+from analiticcl_amd import _lib as L
+arr = (C.c_char_p * len(texts))(*[t.encode() for t in texts])
+spc = p._c_search()
+for rep in range(2):  # the C entry point alone (what a Rust / C caller sees)
+    ms, offs, rows, nrows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)(), C.c_size_t(0)
+    t = time.time()
+    L.check(L.lib().anx_find_all_matches_batch(m.h, arr, len(texts), C.byref(spc), C.byref(ms), C.byref(offs), C.byref(rows), C.byref(nrows)))
+    dt = time.time() - t
+    print(f"C ABI: {size/1e6:.1f} MB in {dt:.2f} s = {size/1e6/dt:.2f} MB/s, {offs[len(texts)]} matches, {nrows.value} variant rows")
+    L.lib().anx_matches_free(ms, offs, rows)
+for rep in range(1):
+    t = time.time()
+    res = m.find_all_matches_ids(texts, p)
+    dt = time.time() - t
+    nm = sum(len(r) for r in res)
+    print(f"{size/1e6:.1f} MB in {len(texts)} texts: {dt:.2f} s = {size/1e6/dt:.2f} MB/s, {nm} matches, {nm/dt:.0f} matches/s")
