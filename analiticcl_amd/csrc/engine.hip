@@ -133,11 +133,12 @@ struct Batch {
   uint32_t* qmaxfreq = nullptr;
   uint32_t* scan_tmp = nullptr;
   uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
-  double* p_score = nullptr;       // per selected slot (dense, selection order)
-  uint32_t* s_meta = nullptr;      // per selected slot: ld | samecase<<7 | lcs<<8 | prefix<<16 | suffix<<24
-  uint32_t* p_meta = nullptr;      // per raw slot: skipped / rejected / pending(selected)
-  uint32_t* sel = nullptr;         // indices of the pair-list slots that passed the prefilter
-  uint32_t* blockcount = nullptr;  // per 256-slot block: selected slots (+ scan scratch)
+  double* p_score = nullptr;       // per pair-list slot: score of the pairs that went through a DL kernel
+  uint32_t* p_meta = nullptr;      // per pair-list slot: skipped / rejected / ld | samecase<<7 | lcs<<8 | prefix<<16 | suffix<<24
+  uint32_t* list8 = nullptr;       // slot lists of the selected pairs the fused kernel leaves to k_score_fast8 / k_score_pairs
+  uint32_t* listg = nullptr;
+  uint32_t* lctr = nullptr;        // [2][SCAN_REGIONS][RC_STRIDE] their fills
+  size_t list_cap = 0;             // slots per region in list8 / listg
   size_t raw_cap = 0;
   double* quot = nullptr;          // table of IEEE quotients x / L (ScoreArgs::quot)
   SurvRec* surv = nullptr;         // survivor records in SCAN_REGIONS regions of surv_region_cap (order arbitrary)
@@ -150,7 +151,8 @@ struct Batch {
   size_t surv_cap = 0;
   uint32_t* r_count = nullptr;
   uint32_t* r_off = nullptr;       // nq+1
-  uint32_t n_raw = 0, n_sel = 0;
+  uint32_t n_raw = 0;
+  uint64_t n_sel = 0;
   uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
   bool ran = false;
   hipEvent_t ev[6] = {};
@@ -539,7 +541,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t* __restrict_
 // rejects ~2/3 of the pairs; the banded DP then runs only on the selected third.  Strings longer than 16
 // symbols or d > 3 are passed through unfiltered.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t META_PENDING = 0xFFFFFFFEu;  // selected for k_score_pairs
 #define PAIR_NONE 0x7Fu
 
 __device__ inline uint32_t nonzero_bytes(uint32_t x) {  // bit 7 of every byte that is non-zero
@@ -594,92 +595,6 @@ __device__ inline bool band_bound_rejects(const uint32_t (&q)[NW], const uint32_
   return filt && (unA > d || unB > d);
 }
 
-// The pair list is SCAN_REGIONS regions of 1 << region_shift slots; region r holds rctr[r][RC_RAW] slots.  The
-// per-slot kernels run on a (blocks of the fullest region) x (regions) grid.
-
-__global__ __launch_bounds__(256) void k_prefilter(uint32_t region_shift, const uint32_t* __restrict__ rctr, const uint2* __restrict__ raw,
-                                                   const uint32_t* __restrict__ qexact, int stop, int enable,
-                                                   const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
-                                                   uint32_t qw, const uint32_t* __restrict__ ent_meta,
-                                                   const uint32_t* __restrict__ ent_rowoff, const uint4* __restrict__ rows,
-                                                   uint32_t* __restrict__ p_meta, uint32_t* __restrict__ blockcount,
-                                                   uint32_t* __restrict__ counters) {
-  __shared__ uint32_t s_cnt[4];
-  const uint32_t fill = rctr[blockIdx.y * RC_STRIDE + RC_RAW], bidx = blockIdx.y * gridDim.x + blockIdx.x;
-  if (blockIdx.x * 256 >= fill) {  // block-uniform: the whole block lies beyond its region's fill
-    if (threadIdx.x == 0) blockcount[bidx] = 0;
-    return;
-  }
-  const uint32_t p = (blockIdx.y << region_shift) + blockIdx.x * 256 + threadIdx.x;
-  const bool live = blockIdx.x * 256 + threadIdx.x < fill;
-  bool selected = false, stop_skipped = false;
-  int d = 0, lq = 0, lc = 0;
-  // words that are not loaded keep the row padding (query 0xFE, candidate 0xFF: never equal to anything)
-  uint32_t q8[8] = {0, 0, 0, 0, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
-  uint32_t c10[10] = {0xFFFFFFFFu, 0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-  bool filt = false, wide = false;
-  if (live) {
-    const uint2 rp = raw[p];
-    const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
-    // unused chunk tail, or (StopAtExactMatch, src/lib.rs:1164-1173) a non-exact class of a query that has one
-    const bool skip = q == RAW_INVALID || (stop && !(rp.y & 0x80000000u) && qexact[q] != 0xFFFFFFFFu);
-    stop_skipped = skip && q != RAW_INVALID;
-    if (!skip) {
-      const uint32_t qm = q_meta[q], em = ent_meta[e];
-      lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
-      const int diff = lq > lc ? lq - lc : lc - lq;
-      selected = diff <= d;  // src/distance.rs:109-130
-      filt = selected && enable && d <= 3 && lq <= 32 && lc <= 32;
-      wide = filt && (lq > 16 || lc > 16);
-      if (filt) {
-        const uint4* qr = q_rows + (size_t)q * qw;
-        const uint4* cr = rows + ent_rowoff[e];
-        const uint4 Q = qr[0], C = cr[0];
-        q8[0] = Q.x; q8[1] = Q.y; q8[2] = Q.z; q8[3] = Q.w;
-        c10[1] = C.x; c10[2] = C.y; c10[3] = C.z; c10[4] = C.w;
-        if (lq > 16) { const uint4 Q1 = qr[1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
-        if (lc > 16) { const uint4 C1 = cr[1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
-      }
-    }
-    if (skip) p_meta[p] = META_SKIPPED;
-  }
-  if (__any(wide)) {  // wave-uniform: some pair of the wave has a string of 17..32 symbols
-    if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
-  } else if (__any(filt)) {
-    const uint32_t q4[4] = {q8[0], q8[1], q8[2], q8[3]}, c6[6] = {0xFFFFFFFFu, c10[1], c10[2], c10[3], c10[4], 0xFFFFFFFFu};
-    if (band_bound_rejects<4>(q4, c6, filt, d, lq, lc)) selected = false;
-  }
-  if (live && !stop_skipped && raw[p].x != RAW_INVALID)
-    p_meta[p] = selected ? META_PENDING : (PAIR_NONE | (1u << 7));  // rejected: ld = None, samecase = true
-  const unsigned long long m = __ballot(selected);
-  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) blockcount[bidx] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-  // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops; only that mode pays an atomic
-  if (stop) {
-    const unsigned long long ms = __ballot(stop_skipped);
-    if ((threadIdx.x & 63) == 0 && ms) atomicAdd(&counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
-  }
-}
-
-// K2b: selected slots -> dense index list (block offsets from the exclusive scan of blockcount)
-__global__ __launch_bounds__(256) void k_select(uint32_t region_shift, const uint32_t* __restrict__ rctr,
-                                                const uint32_t* __restrict__ p_meta,
-                                                const uint32_t* __restrict__ blockoff, uint32_t* __restrict__ sel) {
-  __shared__ uint32_t s_cnt[4];
-  const uint32_t fill = rctr[blockIdx.y * RC_STRIDE + RC_RAW];
-  if (blockIdx.x * 256 >= fill) return;  // block-uniform
-  const uint32_t p = (blockIdx.y << region_shift) + blockIdx.x * 256 + threadIdx.x;
-  const bool selected = blockIdx.x * 256 + threadIdx.x < fill && p_meta[p] == META_PENDING;
-  const unsigned long long m = __ballot(selected);
-  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 0) s_cnt[wid] = (uint32_t)__popcll(m);
-  __syncthreads();
-  uint32_t base = blockoff[blockIdx.y * gridDim.x + blockIdx.x];
-  for (uint32_t i = 0; i < wid; ++i) base += s_cnt[i];
-  if (selected) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
-}
-
 struct ScoreArgs {
   const double* quot;  // [33][33] quot[x*33+L] = (double)x / (double)L computed on the host, or nullptr
   int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL
@@ -691,16 +606,17 @@ struct ScoreArgs {
   uint32_t qw;
 };
 
-// Appends the wave's survivors to the survivor list: one atomic per wave on the counter of region (block % regions).
+// Appends the wave's survivors to the survivor list: one atomic per wave on the counter of the given region (the
+// pair-list region the pairs come from, so a region holds at most as many survivors as that region has slots).
 struct SurvOut {
   SurvRec* list;
   uint32_t* ctr;          // [SCAN_REGIONS][RC_STRIDE]
   uint32_t region_cap;
 };
-__device__ inline void surv_append(const SurvOut& o, bool keep, uint32_t q, uint32_t e, double score) {
+__device__ inline void surv_append(const SurvOut& o, uint32_t region, bool keep, uint32_t q, uint32_t e, double score) {
   const unsigned long long km = __ballot(keep);
   if (!km) return;  // wave-uniform
-  const uint32_t lane = threadIdx.x & 63, region = blockIdx.x % SCAN_REGIONS;
+  const uint32_t lane = threadIdx.x & 63;
   uint32_t base = 0;
   if (lane == (uint32_t)__ffsll((long long)km) - 1u) base = atomicAdd(&o.ctr[region * RC_STRIDE], (uint32_t)__popcll(km));
   base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)km) - 1);
@@ -784,7 +700,6 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
 // l = i-1-a the last earlier row whose symbol equals t[j-1] and db = j-1-b the last earlier column of this row
 // that matches s[i-1], T = D[l-1][db-1] + a + b + 1, only needed for a + b <= D - 1.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t SCORE_DEFER = 0xFFFFFFFDu;  // s_meta marker: pair left to the general k_score_pairs
 
 template <int NW>
 __device__ inline uint32_t byte_of(const uint32_t (&w)[NW], int idx) { return (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; }
@@ -891,87 +806,224 @@ __device__ inline uint32_t dl_band(const uint32_t (&S)[NW], const uint32_t (&T)[
   return res;
 }
 
-// NW = 4: both strings <= 16 symbols (first launch, every selected pair; longer pairs are marked SCORE_DEFER).
-// NW = 8: both <= 32 symbols (second launch, only the deferred pairs).  What is still deferred afterwards (longer
-// strings, d > 3) goes to the general k_score_pairs.
+// A list of pair-list slots per region (the selected pairs a later kernel has to score), appended per wave.
+struct SlotList {
+  uint32_t* list;      // [SCAN_REGIONS][region_cap]
+  uint32_t* ctr;       // [SCAN_REGIONS][RC_STRIDE]
+  uint32_t region_cap;
+};
+__device__ inline void slot_append(const SlotList& o, uint32_t region, bool put, uint32_t slot) {
+  const unsigned long long km = __ballot(put);
+  if (!km) return;  // wave-uniform
+  const uint32_t lane = threadIdx.x & 63;
+  const int first = __ffsll((long long)km) - 1;
+  uint32_t base = 0;
+  if ((int)lane == first) base = atomicAdd(&o.ctr[region * RC_STRIDE], (uint32_t)__popcll(km));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+  const uint32_t pos = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+  if (put && pos < o.region_cap) o.list[(size_t)region * o.region_cap + pos] = slot;
+}
+
+struct PairArgs {  // what every scoring kernel reads / writes
+  const uint2* raw;
+  const uint32_t* q_meta;
+  const uint4* q_rows;
+  const uint32_t* ent_meta;
+  const uint32_t* ent_rowoff;
+  const uint4* rows;
+  const uint32_t* ent_freq;
+  const uint32_t* ent_var_off;
+  double* p_score;      // per pair-list slot
+  uint32_t* p_meta;     // per pair-list slot: ld | samecase<<7 | lcs<<8 | prefix<<16 | suffix<<24, or skipped / rejected
+  uint32_t* qmaxfreq;
+  uint32_t* qsurv;
+  uint32_t* qexpand;
+};
+
+// Scores the pair in slot p with the register-resident DL of NW words (all lanes of the wave call this; lanes with
+// !active only take part in the wave-wide steps).  lds: per-lane staging of both strings for the byte-wise tail.
 template <int D, int NW>
-__global__ __launch_bounds__(256) void k_score_fast(uint32_t nsel, const uint32_t* __restrict__ sel,
-                                                    const uint2* __restrict__ raw, const uint32_t* __restrict__ q_meta,
-                                                    const uint4* __restrict__ q_rows, const uint32_t* __restrict__ ent_meta,
-                                                    const uint32_t* __restrict__ ent_rowoff, const uint4* __restrict__ rows,
-                                                    const uint32_t* __restrict__ ent_freq, ScoreArgs a,
-                                                    const uint32_t* __restrict__ ent_var_off, double* __restrict__ s_score,
-                                                    uint32_t* __restrict__ s_meta, uint32_t* __restrict__ qmaxfreq,
-                                                    uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, SurvOut so) {
-  constexpr int LSTRIDE = 2 * NW + 1;          // per lane: query row + candidate row for the byte-wise tail; odd stride
-  __shared__ uint32_t s_str[256 * LSTRIDE];
-  const uint32_t i_sel = blockIdx.x * 256 + threadIdx.x;
-  const bool active = i_sel < nsel && (NW == 4 || s_meta[i_sel] == SCORE_DEFER);
+__device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& A, const ScoreArgs& a, const SurvOut& so,
+                                       uint32_t surv_region, uint32_t* __restrict__ lds) {
   uint32_t q = 0, e = 0, qm = 0, em = 0;
   int lq = 0, lc = 0, d = 0;
   uint32_t S[NW], T[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) { S[w] = 0xFEFEFEFEu; T[w] = 0xFFFFFFFFu; }
-  bool fast = false;
   if (active) {
-    const uint2 rp = raw[sel[i_sel]];
+    const uint2 rp = A.raw[p];
     q = rp.x;
     e = rp.y & 0x7FFFFFFFu;
-    qm = q_meta[q];
-    em = ent_meta[e];
+    qm = A.q_meta[q];
+    em = A.ent_meta[e];
     lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
-    fast = lq <= 4 * NW && lc <= 4 * NW && d <= D;
-    if (fast) {
-      const uint4* qr = q_rows + (size_t)q * a.qw;
-      const uint4* cr = rows + ent_rowoff[e];
+    const uint4* qr = A.q_rows + (size_t)q * a.qw;
+    const uint4* cr = A.rows + A.ent_rowoff[e];
 #pragma unroll
-      for (int w = 0; w < NW / 4; ++w) {
-        if (w * 16 < lq) { const uint4 Q = qr[w]; S[4 * w] = Q.x; S[4 * w + 1] = Q.y; S[4 * w + 2] = Q.z; S[4 * w + 3] = Q.w; }
-        if (w * 16 < lc) { const uint4 C = cr[w]; T[4 * w] = C.x; T[4 * w + 1] = C.y; T[4 * w + 2] = C.z; T[4 * w + 3] = C.w; }
-      }
+    for (int w = 0; w < NW / 4; ++w) {
+      if (w * 16 < lq) { const uint4 Q = qr[w]; S[4 * w] = Q.x; S[4 * w + 1] = Q.y; S[4 * w + 2] = Q.z; S[4 * w + 3] = Q.w; }
+      if (w * 16 < lc) { const uint4 C = cr[w]; T[4 * w] = C.x; T[4 * w + 1] = C.y; T[4 * w + 2] = C.z; T[4 * w + 3] = C.w; }
     }
   }
-  int lqmax = fast ? lq : 0;
+  int lqmax = active ? lq : 0;
 #pragma unroll
   for (int o = 32; o; o >>= 1) lqmax = max(lqmax, __shfl_xor(lqmax, o));
   lqmax = __builtin_amdgcn_readfirstlane(lqmax);
-  const uint32_t res = dl_band<D, NW>(S, T, fast ? lq : 0, lc, lqmax);
+  const uint32_t res = dl_band<D, NW>(S, T, active ? lq : 0, lc, lqmax);
   uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
   double score = __builtin_nan("");
   bool keep = false;
   const int diff = lq > lc ? lq - lc : lc - lq;
-  if (fast && diff <= d && res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:109-130, 173-178
-    uint32_t* mine = s_str + threadIdx.x * LSTRIDE;
+  if (active && diff <= d && res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:109-130, 173-178
+    uint32_t* mine = lds + (threadIdx.x & 255) * (2 * NW + 1);
 #pragma unroll
     for (int w = 0; w < NW; ++w) { mine[w] = S[w]; mine[NW + w] = T[w]; }
     ld = res;
     score = score_tail(reinterpret_cast<const uint8_t*>(mine), reinterpret_cast<const uint8_t*>(mine + NW), lq, lc, ld, qm, em,
-                       q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase, keep);
+                       q, e, a, A.ent_freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, lcs, pre, suf, samecase, keep);
   }
-  surv_append(so, keep, q, e, score);
-  if (!active) return;
-  if (!fast) {  // longer strings or d > D: a later kernel scores this pair
-    s_meta[i_sel] = SCORE_DEFER;
-    return;
+  surv_append(so, surv_region, keep, q, e, score);
+  if (active) {
+    A.p_score[p] = score;
+    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
-  s_score[i_sel] = score;
-  s_meta[i_sel] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
 }
 
-__global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, const uint2* __restrict__ raw,
-                              const uint32_t* __restrict__ q_meta, const uint4* __restrict__ q_rows,
-                              const uint32_t* __restrict__ ent_meta, const uint32_t* __restrict__ ent_rowoff,
-                              const uint4* __restrict__ rows, const uint32_t* __restrict__ ent_freq, ScoreArgs a,
-                              const uint32_t* __restrict__ ent_var_off, double* __restrict__ s_score,
-                              uint32_t* __restrict__ s_meta, uint32_t* __restrict__ qmaxfreq,
-                              uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, int only_deferred, SurvOut so) {
+// K2+K3 fused: prefilter of every pair-list slot and register-resident DL of the selected pairs, one block per
+// FS_BLK consecutive slots of a region.  Phase 1 (FS_BLK / 256 rounds): length test |lq - lc| <= d
+// (src/distance.rs:109-130), StopAtExactMatch drop (src/lib.rs:1164-1173) and the SWAR band-match bound; selected
+// pairs of <= 16 symbols with d <= D are queued in LDS, longer ones go to the slot lists of the 8-word / general
+// kernels.  Phase 2: the queue is scored 256 pairs at a time, so the DL lanes are dense although only ~1/3 of the
+// slots survive phase 1 (no global compaction pass, no index list).  D = 0: no inline DL (d > 3), everything selected
+// goes to the general kernel's list.
+constexpr uint32_t FS_BLK = 4096;
+struct FilterArgs {
+  uint32_t region_shift;
+  const uint32_t* rctr;     // region fills of the pair list
+  const uint32_t* qexact;
+  int stop, enable;
+  int use_nw8;              // selected pairs of 17..32 symbols go to list8 (else to the general list)
+  uint32_t* counters;
+  uint32_t* stat_ctr;       // [SCAN_REGIONS][RC_STRIDE], word 1: selected pairs
+};
+template <int D>
+__global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg) {
+  __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
+  __shared__ uint32_t s_n;
+  __shared__ uint32_t s_str[256 * 9];
+  // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
+  // counter word sustains only ~88 M atomics/s)
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * FS_BLK;
+  if (base >= fill) return;  // block-uniform
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t nselected = 0;  // wave-uniform
+  for (uint32_t r = 0; r < FS_BLK / 256; ++r) {
+    const uint32_t idx = base + r * 256 + threadIdx.x;
+    if (base + r * 256 >= fill) break;  // block-uniform
+    const uint32_t p = (region << f.region_shift) + idx;
+    const bool live = idx < fill;
+    bool selected = false, stop_skipped = false, invalid = false;
+    int d = 0, lq = 0, lc = 0;
+    // words that are not loaded keep the row padding (query 0xFE, candidate 0xFF: never equal to anything)
+    uint32_t q8[8] = {0, 0, 0, 0, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
+    uint32_t c10[10] = {0xFFFFFFFFu, 0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    bool filt = false, wide = false;
+    if (live) {
+      const uint2 rp = A.raw[p];
+      const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+      invalid = q == RAW_INVALID;
+      // unused chunk tail, or (StopAtExactMatch) a non-exact class of a query that has an exact one
+      const bool skip = invalid || (f.stop && !(rp.y & 0x80000000u) && f.qexact[q] != 0xFFFFFFFFu);
+      stop_skipped = skip && !invalid;
+      if (!skip) {
+        const uint32_t qm = A.q_meta[q], em = A.ent_meta[e];
+        lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
+        const int diff = lq > lc ? lq - lc : lc - lq;
+        selected = diff <= d;
+        filt = selected && f.enable && d <= 3 && lq <= 32 && lc <= 32;
+        wide = filt && (lq > 16 || lc > 16);
+        if (filt) {
+          const uint4* qr = A.q_rows + (size_t)q * a.qw;
+          const uint4* cr = A.rows + A.ent_rowoff[e];
+          const uint4 Q = qr[0], C = cr[0];
+          q8[0] = Q.x; q8[1] = Q.y; q8[2] = Q.z; q8[3] = Q.w;
+          c10[1] = C.x; c10[2] = C.y; c10[3] = C.z; c10[4] = C.w;
+          if (lq > 16) { const uint4 Q1 = qr[1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
+          if (lc > 16) { const uint4 C1 = cr[1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
+        }
+      }
+    }
+    if (__any(wide)) {  // wave-uniform: some pair of the wave has a string of 17..32 symbols
+      if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
+    } else if (__any(filt)) {
+      const uint32_t q4[4] = {q8[0], q8[1], q8[2], q8[3]}, c6[6] = {0xFFFFFFFFu, c10[1], c10[2], c10[3], c10[4], 0xFFFFFFFFu};
+      if (band_bound_rejects<4>(q4, c6, filt, d, lq, lc)) selected = false;
+    }
+    if (live && !selected)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
+      A.p_meta[p] = (invalid || stop_skipped) ? META_SKIPPED : (PAIR_NONE | (1u << 7));
+    const bool inl = selected && D > 0 && lq <= 16 && lc <= 16 && d <= D;
+    const bool to8 = selected && !inl && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
+    const bool tog = selected && !inl && !to8;
+    const unsigned long long mi = __ballot(inl);
+    if (mi) {  // wave-uniform: queue the inline pairs
+      const int first = __ffsll((long long)mi) - 1;
+      uint32_t qb = 0;
+      if ((int)lane == first) qb = atomicAdd(&s_n, (uint32_t)__popcll(mi));
+      qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
+      if (inl) s_q[qb + (uint32_t)__popcll(mi & ((1ull << lane) - 1ull))] = (uint16_t)(r * 256 + threadIdx.x);
+    }
+    slot_append(list8, region, to8, p);
+    slot_append(listg, region, tog, p);
+    nselected += (uint32_t)__popcll(__ballot(selected));
+    if (f.stop) {  // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops
+      const unsigned long long ms = __ballot(stop_skipped);
+      if (lane == 0 && ms) atomicAdd(&f.counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
+    }
+  }
+  if (lane == 0 && nselected) atomicAdd(&f.stat_ctr[region * RC_STRIDE + 1], nselected);
+  __syncthreads();
+  if (D > 0) {
+    const uint32_t n = s_n;
+    for (uint32_t r0 = 0; r0 < n; r0 += 256) {  // block-uniform trip count
+      const uint32_t i = r0 + threadIdx.x;
+      const bool active = i < n;
+      score_fast_pair<(D > 0 ? D : 1), 4>(active ? (region << f.region_shift) + base + s_q[i] : 0u, active, A, a, so, region, s_str);
+    }
+  }
+}
+
+// the selected pairs with a string of 17..32 symbols (list8 of k_filter_score)
+template <int D>
+__global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
+  __shared__ uint32_t s_str[256 * 17];
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, blk = blockIdx.x / SCAN_REGIONS, i = blk * 256 + threadIdx.x, n = in.ctr[region * RC_STRIDE];
+  if (blk * 256 >= n) return;  // block-uniform
+  const bool active = i < n;
+  score_fast_pair<D, 8>(active ? in.list[(size_t)region * in.region_cap + i] : 0u, active, A, a, so, region, s_str);
+}
+
+__global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
   extern __shared__ uint32_t lds32[];
-  const uint32_t i_sel = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint2* __restrict__ raw = A.raw;
+  const uint32_t* __restrict__ q_meta = A.q_meta;
+  const uint4* __restrict__ q_rows = A.q_rows;
+  const uint32_t* __restrict__ ent_meta = A.ent_meta;
+  const uint32_t* __restrict__ ent_rowoff = A.ent_rowoff;
+  const uint4* __restrict__ rows = A.rows;
+  const uint32_t* __restrict__ ent_freq = A.ent_freq;
+  const uint32_t* __restrict__ ent_var_off = A.ent_var_off;
+  uint32_t* __restrict__ qmaxfreq = A.qmaxfreq;
+  uint32_t* __restrict__ qsurv = A.qsurv;
+  uint32_t* __restrict__ qexpand = A.qexpand;
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, blk = blockIdx.x / SCAN_REGIONS, i_sel = blk * blockDim.x + threadIdx.x, nsel = in.ctr[region * RC_STRIDE];
+  if (blk * blockDim.x >= nsel) return;  // block-uniform
   bool keep = false;
   uint32_t kq = 0, ke = 0;
   double kscore = 0.0;
-  if (i_sel < nsel && (!only_deferred || s_meta[i_sel] == SCORE_DEFER)) {
-    const uint32_t p = sel[i_sel];
+  if (i_sel < nsel) {
+    const uint32_t p = in.list[(size_t)region * in.region_cap + i_sel];
     const uint2 rp = raw[p];
     const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
     uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
@@ -1052,10 +1104,10 @@ __global__ void k_score_pairs(uint32_t nsel, const uint32_t* __restrict__ sel, c
         }
       }
     }
-    s_score[i_sel] = score;  // dense, in selection order (coalesced)
-    s_meta[i_sel] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+    A.p_score[p] = score;
+    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
-  surv_append(so, keep, kq, ke, kscore);
+  surv_append(so, region, keep, kq, ke, kscore);
 }
 
 // K3b: gather the survivors (score >= threshold) into per-query segments of result rows.  With variant lists a
@@ -1072,9 +1124,9 @@ __global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ sur
                                                  const uint32_t* __restrict__ var_target,
                                                  const uint32_t* __restrict__ var_target_freq,
                                                  const double* __restrict__ var_score, SurvRow* __restrict__ c_rows) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // grid: (blocks of the fullest region) x (regions)
-  if (i >= sctr[blockIdx.y * RC_STRIDE]) return;
-  const SurvRec sr = surv[(size_t)blockIdx.y * region_cap + i];
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, i = (blockIdx.x / SCAN_REGIONS) * 256 + threadIdx.x;  // 1-D grid, region fastest
+  if (i >= sctr[region * RC_STRIDE]) return;
+  const SurvRec sr = surv[(size_t)region * region_cap + i];
   const double s = sr.score;
   const uint32_t e = sr.e, q = sr.q;
   const EntRec er = ent_rec[e];
@@ -1896,7 +1948,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   }
   lap("uploads");
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->lctr, 2 * SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
@@ -1949,13 +2001,11 @@ static int ensure_raw(Batch* b, size_t slots_per_region, std::string& err) {
   if (shift > 25) { err = "pair list exceeds 2^31 slots: split the batch"; return ANX_ELIMIT; }
   const size_t cap = (size_t)SCAN_REGIONS << shift;
   if (cap <= b->raw_cap) return ANX_OK;
-  for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount})
+  for (void* p : {(void*)b->raw, (void*)b->p_score, (void*)b->p_meta})
     if (p) pool_free(p);
-  b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->s_meta = nullptr; b->sel = nullptr; b->blockcount = nullptr; b->raw_cap = 0;
+  b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->raw_cap = 0;
   int rc;
-  const size_t nblk = cap / 256 + 2;
-  if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err)) ||
-      (rc = dalloc(&b->s_meta, cap, err)) || (rc = dalloc(&b->sel, cap, err)) || (rc = dalloc(&b->blockcount, 2 * nblk + nblk / SCAN_TILE + 16, err))) return rc;
+  if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err))) return rc;
   b->raw_cap = cap;
   b->region_shift = shift;
   return ANX_OK;
@@ -2063,58 +2113,60 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   uint32_t threads = 256;
   while (threads > 64 && (size_t)threads * sa.stride > 64 * 1024) threads >>= 1;
   if ((size_t)threads * sa.stride > 64 * 1024) { err = "per-lane scoring state exceeds the LDS budget"; return ANX_ELIMIT; }
-  // prefilter + selection (ANX_PREFILTER=0 disables the filter: every length-compatible pair goes to the DP)
-  uint32_t nsel = 0;
+  // fused prefilter + register DL (ANX_PREFILTER=0 disables the filter: every length-compatible pair goes to the DL)
+  SurvOut so{nullptr, b->sctr, 0};
+  const bool have_long_q = b->qw > 1;
   if (nraw) {
     static const int enable_filter = []() { const char* e = getenv("ANX_PREFILTER"); return (e && e[0] == '0') ? 0 : 1; }();
-    const uint32_t gx = (maxfill + 255) / 256, nblk = gx * SCAN_REGIONS;
-    uint32_t* blockoff = b->blockcount + nblk + 1;
-    uint32_t* tmp = blockoff + nblk + 1;
-    hipLaunchKernelGGL(k_prefilter, dim3(gx, SCAN_REGIONS), dim3(256), 0, st, b->region_shift, b->rctr, b->raw, b->qexact, stop, enable_filter, b->q_meta,
-                       b->q_rows, b->qw, dl->ent_meta, dl->ent_rowoff, dl->rows, b->p_meta, b->blockcount, b->counters);
-    exclusive_scan(b->blockcount, nblk, blockoff, tmp, st);
-    HIP_TRY(hipMemcpyAsync(&nsel, blockoff + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_select, dim3(gx, SCAN_REGIONS), dim3(256), 0, st, b->region_shift, b->rctr, b->p_meta, blockoff, b->sel);
-    HIP_TRY(hipStreamSynchronize(st));
-  }
-  b->n_sel = nsel;
-  SurvOut so{nullptr, b->sctr, 0};
-  if (nsel) {
-    // survivor records: region r takes the survivors of blocks r, r + 64, ... of either score kernel; a block scores <= 256 pairs
-    const size_t need = 2 * ((((size_t)nsel + 255) / 256 + SCAN_REGIONS - 1) / SCAN_REGIONS + 1) * 256;
-    if (need > b->surv_region_cap) {
+    static const int enable_fast = []() { const char* e = getenv("ANX_SCORE_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int fastD = (enable_fast && d >= 1 && d <= 3) ? (int)d : 0;
+    // survivor records: region r of the survivor list takes the survivors of region r of the pair list (<= maxfill)
+    if ((size_t)maxfill > b->surv_region_cap) {
       if (b->surv) pool_free(b->surv);
       b->surv = nullptr;
       b->surv_region_cap = 0;
+      const size_t need = (size_t)maxfill + (maxfill >> 3) + 256;
       if ((rc = dalloc(&b->surv, need * SCAN_REGIONS, err))) return rc;
       b->surv_region_cap = need;
     }
     so.list = b->surv;
     so.region_cap = (uint32_t)b->surv_region_cap;
-    HIP_TRY(hipMemsetAsync(b->sctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
-    // register-resident fast path for pairs of <= 16 symbols with d <= 3; the general kernel takes the rest
-    static const int enable_fast = []() { const char* e = getenv("ANX_SCORE_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
-    const int fastD = (enable_fast && d >= 1 && d <= 3) ? (int)d : 0;
-    const dim3 fgrid((nsel + 255) / 256);
-#define ANX_FAST_ARGS nsel, b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa, \
-                      dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand, so
-    if (fastD == 1) hipLaunchKernelGGL((k_score_fast<1, 4>), fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
-    else if (fastD == 2) hipLaunchKernelGGL((k_score_fast<2, 4>), fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
-    else if (fastD == 3) hipLaunchKernelGGL((k_score_fast<3, 4>), fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
-    // pairs with a string of 17..32 symbols: the 8-word variant over the deferred pairs -- when the batch has queries
-    // of that length; if only candidates can be longer (<= 16 + d symbols) the deferred pairs are few and the general
-    // kernel is cheaper (measured on config 2: 0.10 vs 0.22 ms)
-    const bool have_long = b->qw > 1;
-    if (have_long) {
-      if (fastD == 1) hipLaunchKernelGGL((k_score_fast<1, 8>), fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
-      else if (fastD == 2) hipLaunchKernelGGL((k_score_fast<2, 8>), fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
-      else if (fastD == 3) hipLaunchKernelGGL((k_score_fast<3, 8>), fgrid, dim3(256), 0, st, ANX_FAST_ARGS);
+    // slot lists for the pairs the fused kernel cannot score inline: strings of 17..32 symbols (8-word kernel, when the
+    // batch has such queries) and everything else (longer strings, d > 3, or the few long candidates of a short-query
+    // batch: for those the general kernel is cheaper than the 8-word one, measured 0.10 vs 0.22 ms on config 2)
+    const bool need_lists = !fastD || have_long_q || dl->max_len > 16;
+    if (need_lists && (size_t)maxfill > b->list_cap) {
+      for (void* p : {(void*)b->list8, (void*)b->listg})
+        if (p) pool_free(p);
+      b->list8 = b->listg = nullptr;
+      b->list_cap = 0;
+      const size_t need = (size_t)maxfill + (maxfill >> 3) + 256;
+      if ((rc = dalloc(&b->list8, need * SCAN_REGIONS, err)) || (rc = dalloc(&b->listg, need * SCAN_REGIONS, err))) return rc;
+      b->list_cap = need;
     }
-#undef ANX_FAST_ARGS
-    if (!fastD || b->qw > 2 || dl->max_len > 32 || (!have_long && dl->max_len > 16))
-      hipLaunchKernelGGL(k_score_pairs, dim3((nsel + threads - 1) / threads), dim3(threads), threads * sa.stride, st, nsel,
-                         b->sel, b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, sa,
-                         dl->ent_var_off, b->p_score, b->s_meta, b->qmaxfreq, b->qsurv, b->qexpand, fastD ? 1 : 0, so);
+    HIP_TRY(hipMemsetAsync(b->sctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(b->lctr, 0, 2 * SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
+    const SlotList l8{b->list8, b->lctr, (uint32_t)b->list_cap}, lg{b->listg, b->lctr + SCAN_REGIONS * RC_STRIDE, (uint32_t)b->list_cap};
+    const PairArgs pa{b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, dl->ent_var_off,
+                      b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand};
+    FilterArgs fa;
+    fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
+    fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr;
+    const dim3 fgrid(((maxfill + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
+    if (fastD == 1) hipLaunchKernelGGL(k_filter_score<1>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
+    else if (fastD == 2) hipLaunchKernelGGL(k_filter_score<2>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
+    else if (fastD == 3) hipLaunchKernelGGL(k_filter_score<3>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
+    else hipLaunchKernelGGL(k_filter_score<0>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
+    if (need_lists) {  // the list fills are only known on the device: grids cover the fullest pair-list region
+      const dim3 lgrid(((maxfill + 255) / 256) * SCAN_REGIONS);
+      if (fastD && have_long_q) {
+        if (fastD == 1) hipLaunchKernelGGL(k_score_fast8<1>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
+        else if (fastD == 2) hipLaunchKernelGGL(k_score_fast8<2>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
+        else hipLaunchKernelGGL(k_score_fast8<3>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
+      }
+      hipLaunchKernelGGL(k_score_pairs, dim3(((maxfill + threads - 1) / threads) * SCAN_REGIONS), dim3(threads), threads * sa.stride, st,
+                         lg, pa, sa, so);
+    }
   }
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors -----------------------------------------------------------------------------
@@ -2122,18 +2174,23 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   uint32_t total_surv = 0;
   HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
-  if (nsel) HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->sctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (nraw) HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->sctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   b->n_pairs = n_valid - h_counters[CTR_SKIPPED];
   b->n_surv = total_surv;
   if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
   uint32_t surv_fill = 0;
-  if (nsel)
-    for (uint32_t r = 0; r < SCAN_REGIONS; ++r) surv_fill = std::max(surv_fill, h_rctr[r * RC_STRIDE]);
+  uint64_t nsel = 0;
+  if (nraw)
+    for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
+      surv_fill = std::max(surv_fill, h_rctr[r * RC_STRIDE]);
+      nsel += h_rctr[r * RC_STRIDE + 1];
+    }
+  b->n_sel = nsel;
   if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
   if (surv_fill) {
     CompactArgs ca{m.have_freq ? 1 : 0, dl->any_variants};
-    hipLaunchKernelGGL(k_compact, dim3((surv_fill + 255) / 256, SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
+    hipLaunchKernelGGL(k_compact, dim3(((surv_fill + 255) / 256) * SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
                        (uint32_t)b->surv_region_cap, ca, b->soff, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
                        dl->var_target_freq, dl->var_score, b->c_rows);
   }
@@ -2164,7 +2221,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   for (int i = 0; i <= NBITPLANES; ++i) s.n_tests_kind[i] = b->n_tests_kind[i];
   s.n_pair_slots = n_slots;
   s.n_survivors = total_surv;
-  s.n_selected = nsel;
+  s.n_selected = b->n_sel;
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.ms_score, b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&s.ms_group, b->ev[2], b->ev[3]);
@@ -2222,20 +2279,13 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
   if (!res) { err = "out of memory"; return ANX_EINVAL; }
   size_t w = 0;
   if (R) {
-    const size_t S = b->n_sel;
     std::vector<uint2> pr(R);
-    std::vector<uint32_t> pm(R), ev(dl->nentries), sm(std::max<size_t>(S, 1)), sl(std::max<size_t>(S, 1));
-    std::vector<double> ps(std::max<size_t>(S, 1));
+    std::vector<uint32_t> pm(R), ev(dl->nentries);
+    std::vector<double> ps(R);
     HIP_TRY(hipMemcpy(pr.data(), b->raw, R * sizeof(uint2), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pm.data(), b->p_meta, R * 4, hipMemcpyDeviceToHost));
-    if (S) {
-      HIP_TRY(hipMemcpy(ps.data(), b->p_score, S * 8, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(sm.data(), b->s_meta, S * 4, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(sl.data(), b->sel, S * 4, hipMemcpyDeviceToHost));
-    }
+    HIP_TRY(hipMemcpy(ps.data(), b->p_score, R * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ev.data(), dl->ent_vocab, (size_t)dl->nentries * 4, hipMemcpyDeviceToHost));
-    std::vector<double> score_of(R, 0.0);
-    for (size_t i = 0; i < S; ++i) { pm[sl[i]] = sm[i]; score_of[sl[i]] = ps[i]; }  // selected slots: DP results
     for (size_t i = 0; i < R; ++i) {
       if ((i & (((size_t)1 << b->region_shift) - 1)) >= b->region_fill[i >> b->region_shift]) continue;  // beyond the region's fill
       if (pm[i] == META_SKIPPED || w >= b->n_pairs) continue;
@@ -2249,7 +2299,7 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
       r.prefixlen = (pm[i] >> 16) & 0xFF;
       r.suffixlen = (pm[i] >> 24) & 0xFF;
       r._pad = 0;
-      r.score = ld == PAIR_NONE ? 0.0 : score_of[i];
+      r.score = ld == PAIR_NONE ? 0.0 : ps[i];
     }
   }
   *out = res;
@@ -2279,7 +2329,7 @@ void batch_free(Batch* b) {
   (void)hipSetDevice(b->device);
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
-                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->s_meta, (void*)b->sel, (void*)b->blockcount,
+                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) pool_free(p);
   for (auto& e : b->ev)
