@@ -306,3 +306,26 @@ def test_large_synthetic_lexicon_long_strings(data_dir, tmp_path):
     compare_batch(g, o, qs, gp, op)
     gp, op = params_pair(("ratio", 0.2), ("ratio", 0.15), 5, 0.3, 0.0)
     compare_batch(g, o, qs[:120], gp, op)
+
+
+def test_very_long_strings(data_dir, tmp_path):
+    """Strings of 20-70 symbols (compounds of lexicon words): pairs beyond the 32-symbol register kernels take the
+    general k_score_pairs through the slot list; mixed with short words so that every scoring kernel sees work."""
+    rng = random.Random(17)
+    words = [w for w in synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon")) if w.isascii() and w.isalpha()][::29]
+    lex = sorted({"".join(rng.choice(words) for _ in range(rng.randrange(2, 7))) for _ in range(4000)} | set(words[:1500]))
+    f = tmp_path / "long.lexicon"
+    f.write_text("\n".join(lex) + "\n", encoding="utf-8")
+    alphabet = os.path.join(data_dir, "simple.alphabet.tsv")
+    g = A.VariantModel(alphabet, A.Weights(), device=0)
+    g.read_lexicon(str(f))
+    g.build()
+    o = O.OracleModel(alphabet_path=alphabet)
+    o.read_lexicon(str(f))
+    o.build()
+    qs = synth.make_queries(lex, 400, max_len=80, min_len=1, seed=23)
+    assert max(len(q) for q in qs) > 40
+    for kw in (dict(k=("abs", 3), d=("abs", 3), n=10), dict(k=("abs", 4), d=("abs", 5), n=5, thr=0.2, cutoff=1.5),
+               dict(k=("ratio", 0.1), d=("ratio", 0.1), n=20, thr=0.0, cutoff=0.0)):
+        gp, op = params_pair(**kw)
+        compare_batch(g, o, qs, gp, op)
