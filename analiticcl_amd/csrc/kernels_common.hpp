@@ -1,0 +1,133 @@
+// kernels_common.hpp -- device-side structures shared by the kernels and the host driver (tiles, batch state, row records)
+// Part of the single translation unit engine.hip (included inside namespace anx); gfx950 only.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Device structures
+// ------------------------------------------------------------------------------------------------
+struct Tile {           // <= SCAN_TQ queries of one scan kind, one length and one signature
+  uint32_t q0, nq;      // query range (queries are sorted by (scan kind, length, signature))
+  uint32_t s0, s1;      // signature range [s0, s1) of the +-k charcount window
+  uint32_t k;           // clamped anagram distance for this length
+  uint32_t lq;          // query length in symbols
+  uint32_t sig_lo, sig_hi;  // the tile's signature (per-group symbol counts, one byte each)
+  uint32_t kind;        // 0 = SAD body, 1..NBITPLANES = bit-plane body with T = kind
+};
+
+constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
+constexpr uint32_t SCAN_TQ = 64;         // queries per tile (= per wave), compared in passes of 32 (one hit-mask bit each)
+constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
+constexpr uint32_t SCAN_REGIONS = 64;     // pair-list regions with one reservation counter each
+constexpr uint32_t RC_STRIDE = 32;        // uint32 words per region counter block (128 B)
+constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t META_SKIPPED = 0xFFFFFFFFu;
+
+struct EntRec {   // per-entry attributes k_compact needs, one 16-B gather
+  uint32_t vocab, freq, order, meta;
+};
+
+struct DeviceLexicon {
+  int device = 0;
+  int nplanes = 0;      // count-vector dwords (SAD path)
+  int nsym = 0;
+  uint32_t nclasses = 0, nentries = 0, cstride = 0, max_len = 0;
+  uint32_t* cls_planes = nullptr;  // [nplanes][cstride] packed u8 counts
+  uint32_t* cls_bits = nullptr;    // [NBITPLANES][cstride] thermometer planes (bit s of plane t: count_s > t), nsym <= 32
+  uint8_t* cls_len = nullptr;      // [cstride]
+  uint32_t* cls_off = nullptr;
+  uint2* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage), lo/hi interleaved
+  uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
+  uint32_t* ent_vocab = nullptr;
+  uint32_t* ent_freq = nullptr;
+  uint32_t* ent_meta = nullptr;
+  uint32_t* ent_rowoff = nullptr;
+  uint32_t* ent_order = nullptr;
+  EntRec* ent_rec = nullptr;           // {vocab, freq, order, meta} per entry
+  uint32_t* ent_var_off = nullptr;     // CSR entry -> VariantOf references (variant lists, src/lib.rs:1677-1727)
+  uint32_t* var_target = nullptr;      // vocab id of the reference item
+  uint32_t* var_target_freq = nullptr;
+  double* var_score = nullptr;
+  int any_variants = 0;
+  uint4* rows = nullptr;
+  size_t bytes = 0;
+};
+
+enum { CTR_SKIPPED = 2, CTR_N = 8 };
+
+struct SurvRow {  // one candidate result row of a query (k_compact -> k_rank); 32 B, written / read as two 16-B words
+  double score;            // dist_score (times the variant score for expanded rows)
+  unsigned long long ord;  // enumeration-order key: ent_order << 20 | position inside the expansion
+  uint32_t vocab, freq;    // vocab id, absolute frequency of the row
+  uint32_t via, pad;       // vocab id of the variant the row was reached through, 0xFFFFFFFF = none
+};
+struct SurvRec {   // one scored pair that passed the score threshold (k_score_* -> k_compact), appended per wave
+  uint32_t q, e;
+  double score;
+};
+struct DevRow {   // one ranked result row (device) for download / gather
+  uint32_t vocab_id, via;
+  double dist_score, freq_score;
+};
+
+struct Batch {
+  int device = 0;
+  size_t nq = 0;            // encoded queries
+  anx_params params;
+  // host side
+  std::vector<uint32_t> order;     // sorted position -> original index
+  std::vector<int32_t> status;     // per original query: 0 ok, ANX_EEMPTY, ANX_ELIMIT
+  size_t n_input = 0;
+  std::vector<Tile> tiles;         // in launch order: bit-plane kinds, then the SAD kind; each by decreasing cost
+  uint32_t n_sad_tiles = 0;
+  uint32_t qw = 1;                 // uint4 words per query row
+  uint32_t dmax = 0;
+  uint64_t n_class_tests = 0;
+  uint64_t n_tests_kind[NBITPLANES + 1] = {};
+  // device: queries
+  uint32_t* q_cv = nullptr;        // [nq][nplanes]
+  uint32_t* q_bits = nullptr;      // [nq][NBITPLANES]
+  uint4* q_rows = nullptr;         // [nq][qw]
+  uint32_t* q_meta = nullptr;      // len | k<<8 | d<<16 | first_is_lower<<24
+  uint32_t* q_orig = nullptr;      // original index
+  Tile* d_tiles = nullptr;
+  // device: pipeline
+  uint32_t* counters = nullptr;
+  uint32_t* rctr = nullptr;        // [SCAN_REGIONS][RC_STRIDE] per-region reservation / statistics counters
+  uint32_t region_shift = 0;       // log2(slots per region); raw_cap = SCAN_REGIONS << region_shift
+  uint32_t region_fill[SCAN_REGIONS] = {};  // host copy of rctr[r][RC_RAW] after the last run
+  uint32_t* qexact = nullptr;      // per query: its exact-anagram class, 0xFFFFFFFF = none (StopAtExactMatch; host lookup)
+  uint32_t* qsurv = nullptr;       // per query: pairs with score >= threshold
+  uint32_t* soff = nullptr;        // nq+1, exclusive scan of qsurv
+  uint32_t* qcur = nullptr;
+  uint32_t* qmaxfreq = nullptr;
+  uint32_t* scan_tmp = nullptr;
+  uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
+  double* p_score = nullptr;       // per pair-list slot: score of the pairs that went through a DL kernel
+  uint32_t* p_meta = nullptr;      // per pair-list slot: skipped / rejected / ld | samecase<<7 | lcs<<8 | prefix<<16 | suffix<<24
+  uint32_t* list8 = nullptr;       // slot lists of the selected pairs the fused kernel leaves to k_score_fast8 / k_score_pairs
+  uint32_t* listg = nullptr;
+  uint32_t* lctr = nullptr;        // [2][SCAN_REGIONS][RC_STRIDE] their fills
+  size_t list_cap = 0;             // slots per region in list8 / listg
+  size_t raw_cap = 0;
+  double* quot = nullptr;          // table of IEEE quotients x / L (ScoreArgs::quot)
+  SurvRec* surv = nullptr;         // survivor records in SCAN_REGIONS regions of surv_region_cap (order arbitrary)
+  uint32_t* sctr = nullptr;        // [SCAN_REGIONS][RC_STRIDE] fill of every survivor region
+  size_t surv_region_cap = 0;
+  SurvRow* c_rows = nullptr;       // candidate result rows grouped by query (survivors, expanded by variant lists)
+  uint32_t* qexpand = nullptr;     // per query: some DL survivor has variant references (has_expandable_variants)
+  DevRow* r_rows = nullptr;        // ranked rows, per query at soff[q] .. soff[q] + r_count[q]
+  double* t_key = nullptr;
+  size_t surv_cap = 0;
+  uint32_t* r_count = nullptr;
+  uint32_t* r_off = nullptr;       // nq+1
+  uint32_t n_raw = 0;
+  uint64_t n_sel = 0;
+  uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
+  bool ran = false;
+  hipEvent_t ev[6] = {};
+  hipEvent_t ev_scan0 = nullptr;   // just before the scan kernels (after the counter memsets)
+  anx_batch_stats stats = {};
+};
+
+typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant address space: s_load
+

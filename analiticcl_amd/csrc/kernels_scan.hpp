@@ -1,0 +1,298 @@
+// kernels_scan.hpp -- K1: signature-pruned anagram scan (k_scan_bits / k_scan_sad)
+// Part of the single translation unit engine.hip (included inside namespace anx); gfx950 only.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// K1: signature-pruned anagram scan.
+//   Spec: the set returned by find_nearest_anahashes (src/lib.rs:1143-1308) equals
+//     { class c : L1(cv_q, cv_c) <= k, |len_c - len_q| <= k, cv_q and cv_c share a symbol }
+//   (the bigint `cand % av == 0` containment test of src/anahash.rs:165-171 is
+//   multiset inclusion, i.e. a statement about the prime-exponent = count vectors).
+//   Pruning: sig(x) = per-group sums of the count vector (LexiconImage::sym_group); summing is a contraction of
+//   L1, so L1(sig_q, sig_c) > k excludes c.  Queries are sorted by (kind, length, signature) and a tile holds
+//   <= 32 queries of ONE signature; classes are stored in (charcount, signature) order, one run per signature.
+//   One WAVE owns one tile: it tests the tile's signature against the signature table of the +-k charcount
+//   window (64 signatures per step, 2 v_sad_u8 each), copies the class ids of the compatible runs to an LDS stage
+//   and, whenever 64*CPL classes are staged, compares them (lane = class, gathered planes in registers) with
+//   every query of the tile (query planes broadcast from LDS).  On eng.aspell k<=3 this leaves 4.6 k of the
+//   68 k class tests per query that the plain charcount window needs.
+//   The query loop is branch-free: every lane keeps one hit bit per (class, query) in registers; after the loop
+//   the hits of the chunk (1-2 % of the remaining tests) are expanded through the class -> entries CSR into
+//   wave-private 256-slot chunks of the pair list.  The pair list is split into SCAN_REGIONS regions with one
+//   reservation counter each (128 B apart): a single contended counter word sustains only ~88 M atomics/s, which
+//   at ~1.5 ms per million queries would be the bottleneck.
+// ------------------------------------------------------------------------------------------------
+enum { RC_RAW = 0, RC_VALID = 1, RC_TESTS = 4 /* u64 per scan kind at 4 + 2*kind */ };
+
+struct WaveOut {
+  uint32_t base, left;  // unused part of the current chunk of the pair list (wave-uniform)
+  uint32_t emitted;     // pairs appended by this wave (wave-uniform)
+  uint32_t nbase;       // chunk reserved by the last wave_reserve when the appended run spills over
+  uint32_t split;       // run indices < split go to [base..), the rest to [nbase..)
+  uint32_t rbase, rend; // this wave's region of the pair list: slots [rbase, rend)
+  uint32_t* ctr;        // the region's counter block
+};
+// Wave-wide exclusive prefix sum of ntot + chunk reservation.  Returns this lane's first index g in the
+// wave's appended run; wave_slot(g) maps run indices to pair-list slots.  A run that does not fit in the
+// rest of the current chunk fills it up and continues in a freshly reserved chunk (ONE atomic).
+__device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane, uint32_t* total_out) {
+  uint32_t incl = ntot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(incl, o);
+    if (lane >= (uint32_t)o) incl += u;
+  }
+  const uint32_t total = __shfl(incl, 63);
+  *total_out = total;
+  w.split = w.left;
+  if (total > w.left) {
+    const uint32_t rest = total - w.left;
+    const uint32_t need = rest > SCAN_CHUNK ? rest : SCAN_CHUNK;
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(&w.ctr[RC_RAW], need);
+    w.nbase = w.rbase + __shfl(b, 0);
+  }
+  return incl - ntot;
+}
+__device__ inline uint32_t wave_slot(const WaveOut& w, uint32_t g) {
+  return g < w.split ? w.base + g : w.nbase + (g - w.split);
+}
+__device__ inline void wave_commit(WaveOut& w, uint32_t total) {
+  if (total > w.left) {
+    const uint32_t rest = total - w.left;
+    const uint32_t need = rest > SCAN_CHUNK ? rest : SCAN_CHUNK;
+    w.base = w.nbase + rest;
+    w.left = need - rest;
+  } else {
+    w.base += total;
+    w.left -= total;
+  }
+  w.emitted += total;
+}
+__device__ inline void wave_close(const WaveOut& w, uint32_t lane, uint2* __restrict__ raw) {
+  for (uint32_t i = lane; i < w.left; i += 64)
+    if (w.base + i < w.rend) raw[w.base + i] = make_uint2(RAW_INVALID, 0u);
+  if (lane == 0 && w.emitted) atomicAdd(&w.ctr[RC_VALID], w.emitted);  // one atomic per wave
+}
+
+struct ScanArgs {
+  const Tile* tiles;
+  uint32_t ntiles;
+  const uint32_t* q_bits;
+  const uint32_t* q_cv;
+  const uint32_t* cls_bits;
+  const uint32_t* cls_planes;
+  uint32_t cstride;
+  uint32_t pad_class;   // a never-matching padding class (bits 0, counts 0xFF, len 255)
+  const uint8_t* cls_len;
+  const uint32_t* cls_off;
+  const uint2* sig;         // signature table: (groups 0-3, groups 4-7) packed as bytes
+  const uint32_t* sig_cbeg;
+  uint2* raw;
+  uint32_t region_cap;  // pair-list slots per region
+  uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
+  const uint32_t* qexact;  // per query: class id of its exact anagram class (0xFFFFFFFF = none); stop mode only
+  int want_exact;
+  int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
+};
+
+__device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount(x) in one v_bcnt_u32_b32
+  int32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
+// T >= 1: thermometer bit planes.  common(q,c) = sum_t popc(Q_t & C_t) is exact when every symbol of the query
+//   occurs at most T times (min(a,b) only needs a's planes; class planes saturate at NBITPLANES).
+//   L1 = len_q + len_c - 2 common, so  hit <=> common >= max(1, ceil((len_q + len_c - k) / 2))   (>= 1: the
+//   classes share a symbol, src/iterators.rs:177).  2 ops per plane: v_and_b32 + accumulating v_bcnt_u32_b32.
+// T == 0: general path (any alphabet size / multiplicity): packed u8 count vectors, NP x v_sad_u8;
+//   hit <=> L1 <= k and L1 < len_q + len_c.
+template <int T, int NP>
+__device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage,
+                                 uint32_t* __restrict__ qlds) {
+  constexpr bool BITS = T > 0;
+  constexpr int CPL = BITS ? 4 : (NP <= 8 ? 4 : NP <= 16 ? 2 : 1);  // classes per lane
+  constexpr int W = BITS ? T : NP;                                   // dwords compared per class
+  constexpr int QSTRIDE = BITS ? NBITPLANES : NP;
+  constexpr uint32_t CHUNK = 64u * CPL;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t* __restrict__ cls_words = BITS ? A.cls_bits : A.cls_planes;
+  const uint8_t* __restrict__ cls_len = A.cls_len;
+  const uint32_t* __restrict__ cls_off = A.cls_off;
+  uint2* __restrict__ raw = A.raw;
+  const uint32_t cstride = A.cstride;
+  const uint32_t region = item % SCAN_REGIONS;
+  WaveOut wo{0, 0, 0, 0, 0, region * A.region_cap, (region + 1) * A.region_cap, A.rctr + region * RC_STRIDE};
+  uint32_t ns = 0;  // staged class ids (wave-uniform)
+  uint32_t nchunks = 0;
+  {  // the tile's query words -> LDS: the comparison loop reads them back as broadcasts into VGPRs
+    const uint32_t* __restrict__ src = (BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE;
+    for (uint32_t i = lane; i < t.nq * QSTRIDE; i += 64) qlds[i] = src[i];
+  }
+
+  // compares the first CHUNK staged classes (padded with the never-matching class) with every query of the tile, 32
+  // queries per pass; bit (npass-1-qi) of hm[j] = query qi of the pass hits class j of this lane.  The query loop is
+  // branch-free: 2 ops per plane + ONE v_alignbit_b32 per test (it shifts the sign bit of acc = "miss" into the mask).
+  auto process = [&]() {
+    ++nchunks;
+    if (A.dbg & 2) return;
+    uint32_t cid[CPL], cw[CPL][W];
+    int32_t thr[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const uint32_t idx = (uint32_t)j * 64u + lane;
+      cid[j] = idx < ns ? stage[idx] : A.pad_class;
+#pragma unroll
+      for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
+      const int32_t lc = (int32_t)cls_len[cid[j]];
+      if (BITS) {
+        const int32_t need = ((int32_t)t.lq - (int32_t)t.k + lc + 1) >> 1;  // ceil((lq + lc - k) / 2)
+        thr[j] = -(need < 1 ? 1 : need);
+      } else {
+        const int32_t share = (int32_t)t.lq + lc - 1;  // L1 < lq + lc: shares a symbol (src/iterators.rs:177, src/lib.rs:1205)
+        thr[j] = share < (int32_t)t.k ? share : (int32_t)t.k;
+      }
+    }
+    for (uint32_t qb = 0; qb < t.nq; qb += 32) {
+      const uint32_t npass = (A.dbg & 1) ? 1u : (t.nq - qb < 32u ? t.nq - qb : 32u);
+      uint32_t hm[CPL];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) hm[j] = 0xFFFFFFFFu;  // miss bits
+      for (uint32_t qi = 0; qi < npass; ++qi) {
+        uint32_t qreg[W];
+#pragma unroll
+        for (int p = 0; p < W; ++p) qreg[p] = qlds[(qb + qi) * QSTRIDE + p];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          int32_t acc;
+          if (BITS) {
+            acc = thr[j];  // common - threshold: negative = miss
+#pragma unroll
+            for (int p = 0; p < W; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
+          } else {
+            uint32_t sad = 0;
+#pragma unroll
+            for (int p = 0; p < W; ++p) sad = __builtin_amdgcn_sad_u8(qreg[p], cw[j][p], sad);
+            acc = thr[j] - (int32_t)sad;  // threshold - L1: negative = miss
+          }
+          hm[j] = __builtin_amdgcn_alignbit(hm[j], (uint32_t)acc, 31);  // (hm << 1) | sign(acc)
+        }
+      }
+      // expand the hits of this pass into (query, entry) pairs
+      const uint32_t valid = npass >= 32u ? 0xFFFFFFFFu : ((1u << npass) - 1u);
+      uint32_t any = 0;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        hm[j] = ~hm[j] & valid;
+        any |= hm[j];
+      }
+      if (__ballot(any != 0) == 0ull) continue;  // wave-uniform
+      uint32_t e0[CPL], ne[CPL], cnt = 0;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        e0[j] = 0;
+        ne[j] = 0;
+        if (hm[j]) {
+          e0[j] = cls_off[cid[j]];
+          ne[j] = cls_off[cid[j] + 1] - e0[j];
+          cnt += (uint32_t)__popc(hm[j]) * ne[j];
+        }
+      }
+      uint32_t total;
+      uint32_t g = wave_reserve(wo, cnt, lane, &total);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        uint32_t m = hm[j];
+        while (m) {
+          const uint32_t bit = 31u - (uint32_t)__clz((int)m);
+          m &= ~(1u << bit);
+          const uint32_t q = t.q0 + qb + (npass - 1u - bit);
+          // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
+          const uint32_t exact = (A.want_exact && A.qexact[q] == cid[j]) ? 0x80000000u : 0u;
+          for (uint32_t i = 0; i < ne[j]; ++i, ++g) {
+            const uint32_t pos = wave_slot(wo, g);
+            if (pos < wo.rend) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
+          }
+        }
+      }
+      wave_commit(wo, total);
+    }
+  };
+
+  // No bounds test on s: signatures outside [s0, s1) belong to other charcounts, so their L1 distance to the tile's
+  // signature is at least the length difference > k, and the table is padded with never-matching entries.
+  const uint2* __restrict__ sigp = A.sig + t.s0 + lane;
+  for (uint32_t sb = t.s0; sb < t.s1; sb += 64, sigp += 64) {
+    const uint32_t s = sb + lane;
+    const uint2 sg = *sigp;
+    const bool ok = __builtin_amdgcn_sad_u8(sg.x, t.sig_lo, __builtin_amdgcn_sad_u8(sg.y, t.sig_hi, 0u)) <= t.k;
+    unsigned long long m = __ballot(ok);
+    if (!m || (A.dbg & 4)) continue;
+    uint32_t cb = 0, n = 0;
+    if (ok) {
+      cb = A.sig_cbeg[s];
+      n = A.sig_cbeg[s + 1] - cb;
+    }
+    while (m) {  // scalar loop over the compatible signatures of this step
+      const int i = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      uint32_t cbi = (uint32_t)__builtin_amdgcn_readlane((int)cb, i), ni = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
+      while (ni) {
+        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 128 ids
+        stage[ns + lane] = cbi + lane;              // all 64 lanes write; only the first `take` ids count
+        ns += take;
+        cbi += take;
+        ni -= take;
+        if (ns >= CHUNK) {
+          process();
+          const uint32_t rem = ns - CHUNK;
+          uint32_t v = 0;
+          if (lane < rem) v = stage[CHUNK + lane];
+          if (lane < rem) stage[lane] = v;
+          ns = rem;
+        }
+      }
+    }
+  }
+  if (ns) process();
+  wave_close(wo, lane, raw);
+  if (lane == 0 && nchunks)
+    atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * T), (unsigned long long)nchunks * CHUNK * t.nq);
+}
+
+// Every wave takes one tile; tiles are ordered by decreasing cost.  The bit-plane tiles (wave-uniform switch over
+// T) and the count-vector tiles run as two launches so that the rarely used wide SAD body does not set the register
+// budget (= occupancy) of the common one.
+constexpr uint32_t SCAN_STAGE = 64 * 4 + 128;
+template <int NP, bool BITS>
+__device__ inline void scan_wave(const ScanArgs& A) {
+  constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
+  __shared__ uint32_t s_qlds[4][QWORDS];
+  __shared__ uint32_t s_stage[4][SCAN_STAGE];
+  const uint32_t wid = threadIdx.x >> 6;
+  const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wid));
+  if (item >= A.ntiles) return;
+  const cptr_u32 tp = (cptr_u32)(A.tiles + item);
+  Tile t;
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8];
+  uint32_t* qlds = s_qlds[wid];
+  uint32_t* stage = s_stage[wid];
+  if (BITS) {
+    switch (t.kind) {
+      case 1: scan_tile<1, NP>(A, t, item, stage, qlds); break;
+      case 2: scan_tile<2, NP>(A, t, item, stage, qlds); break;
+      case 3: scan_tile<3, NP>(A, t, item, stage, qlds); break;
+      default: scan_tile<4, NP>(A, t, item, stage, qlds); break;
+    }
+  } else {
+    scan_tile<0, NP>(A, t, item, stage, qlds);
+  }
+}
+// <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
+// 64 with spills -> 2.60 ms)
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scan_bits(ScanArgs A) { scan_wave<NP, true>(A); }
+template <int NP>
+__global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false>(A); }
+

@@ -1,0 +1,592 @@
+// kernels_score.hpp -- K2+K3: prefilter, register-resident and general Damerau-Levenshtein, LCS / prefix / suffix, score (k_filter_score, k_score_fast8, k_score_pairs)
+// Part of the single translation unit engine.hip (included inside namespace anx); gfx950 only.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// K3: score one (query, candidate) pair per lane, straight off the flat pair list.
+//   damerau_levenshtein (src/distance.rs:101-179) in its band-limited saturating form:
+//   cells with |i-j| > d are d+1, every value saturates at d+1, the transposition term only looks back
+//   d rows / d columns (farther ones cost > d).  Identical to the reference for every outcome <= d.
+//   Per-lane state lives in LDS: query row, candidate row, a ring of d+2 band rows.
+//   longest_common_substring_length / common_prefix_length / common_suffix_length: src/distance.rs:181-231.
+//   Score: src/lib.rs:1433-1452 (f64, same association, no FMA contraction).
+// ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// K2: prefilter + selection.  A necessary condition for damerau_levenshtein(q, c) <= d (src/distance.rs:101-179):
+// every optimal edit script matches all but <= d symbols of q (and of c) to an EQUAL symbol of the other string
+// at an offset within +-d (each unmatched symbol costs one deletion/insertion/substitution; transposed symbols
+// are equal symbols within the offset bound).  So count the positions of q that have no equal symbol of c in
+// [i-d, i+d] (and vice versa); more than d of them => the reference returns None.  Pure register SWAR over the
+// two 16-byte rows (7 byte-shifts with v_alignbyte_b32, zero-byte detection), no LDS, no DP.  On config 2 it
+// rejects ~2/3 of the pairs; the banded DP then runs only on the selected third.  Strings longer than 16
+// symbols or d > 3 are passed through unfiltered.
+// ------------------------------------------------------------------------------------------------
+#define PAIR_NONE 0x7Fu
+
+__device__ inline uint32_t nonzero_bytes(uint32_t x) {  // bit 7 of every byte that is non-zero
+  return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+}
+__device__ inline uint32_t len_mask(int len, int k) {  // 0x80 in every byte position (4k..4k+3) below len
+  const int n = len - 4 * k;
+  return n >= 4 ? 0x80808080u : n <= 0 ? 0u : (0x80808080u & ((1u << (8 * n)) - 1u));
+}
+
+template <int DELTA, int NW>
+__device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], bool enabled, uint32_t (&nmA)[NW],
+                                    uint32_t (&nmB)[NW]) {
+  uint32_t nz[NW + 2];
+  nz[0] = 0xFFFFFFFFu;
+  nz[NW + 1] = 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    uint32_t cs;  // bytes C[4k + DELTA ..]
+    if (DELTA == 0) cs = c[k + 1];
+    else if (DELTA > 0) cs = __builtin_amdgcn_alignbyte(c[k + 2], c[k + 1], DELTA);
+    else cs = __builtin_amdgcn_alignbyte(c[k + 1], c[k], 4 + DELTA);
+    const uint32_t v = nonzero_bytes(q[k] ^ cs);  // bit7 set where q[i] != c[i + DELTA]
+    nz[k + 1] = enabled ? v : 0xFFFFFFFFu;
+    nmA[k] &= nz[k + 1];
+  }
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {  // the same comparisons seen from c: position j pairs with i = j - DELTA
+    uint32_t b;
+    if (DELTA == 0) b = nz[k + 1];
+    else if (DELTA > 0) b = __builtin_amdgcn_alignbyte(nz[k + 1], nz[k], 4 - DELTA);
+    else b = __builtin_amdgcn_alignbyte(nz[k + 2], nz[k + 1], -DELTA);
+    nmB[k] &= b;
+  }
+}
+// band-match bound: a symbol with no equal symbol of the other string within +-d positions costs at least one edit
+template <int NW>
+__device__ inline bool band_bound_rejects(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], bool filt, int d, int lq, int lc) {
+  uint32_t nmA[NW], nmB[NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) { nmA[k] = 0xFFFFFFFFu; nmB[k] = 0xFFFFFFFFu; }
+  filter_shift<0, NW>(q, c, true, nmA, nmB);
+  if (__any(filt && d >= 1)) { filter_shift<1, NW>(q, c, d >= 1, nmA, nmB); filter_shift<-1, NW>(q, c, d >= 1, nmA, nmB); }
+  if (__any(filt && d >= 2)) { filter_shift<2, NW>(q, c, d >= 2, nmA, nmB); filter_shift<-2, NW>(q, c, d >= 2, nmA, nmB); }
+  if (__any(filt && d >= 3)) { filter_shift<3, NW>(q, c, d >= 3, nmA, nmB); filter_shift<-3, NW>(q, c, d >= 3, nmA, nmB); }
+  int unA = 0, unB = 0;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    unA += __popc(nmA[k] & len_mask(lq, k));
+    unB += __popc(nmB[k] & len_mask(lc, k));
+  }
+  return filt && (unA > d || unB > d);
+}
+
+struct ScoreArgs {
+  const double* quot;  // [33][33] quot[x*33+L] = (double)x / (double)L computed on the host, or nullptr
+  int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL
+  double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
+  double score_threshold;
+  int have_freq, any_variants;
+  uint32_t lqp, lcp;   // bytes reserved per lane for the query / candidate row (multiples of 16)
+  uint32_t stride;     // bytes per lane (odd number of dwords: conflict-free ds access)
+  uint32_t qw;
+};
+
+// Appends the wave's survivors to the survivor list: one atomic per wave on the counter of the given region (the
+// pair-list region the pairs come from, so a region holds at most as many survivors as that region has slots).
+struct SurvOut {
+  SurvRec* list;
+  uint32_t* ctr;          // [SCAN_REGIONS][RC_STRIDE]
+  uint32_t region_cap;
+};
+__device__ inline void surv_append(const SurvOut& o, uint32_t region, bool keep, uint32_t q, uint32_t e, double score) {
+  const unsigned long long km = __ballot(keep);
+  if (!km) return;  // wave-uniform
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__ffsll((long long)km) - 1u) base = atomicAdd(&o.ctr[region * RC_STRIDE], (uint32_t)__popcll(km));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)km) - 1);
+  const uint32_t pos = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+  if (keep && pos < o.region_cap) o.list[(size_t)region * o.region_cap + pos] = SurvRec{q, e, score};
+}
+
+// The part of gather_instances / score_and_rank that follows a successful Damerau-Levenshtein (ld <= d):
+// LCS, prefix, suffix, case (src/lib.rs:1352-1377), the f64 score (:1433-1452), max_freq and the survivor count.
+__device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, int lc, uint32_t ld, uint32_t qm, uint32_t em,
+                                    uint32_t q, uint32_t e, const ScoreArgs& a, const uint32_t* __restrict__ ent_freq,
+                                    const uint32_t* __restrict__ ent_var_off, uint32_t* __restrict__ qmaxfreq,
+                                    uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, uint32_t& lcs,
+                                    uint32_t& pre, uint32_t& suf, uint32_t& samecase, bool& keep) {
+  if (a.w_lcs > 0.0 && !(a.dbg & 1)) {
+    // longest common substring (src/lib.rs:1352-1356, src/distance.rs:181-205) = longest run of equal symbols on
+    // any diagonal.  Diagonals are visited from the main one outwards (0, +1, -1, +2, ...): the overlap of a diagonal
+    // only shrinks with |delta|, so the walk stops as soon as neither side can beat the best run found so far.
+    uint32_t best = 0;
+    for (int r = 0; r < max(lq, lc); ++r) {
+      bool open = false;
+      for (int side = 0; side < (r ? 2 : 1); ++side) {
+        const int delta = side ? -r : r;
+        const int i0 = delta < 0 ? -delta : 0;
+        const int i1 = min(lq, lc - delta);
+        if (i1 - i0 <= (int)best) continue;
+        open = true;
+        uint32_t run = 0;
+        for (int i = i0; i < i1; ++i) {
+          run = S[i] == T[i + delta] ? run + 1 : 0;
+          best = max(best, run);
+        }
+      }
+      if (!open) break;
+    }
+    lcs = best;
+  }
+  const int m = min(lq, lc);
+  if (a.w_prefix > 0.0) {
+    int n = 0;
+    while (n < m && S[n] == T[n]) ++n;
+    pre = n;
+  }
+  if (a.w_suffix > 0.0) {
+    int n = 0;
+    while (n < m && S[lq - 1 - n] == T[lc - 1 - n]) ++n;
+    suf = n;
+  }
+  if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
+  // x / L for integers x <= L <= 32 comes from a table of host-computed IEEE quotients (identical bits, no f64 divide)
+  const double L = (double)lq;
+  const bool tab = a.quot && lq <= 32;
+  auto over_L = [&](uint32_t x) { return (tab && x <= 32u) ? a.quot[x * 33u + (uint32_t)lq] : (double)x / L; };
+  const double distance_score = (int)ld > lq ? 0.0 : 1.0 - over_L(ld);
+  const double lcs_score = over_L(lcs);
+  const double prefix_score = over_L(pre);
+  const double suffix_score = over_L(suf);
+  const double num = a.w_ld * distance_score + a.w_lcs * lcs_score + a.w_prefix * prefix_score +
+                     a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0);
+  const double score = a.w_sum == 1.0 ? num : num / a.w_sum;  // x / 1.0 == x
+  // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
+  atomicMax(&qmaxfreq[q], a.have_freq ? ent_freq[e] : 1u);
+  uint32_t nrows = 1;
+  if (a.any_variants) {  // variant lists loaded (src/lib.rs:1464-1466, 1510, 1677-1727)
+    if (em & 0x200u) qexpand[q] = 1;  // benign race: every writer stores 1
+    nrows = (ent_var_off[e + 1] - ent_var_off[e]) + ((em & 0x400u) ? 0u : 1u);  // transparent: references only
+  }
+  keep = score >= a.score_threshold && nrows;  // src/lib.rs:1475
+  if (keep) atomicAdd(&qsurv[q], nrows);
+  return score;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 fast path: pairs with both strings <= 16 symbols and d <= 3 (every pair of BASELINE configs 1-2).
+// The banded unrestricted Damerau-Levenshtein runs entirely in registers: both strings are 4 dwords, the row loop
+// is fully unrolled (row number, band column and matrix column are compile-time constants, lanes whose query is
+// shorter are masked), band rows live in a ring of D+2 register rows, and values are NOT saturated: every cell is
+// >= the true distance and exact along any path of cost <= D, cells outside the band read as D+1 (their true value
+// is >= D+1, so everything derived from them is > D), which gives the same outcome for every result <= d
+// (SURVEY.md appendix A.3).  The transposition term of src/distance.rs:157-162 in band form: with
+// l = i-1-a the last earlier row whose symbol equals t[j-1] and db = j-1-b the last earlier column of this row
+// that matches s[i-1], T = D[l-1][db-1] + a + b + 1, only needed for a + b <= D - 1.
+// ------------------------------------------------------------------------------------------------
+
+template <int NW>
+__device__ inline uint32_t byte_of(const uint32_t (&w)[NW], int idx) { return (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; }
+
+template <int D, int NW>
+__device__ inline uint32_t dl_band(const uint32_t (&S)[NW], const uint32_t (&T)[NW], int lq, int lc, int lqmax) {
+  constexpr int BW = 2 * D + 1, NR = D + 2, MAXLEN = 4 * NW;
+  constexpr uint32_t CAP = D + 1;
+  uint32_t row[NR][BW];
+  // T padded with D+1 never-matching bytes in front: the band window of row i is bytes [i, i+2D] of tp
+  uint32_t tp[NW + 3];
+  {
+    constexpr int SH = D + 1;  // 2..4 bytes
+    const uint32_t fill = 0xFFFFFFFFu;
+    if (SH == 4) {
+      tp[0] = fill;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tp[w + 1] = T[w];
+      tp[NW + 1] = fill;
+      tp[NW + 2] = fill;
+    } else {
+      tp[0] = __builtin_amdgcn_alignbyte(T[0], fill, 4 - SH);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) tp[w] = __builtin_amdgcn_alignbyte(T[w], T[w - 1], 4 - SH);
+      tp[NW] = __builtin_amdgcn_alignbyte(fill, T[NW - 1], 4 - SH);
+      tp[NW + 1] = fill;
+      tp[NW + 2] = fill;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < BW; ++c) row[r][c] = CAP;
+#pragma unroll
+  for (int c = 0; c < BW; ++c) row[0][c] = c - D >= 0 ? (uint32_t)(c - D) : CAP;
+#pragma unroll
+  for (int i = 1; i <= MAXLEN; ++i) {
+    if (i <= lqmax) {    // wave-uniform
+      if (i <= lq) {     // lanes with shorter queries keep their last row
+        const uint32_t sc = byte_of<NW>(S, i - 1);
+        const uint32_t wlo = __builtin_amdgcn_alignbyte(tp[(i >> 2) + 1], tp[i >> 2], i & 3);
+        const uint32_t whi = __builtin_amdgcn_alignbyte(tp[(i >> 2) + 2], tp[(i >> 2) + 1], i & 3);
+        uint32_t (&cur)[BW] = row[i % NR];
+        const uint32_t (&prev)[BW] = row[(i - 1) % NR];
+        bool mt[BW];
+        uint32_t nv[BW];
+#pragma unroll
+        for (int c = 0; c < BW; ++c) {
+          const int j = i + c - D;
+          mt[c] = false;
+          nv[c] = CAP;
+          if (j == 0) nv[c] = (uint32_t)i;
+          else if (j >= 1 && j <= MAXLEN) {
+            const uint32_t tc = ((c < 4 ? wlo : whi) >> (8 * (c & 3))) & 0xFFu;
+            mt[c] = sc == tc;
+            const uint32_t up = c + 1 < BW ? prev[c + 1] : CAP;
+            const uint32_t left = c > 0 ? nv[c - 1] : CAP;
+            uint32_t v = min(min(left, up) + 1u, prev[c] + (mt[c] ? 0u : 1u));
+            // transposition
+            bool eqs[D], any_eqs = false, any_mt = false;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+              eqs[a] = i - 2 - a >= 0 ? byte_of<NW>(S, i - 2 - a >= 0 ? i - 2 - a : 0) == tc : false;
+              any_eqs |= eqs[a];
+            }
+#pragma unroll
+            for (int b = 0; b < D; ++b)
+              if (c - 1 - b >= 0) any_mt |= mt[c - 1 - b];
+            if (__builtin_amdgcn_ballot_w64(any_eqs && any_mt)) {  // wave-uniform: some lane has a transposition candidate
+              bool a_open = true;  // no closer row matched yet
+#pragma unroll
+              for (int a = 0; a < D; ++a) {
+                if (i - 2 - a < 0) break;
+                bool b_open = true;  // no closer column matched yet
+#pragma unroll
+                for (int b = 0; a + b < D; ++b) {
+                  const int cb = c - 1 - b, x = c + a - b;
+                  if (cb < 0 || j - 1 - b < 1) break;
+                  if (x >= 0 && x < BW) {
+                    const bool cond = a_open && eqs[a] && b_open && mt[cb];
+                    const uint32_t tv = row[(i - 2 - a) % NR][x] + (uint32_t)(a + b + 1);
+                    v = cond ? min(v, tv) : v;
+                  }
+                  b_open = b_open && !mt[cb];
+                }
+                a_open = a_open && !eqs[a];
+              }
+            }
+            nv[c] = v;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < BW; ++c) cur[c] = nv[c];
+      }
+    }
+  }
+  // D[lq][lc]: ring row lq % NR, band column lc - lq + D
+  uint32_t res = CAP;
+  const int rsel = lq % NR, csel = lc - lq + D;
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < BW; ++c) res = (rsel == r && csel == c) ? row[r][c] : res;
+  return res;
+}
+
+// A list of pair-list slots per region (the selected pairs a later kernel has to score), appended per wave.
+struct SlotList {
+  uint32_t* list;      // [SCAN_REGIONS][region_cap]
+  uint32_t* ctr;       // [SCAN_REGIONS][RC_STRIDE]
+  uint32_t region_cap;
+};
+__device__ inline void slot_append(const SlotList& o, uint32_t region, bool put, uint32_t slot) {
+  const unsigned long long km = __ballot(put);
+  if (!km) return;  // wave-uniform
+  const uint32_t lane = threadIdx.x & 63;
+  const int first = __ffsll((long long)km) - 1;
+  uint32_t base = 0;
+  if ((int)lane == first) base = atomicAdd(&o.ctr[region * RC_STRIDE], (uint32_t)__popcll(km));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+  const uint32_t pos = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+  if (put && pos < o.region_cap) o.list[(size_t)region * o.region_cap + pos] = slot;
+}
+
+struct PairArgs {  // what every scoring kernel reads / writes
+  const uint2* raw;
+  const uint32_t* q_meta;
+  const uint4* q_rows;
+  const uint32_t* ent_meta;
+  const uint32_t* ent_rowoff;
+  const uint4* rows;
+  const uint32_t* ent_freq;
+  const uint32_t* ent_var_off;
+  double* p_score;      // per pair-list slot
+  uint32_t* p_meta;     // per pair-list slot: ld | samecase<<7 | lcs<<8 | prefix<<16 | suffix<<24, or skipped / rejected
+  uint32_t* qmaxfreq;
+  uint32_t* qsurv;
+  uint32_t* qexpand;
+};
+
+// Scores the pair in slot p with the register-resident DL of NW words (all lanes of the wave call this; lanes with
+// !active only take part in the wave-wide steps).  lds: per-lane staging of both strings for the byte-wise tail.
+template <int D, int NW>
+__device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& A, const ScoreArgs& a, const SurvOut& so,
+                                       uint32_t surv_region, uint32_t* __restrict__ lds) {
+  uint32_t q = 0, e = 0, qm = 0, em = 0;
+  int lq = 0, lc = 0, d = 0;
+  uint32_t S[NW], T[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { S[w] = 0xFEFEFEFEu; T[w] = 0xFFFFFFFFu; }
+  if (active) {
+    const uint2 rp = A.raw[p];
+    q = rp.x;
+    e = rp.y & 0x7FFFFFFFu;
+    qm = A.q_meta[q];
+    em = A.ent_meta[e];
+    lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
+    const uint4* qr = A.q_rows + (size_t)q * a.qw;
+    const uint4* cr = A.rows + A.ent_rowoff[e];
+#pragma unroll
+    for (int w = 0; w < NW / 4; ++w) {
+      if (w * 16 < lq) { const uint4 Q = qr[w]; S[4 * w] = Q.x; S[4 * w + 1] = Q.y; S[4 * w + 2] = Q.z; S[4 * w + 3] = Q.w; }
+      if (w * 16 < lc) { const uint4 C = cr[w]; T[4 * w] = C.x; T[4 * w + 1] = C.y; T[4 * w + 2] = C.z; T[4 * w + 3] = C.w; }
+    }
+  }
+  int lqmax = active ? lq : 0;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) lqmax = max(lqmax, __shfl_xor(lqmax, o));
+  lqmax = __builtin_amdgcn_readfirstlane(lqmax);
+  const uint32_t res = dl_band<D, NW>(S, T, active ? lq : 0, lc, lqmax);
+  uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
+  double score = __builtin_nan("");
+  bool keep = false;
+  const int diff = lq > lc ? lq - lc : lc - lq;
+  if (active && diff <= d && res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:109-130, 173-178
+    uint32_t* mine = lds + (threadIdx.x & 255) * (2 * NW + 1);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { mine[w] = S[w]; mine[NW + w] = T[w]; }
+    ld = res;
+    score = score_tail(reinterpret_cast<const uint8_t*>(mine), reinterpret_cast<const uint8_t*>(mine + NW), lq, lc, ld, qm, em,
+                       q, e, a, A.ent_freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, lcs, pre, suf, samecase, keep);
+  }
+  surv_append(so, surv_region, keep, q, e, score);
+  if (active) {
+    A.p_score[p] = score;
+    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+  }
+}
+
+// K2+K3 fused: prefilter of every pair-list slot and register-resident DL of the selected pairs, one block per
+// FS_BLK consecutive slots of a region.  Phase 1 (FS_BLK / 256 rounds): length test |lq - lc| <= d
+// (src/distance.rs:109-130), StopAtExactMatch drop (src/lib.rs:1164-1173) and the SWAR band-match bound; selected
+// pairs of <= 16 symbols with d <= D are queued in LDS, longer ones go to the slot lists of the 8-word / general
+// kernels.  Phase 2: the queue is scored 256 pairs at a time, so the DL lanes are dense although only ~1/3 of the
+// slots survive phase 1 (no global compaction pass, no index list).  D = 0: no inline DL (d > 3), everything selected
+// goes to the general kernel's list.
+constexpr uint32_t FS_BLK = 4096;
+struct FilterArgs {
+  uint32_t region_shift;
+  const uint32_t* rctr;     // region fills of the pair list
+  const uint32_t* qexact;
+  int stop, enable;
+  int use_nw8;              // selected pairs of 17..32 symbols go to list8 (else to the general list)
+  uint32_t* counters;
+  uint32_t* stat_ctr;       // [SCAN_REGIONS][RC_STRIDE], word 1: selected pairs
+};
+template <int D>
+__global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg) {
+  __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
+  __shared__ uint32_t s_n;
+  __shared__ uint32_t s_str[256 * 9];
+  // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
+  // counter word sustains only ~88 M atomics/s)
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * FS_BLK;
+  if (base >= fill) return;  // block-uniform
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t nselected = 0;  // wave-uniform
+  for (uint32_t r = 0; r < FS_BLK / 256; ++r) {
+    const uint32_t idx = base + r * 256 + threadIdx.x;
+    if (base + r * 256 >= fill) break;  // block-uniform
+    const uint32_t p = (region << f.region_shift) + idx;
+    const bool live = idx < fill;
+    bool selected = false, stop_skipped = false, invalid = false;
+    int d = 0, lq = 0, lc = 0;
+    // words that are not loaded keep the row padding (query 0xFE, candidate 0xFF: never equal to anything)
+    uint32_t q8[8] = {0, 0, 0, 0, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
+    uint32_t c10[10] = {0xFFFFFFFFu, 0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    bool filt = false, wide = false;
+    if (live) {
+      const uint2 rp = A.raw[p];
+      const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+      invalid = q == RAW_INVALID;
+      // unused chunk tail, or (StopAtExactMatch) a non-exact class of a query that has an exact one
+      const bool skip = invalid || (f.stop && !(rp.y & 0x80000000u) && f.qexact[q] != 0xFFFFFFFFu);
+      stop_skipped = skip && !invalid;
+      if (!skip) {
+        const uint32_t qm = A.q_meta[q], em = A.ent_meta[e];
+        lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
+        const int diff = lq > lc ? lq - lc : lc - lq;
+        selected = diff <= d;
+        filt = selected && f.enable && d <= 3 && lq <= 32 && lc <= 32;
+        wide = filt && (lq > 16 || lc > 16);
+        if (filt) {
+          const uint4* qr = A.q_rows + (size_t)q * a.qw;
+          const uint4* cr = A.rows + A.ent_rowoff[e];
+          const uint4 Q = qr[0], C = cr[0];
+          q8[0] = Q.x; q8[1] = Q.y; q8[2] = Q.z; q8[3] = Q.w;
+          c10[1] = C.x; c10[2] = C.y; c10[3] = C.z; c10[4] = C.w;
+          if (lq > 16) { const uint4 Q1 = qr[1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
+          if (lc > 16) { const uint4 C1 = cr[1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
+        }
+      }
+    }
+    if (__any(wide)) {  // wave-uniform: some pair of the wave has a string of 17..32 symbols
+      if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
+    } else if (__any(filt)) {
+      const uint32_t q4[4] = {q8[0], q8[1], q8[2], q8[3]}, c6[6] = {0xFFFFFFFFu, c10[1], c10[2], c10[3], c10[4], 0xFFFFFFFFu};
+      if (band_bound_rejects<4>(q4, c6, filt, d, lq, lc)) selected = false;
+    }
+    if (live && !selected)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
+      A.p_meta[p] = (invalid || stop_skipped) ? META_SKIPPED : (PAIR_NONE | (1u << 7));
+    const bool inl = selected && D > 0 && lq <= 16 && lc <= 16 && d <= D;
+    const bool to8 = selected && !inl && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
+    const bool tog = selected && !inl && !to8;
+    const unsigned long long mi = __ballot(inl);
+    if (mi) {  // wave-uniform: queue the inline pairs
+      const int first = __ffsll((long long)mi) - 1;
+      uint32_t qb = 0;
+      if ((int)lane == first) qb = atomicAdd(&s_n, (uint32_t)__popcll(mi));
+      qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
+      if (inl) s_q[qb + (uint32_t)__popcll(mi & ((1ull << lane) - 1ull))] = (uint16_t)(r * 256 + threadIdx.x);
+    }
+    slot_append(list8, region, to8, p);
+    slot_append(listg, region, tog, p);
+    nselected += (uint32_t)__popcll(__ballot(selected));
+    if (f.stop) {  // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops
+      const unsigned long long ms = __ballot(stop_skipped);
+      if (lane == 0 && ms) atomicAdd(&f.counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
+    }
+  }
+  if (lane == 0 && nselected) atomicAdd(&f.stat_ctr[region * RC_STRIDE + 1], nselected);
+  __syncthreads();
+  if (D > 0) {
+    const uint32_t n = s_n;
+    for (uint32_t r0 = 0; r0 < n; r0 += 256) {  // block-uniform trip count
+      const uint32_t i = r0 + threadIdx.x;
+      const bool active = i < n;
+      score_fast_pair<(D > 0 ? D : 1), 4>(active ? (region << f.region_shift) + base + s_q[i] : 0u, active, A, a, so, region, s_str);
+    }
+  }
+}
+
+// the selected pairs with a string of 17..32 symbols (list8 of k_filter_score)
+template <int D>
+__global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
+  __shared__ uint32_t s_str[256 * 17];
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, blk = blockIdx.x / SCAN_REGIONS, i = blk * 256 + threadIdx.x, n = in.ctr[region * RC_STRIDE];
+  if (blk * 256 >= n) return;  // block-uniform
+  const bool active = i < n;
+  score_fast_pair<D, 8>(active ? in.list[(size_t)region * in.region_cap + i] : 0u, active, A, a, so, region, s_str);
+}
+
+__global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
+  extern __shared__ uint32_t lds32[];
+  const uint2* __restrict__ raw = A.raw;
+  const uint32_t* __restrict__ q_meta = A.q_meta;
+  const uint4* __restrict__ q_rows = A.q_rows;
+  const uint32_t* __restrict__ ent_meta = A.ent_meta;
+  const uint32_t* __restrict__ ent_rowoff = A.ent_rowoff;
+  const uint4* __restrict__ rows = A.rows;
+  const uint32_t* __restrict__ ent_freq = A.ent_freq;
+  const uint32_t* __restrict__ ent_var_off = A.ent_var_off;
+  uint32_t* __restrict__ qmaxfreq = A.qmaxfreq;
+  uint32_t* __restrict__ qsurv = A.qsurv;
+  uint32_t* __restrict__ qexpand = A.qexpand;
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, blk = blockIdx.x / SCAN_REGIONS, i_sel = blk * blockDim.x + threadIdx.x, nsel = in.ctr[region * RC_STRIDE];
+  if (blk * blockDim.x >= nsel) return;  // block-uniform
+  bool keep = false;
+  uint32_t kq = 0, ke = 0;
+  double kscore = 0.0;
+  if (i_sel < nsel) {
+    const uint32_t p = in.list[(size_t)region * in.region_cap + i_sel];
+    const uint2 rp = raw[p];
+    const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+    uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
+    double score = __builtin_nan("");
+    {
+      uint8_t* S = reinterpret_cast<uint8_t*>(lds32) + (size_t)threadIdx.x * a.stride;
+      uint8_t* T = S + a.lqp;
+      uint8_t* R = T + a.lcp;
+      const uint32_t qm = q_meta[q], em = ent_meta[e];
+      const int lq = qm & 0xFF, d = (qm >> 16) & 0xFF, lc = em & 0xFF;
+      const int diff = lq > lc ? lq - lc : lc - lq;
+      if (diff <= d) {  // src/distance.rs:109-130 (both lengths > 0 here)
+        {
+          uint32_t* S32 = reinterpret_cast<uint32_t*>(S);
+          const uint4* qr = q_rows + (size_t)q * a.qw;
+          for (int wq = 0; wq * 16 < lq; ++wq) {
+            const uint4 v = qr[wq];
+            S32[wq * 4 + 0] = v.x; S32[wq * 4 + 1] = v.y; S32[wq * 4 + 2] = v.z; S32[wq * 4 + 3] = v.w;
+          }
+          uint32_t* T32 = reinterpret_cast<uint32_t*>(T);
+          const uint4* cr = rows + ent_rowoff[e];
+          for (int wc = 0; wc * 16 < lc; ++wc) {
+            const uint4 v = cr[wc];
+            T32[wc * 4 + 0] = v.x; T32[wc * 4 + 1] = v.y; T32[wc * 4 + 2] = v.z; T32[wc * 4 + 3] = v.w;
+          }
+        }
+        // ---- banded unrestricted Damerau-Levenshtein ------------------------------------------------
+        const int cap = d + 1, W = 2 * d + 3, NR = d + 2;
+        // row i is stored at R[(i % NR) * W + col], col = j - i + d + 1 in [1, 2d+1]; cols 0, 2d+2 are guards
+        for (int col = 0; col < W; ++col) {
+          const int j = col - d - 1;
+          R[col] = (uint8_t)((j >= 0 && j <= lc && col >= 1 && col <= 2 * d + 1) ? (j < cap ? j : cap) : cap);
+        }
+        for (int i = 1; i <= lq; ++i) {
+          uint8_t* cur = R + (i % NR) * W;
+          const uint8_t* prev = R + ((i - 1) % NR) * W;
+          const uint32_t sc = S[i - 1];
+          int db = 0;
+          cur[0] = (uint8_t)cap;
+          for (int col = 1; col <= 2 * d + 1; ++col) {
+            const int j = i + col - d - 1;
+            uint32_t v;
+            if (j < 0 || j > lc) v = cap;
+            else if (j == 0) v = i < cap ? i : cap;
+            else {
+              const uint32_t tc = T[j - 1];
+              const uint32_t cost = sc != tc;
+              v = min(min((uint32_t)cur[col - 1] + 1u, (uint32_t)prev[col + 1] + 1u), (uint32_t)prev[col] + cost);
+              if (db > 0) {
+                // l = last row i' < i with s[i'-1] == t[j-1] (char_map, src/distance.rs:146,154,170), looking
+                // back at most d rows: farther rows make the term exceed d
+                for (int back = 0; back < d; ++back) {
+                  const int l = i - 1 - back;
+                  if (l < 1) break;
+                  if (S[l - 1] == tc) {
+                    const int colx = db - l + d + 1;  // column of D[l-1][db-1] in row l-1
+                    if (colx >= 1 && colx <= 2 * d + 1) {
+                      const uint32_t tv = (uint32_t)R[((l - 1) % NR) * W + colx] + (uint32_t)(i - l - 1) + 1u +
+                                          (uint32_t)(j - db - 1);  // src/distance.rs:161
+                      v = min(v, tv);
+                    }
+                    break;
+                  }
+                }
+              }
+              v = min(v, (uint32_t)cap);
+              if (cost == 0) db = j;  // src/distance.rs:165-167
+            }
+            cur[col] = (uint8_t)v;
+          }
+          cur[2 * d + 2] = (uint8_t)cap;
+        }
+        const uint32_t res = R[(lq % NR) * W + (lc - lq + d + 1)];
+        if (res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:173-178
+          ld = res;
+          score = score_tail(S, T, lq, lc, ld, qm, em, q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase, keep);
+          kq = q; ke = e; kscore = score;
+        }
+      }
+    }
+    A.p_score[p] = score;
+    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+  }
+  surv_append(so, region, keep, kq, ke, kscore);
+}
+
