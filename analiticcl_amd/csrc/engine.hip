@@ -172,6 +172,11 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   int rc = ANX_OK;
   std::vector<EntRec> rec(img.ent_vocab.size());
   for (size_t e = 0; e < rec.size(); ++e) rec[e] = EntRec{img.ent_vocab[e], img.ent_freq[e], img.ent_order[e], img.ent_meta[e]};
+  std::vector<uint4> erec(2 * img.ent_vocab.size());
+  for (size_t e = 0; e < img.ent_vocab.size(); ++e) {
+    memcpy(&erec[2 * e], &img.rows[(size_t)img.ent_rowoff[e] * 16], 16);
+    erec[2 * e + 1] = make_uint4(img.ent_meta[e], img.ent_rowoff[e], img.ent_freq[e], 0u);
+  }
   std::vector<uint2> sig2(img.sig_lo.size());
   for (size_t i = 0; i < sig2.size(); ++i) sig2[i] = make_uint2(img.sig_lo[i], img.sig_hi[i]);
   std::vector<uint32_t> off = img.cls_off;
@@ -188,6 +193,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->ent_rowoff, img.ent_rowoff.data(), img.ent_rowoff.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_order, img.ent_order.data(), img.ent_order.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_rec, rec.data(), rec.size(), err, &d->bytes)) ||
+      (rc = upload(&d->e_rec, erec.data(), erec.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_var_off, img.ent_var_off.data(), img.ent_var_off.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_target, img.var_target.data(), img.var_target.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_target_freq, img.var_target_freq.data(), img.var_target_freq.size(), err, &d->bytes)) ||
@@ -203,7 +209,7 @@ void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
-                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->ent_var_off,
+                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) pool_free(p);
   bool last;
@@ -388,8 +394,14 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     }
     for (auto& x : th) x.join();
   }
+  std::vector<uint4> h_qrec(2 * nq);
+  for (size_t sidx = 0; sidx < nq; ++sidx) {
+    memcpy(&h_qrec[2 * sidx], &h_rows[sidx * (size_t)b->qw * 16], 16);
+    h_qrec[2 * sidx + 1] = make_uint4(h_meta[sidx], 0u, 0u, 0u);
+  }
   int rc;
-  if ((rc = upload(&b->qexact, h_xcls.data(), nq, err, nullptr)) ||
+  if ((rc = upload(&b->q_rec, h_qrec.data(), h_qrec.size(), err, nullptr)) ||
+      (rc = upload(&b->qexact, h_xcls.data(), nq, err, nullptr)) ||
       (rc = upload(&b->q_cv, h_cv.data(), h_cv.size(), err, nullptr)) ||
       (rc = upload(&b->q_bits, h_bits.data(), h_bits.size(), err, nullptr)) ||
       (rc = upload(reinterpret_cast<uint8_t**>(&b->q_rows), h_rows.data(), h_rows.size(), err, nullptr)) ||
@@ -600,7 +612,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     HIP_TRY(hipMemsetAsync(b->sctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(b->lctr, 0, 2 * SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
     const SlotList l8{b->list8, b->lctr, (uint32_t)b->list_cap}, lg{b->listg, b->lctr + SCAN_REGIONS * RC_STRIDE, (uint32_t)b->list_cap};
-    const PairArgs pa{b->raw, b->q_meta, b->q_rows, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, dl->ent_var_off,
+    const PairArgs pa{b->raw, b->q_meta, b->q_rows, b->q_rec, dl->e_rec, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, dl->ent_var_off,
                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand};
     FilterArgs fa;
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
@@ -780,7 +792,7 @@ void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 void batch_free(Batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
+  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})

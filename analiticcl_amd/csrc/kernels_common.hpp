@@ -43,6 +43,7 @@ struct DeviceLexicon {
   uint32_t* ent_rowoff = nullptr;
   uint32_t* ent_order = nullptr;
   EntRec* ent_rec = nullptr;           // {vocab, freq, order, meta} per entry
+  uint4* e_rec = nullptr;              // [E][2] {first 16 symbols} {meta, row offset, freq, 0}: PairArgs::e_rec
   uint32_t* ent_var_off = nullptr;     // CSR entry -> VariantOf references (variant lists, src/lib.rs:1677-1727)
   uint32_t* var_target = nullptr;      // vocab id of the reference item
   uint32_t* var_target_freq = nullptr;
@@ -87,6 +88,7 @@ struct Batch {
   uint32_t* q_cv = nullptr;        // [nq][nplanes]
   uint32_t* q_bits = nullptr;      // [nq][NBITPLANES]
   uint4* q_rows = nullptr;         // [nq][qw]
+  uint4* q_rec = nullptr;          // [nq][2] {first 16 symbols} {meta, 0, 0, 0}: PairArgs::q_rec
   uint32_t* q_meta = nullptr;      // len | k<<8 | d<<16 | first_is_lower<<24
   uint32_t* q_orig = nullptr;      // original index
   Tile* d_tiles = nullptr;

@@ -308,6 +308,8 @@ struct PairArgs {  // what every scoring kernel reads / writes
   const uint2* raw;
   const uint32_t* q_meta;
   const uint4* q_rows;
+  const uint4* q_rec;       // [Q][2]: {first 16 symbols of the query} {meta, -, -, -}: one 32-B gather instead of two
+  const uint4* e_rec;       // [E][2]: {first 16 symbols of the entry} {meta, row offset, freq, -}
   const uint32_t* ent_meta;
   const uint32_t* ent_rowoff;
   const uint4* rows;
@@ -334,13 +336,17 @@ __device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& 
     const uint2 rp = A.raw[p];
     q = rp.x;
     e = rp.y & 0x7FFFFFFFu;
-    qm = A.q_meta[q];
-    em = A.ent_meta[e];
+    const uint4 Q0 = A.q_rec[2 * (size_t)q], QM = A.q_rec[2 * (size_t)q + 1];
+    const uint4 C0 = A.e_rec[2 * (size_t)e], CM = A.e_rec[2 * (size_t)e + 1];
+    qm = QM.x;
+    em = CM.x;
     lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
+    S[0] = Q0.x; S[1] = Q0.y; S[2] = Q0.z; S[3] = Q0.w;
+    T[0] = C0.x; T[1] = C0.y; T[2] = C0.z; T[3] = C0.w;
     const uint4* qr = A.q_rows + (size_t)q * a.qw;
-    const uint4* cr = A.rows + A.ent_rowoff[e];
+    const uint4* cr = A.rows + CM.y;
 #pragma unroll
-    for (int w = 0; w < NW / 4; ++w) {
+    for (int w = 1; w < NW / 4; ++w) {
       if (w * 16 < lq) { const uint4 Q = qr[w]; S[4 * w] = Q.x; S[4 * w + 1] = Q.y; S[4 * w + 2] = Q.z; S[4 * w + 3] = Q.w; }
       if (w * 16 < lc) { const uint4 C = cr[w]; T[4 * w] = C.x; T[4 * w + 1] = C.y; T[4 * w + 2] = C.z; T[4 * w + 3] = C.w; }
     }
@@ -418,20 +424,19 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       const bool skip = invalid || (f.stop && !(rp.y & 0x80000000u) && f.qexact[q] != 0xFFFFFFFFu);
       stop_skipped = skip && !invalid;
       if (!skip) {
-        const uint32_t qm = A.q_meta[q], em = A.ent_meta[e];
+        const uint4 Q = A.q_rec[2 * (size_t)q], QM = A.q_rec[2 * (size_t)q + 1];  // 32-B records: one line each
+        const uint4 C = A.e_rec[2 * (size_t)e], CM = A.e_rec[2 * (size_t)e + 1];
+        const uint32_t qm = QM.x, em = CM.x;
         lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
         const int diff = lq > lc ? lq - lc : lc - lq;
         selected = diff <= d;
         filt = selected && f.enable && d <= 3 && lq <= 32 && lc <= 32;
         wide = filt && (lq > 16 || lc > 16);
         if (filt) {
-          const uint4* qr = A.q_rows + (size_t)q * a.qw;
-          const uint4* cr = A.rows + A.ent_rowoff[e];
-          const uint4 Q = qr[0], C = cr[0];
           q8[0] = Q.x; q8[1] = Q.y; q8[2] = Q.z; q8[3] = Q.w;
           c10[1] = C.x; c10[2] = C.y; c10[3] = C.z; c10[4] = C.w;
-          if (lq > 16) { const uint4 Q1 = qr[1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
-          if (lc > 16) { const uint4 C1 = cr[1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
+          if (lq > 16) { const uint4 Q1 = A.q_rows[(size_t)q * a.qw + 1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
+          if (lc > 16) { const uint4 C1 = A.rows[CM.y + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
         }
       }
     }
