@@ -177,6 +177,13 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
     memcpy(&erec[2 * e], &img.rows[(size_t)img.ent_rowoff[e] * 16], 16);
     erec[2 * e + 1] = make_uint4(img.ent_meta[e], img.ent_rowoff[e], img.ent_freq[e], 0u);
   }
+  std::vector<uint4> crec(2 * (size_t)img.cstride);
+  for (uint32_t c = 0; c < img.cstride; ++c) {
+    crec[2 * (size_t)c] = make_uint4(img.cls_bits[c], img.cls_bits[(size_t)img.cstride + c], img.cls_bits[2 * (size_t)img.cstride + c],
+                                     img.cls_bits[3 * (size_t)img.cstride + c]);
+    const bool real = c < img.nclasses;
+    crec[2 * (size_t)c + 1] = make_uint4(img.cls_len[c], real ? img.cls_off[c] : 0u, real ? img.cls_off[c + 1] - img.cls_off[c] : 0u, 0u);
+  }
   std::vector<uint2> sig2(img.sig_lo.size());
   for (size_t i = 0; i < sig2.size(); ++i) sig2[i] = make_uint2(img.sig_lo[i], img.sig_hi[i]);
   std::vector<uint32_t> off = img.cls_off;
@@ -185,6 +192,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->cls_bits, img.cls_bits.data(), img.cls_bits.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_len, img.cls_len.data(), img.cls_len.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
+      (rc = upload(&d->cls_rec, crec.data(), crec.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig, sig2.data(), sig2.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_cbeg, img.sig_cbeg.data(), img.sig_cbeg.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_vocab, img.ent_vocab.data(), img.ent_vocab.size(), err, &d->bytes)) ||
@@ -208,7 +216,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->cls_rec, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) pool_free(p);
@@ -514,7 +522,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     if (!b->tiles.empty()) {
       ScanArgs A;
       A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
-      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
+      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cls_rec = dl->cls_rec; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
       A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_cbeg = dl->sig_cbeg;
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
       { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }

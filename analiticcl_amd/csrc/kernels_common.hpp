@@ -35,6 +35,7 @@ struct DeviceLexicon {
   uint32_t* cls_bits = nullptr;    // [NBITPLANES][cstride] thermometer planes (bit s of plane t: count_s > t), nsym <= 32
   uint8_t* cls_len = nullptr;      // [cstride]
   uint32_t* cls_off = nullptr;
+  uint4* cls_rec = nullptr;        // [cstride][2] {4 planes} {len, first entry, entries, 0}: ScanArgs::cls_rec
   uint2* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage), lo/hi interleaved
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint32_t* ent_vocab = nullptr;

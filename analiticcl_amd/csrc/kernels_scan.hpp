@@ -82,6 +82,7 @@ struct ScanArgs {
   const uint32_t* q_cv;
   const uint32_t* cls_bits;
   const uint32_t* cls_planes;
+  const uint4* cls_rec;     // [cstride][2] {4 thermometer planes} {len, first entry, entries, 0} (bit-plane kernel)
   uint32_t cstride;
   uint32_t pad_class;   // a never-matching padding class (bits 0, counts 0xFF, len 255)
   const uint8_t* cls_len;
@@ -137,15 +138,26 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   auto process = [&]() {
     ++nchunks;
     if (A.dbg & 2) return;
-    uint32_t cid[CPL], cw[CPL][W];
+    uint32_t cid[CPL], cw[CPL][W], e0r[CPL], ner[CPL];
     int32_t thr[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const uint32_t idx = (uint32_t)j * 64u + lane;
       cid[j] = idx < ns ? stage[idx] : A.pad_class;
+      int32_t lc;
+      if (BITS) {  // one 32-B class record {4 planes} {len, first entry, entries, -} instead of T + 3 gathers
+        const uint4 pl = A.cls_rec[2 * (size_t)cid[j]], mt = A.cls_rec[2 * (size_t)cid[j] + 1];
+        const uint32_t plw[4] = {pl.x, pl.y, pl.z, pl.w};
 #pragma unroll
-      for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
-      const int32_t lc = (int32_t)cls_len[cid[j]];
+        for (int p = 0; p < W; ++p) cw[j][p] = plw[p];
+        lc = (int32_t)mt.x;
+        e0r[j] = mt.y;
+        ner[j] = mt.z;
+      } else {
+#pragma unroll
+        for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
+        lc = (int32_t)cls_len[cid[j]];
+      }
       if (BITS) {
         const int32_t need = ((int32_t)t.lq - (int32_t)t.k + lc + 1) >> 1;  // ceil((lq + lc - k) / 2)
         thr[j] = -(need < 1 ? 1 : need);
@@ -194,8 +206,11 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         e0[j] = 0;
         ne[j] = 0;
         if (hm[j]) {
-          e0[j] = cls_off[cid[j]];
-          ne[j] = cls_off[cid[j] + 1] - e0[j];
+          if (BITS) { e0[j] = e0r[j]; ne[j] = ner[j]; }
+          else {
+            e0[j] = cls_off[cid[j]];
+            ne[j] = cls_off[cid[j] + 1] - e0[j];
+          }
           cnt += (uint32_t)__popc(hm[j]) * ne[j];
         }
       }
