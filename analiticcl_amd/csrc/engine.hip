@@ -563,7 +563,6 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   b->n_raw = nraw;
   // ---- score -----------------------------------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(b->qsurv, 0, nq * sizeof(uint32_t), st));
-  HIP_TRY(hipMemsetAsync(b->qcur, 0, nq * sizeof(uint32_t), st));
   HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
   if (dl->any_variants) HIP_TRY(hipMemsetAsync(b->qexpand, 0, nq * sizeof(uint32_t), st));
   ScoreArgs sa;
@@ -644,6 +643,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors -----------------------------------------------------------------------------
   exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
+  HIP_TRY(hipMemcpyAsync(b->qcur, b->soff, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));  // cursors of k_compact
   uint32_t total_surv = 0;
   HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
@@ -664,7 +664,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   if (surv_fill) {
     CompactArgs ca{m.have_freq ? 1 : 0, dl->any_variants};
     hipLaunchKernelGGL(k_compact, dim3(((surv_fill + 255) / 256) * SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
-                       (uint32_t)b->surv_region_cap, ca, b->soff, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
+                       (uint32_t)b->surv_region_cap, ca, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
                        dl->var_target_freq, dl->var_score, b->c_rows);
   }
   HIP_TRY(hipEventRecord(b->ev[3], st));

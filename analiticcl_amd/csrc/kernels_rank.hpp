@@ -10,7 +10,7 @@ struct CompactArgs {
   int have_freq, any_variants;
 };
 __global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ surv, const uint32_t* __restrict__ sctr,
-                                                 uint32_t region_cap, CompactArgs a, const uint32_t* __restrict__ soff,
+                                                 uint32_t region_cap, CompactArgs a,
                                                  uint32_t* __restrict__ qcur, const EntRec* __restrict__ ent_rec,
                                                  const uint32_t* __restrict__ ent_var_off,
                                                  const uint32_t* __restrict__ var_target,
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ sur
     self = (er.meta & 0x400u) ? 0u : 1u;
   }
   const uint32_t nrows = (v1 - v0) + self;
-  uint32_t pos = soff[q] + atomicAdd(&qcur[q], nrows);
+  uint32_t pos = atomicAdd(&qcur[q], nrows);  // qcur starts as a copy of soff: one random access instead of two
   for (uint32_t j = v0; j < v1; ++j, ++pos) {  // references first, then the item itself (src/lib.rs:1689-1717)
     const uint32_t tf = var_target_freq[j];
     // min(target frequency, own freq_score)
