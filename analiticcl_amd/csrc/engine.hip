@@ -439,6 +439,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
+  if (hipEventCreate(&b->ev_fs0) != hipSuccess || hipEventCreate(&b->ev_fs1) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
   if (hipEventCreate(&b->ev_scan0) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
   lap("device allocations");
   return b;
@@ -625,10 +626,12 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
     fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr;
     const dim3 fgrid(((maxfill + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
+    HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
     if (fastD == 1) hipLaunchKernelGGL(k_filter_score<1>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
     else if (fastD == 2) hipLaunchKernelGGL(k_filter_score<2>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
     else if (fastD == 3) hipLaunchKernelGGL(k_filter_score<3>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
     else hipLaunchKernelGGL(k_filter_score<0>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
+    HIP_TRY(hipEventRecord(b->ev_fs1, st));
     if (need_lists) {  // the list fills are only known on the device: grids cover the fullest pair-list region
       const dim3 lgrid(((maxfill + 255) / 256) * SCAN_REGIONS);
       if (fastD && have_long_q) {
@@ -701,6 +704,8 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   (void)hipEventElapsedTime(&s.ms_rank, b->ev[3], b->ev[4]);
   (void)hipEventElapsedTime(&s.ms_total, b->ev[0], b->ev[4]);
   (void)hipEventElapsedTime(&s.ms_scan_kernel, b->ev_scan0, b->ev[5]);
+  s.ms_filter_score_kernel = 0.0f;
+  if (nraw) (void)hipEventElapsedTime(&s.ms_filter_score_kernel, b->ev_fs0, b->ev_fs1);
   return ANX_OK;
 }
 
@@ -808,6 +813,8 @@ void batch_free(Batch* b) {
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
+  if (b->ev_fs0) (void)hipEventDestroy(b->ev_fs0);
+  if (b->ev_fs1) (void)hipEventDestroy(b->ev_fs1);
   delete b;
 }
 

@@ -129,6 +129,7 @@ struct Batch {
   bool ran = false;
   hipEvent_t ev[6] = {};
   hipEvent_t ev_scan0 = nullptr;   // just before the scan kernels (after the counter memsets)
+  hipEvent_t ev_fs0 = nullptr, ev_fs1 = nullptr;  // around k_filter_score
   anx_batch_stats stats = {};
 };
 

@@ -105,6 +105,7 @@ def main():
     barrier()
     stage_ms = {"ms_scan": 0.0, "ms_group": 0.0, "ms_score": 0.0, "ms_rank": 0.0, "ms_total": 0.0}
     sum_scan_kernel_ms = 0.0
+    sum_fs_kernel_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -112,6 +113,7 @@ def main():
         for k in stage_ms:
             stage_ms[k] += st[k]
         sum_scan_kernel_ms += st["ms_scan_kernel"]
+        sum_fs_kernel_ms += st["ms_filter_score_kernel"]
     barrier()
     elapsed = time.perf_counter() - t0
     st = batch.stats()
@@ -128,14 +130,22 @@ def main():
         for k in stage_ms:
             stage_ms[k] /= max(args.steps, 1)
         # ---- roofline of the dominant kernel (per launch, rank 0) --------------------------------------
-        # The dominant kernel is k_scan_bits (profiles/r01_final_kernel_trace.md).  Its algorithmic bytes per launch
-        # (DESIGN.md section 5): query planes 16 B/query + tile descriptors 36 B/tile + signature table 12 B/signature +
-        # class planes, length and CSR offsets 21 B/class (each once per launch) + pair list out 8 B/pair.
+        # Two kernels take ~40 % each (profiles/r01_final_kernel_trace.md); the one that is slower in THIS run is reported.
+        # Algorithmic bytes per launch:
+        #  k_scan_bits: query planes 16 B/query + tile descriptors 36 B/tile + class record, signature 44 B/class
+        #               (each once per launch) + pair list out 8 B/pair;
+        #  k_filter_score: SURVEY.md section 8(d)'s per-pair figure Lpad + 32 B (pair record 8 + entry row Lpad + entry meta 8
+        #               + result 16) x scored pairs.
         # SURVEY.md section 8(d)'s whole-path figure, pairs*(Lpad+32) + queries*208, is reported next to it as "pipeline".
         lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
         n_classes = model.num_classes()
-        scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 36 + n_classes * (21 + 12) + st["n_pairs"] * 8
-        kname, kbytes, kms = "k_scan_bits", scan_bytes, sum_scan_kernel_ms / max(args.steps, 1)
+        scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 36 + n_classes * 44 + st["n_pairs"] * 8
+        fs_bytes = st["n_pairs"] * (lpad + 32)
+        scan_ms, fs_ms = sum_scan_kernel_ms / max(args.steps, 1), sum_fs_kernel_ms / max(args.steps, 1)
+        if fs_ms > scan_ms:
+            kname, kbytes, kms = "k_filter_score", fs_bytes, fs_ms
+        else:
+            kname, kbytes, kms = "k_scan_bits", scan_bytes, scan_ms
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         pipeline_bytes = st["n_pairs"] * (lpad + 32) + st["n_queries"] * 208
         pipeline_gbs = pipeline_bytes / (stage_ms["ms_total"] * 1e-3) / 1e9 if stage_ms["ms_total"] > 0 else 0.0
@@ -154,12 +164,13 @@ def main():
         roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": kms,
                     "algorithmic_bytes_per_launch": kbytes,
-                    "note": "integer scan path: VALU-issue-bound, far below the HBM roof (DESIGN.md section 5)",
+                    "note": "integer scan / DL path: VALU-issue and L2-gather bound, below the HBM roof (DESIGN.md section 5)",
+                    "kernels_ms": {"k_scan_bits": scan_ms, "k_filter_score": fs_ms},
                     "pipeline_algorithmic_bytes": pipeline_bytes, "pipeline_gbs": pipeline_gbs,
                     "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
                     "scan_valu_issue_floor_ms": valu_floor_ms,
-                    "scan_valu_issue_frac": valu_floor_ms / kms if kms > 0 else 0.0,
-                    "scan_class_tests_per_s": st["n_class_tests"] / (kms * 1e-3) if kms > 0 else 0.0,
+                    "scan_valu_issue_frac": valu_floor_ms / scan_ms if scan_ms > 0 else 0.0,
+                    "scan_class_tests_per_s": st["n_class_tests"] / (scan_ms * 1e-3) if scan_ms > 0 else 0.0,
                     "scan_tests_by_planes": kinds}
         # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
         cpu = None

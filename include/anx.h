@@ -182,6 +182,7 @@ typedef struct anx_batch_stats {
   float ms_scan, ms_group, ms_score, ms_rank, ms_total; /* HIP-event times of the last run (stages incl. read-backs) */
   float ms_scan_kernel;      /* HIP events directly around the k_scan_bits launch (the dominant kernel) */
   uint64_t n_selected;       /* pairs that passed the prefilter and went through the DL kernels */
+  float ms_filter_score_kernel; /* HIP events directly around the k_filter_score launch */
 } anx_batch_stats;
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
 void anx_batch_free(anx_batch *);
