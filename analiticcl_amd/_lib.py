@@ -106,6 +106,10 @@ def lib():
         "anx_model_set_confusables_before_pruning": (None, [vp]),
         "anx_edit_script": (C.c_int, [cp, cp, C.c_char_p, C.c_int]),
         "anx_model_build": (C.c_int, [vp, C.c_int]),
+        "anx_model_save_index": (C.c_int, [vp, cp]),
+        "anx_model_load_index": (C.c_int, [vp, cp, C.c_int]),
+        "anx_model_num_lexicons": (u64, [vp]),
+        "anx_model_lexicon_name": (cp, [vp, u64]),
         "anx_model_to_device": (C.c_int, [vp, C.c_int]),
         "anx_model_has": (C.c_int, [vp, cp]),
         "anx_model_vocab_size": (u64, [vp]),

@@ -194,6 +194,26 @@ int anx_model_build(anx_model* m, int device) {
   if (device < 0) return ANX_OK;
   return anx_model_to_device(m, device);
 }
+int anx_model_save_index(const anx_model* m, const char* path) {
+  if (!m || !path) return fail(ANX_EINVAL, "NULL argument");
+  std::string err;
+  const int rc = m->host.save_index(path, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
+int anx_model_load_index(anx_model* m, const char* path, int device) {
+  if (!m || !path) return fail(ANX_EINVAL, "NULL argument");
+  std::string err;
+  const int rc = m->host.load_index(path, err);
+  if (rc) return fail(rc, err);
+  anx::lexicon_free(m->dev);
+  m->dev = nullptr;
+  if (device < 0) return ANX_OK;
+  return anx_model_to_device(m, device);
+}
+uint64_t anx_model_num_lexicons(const anx_model* m) { return m ? m->host.lexicons.size() : 0; }
+const char* anx_model_lexicon_name(const anx_model* m, uint64_t i) {
+  return (m && i < m->host.lexicons.size()) ? m->host.lexicons[i].c_str() : nullptr;
+}
 int anx_model_has(const anx_model* m, const char* utf8) { return (m && utf8 && m->host.has(utf8)) ? 1 : 0; }
 uint64_t anx_model_vocab_size(const anx_model* m) { return m ? m->host.decoder.size() : 0; }
 const char* anx_model_vocab_text(const anx_model* m, uint64_t id) {

@@ -148,6 +148,8 @@ class HostModel {
                   const anx_vocab_params& p, uint8_t lexicon_index);  // src/lib.rs:460-514
   int read_variants(const char* path, const anx_vocab_params& p, bool transparent, std::string& err);  // :772-897
   int build_index(std::string& err);  // src/lib.rs:192-245
+  int save_index(const std::string& path, std::string& err) const;  // index_cache.cpp: image of the built model
+  int load_index(const std::string& path, std::string& err);        // instead of read_vocabulary + build_index
   bool has(const char* text) const;   // src/lib.rs:331-338
   // encode one string: norm codes (UNK = len+1), hash-class count vector (UNK = len), symbol count
   bool encode(const char* text, std::vector<uint8_t>& norm, std::vector<uint8_t>& cv) const;

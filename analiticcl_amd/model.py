@@ -274,6 +274,16 @@ class VariantModel:
     def build(self):
         L.check(L.lib().anx_model_build(self.h, self.device))
 
+    def save_index(self, filename: str):
+        """Write the built model (vocabulary + the lexicon image the GPU consumes) to disk (anx_model_save_index)."""
+        L.check(L.lib().anx_model_save_index(self.h, _b(filename)))
+
+    def load_index(self, filename: str):
+        """Instead of read_lexicon / read_variants / build: load an image written by save_index for the same alphabet."""
+        L.check(L.lib().anx_model_load_index(self.h, _b(filename), self.device))
+        n = L.lib().anx_model_num_lexicons(self.h) if hasattr(L.lib(), "anx_model_num_lexicons") else 0
+        self.lexicons = [L.lib().anx_model_lexicon_name(self.h, i).decode("utf-8") for i in range(n)]
+
     def to_device(self, device: int):
         self.device = device
         L.check(L.lib().anx_model_to_device(self.h, device))

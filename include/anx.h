@@ -125,6 +125,15 @@ int anx_model_read_variants(anx_model *, const char *path, const anx_vocab_param
  * `device` = HIP device ordinal to upload to; -1 = build the host index only (queries then fail with
  * ANX_ENODEVICE until anx_model_to_device succeeds). */
 int anx_model_build(anx_model *, int device);
+/* On-disk image of a built model: save after anx_model_build; a later run creates the
+ * model with the same alphabet and calls anx_model_load_index INSTEAD of read_vocabulary / read_variants / build
+ * (device >= 0 also makes it resident, like anx_model_build).  The reference has no counterpart: it rebuilds its index
+ * on every start (src/lib.rs:192-245).  Confusables are not part of the image. */
+int anx_model_save_index(const anx_model *, const char *path);
+int anx_model_load_index(anx_model *, const char *path, int device);
+/* names of the lexicons read so far (VariantModel::lexicons, src/lib.rs:84): bit i of a vocab item's lexindex */
+uint64_t anx_model_num_lexicons(const anx_model *);
+const char *anx_model_lexicon_name(const anx_model *, uint64_t i);
 int anx_model_to_device(anx_model *, int device);
 /* has(text), src/lib.rs:331; get_vocab(id), src/lib.rs:341 */
 int anx_model_has(const anx_model *, const char *utf8);

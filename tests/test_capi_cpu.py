@@ -115,3 +115,37 @@ def test_python_api_surface():
         A.SearchParameters(bogus=1)
     p = A.SearchParameters(max_anagram_distance=(0.3, 4), max_edit_distance=0.2)._c()
     assert (p.max_anagram_distance.kind, p.max_anagram_distance.value) == (2, 4) and p.max_edit_distance.kind == 1
+
+
+def test_index_image_roundtrip(data_dir, tmp_path):
+    """anx_model_save_index / anx_model_load_index: the image of a built model reloads to the same vocabulary ids,
+    index statistics and lookups without read_vocabulary / build; wrong alphabets and truncated files are refused."""
+    alphabet = os.path.join(data_dir, "simple.alphabet.tsv")
+    vl = tmp_path / "variants.tsv"
+    vl.write_text("separate\tseperate\t1.0\tseprate\t0.9\n", encoding="utf-8")
+    m = A.VariantModel(alphabet, A.Weights(), device=-1)
+    m.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    m.read_variants(str(vl), transparent=True)
+    m.add_to_vocabulary("the cat", 7, A.VocabParams(vocabtype="LM"))
+    m.build()
+    img = str(tmp_path / "eng.anxidx")
+    m.save_index(img)
+    m2 = A.VariantModel(alphabet, A.Weights(), device=-1)
+    m2.load_index(img)
+    lib = L.lib()
+    assert lib.anx_model_vocab_size(m2.h) == lib.anx_model_vocab_size(m.h)
+    assert m2.num_classes() == m.num_classes() > 108802 and m2.num_instances() == m.num_instances()
+    for c in range(1, 30):
+        assert lib.anx_model_bucket_size(m2.h, c) == lib.anx_model_bucket_size(m.h, c)
+    for vid in (3, 4, 1000, 60000, lib.anx_model_vocab_size(m.h) - 1):
+        assert m2.vocab_text(vid) == m.vocab_text(vid)
+        assert lib.anx_model_vocab_frequency(m2.h, vid) == lib.anx_model_vocab_frequency(m.h, vid)
+    assert "separate" in m2 and "seperate" in m2 and "zzzzzz" not in m2
+    assert m2.lexicons == m.lexicons
+    wrong = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=-1)
+    with pytest.raises(A.AnxError):
+        wrong.load_index(img)
+    data = open(img, "rb").read()
+    open(img, "wb").write(data[: len(data) // 2])
+    with pytest.raises(A.AnxError):
+        A.VariantModel(alphabet, A.Weights(), device=-1).load_index(img)

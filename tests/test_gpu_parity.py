@@ -329,3 +329,16 @@ def test_very_long_strings(data_dir, tmp_path):
                dict(k=("ratio", 0.1), d=("ratio", 0.1), n=20, thr=0.0, cutoff=0.0)):
         gp, op = params_pair(**kw)
         compare_batch(g, o, qs, gp, op)
+
+
+def test_index_image_gives_identical_results(eng, data_dir, tmp_path):
+    """A model loaded from anx_model_save_index's image answers exactly like the one that was built."""
+    g, _ = eng
+    img = str(tmp_path / "eng.anxidx")
+    g.save_index(img)
+    g2 = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g2.load_index(img)
+    qs = synth.make_queries(synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon")), 500, max_len=20, seed=77)
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    assert g2.find_variants_ids(qs, p) == g.find_variants_ids(qs, p)
+    assert g2.find_variants("seperate", p) == g.find_variants("seperate", p)
