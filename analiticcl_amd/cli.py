@@ -111,6 +111,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--weight-variant-model", type=float, default=3.0)
     p.add_argument("--weight-contextrules", type=float, default=1.0)
     p.add_argument("--batch-size", type=int, default=100000, help="query mode: lines per device batch")
+    p.add_argument("--index-cache", default=None, help="image of the built model: loaded if the file exists (lexicons are then not read), written after build() otherwise")
     p.add_argument("--device", type=int, default=None)
     p.add_argument("--single-thread", "-1", action="store_true", help="accepted for compatibility, no effect")
     p.add_argument("--interactive", "-x", action="store_true", help="one device batch per input line")
@@ -120,6 +121,14 @@ def build_parser() -> argparse.ArgumentParser:
 def make_model(a) -> VariantModel:
     weights = Weights(ld=a.weight_ld, lcs=a.weight_lcs, prefix=a.weight_prefix, suffix=a.weight_suffix, case=a.weight_case)
     model = VariantModel(a.alphabet, weights, device=a.device)
+    import os
+    if a.index_cache and os.path.exists(a.index_cache):
+        model.load_index(a.index_cache)
+        for filename in a.confusables:
+            model.read_confusablelist(filename)
+        if a.early_confusables:
+            model.set_confusables_before_pruning()
+        return model
     # resources in command-line order (bin:1020-1068): lexicons, variant lists, error lists
     order = []
     argv = sys.argv
@@ -143,6 +152,8 @@ def make_model(a) -> VariantModel:
     for filename in a.confusables:
         model.read_confusablelist(filename)
     model.build()
+    if a.index_cache:
+        model.save_index(a.index_cache)
     if a.early_confusables:
         model.set_confusables_before_pruning()
     return model
