@@ -91,6 +91,8 @@ static void rescore_with_confusables(const anx::HostModel& m, const std::vector<
 
 extern "C" {
 
+void anx_results_free(anx_result* rows, size_t* offsets);
+
 const char* anx_last_error(void) { return g_err.c_str(); }
 int anx_abi_version(void) { return ANX_ABI_VERSION; }
 
@@ -354,12 +356,48 @@ void anx_batch_free(anx_batch* b) {
 int anx_find_variants_batch(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p,
                             anx_result** out_rows, size_t** out_offsets) {
   if (!out_rows || !out_offsets) return fail(ANX_EINVAL, "NULL output argument");
-  anx_batch* b = anx_batch_encode(m, utf8, n, p);
-  if (!b) return g_code ? g_code : ANX_EINVAL;
-  int rc = anx_batch_run(m, b, nullptr);
-  if (rc == ANX_OK) rc = anx_batch_fetch(b, out_rows, out_offsets);
-  anx_batch_free(b);
-  return rc;
+  // One device batch holds at most 2^31 pair-list slots (~10 M queries of BASELINE config 2): larger calls are run as
+  // consecutive device batches of kMaxQueriesPerBatch inputs and their CSR results concatenated.
+  size_t kMaxQueriesPerBatch = (size_t)4 << 20;
+  if (const char* e = getenv("ANX_MAX_BATCH")) {  // tests
+    const long v = atol(e);
+    if (v > 0) kMaxQueriesPerBatch = (size_t)v;
+  }
+  if (n <= kMaxQueriesPerBatch) {
+    anx_batch* b = anx_batch_encode(m, utf8, n, p);
+    if (!b) return g_code ? g_code : ANX_EINVAL;
+    int rc = anx_batch_run(m, b, nullptr);
+    if (rc == ANX_OK) rc = anx_batch_fetch(b, out_rows, out_offsets);
+    anx_batch_free(b);
+    return rc;
+  }
+  size_t* offs = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
+  anx_result* rows = nullptr;
+  size_t total = 0, cap = 0;
+  if (!offs) return fail(ANX_EINVAL, "out of memory");
+  for (size_t lo = 0; lo < n; lo += kMaxQueriesPerBatch) {
+    const size_t cnt = std::min(kMaxQueriesPerBatch, n - lo);
+    anx_result* r = nullptr;
+    size_t* o = nullptr;
+    const int rc = anx_find_variants_batch(m, utf8 + lo, cnt, p, &r, &o);
+    if (rc != ANX_OK) { free(rows); free(offs); return rc; }
+    const size_t add = o[cnt];
+    if (total + add > cap) {
+      cap = std::max(total + add, cap * 2);
+      anx_result* grown = static_cast<anx_result*>(realloc(rows, std::max<size_t>(1, cap) * sizeof(anx_result)));
+      if (!grown) { free(rows); free(offs); anx_results_free(r, o); return fail(ANX_EINVAL, "out of memory"); }
+      rows = grown;
+    }
+    if (add) memcpy(rows + total, r, add * sizeof(anx_result));
+    for (size_t i = 0; i < cnt; ++i) offs[lo + i] = total + o[i];
+    total += add;
+    anx_results_free(r, o);
+  }
+  offs[n] = total;
+  if (!rows) rows = static_cast<anx_result*>(malloc(sizeof(anx_result)));
+  *out_rows = rows;
+  *out_offsets = offs;
+  return ANX_OK;
 }
 void anx_results_free(anx_result* rows, size_t* offsets) {
   free(rows);

@@ -342,3 +342,24 @@ def test_index_image_gives_identical_results(eng, data_dir, tmp_path):
     p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
     assert g2.find_variants_ids(qs, p) == g.find_variants_ids(qs, p)
     assert g2.find_variants("seperate", p) == g.find_variants("seperate", p)
+
+
+def test_oversized_call_is_split_into_device_batches(eng, data_dir, monkeypatch):
+    """anx_find_variants_batch runs calls above its per-batch limit as consecutive device batches (limit lowered here)."""
+    g, _ = eng
+    qs = synth.make_queries(synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon")), 350, max_len=16, seed=8) + ["", "zzzzqq"]
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+
+    def via_char_pp():  # the char** entry point (the Python Batch class uses the packed one)
+        import ctypes as C
+        from analiticcl_amd import _lib as L
+        arr = (C.c_char_p * len(qs))(*[q.encode() for q in qs])
+        cp = p._c()
+        rows, offs = C.POINTER(L.Result)(), C.POINTER(C.c_size_t)()
+        L.check(L.lib().anx_find_variants_batch(g.h, arr, len(qs), C.byref(cp), C.byref(rows), C.byref(offs)))
+        out = [[(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score) for j in range(offs[i], offs[i + 1])] for i in range(len(qs))]
+        L.lib().anx_results_free(rows, offs)
+        return out
+    whole = via_char_pp()
+    monkeypatch.setenv("ANX_MAX_BATCH", "100")
+    assert via_char_pp() == whole
