@@ -35,14 +35,22 @@ struct WaveOut {
 // Wave-wide exclusive prefix sum of ntot + chunk reservation.  Returns this lane's first index g in the
 // wave's appended run; wave_slot(g) maps run indices to pair-list slots.  A run that does not fit in the
 // rest of the current chunk fills it up and continues in a freshly reserved chunk (ONE atomic).
+// Inclusive prefix sum over the 64 lanes with DPP adds (row_shr 1/2/3, row_shr 4/8 with bank masks, row_bcast 15/31):
+// 7 VALU ops instead of 6 ds_bpermute round trips.
+__device__ inline uint32_t wave_inclusive_scan(uint32_t x) {
+  uint32_t v = x;
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xF, 0xF, false);  // row_shr:3  -> sums of 4 inside each bank group
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xE, false);  // row_shr:4, banks 1-3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xC, false);  // row_shr:8, banks 2-3 -> row (16-lane) prefix
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
 __device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane, uint32_t* total_out) {
-  uint32_t incl = ntot;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t u = __shfl_up(incl, o);
-    if (lane >= (uint32_t)o) incl += u;
-  }
-  const uint32_t total = __shfl(incl, 63);
+  const uint32_t incl = wave_inclusive_scan(ntot);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   *total_out = total;
   w.split = w.left;
   if (total > w.left) {
