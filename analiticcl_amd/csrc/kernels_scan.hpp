@@ -146,7 +146,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   auto process = [&]() {
     ++nchunks;
     if (A.dbg & 2) return;
-    uint32_t cid[CPL], cw[CPL][W], e0r[CPL], ner[CPL];
+    uint32_t cid[CPL], cw[CPL][W];
     int32_t thr[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -159,8 +159,6 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 #pragma unroll
         for (int p = 0; p < W; ++p) cw[j][p] = plw[p];
         lc = (int32_t)mt.x;
-        e0r[j] = mt.y;
-        ner[j] = mt.z;
       } else {
 #pragma unroll
         for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
@@ -207,39 +205,61 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         hm[j] = ~hm[j] & valid;
         any |= hm[j];
       }
-      if (__ballot(any != 0) == 0ull) continue;  // wave-uniform
-      uint32_t e0[CPL], ne[CPL], cnt = 0;
+      if (__ballot(any != 0) == 0ull || (A.dbg & 8)) continue;  // wave-uniform (dbg 8: timing without the expansion)
+      // The non-empty (class, hit mask) pairs of the wave are first compacted into LDS (the chunk's class ids are in
+      // registers by now, so stage[0, CHUNK) is free) and then expanded one list entry per lane: the expansion loop
+      // runs max-over-entries popcount times instead of the sum over the CPL class slots of their per-lane maxima.
+      constexpr uint32_t LCAP = CHUNK / 2;  // (class, mask) entries that fit in stage[0, CHUNK)
+      uint32_t fill = 0;                    // wave-uniform
+      auto flush = [&]() {
+        for (uint32_t r0 = 0; r0 < fill; r0 += 64) {
+          const uint32_t idx = r0 + lane;
+          uint32_t c = 0, m = 0, e0 = 0, ne = 0;
+          if (idx < fill) {
+            c = stage[2 * idx];
+            m = stage[2 * idx + 1];
+            if (BITS) {
+              const uint4 mt = A.cls_rec[2 * (size_t)c + 1];
+              e0 = mt.y;
+              ne = mt.z;
+            } else {
+              e0 = cls_off[c];
+              ne = cls_off[c + 1] - e0;
+            }
+          }
+          uint32_t total;
+          uint32_t g = wave_reserve(wo, (uint32_t)__popc(m) * ne, lane, &total);
+          while (m) {
+            const uint32_t bit = 31u - (uint32_t)__clz((int)m);
+            m &= ~(1u << bit);
+            const uint32_t q = t.q0 + qb + (npass - 1u - bit);
+            // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
+            const uint32_t exact = (A.want_exact && A.qexact[q] == c) ? 0x80000000u : 0u;
+            for (uint32_t i = 0; i < ne; ++i, ++g) {
+              const uint32_t pos = wave_slot(wo, g);
+              if (pos < wo.rend) raw[pos] = make_uint2(q, (e0 + i) | exact);
+            }
+          }
+          wave_commit(wo, total);
+        }
+        fill = 0;
+      };
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        e0[j] = 0;
-        ne[j] = 0;
-        if (hm[j]) {
-          if (BITS) { e0[j] = e0r[j]; ne[j] = ner[j]; }
-          else {
-            e0[j] = cls_off[cid[j]];
-            ne[j] = cls_off[cid[j] + 1] - e0[j];
+        const bool nz = hm[j] != 0;
+        const unsigned long long bm = __ballot(nz);
+        const uint32_t cnt = (uint32_t)__popcll(bm);
+        if (cnt) {  // wave-uniform
+          if (fill + cnt > LCAP) flush();
+          if (nz) {
+            const uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            stage[2 * pos] = cid[j];
+            stage[2 * pos + 1] = hm[j];
           }
-          cnt += (uint32_t)__popc(hm[j]) * ne[j];
+          fill += cnt;
         }
       }
-      uint32_t total;
-      uint32_t g = wave_reserve(wo, cnt, lane, &total);
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        uint32_t m = hm[j];
-        while (m) {
-          const uint32_t bit = 31u - (uint32_t)__clz((int)m);
-          m &= ~(1u << bit);
-          const uint32_t q = t.q0 + qb + (npass - 1u - bit);
-          // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
-          const uint32_t exact = (A.want_exact && A.qexact[q] == cid[j]) ? 0x80000000u : 0u;
-          for (uint32_t i = 0; i < ne[j]; ++i, ++g) {
-            const uint32_t pos = wave_slot(wo, g);
-            if (pos < wo.rend) raw[pos] = make_uint2(q, (e0[j] + i) | exact);
-          }
-        }
-      }
-      wave_commit(wo, total);
+      flush();
     }
   };
 
