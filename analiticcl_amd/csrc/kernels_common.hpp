@@ -16,6 +16,7 @@ struct Tile {           // <= SCAN_TQ queries of one scan kind, one length and o
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
 constexpr uint32_t SCAN_TQ = 64;         // queries per tile (= per wave), compared in passes of 32 (one hit-mask bit each)
+constexpr uint32_t SCAN_HITS = 512;      // per-wave LDS hit list of the scan (entries); expanded when fewer than 256 are free
 constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
 constexpr uint32_t SCAN_REGIONS = 64;     // pair-list regions with one reservation counter each
 constexpr uint32_t RC_STRIDE = 32;        // uint32 words per region counter block (128 B)

@@ -118,7 +118,7 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
 // T == 0: general path (any alphabet size / multiplicity): packed u8 count vectors, NP x v_sad_u8;
 //   hit <=> L1 <= k and L1 < len_q + len_c.
 template <int T, int NP>
-__device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage,
+__device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage, uint32_t* __restrict__ hits,
                                  uint32_t* __restrict__ qlds) {
   constexpr bool BITS = T > 0;
   constexpr int CPL = BITS ? 4 : (NP <= 8 ? 4 : NP <= 16 ? 2 : 1);  // classes per lane
@@ -139,6 +139,44 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     const uint32_t* __restrict__ src = (BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE;
     for (uint32_t i = lane; i < t.nq * QSTRIDE; i += 64) qlds[i] = src[i];
   }
+
+  uint32_t nhits = 0;  // entries in the hit list (wave-uniform)
+  // expands the hit list into (query, entry) pairs, one list entry per lane and round
+  auto flush = [&]() {
+    for (uint32_t r0 = 0; r0 < nhits; r0 += 64) {
+      const uint32_t idx = r0 + lane;
+      uint32_t c = 0, m = 0, e0 = 0, ne = 0, qb = 0;
+      if (idx < nhits) {
+        c = hits[2 * idx];
+        m = hits[2 * idx + 1];
+        qb = (c >> 27) << 5;
+        c &= (1u << 27) - 1u;
+        if (BITS) {
+          const uint4 mt = A.cls_rec[2 * (size_t)c + 1];
+          e0 = mt.y;
+          ne = mt.z;
+        } else {
+          e0 = cls_off[c];
+          ne = cls_off[c + 1] - e0;
+        }
+      }
+      uint32_t total;
+      uint32_t g = wave_reserve(wo, (uint32_t)__popc(m) * ne, lane, &total);
+      while (m) {
+        const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+        m &= m - 1u;
+        const uint32_t q = t.q0 + qb + bit;
+        // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
+        const uint32_t exact = (A.want_exact && A.qexact[q] == c) ? 0x80000000u : 0u;
+        for (uint32_t i = 0; i < ne; ++i, ++g) {
+          const uint32_t pos = wave_slot(wo, g);
+          if (pos < wo.rend) raw[pos] = make_uint2(q, (e0 + i) | exact);
+        }
+      }
+      wave_commit(wo, total);
+    }
+    nhits = 0;
+  };
 
   // compares the first CHUNK staged classes (padded with the never-matching class) with every query of the tile, 32
   // queries per pass; bit (npass-1-qi) of hm[j] = query qi of the pass hits class j of this lane.  The query loop is
@@ -206,60 +244,24 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         any |= hm[j];
       }
       if (__ballot(any != 0) == 0ull || (A.dbg & 8)) continue;  // wave-uniform (dbg 8: timing without the expansion)
-      // The non-empty (class, hit mask) pairs of the wave are first compacted into LDS (the chunk's class ids are in
-      // registers by now, so stage[0, CHUNK) is free) and then expanded one list entry per lane: the expansion loop
-      // runs max-over-entries popcount times instead of the sum over the CPL class slots of their per-lane maxima.
-      constexpr uint32_t LCAP = CHUNK / 2;  // (class, mask) entries that fit in stage[0, CHUNK)
-      uint32_t fill = 0;                    // wave-uniform
-      auto flush = [&]() {
-        for (uint32_t r0 = 0; r0 < fill; r0 += 64) {
-          const uint32_t idx = r0 + lane;
-          uint32_t c = 0, m = 0, e0 = 0, ne = 0;
-          if (idx < fill) {
-            c = stage[2 * idx];
-            m = stage[2 * idx + 1];
-            if (BITS) {
-              const uint4 mt = A.cls_rec[2 * (size_t)c + 1];
-              e0 = mt.y;
-              ne = mt.z;
-            } else {
-              e0 = cls_off[c];
-              ne = cls_off[c + 1] - e0;
-            }
-          }
-          uint32_t total;
-          uint32_t g = wave_reserve(wo, (uint32_t)__popc(m) * ne, lane, &total);
-          while (m) {
-            const uint32_t bit = 31u - (uint32_t)__clz((int)m);
-            m &= ~(1u << bit);
-            const uint32_t q = t.q0 + qb + (npass - 1u - bit);
-            // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
-            const uint32_t exact = (A.want_exact && A.qexact[q] == c) ? 0x80000000u : 0u;
-            for (uint32_t i = 0; i < ne; ++i, ++g) {
-              const uint32_t pos = wave_slot(wo, g);
-              if (pos < wo.rend) raw[pos] = make_uint2(q, (e0 + i) | exact);
-            }
-          }
-          wave_commit(wo, total);
-        }
-        fill = 0;
-      };
+      // The non-empty (class, hit mask) pairs are appended to the wave's LDS hit list; flush() expands the list one
+      // entry per lane whenever it gets full (and at the end of the tile), so the expansion rounds run with full
+      // waves and the loop runs max-over-entries popcount times.  Mask bit b = query qb + b of the tile.
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         const bool nz = hm[j] != 0;
         const unsigned long long bm = __ballot(nz);
         const uint32_t cnt = (uint32_t)__popcll(bm);
         if (cnt) {  // wave-uniform
-          if (fill + cnt > LCAP) flush();
           if (nz) {
-            const uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-            stage[2 * pos] = cid[j];
-            stage[2 * pos + 1] = hm[j];
+            const uint32_t pos = nhits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            hits[2 * pos] = cid[j] | ((qb >> 5) << 27);
+            hits[2 * pos + 1] = __brev(hm[j]) >> (32u - npass);  // shift-in order -> bit b = query b of the pass
           }
-          fill += cnt;
+          nhits += cnt;
         }
       }
-      flush();
+      if (nhits > SCAN_HITS - CHUNK) flush();  // a pass adds at most CHUNK entries
     }
   };
 
@@ -299,6 +301,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     }
   }
   if (ns) process();
+  flush();
   wave_close(wo, lane, raw);
   if (lane == 0 && nchunks)
     atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * T), (unsigned long long)nchunks * CHUNK * t.nq);
@@ -313,6 +316,7 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
   __shared__ uint32_t s_stage[4][SCAN_STAGE];
+  __shared__ uint32_t s_hits[4][2 * SCAN_HITS];  // per wave: (class | pass << 27, hit mask) entries awaiting expansion
   const uint32_t wid = threadIdx.x >> 6;
   const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wid));
   if (item >= A.ntiles) return;
@@ -323,13 +327,13 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   uint32_t* stage = s_stage[wid];
   if (BITS) {
     switch (t.kind) {
-      case 1: scan_tile<1, NP>(A, t, item, stage, qlds); break;
-      case 2: scan_tile<2, NP>(A, t, item, stage, qlds); break;
-      case 3: scan_tile<3, NP>(A, t, item, stage, qlds); break;
-      default: scan_tile<4, NP>(A, t, item, stage, qlds); break;
+      case 1: scan_tile<1, NP>(A, t, item, stage, s_hits[wid], qlds); break;
+      case 2: scan_tile<2, NP>(A, t, item, stage, s_hits[wid], qlds); break;
+      case 3: scan_tile<3, NP>(A, t, item, stage, s_hits[wid], qlds); break;
+      default: scan_tile<4, NP>(A, t, item, stage, s_hits[wid], qlds); break;
     }
   } else {
-    scan_tile<0, NP>(A, t, item, stage, qlds);
+    scan_tile<0, NP>(A, t, item, stage, s_hits[wid], qlds);
   }
 }
 // <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
