@@ -322,57 +322,78 @@ struct PairArgs {  // what every scoring kernel reads / writes
   uint32_t* qexpand;
 };
 
+// Loads the pair of slot p into registers (NW words per string); returns false for !active.
+template <int NW>
+struct PairRegs {
+  uint32_t q = 0, e = 0, qm = 0, em = 0;
+  int lq = 0, lc = 0, d = 0;
+  uint32_t S[NW], T[NW];
+};
+template <int NW>
+__device__ inline void load_pair(uint32_t p, bool active, const PairArgs& A, const ScoreArgs& a, PairRegs<NW>& r) {
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { r.S[w] = 0xFEFEFEFEu; r.T[w] = 0xFFFFFFFFu; }
+  if (!active) return;
+  const uint2 rp = A.raw[p];
+  r.q = rp.x;
+  r.e = rp.y & 0x7FFFFFFFu;
+  const uint4 Q0 = A.q_rec[2 * (size_t)r.q], QM = A.q_rec[2 * (size_t)r.q + 1];
+  const uint4 C0 = A.e_rec[2 * (size_t)r.e], CM = A.e_rec[2 * (size_t)r.e + 1];
+  r.qm = QM.x;
+  r.em = CM.x;
+  r.lq = r.qm & 0xFF; r.d = (r.qm >> 16) & 0xFF; r.lc = r.em & 0xFF;
+  r.S[0] = Q0.x; r.S[1] = Q0.y; r.S[2] = Q0.z; r.S[3] = Q0.w;
+  r.T[0] = C0.x; r.T[1] = C0.y; r.T[2] = C0.z; r.T[3] = C0.w;
+  const uint4* qr = A.q_rows + (size_t)r.q * a.qw;
+  const uint4* cr = A.rows + CM.y;
+#pragma unroll
+  for (int w = 1; w < NW / 4; ++w) {
+    if (w * 16 < r.lq) { const uint4 Q = qr[w]; r.S[4 * w] = Q.x; r.S[4 * w + 1] = Q.y; r.S[4 * w + 2] = Q.z; r.S[4 * w + 3] = Q.w; }
+    if (w * 16 < r.lc) { const uint4 C = cr[w]; r.T[4 * w] = C.x; r.T[4 * w + 1] = C.y; r.T[4 * w + 2] = C.z; r.T[4 * w + 3] = C.w; }
+  }
+}
+// DL of the loaded pair (all lanes of the wave call this); PAIR_NONE if above the pair's d
+template <int D, int NW>
+__device__ inline uint32_t dl_of_pair(const PairRegs<NW>& r, bool active) {
+  int lqmax = active ? r.lq : 0;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) lqmax = max(lqmax, __shfl_xor(lqmax, o));
+  lqmax = __builtin_amdgcn_readfirstlane(lqmax);
+  const uint32_t res = dl_band<D, NW>(r.S, r.T, active ? r.lq : 0, r.lc, lqmax);
+  const int diff = r.lq > r.lc ? r.lq - r.lc : r.lc - r.lq;
+  return (active && diff <= r.d && res <= (uint32_t)r.d) ? res : PAIR_NONE;  // src/distance.rs:109-130, 173-178
+}
+// tail of a DL survivor (ld != PAIR_NONE for has) + outputs; all lanes of the wave call this
+template <int NW>
+__device__ inline void tail_of_pair(uint32_t p, bool has, uint32_t ld, const PairRegs<NW>& r, const PairArgs& A, const ScoreArgs& a,
+                                    const SurvOut& so, uint32_t surv_region, uint32_t* __restrict__ lds) {
+  uint32_t lcs = 0, pre = 0, suf = 0, samecase = 1;
+  double score = __builtin_nan("");
+  bool keep = false;
+  if (has && !(a.dbg & 2)) {
+    uint32_t* mine = lds + (threadIdx.x & 255) * (2 * NW + 1);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { mine[w] = r.S[w]; mine[NW + w] = r.T[w]; }
+    score = score_tail(reinterpret_cast<const uint8_t*>(mine), reinterpret_cast<const uint8_t*>(mine + NW), r.lq, r.lc, ld, r.qm,
+                       r.em, r.q, r.e, a, A.ent_freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, lcs, pre, suf, samecase, keep);
+  }
+  surv_append(so, surv_region, keep, r.q, r.e, score);
+  if (has) {
+    A.p_score[p] = score;
+    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+  }
+}
+
 // Scores the pair in slot p with the register-resident DL of NW words (all lanes of the wave call this; lanes with
 // !active only take part in the wave-wide steps).  lds: per-lane staging of both strings for the byte-wise tail.
 template <int D, int NW>
 __device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& A, const ScoreArgs& a, const SurvOut& so,
                                        uint32_t surv_region, uint32_t* __restrict__ lds) {
-  uint32_t q = 0, e = 0, qm = 0, em = 0;
-  int lq = 0, lc = 0, d = 0;
-  uint32_t S[NW], T[NW];
-#pragma unroll
-  for (int w = 0; w < NW; ++w) { S[w] = 0xFEFEFEFEu; T[w] = 0xFFFFFFFFu; }
-  if (active) {
-    const uint2 rp = A.raw[p];
-    q = rp.x;
-    e = rp.y & 0x7FFFFFFFu;
-    const uint4 Q0 = A.q_rec[2 * (size_t)q], QM = A.q_rec[2 * (size_t)q + 1];
-    const uint4 C0 = A.e_rec[2 * (size_t)e], CM = A.e_rec[2 * (size_t)e + 1];
-    qm = QM.x;
-    em = CM.x;
-    lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
-    S[0] = Q0.x; S[1] = Q0.y; S[2] = Q0.z; S[3] = Q0.w;
-    T[0] = C0.x; T[1] = C0.y; T[2] = C0.z; T[3] = C0.w;
-    const uint4* qr = A.q_rows + (size_t)q * a.qw;
-    const uint4* cr = A.rows + CM.y;
-#pragma unroll
-    for (int w = 1; w < NW / 4; ++w) {
-      if (w * 16 < lq) { const uint4 Q = qr[w]; S[4 * w] = Q.x; S[4 * w + 1] = Q.y; S[4 * w + 2] = Q.z; S[4 * w + 3] = Q.w; }
-      if (w * 16 < lc) { const uint4 C = cr[w]; T[4 * w] = C.x; T[4 * w + 1] = C.y; T[4 * w + 2] = C.z; T[4 * w + 3] = C.w; }
-    }
-  }
-  int lqmax = active ? lq : 0;
-#pragma unroll
-  for (int o = 32; o; o >>= 1) lqmax = max(lqmax, __shfl_xor(lqmax, o));
-  lqmax = __builtin_amdgcn_readfirstlane(lqmax);
-  const uint32_t res = dl_band<D, NW>(S, T, active ? lq : 0, lc, lqmax);
-  uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
-  double score = __builtin_nan("");
-  bool keep = false;
-  const int diff = lq > lc ? lq - lc : lc - lq;
-  if (active && diff <= d && res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:109-130, 173-178
-    uint32_t* mine = lds + (threadIdx.x & 255) * (2 * NW + 1);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { mine[w] = S[w]; mine[NW + w] = T[w]; }
-    ld = res;
-    score = score_tail(reinterpret_cast<const uint8_t*>(mine), reinterpret_cast<const uint8_t*>(mine + NW), lq, lc, ld, qm, em,
-                       q, e, a, A.ent_freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, lcs, pre, suf, samecase, keep);
-  }
-  surv_append(so, surv_region, keep, q, e, score);
-  if (active) {
-    A.p_score[p] = score;
-    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
-  }
+  PairRegs<NW> r;
+  load_pair<NW>(p, active, A, a, r);
+  const uint32_t ld = dl_of_pair<D, NW>(r, active);
+  if (active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+  tail_of_pair<NW>(p, ld != PAIR_NONE, ld, r, A, a, so, surv_region, lds);
 }
 
 // K2+K3 fused: prefilter of every pair-list slot and register-resident DL of the selected pairs, one block per
@@ -470,11 +491,44 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   if (lane == 0 && nselected) atomicAdd(&f.stat_ctr[region * RC_STRIDE + 1], nselected);
   __syncthreads();
   if (D > 0) {
+    // Phase 2a: DL of the queued pairs, 256 per round.  Survivors (ld <= d, ~30 % of the queue) are queued again, in
+    // place: entries [0, s_m) of s_q = slot offset | ld << 12 (s_m never overtakes the read position; a barrier
+    // separates a round's reads from its writes).  Phase 2b: LCS / prefix / suffix / score of the survivors in dense
+    // rounds -- the tail costs as much as the DL itself and would otherwise run with a third of its lanes.
+    constexpr int DD = D > 0 ? D : 1;
     const uint32_t n = s_n;
+    __shared__ uint32_t s_m;
+    if (threadIdx.x == 0) s_m = 0;
     for (uint32_t r0 = 0; r0 < n; r0 += 256) {  // block-uniform trip count
       const uint32_t i = r0 + threadIdx.x;
       const bool active = i < n;
-      score_fast_pair<(D > 0 ? D : 1), 4>(active ? (region << f.region_shift) + base + s_q[i] : 0u, active, A, a, so, region, s_str);
+      const uint32_t off = active ? s_q[i] : 0u;
+      __syncthreads();
+      const uint32_t p = (region << f.region_shift) + base + off;
+      PairRegs<4> r;
+      load_pair<4>(p, active, A, a, r);
+      const uint32_t ld = dl_of_pair<DD, 4>(r, active);
+      if (active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+      const bool surv = ld != PAIR_NONE;
+      const unsigned long long ms = __ballot(surv);
+      if (ms) {  // wave-uniform
+        const int first = __ffsll((long long)ms) - 1;
+        uint32_t qb = 0;
+        if ((int)lane == first) qb = atomicAdd(&s_m, (uint32_t)__popcll(ms));
+        qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
+        if (surv) s_q[qb + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))] = (uint16_t)(off | (ld << 12));
+      }
+    }
+    __syncthreads();
+    const uint32_t m = s_m;
+    for (uint32_t r0 = 0; r0 < m; r0 += 256) {
+      const uint32_t i = r0 + threadIdx.x;
+      const bool active = i < m;
+      const uint32_t ent = active ? s_q[i] : 0u;
+      const uint32_t p = (region << f.region_shift) + base + (ent & 0xFFFu);
+      PairRegs<4> r;
+      load_pair<4>(p, active, A, a, r);
+      tail_of_pair<4>(p, active, ent >> 12, r, A, a, so, region, s_str);
     }
   }
 }
