@@ -426,19 +426,23 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
   nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, 1));
   nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, 2));
   nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
-  if (nmax <= 16) {
+  {  // the queries with <= 16 candidate rows: side by side, 16 lanes each (the others are skipped here)
     const int grp = lane >> 4, gl = lane & 15;
     // per group: 16 keys (8 B), 16 order keys (8 B), 16 freqs (4 B), 16 source rows (2 B), 16 + 16 ranked heads (8 B) = 608 B
     uint8_t* gb = wl + grp * 608;
-    rank_query<16, 16>(qbase + grp, qbase + grp < nq, gl, grp * 16, 16u, reinterpret_cast<double*>(gb),
+    const uint32_t ng = (uint32_t)__shfl((int)my_n, grp);
+    rank_query<16, 16>(qbase + grp, qbase + grp < nq && ng <= 16u, gl, grp * 16, 16u, reinterpret_cast<double*>(gb),
                        reinterpret_cast<unsigned long long*>(gb + 128), reinterpret_cast<uint32_t*>(gb + 256),
                        reinterpret_cast<uint16_t*>(gb + 320), reinterpret_cast<double*>(gb + 352), reinterpret_cast<double*>(gb + 480),
-                       (uint32_t)__shfl((int)my_seg0, grp), (uint32_t)__shfl((int)my_n, grp), (uint32_t)__shfl((int)my_maxf, grp),
+                       (uint32_t)__shfl((int)my_seg0, grp), ng, (uint32_t)__shfl((int)my_maxf, grp),
                        (uint32_t)__shfl((int)my_qex, grp), c_rows, a, t_key, r_rows, r_count);
-  } else {
+  }
+  if (nmax > 16) {  // wave-uniform: the longer lists one after the other, 64 lanes each
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (int k = 0; k < RANK_QPW; ++k) {
       if (qbase + k >= nq) break;  // wave-uniform
       const uint32_t nk = (uint32_t)__builtin_amdgcn_readlane((int)my_n, k);
+      if (nk <= 16u) continue;     // wave-uniform: done above
       rank_query<64, RANK_LCAP>(qbase + k, true, lane, 0, nk, reinterpret_cast<double*>(wl),
                                 reinterpret_cast<unsigned long long*>(wl + RANK_LCAP * 8),
                                 reinterpret_cast<uint32_t*>(wl + RANK_LCAP * 16), reinterpret_cast<uint16_t*>(wl + RANK_LCAP * 20),
