@@ -215,7 +215,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       uint32_t hm[CPL];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) hm[j] = 0xFFFFFFFFu;  // miss bits
-      for (uint32_t qi = 0; qi < npass; ++qi) {
+      auto test_query = [&](uint32_t qi) {  // one query against the lane's CPL classes: shifts one bit into every hm[j]
         uint32_t qreg[W];
 #pragma unroll
         for (int p = 0; p < W; ++p) qreg[p] = qlds[(qb + qi) * QSTRIDE + p];
@@ -234,7 +234,13 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
           }
           hm[j] = __builtin_amdgcn_alignbit(hm[j], (uint32_t)acc, 31);  // (hm << 1) | sign(acc)
         }
+      };
+      uint32_t qi = 0;
+      for (; qi + 2 <= npass; qi += 2) {  // two queries per trip: half the loop overhead, both LDS reads in flight
+        test_query(qi);
+        test_query(qi + 1);
       }
+      if (qi < npass) test_query(qi);
       // expand the hits of this pass into (query, entry) pairs
       const uint32_t valid = npass >= 32u ? 0xFFFFFFFFu : ((1u << npass) - 1u);
       uint32_t any = 0;
