@@ -363,3 +363,40 @@ def test_oversized_call_is_split_into_device_batches(eng, data_dir, monkeypatch)
     whole = via_char_pp()
     monkeypatch.setenv("ANX_MAX_BATCH", "100")
     assert via_char_pp() == whole
+
+
+@pytest.mark.parametrize("nclasses", [40, 70, 110, 150])
+def test_large_alphabets_take_the_count_vector_kernel(nclasses, tmp_path):
+    """Alphabets with more than 31 classes cannot use the 32-bit thermometer planes: every tile runs k_scan_sad<NP>
+    (NP = 16, 24, 32, 42 count-vector words).  Synthetic words over a nclasses-letter alphabet vs the oracle."""
+    rng = random.Random(nclasses)
+    letters = ([chr(c) for c in range(0x3B1, 0x3B1 + 25)] + [chr(c) for c in range(0x430, 0x430 + 32)] +
+               [chr(c) for c in range(ord("a"), ord("z") + 1)] + [chr(c) for c in range(0x5D0, 0x5D0 + 27)] +
+               [chr(c) for c in range(0x561, 0x561 + 38)] + [chr(c) for c in range(0x10D0, 0x10D0 + 33)])
+    letters = letters[:nclasses]
+    assert len(letters) == nclasses
+    tsv = "\n".join(letters) + "\n"
+    words = sorted({"".join(rng.choice(letters[: max(8, nclasses // 3)] if rng.random() < 0.5 else letters)
+                            for _ in range(rng.randrange(2, 12))) for _ in range(6000)})
+    g = A.VariantModel("", alphabet_text=tsv, device=0)
+    o = O.OracleModel(alphabet_text=tsv)
+    for w in words:
+        g.add_to_vocabulary(w)
+        o.add(w)
+    g.build()
+    o.build()
+    qs = []
+    for _ in range(300):
+        cs = list(rng.choice(words))
+        for _ in range(rng.randrange(0, 3)):
+            op = rng.randrange(3)
+            if op == 0 and len(cs) > 1:
+                del cs[rng.randrange(len(cs))]
+            elif op == 1:
+                cs.insert(rng.randrange(len(cs) + 1), rng.choice(letters))
+            else:
+                cs[rng.randrange(len(cs))] = rng.choice(letters)
+        qs.append("".join(cs))
+    gp, op = params_pair(("abs", 3), ("abs", 2), 10, 0.2, 2.0)
+    st = compare_batch(g, o, qs, gp, op)
+    assert st["n_tests_kind"][0] > 0 and sum(st["n_tests_kind"][1:]) == 0
