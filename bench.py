@@ -26,6 +26,15 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def baseline_metric() -> str:
+    """BASELINE.json's metric string, verbatim."""
+    try:
+        with open(os.path.join(REPO, "BASELINE.json"), encoding="utf-8") as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "scored (query,candidate) pairs/sec + queries/sec, 200k-lexicon, len\u226416, 1/2/4/8 GPU"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +206,7 @@ def main():
                    "sample": f"first {sample} of the same {args.queries} queries, C oracle (oracle/anx_oracle.c), "
                              f"OpenMP dynamic schedule, {ncores} threads, {dt:.1f} s"}
         out = {
-            "metric": "scored (query,candidate) pairs/sec + queries/sec, 200k-lexicon, len<=16",
+            "metric": baseline_metric(),
             "value": pairs * args.steps / elapsed, "unit": "pairs/s",
             "queries_per_s": nq * args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
