@@ -7,6 +7,8 @@
 
 #include "engine.h"
 #include <algorithm>
+#include <thread>
+#include <atomic>
 
 #include "host_model.h"
 
@@ -46,47 +48,73 @@ static void rescore_with_confusables(const anx::HostModel& m, const std::vector<
                                      anx_result* rows, size_t* offs) {
   const float fw = p.freq_weight;
   const bool early = m.confusables_before_pruning;
-  size_t w = 0, prev_end = 0;
-  for (size_t i = 0; i < inputs.size(); ++i) {
-    const size_t b0 = prev_end, e0 = offs[i + 1];
-    prev_end = e0;
-    std::vector<anx_result> v(rows + b0, rows + e0);
-    // the weight belongs to the matched item: the variant itself for rows reached through a variant list
-    for (anx_result& r : v) r.dist_score *= m.confusable_weight(inputs[i], r.via != ANX_NO_VIA ? r.via : r.vocab_id);
-    std::stable_sort(v.begin(), v.end(), [&](const anx_result& a, const anx_result& b) {  // rank_cmp, src/types.rs:344-365
-      if (fw > 0.0f) return vr_score(a, fw) > vr_score(b, fw);
-      if (a.dist_score != b.dist_score) return a.dist_score > b.dist_score;
-      return a.freq_score > b.freq_score;
-    });
-    size_t len = v.size();
-    if (early && p.max_matches > 0 && len > p.max_matches) {  // crop with the tie rule
-      const size_t mm = (size_t)p.max_matches;
-      const double last = vr_score(v[mm - 1], fw), cropped = vr_score(v[mm], fw);
-      if (cropped < last) len = mm;
-      else {
-        size_t early_cut = 0, late_cut = 0;
-        for (size_t k = 0; k < v.size(); ++k) {
-          if (v[k].dist_score == cropped && early_cut == 0) early_cut = k;
-          if (v[k].dist_score < cropped) { late_cut = k; break; }
+  const size_t n = inputs.size();
+  std::vector<size_t> newlen(n, 0);
+  // every input is independent: edit scripts, re-ranking and cut-off on host threads, in place inside the input's row range
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      anx_result* v = rows + offs[i];
+      const size_t cnt = offs[i + 1] - offs[i];
+      // the weight belongs to the matched item: the variant itself for rows reached through a variant list
+      for (size_t k = 0; k < cnt; ++k) v[k].dist_score *= m.confusable_weight(inputs[i], v[k].via != ANX_NO_VIA ? v[k].via : v[k].vocab_id);
+      std::stable_sort(v, v + cnt, [&](const anx_result& a, const anx_result& b) {  // rank_cmp, src/types.rs:344-365
+        if (fw > 0.0f) return vr_score(a, fw) > vr_score(b, fw);
+        if (a.dist_score != b.dist_score) return a.dist_score > b.dist_score;
+        return a.freq_score > b.freq_score;
+      });
+      size_t len = cnt;
+      if (early && p.max_matches > 0 && len > p.max_matches) {  // crop with the tie rule
+        const size_t mm = (size_t)p.max_matches;
+        const double last = vr_score(v[mm - 1], fw), cropped = vr_score(v[mm], fw);
+        if (cropped < last) len = mm;
+        else {
+          size_t early_cut = 0, late_cut = 0;
+          for (size_t k = 0; k < cnt; ++k) {
+            if (v[k].dist_score == cropped && early_cut == 0) early_cut = k;
+            if (v[k].dist_score < cropped) { late_cut = k; break; }
+          }
+          if (early_cut > 0) len = early_cut + 1;
+          else if (late_cut > 0) len = late_cut + 1;
         }
-        if (early_cut > 0) len = early_cut + 1;
-        else if (late_cut > 0) len = late_cut + 1;
       }
-    }
-    if (p.cutoff_threshold >= 1.0) {
-      bool have = false;
-      double best = 0.0;
-      for (size_t k = 0; k < len; ++k) {
-        const double s = vr_score(v[k], fw);
-        if (have) {
-          if (s <= best / p.cutoff_threshold) { len = k; break; }
-        } else { best = s; have = true; }
+      if (p.cutoff_threshold >= 1.0) {
+        bool have = false;
+        double best = 0.0;
+        for (size_t k = 0; k < len; ++k) {
+          const double s = vr_score(v[k], fw);
+          if (have) {
+            if (s <= best / p.cutoff_threshold) { len = k; break; }
+          } else { best = s; have = true; }
+        }
       }
+      newlen[i] = len;
     }
-    offs[i] = w;
-    for (size_t k = 0; k < len; ++k) rows[w++] = v[k];
+  };
+  unsigned nthreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  if (n < 256) nthreads = 1;
+  if (nthreads == 1) work(0, n);
+  else {
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    const size_t chunk = 256;
+    for (unsigned t = 0; t < nthreads; ++t)
+      th.emplace_back([&]() {
+        for (;;) {
+          const size_t lo = next.fetch_add(chunk);
+          if (lo >= n) break;
+          work(lo, std::min(n, lo + chunk));
+        }
+      });
+    for (auto& x : th) x.join();
   }
-  offs[inputs.size()] = w;
+  size_t w = 0;  // compact the shortened lists
+  for (size_t i = 0; i < n; ++i) {
+    const size_t b0 = offs[i];
+    offs[i] = w;
+    if (w != b0) memmove(rows + w, rows + b0, newlen[i] * sizeof(anx_result));
+    w += newlen[i];
+  }
+  offs[n] = w;
 }
 
 extern "C" {
