@@ -587,6 +587,16 @@ void HostModel::build_lm() {
       else if (ng.size() == 2) bigrams[(ng[0] << 32) | (ng[1] & 0xFFFFFFFFull)] += decoder[id].frequency;
     }
   have_lm = !ngrams.empty();
+  ngram_off.assign(1, 0u);
+  ngram_ids.clear();
+  if (have_lm) {
+    ngram_off.reserve(decoder.size() + 1);
+    for (size_t id = 0; id < decoder.size(); ++id) {
+      if (into_ngram(id, ng))
+        for (uint64_t t : ng) ngram_ids.push_back((uint32_t)t);
+      ngram_off.push_back((uint32_t)ngram_ids.size());
+    }
+  }
 }
 
 bool HostModel::has(const char* text) const {

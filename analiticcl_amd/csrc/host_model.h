@@ -136,6 +136,9 @@ class HostModel {
   bool have_lm = false;
   std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
   std::unordered_map<uint64_t, uint32_t> unigrams, bigrams;  // the two orders lm_score_tokens looks up (id, id1 << 32 | id2)
+  // into_ngram of every vocabulary item, precomputed (CSR; an item with more than 5 tokens has no tokens): the lattice
+  // rerank asks for it once per symbol of each of up to max_seq paths
+  std::vector<uint32_t> ngram_off, ngram_ids;
   LexiconImage lex;
   std::unordered_map<std::string, uint32_t> class_of_cv;  // count vector bytes -> class rank
 

@@ -7,6 +7,7 @@
 // orders are processed one after another.
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <thread>
 #include <chrono>
 #include <cmath>
@@ -29,12 +30,22 @@ namespace {
 
 using anx::HostModel;
 
+struct RowView {  // the ranked variants of a segment: a range of one n-gram order's result array (kept until the end)
+  const anx_result* p = nullptr;
+  size_t n = 0;
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  const anx_result& operator[](size_t i) const { return p[i]; }
+  const anx_result* begin() const { return p; }
+  const anx_result* end() const { return p + n; }
+};
+
 struct Span {  // Match without variants (boundaries, segments); byte offsets into the text
   Span(size_t b, size_t e) : begin(b), end(e) {}
   size_t begin, end;
   uint32_t n = 0;
   int64_t var_slot = -1;  // index into the per-order result table (-1: no lookup done => variants = None)
-  std::vector<anx_result> variants;
+  RowView variants;
   bool has_variants = false;  // Some(vec) vs None
   int selected = -1;
 };
@@ -144,20 +155,22 @@ void lm_score_tokens(const HostModel& m, const std::vector<int64_t>& tokens, flo
 // lm_score (src/lib.rs:2580-2629)
 void lm_score(const HostModel& m, const char* text, const std::vector<OutSym>& seq, const Span* bs, float* lp, double* ppl) {
   std::vector<int64_t> tokens;
-  std::vector<uint64_t> ng;
+  auto push_item = [&](uint64_t id) {  // into_ngram(id), precomputed by build_lm
+    for (uint32_t k = m.ngram_off[id]; k < m.ngram_off[id + 1]; ++k) tokens.push_back((int64_t)m.ngram_ids[k]);
+  };
   tokens.push_back(0);  // BOS
   for (const OutSym& o : seq) {
     if (o.vocab_id == 0) tokens.push_back(-1);
-    else if (m.into_ngram(o.vocab_id, ng))
-      for (uint64_t t : ng) tokens.push_back((int64_t)t);
+    else push_item(o.vocab_id);
     const Span& nb = bs[o.boundary_index];
-    const std::string bt = anx::trim_whitespace(std::string(text + nb.begin, nb.end - nb.begin));
-    if (!bt.empty()) {
-      auto it = m.encoder.find(bt);
-      if (it != m.encoder.end()) {
-        if (m.into_ngram(it->second, ng))
-          for (uint64_t t : ng) tokens.push_back((int64_t)t);
-      } else tokens.push_back(-1);
+    // the boundary text, trimmed, as a token of its own (src/lib.rs:2600-2620); a single space needs no string
+    if (!(nb.end - nb.begin == 1 && text[nb.begin] == ' ') && nb.end > nb.begin) {
+      const std::string bt = anx::trim_whitespace(std::string(text + nb.begin, nb.end - nb.begin));
+      if (!bt.empty()) {
+        auto it = m.encoder.find(bt);
+        if (it != m.encoder.end()) push_item(it->second);
+        else tokens.push_back(-1);
+      }
     }
   }
   tokens.push_back(1);  // EOS
@@ -201,24 +214,32 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   if (symbols.size() == 1 || finals.empty()) { out.insert(out.end(), matches.begin(), matches.end()); return; }
   // k-best paths into every state, kept as back-pointers (source state, rank there, symbol); states are in
   // topological order by index, so best[s] is final (sorted, cut to K) before it is expanded.
-  struct Node { float cost; uint32_t ps, pr; long sym; };
+  struct Node { float cost; uint32_t ps, pr; long sym; uint32_t seq; };
   const size_t K = std::max<uint32_t>(1, p.max_seq);
   std::vector<std::vector<Node>> best(nstates);
-  best[0].push_back(Node{0.0f, UINT32_MAX, 0, -1});  // the start node
-  auto by_cost = [](const Node& a, const Node& b) { return a.cost < b.cost; };
+  best[0].push_back(Node{0.0f, UINT32_MAX, 0, -1, 0});  // the start node
+  // the K cheapest candidates in stable order (= stable sort by cost, cut at K): selection by (cost, insertion index)
+  // costs O(n) for the n >> K candidates of a state instead of O(n log n)
+  auto keep_k_best = [K](std::vector<Node>& v) {
+    for (size_t i = 0; i < v.size(); ++i) v[i].seq = (uint32_t)i;
+    auto cmp = [](const Node& a, const Node& b) { return a.cost < b.cost || (a.cost == b.cost && a.seq < b.seq); };
+    if (v.size() > K) {
+      std::nth_element(v.begin(), v.begin() + (long)K, v.end(), cmp);
+      v.resize(K);
+    }
+    std::sort(v.begin(), v.end(), cmp);
+  };
   for (size_t s = 0; s < nstates; ++s) {
     if (best[s].empty()) continue;
-    std::stable_sort(best[s].begin(), best[s].end(), by_cost);
-    if (best[s].size() > K) best[s].resize(K);
+    keep_k_best(best[s]);
     for (const Arc& a : arcs[s])
       for (size_t r = 0; r < best[s].size(); ++r)
-        best[a.dst].push_back(Node{best[s][r].cost + a.cost, (uint32_t)s, (uint32_t)r, a.sym});
+        best[a.dst].push_back(Node{best[s][r].cost + a.cost, (uint32_t)s, (uint32_t)r, a.sym, 0});
   }
   struct Path { float cost; std::vector<long> syms; };
   std::vector<Node> ends;
   for (size_t f : finals) ends.insert(ends.end(), best[f].begin(), best[f].end());
-  std::stable_sort(ends.begin(), ends.end(), by_cost);
-  if (ends.size() > K) ends.resize(K);
+  keep_k_best(ends);
   std::vector<Path> paths(ends.size());
   for (size_t i = 0; i < ends.size(); ++i) {
     paths[i].cost = ends[i].cost;
@@ -308,34 +329,73 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
       }
   }
   lap("boundaries");
-  // one device batch per n-gram order
+  // one device batch per n-gram order; the result arrays stay alive until the output has been written
+  struct OrderRows { anx_result* rows; size_t* offs; };
+  std::vector<OrderRows> kept;
+  auto free_kept = [&]() { for (OrderRows& o : kept) anx_results_free(o.rows, o.offs); kept.clear(); };
+  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  auto parallel_stretches = [&](const std::function<void(size_t, size_t)>& work) {
+    const size_t ns = stretches.size();
+    if (ns < 256 || hw == 1) { work(0, ns); return; }
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    const size_t chunk = 64;
+    for (unsigned t = 0; t < hw; ++t)
+      th.emplace_back([&]() {
+        for (;;) {
+          const size_t lo = next.fetch_add(chunk);
+          if (lo >= ns) break;
+          work(lo, std::min(ns, lo + chunk));
+        }
+      });
+    for (auto& x : th) x.join();
+  };
   for (uint32_t order = 1; order <= sp->max_ngram; ++order) {
     std::vector<std::vector<Span>> cur(stretches.size());
-    std::vector<std::string> seg_text;
-    std::vector<std::pair<size_t, size_t>> seg_ref;  // (stretch, index in cur[stretch])
-    for (size_t si = 0; si < stretches.size(); ++si) {
-      Stretch& st = stretches[si];
-      const char* text = texts[st.text_index];
-      find_match_ngrams(text, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, cur[si]);
+    std::vector<std::vector<uint8_t>> lookup(stretches.size());  // per segment: goes to the device (not redundant)
+    parallel_stretches([&](size_t lo, size_t hi) {
+      for (size_t si = lo; si < hi; ++si) {
+        Stretch& st = stretches[si];
+        find_match_ngrams(texts[st.text_index], bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, cur[si]);
+        lookup[si].resize(cur[si].size());
+        for (size_t k = 0; k < cur[si].size(); ++k) lookup[si][k] = (order == 1 || !redundant_match(cur[si][k], st.matches)) ? 1 : 0;
+      }
+    });
+    // all segments of this order in one NUL-separated arena
+    size_t nseg = 0, bytes = 0;
+    for (size_t si = 0; si < stretches.size(); ++si)
       for (size_t k = 0; k < cur[si].size(); ++k)
-        if (order == 1 || !redundant_match(cur[si][k], st.matches)) {
-          seg_text.emplace_back(text + cur[si][k].begin, cur[si][k].end - cur[si][k].begin);
-          seg_ref.emplace_back(si, k);
-        }
-    }
-    if (!seg_text.empty()) {
-      std::vector<const char*> ptrs(seg_text.size());
-      for (size_t i = 0; i < seg_text.size(); ++i) ptrs[i] = seg_text[i].c_str();
+        if (lookup[si][k]) { ++nseg; bytes += cur[si][k].end - cur[si][k].begin + 1; }
+    if (nseg) {
+      std::string arena;
+      arena.reserve(bytes);
+      std::vector<size_t> seg_off;
+      seg_off.reserve(nseg);
+      for (size_t si = 0; si < stretches.size(); ++si) {
+        const char* text = texts[stretches[si].text_index];
+        for (size_t k = 0; k < cur[si].size(); ++k)
+          if (lookup[si][k]) {
+            seg_off.push_back(arena.size());
+            arena.append(text + cur[si][k].begin, cur[si][k].end - cur[si][k].begin);
+            arena.push_back('\0');
+          }
+      }
+      std::vector<const char*> ptrs(nseg);
+      for (size_t i = 0; i < nseg; ++i) ptrs[i] = arena.data() + seg_off[i];
       anx_result* rows = nullptr;
       size_t* offs = nullptr;
-      const int rc = anx_find_variants_batch(model, ptrs.data(), ptrs.size(), &sp->base, &rows, &offs);
-      if (rc != ANX_OK) return rc;
-      for (size_t i = 0; i < seg_ref.size(); ++i) {
-        Span& s = cur[seg_ref[i].first][seg_ref[i].second];
-        s.has_variants = true;
-        s.variants.assign(rows + offs[i], rows + offs[i + 1]);
-      }
-      anx_results_free(rows, offs);
+      const int rc = anx_find_variants_batch(model, ptrs.data(), nseg, &sp->base, &rows, &offs);
+      if (rc != ANX_OK) { free_kept(); return rc; }
+      kept.push_back(OrderRows{rows, offs});
+      size_t i = 0;
+      for (size_t si = 0; si < stretches.size(); ++si)
+        for (size_t k = 0; k < cur[si].size(); ++k)
+          if (lookup[si][k]) {
+            Span& sg = cur[si][k];
+            sg.has_variants = true;
+            sg.variants = RowView{rows + offs[i], offs[i + 1] - offs[i]};
+            ++i;
+          }
     }
     for (size_t si = 0; si < stretches.size(); ++si)
       stretches[si].matches.insert(stretches[si].matches.end(), cur[si].begin(), cur[si].end());
@@ -385,7 +445,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, total) * sizeof(anx_match)));
   size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
   anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, total_rows) * sizeof(anx_result)));
-  if (!om || !oo || !orows) { free(om); free(oo); free(orows); return anx_fail(ANX_EINVAL, "out of memory"); }
+  if (!om || !oo || !orows) { free(om); free(oo); free(orows); free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
   size_t w = 0, rw = 0;
   for (size_t t = 0; t < n; ++t) {
     oo[t] = w;
@@ -415,6 +475,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     }
   }
   oo[n] = w;
+  free_kept();
   lap("output");
   *out_matches = om;
   *out_offsets = oo;
