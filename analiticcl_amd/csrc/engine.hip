@@ -720,27 +720,25 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
   anx_result* out = static_cast<anx_result*>(malloc(std::max<size_t>(1, b->n_results) * sizeof(anx_result)));
   if (!off || !out) { free(off); free(out); err = "out of memory"; return ANX_EINVAL; }
   if (b->nq && b->n_results) {
-    DevRow* d_rows = nullptr;
-    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_rows), b->n_results * sizeof(DevRow)));
-    hipLaunchKernelGGL(k_pack_rows, dim3(((uint32_t)b->nq + 255) / 256), dim3(256), 0, 0, (uint32_t)b->nq, b->soff,
-                       b->r_off, b->r_count, b->r_rows, d_rows);
-    std::vector<DevRow> h(b->n_results);
-    std::vector<uint32_t> h_cnt(b->nq);
-    HIP_TRY(hipMemcpy(h.data(), d_rows, b->n_results * sizeof(DevRow), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_cnt.data(), b->r_count, b->nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    pool_free(d_rows);
-    for (size_t s = 0; s < b->nq; ++s) off[b->order[s] + 1] = h_cnt[s];
-    for (size_t i = 0; i < n; ++i) off[i + 1] += off[i];
-    size_t src = 0;
-    for (size_t s = 0; s < b->nq; ++s) {
-      size_t dst = off[b->order[s]];
-      for (uint32_t i = 0; i < h_cnt[s]; ++i, ++src, ++dst) {
-        out[dst].vocab_id = h[src].vocab_id;
-        out[dst].dist_score = h[src].dist_score;
-        out[dst].freq_score = h[src].freq_score;
-        out[dst].via = h[src].via == 0xFFFFFFFFu ? ANX_NO_VIA : (uint64_t)h[src].via;
-      }
-    }
+    // the device lays the rows out in the caller's input order (counts scattered to the original indices, exclusive
+    // scan, row copy), so the host only copies: offsets (u32) and the finished anx_result array
+    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_tmp = nullptr;
+    anx_result* d_out = nullptr;
+    const uint32_t n32 = (uint32_t)n, nq32 = (uint32_t)b->nq;
+    const size_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE + 2;
+    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_cnt), n * sizeof(uint32_t)));
+    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_off), (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_tmp), nblk * sizeof(uint32_t)));
+    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_out), b->n_results * sizeof(anx_result)));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, n * sizeof(uint32_t), 0));
+    hipLaunchKernelGGL(k_fetch_counts, dim3((nq32 + 255) / 256), dim3(256), 0, 0, nq32, b->r_count, b->q_orig, d_cnt);
+    exclusive_scan(d_cnt, n32, d_off, d_tmp, 0);
+    hipLaunchKernelGGL(k_fetch_rows, dim3((nq32 + 255) / 256), dim3(256), 0, 0, nq32, b->soff, b->r_count, b->r_rows, b->q_orig, d_off, d_out);
+    std::vector<uint32_t> h_off(n + 1);
+    HIP_TRY(hipMemcpy(h_off.data(), d_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out, b->n_results * sizeof(anx_result), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i <= n; ++i) off[i] = h_off[i];
+    for (void* p : {(void*)d_cnt, (void*)d_off, (void*)d_tmp, (void*)d_out}) pool_free(p);
   }
   *rows = out;
   *offs = off;

@@ -464,6 +464,28 @@ __global__ __launch_bounds__(256) void k_pack_rows(uint32_t nq, const uint32_t* 
   const uint32_t n = r_count[q], src = soff[q], dst = r_off[q];
   for (uint32_t i = 0; i < n; ++i) out[dst + i] = r_rows[src + i];
 }
+// download path: result rows in the CALLER's input order, ready to be copied into the anx_result array
+__global__ __launch_bounds__(256) void k_fetch_counts(uint32_t nq, const uint32_t* __restrict__ r_count,
+                                                      const uint32_t* __restrict__ q_orig, uint32_t* __restrict__ cnt_orig) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s < nq) cnt_orig[q_orig[s]] = r_count[s];
+}
+__global__ __launch_bounds__(256) void k_fetch_rows(uint32_t nq, const uint32_t* __restrict__ soff, const uint32_t* __restrict__ r_count,
+                                                    const DevRow* __restrict__ r_rows, const uint32_t* __restrict__ q_orig,
+                                                    const uint32_t* __restrict__ off_orig, anx_result* __restrict__ out) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nq) return;
+  const uint32_t n = r_count[s], src = soff[s], dst = off_orig[q_orig[s]];
+  for (uint32_t i = 0; i < n; ++i) {
+    const DevRow d = r_rows[src + i];
+    anx_result r;
+    r.vocab_id = d.vocab_id;
+    r.dist_score = d.dist_score;
+    r.freq_score = d.freq_score;
+    r.via = d.via == 0xFFFFFFFFu ? ANX_NO_VIA : (uint64_t)d.via;
+    out[dst + i] = r;
+  }
+}
 __global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t stride, const uint32_t* __restrict__ soff,
                                                      const uint32_t* __restrict__ r_count,
                                                      const DevRow* __restrict__ r_rows,
