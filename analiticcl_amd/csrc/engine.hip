@@ -373,7 +373,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     static const uint32_t tq = []() { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }();
     for (size_t s = i; s < j; s += tq)
       b->tiles.push_back(Tile{(uint32_t)s, (uint32_t)std::min<size_t>(tq, j - s), s0, s1, k, lq, (uint32_t)h_sig[i],
-                              (uint32_t)(h_sig[i] >> 32), kind});
+                              (uint32_t)(h_sig[i] >> 32), kind, (h_meta[i] >> 16) & 0xFFu});
     i = j;
   }
   // longest-processing-time-first: cost ~ queries (the compatible classes per query vary little inside a length)
@@ -504,6 +504,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint32_t nq = (uint32_t)b->nq;
   b->ran = false;
+  b->ran_keep_all = b->keep_all_pairs || b->params.stop_at_exact_match;
   b->n_pairs = b->n_results = b->n_surv = 0;
   b->n_raw = 0;
   if (nq == 0) { b->ran = true; return ANX_OK; }
@@ -526,6 +527,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cls_rec = dl->cls_rec; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
       A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_cbeg = dl->sig_cbeg;
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
+      A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
       { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
       const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
       switch (dl->nplanes) {
@@ -745,11 +747,19 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
   return ANX_OK;
 }
 
-int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_pair** out, size_t* n,
+int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* cb, anx_pair** out, size_t* n,
                       std::string& err) {
-  (void)m;
-  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
-  HIP_TRY(hipSetDevice(b->device));
+  if (!cb->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  HIP_TRY(hipSetDevice(cb->device));
+  if (!cb->ran_keep_all) {
+    // the production run only counts the pairs that fail the DL's length test; this debug view lists every pair, so the
+    // batch is run once more with all of them materialised (same results, same statistics)
+    Batch* mb = const_cast<Batch*>(cb);
+    mb->keep_all_pairs = true;
+    const int rc = batch_run(m, dl, mb, nullptr, err);
+    if (rc) return rc;
+  }
+  const Batch* b = cb;
   const size_t R = b->n_raw;
   anx_pair* res = static_cast<anx_pair*>(malloc(std::max<size_t>(1, (size_t)b->n_pairs) * sizeof(anx_pair)));
   if (!res) { err = "out of memory"; return ANX_EINVAL; }

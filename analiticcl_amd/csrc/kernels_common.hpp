@@ -12,6 +12,7 @@ struct Tile {           // <= SCAN_TQ queries of one scan kind, one length and o
   uint32_t lq;          // query length in symbols
   uint32_t sig_lo, sig_hi;  // the tile's signature (per-group symbol counts, one byte each)
   uint32_t kind;        // 0 = SAD body, 1..NBITPLANES = bit-plane body with T = kind
+  uint32_t d;           // clamped edit distance for this length
 };
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
@@ -128,6 +129,8 @@ struct Batch {
   uint64_t n_sel = 0;
   uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
   bool ran = false;
+  bool keep_all_pairs = false;     // also materialise the pairs whose lengths differ by more than d (debug fetch of every pair)
+  bool ran_keep_all = false;       // what the last run did
   hipEvent_t ev[6] = {};
   hipEvent_t ev_scan0 = nullptr;   // just before the scan kernels (after the counter memsets)
   hipEvent_t ev_fs0 = nullptr, ev_fs1 = nullptr;  // around k_filter_score

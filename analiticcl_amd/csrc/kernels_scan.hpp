@@ -102,6 +102,8 @@ struct ScanArgs {
   uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
   const uint32_t* qexact;  // per query: class id of its exact anagram class (0xFFFFFFFF = none); stop mode only
   int want_exact;
+  int drop_len;             // do not materialise pairs with |len_q - len_c| > d: damerau_levenshtein returns None for them at its
+                            // first test (src/distance.rs:109-130); they are only counted as scored pairs
   int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
 };
 
@@ -141,6 +143,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   }
 
   uint32_t nhits = 0;  // entries in the hit list (wave-uniform)
+  uint32_t counted_only = 0;  // per lane: pairs dropped by the length test (they still count as scored pairs)
   // expands the hit list into (query, entry) pairs, one list entry per lane and round
   auto flush = [&]() {
     for (uint32_t r0 = 0; r0 < nhits; r0 += 64) {
@@ -151,13 +154,21 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         m = hits[2 * idx + 1];
         qb = (c >> 27) << 5;
         c &= (1u << 27) - 1u;
+        uint32_t lc;
         if (BITS) {
           const uint4 mt = A.cls_rec[2 * (size_t)c + 1];
+          lc = mt.x;
           e0 = mt.y;
           ne = mt.z;
         } else {
+          lc = cls_len[c];
           e0 = cls_off[c];
           ne = cls_off[c + 1] - e0;
+        }
+        const uint32_t diff = lc > t.lq ? lc - t.lq : t.lq - lc;
+        if (A.drop_len && diff > t.d) {  // every pair of this class fails the length test of the DL: count, do not emit
+          counted_only += (uint32_t)__popc(m) * ne;
+          m = 0;
         }
       }
       uint32_t total;
@@ -308,6 +319,10 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   }
   if (ns) process();
   flush();
+  if (A.drop_len) {  // wave sum of the counted-only pairs -> RC_VALID (n_pairs = every DL invocation of the reference)
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(counted_only), 63);
+    wo.emitted += tot;
+  }
   wave_close(wo, lane, raw);
   if (lane == 0 && nchunks)
     atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * T), (unsigned long long)nchunks * CHUNK * t.nq);
@@ -328,7 +343,7 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   if (item >= A.ntiles) return;
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
-  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8];
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9];
   uint32_t* qlds = s_qlds[wid];
   uint32_t* stage = s_stage[wid];
   if (BITS) {

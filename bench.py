@@ -149,7 +149,8 @@ def main():
         lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
         n_classes = model.num_classes()
         scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 36 + n_classes * 44 + st["n_pairs"] * 8
-        fs_bytes = st["n_pairs"] * (lpad + 32)
+        # pairs that fail the DL's length test are counted by the scan but never materialised: only the slots the kernel reads
+        fs_bytes = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
         scan_ms, fs_ms = sum_scan_kernel_ms / max(args.steps, 1), sum_fs_kernel_ms / max(args.steps, 1)
         if fs_ms > scan_ms:
             kname, kbytes, kms = "k_filter_score", fs_bytes, fs_ms
