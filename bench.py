@@ -202,7 +202,13 @@ def main():
             t = time.perf_counter()
             rc, _res, _counts, cpairs, _ccls = om.find_variants_batch(queries[:sample], op, nthreads=ncores, stride=16)
             dt = time.perf_counter() - t
+            # one thread as well: a short prefix of the same sample, ~5 s
+            n1 = int(max(64, min(sample, (sample / dt) / ncores * 5.0 * 4)))
+            t = time.perf_counter()
+            _rc, _r, _c, cpairs1, _cc = om.find_variants_batch(queries[:n1], op, nthreads=1, stride=16)
+            dt1 = time.perf_counter() - t
             cpu = {"value": cpairs / dt, "unit": "pairs/s", "cores": ncores, "kind": "port",
+                   "single_thread": {"value": cpairs1 / dt1, "queries_per_s": n1 / dt1, "sample": f"first {n1} queries, {dt1:.1f} s"},
                    "queries_per_s": sample / dt,
                    "sample": f"first {sample} of the same {args.queries} queries, C oracle (oracle/anx_oracle.c), "
                              f"OpenMP dynamic schedule, {ncores} threads, {dt:.1f} s"}
