@@ -90,7 +90,7 @@ static void rescore_with_confusables(const anx::HostModel& m, const std::vector<
       newlen[i] = len;
     }
   };
-  unsigned nthreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  unsigned nthreads = std::max(1u, std::min(64u, anx::usable_hw_threads()));
   if (n < 256) nthreads = 1;
   if (nthreads == 1) work(0, n);
   else {

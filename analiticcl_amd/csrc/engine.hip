@@ -256,7 +256,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     uint64_t sig;    // per-group symbol counts (LexiconImage::sym_group)
   };
   std::vector<Enc> enc(n);
-  unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  unsigned nthreads = std::max(1u, std::min(32u, usable_hw_threads()));
   if (n < 4096) nthreads = 1;
   std::vector<std::vector<uint8_t>> arena(nthreads);
   const int A = m.alphabet.size();

@@ -1,6 +1,10 @@
 // host_model.cpp -- see host_model.h.  Host-only code (no HIP here).
 #include "host_model.h"
 
+#include <sched.h>
+
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -402,6 +406,30 @@ static int pick_planes(int nsym) {  // kernel variants are instantiated for thes
   for (int v : {8, 16, 24, 32, 42})
     if (need <= v) return v;
   return -1;
+}
+
+unsigned usable_hw_threads() {
+  static const unsigned cached = []() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+      char q[32];
+      long period = 0;
+      if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+        const long quota = atol(q);
+        if (quota > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, (quota + period - 1) / period));
+      }
+      fclose(f);
+    } else {
+      long quota = -1, period = 0;
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+      if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, (quota + period - 1) / period));
+    }
+    return n;
+  }();
+  return cached;
 }
 
 uint64_t signature_of(const uint8_t* cv, size_t n, const std::vector<uint8_t>& sym_group) {

@@ -41,6 +41,9 @@ bool first_char_is_lowercase(const char* utf8);  // char::is_lowercase on text.c
 bool is_alphabetic_cp(uint32_t cp);              // char::is_alphabetic (L* + Nl; see oracle/gen_unicode.py)
 uint32_t utf8_decode_at(const char* s, size_t avail, int* len);
 std::string trim_whitespace(const std::string& s);  // str::trim()
+// Host threads worth starting: hardware threads, limited by the affinity mask and the cgroup CPU quota (the GPU boxes
+// show 256 hardware threads and grant 16 CPUs).
+unsigned usable_hw_threads();
 
 struct VariantRef {  // VariantReference, src/types.rs:315-324
   bool variant_of;  // true = VariantOf((id, score)), false = ReferenceFor((id, score))

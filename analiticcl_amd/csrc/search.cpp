@@ -333,7 +333,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   struct OrderRows { anx_result* rows; size_t* offs; };
   std::vector<OrderRows> kept;
   auto free_kept = [&]() { for (OrderRows& o : kept) anx_results_free(o.rows, o.offs); kept.clear(); };
-  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned hw = std::max(1u, std::min(64u, anx::usable_hw_threads()));
   auto parallel_stretches = [&](const std::function<void(size_t, size_t)>& work) {
     const size_t ns = stretches.size();
     if (ns < 256 || hw == 1) { work(0, ns); return; }
@@ -415,7 +415,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
           for (Span& s : st.matches) { s.selected = 0; decoded[si].push_back(std::move(s)); }
       }
     };
-    unsigned nthreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    unsigned nthreads = std::max(1u, std::min(64u, anx::usable_hw_threads()));
     if (stretches.size() < 64) nthreads = 1;
     if (nthreads == 1) work(0, stretches.size());
     else {
