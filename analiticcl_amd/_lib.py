@@ -48,13 +48,18 @@ class Result(C.Structure):
 
 
 class SearchParams(C.Structure):
-    _fields_ = [("base", Params), ("max_ngram", C.c_uint32), ("max_seq", C.c_uint32), ("lm_weight", C.c_float),
+    _fields_ = [("base", Params), ("max_ngram", C.c_uint8), ("max_seq", C.c_uint32), ("lm_weight", C.c_float),
                 ("variantmodel_weight", C.c_float), ("contextrules_weight", C.c_float), ("unicodeoffsets", C.c_int32)]
 
 
 class Match(C.Structure):
     _fields_ = [("begin", C.c_size_t), ("end", C.c_size_t), ("n", C.c_uint32), ("selected", C.c_int32),
-                ("var_begin", C.c_size_t), ("var_end", C.c_size_t)]
+                ("var_begin", C.c_size_t), ("var_end", C.c_size_t), ("tag_begin", C.c_uint32),
+                ("tag_end", C.c_uint32)]
+
+
+class MatchTag(C.Structure):
+    _fields_ = [("tag", C.c_uint16), ("seqnr", C.c_uint8), ("_pad", C.c_uint8)]
 
 
 class Pair(C.Structure):
@@ -128,8 +133,13 @@ def lib():
         "anx_default_search_params": (None, [C.POINTER(SearchParams)]),
         "anx_find_all_matches_batch": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(SearchParams),
                                                  C.POINTER(C.POINTER(Match)), C.POINTER(C.POINTER(sz)),
-                                                 C.POINTER(C.POINTER(Result)), C.POINTER(sz)]),
-        "anx_matches_free": (None, [C.POINTER(Match), C.POINTER(sz), C.POINTER(Result)]),
+                                                 C.POINTER(C.POINTER(Result)), C.POINTER(sz),
+                                                 C.POINTER(C.POINTER(MatchTag))]),
+        "anx_matches_free": (None, [C.POINTER(Match), C.POINTER(sz), C.POINTER(Result), C.POINTER(MatchTag)]),
+        "anx_model_add_contextrule": (C.c_int, [vp, cp, C.c_float, C.POINTER(cp), sz, C.POINTER(cp), sz]),
+        "anx_model_read_contextrules": (C.c_int, [vp, cp]),
+        "anx_model_num_tags": (sz, [vp]),
+        "anx_model_tag_name": (cp, [vp, sz]),
         "anx_batch_encode": (vp, [vp, C.POINTER(cp), sz, C.POINTER(Params)]),
         "anx_batch_encode_packed": (vp, [vp, C.c_char_p, sz, sz, C.POINTER(Params)]),
         "anx_batch_run": (C.c_int, [vp, vp, vp]),

@@ -4,7 +4,7 @@
 Same option names and defaults (note the CLI's own weight defaults 0.5/0.125/0.125/0.125/0.125, bin:760-800, and
 k=3 d=2 n=10, bin:800-817), same TSV / JSON output (bin:21-187).  `query` reads one input per line and runs every
 `--batch-size` lines as ONE device batch (the reference: 1000-line rayon batches, bin:416-448); `search` groups lines
-into texts like bin:561-636 and decodes them with find_all_matches.  Not mirrored: learn / index modes, context rules,
+into texts like bin:561-636 and decodes them with find_all_matches.  Not mirrored: learn / index modes,
 --interactive buffering semantics (output is flushed per batch), --progress.  `--unicode-offsets` is accepted and,
 as in the reference (the flag is looked up under the wrong name, bin:1175), has no effect."""
 import argparse
@@ -54,11 +54,14 @@ def tsv_line(inp: str, variants: Optional[List[dict]], offset=None, output_lexma
     return "".join(out)
 
 
-def json_item(inp: str, variants: Optional[List[dict]], seqnr: int, offset=None, output_lexmatch=False) -> str:
+def json_item(inp: str, variants: Optional[List[dict]], seqnr: int, offset=None, output_lexmatch=False,
+              tag=(), tag_seqnr=()) -> str:
     """output_matches_as_json / output_result_as_json (bin:78-187)."""
     out = ["    ," if seqnr > 1 else "    ", '{ "input": "%s"' % _esc(inp)]
     if offset is not None:
         out.append(f', "begin": {offset[0]}, "end": {offset[1]}')
+    if tag:  # bin:99-121
+        out.append(', "tag": [%s], "seqnr": [ %s]' % (",".join('"%s"' % t for t in tag), ",".join(str(n) for n in tag_seqnr)))
     if variants is None:
         out.append(" }\n")
         return "".join(out)
@@ -87,6 +90,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--alphabet", "-a", required=True)
     p.add_argument("--confusables", "-C", action="append", default=[])
     p.add_argument("--early-confusables", action="store_true")
+    p.add_argument("--contextrules", "-R", action="append", default=[])
     p.add_argument("--lm", action="append", default=[])
     p.add_argument("--output-lexmatch", action="store_true")
     p.add_argument("--json", "-j", action="store_true")
@@ -126,6 +130,8 @@ def make_model(a) -> VariantModel:
         model.load_index(a.index_cache)
         for filename in a.confusables:
             model.read_confusablelist(filename)
+        for filename in a.contextrules:
+            model.read_contextrules(filename)
         if a.early_confusables:
             model.set_confusables_before_pruning()
         return model
@@ -151,6 +157,8 @@ def make_model(a) -> VariantModel:
         model.read_vocabulary(filename, VocabParams(vocabtype="LM"))
     for filename in a.confusables:
         model.read_confusablelist(filename)
+    for filename in a.contextrules:  # bin:1097-1109
+        model.read_contextrules(filename)
     model.build()
     if a.index_cache:
         model.save_index(a.index_cache)
@@ -233,7 +241,7 @@ def run_search(model, params, a, out) -> None:
             off = (m["offset"]["begin"], m["offset"]["end"])
             variants = m["variants"]
             if a.json:
-                out.write(json_item(m["input"], variants, seqnr, off, a.output_lexmatch))
+                out.write(json_item(m["input"], variants, seqnr, off, a.output_lexmatch, m.get("tag", ()), m.get("seqnr", ())))
             else:
                 out.write(tsv_line(m["input"], variants, off, a.output_lexmatch) + "\n")
         out.flush()

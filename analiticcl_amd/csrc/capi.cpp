@@ -292,6 +292,26 @@ int anx_model_read_confusablelist(anx_model* m, const char* path) {
   const int rc = m->host.read_confusablelist(path, err);
   return rc ? fail(rc, err) : ANX_OK;
 }
+int anx_model_add_contextrule(anx_model* m, const char* pattern, float score, const char* const* tags, size_t n_tags,
+                              const char* const* tagoffsets, size_t n_tagoffsets) {
+  if (!m || !pattern || (!tags && n_tags) || (!tagoffsets && n_tagoffsets)) return fail(ANX_EINVAL, "NULL argument");
+  std::vector<std::string> t, o;
+  for (size_t i = 0; i < n_tags; ++i) t.emplace_back(tags[i] ? tags[i] : "");
+  for (size_t i = 0; i < n_tagoffsets; ++i) o.emplace_back(tagoffsets[i] ? tagoffsets[i] : "");
+  std::string err;
+  const int rc = m->host.add_contextrule(pattern, score, t, o, err);
+  return rc == ANX_OK ? ANX_OK : fail(rc, err);
+}
+int anx_model_read_contextrules(anx_model* m, const char* path) {
+  if (!m || !path) return fail(ANX_EINVAL, "NULL argument");
+  std::string err;
+  const int rc = m->host.read_contextrules(path, err);
+  return rc == ANX_OK ? ANX_OK : fail(rc, err);
+}
+size_t anx_model_num_tags(const anx_model* m) { return m ? m->host.tags.size() : 0; }
+const char* anx_model_tag_name(const anx_model* m, size_t index) {
+  return m && index < m->host.tags.size() ? m->host.tags[index].c_str() : nullptr;
+}
 void anx_model_set_confusables_before_pruning(anx_model* m) {
   if (m) m->host.confusables_before_pruning = true;
 }

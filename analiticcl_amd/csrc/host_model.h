@@ -121,8 +121,37 @@ struct Confusable {  // src/confusables.rs:5-11; one edit-script pattern with '|
 };
 std::string edit_script_string(const std::string& source, const std::string& target);  // sesdiff notation, for tests
 
+// Context rules (src/search.rs:338-524): a pattern over the (vocab id, lexicon mask) pairs of a candidate sequence with a
+// bonus (> 1) or penalty (< 1) score and optional tags.
+struct PatternMatch {  // src/search.rs:339-353
+  enum Kind : uint8_t { Vocab, Any, NoLexicon, FromLexicon, Not, Disjunction } kind = Any;
+  uint64_t vocab_id = 0;   // Vocab
+  uint8_t lexicon = 0;     // FromLexicon
+  std::vector<PatternMatch> sub;  // Not (one), Disjunction (any)
+  bool matches(uint64_t vocab_id, uint32_t lexindex) const;  // src/search.rs:373-411
+};
+struct ContextRule {  // src/search.rs:355-364
+  std::vector<PatternMatch> pattern;
+  float score = 1.0f;
+  std::vector<uint16_t> tag;
+  std::vector<std::pair<uint8_t, uint8_t>> tagoffset;  // begin, length
+};
+struct PatternMatchResult {  // src/search.rs:366-371
+  float score;
+  int32_t tag;  // -1 = None
+  uint8_t seqnr;
+};
+
 class HostModel {
  public:
+  std::vector<ContextRule> context_rules;  // src/lib.rs:82
+  std::vector<std::string> tags;           // src/lib.rs:84
+  int add_contextrule(const std::string& pattern, float score, const std::vector<std::string>& tag,
+                      const std::vector<std::string>& tagoffset, std::string& err);  // src/lib.rs:658-765
+  int read_contextrules(const std::string& path, std::string& err);                  // src/lib.rs:570-656
+  // test_context_rules (src/lib.rs:2501-2578) over the (vocab id, lexindex) pairs of one candidate sequence
+  double test_context_rules(const std::vector<std::pair<uint64_t, uint32_t>>& sequence,
+                            std::vector<std::vector<PatternMatchResult>>& results) const;
   Alphabet alphabet;
   anx_weights weights;
   int debug = 0;

@@ -1,6 +1,6 @@
 // search.cpp -- search mode: the caller of the hot path.
 // Host-side restatement of VariantModel::find_all_matches (/root/reference/src/lib.rs:1790-1957), the text
-// segmentation of src/search.rs:190-336 and the sequence decoding of src/lib.rs:2088-2495 (without context rules),
+// segmentation of src/search.rs:190-336 and the sequence decoding of src/lib.rs:2088-2495 (context rules: contextrules.cpp),
 // re-organised so that ALL segments of one n-gram order -- over every hard-boundary stretch of every input text --
 // go to the device as ONE anx_find_variants_batch call (the reference calls find_variants once per segment from a
 // rayon par_iter, src/lib.rs:1883-1899).  Order n depends on the unigram results through redundant_match, so the
@@ -48,6 +48,7 @@ struct Span {  // Match without variants (boundaries, segments); byte offsets in
   RowView variants;
   bool has_variants = false;  // Some(vec) vs None
   int selected = -1;
+  std::vector<std::pair<uint16_t, uint8_t>> tags;  // Match.tag / Match.seqnr (src/search.rs:60-66), set by context rules
 };
 
 // find_boundaries (src/search.rs:190-233)
@@ -177,7 +178,7 @@ void lm_score(const HostModel& m, const char* text, const std::vector<OutSym>& s
   lm_score_tokens(m, tokens, lp, ppl);
 }
 
-// most_likely_sequence (src/lib.rs:2088-2495) without context rules.  The reference decodes with rustfst's
+// most_likely_sequence (src/lib.rs:2088-2495).  The reference decodes with rustfst's
 // shortest_path(nshortest = max_seq) over a lattice whose states are the boundaries; this is the exact k-best over the
 // same DAG.  The order among equal-cost paths is rustfst-internal in the reference and is not pinned.
 void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span>& matches, const Span* bs, size_t nb,
@@ -249,10 +250,13 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   }
   // rerank (src/lib.rs:2318-2425)
   const bool use_lm = m.have_lm && p.lm_weight > 0.0f;
-  double best_ppl = 999999.0;
+  const bool use_rules = !m.context_rules.empty();
+  double best_ppl = 999999.0, best_ctx = 0.0;
   float best_cost = (float)(nb - 1) * 2.0f;
-  std::vector<double> ppls(paths.size(), 0.0);
+  std::vector<double> ppls(paths.size(), 0.0), ctx(paths.size(), 1.0);
+  std::vector<std::vector<std::vector<anx::PatternMatchResult>>> ctx_results(use_rules ? paths.size() : 0);
   std::vector<OutSym> seq;
+  std::vector<std::pair<uint64_t, uint32_t>> idseq;
   for (size_t i = 0; i < paths.size(); ++i) {
     if (use_lm) {
       seq.clear();
@@ -261,24 +265,39 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
       lm_score(m, text, seq, bs, &lp, &ppls[i]);
       if (ppls[i] < best_ppl) best_ppl = ppls[i];
     }
+    if (use_rules) {  // src/lib.rs:2345-2363, 2505-2518
+      idseq.clear();
+      for (long sy : paths[i].syms) {
+        const uint64_t id = symbols[(size_t)sy].vocab_id;
+        idseq.emplace_back(id, id != 0 && id < m.decoder.size() ? m.decoder[id].lexindex : 0u);
+      }
+      ctx[i] = m.test_context_rules(idseq, ctx_results[i]);
+    }
     if (paths[i].cost < best_cost) best_cost = paths[i].cost;
+    if (ctx[i] > best_ctx) best_ctx = ctx[i];
   }
+  const bool shortcut = (!m.have_lm || p.lm_weight == 0.0f) && (!use_rules || p.contextrules_weight == 0.0f);
   double best_score = -99999999.0;
   long best_i = -1;
   for (size_t i = 0; i < paths.size(); ++i) {
     const double norm_lm = use_lm ? std::log(best_ppl / ppls[i]) : 0.0;
     const double norm_var = std::log((double)best_cost / (double)paths[i].cost);
+    const double norm_ctx = std::log(ctx[i] / best_ctx);
     double score;
-    if (!use_lm) score = norm_var;
+    if (shortcut) score = norm_var;
     else
-      score = ((double)p.lm_weight * norm_lm + (double)p.variantmodel_weight * norm_var + (double)p.contextrules_weight * 0.0) /
+      score = ((double)p.lm_weight * norm_lm + (double)p.variantmodel_weight * norm_var + (double)p.contextrules_weight * norm_ctx) /
               ((double)p.lm_weight + (double)p.variantmodel_weight + (double)p.contextrules_weight);
     if (score > best_score || best_i < 0) { best_score = score; best_i = (long)i; }
   }
-  for (long sy : paths[(size_t)best_i].syms) {
-    const OutSym& o = symbols[(size_t)sy];
+  const std::vector<long>& best_syms = paths[(size_t)best_i].syms;
+  for (size_t j = 0; j < best_syms.size(); ++j) {
+    const OutSym& o = symbols[(size_t)best_syms[j]];
     Span r = matches[o.match_index];
     r.selected = o.variant_index;
+    if (use_rules)
+      for (const anx::PatternMatchResult& pm : ctx_results[(size_t)best_i][j])
+        if (pm.tag >= 0) r.tags.emplace_back((uint16_t)pm.tag, pm.seqnr);
     out.push_back(std::move(r));
   }
 }
@@ -303,7 +322,9 @@ void anx_default_search_params(anx_search_params* p) {  // src/types.rs:170-192
 }
 
 int anx_find_all_matches_batch(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp,
-                               anx_match** out_matches, size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows) {
+                               anx_match** out_matches, size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows,
+                               anx_match_tag** out_tags) {
+  if (out_tags) *out_tags = nullptr;
   if (!model || (!texts && n) || !sp || !out_matches || !out_offsets || !out_rows || !out_n_rows)
     return anx_fail(ANX_EINVAL, "NULL argument");
   static const bool timing = getenv("ANX_SEARCH_TIMING") != nullptr;
@@ -408,7 +429,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     auto work = [&](size_t lo, size_t hi) {
       for (size_t si = lo; si < hi; ++si) {
         Stretch& st = stretches[si];
-        if (sp->max_ngram > 1 || m.have_lm)
+        if (sp->max_ngram > 1 || m.have_lm || !m.context_rules.empty())  // src/lib.rs:1912
           most_likely_sequence(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end,
                                *sp, decoded[si]);
         else
@@ -440,13 +461,15 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     for (Span& s : decoded[si]) dst.push_back(std::move(s));
   }
   lap("lattice + LM");
-  size_t total = 0, total_rows = 0;
-  for (auto& v : per_text) { total += v.size(); for (auto& s : v) total_rows += s.variants.size(); }
+  size_t total = 0, total_rows = 0, total_tags = 0;
+  for (auto& v : per_text) { total += v.size(); for (auto& s : v) { total_rows += s.variants.size(); total_tags += s.tags.size(); } }
+  anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, total_tags) * sizeof(anx_match_tag))) : nullptr;
+  if (out_tags && !otags) { free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
   anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, total) * sizeof(anx_match)));
   size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
   anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, total_rows) * sizeof(anx_result)));
-  if (!om || !oo || !orows) { free(om); free(oo); free(orows); free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
-  size_t w = 0, rw = 0;
+  if (!om || !oo || !orows) { free(om); free(oo); free(orows); free(otags); free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
+  size_t w = 0, rw = 0, tw = 0;
   for (size_t t = 0; t < n; ++t) {
     oo[t] = w;
     std::vector<size_t> cpmap;  // byte offset -> code point index (remap_offsets_to_unicodepoints, src/search.rs:527-546)
@@ -472,6 +495,10 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
       o.var_begin = rw;
       for (const anx_result& r : s.variants) orows[rw++] = r;
       o.var_end = rw;
+      o.tag_begin = (uint32_t)tw;
+      if (otags)
+        for (const auto& tg : s.tags) otags[tw++] = anx_match_tag{tg.first, tg.second, 0};
+      o.tag_end = (uint32_t)tw;
     }
   }
   oo[n] = w;
@@ -481,13 +508,15 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   *out_offsets = oo;
   *out_rows = orows;
   *out_n_rows = rw;
+  if (out_tags) *out_tags = otags;
   return ANX_OK;
 }
 
-void anx_matches_free(anx_match* matches, size_t* offsets, anx_result* rows) {
+void anx_matches_free(anx_match* matches, size_t* offsets, anx_result* rows, anx_match_tag* tags) {
   free(matches);
   free(offsets);
   free(rows);
+  free(tags);
 }
 
 }  // extern "C"

@@ -370,9 +370,10 @@ class VariantModel:
         arr = (C.c_char_p * max(n, 1))(*enc)
         sp = params._c_search()
         ms, offs, rows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)()
+        tags = C.POINTER(L.MatchTag)()
         nrows = C.c_size_t(0)
         L.check(L.lib().anx_find_all_matches_batch(self.h, arr, n, C.byref(sp), C.byref(ms), C.byref(offs),
-                                                   C.byref(rows), C.byref(nrows)))
+                                                   C.byref(rows), C.byref(nrows), C.byref(tags)))
         try:
             out = []
             for i in range(n):
@@ -383,11 +384,13 @@ class VariantModel:
                                 "selected": None if m.selected < 0 else m.selected,
                                 "variants": [(rows[r].vocab_id, rows[r].dist_score, rows[r].freq_score,
                                               None if rows[r].via == L.ANX_NO_VIA else rows[r].via)
-                                             for r in range(m.var_begin, m.var_end)]})
+                                             for r in range(m.var_begin, m.var_end)],
+                                "tag": [tags[k].tag for k in range(m.tag_begin, m.tag_end)],
+                                "seqnr": [tags[k].seqnr for k in range(m.tag_begin, m.tag_end)]})
                 out.append(cur)
             return out
         finally:
-            L.lib().anx_matches_free(ms, offs, rows)
+            L.lib().anx_matches_free(ms, offs, rows, tags)
 
     def find_all_matches(self, text: str, params: SearchParameters) -> List[dict]:
         """find_all_matches of the pyo3 binding (bindings/python/src/lib.rs:752-805): the selected variant first."""
@@ -400,10 +403,33 @@ class VariantModel:
             if m["selected"] is not None and m["selected"] < len(order):
                 order.remove(m["selected"])
                 order.insert(0, m["selected"])
-            out.append({"input": inp, "offset": {"begin": m["begin"], "end": m["end"]},
-                        "variants": [self._to_dict(*m["variants"][k][:3], params.freq_weight, m["variants"][k][3])
-                                     for k in order]})
+            item = {"input": inp, "offset": {"begin": m["begin"], "end": m["end"]}}
+            if m["tag"]:  # bindings/python/src/lib.rs:768-782
+                item["tag"] = [self.tag_name(t) for t in m["tag"]]
+                item["seqnr"] = list(m["seqnr"])
+            item["variants"] = [self._to_dict(*m["variants"][k][:3], params.freq_weight, m["variants"][k][3])
+                                for k in order]
+            out.append(item)
         return out
+
+    # -- context rules of search mode (src/lib.rs:570-765; bindings/python/src/lib.rs:630-700) -------------
+    def add_contextrule(self, pattern: str, score: float, tag: Sequence[str] = (), tagoffset: Sequence[str] = ()):
+        t = (C.c_char_p * max(1, len(tag)))(*[_b(x) for x in tag])
+        o = (C.c_char_p * max(1, len(tagoffset)))(*[_b(x) for x in tagoffset])
+        L.check(L.lib().anx_model_add_contextrule(self.h, _b(pattern), float(score), t, len(tag), o, len(tagoffset)))
+
+    def read_contextrules(self, filename: str):
+        L.check(L.lib().anx_model_read_contextrules(self.h, _b(filename)))
+
+    @property
+    def tags(self) -> List[str]:
+        return [self.tag_name(i) for i in range(L.lib().anx_model_num_tags(self.h))]
+
+    def tag_name(self, index: int) -> str:
+        s = L.lib().anx_model_tag_name(self.h, index)
+        if s is None:
+            raise IndexError("tag %d" % index)
+        return s.decode("utf-8")
 
     # -- confusables: host-side rescoring of the ranked lists ---------------
     def read_confusablelist(self, filename: str):

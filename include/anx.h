@@ -211,7 +211,7 @@ int anx_edit_script(const char *source, const char *target, char *out, int cap);
 /* ---- search mode: the main caller of the hot path -------------------------------
  * VariantModel::find_all_matches(&self, text, &SearchParameters) -> Vec<Match>, src/lib.rs:1790, for n texts at once.
  * Host side: boundaries / n-gram windows / redundancy filter (src/search.rs:190-336), lattice decoding and bigram-LM
- * rerank (src/lib.rs:2088-2495, 2580-2674; context rules are not implemented).  Device side: every segment of one
+ * rerank (src/lib.rs:2088-2495, 2580-2674) with context rules (below).  Device side: every segment of one
  * n-gram order, over all texts, is ONE anx_find_variants_batch call. */
 typedef struct anx_search_params {
   anx_params base;
@@ -219,7 +219,7 @@ typedef struct anx_search_params {
   uint32_t max_seq;           /* default 250: candidate sequences taken to the rerank stage */
   float lm_weight;            /* default 1.0 */
   float variantmodel_weight;  /* default 3.0 */
-  float contextrules_weight;  /* default 1.0 (enters the normalisation only) */
+  float contextrules_weight;  /* default 1.0 */
   int32_t unicodeoffsets;     /* offsets in code points instead of UTF-8 bytes */
 } anx_search_params;
 /* Match, src/search.rs:40-68 */
@@ -228,12 +228,33 @@ typedef struct anx_match {
   uint32_t n;                 /* tokens (boundaries) spanned */
   int32_t selected;           /* index of the chosen variant, -1 = none (out-of-vocabulary, copied from the input) */
   uint64_t var_begin, var_end; /* its ranked variants: rows [var_begin, var_end) of the row array */
+  uint32_t tag_begin, tag_end; /* Match.tag / Match.seqnr: entries [tag_begin, tag_end) of the tag array */
 } anx_match;
+/* one (tag, sequence number) of a match, assigned by a context rule: src/search.rs:60-66 */
+typedef struct anx_match_tag {
+  uint16_t tag;   /* index for anx_model_tag_name */
+  uint8_t seqnr;  /* position of the match inside the tagged span */
+  uint8_t pad_;
+} anx_match_tag;
 void anx_default_search_params(anx_search_params *);
-/* matches of text i are (*out_matches)[(*out_offsets)[i] .. (*out_offsets)[i+1]); release with anx_matches_free */
+/* matches of text i are (*out_matches)[(*out_offsets)[i] .. (*out_offsets)[i+1]); out_tags may be NULL (tags are then
+ * not reported); release with anx_matches_free */
 int anx_find_all_matches_batch(const anx_model *, const char *const *utf8_texts, size_t n, const anx_search_params *,
-                               anx_match **out_matches, size_t **out_offsets, anx_result **out_rows, size_t *out_n_rows);
-void anx_matches_free(anx_match *matches, size_t *offsets, anx_result *rows);
+                               anx_match **out_matches, size_t **out_offsets, anx_result **out_rows, size_t *out_n_rows,
+                               anx_match_tag **out_tags);
+void anx_matches_free(anx_match *matches, size_t *offsets, anx_result *rows, anx_match_tag *tags);
+
+/* ---- context rules of search mode -----------------------------------------------------------------------------
+ * VariantModel::add_contextrule(pattern, score, tag, tagoffset), src/lib.rs:658-765; read_contextrules, :570-656.
+ * pattern: ';'-separated expressions -- a vocabulary word, "?" (anything), "^" (in no lexicon), "@lexicon", "!x"
+ * (negation), "a|b" (disjunction), "!(a|b)"; src/search.rs:413-459.  score > 1 favours, < 1 penalises a candidate
+ * sequence the pattern occurs in (src/lib.rs:2501-2578).  tags / tagoffsets ("begin:length", either may be empty):
+ * n_tags strings, n_tagoffsets strings.  Rules are applied to every candidate sequence of the lattice on the host. */
+int anx_model_add_contextrule(anx_model *, const char *pattern, float score, const char *const *tags, size_t n_tags,
+                              const char *const *tagoffsets, size_t n_tagoffsets);
+int anx_model_read_contextrules(anx_model *, const char *path);
+size_t anx_model_num_tags(const anx_model *);
+const char *anx_model_tag_name(const anx_model *, size_t index); /* NULL when out of range */
 
 #ifdef __cplusplus
 }

@@ -434,6 +434,7 @@ class VocabValue:  # src/vocab.rs:8-29 (query-path subset)
     transparent: bool = False
     # Option<Vec<VariantReference>> (src/types.rs:315-324): ("ref_for" | "variant_of", vocab_id, score)
     variants: Optional[List[Tuple[str, int, float]]] = None
+    lexindex: int = 1  # bit i: present in lexicon i (src/vocab.rs:19, src/lib.rs:941,958)
 
 
 @dataclass
@@ -468,23 +469,25 @@ class VariantModel:
         self.decoder: List[VocabValue] = []
         self.encoder: Dict[str, int] = {}
         self.have_freq = False
+        self.lexicons: List[str] = []
         self.index: Dict[int, Tuple[List[int], int]] = {}  # anavalue -> (instances, charcount)
         self.sortedindex: Dict[int, List[int]] = {}
         # src/vocab.rs:145-181: ids 0,1,2 reserved, not INDEXED
         for t in ("<bos>", "<eos>", "<unk>"):
             self.encoder[t] = len(self.decoder)
-            self.decoder.append(VocabValue(t, [], 0, indexed=False))
+            self.decoder.append(VocabValue(t, [], 0, indexed=False, lexindex=0))
 
     def alphabet_size(self) -> int:  # src/lib.rs:163-165
         return len(self.alphabet) + 1
 
     def add_to_vocabulary(self, text: str, frequency: Optional[int] = None,
-                          freq_handling: str = "max", transparent: bool = False) -> int:
+                          freq_handling: str = "max", transparent: bool = False, lexicon_index: int = 0) -> int:
         """src/lib.rs:900-967 (INDEXED entries only)."""
         frequency = 1 if frequency is None else frequency
         vid = self.encoder.get(text)
         if vid is not None:
             item = self.decoder[vid]
+            item.lexindex |= 1 << lexicon_index
             if item.transparent and not transparent and vid > 2:
                 item.transparent = False  # src/lib.rs:935-940
             if freq_handling == "sum":
@@ -498,13 +501,13 @@ class VariantModel:
             return vid
         self.encoder[text] = len(self.decoder)
         self.decoder.append(VocabValue(text, normalize_to_alphabet(text, self.alphabet), frequency,
-                                       transparent=transparent))
+                                       transparent=transparent, lexindex=1 << lexicon_index))
         return len(self.decoder) - 1
 
     def add_variant(self, ref_id: int, variant: str, score: float, freq: Optional[int] = None,
-                    transparent: bool = False) -> bool:
+                    transparent: bool = False, lexicon_index: int = 0) -> bool:
         """src/lib.rs:460-514."""
-        variantid = self.add_to_vocabulary(variant, freq, transparent=transparent)
+        variantid = self.add_to_vocabulary(variant, freq, transparent=transparent, lexicon_index=lexicon_index)
         if variantid == ref_id:
             return False
         ref = self.decoder[ref_id]
@@ -524,6 +527,7 @@ class VariantModel:
         with open(path, "r", encoding="utf-8", newline="") as f:
             data = f.read()
         has_freq = None
+        lexicon_index = len(self.lexicons)  # src/lib.rs:784
         for line in rust_lines(data):
             if line == "":
                 continue
@@ -542,15 +546,16 @@ class VariantModel:
                     has_freq = False
             elif has_freq:
                 freq = int(fields[1])
-            ref_id = self.add_to_vocabulary(fields[0], freq)
+            ref_id = self.add_to_vocabulary(fields[0], freq, lexicon_index=lexicon_index)
             if has_freq:
                 rest = fields[2:]
                 for i in range(0, len(rest) - 2, 3):
-                    self.add_variant(ref_id, rest[i], float(rest[i + 1]), int(rest[i + 2]), transparent)
+                    self.add_variant(ref_id, rest[i], float(rest[i + 1]), int(rest[i + 2]), transparent, lexicon_index)
             else:
                 rest = fields[1:]
                 for i in range(0, len(rest) - 1, 2):
-                    self.add_variant(ref_id, rest[i], float(rest[i + 1]), None, transparent)
+                    self.add_variant(ref_id, rest[i], float(rest[i + 1]), None, transparent, lexicon_index)
+        self.lexicons.append(path)  # src/lib.rs:895
 
     def expand_variants(self, results: List["VariantResult"]) -> List["VariantResult"]:
         """src/lib.rs:1677-1727."""
@@ -572,6 +577,7 @@ class VariantModel:
         """src/lib.rs:519-568."""
         with open(path, "r", encoding="utf-8", newline="") as f:
             data = f.read()
+        lexicon_index = len(self.lexicons)  # src/lib.rs:536
         for line in rust_lines(data):
             if line == "":
                 continue
@@ -582,7 +588,8 @@ class VariantModel:
                 frequency = int(fields[freq_column]) if freq_column < len(fields) else 1
             else:
                 frequency = 1
-            self.add_to_vocabulary(text, frequency, freq_handling)
+            self.add_to_vocabulary(text, frequency, freq_handling, lexicon_index=lexicon_index)
+        self.lexicons.append(path)  # src/lib.rs:566
 
     def build(self) -> None:
         """src/lib.rs:192-245."""
@@ -831,6 +838,8 @@ class Match:  # src/search.rs:40-68
     variants: Optional[List[VariantResult]] = None
     selected: Optional[int] = None
     n: int = 0
+    tag: List[int] = field(default_factory=list)    # src/search.rs:60-66, set by context rules
+    seqnr: List[int] = field(default_factory=list)
 
 
 def is_alphabetic(ch: str) -> bool:
@@ -942,15 +951,82 @@ def redundant_match(candidate: Match, matches: List[Match]) -> bool:
 
 
 def _ln(x: float) -> float:
-    """f64::ln: ln(0) = -inf instead of Python's ValueError."""
+    """f64::ln: ln(0) = -inf, ln(negative) = ln(NaN) = NaN instead of Python's ValueError."""
+    if x != x or x < 0.0:
+        return math.nan
     return -math.inf if x == 0.0 else math.log(x)
 
 
+def _div(a: float, b: float) -> float:
+    """f64 division: x/0 = +-inf, 0/0 = NaN instead of ZeroDivisionError."""
+    if b == 0.0:
+        return math.nan if a == 0.0 or a != a else math.copysign(math.inf, a)
+    return a / b
+
+
+def _parse_u8(s: str, msg: str) -> int:
+    if not (s.isascii() and s.lstrip("+").isdigit() and len(s) - len(s.lstrip("+")) <= 1) or int(s) > 255:
+        raise ValueError(msg)
+    return int(s)
+
+
+def parse_pattern(s: str, lexicons: List[str], encoder: Dict[str, int]):
+    """PatternMatch::parse (src/search.rs:413-459) -> ("any",) | ("nolex",) | ("vocab", id) | ("lex", i) |
+    ("not", pm) | ("or", [pm])."""
+    s = rust_trim(s)
+    if s == "?":
+        return ("any",)
+    if s == "^":
+        return ("nolex",)
+    if s.startswith("!(") and s.endswith(")"):
+        return ("not", parse_pattern(s[2:-1], lexicons, encoder))
+    if "|" in s:
+        return ("or", [parse_pattern(item, lexicons, encoder) for item in s.split("|")])
+    if s.startswith("!"):
+        return ("not", parse_pattern(s[1:], lexicons, encoder))
+    if s.startswith("@"):
+        source = s[1:]
+        for i, lexicon in enumerate(lexicons):
+            if source == lexicon or lexicon.endswith("/" + source):
+                return ("lex", i)
+        raise ValueError("WARNING: Context rule references lexicon or variant list '%s' but this source was not loaded" % source)
+    if s in encoder:
+        return ("vocab", encoder[s])
+    raise ValueError("WARNING: Context rule references word '%s' but this word does not occur in any lexicon" % s)
+
+
+def pattern_matches(pm, item: Tuple[int, int]) -> bool:
+    """PatternMatch::matches (src/search.rs:373-411) on one (vocab_id, lexindex)."""
+    vocab_id, lexindex = item
+    kind = pm[0]
+    if kind == "any":
+        return True
+    if kind == "nolex":
+        return lexindex == 0 or vocab_id == 0
+    if kind == "vocab":
+        return vocab_id == pm[1]
+    if kind == "lex":
+        return lexindex & (1 << pm[1]) == 1 << pm[1]
+    if kind == "not":
+        return not pattern_matches(pm[1], item)
+    return any(pattern_matches(x, item) for x in pm[1])
+
+
+@dataclass
+class ContextRule:  # src/search.rs:355-364
+    pattern: list
+    score: float
+    tag: List[int]
+    tagoffset: List[Tuple[int, int]]
+
+
 class SearchModel(VariantModel):
-    """VariantModel + language-model vocabulary + find_all_matches (no context rules)."""
+    """VariantModel + language-model vocabulary + context rules + find_all_matches."""
 
     def __init__(self, alphabet, weights=None):
         super().__init__(alphabet, weights)
+        self.context_rules: List[ContextRule] = []
+        self.tags: List[str] = []
         self.ngrams: Dict[tuple, int] = {}
         self.have_lm = False
         self.lm_ids: List[int] = []
@@ -986,6 +1062,83 @@ class SearchModel(VariantModel):
             if ng is not None:
                 self.ngrams[ng] = self.ngrams.get(ng, 0) + self.decoder[vid].frequency
         self.have_lm = bool(self.ngrams)
+
+    # -- context rules ---------------------------------------------------------------------------------------
+    def add_contextrule(self, pattern: str, score: float, tag: Sequence[str] = (), tagoffset: Sequence[str] = ()) -> None:
+        """src/lib.rs:658-765."""
+        pms = [parse_pattern(rust_trim(e), self.lexicons, self.encoder) for e in pattern.split(";")]
+        tags = []
+        empty = False
+        for t in tag:
+            if t == "":
+                empty = True
+            if t not in self.tags:
+                self.tags.append(t)
+            tags.append(self.tags.index(t))
+        if empty:
+            raise ValueError("tag is empty")
+        offs = []
+        for spec in tagoffset:
+            fields = spec.split(":")
+            begin = 0 if fields[0] == "" else _parse_u8(fields[0], "tag offset should be an integer")
+            if len(fields) > 1 and fields[1] != "":
+                length = _parse_u8(fields[1], "tag length should be an integer")
+            else:
+                length = (len(pms) - begin) & 0xFF
+            offs.append((begin, length))
+        while len(offs) < len(tags):
+            offs.append((0, len(pms)))
+        self.context_rules.append(ContextRule(pms, float(_np.float32(score)), tags, offs))
+
+    def read_contextrules(self, filename: str) -> None:
+        """src/lib.rs:570-656."""
+        with open(filename, "r", encoding="utf-8", newline="") as f:
+            data = f.read()
+
+        def tagfields(s):
+            return [w for w in (rust_trim(x) for x in s.split(";")) if w != ""]
+        for linenr, line in enumerate(rust_lines(data), 1):
+            if line == "" or line.startswith("#"):
+                continue
+            fields = line.split("\t")
+            if len(fields) < 2:
+                raise ValueError("Expected at least two columns in context rules file %s, line %d" % (filename, linenr))
+            if fields[0] == "":
+                continue
+            score = float(fields[1])
+            tag = tagfields(fields[2]) if len(fields) > 2 else []
+            tagoffset = tagfields(fields[3]) if len(fields) > 3 else []
+            if len(tag) == 1 and not tagoffset:
+                tagoffset.append("0:")
+            elif len(tag) != len(tagoffset):
+                raise ValueError("Multiple tags are specified for a context rule, expected the same number of tag offsets!")
+            self.add_contextrule(fields[0], score, tag, tagoffset)
+
+    def test_context_rules(self, sequence: List[Tuple[int, int]]):
+        """src/lib.rs:2501-2578 with ContextRule::matches (src/search.rs:472-524): (context score, per position
+        [(score, tag | None, seqnr)])."""
+        results: List[list] = [[] for _ in sequence]
+        found = False
+        for begin in range(len(sequence)):
+            for rule in self.context_rules:
+                n = len(rule.pattern)
+                if begin + n > len(sequence):
+                    continue
+                if any(results[begin + c] or not pattern_matches(rule.pattern[c], sequence[begin + c]) for c in range(n)):
+                    continue
+                found = True
+                for c in range(n):
+                    if not rule.tag:
+                        results[begin + c] = [(rule.score, None, c)]
+                    else:
+                        results[begin + c] = [(rule.score, t, c - b) for t, (b, l) in zip(rule.tag, rule.tagoffset)
+                                              if b <= c < b + l]
+        if not found:
+            return 1.0, results
+        total = _np.float32(0.0)
+        for r in results:
+            total = _np.float32(total + _np.float32(r[0][0] if r else 1.0))
+        return float(total) / float(len(sequence)), results
 
     # -- LM ------------------------------------------------------------------------------------------------
     def lm_score_tokens(self, tokens: List[Optional[int]]) -> Tuple[float, float]:
@@ -1086,34 +1239,49 @@ class SearchModel(VariantModel):
         paths = paths[:K]
         # rerank (src/lib.rs:2318-2425)
         seqs = []
-        best_ppl, best_cost = 999999.0, f32((len(boundaries) - 1) * 2.0)
+        best_ppl, best_cost, best_ctx = 999999.0, f32((len(boundaries) - 1) * 2.0), 0.0
         use_lm = self.have_lm and params.lm_weight > 0.0
         for cost, syms in paths:
             osyms = [symbols[s] for s in syms]
             logprob, ppl = (0.0, 0.0)
+            ctx, tags = 1.0, []
             if use_lm:
                 logprob, ppl = self.lm_score(osyms, boundaries)
                 best_ppl = min(best_ppl, ppl)
+            if self.context_rules:  # src/lib.rs:2345-2363
+                ctx, results = self.test_context_rules(
+                    [(vid, self.decoder[vid].lexindex if vid != 0 else 0) for vid, _mi, _vi, _b in osyms])
+                tags = [[(t, nr) for _sc, t, nr in r if t is not None] for r in results]
             if cost < best_cost:
                 best_cost = cost
-            seqs.append((cost, osyms, ppl))
-        best_score, best_seq = -99999999.0, None
-        for cost, osyms, ppl in seqs:
-            norm_lm = _ln(best_ppl / ppl) if use_lm else 0.0
+            if ctx > best_ctx:
+                best_ctx = ctx
+            seqs.append((cost, osyms, ppl, ctx, tags))
+        best_score, best_seq, best_tags = -99999999.0, None, []
+        lw, vw, cw = float(f32(params.lm_weight)), float(f32(params.variantmodel_weight)), float(f32(params.contextrules_weight))
+        shortcut = (not self.have_lm or lw == 0.0) and (not self.context_rules or cw == 0.0)
+        for cost, osyms, ppl, ctx, tags in seqs:
+            norm_lm = _ln(_div(best_ppl, ppl)) if use_lm else 0.0
             # a stretch with ONE boundary leaves best_cost at 0.0 (src/lib.rs:2320): ln(0) = -inf for every path, and
             # the first path the FST yields wins (src/lib.rs:2419); here that is the cheapest one
-            norm_var = _ln(float(best_cost) / float(cost))
-            if not use_lm:
+            norm_var = _ln(_div(float(best_cost), float(cost)))
+            norm_ctx = _ln(_div(ctx, best_ctx))
+            if shortcut:
                 score = norm_var
             else:
-                lw, vw, cw = float(f32(params.lm_weight)), float(f32(params.variantmodel_weight)), float(f32(params.contextrules_weight))
-                score = (lw * norm_lm + vw * norm_var + cw * 0.0) / (lw + vw + cw)
+                with _np.errstate(all="ignore"):
+                    score = float((_np.float64(lw) * norm_lm + _np.float64(vw) * norm_var + _np.float64(cw) * norm_ctx)
+                                  / _np.float64(lw + vw + cw))
             if score > best_score or best_seq is None:
-                best_score, best_seq = score, osyms
+                best_score, best_seq, best_tags = score, osyms, tags
         out = []
-        for vocab_id, mi, vi, _b in best_seq:
+        for i, (vocab_id, mi, vi, _b) in enumerate(best_seq):
             m = matches[mi]
-            out.append(Match(m.text, m.begin, m.end, m.variants, vi, m.n))
+            r = Match(m.text, m.begin, m.end, m.variants, vi, m.n)
+            if best_tags:
+                r.tag = [t for t, _nr in best_tags[i]]
+                r.seqnr = [nr for _t, nr in best_tags[i]]
+            out.append(r)
         return out
 
     def find_all_matches(self, text: str, params: "SearchParams") -> List[Match]:
@@ -1135,7 +1303,7 @@ class SearchModel(VariantModel):
                         if order == 1 or not redundant_match(seg, batch):
                             seg.variants = self.find_variants(seg.text, params)
                     batch.extend(cur)
-                if params.max_ngram > 1 or self.have_lm:
+                if params.max_ngram > 1 or self.have_lm or self.context_rules:  # src/lib.rs:1912
                     matches.extend(self.most_likely_sequence(batch, bslice, begin, boundary.begin, params))
                 else:
                     for m in batch:

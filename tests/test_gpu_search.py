@@ -140,8 +140,8 @@ def random_texts(words, phrases, n, seed):
     return texts
 
 
-@pytest.mark.parametrize("with_lm", [False, True])
-def test_random_texts_vs_twin(with_lm):
+@pytest.mark.parametrize("with_lm,with_rules", [(False, False), (True, False), (False, True), (True, True)])
+def test_random_texts_vs_twin(with_lm, with_rules):
     """Markov-free small world: 3000 lexicon words (+ a bigram LM over them when with_lm), 200 random texts, the whole
     batch in ONE anx_find_all_matches_batch call; every Match field must equal the twin's."""
     words = [w for w in synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz")) if w.isascii() and w.isalpha()][::37][:3000]
@@ -176,12 +176,23 @@ def test_random_texts_vs_twin(with_lm):
     orc.build()
     g.build()
     tw.attach(orc)
+    if with_rules:  # context rules over frequent words: bonus / penalty, wildcards, negation, disjunction, tags
+        common = words[:400]
+        for i in range(300):
+            kind = i % 6
+            a, b, c = rng.choice(common), rng.choice(common), rng.choice(common)
+            pattern = (a, f"{a}; ?", f"^; {a}", f"{a}|{b}; !{c}", f"!({a}|{b}); {c}", f"?; {a}; ^")[kind]
+            score = rng.choice((0.5, 0.8, 0.9, 1.1, 1.3, 2.0))
+            tags, offs = ((), ()) if i % 3 == 0 else ((f"t{i % 7}",), ()) if i % 3 == 1 else ((f"t{i % 5}", "u"), ("0:1", ":"))
+            tw.add_contextrule(pattern, score, list(tags), list(offs))
+            g.add_contextrule(pattern, score, list(tags), list(offs))
+        assert g.tags == tw.tags
     texts = random_texts(words[:400] if with_lm else words, phrases, 200, 5 + int(with_lm))
     gp = A.SearchParameters(max_anagram_distance=2, max_edit_distance=2, max_matches=6, score_threshold=0.3,
                             cutoff_threshold=0.0, max_ngram=3, max_seq=40)
     tp = T.SearchParams(("abs", 2), ("abs", 2), 6, 0.3, 0.0, False, 0.0, max_ngram=3, max_seq=40)
     got = g.find_all_matches_ids(texts, gp)
-    n_multi = 0
+    n_multi = n_tagged = 0
     for text, gm in zip(texts, got):
         exp = tw.find_all_matches(text, tp)
         raw = text.encode()
@@ -194,8 +205,91 @@ def test_random_texts_vs_twin(with_lm):
                 assert abs(v[1] - w.dist_score) < 1e-6 and abs(v[2] - w.freq_score) < 1e-6
             if ev:
                 assert m["selected"] == e.selected, (text, e.text)
+            assert (m["tag"], m["seqnr"]) == (e.tag, e.seqnr), (text, e.text)
             n_multi += e.n > 1
+            n_tagged += bool(e.tag)
     assert n_multi > 0  # the lattice did pick some bigram/trigram segments
+    assert (n_tagged > 0) == with_rules
+
+
+# -- context rules: tests/main.rs:1575-1800 (values transcribed) ----------------------------------------------------
+def rules_model():
+    return small(("I", "think", "sink", "you", "are", "right"), freq=2)
+
+
+def chosen(r):
+    return [m["variants"][0]["text"] if m["variants"] else m["input"] for m in r]
+
+
+def test0902_0905_context_rules():
+    p = sparams(max_ngram=1, lm_weight=0.0)
+    text = "I tink you are rihgt"
+    g = rules_model()
+    g.add_contextrule("I; think", 1.1, ["testtag"], [])  # bonus
+    r = g.find_all_matches(text, p)
+    assert chosen(r) == ["I", "think", "you", "are", "right"]
+    assert (r[0]["tag"], r[0]["seqnr"], r[1]["tag"], r[1]["seqnr"]) == (["testtag"], [0], ["testtag"], [1])
+    assert "tag" not in r[2]
+    g = rules_model()
+    g.add_contextrule("I; think", 0.9)  # penalty
+    assert chosen(g.find_all_matches(text, p)) == ["I", "sink", "you", "are", "right"]
+    g = rules_model()
+    for w in ("think", "are", "right"):
+        g.add_contextrule(w, 1.0, ["testtag"])
+    r = g.find_all_matches(text, p)
+    assert chosen(r) == ["I", "think", "you", "are", "right"]
+    assert [m.get("tag", []) for m in r] == [[], ["testtag"], [], ["testtag"], ["testtag"]]
+    assert [m.get("seqnr", []) for m in r] == [[], [0], [], [0], [0]]
+    g = rules_model()
+    g.add_contextrule("I; think", 1.1, ["testtag", "testtag2"])
+    r = g.find_all_matches(text, p)
+    assert (r[0]["tag"], r[0]["seqnr"], r[1]["tag"], r[1]["seqnr"]) == \
+        (["testtag", "testtag2"], [0, 0], ["testtag", "testtag2"], [1, 1])
+    assert g.tags == ["testtag", "testtag2"]
+
+
+def test_contextrules_file_and_lexicons(tmp_path):
+    """read_contextrules (src/lib.rs:570-656) with @lexicon patterns over two lexicon files: product == twin."""
+    amph, rept = tmp_path / "amphibians.tsv", tmp_path / "reptiles.tsv"
+    amph.write_text("salamander\t3\nfrog\t3\ntoad\t2\nnewt\t1\n")
+    rept.write_text("lizard\t3\nsnake\t3\nskink\t1\nnewt\t1\n")
+    rules = tmp_path / "rules.tsv"
+    rules.write_text("# pattern\tscore\ttags\toffsets\n"
+                     "@amphibians.tsv; @reptiles.tsv\t1.2\tpair\n"
+                     "\n"
+                     "@reptiles.tsv\t0.9\treptile; any\t0:1; :\n"
+                     "^; frog\t1.1\n"
+                     "!(snake|toad); newt|skink\t1.05\tx\t1:1\n")
+    g = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
+    tw = T.SearchModel(T.TEST_ALPHABET)
+    for f in (amph, rept):
+        g.read_lexicon(str(f))
+        tw.read_vocabulary(str(f))
+    g.build()
+    tw.build()
+    g.read_contextrules(str(rules))
+    tw.read_contextrules(str(rules))
+    assert g.tags == tw.tags == ["pair", "reptile", "any", "x"]
+    gp = sparams(max_ngram=1, lm_weight=0.0)
+    tp = T.test_searchparams_search()
+    tp.max_ngram, tp.lm_weight = 1, 0.0
+    for text in ("salamnder lizrd frog snke toad", "qqqq frog newt skink", "snake newt lizard, toad skink!", "nwet"):
+        got = g.find_all_matches(text, gp)
+        exp = tw.find_all_matches(text, tp)
+        assert [m["input"] for m in got] == [e.text for e in exp]
+        assert chosen(got) == [tw.match_to_str(e) for e in exp], text
+        assert [m.get("tag", []) for m in got] == [[tw.tags[t] for t in e.tag] for e in exp], text
+        assert [m.get("seqnr", []) for m in got] == [e.seqnr for e in exp], text
+    with pytest.raises(A.AnxError):
+        g.add_contextrule("notaword", 1.0)
+    with pytest.raises(A.AnxError):
+        g.add_contextrule("@nolexicon.tsv", 1.0)
+    with pytest.raises(A.AnxError):
+        g.add_contextrule("frog", 1.0, ["t"], ["x:1"])
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("frog\tnotanumber\n")
+    with pytest.raises(A.AnxError):
+        g.read_contextrules(str(bad))
 
 
 def test_cli_query_readme_line(data_dir, tmp_path, capsys):

@@ -118,3 +118,86 @@ def test_tutorial_find_all_matches(data_dir, tutorial_outputs):
     x = r[case["only_match_index"]]
     assert (x.text, x.begin, x.end) == (c["input"], c["begin"], c["end"])
     assert [[m.decoder[v.vocab_id].text, v.score(0.0), v.dist_score, v.freq_score] for v in x.variants] == c["variants"]
+
+
+# -- context rules: tests/main.rs:1575-1800 (values transcribed) -------------------------------------------------
+def _rules_model():
+    m = T.SearchModel(A)
+    for w in ("I", "think", "sink", "you", "are", "right"):  # "context rule will decide between think/sink"
+        m.add_to_vocabulary(w, 2)
+    m.build()
+    return m
+
+
+def _rules_params():
+    p = T.test_searchparams_search()
+    p.lm_weight = 0.0
+    p.max_ngram = 1
+    return p
+
+
+def test0902_context_rules_bonus():  # :1575-1610
+    m = _rules_model()
+    m.add_contextrule("I; think", 1.1, ["testtag"], [])
+    r = m.find_all_matches("I tink you are rihgt", _rules_params())
+    assert [x.text for x in r] == ["I", "tink", "you", "are", "rihgt"]
+    assert [m.match_to_str(x) for x in r] == ["I", "think", "you", "are", "right"]
+    assert (r[0].tag, r[0].seqnr, r[1].tag, r[1].seqnr) == ([0], [0], [0], [1])
+
+
+def test0903_context_rules_penalty():  # :1613-1640
+    m = _rules_model()
+    m.add_contextrule("I; think", 0.9, [], [])
+    r = m.find_all_matches("I tink you are rihgt", _rules_params())
+    assert [m.match_to_str(x) for x in r] == ["I", "sink", "you", "are", "right"]
+
+
+def test0904_context_rules_tags():  # :1643-1685
+    m = _rules_model()
+    for w in ("think", "are", "right"):
+        m.add_contextrule(w, 1.0, ["testtag"], [])
+    r = m.find_all_matches("I tink you are rihgt", _rules_params())
+    assert [m.match_to_str(x) for x in r] == ["I", "think", "you", "are", "right"]
+    assert [x.tag for x in r] == [[], [0], [], [0], [0]]
+    assert [x.seqnr for x in r] == [[], [0], [], [0], [0]]
+
+
+def test0905_context_rules_multitag():  # :1688-1722
+    m = _rules_model()
+    m.add_contextrule("I; think", 1.1, ["testtag", "testtag2"], [])
+    r = m.find_all_matches("I tink you are rihgt", _rules_params())
+    assert [m.match_to_str(x) for x in r] == ["I", "think", "you", "are", "right"]
+    assert (r[0].tag, r[0].seqnr, r[1].tag, r[1].seqnr) == ([0, 1], [0, 0], [0, 1], [1, 1])
+    assert m.tags == ["testtag", "testtag2"]
+
+
+def test_pattern_parse_and_match():  # src/search.rs:373-459
+    m = _rules_model()
+    m.lexicons = ["data/a.tsv", "b.tsv"]
+    P = lambda s: T.parse_pattern(s, m.lexicons, m.encoder)
+    think = m.encoder["think"]
+    assert P(" ? ") == ("any",) and P("^") == ("nolex",) and P("think") == ("vocab", think)
+    assert P("@a.tsv") == ("lex", 0) and P("@b.tsv") == ("lex", 1) and P("@data/a.tsv") == ("lex", 0)
+    assert P("!think") == ("not", ("vocab", think))
+    assert P("think|sink")[0] == "or" and P("!(think|sink)")[0] == "not"
+    assert P("!think|sink") == ("or", [("not", ("vocab", think)), ("vocab", m.encoder["sink"])])
+    with pytest.raises(ValueError):
+        P("unknownword")
+    with pytest.raises(ValueError):
+        P("@c.tsv")
+    assert T.pattern_matches(P("^"), (0, 0)) and T.pattern_matches(P("^"), (7, 0)) and not T.pattern_matches(P("^"), (7, 1))
+    assert T.pattern_matches(P("@b.tsv"), (7, 2)) and not T.pattern_matches(P("@b.tsv"), (7, 1))
+    assert T.pattern_matches(P("!(think|sink)"), (9999, 1)) and not T.pattern_matches(P("!(think|sink)"), (think, 1))
+
+
+def test_tagoffsets():  # src/lib.rs:703-751, src/search.rs:496-515
+    m = _rules_model()
+    m.add_contextrule("I; think; you", 1.2, ["a", "b"], ["1:1", ":2"])
+    assert m.context_rules[0].tagoffset == [(1, 1), (0, 2)]
+    r = m.find_all_matches("I tink you are rihgt", _rules_params())
+    assert [x.tag for x in r] == [[1], [0, 1], [], [], []]
+    assert [x.seqnr for x in r] == [[0], [0, 1], [], [], []]
+    with pytest.raises(ValueError):
+        m.add_contextrule("I", 1.0, ["t"], ["x:1"])
+    with pytest.raises(ValueError):
+        m.add_contextrule("I", 1.0, [""], [])
