@@ -147,6 +147,7 @@ def lib():
         "anx_batch_fetch_pairs": (C.c_int, [vp, C.POINTER(C.POINTER(Pair)), C.POINTER(sz)]),
         "anx_pairs_free": (None, [C.POINTER(Pair)]),
         "anx_batch_export_topk": (C.c_int, [vp, vp, C.c_uint32, vp]),
+        "anx_batch_export_compact": (C.c_int, [vp, vp, sz, vp, C.POINTER(sz)]),
         "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats)]),
         "anx_batch_free": (None, [vp]),
     }

@@ -390,6 +390,13 @@ int anx_batch_export_topk(const anx_batch* b, void* dst, uint32_t stride, void* 
   int rc = anx::batch_export_topk(b->model->dev, b->b, dst, stride, stream, err);
   return rc ? fail(rc, err) : ANX_OK;
 }
+int anx_batch_export_compact(const anx_batch* b, void* dst, size_t capacity, void* stream, size_t* used) {
+  if (!b || !used) return fail(ANX_EINVAL, "NULL argument");
+  if (b->rescore) return fail(ANX_EINVAL, "confusables are loaded: results are rescored on the host, use anx_batch_fetch");
+  std::string err;
+  int rc = anx::batch_export_compact(b->model->dev, b->b, dst, capacity, stream, used, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
 int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* s) {
   if (!b || !s) return fail(ANX_EINVAL, "NULL argument");
   anx::batch_stats(b->b, s);

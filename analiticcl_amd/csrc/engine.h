@@ -24,6 +24,8 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
                       std::string& err);
 int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32_t stride, void* stream,
                       std::string& err);
+int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, size_t capacity, void* stream,
+                         size_t* used, std::string& err);
 void batch_stats(const Batch* b, anx_batch_stats* s);
 void batch_free(Batch*);
 

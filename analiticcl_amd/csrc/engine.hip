@@ -808,6 +808,37 @@ int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32
   return ANX_OK;
 }
 
+// Compact form of the same records: uint32 offsets[n+1] (input order; padded to a 16-byte multiple), then the
+// n_results records back to back.  The size is known on the host (n_results is read back by the run), so the
+// multi-GPU gather moves the used bytes only (config 2: 4.4 results per query, 74 MB per million instead of 176 MB).
+int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, size_t capacity, void* stream,
+                         size_t* used, std::string& err) {
+  (void)dl;
+  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  if (!dst || !used) { err = "bad export arguments"; return ANX_EINVAL; }
+  const size_t n = b->n_input;
+  const size_t off_bytes = ((n + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+  *used = off_bytes + (size_t)b->n_results * sizeof(anx_topk_record);
+  if (capacity < *used) { err = "export buffer too small: " + std::to_string(*used) + " bytes needed"; return ANX_ELIMIT; }
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  uint32_t* d_off = static_cast<uint32_t*>(dst);
+  anx_topk_record* d_rows = reinterpret_cast<anx_topk_record*>(static_cast<char*>(dst) + off_bytes);
+  if (n == 0 || b->nq == 0) { HIP_TRY(hipMemsetAsync(d_off, 0, off_bytes, st)); return ANX_OK; }
+  if (!b->x_cnt) {
+    const size_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE + 2;
+    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&b->x_cnt), n * sizeof(uint32_t)));
+    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&b->x_tmp), nblk * sizeof(uint32_t)));
+  }
+  const uint32_t n32 = (uint32_t)n, nq32 = (uint32_t)b->nq;
+  HIP_TRY(hipMemsetAsync(b->x_cnt, 0, n * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_fetch_counts, dim3((nq32 + 255) / 256), dim3(256), 0, st, nq32, b->r_count, b->q_orig, b->x_cnt);
+  exclusive_scan(b->x_cnt, n32, d_off, b->x_tmp, st);
+  hipLaunchKernelGGL(k_export_rows, dim3((nq32 + 255) / 256), dim3(256), 0, st, nq32, b->soff, b->r_count, b->r_rows, b->q_orig, d_off, d_rows);
+  HIP_TRY(hipGetLastError());
+  return ANX_OK;
+}
+
 void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 
 void batch_free(Batch* b) {
@@ -815,7 +846,7 @@ void batch_free(Batch* b) {
   (void)hipSetDevice(b->device);
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
-                  (void*)b->qmaxfreq, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->lctr,
+                  (void*)b->qmaxfreq, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) pool_free(p);
   for (auto& e : b->ev)

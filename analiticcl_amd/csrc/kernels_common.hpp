@@ -128,6 +128,7 @@ struct Batch {
   uint32_t n_raw = 0;
   uint64_t n_sel = 0;
   uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
+  mutable uint32_t *x_cnt = nullptr, *x_tmp = nullptr;  // export_compact temporaries (input-order counts, scan sums)
   bool ran = false;
   bool keep_all_pairs = false;     // also materialise the pairs whose lengths differ by more than d (debug fetch of every pair)
   bool ran_keep_all = false;       // what the last run did

@@ -507,3 +507,20 @@ __global__ __launch_bounds__(256) void k_export_topk(uint32_t nq, uint32_t strid
   out[(size_t)q_orig[q] * stride + i] = r;
 }
 
+
+// compact export: rows of query s (sorted order) -> records at off_orig[q_orig[s]] .. (input order, no padding)
+__global__ __launch_bounds__(256) void k_export_rows(uint32_t nq, const uint32_t* __restrict__ soff, const uint32_t* __restrict__ r_count,
+                                                     const DevRow* __restrict__ r_rows, const uint32_t* __restrict__ q_orig,
+                                                     const uint32_t* __restrict__ off_orig, anx_topk_record* __restrict__ out) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nq) return;
+  const uint32_t n = r_count[s], src = soff[s], dst = off_orig[q_orig[s]];
+  for (uint32_t i = 0; i < n; ++i) {
+    const DevRow d = r_rows[src + i];
+    anx_topk_record r;
+    r.vocab_id = d.vocab_id;
+    r.freq_score = (float)d.freq_score;
+    r.dist_score = d.dist_score;
+    out[dst + i] = r;
+  }
+}

@@ -209,6 +209,12 @@ class Batch:
     def export_topk(self, device_ptr: int, stride: int, stream: int = 0):
         L.check(L.lib().anx_batch_export_topk(self.h, C.c_void_p(device_ptr), stride, C.c_void_p(stream)))
 
+    def export_compact(self, device_ptr: int, capacity: int, stream: int = 0) -> int:
+        """offsets[n+1] (u32, padded to 16 bytes) + unpadded records into a device buffer; returns the bytes used."""
+        used = C.c_size_t(0)
+        L.check(L.lib().anx_batch_export_compact(self.h, C.c_void_p(device_ptr), capacity, C.c_void_p(stream), C.byref(used)))
+        return used.value
+
     def free(self):
         if getattr(self, "h", None):
             L.lib().anx_batch_free(self.h)

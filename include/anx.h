@@ -179,6 +179,11 @@ void anx_pairs_free(anx_pair *);
 /* write fixed-stride ranked records (stride records per query, batch order) into a DEVICE buffer of
  * n*stride*sizeof(anx_topk_record) bytes (e.g. a torch tensor) -- the payload of the multi-GPU gather */
 int anx_batch_export_topk(const anx_batch *, void *device_dst, uint32_t stride, void *stream);
+/* the same records without padding, into a DEVICE buffer of `capacity` bytes: uint32 offsets[n+1] in input order
+ * (padded to a multiple of 16 bytes), then the records of all inputs back to back.  *used = bytes written (known on
+ * the host without a device round trip), also set when the call fails with ANX_ELIMIT because capacity is too small;
+ * the multi-GPU gather then moves the used bytes only. */
+int anx_batch_export_compact(const anx_batch *, void *device_dst, size_t capacity, void *stream, size_t *used);
 typedef struct anx_batch_stats {
   uint64_t n_queries;
   uint64_t n_pairs;          /* scored (query,candidate) pairs = DL invocations of the reference */

@@ -62,6 +62,72 @@ def test_shard_and_gather(world, n):
     assert got == exp
 
 
+def _compact(lo, hi, step):
+    """a synthetic compact export of inputs lo..hi-1 whose result counts depend on the step"""
+    counts = [(q * 7 + step * 3) % 6 for q in range(lo, hi)]
+    off = np.zeros(hi - lo + 1, dtype="<u4")
+    off[1:] = np.cumsum(counts)
+    rows = np.zeros(int(off[-1]), dtype=shard.TOPK_DTYPE)
+    k = 0
+    for q, c in zip(range(lo, hi), counts):
+        for i in range(c):
+            rows[k] = (q * 100 + i + step, 1.0 / (i + 1 + step), 1.0 - i / 64.0)
+            k += 1
+    head = off.tobytes()
+    head += b"\0" * (shard.compact_offsets_bytes(hi - lo) - len(head))
+    return head + rows.tobytes()
+
+
+def _compact_worker(rank, world, port, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard.shard_range(n, rank, world)
+    per = max(shard.shard_range(n, r, world)[1] - shard.shard_range(n, r, world)[0] for r in range(world))
+    g = shard.CompactGather(shard.compact_capacity(per, 5), "cpu", rank, world)
+    seen = {}
+
+    def collect(slot, step):
+        if rank == 0 and step >= 0:
+            parts = g.result(slot)
+            seen[step] = [shard.decode_compact(parts[r], shard.shard_range(n, r, world)[1] - shard.shard_range(n, r, world)[0])
+                          for r in range(world)]
+    for step in range(steps):
+        slot = step & 1
+        buf = g.acquire(slot)          # the transfer of step - 2 has finished: its result is complete
+        collect(slot, step - 2)
+        payload = _compact(lo, hi, step)
+        buf[:len(payload)] = torch.from_numpy(np.frombuffer(payload, dtype=np.uint8).copy())
+        g.submit(slot, len(payload))
+    g.flush()
+    for step in (steps - 2, steps - 1):
+        collect(step & 1, step)
+    if rank == 0:
+        q.put(seen)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,steps", [(2, 11, 5), (3, 10, 4), (1, 4, 3)])
+def test_compact_gather_pipeline(world, n, steps):
+    """the variable-size gather of compact exports: sizes one step ahead of the payloads, two rotating buffers"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compact_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(seen) == list(range(steps))
+    for step in range(steps):
+        for r in range(world):
+            lo, hi = shard.shard_range(n, r, world)
+            assert seen[step][r] == shard.decode_compact(_compact(lo, hi, step), hi - lo), (step, r)
+
+
 def test_shard_range_partition():
     for n in (0, 1, 7, 8, 1000003):
         for w in (1, 2, 3, 8):

@@ -178,6 +178,41 @@ def test_export_topk_matches_fetch(eng):
     b.free()
 
 
+def test_export_compact_matches_fetch(eng):
+    """anx_batch_export_compact: offsets + unpadded records in a device buffer == the fetched rows; through the
+    CompactGather helper (world 1) as bench.py uses it; too small a buffer is refused with the size needed."""
+    import torch
+    from analiticcl_amd import shard, synth
+    g, _ = eng
+    words = synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz"))
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+    qs = ["seperate", "", "recieve", "teh", "xyzzyq", "acommodate", ""] + synth.make_queries(words, 3000, max_len=16, seed=77)
+    b = g.encode_batch(qs, p)
+    b.run()
+    res = b.fetch()
+    gather = shard.CompactGather(shard.compact_capacity(len(qs), 11), "cuda:0", 0, 1)
+    for step in range(3):
+        buf = gather.acquire(step & 1)
+        used = b.export_compact(buf.data_ptr(), buf.numel())
+        gather.submit(step & 1, used)
+    gather.flush()
+    torch.cuda.synchronize()
+    assert used == shard.compact_offsets_bytes(len(qs)) + 16 * sum(len(r) for r in res)
+    for slot in (0, 1):
+        got = shard.decode_compact(gather.result(slot)[0], len(qs))
+        assert [[(v, d) for v, d, _ in r] for r in got] == [[(v, d) for v, d, _ in r] for r in res]
+        assert all(abs(a[2] - c[2]) < 1e-6 for r, e in zip(got, res) for a, c in zip(r, e))
+    small = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(A.AnxError):
+        b.export_compact(small.data_ptr(), small.numel())
+    b.free()
+    e = g.encode_batch(["", ""], p)
+    e.run()
+    buf = torch.ones(64, dtype=torch.uint8, device="cuda:0")
+    assert e.export_compact(buf.data_ptr(), 64) == 16 and shard.decode_compact(buf, 2) == [[], []]
+    e.free()
+
+
 def test_small_model_reference_tests():  # tests/main.rs:858-911
     lex = ["rites", "tiers", "tires", "tries", "tyres", "rides", "brides", "dire"]
     g = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=0)
