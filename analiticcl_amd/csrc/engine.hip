@@ -500,6 +500,7 @@ static int ensure_surv(Batch* b, size_t cap, std::string& err) {
 
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
   if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
+  if (b->nq >= (1u << 27) || dl->nentries >= (1u << 27)) { err = "more than 2^27 queries per batch or lexicon entries (32-bit record offsets)"; return ANX_ELIMIT; }
   HIP_TRY(hipSetDevice(dl->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint32_t nq = (uint32_t)b->nq;

@@ -32,8 +32,9 @@ __device__ inline uint32_t len_mask(int len, int k) {  // 0x80 in every byte pos
 }
 
 template <int DELTA, int NW>
-__device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], bool enabled, uint32_t (&nmA)[NW],
+__device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], uint32_t off, uint32_t (&nmA)[NW],
                                     uint32_t (&nmB)[NW]) {
+  // off: 0 for lanes that use this shift (d >= |DELTA|), all ones for the others (nothing matches at this shift)
   uint32_t nz[NW + 2];
   nz[0] = 0xFFFFFFFFu;
   nz[NW + 1] = 0xFFFFFFFFu;
@@ -43,8 +44,8 @@ __device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)
     if (DELTA == 0) cs = c[k + 1];
     else if (DELTA > 0) cs = __builtin_amdgcn_alignbyte(c[k + 2], c[k + 1], DELTA);
     else cs = __builtin_amdgcn_alignbyte(c[k + 1], c[k], 4 + DELTA);
-    const uint32_t v = nonzero_bytes(q[k] ^ cs);  // bit7 set where q[i] != c[i + DELTA]
-    nz[k + 1] = enabled ? v : 0xFFFFFFFFu;
+    const uint32_t x = q[k] ^ cs;
+    nz[k + 1] = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | off;  // bit7 set where q[i] != c[i + DELTA] (v_or3)
     nmA[k] &= nz[k + 1];
   }
 #pragma unroll
@@ -56,21 +57,23 @@ __device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)
     nmB[k] &= b;
   }
 }
-// band-match bound: a symbol with no equal symbol of the other string within +-d positions costs at least one edit
+// band-match bound: a symbol with no equal symbol of the other string within +-d positions costs at least one edit.
+// Rows are padded beyond their length with bytes that equal nothing (query 0xFE, candidate 0xFF), so the 4*NW - len
+// padding positions always count as unmatched and are subtracted instead of masked.
 template <int NW>
 __device__ inline bool band_bound_rejects(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], bool filt, int d, int lq, int lc) {
   uint32_t nmA[NW], nmB[NW];
 #pragma unroll
   for (int k = 0; k < NW; ++k) { nmA[k] = 0xFFFFFFFFu; nmB[k] = 0xFFFFFFFFu; }
-  filter_shift<0, NW>(q, c, true, nmA, nmB);
-  if (__any(filt && d >= 1)) { filter_shift<1, NW>(q, c, d >= 1, nmA, nmB); filter_shift<-1, NW>(q, c, d >= 1, nmA, nmB); }
-  if (__any(filt && d >= 2)) { filter_shift<2, NW>(q, c, d >= 2, nmA, nmB); filter_shift<-2, NW>(q, c, d >= 2, nmA, nmB); }
-  if (__any(filt && d >= 3)) { filter_shift<3, NW>(q, c, d >= 3, nmA, nmB); filter_shift<-3, NW>(q, c, d >= 3, nmA, nmB); }
-  int unA = 0, unB = 0;
+  filter_shift<0, NW>(q, c, 0u, nmA, nmB);
+  if (__any(filt && d >= 1)) { const uint32_t off = d >= 1 ? 0u : 0xFFFFFFFFu; filter_shift<1, NW>(q, c, off, nmA, nmB); filter_shift<-1, NW>(q, c, off, nmA, nmB); }
+  if (__any(filt && d >= 2)) { const uint32_t off = d >= 2 ? 0u : 0xFFFFFFFFu; filter_shift<2, NW>(q, c, off, nmA, nmB); filter_shift<-2, NW>(q, c, off, nmA, nmB); }
+  if (__any(filt && d >= 3)) { const uint32_t off = d >= 3 ? 0u : 0xFFFFFFFFu; filter_shift<3, NW>(q, c, off, nmA, nmB); filter_shift<-3, NW>(q, c, off, nmA, nmB); }
+  int unA = lq - 4 * NW, unB = lc - 4 * NW;
 #pragma unroll
   for (int k = 0; k < NW; ++k) {
-    unA += __popc(nmA[k] & len_mask(lq, k));
-    unB += __popc(nmB[k] & len_mask(lc, k));
+    unA += __popc(nmA[k] & 0x80808080u);
+    unB += __popc(nmB[k] & 0x80808080u);
   }
   return filt && (unA > d || unB > d);
 }
@@ -322,6 +325,10 @@ struct PairArgs {  // what every scoring kernel reads / writes
   uint32_t* qexpand;
 };
 
+// 32-byte record i of a record array (i < 2^27): a 32-bit byte offset lets the load use the SGPR base + VGPR offset form
+__device__ inline const uint4* rec32(const uint4* base, uint32_t i) {
+  return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (i << 5));
+}
 // Loads the pair of slot p into registers (NW words per string); returns false for !active.
 template <int NW>
 struct PairRegs {
@@ -337,8 +344,8 @@ __device__ inline void load_pair(uint32_t p, bool active, const PairArgs& A, con
   const uint2 rp = A.raw[p];
   r.q = rp.x;
   r.e = rp.y & 0x7FFFFFFFu;
-  const uint4 Q0 = A.q_rec[2 * (size_t)r.q], QM = A.q_rec[2 * (size_t)r.q + 1];
-  const uint4 C0 = A.e_rec[2 * (size_t)r.e], CM = A.e_rec[2 * (size_t)r.e + 1];
+  const uint4 Q0 = rec32(A.q_rec, r.q)[0], QM = rec32(A.q_rec, r.q)[1];
+  const uint4 C0 = rec32(A.e_rec, r.e)[0], CM = rec32(A.e_rec, r.e)[1];
   r.qm = QM.x;
   r.em = CM.x;
   r.lq = r.qm & 0xFF; r.d = (r.qm >> 16) & 0xFF; r.lc = r.em & 0xFF;
@@ -433,38 +440,41 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     const bool live = idx < fill;
     bool selected = false, stop_skipped = false, invalid = false;
     int d = 0, lq = 0, lc = 0;
-    // words that are not loaded keep the row padding (query 0xFE, candidate 0xFF: never equal to anything)
-    uint32_t q8[8] = {0, 0, 0, 0, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
-    uint32_t c10[10] = {0xFFFFFFFFu, 0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     bool filt = false, wide = false;
+    // the first 16 symbols of both strings come with the records (rows are padded with bytes that equal nothing:
+    // query 0xFE, candidate 0xFF); lanes without a pair keep zeros, their verdict is masked by `filt`
+    uint4 Q = make_uint4(0, 0, 0, 0), C = make_uint4(0, 0, 0, 0);
+    uint32_t q = 0, crow = 0;
     if (live) {
       const uint2 rp = A.raw[p];
-      const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+      q = rp.x;
+      const uint32_t e = rp.y & 0x7FFFFFFFu;
       invalid = q == RAW_INVALID;
       // unused chunk tail, or (StopAtExactMatch) a non-exact class of a query that has an exact one
       const bool skip = invalid || (f.stop && !(rp.y & 0x80000000u) && f.qexact[q] != 0xFFFFFFFFu);
       stop_skipped = skip && !invalid;
       if (!skip) {
-        const uint4 Q = A.q_rec[2 * (size_t)q], QM = A.q_rec[2 * (size_t)q + 1];  // 32-B records: one line each
-        const uint4 C = A.e_rec[2 * (size_t)e], CM = A.e_rec[2 * (size_t)e + 1];
+        Q = rec32(A.q_rec, q)[0];  // 32-B records: one line each
+        const uint4 QM = rec32(A.q_rec, q)[1];
+        C = rec32(A.e_rec, e)[0];
+        const uint4 CM = rec32(A.e_rec, e)[1];
         const uint32_t qm = QM.x, em = CM.x;
+        crow = CM.y;
         lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
         const int diff = lq > lc ? lq - lc : lc - lq;
         selected = diff <= d;
         filt = selected && f.enable && d <= 3 && lq <= 32 && lc <= 32;
         wide = filt && (lq > 16 || lc > 16);
-        if (filt) {
-          q8[0] = Q.x; q8[1] = Q.y; q8[2] = Q.z; q8[3] = Q.w;
-          c10[1] = C.x; c10[2] = C.y; c10[3] = C.z; c10[4] = C.w;
-          if (lq > 16) { const uint4 Q1 = A.q_rows[(size_t)q * a.qw + 1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
-          if (lc > 16) { const uint4 C1 = A.rows[CM.y + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
-        }
       }
     }
-    if (__any(wide)) {  // wave-uniform: some pair of the wave has a string of 17..32 symbols
+    if (__any(wide)) {  // wave-uniform, rare: some pair of the wave has a string of 17..32 symbols
+      uint32_t q8[8] = {Q.x, Q.y, Q.z, Q.w, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
+      uint32_t c10[10] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      if (wide && lq > 16) { const uint4 Q1 = A.q_rows[(size_t)q * a.qw + 1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
+      if (wide && lc > 16) { const uint4 C1 = A.rows[crow + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
       if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
     } else if (__any(filt)) {
-      const uint32_t q4[4] = {q8[0], q8[1], q8[2], q8[3]}, c6[6] = {0xFFFFFFFFu, c10[1], c10[2], c10[3], c10[4], 0xFFFFFFFFu};
+      const uint32_t q4[4] = {Q.x, Q.y, Q.z, Q.w}, c6[6] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu};
       if (band_bound_rejects<4>(q4, c6, filt, d, lq, lc)) selected = false;
     }
     if (live && !selected)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
