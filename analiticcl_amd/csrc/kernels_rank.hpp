@@ -17,7 +17,40 @@ __global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ sur
                                                  const uint32_t* __restrict__ var_target_freq,
                                                  const double* __restrict__ var_score, SurvRow* __restrict__ c_rows) {
   const uint32_t region = blockIdx.x % SCAN_REGIONS, i = (blockIdx.x / SCAN_REGIONS) * 256 + threadIdx.x;  // 1-D grid, region fastest
-  if (i >= sctr[region * RC_STRIDE]) return;
+  const bool live = i < sctr[region * RC_STRIDE];
+  if (!a.any_variants) {
+    // Without variant lists every survivor is one row.  Neighbouring survivors often belong to the same query (they come
+    // from the same scan tile), so the lanes of a wave are grouped by query first (ballot loop, no memory traffic) and
+    // only one lane per group bumps the query's cursor: returning atomics sustain ~25 G/s, VALU is idle in this kernel.
+    const uint32_t lane = threadIdx.x & 63;
+    SurvRec sr{0xFFFFFFFFu, 0u, 0.0};
+    if (live) sr = surv[(size_t)region * region_cap + i];
+    uint32_t leader = lane, rank = 0, count = 1;
+    bool pending = live;
+    for (;;) {
+      const unsigned long long mp = __ballot(pending);
+      if (!mp) break;  // wave-uniform
+      const int first = __ffsll((long long)mp) - 1;
+      const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)sr.q, first);
+      const bool mine = pending && sr.q == q0;
+      const unsigned long long ms = __ballot(mine);
+      if (mine) {
+        leader = (uint32_t)first;
+        rank = (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+        count = (uint32_t)__popcll(ms);
+        pending = false;
+      }
+    }
+    if (!__ballot(live)) return;
+    uint32_t base = 0;
+    if (live && leader == lane) base = atomicAdd(&qcur[sr.q], count);
+    base = (uint32_t)__shfl((int)base, (int)leader);
+    if (!live) return;
+    const EntRec er = ent_rec[sr.e];
+    c_rows[base + rank] = SurvRow{sr.score, (unsigned long long)er.order << 20, er.vocab, a.have_freq ? er.freq : 1u, 0xFFFFFFFFu, 0u};
+    return;
+  }
+  if (!live) return;
   const SurvRec sr = surv[(size_t)region * region_cap + i];
   const double s = sr.score;
   const uint32_t e = sr.e, q = sr.q;
