@@ -141,6 +141,22 @@ def edit_script(source: str, target: str) -> str:
     return buf.value.decode("utf-8")
 
 
+def _result_columns(rows, total: int):
+    """anx_result[total] -> (vocab_id, dist_score, freq_score, via) as Python lists, converted in bulk (element-wise
+    ctypes access costs about a microsecond per field)."""
+    import numpy as np
+    if total == 0:
+        return [], [], [], []
+    dt = np.dtype([("vocab_id", "<u8"), ("dist", "<f8"), ("freq", "<f8"), ("via", "<u8")])
+    a = np.frombuffer((C.c_char * (total * dt.itemsize)).from_address(C.addressof(rows.contents)), dtype=dt)
+    return a["vocab_id"].tolist(), a["dist"].tolist(), a["freq"].tolist(), a["via"].tolist()
+
+
+def _offsets(offs, n: int) -> List[int]:
+    import numpy as np
+    return np.ctypeslib.as_array(offs, shape=(n + 1,)).tolist()
+
+
 class Batch:
     """A batch of queries encoded and resident in HBM (anx_batch_*): encode once, run many times."""
 
@@ -169,11 +185,9 @@ class Batch:
         offs = C.POINTER(C.c_size_t)()
         L.check(L.lib().anx_batch_fetch(self.h, C.byref(rows), C.byref(offs)))
         try:
-            out = []
-            for i in range(self.n):
-                out.append([(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score)
-                            for j in range(offs[i], offs[i + 1])])
-            return out
+            off = _offsets(offs, self.n)
+            v, d, f, _via = _result_columns(rows, off[-1])
+            return [list(zip(v[off[i]:off[i + 1]], d[off[i]:off[i + 1]], f[off[i]:off[i + 1]])) for i in range(self.n)]
         finally:
             L.lib().anx_results_free(rows, offs)
 
@@ -248,14 +262,17 @@ class VariantModel:
 
     # -- loading -----------------------------------------------------------------------------------
     def read_vocabulary(self, filename: str, params: Optional[VocabParams] = None):
+        self.__dict__.pop("_vocab_cache", None)
         p = (params or VocabParams())._c()
         L.check(L.lib().anx_model_read_vocabulary(self.h, _b(filename), C.byref(p)))
         self.lexicons.append(filename)
 
     def read_lexicon(self, filename: str):
+        self.__dict__.pop("_vocab_cache", None)
         self.read_vocabulary(filename, VocabParams())
 
     def add_to_vocabulary(self, text: str, frequency: Optional[int] = None, params: Optional[VocabParams] = None):
+        self.__dict__.pop("_vocab_cache", None)
         p = (params or VocabParams())._c()
         return L.lib().anx_model_add_to_vocabulary(self.h, _b(text), 0 if frequency is None else 1,
                                                    frequency or 0, C.byref(p))
@@ -263,6 +280,7 @@ class VariantModel:
     def add_variant(self, ref_id: int, variant: str, score: float, frequency: Optional[int] = None,
                     params: Optional[VocabParams] = None) -> bool:
         """add_variant (src/lib.rs:460): link `variant` to the reference item `ref_id` with a score"""
+        self.__dict__.pop("_vocab_cache", None)
         p = (params or VocabParams())._c()
         rc = L.lib().anx_model_add_variant(self.h, ref_id, _b(variant), float(score), 0 if frequency is None else 1,
                                            frequency or 0, C.byref(p))
@@ -273,11 +291,13 @@ class VariantModel:
     def read_variants(self, filename: str, transparent: bool = False):
         """Load a weighted variant list; transparent=True for error lists whose items are never returned themselves
         (bindings/python/src/lib.rs:671-681)"""
+        self.__dict__.pop("_vocab_cache", None)
         p = VocabParams()._c()
         L.check(L.lib().anx_model_read_variants(self.h, _b(filename), C.byref(p), 1 if transparent else 0))
         self.lexicons.append(filename)
 
     def build(self):
+        self.__dict__.pop("_vocab_cache", None)
         L.check(L.lib().anx_model_build(self.h, self.device))
 
     def save_index(self, filename: str):
@@ -286,6 +306,7 @@ class VariantModel:
 
     def load_index(self, filename: str):
         """Instead of read_lexicon / read_variants / build: load an image written by save_index for the same alphabet."""
+        self.__dict__.pop("_vocab_cache", None)
         L.check(L.lib().anx_model_load_index(self.h, _b(filename), self.device))
         n = L.lib().anx_model_num_lexicons(self.h) if hasattr(L.lib(), "anx_model_num_lexicons") else 0
         self.lexicons = [L.lib().anx_model_lexicon_name(self.h, i).decode("utf-8") for i in range(n)]
@@ -338,12 +359,13 @@ class VariantModel:
         offs = C.POINTER(C.c_size_t)()
         L.check(L.lib().anx_find_variants_batch(self.h, arr, n, C.byref(cp), C.byref(rows), C.byref(offs)))
         try:
+            off = _offsets(offs, n)
+            v, d, f, via = _result_columns(rows, off[-1])
             if with_via:
-                return [[(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score,
-                          None if rows[j].via == L.ANX_NO_VIA else rows[j].via) for j in range(offs[i], offs[i + 1])]
+                via = [None if x == L.ANX_NO_VIA else x for x in via]
+                return [list(zip(v[off[i]:off[i + 1]], d[off[i]:off[i + 1]], f[off[i]:off[i + 1]], via[off[i]:off[i + 1]]))
                         for i in range(n)]
-            return [[(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score) for j in range(offs[i], offs[i + 1])]
-                    for i in range(n)]
+            return [list(zip(v[off[i]:off[i + 1]], d[off[i]:off[i + 1]], f[off[i]:off[i + 1]])) for i in range(n)]
         finally:
             L.lib().anx_results_free(rows, offs)
 
@@ -351,11 +373,15 @@ class VariantModel:
         # variantresult_to_dict, bindings/python/src/lib.rs:554-588
         fw = float(freq_weight)
         score = dist if fw == 0.0 else (dist + fw * freq) / (1.0 + fw)
-        lexindex = L.lib().anx_model_vocab_lexindex(self.h, vid)
-        d = {"text": self.vocab_text(vid), "score": score, "dist_score": dist, "freq_score": freq}
+        cache = self.__dict__.setdefault("_vocab_cache", {})  # vocabulary items do not change after build()
+        hit = cache.get(vid)
+        if hit is None:
+            lexindex = L.lib().anx_model_vocab_lexindex(self.h, vid)
+            hit = cache[vid] = (self.vocab_text(vid), [name for i, name in enumerate(self.lexicons) if lexindex & (1 << i)])
+        d = {"text": hit[0], "score": score, "dist_score": dist, "freq_score": freq}
         if via is not None:
             d["via"] = self.vocab_text(via)
-        d["lexicons"] = [name for i, name in enumerate(self.lexicons) if lexindex & (1 << i)]
+        d["lexicons"] = list(hit[1])
         return d
 
     def find_variants(self, input: str, params: SearchParameters) -> List[dict]:
@@ -381,19 +407,30 @@ class VariantModel:
         L.check(L.lib().anx_find_all_matches_batch(self.h, arr, n, C.byref(sp), C.byref(ms), C.byref(offs),
                                                    C.byref(rows), C.byref(nrows), C.byref(tags)))
         try:
-            out = []
-            for i in range(n):
-                cur = []
-                for j in range(offs[i], offs[i + 1]):
-                    m = ms[j]
-                    cur.append({"begin": m.begin, "end": m.end, "n": m.n,
-                                "selected": None if m.selected < 0 else m.selected,
-                                "variants": [(rows[r].vocab_id, rows[r].dist_score, rows[r].freq_score,
-                                              None if rows[r].via == L.ANX_NO_VIA else rows[r].via)
-                                             for r in range(m.var_begin, m.var_end)],
-                                "tag": [tags[k].tag for k in range(m.tag_begin, m.tag_end)],
-                                "seqnr": [tags[k].seqnr for k in range(m.tag_begin, m.tag_end)]})
-                out.append(cur)
+            import numpy as np
+            off = _offsets(offs, n)
+            v, d, f, via = _result_columns(rows, nrows.value)
+            via = [None if x == L.ANX_NO_VIA else x for x in via]
+            out = [[] for _ in range(n)]
+            if off[-1]:
+                mdt = np.dtype([("begin", "<u8"), ("end", "<u8"), ("n", "<u4"), ("selected", "<i4"), ("vb", "<u8"), ("ve", "<u8"),
+                                ("tb", "<u4"), ("te", "<u4")])
+                ma = np.frombuffer((C.c_char * (off[-1] * mdt.itemsize)).from_address(C.addressof(ms.contents)), dtype=mdt)
+                cols = [ma[k].tolist() for k in ("begin", "end", "n", "selected", "vb", "ve", "tb", "te")]
+                ntags = max(cols[7]) if cols[7] else 0
+                tg = sq = []
+                if ntags:
+                    tdt = np.dtype([("tag", "<u2"), ("seqnr", "u1"), ("pad", "u1")])
+                    ta = np.frombuffer((C.c_char * (ntags * tdt.itemsize)).from_address(C.addressof(tags.contents)), dtype=tdt)
+                    tg, sq = ta["tag"].tolist(), ta["seqnr"].tolist()
+                for i in range(n):
+                    cur = out[i]
+                    for j in range(off[i], off[i + 1]):
+                        vb, ve, tb, te = cols[4][j], cols[5][j], cols[6][j], cols[7][j]
+                        cur.append({"begin": cols[0][j], "end": cols[1][j], "n": cols[2][j],
+                                    "selected": None if cols[3][j] < 0 else cols[3][j],
+                                    "variants": list(zip(v[vb:ve], d[vb:ve], f[vb:ve], via[vb:ve])),
+                                    "tag": tg[tb:te], "seqnr": sq[tb:te]})
             return out
         finally:
             L.lib().anx_matches_free(ms, offs, rows, tags)

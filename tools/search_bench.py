@@ -36,10 +36,10 @@ spc = p._c_search()
 for rep in range(2):  # the C entry point alone (what a Rust / C caller sees)
     ms, offs, rows, nrows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)(), C.c_size_t(0)
     t = time.time()
-    L.check(L.lib().anx_find_all_matches_batch(m.h, arr, len(texts), C.byref(spc), C.byref(ms), C.byref(offs), C.byref(rows), C.byref(nrows)))
+    L.check(L.lib().anx_find_all_matches_batch(m.h, arr, len(texts), C.byref(spc), C.byref(ms), C.byref(offs), C.byref(rows), C.byref(nrows), None))
     dt = time.time() - t
     print(f"C ABI: {size/1e6:.1f} MB in {dt:.2f} s = {size/1e6/dt:.2f} MB/s, {offs[len(texts)]} matches, {nrows.value} variant rows")
-    L.lib().anx_matches_free(ms, offs, rows)
+    L.lib().anx_matches_free(ms, offs, rows, None)
 for rep in range(1):
     t = time.time()
     res = m.find_all_matches_ids(texts, p)
