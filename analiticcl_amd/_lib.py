@@ -130,6 +130,12 @@ def lib():
         "anx_find_variants_batch": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(Params),
                                               C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
         "anx_results_free": (None, [C.POINTER(Result), C.POINTER(sz)]),
+        "anx_format_query_output": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(Result), C.POINTER(sz), C.c_float, C.c_int,
+                                              C.c_int, u64, C.POINTER(C.c_void_p), C.POINTER(sz)]),
+        "anx_string_free": (None, [C.c_void_p]),
+        "anx_format_search_output": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(Match), C.POINTER(sz), C.POINTER(Result),
+                                               C.POINTER(MatchTag), C.c_float, C.c_int, C.c_int, u64,
+                                               C.POINTER(C.c_void_p), C.POINTER(sz)]),
         "anx_default_search_params": (None, [C.POINTER(SearchParams)]),
         "anx_find_all_matches_batch": (C.c_int, [vp, C.POINTER(cp), sz, C.POINTER(SearchParams),
                                                  C.POINTER(C.POINTER(Match)), C.POINTER(C.POINTER(sz)),

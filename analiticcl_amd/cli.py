@@ -195,12 +195,9 @@ def run_query(model, params, a, out) -> None:
         nonlocal seqnr
         if not batch:
             return
-        for item in model.find_variants_par(batch, params):
-            seqnr += 1
-            if a.json:
-                out.write(json_item(item["input"], item["variants"], seqnr, None, a.output_lexmatch))
-            else:
-                out.write(tsv_line(item["input"], item["variants"], None, a.output_lexmatch) + "\n")
+        # one device batch, formatted natively (anx_format_query_output = tsv_line / json_item of this module)
+        out.write(model.query_output(batch, params, a.json, a.output_lexmatch, seqnr + 1))
+        seqnr += len(batch)
         out.flush()
         batch.clear()
 
@@ -233,17 +230,12 @@ def run_search(model, params, a, out) -> None:
                 break
             if text == "":
                 break
-        matches = model.find_all_matches(text, params) if text else []
-        if seqnr > 0 and matches:
+        # one text through find_all_matches, formatted natively (anx_format_search_output = tsv_line / json_item above)
+        text_out, nmatches = model.search_output([text], params, a.json, a.output_lexmatch, seqnr + 1) if text else ("", 0)
+        if seqnr > 0 and nmatches:
             out.write("\n")
-        for m in matches:
-            seqnr += 1
-            off = (m["offset"]["begin"], m["offset"]["end"])
-            variants = m["variants"]
-            if a.json:
-                out.write(json_item(m["input"], variants, seqnr, off, a.output_lexmatch, m.get("tag", ()), m.get("seqnr", ())))
-            else:
-                out.write(tsv_line(m["input"], variants, off, a.output_lexmatch) + "\n")
+        out.write(text_out)
+        seqnr += nmatches
         out.flush()
 
 

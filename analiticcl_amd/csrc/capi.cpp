@@ -1,5 +1,6 @@
 // capi.cpp -- the extern "C" boundary declared in include/anx.h.
 #include <cstdlib>
+#include <charconv>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -279,6 +280,161 @@ int anx_model_anahash(const anx_model* m, const char* utf8, char* out, int cap) 
   memcpy(out, s.c_str(), s.size() + 1);
   return (int)s.size();
 }
+
+// Rust's `{}` for f64: shortest digits that round-trip, positional notation, "1" for 1.0, NaN / inf / -inf
+static void append_rust_f64(std::string& o, double x) {
+  if (x != x) { o += "NaN"; return; }
+  if (x == __builtin_inf()) { o += "inf"; return; }
+  if (x == -__builtin_inf()) { o += "-inf"; return; }
+  char buf[400];
+  const auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::fixed);
+  o.append(buf, r.ptr);
+}
+static void append_json_escaped(std::string& o, const char* s) {  // only '"' is escaped (src/bin/analiticcl.rs:94)
+  for (; *s; ++s) {
+    if (*s == '"') o += '\\';
+    o += *s;
+  }
+}
+namespace {
+struct OutputFormatter {  // shared by the query and search writers
+  const anx::HostModel& h;
+  double fw;
+  bool lexmatch;
+  std::string o;
+  const char* text_of(uint64_t id) const { return id < h.decoder.size() ? h.decoder[id].text.c_str() : ""; }
+  void lexnames(uint64_t id, const char* sep, bool quoted) {
+    const uint32_t lexindex = id < h.decoder.size() ? h.decoder[id].lexindex : 0u;
+    bool first = true;
+    for (size_t i = 0; i < h.lexicons.size() && i < 32; ++i)
+      if (lexindex & (1u << i)) {
+        if (!first) o += sep;
+        first = false;
+        if (quoted) { o += '"'; append_json_escaped(o, h.lexicons[i].c_str()); o += '"'; }
+        else o += h.lexicons[i];
+      }
+  }
+  double score(const anx_result& v) const { return fw == 0.0 ? v.dist_score : (v.dist_score + fw * v.freq_score) / (1.0 + fw); }
+  void tsv_variant(const anx_result& v) {  // output_result_as_tsv, bin:60-76
+    o += '\t';
+    o += text_of(v.vocab_id);
+    o += '\t';
+    append_rust_f64(o, score(v));
+    o += '\t';
+    if (lexmatch) { o += "\t\""; lexnames(v.vocab_id, ";", false); o += '"'; }
+  }
+  void json_variant(const anx_result& v, bool first) {  // output_result_as_json, bin:150-187
+    if (!first) o += ",\n";
+    o += "        { \"text\": \"";
+    append_json_escaped(o, text_of(v.vocab_id));
+    o += "\", \"score\": ";
+    append_rust_f64(o, score(v));
+    o += ", \"dist_score\": ";
+    append_rust_f64(o, v.dist_score);
+    o += ", \"freq_score\": ";
+    append_rust_f64(o, v.freq_score);
+    if (v.via != ANX_NO_VIA) {
+      o += ", \"via\": \"";
+      append_json_escaped(o, text_of(v.via));
+      o += '"';
+    }
+    if (lexmatch) { o += ", \"lexicons\": [ "; lexnames(v.vocab_id, ", ", true); o += " ]"; }
+    o += " }";
+  }
+  int finish(char** out, size_t* out_len) {
+    char* buf = static_cast<char*>(malloc(o.size() + 1));
+    if (!buf) return fail(ANX_EINVAL, "out of memory");
+    memcpy(buf, o.data(), o.size());
+    buf[o.size()] = 0;
+    *out = buf;
+    *out_len = o.size();
+    return ANX_OK;
+  }
+};
+}  // namespace
+
+int anx_format_query_output(const anx_model* m, const char* const* inputs, size_t n, const anx_result* rows,
+                            const size_t* offs, float freq_weight, int json, int output_lexmatch,
+                            uint64_t first_seqnr, char** out, size_t* out_len) {
+  if (!m || (!inputs && n) || !offs || (!rows && n && offs[n]) || !out || !out_len) return fail(ANX_EINVAL, "NULL argument");
+  OutputFormatter f{m->host, (double)freq_weight, output_lexmatch != 0, {}};
+  f.o.reserve(n * 96);
+  for (size_t i = 0; i < n; ++i) {
+    const char* inp = inputs[i] ? inputs[i] : "";
+    if (!json) {  // output_matches_as_tsv, bin:21-76
+      f.o += inp;
+      for (size_t r = offs[i]; r < offs[i + 1]; ++r) f.tsv_variant(rows[r]);
+      f.o += '\n';
+      continue;
+    }
+    // output_matches_as_json, bin:78-187
+    f.o += first_seqnr + i > 1 ? "    ," : "    ";
+    f.o += "{ \"input\": \"";
+    append_json_escaped(f.o, inp);
+    f.o += "\", \"variants\": [ \n";
+    for (size_t r = offs[i]; r < offs[i + 1]; ++r) f.json_variant(rows[r], r == offs[i]);
+    f.o += "\n    ] }\n";
+  }
+  return f.finish(out, out_len);
+}
+
+int anx_format_search_output(const anx_model* m, const char* const* texts, size_t n, const anx_match* matches,
+                             const size_t* offs, const anx_result* rows, const anx_match_tag* tags, float freq_weight,
+                             int json, int output_lexmatch, uint64_t first_seqnr, char** out, size_t* out_len) {
+  if (!m || (!texts && n) || !offs || (!matches && n && offs[n]) || !out || !out_len) return fail(ANX_EINVAL, "NULL argument");
+  OutputFormatter f{m->host, (double)freq_weight, output_lexmatch != 0, {}};
+  uint64_t seqnr = first_seqnr;
+  for (size_t t = 0; t < n; ++t) {
+    const char* text = texts[t] ? texts[t] : "";
+    const size_t len = strlen(text);
+    for (size_t j = offs[t]; j < offs[t + 1]; ++j, ++seqnr) {
+      const anx_match& mt = matches[j];
+      if (mt.begin > mt.end || mt.end > len) return fail(ANX_EINVAL, "match offsets outside the text (byte offsets are required)");
+      const std::string inp(text + mt.begin, text + mt.end);
+      const size_t vb = mt.var_begin, ve = mt.var_end;
+      const bool has_sel = mt.selected >= 0 && vb + (size_t)mt.selected < ve;
+      if (!json) {  // bin:21-58: input, begin:end, the selected variant first
+        f.o += inp;
+        f.o += '\t';
+        f.o += std::to_string(mt.begin);
+        f.o += ':';
+        f.o += std::to_string(mt.end);
+        if (has_sel) f.tsv_variant(rows[vb + (size_t)mt.selected]);
+        for (size_t r = vb; r < ve; ++r)
+          if (!has_sel || r != vb + (size_t)mt.selected) f.tsv_variant(rows[r]);
+        f.o += '\n';
+        continue;
+      }
+      f.o += seqnr > 1 ? "    ," : "    ";
+      f.o += "{ \"input\": \"";
+      append_json_escaped(f.o, inp.c_str());
+      f.o += "\", \"begin\": " + std::to_string(mt.begin) + ", \"end\": " + std::to_string(mt.end);
+      if (tags && mt.tag_end > mt.tag_begin) {  // bin:99-121
+        f.o += ", \"tag\": [";
+        for (uint32_t k = mt.tag_begin; k < mt.tag_end; ++k) {
+          if (k > mt.tag_begin) f.o += ',';
+          f.o += '"';
+          f.o += tags[k].tag < m->host.tags.size() ? m->host.tags[tags[k].tag] : std::string();
+          f.o += '"';
+        }
+        f.o += "], \"seqnr\": [ ";
+        for (uint32_t k = mt.tag_begin; k < mt.tag_end; ++k) {
+          if (k > mt.tag_begin) f.o += ',';
+          f.o += std::to_string((unsigned)tags[k].seqnr);
+        }
+        f.o += ']';
+      }
+      f.o += ", \"variants\": [ \n";
+      bool first = true;
+      if (has_sel) { f.json_variant(rows[vb + (size_t)mt.selected], true); first = false; }
+      for (size_t r = vb; r < ve; ++r)
+        if (!has_sel || r != vb + (size_t)mt.selected) { f.json_variant(rows[r], first); first = false; }
+      f.o += "\n    ] }\n";
+    }
+  }
+  return f.finish(out, out_len);
+}
+void anx_string_free(char* s) { free(s); }
 
 int anx_model_add_to_confusables(anx_model* m, const char* editscript, double weight) {
   if (!m || !editscript) return fail(ANX_EINVAL, "NULL argument");

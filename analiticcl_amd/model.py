@@ -369,6 +369,27 @@ class VariantModel:
         finally:
             L.lib().anx_results_free(rows, offs)
 
+    def query_output(self, inputs: Sequence[str], params: SearchParameters, json: bool = False,
+                     output_lexmatch: bool = False, first_seqnr: int = 1) -> str:
+        """One device batch + the text `analiticcl query` prints for it (anx_format_query_output: the TSV lines or JSON
+        items of src/bin/analiticcl.rs:21-187, formatted natively)."""
+        n = len(inputs)
+        arr = (C.c_char_p * max(n, 1))(*[_b(t) for t in inputs])
+        cp = params._c()
+        rows = C.POINTER(L.Result)()
+        offs = C.POINTER(C.c_size_t)()
+        L.check(L.lib().anx_find_variants_batch(self.h, arr, n, C.byref(cp), C.byref(rows), C.byref(offs)))
+        try:
+            buf, ln = C.c_void_p(), C.c_size_t(0)
+            L.check(L.lib().anx_format_query_output(self.h, arr, n, rows, offs, float(params.freq_weight), int(bool(json)),
+                                                    int(bool(output_lexmatch)), first_seqnr, C.byref(buf), C.byref(ln)))
+            try:
+                return C.string_at(buf, ln.value).decode("utf-8")
+            finally:
+                L.lib().anx_string_free(buf)
+        finally:
+            L.lib().anx_results_free(rows, offs)
+
     def _to_dict(self, vid: int, dist: float, freq: float, freq_weight: float, via: Optional[int] = None) -> Dict:
         # variantresult_to_dict, bindings/python/src/lib.rs:554-588
         fw = float(freq_weight)
@@ -432,6 +453,32 @@ class VariantModel:
                                     "variants": list(zip(v[vb:ve], d[vb:ve], f[vb:ve], via[vb:ve])),
                                     "tag": tg[tb:te], "seqnr": sq[tb:te]})
             return out
+        finally:
+            L.lib().anx_matches_free(ms, offs, rows, tags)
+
+    def search_output(self, texts: Sequence[str], params: SearchParameters, json: bool = False,
+                      output_lexmatch: bool = False, first_seqnr: int = 1):
+        """find_all_matches over the texts + the text `analiticcl search` prints for the matches
+        (anx_format_search_output) -> (text, number of matches)."""
+        if params.unicodeoffsets:
+            raise ValueError("search_output needs byte offsets (unicodeoffsets=False)")
+        n = len(texts)
+        arr = (C.c_char_p * max(n, 1))(*[_b(t) for t in texts])
+        sp = params._c_search()
+        ms, offs, rows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)()
+        tags = C.POINTER(L.MatchTag)()
+        nrows = C.c_size_t(0)
+        L.check(L.lib().anx_find_all_matches_batch(self.h, arr, n, C.byref(sp), C.byref(ms), C.byref(offs),
+                                                   C.byref(rows), C.byref(nrows), C.byref(tags)))
+        try:
+            buf, ln = C.c_void_p(), C.c_size_t(0)
+            L.check(L.lib().anx_format_search_output(self.h, arr, n, ms, offs, rows, tags, float(params.freq_weight),
+                                                     int(bool(json)), int(bool(output_lexmatch)), first_seqnr,
+                                                     C.byref(buf), C.byref(ln)))
+            try:
+                return C.string_at(buf, ln.value).decode("utf-8"), int(offs[n])
+            finally:
+                L.lib().anx_string_free(buf)
         finally:
             L.lib().anx_matches_free(ms, offs, rows, tags)
 

@@ -201,6 +201,16 @@ typedef struct anx_batch_stats {
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
 void anx_batch_free(anx_batch *);
 
+/* ---- output of `analiticcl query` --------------------------------------------------
+ * The TSV lines / JSON items of output_matches_as_tsv / output_matches_as_json (src/bin/analiticcl.rs:21-187) for n
+ * inputs and their ranked rows as anx_find_variants_batch returns them: one malloc'd UTF-8 buffer (not NUL-safe:
+ * use *out_len), released with anx_string_free.  JSON items are numbered from first_seqnr (1 = first of the run, which
+ * gets no leading comma).  Scores print like Rust's `{}` for f64 (shortest round-trip digits, no exponent). */
+int anx_format_query_output(const anx_model *, const char *const *utf8_inputs, size_t n, const anx_result *rows,
+                            const size_t *offsets, float freq_weight, int json, int output_lexmatch,
+                            uint64_t first_seqnr, char **out, size_t *out_len);
+void anx_string_free(char *);
+
 /* ---- confusables --------------------------------------------------------------
  * add_to_confusables / read_confusablelist / set_confusables_before_pruning: src/lib.rs:446-458, :409-443, :157-159.
  * Patterns are sesdiff edit scripts ("-[y]+[i]", "=[c|k]-[y]+[i]", "^...", "...$"; src/confusables.rs:13-44).  With
@@ -248,6 +258,13 @@ int anx_find_all_matches_batch(const anx_model *, const char *const *utf8_texts,
                                anx_match **out_matches, size_t **out_offsets, anx_result **out_rows, size_t *out_n_rows,
                                anx_match_tag **out_tags);
 void anx_matches_free(anx_match *matches, size_t *offsets, anx_result *rows, anx_match_tag *tags);
+/* the text `analiticcl search` prints for the matches of n texts (src/bin/analiticcl.rs:21-187, 600-630): per match the
+ * input slice, its offsets, tags, and the variants with the selected one first.  Needs byte offsets (unicodeoffsets
+ * = 0).  *n_matches = matches formatted (JSON items are numbered from first_seqnr). */
+int anx_format_search_output(const anx_model *, const char *const *utf8_texts, size_t n, const anx_match *matches,
+                             const size_t *offsets, const anx_result *rows, const anx_match_tag *tags,
+                             float freq_weight, int json, int output_lexmatch, uint64_t first_seqnr, char **out,
+                             size_t *out_len);
 
 /* ---- context rules of search mode -----------------------------------------------------------------------------
  * VariantModel::add_contextrule(pattern, score, tag, tagoffset), src/lib.rs:658-765; read_contextrules, :570-656.

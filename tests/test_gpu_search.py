@@ -310,3 +310,57 @@ def test_cli_query_readme_line(data_dir, tmp_path, capsys):
     import json
     js = json.loads(capsys.readouterr().out)
     assert js[0]["input"] == "seperate" and js[0]["begin"] == 0 and js[0]["end"] == 8 and js[0]["variants"][0]["text"] == "separate"
+
+
+def test_native_query_output_equals_python_formatter(data_dir, tmp_path):
+    """anx_format_query_output (the text `query` mode prints) == tsv_line / json_item of analiticcl_amd/cli.py (which
+    tests/test_cli_cpu.py pins to the reference's formats), incl. lexicon names, frequency-weighted scores, `via` of
+    variant lists, quotes in the input and empty result lists."""
+    from analiticcl_amd import cli
+    lex2 = tmp_path / "extra.tsv"
+    lex2.write_text("separate\t5\nzebra\t2\nquote\"d\t1\n")
+    vl = tmp_path / "variants.tsv"
+    vl.write_text("separate\tseperate\t1.0\tseparete\t0.9\n")
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    g.read_lexicon(str(lex2))
+    g.read_variants(str(vl))
+    g.build()
+    qs = ["seperate", "zebr", 'quote"d', "", "xqzzyvw", "recieve", "separete", "tesst"] + \
+        synth.make_queries(synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz")), 300, seed=3)
+    for fw in (0.0, 0.5):
+        p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, score_threshold=0.25,
+                               cutoff_threshold=2.0, freq_weight=fw)
+        items = g.find_variants_par(qs, p)
+        for lexmatch in (False, True):
+            exp = "".join(cli.tsv_line(it["input"], it["variants"], None, lexmatch) + "\n" for it in items)
+            assert g.query_output(qs, p, False, lexmatch) == exp
+            exp = "".join(cli.json_item(it["input"], it["variants"], 5 + i, None, lexmatch) for i, it in enumerate(items))
+            assert g.query_output(qs, p, True, lexmatch, 5) == exp
+        first = g.query_output(qs[:2], p, True, False, 1)
+        assert first.startswith('    { "input": "seperate"') and '\n    ,{ "input": "zebr"' in first
+    assert any("via" in v for it in items for v in it["variants"])
+
+
+def test_native_search_output_equals_python_formatter():
+    """anx_format_search_output == tsv_line / json_item over find_all_matches (selected variant first, offsets, tags)."""
+    from analiticcl_amd import cli
+    g = lm_model()
+    g.add_contextrule("I; think", 1.1, ["subj", "pair"], ["0:1", ":"])
+    texts = ["I tink you are rihgt", "you are\nrihgt, I sink!", "", "zzzzqq I"]
+    for kw in (dict(), dict(lm_weight=0.0), dict(max_ngram=1)):
+        p = sparams(**kw)
+        for lexmatch in (False, True):
+            for js in (False, True):
+                seq, exp = 1, ""
+                for t in texts:
+                    for m in (g.find_all_matches(t, p) if t else []):
+                        off = (m["offset"]["begin"], m["offset"]["end"])
+                        exp += (cli.json_item(m["input"], m["variants"], seq, off, lexmatch, m.get("tag", ()), m.get("seqnr", ()))
+                                if js else cli.tsv_line(m["input"], m["variants"], off, lexmatch) + "\n")
+                        seq += 1
+                got, n = g.search_output(texts, p, js, lexmatch, 1)
+                assert got == exp and n == seq - 1
+    assert '"tag": ["subj","pair"], "seqnr": [ 0,0]' in g.search_output(["I tink"], sparams(), True)[0]
+    with pytest.raises(ValueError):
+        g.search_output(["I"], sparams(unicodeoffsets=True))
