@@ -364,3 +364,29 @@ def test_native_search_output_equals_python_formatter():
     assert '"tag": ["subj","pair"], "seqnr": [ 0,0]' in g.search_output(["I tink"], sparams(), True)[0]
     with pytest.raises(ValueError):
         g.search_output(["I"], sparams(unicodeoffsets=True))
+
+
+def test_cli_search_with_contextrules(tmp_path, capsys):
+    """`search --contextrules FILE --json`: the rule file is read after the lexicons (bin:1097-1109) and the tags of the
+    winning sequence are printed (bin:99-121)."""
+    import json
+    from analiticcl_amd import cli
+    alphabet = tmp_path / "alphabet.tsv"
+    alphabet.write_text(TEST_ALPHABET_TSV)
+    lex = tmp_path / "lex.tsv"
+    lex.write_text("".join(f"{w}\t2\n" for w in ("I", "think", "sink", "you", "are", "right")))
+    rules = tmp_path / "rules.tsv"
+    rules.write_text("I; think\t1.1\tsubject-verb\n")
+    inp = tmp_path / "in.txt"
+    inp.write_text("I tink you are rihgt\n")
+    argv = ["search", "--lexicon", str(lex), "--alphabet", str(alphabet), "--json", "-k", "2", "-d", "2", "--weight-lm", "0",
+            "--max-ngram-order", "1", str(inp)]
+    assert cli.main(argv + ["--contextrules", str(rules)]) == 0
+    js = json.loads(capsys.readouterr().out)
+    assert [m["variants"][0]["text"] for m in js] == ["I", "think", "you", "are", "right"]
+    assert (js[0]["tag"], js[0]["seqnr"], js[1]["tag"], js[1]["seqnr"]) == (["subject-verb"], [0], ["subject-verb"], [1])
+    assert "tag" not in js[2]
+    rules.write_text("I; think\t0.9\n")  # the penalty makes "sink" win (tests/main.rs:1613-1640)
+    assert cli.main(argv + ["-R", str(rules)]) == 0
+    js = json.loads(capsys.readouterr().out)
+    assert [m["variants"][0]["text"] for m in js] == ["I", "sink", "you", "are", "right"]
