@@ -149,3 +149,57 @@ def test_index_image_roundtrip(data_dir, tmp_path):
     open(img, "wb").write(data[: len(data) // 2])
     with pytest.raises(A.AnxError):
         A.VariantModel(alphabet, A.Weights(), device=-1).load_index(img)
+
+
+def test_contextrules_host_side(tmp_path):
+    """add_contextrule / read_contextrules (src/lib.rs:570-765, src/search.rs:413-459) are host logic: patterns, tags,
+    tag offsets and the error cases, on a model without a device."""
+    amph, rept = tmp_path / "amphibians.tsv", tmp_path / "reptiles.tsv"
+    amph.write_text("salamander\t3\nfrog\t3\ntoad\t2\n")
+    rept.write_text("lizard\t3\nsnake\t3\n")
+    m = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=-1)
+    m.read_lexicon(str(amph))
+    m.read_lexicon(str(rept))
+    m.add_contextrule("frog; ?; ^", 1.1, ["a", "b"], ["0:1", "1:"])
+    m.add_contextrule("@amphibians.tsv; !@reptiles.tsv", 0.9)
+    m.add_contextrule("frog|toad; !(snake|lizard)", 1.2, ["a"])
+    assert m.tags == ["a", "b"]
+    assert L.lib().anx_model_num_tags(m.h) == 2 and L.lib().anx_model_tag_name(m.h, 5) is None
+    for bad in (("newt", 1.0, [], []), ("@missing.tsv", 1.0, [], []), ("frog", 1.0, ["t"], ["x:1"]), ("frog", 1.0, ["t"], ["0:y"]),
+                ("frog", 1.0, [""], []), ("frog; ", 1.0, [], [])):
+        with pytest.raises(A.AnxError):
+            m.add_contextrule(*bad)
+    rules = tmp_path / "rules.tsv"
+    rules.write_text("# comment\n\nfrog; toad\t1.5\tpair\n\t1.0\nsnake\t0.8\tx; y\t0:1; :\n")
+    m.read_contextrules(str(rules))
+    assert m.tags == ["a", "b", "t", "", "pair", "x", "y"]  # tags are interned before a rule is rejected (src/lib.rs:680-700)
+    for text in ("frog\n", "frog\tabc\n", "frog\t1.0\tx; y\n", "frog\t1.0\tx\t0:1; 1:1\n"):
+        bad = tmp_path / "bad.tsv"
+        bad.write_text(text)
+        with pytest.raises(A.AnxError):
+            m.read_contextrules(str(bad))
+    with pytest.raises(A.AnxError):
+        m.read_contextrules(str(tmp_path / "does-not-exist.tsv"))
+
+
+def test_output_formatters_host_side():
+    """anx_format_query_output on hand-made rows (no device): Rust's f64 Display, TSV / JSON shapes (bin:21-187)."""
+    m = A.VariantModel("", alphabet_text=TEST_ALPHABET_TSV, device=-1)
+    ids = [m.add_to_vocabulary(w, 3) for w in ("separate", 'qu"ote')]
+    rows = (L.Result * 3)()
+    for r, (vid, d, f) in zip(rows, ((ids[0], 0.734375, 1.0), (ids[1], 1.0, 0.5), (ids[0], 1e-7, 0.25))):
+        r.vocab_id, r.dist_score, r.freq_score, r.via = vid, d, f, L.ANX_NO_VIA
+    offs = (ctypes.c_size_t * 3)(0, 2, 3)
+    inputs = (ctypes.c_char_p * 2)(b"seperate", b'x"y')
+    def fmt(js, fw, first=1):
+        buf, ln = ctypes.c_void_p(), ctypes.c_size_t(0)
+        L.check(L.lib().anx_format_query_output(m.h, inputs, 2, rows, offs, fw, js, 0, first, ctypes.byref(buf), ctypes.byref(ln)))
+        s = ctypes.string_at(buf, ln.value).decode()
+        L.lib().anx_string_free(buf)
+        return s
+    assert fmt(0, 0.0) == 'seperate\tseparate\t0.734375\t\tqu"ote\t1\t\nx"y\tseparate\t0.0000001\t\n'
+    assert fmt(0, 1.0).startswith("seperate\tseparate\t0.8671875\t\tqu\"ote\t0.75\t\n")
+    js = fmt(1, 0.0, 1)
+    assert js.startswith('    { "input": "seperate", "variants": [ \n        { "text": "separate", "score": 0.734375, "dist_score": 0.734375, "freq_score": 1 },\n')
+    assert '{ "text": "qu\\"ote", "score": 1, "dist_score": 1, "freq_score": 0.5 }\n    ] }\n    ,{ "input": "x\\"y"' in js
+    assert fmt(1, 0.0, 7).startswith("    ,{")
