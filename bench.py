@@ -197,6 +197,11 @@ def main():
                     "algorithmic_bytes_per_launch": kbytes,
                     "note": "integer scan / DL path: VALU-issue and L2-gather bound, below the HBM roof (DESIGN.md section 5)",
                     "kernels_ms": {"k_scan_bits": scan_ms, "k_filter_score": fs_ms},
+                    # both candidates for "dominant" (they take ~1.6 ms each; which one is slower varies by run)
+                    "per_kernel": {name: {"avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+                                          "achieved": (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
+                                          "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0)}
+                                   for name, nbytes, ms in (("k_scan_bits", scan_bytes, scan_ms), ("k_filter_score", fs_bytes, fs_ms))},
                     "pipeline_algorithmic_bytes": pipeline_bytes, "pipeline_gbs": pipeline_gbs,
                     "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
                     "scan_valu_issue_floor_ms": valu_floor_ms,
