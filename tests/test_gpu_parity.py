@@ -435,3 +435,34 @@ def test_large_alphabets_take_the_count_vector_kernel(nclasses, tmp_path):
     gp, op = params_pair(("abs", 3), ("abs", 2), 10, 0.2, 2.0)
     st = compare_batch(g, o, qs, gp, op)
     assert st["n_tests_kind"][0] > 0 and sum(st["n_tests_kind"][1:]) == 0
+
+
+def test_concurrent_calls_from_host_threads(eng):
+    """find_variants takes &self in the reference and is called from a rayon pool (src/bin/analiticcl.rs:445-448); the
+    C entry point must therefore be callable from several host threads on one model at once (ctypes drops the GIL
+    during the call).  Every thread's results equal the sequential ones."""
+    import threading
+    from analiticcl_amd import synth
+    g, _ = eng
+    words = synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz"))
+    ps = [A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0),
+          A.SearchParameters(max_anagram_distance=2, max_edit_distance=2, max_matches=3, score_threshold=0.1, cutoff_threshold=0.0),
+          A.SearchParameters(max_anagram_distance=3, max_edit_distance=3, max_matches=20, stop_criterion=True)]
+    jobs = [(synth.make_queries(words, 4000 + 500 * i, max_len=20, seed=100 + i), ps[i % 3]) for i in range(6)]
+    expected = [g.find_variants_ids(q, p) for q, p in jobs]
+    got = [None] * len(jobs)
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = g.find_variants_ids(*jobs[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    assert got == expected
