@@ -109,19 +109,29 @@ def main():
     step_no = [0]
     gather_bytes = [0]
 
+    gather_error = [None]
+
     def step():
         batch.run(stream.cuda_stream)
-        if do_gather:
-            i = step_no[0] & 1
-            buf = gather.acquire(i)        # the stream waits for the transfer that last used this buffer
-            used = batch.export_compact(buf.data_ptr(), buf.numel(), stream.cuda_stream)
-            gather.submit(i, used)
-            gather_bytes[0] = used
-            step_no[0] += 1
+        if do_gather and gather_error[0] is None:
+            try:
+                i = step_no[0] & 1
+                buf = gather.acquire(i)        # the stream waits for the transfer that last used this buffer
+                used = batch.export_compact(buf.data_ptr(), buf.numel(), stream.cuda_stream)
+                gather.submit(i, used)
+                gather_bytes[0] = used
+                step_no[0] += 1
+            except Exception as e:  # noqa: BLE001 -- keep the compute measurement; the JSON line says what happened
+                gather_error[0] = repr(e)[:200]
+                sys.stderr.write(f"[bench] rank {rank}: result gather disabled: {gather_error[0]}\n")
 
     def drain():
-        if do_gather:
-            gather.flush()
+        if do_gather and gather_error[0] is None:
+            try:
+                gather.flush()
+            except Exception as e:  # noqa: BLE001
+                gather_error[0] = repr(e)[:200]
+                sys.stderr.write(f"[bench] rank {rank}: result gather failed in flush: {gather_error[0]}\n")
 
     def barrier():
         drain()
@@ -251,7 +261,8 @@ def main():
                        "queries_per_gpu": args.queries, "lexicon_entries": model.num_instances(),
                        "anagram_classes": n_classes, "pairs_per_query": pairs / nq if nq else 0.0,
                        "class_tests_per_query": tests / nq if nq else 0.0,
-                       "parallelism": f"query-sharded x{world}" + (f", RCCL gather of compact top-k records ({gather_bytes[0] / 1e6:.0f} MB per rank and step)" if do_gather else "")},
+                       "parallelism": f"query-sharded x{world}" + (f", RCCL gather of compact top-k records ({gather_bytes[0] / 1e6:.0f} MB per rank and step)" if do_gather and gather_error[0] is None else "")
+                       + (f", result gather FAILED on rank 0: {gather_error[0]}" if gather_error[0] else "")},
             "stage_ms": {"scan": stage_ms["ms_scan"], "score": stage_ms["ms_score"], "compact": stage_ms["ms_group"], "rank": stage_ms["ms_rank"], "total": stage_ms["ms_total"]},
             "pair_slots": st["n_pair_slots"], "dl_pairs": st["n_selected"], "survivors": st["n_survivors"], "results": st["n_results"], "encode_upload_s": t_enc,
             "roofline": roofline, "cpu_baseline": cpu,
