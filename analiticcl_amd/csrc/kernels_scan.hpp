@@ -173,15 +173,28 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       }
       uint32_t total;
       uint32_t g = wave_reserve(wo, (uint32_t)__popc(m) * ne, lane, &total);
-      while (m) {
-        const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
-        m &= m - 1u;
-        const uint32_t q = t.q0 + qb + bit;
-        // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
-        const uint32_t exact = (A.want_exact && A.qexact[q] == c) ? 0x80000000u : 0u;
-        for (uint32_t i = 0; i < ne; ++i, ++g) {
-          const uint32_t pos = wave_slot(wo, g);
-          if (pos < wo.rend) raw[pos] = make_uint2(q, (e0 + i) | exact);
+      if (total <= wo.split && wo.base + total <= wo.rend) {
+        // wave-uniform common case: the run fits the rest of the current chunk, so slot = base + run index, no
+        // spill select and no bounds test per pair
+        uint2* __restrict__ dst = raw + wo.base;
+        while (m) {
+          const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+          m &= m - 1u;
+          const uint32_t q = t.q0 + qb + bit;
+          const uint32_t exact = (A.want_exact && A.qexact[q] == c) ? 0x80000000u : 0u;
+          for (uint32_t i = 0; i < ne; ++i, ++g) dst[g] = make_uint2(q, (e0 + i) | exact);
+        }
+      } else {
+        while (m) {
+          const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+          m &= m - 1u;
+          const uint32_t q = t.q0 + qb + bit;
+          // the exact anagram class (StopAtExactMatch, src/lib.rs:1164-1173)
+          const uint32_t exact = (A.want_exact && A.qexact[q] == c) ? 0x80000000u : 0u;
+          for (uint32_t i = 0; i < ne; ++i, ++g) {
+            const uint32_t pos = wave_slot(wo, g);
+            if (pos < wo.rend) raw[pos] = make_uint2(q, (e0 + i) | exact);
+          }
         }
       }
       wave_commit(wo, total);
