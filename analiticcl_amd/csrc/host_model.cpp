@@ -148,6 +148,10 @@ void Alphabet::index() {
   for (int c = 0; c < size(); ++c)
     for (const AlphabetMember& m : classes[c])
       if (!m.bytes.empty()) by_first[(unsigned char)m.bytes[0]].push_back(Cand{(int16_t)c, &m});
+  for (int b = 0; b < 256; ++b) {
+    const std::vector<Cand>& v = by_first[b];
+    fast[b] = v.empty() ? (int16_t)-1 : (v[0].m->bytes.size() == 1 && v[0].m->nchars == 1 ? v[0].cls : (int16_t)-2);
+  }
 }
 
 // Same result as trying every class and member in file order at each position (src/anahash.rs:25-39): only
@@ -156,7 +160,9 @@ int Alphabet::scan_into(const char* text, size_t nbytes, int16_t* out, int cap) 
   int n = 0, skip = 0;
   for (size_t pos = 0; pos < nbytes; pos += (size_t)u8len((unsigned char)text[pos])) {
     if (skip > 0) { --skip; continue; }
-    int hit = -1;
+    int hit = fast[(unsigned char)text[pos]];
+    if (hit == -2) hit = -1;
+    else { if (n >= cap) return -1; out[n++] = (int16_t)hit; continue; }
     for (const Cand& cd : by_first[(unsigned char)text[pos]]) {
       const AlphabetMember& m = *cd.m;
       if (pos + m.bytes.size() <= nbytes && memcmp(text + pos, m.bytes.data(), m.bytes.size()) == 0) {

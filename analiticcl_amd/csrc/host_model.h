@@ -27,6 +27,9 @@ struct Alphabet {
   // members whose first byte is b, in (class, member) file order: the scan only has to try these
   struct Cand { int16_t cls; const AlphabetMember* m; };
   std::vector<Cand> by_first[256];
+  // per first byte: the class when the FIRST candidate is a one-byte member (it always matches), -1 when no member
+  // starts with the byte, -2 when the candidates have to be tried (multi-byte members first)
+  int16_t fast[256];
   void index();  // (re)builds by_first; called by parse_alphabet
   // Walks `text` exactly like str::anahash / str::normalize_to_alphabet (src/anahash.rs:16-80) and
   // returns, per consumed position, the class index or -1 for an unmatched character.
