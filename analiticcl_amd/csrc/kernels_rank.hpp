@@ -470,12 +470,36 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
                        (uint32_t)__shfl((int)my_seg0, grp), ng, (uint32_t)__shfl((int)my_maxf, grp),
                        (uint32_t)__shfl((int)my_qex, grp), c_rows, a, t_key, r_rows, r_count);
   }
-  if (nmax > 16) {  // wave-uniform: the longer lists one after the other, 64 lanes each
+  if (nmax > 16) {  // wave-uniform
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // lists of 17..32 rows (8 % of the queries of config 2): two side by side, 32 lanes each
+    uint32_t mask32 = 0;  // wave-uniform
+    for (int k = 0; k < RANK_QPW; ++k) {
+      const uint32_t nk = (uint32_t)__builtin_amdgcn_readlane((int)my_n, k);
+      if (qbase + k < nq && nk > 16u && nk <= 32u) mask32 |= 1u << k;
+    }
+    while (mask32) {
+      const int k0 = __ffs((int)mask32) - 1;
+      mask32 &= mask32 - 1u;
+      const int k1 = mask32 ? __ffs((int)mask32) - 1 : -1;
+      if (k1 >= 0) mask32 &= mask32 - 1u;
+      const int half = lane >> 5, gl = lane & 31, kk = half ? k1 : k0;
+      const bool valid = kk >= 0;
+      const int src = valid ? kk : 0;
+      // per half: 32 keys, order keys (8 B each), freqs (4 B), source rows (2 B), 32 + 32 ranked heads (8 B) = 1216 B
+      uint8_t* gb = wl + half * 1216;
+      rank_query<32, 32>(qbase + (uint32_t)src, valid, gl, half * 32, 32u, reinterpret_cast<double*>(gb),
+                         reinterpret_cast<unsigned long long*>(gb + 256), reinterpret_cast<uint32_t*>(gb + 512),
+                         reinterpret_cast<uint16_t*>(gb + 640), reinterpret_cast<double*>(gb + 704), reinterpret_cast<double*>(gb + 960),
+                         (uint32_t)__shfl((int)my_seg0, src), (uint32_t)__shfl((int)my_n, src), (uint32_t)__shfl((int)my_maxf, src),
+                         (uint32_t)__shfl((int)my_qex, src), c_rows, a, t_key, r_rows, r_count);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    // the longer lists one after the other, 64 lanes each
     for (int k = 0; k < RANK_QPW; ++k) {
       if (qbase + k >= nq) break;  // wave-uniform
       const uint32_t nk = (uint32_t)__builtin_amdgcn_readlane((int)my_n, k);
-      if (nk <= 16u) continue;     // wave-uniform: done above
+      if (nk <= 32u) continue;     // wave-uniform: done above
       rank_query<64, RANK_LCAP>(qbase + k, true, lane, 0, nk, reinterpret_cast<double*>(wl),
                                 reinterpret_cast<unsigned long long*>(wl + RANK_LCAP * 8),
                                 reinterpret_cast<uint32_t*>(wl + RANK_LCAP * 16), reinterpret_cast<uint16_t*>(wl + RANK_LCAP * 20),
