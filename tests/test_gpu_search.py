@@ -390,3 +390,25 @@ def test_cli_search_with_contextrules(tmp_path, capsys):
     assert cli.main(argv + ["-R", str(rules)]) == 0
     js = json.loads(capsys.readouterr().out)
     assert [m["variants"][0]["text"] for m in js] == ["I", "sink", "you", "are", "right"]
+
+
+def test_cli_index_cache_roundtrip(data_dir, tmp_path, capsys):
+    """--index-cache: the first run builds the model and writes the image, the second one loads it (no lexicon read, no
+    index build) and must print the same bytes -- query and search mode, with a context-rule file on top of the image."""
+    from analiticcl_amd import cli
+    cache = tmp_path / "model.idx"
+    inp = tmp_path / "in.txt"
+    inp.write_text("seperate\nrecieve teh mesage\nacommodate\n", encoding="utf-8")
+    rules = tmp_path / "rules.tsv"
+    rules.write_text("receive; the\t1.1\tpair\n")
+    base = ["--lexicon", os.path.join(data_dir, "eng.aspell.lexicon"), "--alphabet", os.path.join(data_dir, "simple.alphabet.tsv"),
+            "--index-cache", str(cache)]
+    outs = []
+    for _ in range(2):
+        assert cli.main(["query"] + base + [str(inp)]) == 0
+        q = capsys.readouterr().out
+        assert cli.main(["search"] + base + ["--json", "--contextrules", str(rules), str(inp)]) == 0
+        outs.append((q, capsys.readouterr().out))
+        assert cache.exists()
+    assert outs[0] == outs[1]
+    assert outs[0][0].startswith("seperate\tseparate\t0.734375\t") and '"input": "recieve"' in outs[0][1]
