@@ -755,9 +755,13 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
   if (surv_fill) {
     CompactArgs ca{m.have_freq ? 1 : 0, dl->any_variants};
-    hipLaunchKernelGGL(k_compact, dim3(((surv_fill + 255) / 256) * SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
-                       (uint32_t)b->surv_region_cap, ca, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
-                       dl->var_target_freq, dl->var_score, b->c_rows);
+    if (!dl->any_variants)
+      hipLaunchKernelGGL(k_compact_grouped, dim3(((surv_fill + COMPACT_B - 1) / COMPACT_B) * SCAN_REGIONS), dim3(COMPACT_B), 0, st,
+                         b->surv, b->sctr, (uint32_t)b->surv_region_cap, ca.have_freq, b->qcur, dl->ent_rec, b->c_rows);
+    else
+      hipLaunchKernelGGL(k_compact, dim3(((surv_fill + 255) / 256) * SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
+                         (uint32_t)b->surv_region_cap, ca, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
+                         dl->var_target_freq, dl->var_score, b->c_rows);
   }
   HIP_TRY(hipEventRecord(b->ev[3], st));
   // ---- rank ------------------------------------------------------------------------------------------

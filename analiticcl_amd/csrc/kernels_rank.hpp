@@ -18,38 +18,6 @@ __global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ sur
                                                  const double* __restrict__ var_score, SurvRow* __restrict__ c_rows) {
   const uint32_t region = blockIdx.x % SCAN_REGIONS, i = (blockIdx.x / SCAN_REGIONS) * 256 + threadIdx.x;  // 1-D grid, region fastest
   const bool live = i < sctr[region * RC_STRIDE];
-  if (!a.any_variants) {
-    // Without variant lists every survivor is one row.  Neighbouring survivors often belong to the same query (they come
-    // from the same scan tile), so the lanes of a wave are grouped by query first (ballot loop, no memory traffic) and
-    // only one lane per group bumps the query's cursor: returning atomics sustain ~25 G/s, VALU is idle in this kernel.
-    const uint32_t lane = threadIdx.x & 63;
-    SurvRec sr{0xFFFFFFFFu, 0u, 0.0};
-    if (live) sr = surv[(size_t)region * region_cap + i];
-    uint32_t leader = lane, rank = 0, count = 1;
-    bool pending = live;
-    for (;;) {
-      const unsigned long long mp = __ballot(pending);
-      if (!mp) break;  // wave-uniform
-      const int first = __ffsll((long long)mp) - 1;
-      const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)sr.q, first);
-      const bool mine = pending && sr.q == q0;
-      const unsigned long long ms = __ballot(mine);
-      if (mine) {
-        leader = (uint32_t)first;
-        rank = (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-        count = (uint32_t)__popcll(ms);
-        pending = false;
-      }
-    }
-    if (!__ballot(live)) return;
-    uint32_t base = 0;
-    if (live && leader == lane) base = atomicAdd(&qcur[sr.q], count);
-    base = (uint32_t)__shfl((int)base, (int)leader);
-    if (!live) return;
-    const EntRec er = ent_rec[sr.e];
-    c_rows[base + rank] = SurvRow{sr.score, (unsigned long long)er.order << 20, er.vocab, a.have_freq ? er.freq : 1u, 0xFFFFFFFFu, 0u};
-    return;
-  }
   if (!live) return;
   const SurvRec sr = surv[(size_t)region * region_cap + i];
   const double s = sr.score;
@@ -72,6 +40,44 @@ __global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ sur
                           a.have_freq ? (tf < f ? tf : f) : (tf < 1u ? tf : 1u), er.vocab, 0u};
   }
   if (self) c_rows[pos] = SurvRow{s, ord | (unsigned long long)(v1 - v0), er.vocab, f, 0xFFFFFFFFu, 0u};
+}
+
+// The same without variant lists (every survivor is exactly one row), for blocks of COMPACT_B survivors of one region.
+// Returning atomics on scattered addresses sustain only ~25 G/s in total and VALU / LDS are idle here, so the block first
+// groups its survivors by query in an LDS hash table (neighbouring survivors come from the same scan tiles: ~10x fewer
+// distinct queries than survivors): LDS atomics hand out the rank inside the group, ONE lane per group bumps the query's
+// cursor in global memory, everybody adds its rank.  9.75 M global atomics -> ~1.7 M on config 2.
+constexpr uint32_t COMPACT_B = 1024, COMPACT_H = 2048;  // hash slots: twice the block size (open addressing, linear probing)
+__global__ __launch_bounds__(COMPACT_B) void k_compact_grouped(const SurvRec* __restrict__ surv, const uint32_t* __restrict__ sctr,
+                                                               uint32_t region_cap, int have_freq, uint32_t* __restrict__ qcur,
+                                                               const EntRec* __restrict__ ent_rec, SurvRow* __restrict__ c_rows) {
+  __shared__ uint32_t h_key[COMPACT_H], h_cnt[COMPACT_H], h_base[COMPACT_H];
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, i0 = (blockIdx.x / SCAN_REGIONS) * COMPACT_B, fill = sctr[region * RC_STRIDE];
+  if (i0 >= fill) return;  // block-uniform
+  for (uint32_t h = threadIdx.x; h < COMPACT_H; h += COMPACT_B) { h_key[h] = 0xFFFFFFFFu; h_cnt[h] = 0; }
+  __syncthreads();
+  const uint32_t i = i0 + threadIdx.x;
+  const bool live = i < fill;
+  SurvRec sr{0u, 0u, 0.0};
+  uint32_t slot = 0, rank = 0;
+  bool owner = false;
+  if (live) {
+    sr = surv[(size_t)region * region_cap + i];
+    slot = (sr.q * 2654435761u) >> 21;  // 11 bits
+    for (;;) {
+      const uint32_t prev = atomicCAS(&h_key[slot], 0xFFFFFFFFu, sr.q);
+      if (prev == 0xFFFFFFFFu) { owner = true; break; }
+      if (prev == sr.q) break;
+      slot = (slot + 1u) & (COMPACT_H - 1u);
+    }
+    rank = atomicAdd(&h_cnt[slot], 1u);
+  }
+  __syncthreads();
+  if (owner) h_base[slot] = atomicAdd(&qcur[sr.q], h_cnt[slot]);  // qcur starts as a copy of soff
+  __syncthreads();
+  if (!live) return;
+  const EntRec er = ent_rec[sr.e];
+  c_rows[h_base[slot] + rank] = SurvRow{sr.score, (unsigned long long)er.order << 20, er.vocab, have_freq ? er.freq : 1u, 0xFFFFFFFFu, 0u};
 }
 
 // ------------------------------------------------------------------------------------------------
