@@ -733,51 +733,81 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     }
   }
   HIP_TRY(hipEventRecord(b->ev[2], st));
-  // ---- compact survivors -----------------------------------------------------------------------------
-  exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
-  HIP_TRY(hipMemcpyAsync(b->qcur, b->soff, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));  // cursors of k_compact
-  uint32_t total_surv = 0;
-  HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
-  if (nraw) HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->sctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  b->n_pairs = n_valid - h_counters[CTR_SKIPPED];
-  b->n_surv = total_surv;
-  if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
-  uint32_t surv_fill = 0;
-  uint64_t nsel = 0;
-  if (nraw)
-    for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
-      surv_fill = std::max(surv_fill, h_rctr[r * RC_STRIDE]);
-      nsel += h_rctr[r * RC_STRIDE + 1];
-    }
-  b->n_sel = nsel;
-  if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
-  if (surv_fill) {
-    CompactArgs ca{m.have_freq ? 1 : 0, dl->any_variants};
-    if (!dl->any_variants)
-      hipLaunchKernelGGL(k_compact_grouped, dim3(((surv_fill + COMPACT_B - 1) / COMPACT_B) * SCAN_REGIONS), dim3(COMPACT_B), 0, st,
-                         b->surv, b->sctr, (uint32_t)b->surv_region_cap, ca.have_freq, b->qcur, dl->ent_rec, b->c_rows);
-    else
-      hipLaunchKernelGGL(k_compact, dim3(((surv_fill + 255) / 256) * SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
-                         (uint32_t)b->surv_region_cap, ca, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
-                         dl->var_target_freq, dl->var_score, b->c_rows);
-  }
-  HIP_TRY(hipEventRecord(b->ev[3], st));
-  // ---- rank ------------------------------------------------------------------------------------------
+  // ---- compact survivors + rank -----------------------------------------------------------------------
   RankArgs ra;
   ra.cutoff_threshold = b->params.cutoff_threshold;
   ra.max_matches = b->params.max_matches;
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
   ra.any_variants = dl->any_variants;
-  hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
-                     b->qexpand, ra, b->t_key, b->r_rows, b->r_count);
-  exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
-  HIP_TRY(hipEventRecord(b->ev[4], st));
-  uint32_t total_results = 0;
-  HIP_TRY(hipMemcpyAsync(&total_results, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
+  uint32_t total_surv = 0, total_results = 0, surv_fill = 0;
+  uint64_t nsel = 0;
+  auto read_counts = [&]() -> int {  // (the only read-back between the scan and the end of the run)
+    HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
+    if (nraw) HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->sctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    return ANX_OK;
+  };
+  auto use_counts = [&]() {
+    b->n_pairs = n_valid - h_counters[CTR_SKIPPED];
+    b->n_surv = total_surv;
+    surv_fill = 0;
+    nsel = 0;
+    if (nraw)
+      for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
+        surv_fill = std::max(surv_fill, h_rctr[r * RC_STRIDE]);
+        nsel += h_rctr[r * RC_STRIDE + 1];
+      }
+    b->n_sel = nsel;
+  };
+  if (dl->any_variants) {
+    // variant lists: a survivor expands to several rows; the grid of k_compact comes from the survivor counts
+    HIP_TRY(hipMemcpyAsync(b->qcur, b->soff, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));  // cursors of k_compact
+    if ((rc = read_counts())) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    use_counts();
+    if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
+    if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
+    if (surv_fill) {
+      CompactArgs ca{m.have_freq ? 1 : 0, dl->any_variants};
+      hipLaunchKernelGGL(k_compact, dim3(((surv_fill + 255) / 256) * SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
+                         (uint32_t)b->surv_region_cap, ca, b->qcur, dl->ent_rec, dl->ent_var_off, dl->var_target,
+                         dl->var_target_freq, dl->var_score, b->c_rows);
+    }
+    HIP_TRY(hipEventRecord(b->ev[3], st));
+    hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
+                       b->qexpand, ra, b->t_key, b->r_rows, b->r_count, 0xFFFFFFFFu);
+    exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
+    HIP_TRY(hipEventRecord(b->ev[4], st));
+    HIP_TRY(hipMemcpyAsync(&total_results, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    // No host round trip between scoring and ranking: the row buffers keep the size of the previous run (first run:
+    // an estimate), the kernels check the total on the device, and in the rare case it does not fit the host grows the
+    // buffers and repeats compaction + ranking.
+    for (int attempt = 0;; ++attempt) {
+      if (b->surv_cap == 0 && (rc = ensure_surv(b, (size_t)nq * 16 + 1024, err))) return rc;
+      const uint32_t row_cap = (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu);
+      HIP_TRY(hipMemcpyAsync(b->qcur, b->soff, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));  // cursors of the compaction
+      if (nraw)
+        hipLaunchKernelGGL(k_compact_grouped, dim3(COMPACT_P * SCAN_REGIONS), dim3(COMPACT_B), 0, st, b->surv, b->sctr,
+                           (uint32_t)b->surv_region_cap, m.have_freq ? 1 : 0, b->qcur, dl->ent_rec, b->c_rows, b->soff + nq, row_cap);
+      HIP_TRY(hipEventRecord(b->ev[3], st));
+      hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
+                         b->qexpand, ra, b->t_key, b->r_rows, b->r_count, row_cap);
+      exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
+      HIP_TRY(hipEventRecord(b->ev[4], st));
+      if ((rc = read_counts())) return rc;
+      HIP_TRY(hipMemcpyAsync(&total_results, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      use_counts();
+      if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
+      if ((size_t)total_surv <= b->surv_cap) break;
+      if (attempt == 1) { err = "candidate rows do not fit after regrow"; return ANX_ENODEVICE; }
+      if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
+    }
+  }
   HIP_TRY(hipGetLastError());
   b->n_results = total_results;
   b->ran = true;

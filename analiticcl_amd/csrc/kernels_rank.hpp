@@ -48,36 +48,45 @@ __global__ __launch_bounds__(256) void k_compact(const SurvRec* __restrict__ sur
 // distinct queries than survivors): LDS atomics hand out the rank inside the group, ONE lane per group bumps the query's
 // cursor in global memory, everybody adds its rank.  9.75 M global atomics -> ~1.7 M on config 2.
 constexpr uint32_t COMPACT_B = 1024, COMPACT_H = 2048;  // hash slots: twice the block size (open addressing, linear probing)
+constexpr uint32_t COMPACT_P = 16;                      // blocks per region: each walks its region's survivors in strides
+// The grid does not depend on the number of survivors (the host does not know it yet: no read-back between scoring and
+// ranking); `row_cap` = rows c_rows can hold: when the batch has more (soff[nq]), nothing is written and the host, which
+// sees the total after the run, grows the buffers and repeats compaction and ranking.
 __global__ __launch_bounds__(COMPACT_B) void k_compact_grouped(const SurvRec* __restrict__ surv, const uint32_t* __restrict__ sctr,
                                                                uint32_t region_cap, int have_freq, uint32_t* __restrict__ qcur,
-                                                               const EntRec* __restrict__ ent_rec, SurvRow* __restrict__ c_rows) {
+                                                               const EntRec* __restrict__ ent_rec, SurvRow* __restrict__ c_rows,
+                                                               const uint32_t* __restrict__ total_rows, uint32_t row_cap) {
   __shared__ uint32_t h_key[COMPACT_H], h_cnt[COMPACT_H], h_base[COMPACT_H];
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, i0 = (blockIdx.x / SCAN_REGIONS) * COMPACT_B, fill = sctr[region * RC_STRIDE];
-  if (i0 >= fill) return;  // block-uniform
-  for (uint32_t h = threadIdx.x; h < COMPACT_H; h += COMPACT_B) { h_key[h] = 0xFFFFFFFFu; h_cnt[h] = 0; }
-  __syncthreads();
-  const uint32_t i = i0 + threadIdx.x;
-  const bool live = i < fill;
-  SurvRec sr{0u, 0u, 0.0};
-  uint32_t slot = 0, rank = 0;
-  bool owner = false;
-  if (live) {
-    sr = surv[(size_t)region * region_cap + i];
-    slot = (sr.q * 2654435761u) >> 21;  // 11 bits
-    for (;;) {
-      const uint32_t prev = atomicCAS(&h_key[slot], 0xFFFFFFFFu, sr.q);
-      if (prev == 0xFFFFFFFFu) { owner = true; break; }
-      if (prev == sr.q) break;
-      slot = (slot + 1u) & (COMPACT_H - 1u);
+  if (*total_rows > row_cap) return;
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = sctr[region * RC_STRIDE];
+  for (uint32_t i0 = (blockIdx.x / SCAN_REGIONS) * COMPACT_B; i0 < fill; i0 += COMPACT_P * COMPACT_B) {  // block-uniform
+    for (uint32_t h = threadIdx.x; h < COMPACT_H; h += COMPACT_B) { h_key[h] = 0xFFFFFFFFu; h_cnt[h] = 0; }
+    __syncthreads();
+    const uint32_t i = i0 + threadIdx.x;
+    const bool live = i < fill;
+    SurvRec sr{0u, 0u, 0.0};
+    uint32_t slot = 0, rank = 0;
+    bool owner = false;
+    if (live) {
+      sr = surv[(size_t)region * region_cap + i];
+      slot = (sr.q * 2654435761u) >> 21;  // 11 bits
+      for (;;) {
+        const uint32_t prev = atomicCAS(&h_key[slot], 0xFFFFFFFFu, sr.q);
+        if (prev == 0xFFFFFFFFu) { owner = true; break; }
+        if (prev == sr.q) break;
+        slot = (slot + 1u) & (COMPACT_H - 1u);
+      }
+      rank = atomicAdd(&h_cnt[slot], 1u);
     }
-    rank = atomicAdd(&h_cnt[slot], 1u);
+    __syncthreads();
+    if (owner) h_base[slot] = atomicAdd(&qcur[sr.q], h_cnt[slot]);  // qcur starts as a copy of soff
+    __syncthreads();
+    if (live) {
+      const EntRec er = ent_rec[sr.e];
+      c_rows[h_base[slot] + rank] = SurvRow{sr.score, (unsigned long long)er.order << 20, er.vocab, have_freq ? er.freq : 1u, 0xFFFFFFFFu, 0u};
+    }
+    __syncthreads();  // the table is cleared for the next chunk
   }
-  __syncthreads();
-  if (owner) h_base[slot] = atomicAdd(&qcur[sr.q], h_cnt[slot]);  // qcur starts as a copy of soff
-  __syncthreads();
-  if (!live) return;
-  const EntRec er = ent_rec[sr.e];
-  c_rows[h_base[slot] + rank] = SurvRow{sr.score, (unsigned long long)er.order << 20, er.vocab, have_freq ? er.freq : 1u, 0xFFFFFFFFu, 0u};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -448,8 +457,9 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
                                               const uint32_t* __restrict__ qmaxfreq,
                                               const uint32_t* __restrict__ qexpand, RankArgs a,
                                               double* __restrict__ t_key, DevRow* __restrict__ r_rows,
-                                              uint32_t* __restrict__ r_count) {
+                                              uint32_t* __restrict__ r_count, uint32_t row_cap) {
   __shared__ __attribute__((aligned(16))) uint8_t s_raw[4 * RANK_WAVE_BYTES];
+  if (soff[nq] > row_cap) return;  // more candidate rows than c_rows / r_rows hold: the host grows them and repeats (k_compact_grouped)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   uint8_t* wl = s_raw + wid * RANK_WAVE_BYTES;
   const uint32_t qbase = (blockIdx.x * 4 + wid) * RANK_QPW;
