@@ -14,7 +14,7 @@ for name, blk in blocks():
     f, w, va, g, vi, si = (val(blk, c) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"))
     if f is not None and w is not None:
         kern[name] = {"fetch_kb": f, "write_kb": w, "traffic_bytes": int((2 * f + w) * 1024)}
-    if va and g and name in ("k_scan_bits", "k_filter_score", "k_rank", "k_compact"):
+    if va and g and name in ("k_scan_bits", "k_filter_score", "k_rank", "k_compact", "k_compact_grouped"):
         lines.append(f"# {name}: VALU-active = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = {va*4/(g/8*1024)*100:.0f} %; "
                      f"{vi/1e6:.0f} M VALU + {si/1e6:.0f} M SALU wave-instructions; HBM traffic 2*{f/1024:.0f} MB + {w/1024:.0f} MB = {(2*f+w)/1048576:.2f} GB per launch")
 hdr = ("# Round 1 final -- rocprofv3 --pmc passes (separate runs, --kernel-trace only), python3 bench.py --steps 2 --warmup 1 --cpu-sample 0\n"
