@@ -722,13 +722,13 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     else hipLaunchKernelGGL(k_filter_score<0>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
     HIP_TRY(hipEventRecord(b->ev_fs1, st));
     if (need_lists) {  // the list fills are only known on the device: grids cover the fullest pair-list region
-      const dim3 lgrid(((maxfill + 255) / 256) * SCAN_REGIONS);
+      const dim3 lgrid(LIST_P * SCAN_REGIONS);
       if (fastD && have_long_q) {
         if (fastD == 1) hipLaunchKernelGGL(k_score_fast8<1>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
         else if (fastD == 2) hipLaunchKernelGGL(k_score_fast8<2>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
         else hipLaunchKernelGGL(k_score_fast8<3>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
       }
-      hipLaunchKernelGGL(k_score_pairs, dim3(((maxfill + threads - 1) / threads) * SCAN_REGIONS), dim3(threads), threads * sa.stride, st,
+      hipLaunchKernelGGL(k_score_pairs, dim3(LIST_P * SCAN_REGIONS), dim3(threads), threads * sa.stride, st,
                          lg, pa, sa, so);
     }
   }

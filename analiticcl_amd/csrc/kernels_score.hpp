@@ -543,14 +543,20 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   }
 }
 
+constexpr uint32_t LIST_P = 64;  // blocks per region of the slot-list kernels
 // the selected pairs with a string of 17..32 symbols (list8 of k_filter_score)
 template <int D>
 __global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
   __shared__ uint32_t s_str[256 * 17];
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, blk = blockIdx.x / SCAN_REGIONS, i = blk * 256 + threadIdx.x, n = in.ctr[region * RC_STRIDE];
-  if (blk * 256 >= n) return;  // block-uniform
-  const bool active = i < n;
-  score_fast_pair<D, 8>(active ? in.list[(size_t)region * in.region_cap + i] : 0u, active, A, a, so, region, s_str);
+  // LIST_P blocks per region walk the region's slot list in strides: the list fills are only known on the device, and a
+  // grid sized for the fullest possible list would consist of ~400 k empty blocks (0.08 ms of dispatch on config 2)
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = in.ctr[region * RC_STRIDE];
+  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += LIST_P) {  // block-uniform
+    const uint32_t i = blk * 256 + threadIdx.x;
+    const bool active = i < n;
+    score_fast_pair<D, 8>(active ? in.list[(size_t)region * in.region_cap + i] : 0u, active, A, a, so, region, s_str);
+    __syncthreads();  // s_str is reused by the next round
+  }
 }
 
 __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
@@ -566,8 +572,9 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
   uint32_t* __restrict__ qmaxfreq = A.qmaxfreq;
   uint32_t* __restrict__ qsurv = A.qsurv;
   uint32_t* __restrict__ qexpand = A.qexpand;
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, blk = blockIdx.x / SCAN_REGIONS, i_sel = blk * blockDim.x + threadIdx.x, nsel = in.ctr[region * RC_STRIDE];
-  if (blk * blockDim.x >= nsel) return;  // block-uniform
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, nsel = in.ctr[region * RC_STRIDE];
+  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * blockDim.x < nsel; blk += LIST_P) {  // block-uniform; see k_score_fast8
+  const uint32_t i_sel = blk * blockDim.x + threadIdx.x;
   bool keep = false;
   uint32_t kq = 0, ke = 0;
   double kscore = 0.0;
@@ -657,5 +664,6 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
     A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
   surv_append(so, region, keep, kq, ke, kscore);
+  }
 }
 
