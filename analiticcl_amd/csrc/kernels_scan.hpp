@@ -298,9 +298,12 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   // No bounds test on s: signatures outside [s0, s1) belong to other charcounts, so their L1 distance to the tile's
   // signature is at least the length difference > k, and the table is padded with never-matching entries.
   const uint2* __restrict__ sigp = A.sig + t.s0 + lane;
-  for (uint32_t sb = t.s0; sb < t.s1; sb += 64, sigp += 64) {
+  uint2 sg_next = t.s0 < t.s1 ? *sigp : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
     const uint32_t s = sb + lane;
-    const uint2 sg = *sigp;
+    const uint2 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
+    sigp += 64;
+    if (sb + 64 < t.s1) sg_next = *sigp;
     const bool ok = __builtin_amdgcn_sad_u8(sg.x, t.sig_lo, __builtin_amdgcn_sad_u8(sg.y, t.sig_hi, 0u)) <= t.k;
     unsigned long long m = __ballot(ok);
     if (!m || (A.dbg & 4)) continue;
