@@ -462,9 +462,18 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     const uint32_t s0 = m.lex.siglen_begin[lo], s1 = m.lex.siglen_begin[hi + 1];
     static const uint32_t tq = []() { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }();
+    // The count-vector (SAD) tiles are rare (queries with a symbol more than NBITPLANES times) and run as a launch of
+    // their own: a handful of waves whose time is the latency of ONE wave walking the whole signature window.  Their
+    // windows are therefore split over several waves (disjoint signature ranges = disjoint classes: same pairs).
+    const uint32_t nsplit = kind == 0 ? 8u : 1u;
+    const uint32_t step = (((s1 - s0) + nsplit - 1) / nsplit + 63u) & ~63u;
     for (size_t s = i; s < j; s += tq)
-      b->tiles.push_back(Tile{(uint32_t)s, (uint32_t)std::min<size_t>(tq, j - s), s0, s1, k, lq, (uint32_t)h_sig[i],
-                              (uint32_t)(h_sig[i] >> 32), kind, (h_meta[i] >> 16) & 0xFFu});
+      for (uint32_t part = 0; part < nsplit; ++part) {
+        const uint32_t a0 = s0 + part * step, a1 = std::min(s1, a0 + step);
+        if (a0 >= a1 && part) break;
+        b->tiles.push_back(Tile{(uint32_t)s, (uint32_t)std::min<size_t>(tq, j - s), a0, a1, k, lq, (uint32_t)h_sig[i],
+                                (uint32_t)(h_sig[i] >> 32), kind, (h_meta[i] >> 16) & 0xFFu});
+      }
     i = j;
   }
   // longest-processing-time-first: cost ~ queries (the compatible classes per query vary little inside a length)
