@@ -202,8 +202,9 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
     const bool real = c < img.nclasses;
     crec[2 * (size_t)c + 1] = make_uint4(img.cls_len[c], real ? img.cls_off[c] : 0u, real ? img.cls_off[c + 1] - img.cls_off[c] : 0u, 0u);
   }
-  std::vector<uint2> sig2(img.sig_lo.size());
-  for (size_t i = 0; i < sig2.size(); ++i) sig2[i] = make_uint2(img.sig_lo[i], img.sig_hi[i]);
+  std::vector<uint4> sig2(img.sig_lo.size());  // {signature, first class of the run, classes in the run}
+  for (size_t i = 0; i < sig2.size(); ++i)
+    sig2[i] = make_uint4(img.sig_lo[i], img.sig_hi[i], img.sig_cbeg[i], i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] - img.sig_cbeg[i] : 0u);
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
   if ((rc = upload(&d->cls_planes, img.cls_planes.data(), img.cls_planes.size(), err, &d->bytes)) ||

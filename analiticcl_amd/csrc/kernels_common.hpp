@@ -38,7 +38,7 @@ struct DeviceLexicon {
   uint8_t* cls_len = nullptr;      // [cstride]
   uint32_t* cls_off = nullptr;
   uint4* cls_rec = nullptr;        // [cstride][2] {4 planes} {len, first entry, entries, 0}: ScanArgs::cls_rec
-  uint2* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage), lo/hi interleaved
+  uint4* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage): {groups 0-3, groups 4-7, first class of the run, classes}
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint32_t* ent_vocab = nullptr;
   uint32_t* ent_freq = nullptr;

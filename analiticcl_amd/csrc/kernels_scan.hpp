@@ -95,7 +95,7 @@ struct ScanArgs {
   uint32_t pad_class;   // a never-matching padding class (bits 0, counts 0xFF, len 255)
   const uint8_t* cls_len;
   const uint32_t* cls_off;
-  const uint2* sig;         // signature table: (groups 0-3, groups 4-7) packed as bytes
+  const uint4* sig;         // signature table: {groups 0-3, groups 4-7 packed as bytes, first class of the run, classes}
   const uint32_t* sig_cbeg;
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
@@ -297,21 +297,18 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 
   // No bounds test on s: signatures outside [s0, s1) belong to other charcounts, so their L1 distance to the tile's
   // signature is at least the length difference > k, and the table is padded with never-matching entries.
-  const uint2* __restrict__ sigp = A.sig + t.s0 + lane;
-  uint2 sg_next = t.s0 < t.s1 ? *sigp : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  // One 16-byte record per signature: the run (first class, count) comes with the signature, so a matching step does not
+  // wait for a second, dependent load -- a tile is one wave's serial chain over ~220 steps.
+  const uint4* __restrict__ sigp = A.sig + t.s0 + lane;
+  uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
   for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
-    const uint32_t s = sb + lane;
-    const uint2 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
+    const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
     sigp += 64;
     if (sb + 64 < t.s1) sg_next = *sigp;
     const bool ok = __builtin_amdgcn_sad_u8(sg.x, t.sig_lo, __builtin_amdgcn_sad_u8(sg.y, t.sig_hi, 0u)) <= t.k;
     unsigned long long m = __ballot(ok);
     if (!m || (A.dbg & 4)) continue;
-    uint32_t cb = 0, n = 0;
-    if (ok) {
-      cb = A.sig_cbeg[s];
-      n = A.sig_cbeg[s + 1] - cb;
-    }
+    const uint32_t cb = ok ? sg.z : 0u, n = ok ? sg.w : 0u;
     while (m) {  // scalar loop over the compatible signatures of this step
       const int i = __ffsll((long long)m) - 1;
       m &= m - 1;
