@@ -601,7 +601,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint32_t nq = (uint32_t)b->nq;
   b->ran = false;
-  b->ran_keep_all = b->keep_all_pairs || b->params.stop_at_exact_match;
+  b->ran_keep_all = b->keep_all_pairs;  // the run that also stores the per-slot outputs the debug fetch of every pair reads
   b->n_pairs = b->n_results = b->n_surv = 0;
   b->n_raw = 0;
   if (nq == 0) { b->ran = true; return ANX_OK; }
@@ -668,6 +668,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   ScoreArgs sa;
   { static const int dbg = []() { const char* e = getenv("ANX_SCORE_DBG"); return e ? atoi(e) : 0; }(); sa.dbg = dbg; }
   sa.quot = b->quot;
+  sa.store_pairs = b->keep_all_pairs ? 1 : 0;
   sa.w_ld = m.weights.ld; sa.w_lcs = m.weights.lcs; sa.w_prefix = m.weights.prefix; sa.w_suffix = m.weights.suffix;
   sa.w_case = m.weights.casew;
   sa.w_sum = m.weights.ld + m.weights.lcs + m.weights.prefix + m.weights.suffix + m.weights.casew;  // src/types.rs:69-73

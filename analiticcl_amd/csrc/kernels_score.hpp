@@ -81,6 +81,7 @@ __device__ inline bool band_bound_rejects(const uint32_t (&q)[NW], const uint32_
 struct ScoreArgs {
   const double* quot;  // [33][33] quot[x*33+L] = (double)x / (double)L computed on the host, or nullptr
   int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL
+  int store_pairs;  // write the per-slot outputs p_meta / p_score (only the debug view anx_batch_fetch_pairs reads them)
   double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
   double score_threshold;
   int have_freq, any_variants;
@@ -386,8 +387,10 @@ __device__ inline void tail_of_pair(uint32_t p, bool has, uint32_t ld, const Pai
   }
   surv_append(so, surv_region, keep, r.q, r.e, score);
   if (has) {
-    A.p_score[p] = score;
-    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+    if (a.store_pairs) {
+      A.p_score[p] = score;
+      A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+    }
   }
 }
 
@@ -399,7 +402,7 @@ __device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& 
   PairRegs<NW> r;
   load_pair<NW>(p, active, A, a, r);
   const uint32_t ld = dl_of_pair<D, NW>(r, active);
-  if (active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+  if (a.store_pairs && active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
   tail_of_pair<NW>(p, ld != PAIR_NONE, ld, r, A, a, so, surv_region, lds);
 }
 
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       const uint32_t q4[4] = {Q.x, Q.y, Q.z, Q.w}, c6[6] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu};
       if (band_bound_rejects<4>(q4, c6, filt, d, lq, lc)) selected = false;
     }
-    if (live && !selected)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
+    if (a.store_pairs && live && !selected)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
       A.p_meta[p] = (invalid || stop_skipped) ? META_SKIPPED : (PAIR_NONE | (1u << 7));
     const bool inl = selected && D > 0 && lq <= 16 && lc <= 16 && d <= D;
     const bool to8 = selected && !inl && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       PairRegs<4> r;
       load_pair<4>(p, active, A, a, r);
       const uint32_t ld = dl_of_pair<DD, 4>(r, active);
-      if (active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+      if (a.store_pairs && active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
       const bool surv = ld != PAIR_NONE;
       const unsigned long long ms = __ballot(surv);
       if (ms) {  // wave-uniform
@@ -660,8 +663,10 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
         }
       }
     }
-    A.p_score[p] = score;
-    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+    if (a.store_pairs) {
+      A.p_score[p] = score;
+      A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
+    }
   }
   surv_append(so, region, keep, kq, ke, kscore);
   }
