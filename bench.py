@@ -183,9 +183,10 @@ def main():
         # pairs that fail the DL's length test are counted by the scan but never materialised: only the slots the kernel reads
         fs_bytes = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
         scan_ms, fs_ms = sum_scan_kernel_ms / max(args.steps, 1), sum_fs_kernel_ms / max(args.steps, 1)
-        # the two take the same time within run-to-run noise (1.57 vs 1.58 ms): a tie (within 3 %) goes to the kernel that
-        # moves more algorithmic bytes, so the headline entry does not flip between runs; "per_kernel" always has both
-        if fs_ms > scan_ms or (scan_ms > 0 and (scan_ms - fs_ms) / scan_ms < 0.03 and fs_bytes >= scan_bytes):
+        # the two take the same time within the variation between runs and boxes (k_scan_bits 1.49-1.62 ms, k_filter_score
+        # 1.44-1.46 ms on five boxes): within 5 % the entry goes to the kernel that moves more algorithmic bytes, so the
+        # headline does not flip between runs; "per_kernel" always carries both
+        if fs_ms > scan_ms or (scan_ms > 0 and (scan_ms - fs_ms) / scan_ms < 0.05 and fs_bytes >= scan_bytes):
             kname, kbytes, kms = "k_filter_score", fs_bytes, fs_ms
         else:
             kname, kbytes, kms = "k_scan_bits", scan_bytes, scan_ms
