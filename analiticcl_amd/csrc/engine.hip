@@ -575,11 +575,19 @@ static int ensure_raw(Batch* b, size_t slots_per_region, std::string& err) {
     if (p) pool_free(p);
   b->raw = nullptr; b->p_score = nullptr; b->p_meta = nullptr; b->raw_cap = 0;
   int rc;
-  if ((rc = dalloc(&b->raw, cap, err)) || (rc = dalloc(&b->p_score, cap, err)) || (rc = dalloc(&b->p_meta, cap, err))) return rc;
+  if ((rc = dalloc(&b->raw, cap, err))) return rc;
   b->raw_cap = cap;
   b->region_shift = shift;
   return ANX_OK;
 }
+// per-slot outputs of the scoring kernels (12 B per slot): only the debug view of every pair needs them
+static int ensure_pair_outputs(Batch* b, std::string& err) {
+  if (b->p_meta) return ANX_OK;  // ensure_raw drops them whenever the pair list is regrown
+  int rc;
+  if ((rc = dalloc(&b->p_score, b->raw_cap, err)) || (rc = dalloc(&b->p_meta, b->raw_cap, err))) return rc;
+  return ANX_OK;
+}
+
 static int ensure_surv(Batch* b, size_t cap, std::string& err) {
   if (cap <= b->surv_cap) return ANX_OK;
   for (void* p : {(void*)b->c_rows, (void*)b->r_rows, (void*)b->t_key})
@@ -669,6 +677,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   { static const int dbg = []() { const char* e = getenv("ANX_SCORE_DBG"); return e ? atoi(e) : 0; }(); sa.dbg = dbg; }
   sa.quot = b->quot;
   sa.store_pairs = b->keep_all_pairs ? 1 : 0;
+  if (sa.store_pairs && (rc = ensure_pair_outputs(b, err))) return rc;
   sa.w_ld = m.weights.ld; sa.w_lcs = m.weights.lcs; sa.w_prefix = m.weights.prefix; sa.w_suffix = m.weights.suffix;
   sa.w_case = m.weights.casew;
   sa.w_sum = m.weights.ld + m.weights.lcs + m.weights.prefix + m.weights.suffix + m.weights.casew;  // src/types.rs:69-73
