@@ -1,0 +1,84 @@
+"""The sharded job end to end on real engine output: two one-GPU ranks (both on device 0 here, gloo
+for the exchange: the pool's boxes have one GPU) shard the queries, run the device pipeline, export their compact top-k
+records and rank 0 receives them through analiticcl_amd.shard.CompactGather; the decoded parts must equal the single-
+process results of the same queries.  The NCCL path itself (bench.py --gpus N) needs a multi-GPU node."""
+import os
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nq, steps, q):
+    import torch
+    import torch.distributed as dist
+
+    import analiticcl_amd as A
+    from analiticcl_amd import shard, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = synth.materialize_golden(f"/tmp/anx_dist_test_{os.getuid()}_{rank}")
+    g = A.VariantModel(d["alphabet"], A.Weights(), device=0)
+    g.read_lexicon(d["eng"])
+    g.build()
+    queries = synth.make_queries(synth.load_lexicon_words(d["eng"]), nq, max_len=16, seed=21) + ["", "zzzzqqqq"]
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+    lo, hi = shard.shard_range(len(queries), rank, world)
+    mine = queries[lo:hi]
+    b = g.encode_batch(mine, p)
+    cap = shard.compact_capacity(len(mine) + 1, 16)
+    dev = torch.empty(cap, dtype=torch.uint8, device="cuda:0")
+    gather = shard.CompactGather(cap, "cpu", rank, world)
+    seen = {}
+    for step in range(steps):
+        slot = step & 1
+        buf = gather.acquire(slot)
+        if rank == 0 and step >= 2:
+            seen[step - 2] = [shard.decode_compact(part, shard.shard_range(len(queries), r, world)[1] - shard.shard_range(len(queries), r, world)[0])
+                              for r, part in enumerate(gather.result(slot))]
+        b.run()
+        used = b.export_compact(dev.data_ptr(), cap)
+        torch.cuda.synchronize()
+        buf[:used].copy_(dev[:used])
+        gather.submit(slot, used)
+    gather.flush()
+    if rank == 0:
+        for step in (steps - 2, steps - 1):
+            seen[step] = [shard.decode_compact(part, shard.shard_range(len(queries), r, world)[1] - shard.shard_range(len(queries), r, world)[0])
+                          for r, part in enumerate(gather.result(step & 1))]
+        whole = g.find_variants_ids(queries, p)
+        q.put((seen, whole))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_export_gather():
+    import torch.multiprocessing as mp
+    world, nq, steps = 2, 3000, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nq, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    seen, whole = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(seen) == list(range(steps))
+    for step in range(steps):
+        merged = [row for part in seen[step] for row in part]
+        assert len(merged) == len(whole)
+        for got, exp in zip(merged, whole):
+            assert [(v, d) for v, d, _ in got] == [(v, d) for v, d, _ in exp]
+            assert all(abs(a[2] - c[2]) < 1e-6 for a, c in zip(got, exp))
