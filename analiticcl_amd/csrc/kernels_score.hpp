@@ -424,7 +424,7 @@ struct FilterArgs {
   uint32_t* stat_ctr;       // [SCAN_REGIONS][RC_STRIDE], word 1: selected pairs
 };
 template <int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg) {
+__global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg) {
   __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
   __shared__ uint32_t s_n;
   __shared__ uint32_t s_str[256 * 9];
