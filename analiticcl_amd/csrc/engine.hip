@@ -517,7 +517,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   }
   lap("uploads");
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->lctr, 2 * SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->lctr, 3 * SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
     *code = rc;
@@ -718,17 +718,19 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     // batch: for those the general kernel is cheaper than the 8-word one, measured 0.10 vs 0.22 ms on config 2)
     const bool need_lists = !fastD || have_long_q || dl->max_len > 16;
     if (need_lists && (size_t)maxfill > b->list_cap) {
-      for (void* p : {(void*)b->list8, (void*)b->listg})
+      for (void* p : {(void*)b->list8, (void*)b->listg, (void*)b->listw})
         if (p) pool_free(p);
-      b->list8 = b->listg = nullptr;
+      b->list8 = b->listg = b->listw = nullptr;
       b->list_cap = 0;
       const size_t need = (size_t)maxfill + (maxfill >> 3) + 256;
-      if ((rc = dalloc(&b->list8, need * SCAN_REGIONS, err)) || (rc = dalloc(&b->listg, need * SCAN_REGIONS, err))) return rc;
+      if ((rc = dalloc(&b->list8, need * SCAN_REGIONS, err)) || (rc = dalloc(&b->listg, need * SCAN_REGIONS, err)) ||
+          (rc = dalloc(&b->listw, need * SCAN_REGIONS, err))) return rc;
       b->list_cap = need;
     }
     HIP_TRY(hipMemsetAsync(b->sctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(b->lctr, 0, 2 * SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
-    const SlotList l8{b->list8, b->lctr, (uint32_t)b->list_cap}, lg{b->listg, b->lctr + SCAN_REGIONS * RC_STRIDE, (uint32_t)b->list_cap};
+    HIP_TRY(hipMemsetAsync(b->lctr, 0, 3 * SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
+    const SlotList l8{b->list8, b->lctr, (uint32_t)b->list_cap}, lg{b->listg, b->lctr + SCAN_REGIONS * RC_STRIDE, (uint32_t)b->list_cap},
+                   lw{b->listw, b->lctr + 2 * SCAN_REGIONS * RC_STRIDE, (uint32_t)b->list_cap};
     const PairArgs pa{b->raw, b->q_meta, b->q_rows, b->q_rec, dl->e_rec, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, dl->ent_var_off,
                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand};
     FilterArgs fa;
@@ -736,13 +738,25 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr;
     const dim3 fgrid(((maxfill + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
     HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
-    if (fastD == 1) hipLaunchKernelGGL(k_filter_score<1>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
-    else if (fastD == 2) hipLaunchKernelGGL(k_filter_score<2>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
-    else if (fastD == 3) hipLaunchKernelGGL(k_filter_score<3>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
-    else hipLaunchKernelGGL(k_filter_score<0>, fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg);
+    // batches without long queries defer the 8-word prefilter of their few wide pairs (a 17..19-symbol candidate) to
+    // k_filter_wide: without that state the fused kernel fits 8 waves per SIMD
+    static const int enable_split = []() { const char* e = getenv("ANX_FS_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool split_wide = !have_long_q && enable_split;
+    if (split_wide) {
+      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      else hipLaunchKernelGGL((k_filter_score<0, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+    } else {
+      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      else hipLaunchKernelGGL((k_filter_score<0, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+    }
     HIP_TRY(hipEventRecord(b->ev_fs1, st));
     if (need_lists) {  // the list fills are only known on the device: grids cover the fullest pair-list region
       const dim3 lgrid(LIST_P * SCAN_REGIONS);
+      if (split_wide && enable_filter) hipLaunchKernelGGL(k_filter_wide, lgrid, dim3(256), 0, st, lw, fa, pa, sa, fastD, l8, lg);
       if (fastD && have_long_q) {
         if (fastD == 1) hipLaunchKernelGGL(k_score_fast8<1>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
         else if (fastD == 2) hipLaunchKernelGGL(k_score_fast8<2>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
@@ -987,7 +1001,7 @@ void batch_free(Batch* b) {
   (void)hipSetDevice(b->device);
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
-                  (void*)b->qmaxfreq, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->lctr,
+                  (void*)b->qmaxfreq, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) pool_free(p);
   for (auto& e : b->ev)

@@ -111,7 +111,8 @@ struct Batch {
   uint32_t* p_meta = nullptr;      // per pair-list slot: skipped / rejected / ld | samecase<<7 | lcs<<8 | prefix<<16 | suffix<<24
   uint32_t* list8 = nullptr;       // slot lists of the selected pairs the fused kernel leaves to k_score_fast8 / k_score_pairs
   uint32_t* listg = nullptr;
-  uint32_t* lctr = nullptr;        // [2][SCAN_REGIONS][RC_STRIDE] their fills
+  uint32_t* listw = nullptr;       // wide pairs (a string of 17..32 symbols) awaiting the 8-word prefilter of k_filter_wide
+  uint32_t* lctr = nullptr;        // [3][SCAN_REGIONS][RC_STRIDE] their fills
   size_t list_cap = 0;             // slots per region in list8 / listg
   size_t raw_cap = 0;
   double* quot = nullptr;          // table of IEEE quotients x / L (ScoreArgs::quot)

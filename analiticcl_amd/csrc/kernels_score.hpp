@@ -423,8 +423,12 @@ struct FilterArgs {
   uint32_t* counters;
   uint32_t* stat_ctr;       // [SCAN_REGIONS][RC_STRIDE], word 1: selected pairs
 };
-template <int D>
-__global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg) {
+// WIDE = true: the 8-word prefilter of pairs with a string of 17..32 symbols runs inline (batches with such queries: many
+// wide pairs).  WIDE = false (every query <= 16 symbols, so only the few pairs with a 17..19-symbol candidate are wide):
+// wide pairs are appended unfiltered to listw and k_filter_wide prefilters them -- the 8-word SWAR state is what sets the
+// register count of this kernel (72 VGPRs with it, 43 / 52 / 69 for D = 1 / 2 / 3 without: 8 waves per SIMD instead of 7).
+template <int D, bool WIDE>
+__global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg, SlotList listw) {
   __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
   __shared__ uint32_t s_n;
   __shared__ uint32_t s_str[256 * 9];
@@ -470,21 +474,22 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
         wide = filt && (lq > 16 || lc > 16);
       }
     }
-    if (__any(wide)) {  // wave-uniform, rare: some pair of the wave has a string of 17..32 symbols
+    if (WIDE && __any(wide)) {  // wave-uniform, rare: some pair of the wave has a string of 17..32 symbols
       uint32_t q8[8] = {Q.x, Q.y, Q.z, Q.w, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
       uint32_t c10[10] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
       if (wide && lq > 16) { const uint4 Q1 = A.q_rows[(size_t)q * a.qw + 1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
       if (wide && lc > 16) { const uint4 C1 = A.rows[crow + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
       if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
-    } else if (__any(filt)) {
+    } else if (__any(filt && !wide)) {
       const uint32_t q4[4] = {Q.x, Q.y, Q.z, Q.w}, c6[6] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu};
-      if (band_bound_rejects<4>(q4, c6, filt, d, lq, lc)) selected = false;
+      if (band_bound_rejects<4>(q4, c6, filt && !wide, d, lq, lc)) selected = false;
     }
-    if (a.store_pairs && live && !selected)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
+    const bool tow = !WIDE && wide;  // prefiltered later by k_filter_wide (which also counts it as selected if it passes)
+    if (a.store_pairs && live && !selected && !tow)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
       A.p_meta[p] = (invalid || stop_skipped) ? META_SKIPPED : (PAIR_NONE | (1u << 7));
     const bool inl = selected && D > 0 && lq <= 16 && lc <= 16 && d <= D;
-    const bool to8 = selected && !inl && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
-    const bool tog = selected && !inl && !to8;
+    const bool to8 = selected && !inl && !tow && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
+    const bool tog = selected && !inl && !tow && !to8;
     const unsigned long long mi = __ballot(inl);
     if (mi) {  // wave-uniform: queue the inline pairs
       const int first = __ffsll((long long)mi) - 1;
@@ -495,7 +500,8 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     }
     slot_append(list8, region, to8, p);
     slot_append(listg, region, tog, p);
-    nselected += (uint32_t)__popcll(__ballot(selected));
+    if (!WIDE) slot_append(listw, region, tow, p);
+    nselected += (uint32_t)__popcll(__ballot(selected && !tow));
     if (f.stop) {  // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops
       const unsigned long long ms = __ballot(stop_skipped);
       if (lane == 0 && ms) atomicAdd(&f.counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
@@ -547,6 +553,37 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
 }
 
 constexpr uint32_t LIST_P = 64;  // blocks per region of the slot-list kernels
+// The 8-word band-match prefilter of the wide pairs k_filter_score<D, false> deferred (listw): survivors go to the slot
+// list of the 8-word kernel (fastD > 0 and the batch uses it) or of the general kernel.
+__global__ __launch_bounds__(256) void k_filter_wide(SlotList in, FilterArgs f, PairArgs A, ScoreArgs a, int fastD, SlotList list8, SlotList listg) {
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = in.ctr[region * RC_STRIDE], lane = threadIdx.x & 63;
+  uint32_t nselected = 0;  // wave-uniform
+  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += LIST_P) {  // block-uniform
+    const uint32_t i = blk * 256 + threadIdx.x;
+    const bool active = i < n;
+    const uint32_t p = active ? in.list[(size_t)region * in.region_cap + i] : 0u;
+    uint32_t q8[8] = {0u, 0u, 0u, 0u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
+    uint32_t c10[10] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    int d = 0, lq = 0, lc = 0;
+    if (active) {
+      const uint2 rp = A.raw[p];
+      const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+      const uint4 Q = rec32(A.q_rec, q)[0], QM = rec32(A.q_rec, q)[1], C = rec32(A.e_rec, e)[0], CM = rec32(A.e_rec, e)[1];
+      lq = QM.x & 0xFF; d = (QM.x >> 16) & 0xFF; lc = CM.x & 0xFF;
+      q8[0] = Q.x; q8[1] = Q.y; q8[2] = Q.z; q8[3] = Q.w;
+      c10[1] = C.x; c10[2] = C.y; c10[3] = C.z; c10[4] = C.w;
+      if (lq > 16) { const uint4 Q1 = A.q_rows[(size_t)q * a.qw + 1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
+      if (lc > 16) { const uint4 C1 = A.rows[CM.y + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
+    }
+    const bool selected = active && !band_bound_rejects<8>(q8, c10, active, d, lq, lc);
+    if (a.store_pairs && active && !selected) A.p_meta[p] = PAIR_NONE | (1u << 7);  // rejected: ld = None, samecase = true
+    const bool to8 = selected && f.use_nw8 && fastD > 0 && lq <= 32 && lc <= 32 && d <= fastD;
+    slot_append(list8, region, to8, p);
+    slot_append(listg, region, selected && !to8, p);
+    nselected += (uint32_t)__popcll(__ballot(selected));
+  }
+  if (lane == 0 && nselected) atomicAdd(&f.stat_ctr[region * RC_STRIDE + 1], nselected);
+}
 // the selected pairs with a string of 17..32 symbols (list8 of k_filter_score)
 template <int D>
 __global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
