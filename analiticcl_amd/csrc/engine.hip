@@ -205,6 +205,27 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   std::vector<uint4> sig2(img.sig_lo.size());  // {signature, first class of the run, classes in the run}
   for (size_t i = 0; i < sig2.size(); ++i)
     sig2[i] = make_uint4(img.sig_lo[i], img.sig_hi[i], img.sig_cbeg[i], i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] - img.sig_cbeg[i] : 0u);
+  // bounding boxes of the 64-signature blocks (two-level walk of k_scan): per-group minimum and maximum over the real
+  // signatures of the block; a block of padding only gets a box nothing is near to
+  std::vector<uint4> sblk(2 * (sig2.size() / 64 + 64), make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
+  for (size_t bk = 0; bk < sig2.size() / 64; ++bk) {
+    uint8_t mn[8], mx[8];
+    memset(mn, 0xFF, 8); memset(mx, 0, 8);
+    bool any = false;
+    for (size_t i = bk * 64; i < bk * 64 + 64 && i < img.nsigs; ++i) {
+      any = true;
+      const uint64_t v = (uint64_t)img.sig_lo[i] | (uint64_t)img.sig_hi[i] << 32;
+      for (int g = 0; g < 8; ++g) { const uint8_t x = (uint8_t)(v >> (8 * g)); mn[g] = std::min(mn[g], x); mx[g] = std::max(mx[g], x); }
+    }
+    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, slack = 0;
+    if (any) {
+      memcpy(&w[0], mn, 4); memcpy(&w[1], mn + 4, 4); memcpy(&w[2], mx, 4); memcpy(&w[3], mx + 4, 4);
+      for (int g = 0; g < 8; ++g) slack += (uint32_t)(mx[g] - mn[g]);
+    }
+    sblk[2 * bk] = make_uint4(w[0], w[1], w[2], w[3]);
+    sblk[2 * bk + 1] = make_uint4(slack, 0u, 0u, 0u);
+  }
+  for (size_t bk = sig2.size() / 64; 2 * bk + 1 < sblk.size(); ++bk) sblk[2 * bk + 1] = make_uint4(0u, 0u, 0u, 0u);
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
   if ((rc = upload(&d->cls_planes, img.cls_planes.data(), img.cls_planes.size(), err, &d->bytes)) ||
@@ -213,6 +234,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_rec, crec.data(), crec.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig, sig2.data(), sig2.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sigblk, sblk.data(), sblk.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_cbeg, img.sig_cbeg.data(), img.sig_cbeg.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_vocab, img.ent_vocab.data(), img.ent_vocab.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_freq, img.ent_freq.data(), img.ent_freq.size(), err, &d->bytes)) ||
@@ -235,7 +257,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->cls_rec, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->cls_rec, (void*)d->sig, (void*)d->sigblk, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) pool_free(p);
@@ -269,7 +291,8 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   // ---- host encoding, threaded: normalisation (src/anahash.rs:50-80), count vector, threshold clamps -------
   struct Enc {
     uint32_t meta;   // len | k<<8 | d<<16 | first_is_lower<<24 ; 0 = not encodable
-    uint32_t key;    // kind*256 + len : bucket for the counting sort
+    uint32_t key;    // (bit-plane kinds ? 256 : 0) + len : bucket for the counting sort
+    uint32_t kind;   // 0 = count-vector (SAD) scan, 1..NBITPLANES = planes the bit-plane scan compares for this query
     uint32_t off;    // offset of the norm string in its thread's arena
     uint16_t thread;
     uint64_t sig;    // per-group symbol counts (LexiconImage::sym_group)
@@ -287,7 +310,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     int16_t codes[kMaxSymbols];
     for (size_t i = lo; i < hi; ++i) {
       Enc& e = enc[i];
-      e.meta = 0; e.key = 0; e.off = 0; e.thread = (uint16_t)tid; e.sig = 0;
+      e.meta = 0; e.key = 0; e.kind = 0; e.off = 0; e.thread = (uint16_t)tid; e.sig = 0;
       memset(&cv_all[i * cvbytes], 0, cvbytes);
       const int len = utf8[i] ? m.alphabet.scan_into(utf8[i], strlen(utf8[i]), codes, kMaxSymbols) : -1;
       if (len < 0) { b->status[i] = ANX_ELIMIT; continue; }
@@ -305,7 +328,8 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
       e.meta = (uint32_t)len | ((uint32_t)k << 8) | ((uint32_t)d << 16) |
                (first_char_is_lowercase(utf8[i]) ? 1u << 24 : 0u);
       const uint32_t kind = (bits_ok && maxcount <= (uint32_t)NBITPLANES) ? maxcount : 0;
-      e.key = kind * 256 + (uint32_t)len;
+      e.kind = kind;
+      e.key = (kind ? 256u : 0u) + (uint32_t)len;
       e.sig = signature_of(cv, cvbytes, m.lex.sym_group);
     }
   };
@@ -319,8 +343,8 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     for (auto& x : th) x.join();
   }
   lap("normalise + count vectors");
-  // (kernel kind, length)-bucketed order, stable (counting sort): a bucket shares k, d and the class window
-  constexpr uint32_t NKEYS = (NBITPLANES + 1) * 256;
+  // (scan kernel, length)-bucketed order, stable (counting sort): a bucket shares k, d and the class window
+  constexpr uint32_t NKEYS = 2 * 256;
   std::vector<size_t> kstart(NKEYS + 1, 0);
   size_t maxlen = 1;
   // per-thread histograms over contiguous input ranges -> per-thread cursors: a parallel, stable counting sort
@@ -379,10 +403,11 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
       if (enc[i].meta) b->order[cursor[enc[i].key]++] = (uint32_t)i;
   }, n);
   lap("counting sort");
-  {  // inside a (kind, length) bucket: by signature, stable; buckets are independent -> threads take them round-robin.
-     // LSD radix sort (8-bit digits, digits on which the whole bucket agrees are skipped) over (signature, input index)
-     // pairs: contiguous keys instead of a comparison sort through enc[] (23 -> 8 ms per million queries)
-    struct SigIdx { uint64_t sig; uint32_t idx; };
+  {  // inside a (scan kernel, length) bucket: by (signature, kind), stable; buckets are independent -> threads take them
+     // round-robin.  LSD radix sort (8-bit digits, digits on which the whole bucket agrees are skipped; the kind is the
+     // least significant digit) over (signature, kind, input index) records: contiguous keys instead of a comparison sort
+     // through enc[] (23 -> 8 ms per million queries)
+    struct SigIdx { uint64_t sig; uint32_t idx; uint32_t kind; };
     auto sort_buckets = [&](unsigned tid) {
       std::vector<SigIdx> a, t2;
       for (uint32_t kx = tid; kx < NKEYS; kx += nthreads) {
@@ -391,14 +416,24 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
         a.resize(cnt);
         t2.resize(cnt);
         uint64_t all_or = 0, all_and = ~0ull;
+        uint32_t kind_or = 0, kind_and = ~0u;
         for (size_t i = 0; i < cnt; ++i) {
           const uint32_t x = b->order[b0 + i];
-          a[i] = SigIdx{enc[x].sig, x};
+          a[i] = SigIdx{enc[x].sig, x, enc[x].kind};
           all_or |= a[i].sig;
           all_and &= a[i].sig;
+          kind_or |= a[i].kind;
+          kind_and &= a[i].kind;
         }
         const uint64_t varying = all_or ^ all_and;  // bits on which some keys differ
         SigIdx *src = a.data(), *dst = t2.data();
+        if (kind_or != kind_and) {  // least significant digit: the kind (0..NBITPLANES)
+          size_t cnts[NBITPLANES + 2] = {0};
+          for (size_t i = 0; i < cnt; ++i) cnts[src[i].kind + 1]++;
+          for (int v = 0; v <= NBITPLANES; ++v) cnts[v + 1] += cnts[v];
+          for (size_t i = 0; i < cnt; ++i) dst[cnts[src[i].kind]++] = src[i];
+          std::swap(src, dst);
+        }
         for (int byte = 0; byte < 8; ++byte) {
           if (!((varying >> (8 * byte)) & 0xFF)) continue;
           size_t cnts[257] = {0};
@@ -441,7 +476,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
       h_qrec[2 * s + 1] = make_uint4(e.meta, 0u, 0u, 0u);
       h_meta[s] = e.meta;
       h_orig[s] = (uint32_t)i;
-      h_kind[s] = e.key >> 8;
+      h_kind[s] = e.kind;
       h_sig[s] = e.sig;
     }
   };
@@ -455,26 +490,34 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     for (auto& x : th) x.join();
   }
   lap("fill device images");
-  // tiles: <= SCAN_TQ queries of one kind, length and signature; one wave of k_scan each
+  // tiles: <= SCAN_TQ queries of one scan kernel, length and signature (sorted by kind inside); one wave of k_scan each
   for (size_t i = 0; i < nq;) {
     size_t j = i;
-    while (j < nq && h_kind[j] == h_kind[i] && (h_meta[j] & 0xFF) == (h_meta[i] & 0xFF) && h_sig[j] == h_sig[i]) ++j;
-    const uint32_t kind = h_kind[i], lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
+    const bool sad = h_kind[i] == 0;
+    while (j < nq && (h_kind[j] == 0) == sad && (h_meta[j] & 0xFF) == (h_meta[i] & 0xFF) && h_sig[j] == h_sig[i]) ++j;
+    const uint32_t lq = h_meta[i] & 0xFF, k = (h_meta[i] >> 8) & 0xFF;
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
-    const uint32_t s0 = m.lex.siglen_begin[lo], s1 = m.lex.siglen_begin[hi + 1];
+    // aligned to whole 64-signature blocks (the neighbours inside the edge blocks belong to charcounts outside the window)
+    const uint32_t s0 = m.lex.siglen_begin[lo] & ~63u, s1 = (m.lex.siglen_begin[hi + 1] + 63u) & ~63u;
     static const uint32_t tq = []() { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }();
     // The count-vector (SAD) tiles are rare (queries with a symbol more than NBITPLANES times) and run as a launch of
     // their own: a handful of waves whose time is the latency of ONE wave walking the whole signature window.  Their
     // windows are therefore split over several waves (disjoint signature ranges = disjoint classes: same pairs).
-    const uint32_t nsplit = kind == 0 ? 8u : 1u;
+    const uint32_t nsplit = sad ? 8u : 1u;
     const uint32_t step = (((s1 - s0) + nsplit - 1) / nsplit + 63u) & ~63u;
-    for (size_t s = i; s < j; s += tq)
+    for (size_t s = i; s < j; s += tq) {
+      const uint32_t tn = (uint32_t)std::min<size_t>(tq, j - s);
+      uint32_t ke[3] = {0, 0, 0};  // end of the kind-1 / kind-2 / kind-3 queries inside the tile
+      for (uint32_t x = 0; x < tn; ++x)
+        for (uint32_t kd = h_kind[s + x]; kd >= 1 && kd <= 3; ++kd) ke[kd - 1]++;
+      const uint32_t kend = sad ? 0u : (ke[0] | ke[1] << 8 | ke[2] << 16);
       for (uint32_t part = 0; part < nsplit; ++part) {
         const uint32_t a0 = s0 + part * step, a1 = std::min(s1, a0 + step);
         if (a0 >= a1 && part) break;
-        b->tiles.push_back(Tile{(uint32_t)s, (uint32_t)std::min<size_t>(tq, j - s), a0, a1, k, lq, (uint32_t)h_sig[i],
-                                (uint32_t)(h_sig[i] >> 32), kind, (h_meta[i] >> 16) & 0xFFu});
+        b->tiles.push_back(Tile{(uint32_t)s, tn, a0, a1, k, lq, (uint32_t)h_sig[i], (uint32_t)(h_sig[i] >> 32), sad ? 0u : 1u,
+                                (h_meta[i] >> 16) & 0xFFu, kend});
       }
+    }
     i = j;
   }
   // longest-processing-time-first: cost ~ queries (the compatible classes per query vary little inside a length)
@@ -630,7 +673,8 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       ScanArgs A;
       A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
       A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cls_rec = dl->cls_rec; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
-      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_cbeg = dl->sig_cbeg;
+      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
+      { static const int hier = []() { const char* e = getenv("ANX_SCAN_WALK"); return (e && strcmp(e, "flat") == 0) ? 0 : 1; }(); A.hier = hier; }
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
       A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
       { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }

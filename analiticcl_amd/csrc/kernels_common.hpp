@@ -5,14 +5,15 @@
 // ------------------------------------------------------------------------------------------------
 // Device structures
 // ------------------------------------------------------------------------------------------------
-struct Tile {           // <= SCAN_TQ queries of one scan kind, one length and one signature
+struct Tile {           // <= SCAN_TQ queries of one length and one signature (bit-plane tiles: every kind 1..NBITPLANES, sorted by kind)
   uint32_t q0, nq;      // query range (queries are sorted by (scan kind, length, signature))
-  uint32_t s0, s1;      // signature range [s0, s1) of the +-k charcount window
+  uint32_t s0, s1;      // signature range [s0, s1) covering the +-k charcount window, aligned to 64-signature blocks
   uint32_t k;           // clamped anagram distance for this length
   uint32_t lq;          // query length in symbols
   uint32_t sig_lo, sig_hi;  // the tile's signature (per-group symbol counts, one byte each)
-  uint32_t kind;        // 0 = SAD body, 1..NBITPLANES = bit-plane body with T = kind
+  uint32_t kind;        // 0 = SAD body (count vectors), 1 = bit-plane body
   uint32_t d;           // clamped edit distance for this length
+  uint32_t kend;        // bit-plane tiles: end (within the tile) of the queries of kind 1 | kind 2 << 8 | kind 3 << 16; the rest are kind 4
 };
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
@@ -40,6 +41,7 @@ struct DeviceLexicon {
   uint4* cls_rec = nullptr;        // [cstride][2] {4 planes} {len, first entry, entries, 0}: ScanArgs::cls_rec
   uint4* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage): {groups 0-3, groups 4-7, first class of the run, classes}
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
+  uint4* sigblk = nullptr;         // [nsig_pad / 64][2] bounding box of every 64-signature block (ScanArgs::sigblk)
   uint32_t* ent_vocab = nullptr;
   uint32_t* ent_freq = nullptr;
   uint32_t* ent_meta = nullptr;

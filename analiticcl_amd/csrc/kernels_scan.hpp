@@ -97,6 +97,8 @@ struct ScanArgs {
   const uint32_t* cls_off;
   const uint4* sig;         // signature table: {groups 0-3, groups 4-7 packed as bytes, first class of the run, classes}
   const uint32_t* sig_cbeg;
+  const uint4* sigblk;      // [blocks][2] per 64-signature block: {group minima lo, hi, group maxima lo, hi} {sum(max) - sum(min), -, -, -}
+  int hier;                 // two-level signature walk (ANX_SCAN_WALK=flat: every block of the window)
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
   uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
@@ -119,12 +121,11 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
 //   classes share a symbol, src/iterators.rs:177).  2 ops per plane: v_and_b32 + accumulating v_bcnt_u32_b32.
 // T == 0: general path (any alphabet size / multiplicity): packed u8 count vectors, NP x v_sad_u8;
 //   hit <=> L1 <= k and L1 < len_q + len_c.
-template <int T, int NP>
+template <bool BITS, int NP>
 __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage, uint32_t* __restrict__ hits,
                                  uint32_t* __restrict__ qlds) {
-  constexpr bool BITS = T > 0;
   constexpr int CPL = BITS ? 4 : (NP <= 8 ? 4 : NP <= 16 ? 2 : 1);  // classes per lane
-  constexpr int W = BITS ? T : NP;                                   // dwords compared per class
+  constexpr int W = BITS ? NBITPLANES : NP;                          // dwords held per class
   constexpr int QSTRIDE = BITS ? NBITPLANES : NP;
   constexpr uint32_t CHUNK = 64u * CPL;
   const uint32_t lane = threadIdx.x & 63;
@@ -239,32 +240,50 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       uint32_t hm[CPL];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) hm[j] = 0xFFFFFFFFu;  // miss bits
-      auto test_query = [&](uint32_t qi) {  // one query against the lane's CPL classes: shifts one bit into every hm[j]
-        uint32_t qreg[W];
+      // one query against the lane's CPL classes: shifts one bit into every hm[j].  TW = planes compared: the query's
+      // kind (bit-plane tiles hold queries of every kind 1..NBITPLANES, sorted by kind) or NP count-vector dwords.
+      auto test_query = [&](auto tw, uint32_t qi) {
+        constexpr int TW = decltype(tw)::value;
+        uint32_t qreg[TW];
 #pragma unroll
-        for (int p = 0; p < W; ++p) qreg[p] = qlds[(qb + qi) * QSTRIDE + p];
+        for (int p = 0; p < TW; ++p) qreg[p] = qlds[(qb + qi) * QSTRIDE + p];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           int32_t acc;
           if (BITS) {
             acc = thr[j];  // common - threshold: negative = miss
 #pragma unroll
-            for (int p = 0; p < W; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
+            for (int p = 0; p < TW; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
           } else {
             uint32_t sad = 0;
 #pragma unroll
-            for (int p = 0; p < W; ++p) sad = __builtin_amdgcn_sad_u8(qreg[p], cw[j][p], sad);
+            for (int p = 0; p < TW; ++p) sad = __builtin_amdgcn_sad_u8(qreg[p], cw[j][p], sad);
             acc = thr[j] - (int32_t)sad;  // threshold - L1: negative = miss
           }
           hm[j] = __builtin_amdgcn_alignbit(hm[j], (uint32_t)acc, 31);  // (hm << 1) | sign(acc)
         }
       };
-      uint32_t qi = 0;
-      for (; qi + 2 <= npass; qi += 2) {  // two queries per trip: half the loop overhead, both LDS reads in flight
-        test_query(qi);
-        test_query(qi + 1);
+      auto run_queries = [&](auto tw, uint32_t lo, uint32_t hi) {  // queries [lo, hi) of the pass, in order
+        uint32_t qi = lo;
+        for (; qi + 2 <= hi; qi += 2) {  // two queries per trip: half the loop overhead, both LDS reads in flight
+          test_query(tw, qi);
+          test_query(tw, qi + 1);
+        }
+        if (qi < hi) test_query(tw, qi);
+      };
+      if (BITS) {
+        // the tile's queries are sorted by kind; ke[t] = end of the kind-t queries.  The four sub-ranges of the pass run
+        // in order, so bit positions keep following the query order.
+        const uint32_t pend = qb + npass;
+        auto clampr = [&](uint32_t x) { return (x < qb ? qb : (x > pend ? pend : x)) - qb; };
+        const uint32_t b1 = clampr(t.kend & 0xFFu), b2 = clampr((t.kend >> 8) & 0xFFu), b3 = clampr((t.kend >> 16) & 0xFFu);
+        run_queries(std::integral_constant<int, 1>{}, 0u, b1);
+        run_queries(std::integral_constant<int, 2>{}, b1, b2);
+        run_queries(std::integral_constant<int, 3>{}, b2, b3);
+        run_queries(std::integral_constant<int, BITS ? 4 : 1>{}, b3, npass);
+      } else {
+        run_queries(std::integral_constant<int, BITS ? 1 : NP>{}, 0u, npass);
       }
-      if (qi < npass) test_query(qi);
       // expand the hits of this pass into (query, entry) pairs
       const uint32_t valid = npass >= 32u ? 0xFFFFFFFFu : ((1u << npass) - 1u);
       uint32_t any = 0;
@@ -295,19 +314,15 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     }
   };
 
-  // No bounds test on s: signatures outside [s0, s1) belong to other charcounts, so their L1 distance to the tile's
-  // signature is at least the length difference > k, and the table is padded with never-matching entries.
+  // The tile's signature window [s0, s1) is aligned to whole 64-signature blocks (no bounds test is needed: the other
+  // signatures of the first / last block belong to other charcounts, so their L1 distance to the tile's signature is at
+  // least the length difference > k, and the table is padded with never-matching entries).
   // One 16-byte record per signature: the run (first class, count) comes with the signature, so a matching step does not
-  // wait for a second, dependent load -- a tile is one wave's serial chain over ~220 steps.
-  const uint4* __restrict__ sigp = A.sig + t.s0 + lane;
-  uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-  for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
-    const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
-    sigp += 64;
-    if (sb + 64 < t.s1) sg_next = *sigp;
+  // wait for a second, dependent load.
+  auto test_block = [&](const uint4 sg) {  // the 64 signatures of one block, one per lane: stage the class runs of the compatible ones
     const bool ok = __builtin_amdgcn_sad_u8(sg.x, t.sig_lo, __builtin_amdgcn_sad_u8(sg.y, t.sig_hi, 0u)) <= t.k;
     unsigned long long m = __ballot(ok);
-    if (!m || (A.dbg & 4)) continue;
+    if (!m || (A.dbg & 4)) return;
     const uint32_t cb = ok ? sg.z : 0u, n = ok ? sg.w : 0u;
     while (m) {  // scalar loop over the compatible signatures of this step
       const int i = __ffsll((long long)m) - 1;
@@ -329,6 +344,41 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         }
       }
     }
+  };
+  if (A.hier) {
+    // Two-level walk: one 32-byte summary per block = bounding box (per-group minimum and maximum) of its 64 signatures.
+    // distance(signature, box) = sum_g max(0, min_g - q_g) + max(0, q_g - max_g) is a lower bound of the L1 distance to every
+    // signature inside, and with max(0, x) = (|x| + x) / 2 it is (SAD(min, q) + SAD(max, q) - slack) / 2, slack = sum(max) -
+    // sum(min): a block is visited iff SAD(min, q) + SAD(max, q) <= 2k + slack.  64 summaries per step.
+    const uint32_t b0 = t.s0 >> 6, b1 = t.s1 >> 6;
+    for (uint32_t bb = b0; bb < b1; bb += 64) {
+      const uint32_t blk = bb + lane;
+      bool okb = false;
+      if (blk < b1) {
+        const uint4 box = A.sigblk[2 * (size_t)blk], bx2 = A.sigblk[2 * (size_t)blk + 1];
+        const uint32_t sad = __builtin_amdgcn_sad_u8(box.x, t.sig_lo, __builtin_amdgcn_sad_u8(box.y, t.sig_hi,
+                             __builtin_amdgcn_sad_u8(box.z, t.sig_lo, __builtin_amdgcn_sad_u8(box.w, t.sig_hi, 0u))));
+        okb = sad <= 2u * t.k + bx2.x;
+      }
+      unsigned long long mb = __ballot(okb);
+      if (!mb) continue;
+      uint4 sg_next = A.sig[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
+      while (mb) {
+        mb &= mb - 1;
+        const uint4 sg = sg_next;  // the next candidate block is loaded while this one is tested and staged
+        if (mb) sg_next = A.sig[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
+        test_block(sg);
+      }
+    }
+  } else {
+    const uint4* __restrict__ sigp = A.sig + t.s0 + lane;
+    uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+    for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
+      const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
+      sigp += 64;
+      if (sb + 64 < t.s1) sg_next = *sigp;
+      test_block(sg);
+    }
   }
   if (ns) process();
   flush();
@@ -337,8 +387,16 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     wo.emitted += tot;
   }
   wave_close(wo, lane, raw);
-  if (lane == 0 && nchunks)
-    atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * T), (unsigned long long)nchunks * CHUNK * t.nq);
+  if (lane == 0 && nchunks) {  // class tests by planes compared (statistics)
+    if (BITS) {
+      const uint32_t e[5] = {0u, t.kend & 0xFFu, (t.kend >> 8) & 0xFFu, (t.kend >> 16) & 0xFFu, t.nq};
+      for (int k = 1; k <= NBITPLANES; ++k)
+        if (e[k] > e[k - 1])
+          atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS + 2 * k), (unsigned long long)nchunks * CHUNK * (e[k] - e[k - 1]));
+    } else {
+      atomicAdd(reinterpret_cast<unsigned long long*>(wo.ctr + RC_TESTS), (unsigned long long)nchunks * CHUNK * t.nq);
+    }
+  }
 }
 
 // Every wave takes one tile; tiles are ordered by decreasing cost.  The bit-plane tiles (wave-uniform switch over
@@ -356,19 +414,8 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   if (item >= A.ntiles) return;
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
-  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9];
-  uint32_t* qlds = s_qlds[wid];
-  uint32_t* stage = s_stage[wid];
-  if (BITS) {
-    switch (t.kind) {
-      case 1: scan_tile<1, NP>(A, t, item, stage, s_hits[wid], qlds); break;
-      case 2: scan_tile<2, NP>(A, t, item, stage, s_hits[wid], qlds); break;
-      case 3: scan_tile<3, NP>(A, t, item, stage, s_hits[wid], qlds); break;
-      default: scan_tile<4, NP>(A, t, item, stage, s_hits[wid], qlds); break;
-    }
-  } else {
-    scan_tile<0, NP>(A, t, item, stage, s_hits[wid], qlds);
-  }
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10];
+  scan_tile<BITS, NP>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid]);
 }
 // <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
 // 64 with spills -> 2.60 ms)

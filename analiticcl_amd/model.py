@@ -465,6 +465,33 @@ class VariantModel:
         finally:
             L.lib().anx_matches_free(ms, offs, rows, tags)
 
+    def find_all_matches_arrays(self, texts: Sequence[str], params: SearchParameters):
+        """Bulk form of find_all_matches_ids: numpy copies of what anx_find_all_matches_batch returns, no per-match Python
+        objects.  -> (offs[n+1], matches (structured: begin, end, n, selected, vb, ve, tb, te), rows (structured:
+        vocab_id, dist, freq, via)); the matches of text i are matches[offs[i]:offs[i+1]], the variants of a match
+        rows[vb:ve] (selected = index into them, -1 = none)."""
+        import numpy as np
+        n = len(texts)
+        arr = (C.c_char_p * max(n, 1))(*[_b(t) for t in texts])
+        sp = params._c_search()
+        ms, offs, rows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)()
+        nrows = C.c_size_t(0)
+        L.check(L.lib().anx_find_all_matches_batch(self.h, arr, n, C.byref(sp), C.byref(ms), C.byref(offs),
+                                                   C.byref(rows), C.byref(nrows), None))
+        try:
+            off = np.ctypeslib.as_array(offs, shape=(n + 1,)).astype(np.int64)
+            mdt = np.dtype([("begin", "<u8"), ("end", "<u8"), ("n", "<u4"), ("selected", "<i4"), ("vb", "<u8"), ("ve", "<u8"),
+                            ("tb", "<u4"), ("te", "<u4")])
+            rdt = np.dtype([("vocab_id", "<u8"), ("dist", "<f8"), ("freq", "<f8"), ("via", "<u8")])
+            nm = int(off[-1])
+            ma = np.frombuffer((C.c_char * (nm * mdt.itemsize)).from_address(C.addressof(ms.contents)), dtype=mdt).copy() \
+                if nm else np.zeros(0, dtype=mdt)
+            ra = np.frombuffer((C.c_char * (nrows.value * rdt.itemsize)).from_address(C.addressof(rows.contents)), dtype=rdt).copy() \
+                if nrows.value else np.zeros(0, dtype=rdt)
+            return off, ma, ra
+        finally:
+            L.lib().anx_matches_free(ms, offs, rows, None)
+
     def search_output(self, texts: Sequence[str], params: SearchParameters, json: bool = False,
                       output_lexmatch: bool = False, first_seqnr: int = 1):
         """find_all_matches over the texts + the text `analiticcl search` prints for the matches

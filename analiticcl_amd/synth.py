@@ -91,3 +91,24 @@ def make_lexicon(words: Sequence[str], n: int, min_len: int = 4, max_len: int = 
             seen.add(w)
             out.append(w)
     return out[:n]
+
+
+def make_running_text(words: Sequence[str], megabytes: float, seed: int = SEED, sentences_per_text: int = 8) -> List[str]:
+    """BASELINE.json configs[4] shape: running text of sentences of 5-25 perturbed lexicon words (make_queries: 0-2 edits
+    each) ending in ". " / newline / ", " / an empty line; `sentences_per_text` sentences per input text."""
+    rng = random.Random(seed)
+    pert = make_queries(words, int(megabytes * 1e6 / 7) + 100, max_len=16, seed=seed + 1)
+    texts: List[str] = []
+    cur: List[str] = []
+    size, k = 0, 0
+    while size < megabytes * 1e6:
+        n = rng.randrange(5, 26)
+        if k + n > len(pert):
+            k = 0
+        cur.append(" ".join(pert[k:k + n]) + rng.choice([". ", "\n", ", ", "\n\n"]))
+        k += n
+        if len(cur) == sentences_per_text:
+            texts.append("".join(cur))
+            size += len(texts[-1].encode("utf-8"))
+            cur = []
+    return texts

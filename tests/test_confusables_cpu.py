@@ -85,3 +85,39 @@ def test_product_pattern_errors():
     with pytest.raises(A.AnxError):
         m.add_to_confusables("-[]", 1.1)
     m.add_to_confusables("^=[c|k]-[y]+[i]$", 0.9)
+
+
+def test_composed_confusable_oracle_equals_twin(data_dir):
+    """oracle/confusable_oracle.py (C oracle up to the crop + sesdiff twin rescoring + re-rank + cutoff) against the full
+    pure-Python twin on a 3000-word nld subset with the committed 10-pattern list: the composition the full-size GPU test
+    of BASELINE configs[2] uses as its checker (the twin alone needs seconds per query on the whole lexicon)."""
+    import os
+    from analiticcl_amd import synth
+    from oracle import cwrap as O
+    from oracle import confusable_oracle as CO
+    alpha = os.path.join(data_dir, "simple.alphabet.tsv")
+    conf_path = os.path.join(synth.GOLDEN_DATA, "confusables10.tsv")
+    allw = synth.load_lexicon_words(os.path.join(data_dir, "nld.aspell.lexicon"))
+    # contiguous (alphabetical) slices: neighbouring word forms, so that queries have several near candidates
+    words = allw[30000:31500] + allw[120000:121500] + [w for w in allw if "y" in w or "ck" in w][:600]
+    tw = T.VariantModel(T.read_alphabet(alpha))
+    o = O.OracleModel(alphabet_path=alpha)
+    for w in words:
+        tw.add_to_vocabulary(w)
+        o.add(w)
+    tw.read_confusablelist(conf_path)
+    tw.build()
+    o.build()
+    confs = CO.read_confusables(conf_path)
+    assert len(confs) == 10
+    qs = synth.make_queries(words, 250, max_len=24, seed=31)
+    fired = 0
+    for mm, cut in ((10, 2.0), (3, 1.2)):
+        tp = T.SearchParameters(("abs", 3), ("abs", 3), mm, 0.25, cut, False, 0.0)
+        op = O.make_params(("abs", 3), ("abs", 3), mm, 0.25, 0.0)  # no cutoff yet: it follows the late rescoring
+        for q in qs:
+            exp = [(x.vocab_id, x.dist_score, x.freq_score) for x in tw.find_variants(q, tp)]
+            got = CO.late_rescore(o.find_variants(q, op), q, confs, o.text, 0.0, cut)
+            assert got == exp, (q, got[:3], exp[:3])
+            fired += any(CO.confusable_weight(confs, q, o.text(v)) != 1.0 for v, _d, _f in got)
+    assert fired > 20

@@ -1,0 +1,77 @@
+"""BASELINE.json configs[2] as stated, all at once: nld.aspell lexicon (~230 k entries), 1 M synthetic queries of length <= 24,
+max-edit-distance 3, WITH confusable weighting (the committed 10-pattern list tests/golden/data/confusables10.tsv), on one
+MI355X.  Checked through size-independent properties and >= 1000 spot checks against the oracle with confusables ON
+(oracle/confusable_oracle.py: C oracle up to the crop + sesdiff twin rescoring, re-rank, cutoff; the composition is pinned to
+the full twin by tests/test_confusables_cpu.py).  Reference: src/lib.rs:972-1027, :1591-1595, :1656-1663, :1733-1756."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import analiticcl_amd as A
+from analiticcl_amd import synth
+from oracle import confusable_oracle as CO
+from oracle import cwrap as O
+
+from fullsize_common import check_ranked, check_shards_equal_whole, checksum
+
+N = 1_000_000
+CONF = os.path.join(synth.GOLDEN_DATA, "confusables10.tsv")
+
+
+@pytest.fixture(scope="module")
+def setup(data_dir):
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(os.path.join(data_dir, "nld.aspell.lexicon"))
+    g.read_confusablelist(CONF)
+    g.build()
+    words = synth.load_lexicon_words(os.path.join(data_dir, "nld.aspell.lexicon"))
+    qs = synth.make_queries(words, N, max_len=24, seed=synth.SEED + 2)
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=3, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+    b = g.encode_batch(qs, p)
+    b.run()
+    return g, qs, p, b, b.fetch_arrays(), b.stats()
+
+
+def test_counts_and_idempotence(setup):
+    g, qs, p, b, (off, vid, dist, freq), st = setup
+    assert st["n_queries"] == N and st["n_results"] == off[-1]
+    assert 50 * N < st["n_pairs"] < 400 * N
+    c1 = checksum(off, vid, dist, freq)
+    b.run()
+    assert b.stats()["n_pairs"] == st["n_pairs"]
+    assert checksum(*b.fetch_arrays()) == c1
+
+
+def test_ranked_bounded_and_confusables_fired(setup):
+    _g, _qs, _p, _b, (off, vid, dist, freq), _st = setup
+    # rescored rows may exceed 1.0 (weight 1.1) and a penalised row may fall below the score threshold it passed before
+    check_ranked(off, dist, N, 11, 0.25, 2.0, score_floor_exact=False)
+    assert dist.max() > 1.0 and dist.max() <= 1.1 * 1.1 * 1.1 + 1e-12
+    assert np.all(freq == 1.0)
+
+
+def test_shards_equal_whole(setup):
+    g, qs, p, _b, arrays, _st = setup
+    check_shards_equal_whole(g, qs, p, arrays, ((0, 40_000), (700_001, 745_000)))
+
+
+def test_oracle_spot_check_with_confusables(setup, data_dir):
+    g, qs, _p, _b, (off, vid, dist, freq), _st = setup
+    o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+    o.read_lexicon(os.path.join(data_dir, "nld.aspell.lexicon"))
+    o.build()
+    confs = CO.read_confusables(CONF)
+    op = O.make_params(("abs", 3), ("abs", 3), 10, 0.25, 0.0)  # the cutoff follows the late rescoring
+    rng = np.random.default_rng(11)
+    fired = 0
+    for i in rng.choice(N, 1200, replace=False):
+        exp = CO.late_rescore(o.find_variants(qs[i], op), qs[i], confs, o.text, 0.0, 2.0)
+        got = [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
+        assert [v for v, _d, _f in got] == [v for v, _d, _f in exp], qs[i]
+        for (_v, d, f), (_v2, d2, f2) in zip(got, exp):
+            assert abs(d - d2) <= 1e-6 and f == f2, qs[i]  # north_star: float composite score within 1e-6
+        fired += any(CO.confusable_weight(confs, qs[i], o.text(v)) != 1.0 for v, _d, _f in exp)
+    assert fired > 100  # the patterns did fire on the sample

@@ -1,0 +1,80 @@
+"""BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon (eng.aspell + nld.aspell + seeded Markov-chain
+words of 4-32 symbols, analiticcl_amd/synth.py make_lexicon), 1.25 M of the 10 M length-bucketed queries of 4-32 symbols
+(10 M / 8 GPUs), CLI defaults with max-edit-distance 2.  Size-independent properties (idempotence, shard == whole: the
+multi-GPU split) and 600 spot checks against the C oracle built on the same 1 M-entry lexicon.  Reference: src/lib.rs:972-1027."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import analiticcl_amd as A
+from analiticcl_amd import synth
+from oracle import cwrap as O
+
+from fullsize_common import check_ranked, check_shards_equal_whole, checksum
+
+NE = 1_000_000
+NQ = 1_250_000
+
+
+@pytest.fixture(scope="module")
+def setup(data_dir, tmp_path_factory):
+    words = list(dict.fromkeys(synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon")) +
+                               synth.load_lexicon_words(os.path.join(data_dir, "nld.aspell.lexicon"))))
+    lex = synth.make_lexicon(words, NE, seed=11)
+    assert len(lex) == NE and len(set(lex)) == NE
+    path = str(tmp_path_factory.mktemp("biglex") / "merged.lexicon")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lex) + "\n")
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(path)
+    g.build()
+    qs = synth.make_queries(lex, NQ, max_len=32, min_len=4, seed=5)
+    qs.sort(key=len)  # length-bucketed
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+    b = g.encode_batch(qs, p)
+    b.run()
+    return g, path, qs, p, b, b.fetch_arrays(), b.stats()
+
+
+def test_counts_and_idempotence(setup):
+    g, _path, qs, p, b, (off, vid, dist, freq), st = setup
+    assert g.num_instances() == NE
+    assert st["n_queries"] == NQ and st["n_results"] == off[-1]
+    assert 100 * NQ < st["n_pairs"] < 1000 * NQ
+    lens = np.array([len(q) for q in qs])
+    assert lens.min() >= 1 and lens.max() == 32 and (lens > 16).sum() > NQ // 4   # the 8-word and general kernels are in play
+    c1 = checksum(off, vid, dist, freq)
+    b.run()
+    assert b.stats()["n_pairs"] == st["n_pairs"]
+    assert checksum(*b.fetch_arrays()) == c1
+
+
+def test_ranked_and_bounded(setup):
+    _g, _path, _qs, _p, _b, (off, vid, dist, freq), _st = setup
+    check_ranked(off, dist, NQ, 11, 0.25, 2.0)
+    assert np.all(dist <= 1.0) and np.all(freq == 1.0)
+
+
+def test_shards_equal_whole(setup):
+    g, _path, qs, p, _b, arrays, _st = setup
+    check_shards_equal_whole(g, qs, p, arrays, ((0, 30_000), (600_000, 640_000), (NQ - 25_000, NQ)))
+
+
+def test_oracle_spot_check(setup, data_dir):
+    g, path, qs, _p, _b, (off, vid, dist, freq), _st = setup
+    o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+    o.read_lexicon(path)
+    o.build()
+    op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
+    rng = np.random.default_rng(3)
+    idx = [int(i) for i in rng.choice(NQ, 600, replace=False)]
+    stride = 16
+    _rc, res, counts, _tp, _tc = o.find_variants_batch([qs[i] for i in idx], op, nthreads=0, stride=stride)
+    for n, i in enumerate(idx):
+        assert 0 <= counts[n] <= stride
+        exp = [(res[n * stride + j].vocab_id, res[n * stride + j].dist_score, res[n * stride + j].freq_score) for j in range(counts[n])]
+        got = [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
+        assert got == exp, qs[i]

@@ -16,6 +16,8 @@ from analiticcl_amd import synth
 from oracle import cwrap as O
 from oracle import twin as T
 
+from search_common import TwinOverOracle
+
 TEST_ALPHABET_TSV = "\n".join(f"{c}\t{c.upper()}" for c in "abcdefghijklmnopqrstuvwxyz") + "\n.\t,\n"
 LM = A.VocabParams(vocabtype="LM")
 
@@ -104,20 +106,6 @@ def test_tutorial_find_all_matches(eng, tutorial_outputs):
     c = case["matches"][0]
     assert (m["input"], m["offset"]["begin"], m["offset"]["end"]) == (c["input"], c["begin"], c["end"])
     assert [[v["text"], v["score"], v["dist_score"], v["freq_score"]] for v in m["variants"]] == c["variants"]
-
-
-class TwinOverOracle(T.SearchModel):
-    """The twin's search mode with find_variants answered by the C oracle (ids are aligned: both number the
-    vocabulary in insertion order after BOS/EOS/UNK)."""
-
-    def attach(self, orc):
-        self.orc = orc
-
-    def find_variants(self, text, params, trace=None):
-        cp = O.make_params(params.max_anagram_distance, params.max_edit_distance, params.max_matches,
-                           params.score_threshold, params.cutoff_threshold, params.stop_at_exact_match,
-                           params.freq_weight)
-        return [T.VariantResult(v, d, f, via) for v, d, f, via in self.orc.find_variants_via(text, cp)]
 
 
 def random_texts(words, phrases, n, seed):
