@@ -156,6 +156,7 @@ def lib():
         "anx_batch_export_compact": (C.c_int, [vp, vp, sz, vp, C.POINTER(sz)]),
         "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats)]),
         "anx_batch_free": (None, [vp]),
+        "anx_device_pool_trim": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

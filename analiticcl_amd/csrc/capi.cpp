@@ -558,6 +558,8 @@ int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* s) {
   anx::batch_stats(b->b, s);
   return ANX_OK;
 }
+void anx_device_pool_trim(int device) { anx::device_pool_trim(device); }
+
 void anx_batch_free(anx_batch* b) {
   if (!b) return;
   anx::batch_free(b->b);

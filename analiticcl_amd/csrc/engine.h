@@ -14,6 +14,7 @@ struct Batch;          // encoded queries + pipeline buffers + results, HBM-resi
 int device_count(std::string& err);
 DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& err);
 void lexicon_free(DeviceLexicon*);
+void device_pool_trim(int device);  // hands the cached scratch blocks of the device back to the driver
 
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
                     const anx_params& p, std::string& err, int* code);

@@ -68,7 +68,16 @@ struct DevPool {
   size_t cached = 0;
   int lexicons = 0;
 };
-constexpr size_t POOL_CACHE_LIMIT = (size_t)96 << 30;  // bytes kept per device (MI355X: 288 GB HBM)
+// bytes of freed blocks kept per device (MI355X: 288 GB HBM; a 1 M-query batch holds 3-6 GB of scratch).  ANX_POOL_CACHE_MB
+// overrides the default; anx_device_pool_trim() hands the cache back to the driver at any time.
+static size_t pool_cache_limit() {
+  static const size_t lim = []() {
+    const char* e = getenv("ANX_POOL_CACHE_MB");
+    const long long v = e ? atoll(e) : -1;
+    return v >= 0 ? (size_t)v << 20 : (size_t)32 << 30;
+  }();
+  return lim;
+}
 DevPool& pool_of(int device) {
   static DevPool pools[64];
   return pools[device >= 0 && device < 64 ? device : 0];
@@ -114,7 +123,7 @@ void pool_free(void* p) {
   {
     std::lock_guard<std::mutex> g(pl.mu);
     auto it = pl.size_of.find(p);
-    if (it != pl.size_of.end() && pl.cached + it->second <= POOL_CACHE_LIMIT) {
+    if (it != pl.size_of.end() && pl.cached + it->second <= pool_cache_limit()) {
       pl.free_blocks.emplace(it->second, p);
       pl.cached += it->second;
       return;
@@ -135,6 +144,7 @@ void pool_trim(int device) {
   for (void* d : drop) (void)hipFree(d);
 }
 }  // namespace
+void device_pool_trim(int device) { if (hipSetDevice(device) == hipSuccess) pool_trim(device); }
 
 // Host staging array WITHOUT value-initialisation: the threaded fill loops write every element, so the pages are first
 // touched (and faulted in) by the worker threads instead of being zero-filled by the calling thread (a million queries
@@ -584,10 +594,10 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
   return b;
 }
 
-static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, hipStream_t st) {
+static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, hipStream_t st, uint32_t* maxout = nullptr) {
   const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return hipMemsetAsync(out, 0, sizeof(uint32_t), st) == hipSuccess ? 0 : -1;
-  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, out, tmp);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, out, tmp, maxout);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, tmp, nb);
   hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, st, out, n, tmp, nb);
   return 0;
@@ -651,6 +661,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   HIP_TRY(hipSetDevice(dl->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint32_t nq = (uint32_t)b->nq;
+  b->last_stream = stream;
   b->ran = false;
   b->ran_keep_all = b->keep_all_pairs;  // the run that also stores the per-slot outputs the debug fetch of every pair reads
   b->n_pairs = b->n_results = b->n_surv = 0;
@@ -674,10 +685,10 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
       A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cls_rec = dl->cls_rec; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
       A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
-      { static const int hier = []() { const char* e = getenv("ANX_SCAN_WALK"); return (e && strcmp(e, "flat") == 0) ? 0 : 1; }(); A.hier = hier; }
+      { const char* e = getenv("ANX_SCAN_WALK"); A.hier = (e && strcmp(e, "flat") == 0) ? 0 : 1; }
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
       A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
-      { static const int dbg = []() { const char* e = getenv("ANX_SCAN_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
+      { const char* e = getenv("ANX_SCAN_DBG"); A.dbg = e ? atoi(e) : 0; }  // read per run: tools/scan_probe.py switches it between runs
       const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
       switch (dl->nplanes) {
         case 8: launch_scan<8>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
@@ -718,7 +729,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
   if (dl->any_variants) HIP_TRY(hipMemsetAsync(b->qexpand, 0, nq * sizeof(uint32_t), st));
   ScoreArgs sa;
-  { static const int dbg = []() { const char* e = getenv("ANX_SCORE_DBG"); return e ? atoi(e) : 0; }(); sa.dbg = dbg; }
+  { const char* e = getenv("ANX_SCORE_DBG"); sa.dbg = e ? atoi(e) : 0; }
   sa.quot = b->quot;
   sa.store_pairs = b->keep_all_pairs ? 1 : 0;
   if (sa.store_pairs && (rc = ensure_pair_outputs(b, err))) return rc;
@@ -856,9 +867,10 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     HIP_TRY(hipEventRecord(b->ev[3], st));
     hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
                        b->qexpand, ra, b->t_key, b->r_rows, b->r_count, 0xFFFFFFFFu);
-    exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
+    exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st, b->counters + CTR_MAXROWS);
     HIP_TRY(hipEventRecord(b->ev[4], st));
     HIP_TRY(hipMemcpyAsync(&total_results, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&h_counters[CTR_MAXROWS], b->counters + CTR_MAXROWS, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
   } else {
     // No host round trip between scoring and ranking: the row buffers keep the size of the previous run (first run:
@@ -874,7 +886,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       HIP_TRY(hipEventRecord(b->ev[3], st));
       hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
                          b->qexpand, ra, b->t_key, b->r_rows, b->r_count, row_cap);
-      exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st);
+      exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st, b->counters + CTR_MAXROWS);
       HIP_TRY(hipEventRecord(b->ev[4], st));
       if ((rc = read_counts())) return rc;
       HIP_TRY(hipMemcpyAsync(&total_results, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -888,6 +900,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   }
   HIP_TRY(hipGetLastError());
   b->n_results = total_results;
+  b->max_rows = h_counters[CTR_MAXROWS];
   b->ran = true;
   anx_batch_stats& s = b->stats;
   s.n_queries = nq;
@@ -920,27 +933,37 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
   size_t* off = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
   anx_result* out = static_cast<anx_result*>(malloc(std::max<size_t>(1, b->n_results) * sizeof(anx_result)));
   if (!off || !out) { free(off); free(out); err = "out of memory"; return ANX_EINVAL; }
+  int rc = ANX_OK;
   if (b->nq && b->n_results) {
     // the device lays the rows out in the caller's input order (counts scattered to the original indices, exclusive
-    // scan, row copy), so the host only copies: offsets (u32) and the finished anx_result array
+    // scan, row copy), so the host only copies: offsets (u32) and the finished anx_result array.  Runs on the stream of
+    // the batch's last run; every exit frees the temporaries.
     uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_tmp = nullptr;
     anx_result* d_out = nullptr;
-    const uint32_t n32 = (uint32_t)n, nq32 = (uint32_t)b->nq;
-    const size_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE + 2;
-    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_cnt), n * sizeof(uint32_t)));
-    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_off), (n + 1) * sizeof(uint32_t)));
-    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_tmp), nblk * sizeof(uint32_t)));
-    HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_out), b->n_results * sizeof(anx_result)));
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, n * sizeof(uint32_t), 0));
-    hipLaunchKernelGGL(k_fetch_counts, dim3((nq32 + 255) / 256), dim3(256), 0, 0, nq32, b->r_count, b->q_orig, d_cnt);
-    exclusive_scan(d_cnt, n32, d_off, d_tmp, 0);
-    hipLaunchKernelGGL(k_fetch_rows, dim3((nq32 + 255) / 256), dim3(256), 0, 0, nq32, b->soff, b->r_count, b->r_rows, b->q_orig, d_off, d_out);
-    std::vector<uint32_t> h_off(n + 1);
-    HIP_TRY(hipMemcpy(h_off.data(), d_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out, d_out, b->n_results * sizeof(anx_result), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i <= n; ++i) off[i] = h_off[i];
+    hipStream_t st = reinterpret_cast<hipStream_t>(b->last_stream);
+    auto body = [&]() -> int {
+      const uint32_t n32 = (uint32_t)n, nq32 = (uint32_t)b->nq;
+      const size_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE + 2;
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_cnt), n * sizeof(uint32_t)));
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_off), (n + 1) * sizeof(uint32_t)));
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_tmp), nblk * sizeof(uint32_t)));
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_out), b->n_results * sizeof(anx_result)));
+      HIP_TRY(hipMemsetAsync(d_cnt, 0, n * sizeof(uint32_t), st));
+      hipLaunchKernelGGL(k_fetch_counts, dim3((nq32 + 255) / 256), dim3(256), 0, st, nq32, b->r_count, b->q_orig, d_cnt);
+      exclusive_scan(d_cnt, n32, d_off, d_tmp, st);
+      hipLaunchKernelGGL(k_fetch_rows, dim3((nq32 + 255) / 256), dim3(256), 0, st, nq32, b->soff, b->r_count, b->r_rows, b->q_orig, d_off, d_out);
+      std::vector<uint32_t> h_off(n + 1);
+      HIP_TRY(hipMemcpyAsync(h_off.data(), d_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(out, d_out, b->n_results * sizeof(anx_result), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      for (size_t i = 0; i <= n; ++i) off[i] = h_off[i];
+      return ANX_OK;
+    };
+    rc = body();
+    if (rc) (void)hipStreamSynchronize(st);  // nothing of this call may still be in flight when its blocks return to the pool
     for (void* p : {(void*)d_cnt, (void*)d_off, (void*)d_tmp, (void*)d_out}) pool_free(p);
   }
+  if (rc) { free(off); free(out); return rc; }
   *rows = out;
   *offs = off;
   return ANX_OK;
@@ -997,7 +1020,13 @@ int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32
   (void)dl;
   if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
   if (!dst || stride == 0) { err = "bad export arguments"; return ANX_EINVAL; }
+  if (stride < b->max_rows) {  // rows beyond the stride would be dropped silently (freq_weight != 0, variant lists or max_matches = 0
+                               // can return more than max_matches + 1 rows): refuse
+    err = "export stride " + std::to_string(stride) + " is smaller than the longest result list (" + std::to_string(b->max_rows) + " rows): use a larger stride or anx_batch_export_compact";
+    return ANX_ELIMIT;
+  }
   HIP_TRY(hipSetDevice(b->device));
+  b->async_stream = stream; b->async_pending = true;
   const uint64_t total = (uint64_t)b->nq * stride;
   if (total)
     hipLaunchKernelGGL(k_export_topk, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0,
@@ -1021,6 +1050,7 @@ int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, siz
   if (capacity < *used) { err = "export buffer too small: " + std::to_string(*used) + " bytes needed"; return ANX_ELIMIT; }
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  b->async_stream = stream; b->async_pending = true;
   uint32_t* d_off = static_cast<uint32_t*>(dst);
   anx_topk_record* d_rows = reinterpret_cast<anx_topk_record*>(static_cast<char*>(dst) + off_bytes);
   if (n == 0 || b->nq == 0) { HIP_TRY(hipMemsetAsync(d_off, 0, off_bytes, st)); return ANX_OK; }
@@ -1043,6 +1073,9 @@ void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 void batch_free(Batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
+  // the export kernels are asynchronous on the caller's stream and read this batch's buffers: they must have finished
+  // before the blocks go back to the pool, where another batch / thread / stream may take them at once
+  if (b->async_pending) (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(b->async_stream));
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,

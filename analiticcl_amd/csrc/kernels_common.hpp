@@ -58,7 +58,7 @@ struct DeviceLexicon {
   size_t bytes = 0;
 };
 
-enum { CTR_SKIPPED = 2, CTR_N = 8 };
+enum { CTR_SKIPPED = 2, CTR_MAXROWS = 3 /* longest ranked list of the run */, CTR_N = 8 };
 
 struct SurvRow {  // one candidate result row of a query (k_compact -> k_rank); 32 B, written / read as two 16-B words
   double score;            // dist_score (times the variant score for expanded rows)
@@ -132,6 +132,10 @@ struct Batch {
   uint64_t n_sel = 0;
   uint64_t n_pairs = 0, n_surv = 0, n_results = 0;
   mutable uint32_t *x_cnt = nullptr, *x_tmp = nullptr;  // export_compact temporaries (input-order counts, scan sums)
+  uint32_t max_rows = 0;           // longest ranked list of the last run (a fixed-stride export needs stride >= max_rows)
+  void* last_stream = nullptr;     // stream of the last run (batch_fetch continues on it)
+  mutable void* async_stream = nullptr;   // stream the last asynchronous export was launched on
+  mutable bool async_pending = false;     // ... and batch_free has to wait for
   bool ran = false;
   bool keep_all_pairs = false;     // also materialise the pairs whose lengths differ by more than d (debug fetch of every pair)
   bool ran_keep_all = false;       // what the last run did

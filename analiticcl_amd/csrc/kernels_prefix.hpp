@@ -29,7 +29,7 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
 }
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t* __restrict__ in, uint32_t n,
                                                              uint32_t* __restrict__ out,
-                                                             uint32_t* __restrict__ blocksum) {
+                                                             uint32_t* __restrict__ blocksum, uint32_t* __restrict__ maxout) {
   const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
@@ -45,6 +45,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t* __r
     ex += v[i];
   }
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+  if (maxout) {  // also the largest input value (one atomic per wave): the row capacity a fixed-stride export needs
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) mx = max(mx, v[i]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxout, mx);
+  }
 }
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(uint32_t* __restrict__ blocksum, uint32_t nb) {
   uint32_t carry = 0;

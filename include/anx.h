@@ -199,7 +199,13 @@ typedef struct anx_batch_stats {
   float ms_filter_score_kernel; /* HIP events directly around the k_filter_score launch */
 } anx_batch_stats;
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
+/* Waits for asynchronous exports of the batch (anx_batch_export_topk / _compact on the caller's stream), then releases it. */
 void anx_batch_free(anx_batch *);
+/* Device scratch (pair lists, survivor rows: several GB per million queries) comes from a per-device pool that keeps freed
+ * blocks for the next batch (up to 32 GB, ANX_POOL_CACHE_MB overrides; the reference has no counterpart: its scratch is
+ * Vec storage inside find_variants, src/lib.rs:1311-1402).  This hands the cached blocks back to the driver, e.g. before
+ * another library needs the memory. */
+void anx_device_pool_trim(int device);
 
 /* ---- output of `analiticcl query` --------------------------------------------------
  * The TSV lines / JSON items of output_matches_as_tsv / output_matches_as_json (src/bin/analiticcl.rs:21-187) for n
