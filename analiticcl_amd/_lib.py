@@ -152,6 +152,8 @@ def lib():
         "anx_batch_fetch": (C.c_int, [vp, C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
         "anx_batch_fetch_pairs": (C.c_int, [vp, C.POINTER(C.POINTER(Pair)), C.POINTER(sz)]),
         "anx_pairs_free": (None, [C.POINTER(Pair)]),
+        "anx_batch_pair_counts": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint32))]),
+        "anx_counts_free": (None, [C.POINTER(C.c_uint32)]),
         "anx_batch_export_topk": (C.c_int, [vp, vp, C.c_uint32, vp]),
         "anx_batch_export_compact": (C.c_int, [vp, vp, sz, vp, C.POINTER(sz)]),
         "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats)]),

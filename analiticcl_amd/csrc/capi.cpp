@@ -539,6 +539,13 @@ int anx_batch_fetch_pairs(const anx_batch* b, anx_pair** out, size_t* n) {
   return rc ? fail(rc, err) : ANX_OK;
 }
 void anx_pairs_free(anx_pair* p) { free(p); }
+int anx_batch_pair_counts(anx_batch* b, uint32_t** out) {
+  if (!b || !out) return fail(ANX_EINVAL, "NULL argument");
+  std::string err;
+  int rc = anx::batch_pair_counts(b->model->host, b->model->dev, b->b, out, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
+void anx_counts_free(uint32_t* p) { free(p); }
 int anx_batch_export_topk(const anx_batch* b, void* dst, uint32_t stride, void* stream) {
   if (!b) return fail(ANX_EINVAL, "NULL batch");
   if (b->rescore) return fail(ANX_EINVAL, "confusables are loaded: results are rescored on the host, use anx_batch_fetch");

@@ -23,6 +23,7 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
                 std::string& err);
 int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_pair** out, size_t* n,
                       std::string& err);
+int batch_pair_counts(const HostModel& m, const DeviceLexicon* dl, Batch* b, uint32_t** out, std::string& err);
 int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32_t stride, void* stream,
                       std::string& err);
 int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, size_t capacity, void* stream,

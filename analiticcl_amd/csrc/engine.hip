@@ -205,13 +205,17 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
     memcpy(&erec[2 * e], &img.rows[(size_t)img.ent_rowoff[e] * 16], 16);
     erec[2 * e + 1] = make_uint4(img.ent_meta[e], img.ent_rowoff[e], img.ent_freq[e], 0u);
   }
-  std::vector<uint4> crec(2 * (size_t)img.cstride);
-  for (uint32_t c = 0; c < img.cstride; ++c) {
-    crec[2 * (size_t)c] = make_uint4(img.cls_bits[c], img.cls_bits[(size_t)img.cstride + c], img.cls_bits[2 * (size_t)img.cstride + c],
-                                     img.cls_bits[3 * (size_t)img.cstride + c]);
-    const bool real = c < img.nclasses;
-    crec[2 * (size_t)c + 1] = make_uint4(img.cls_len[c], real ? img.cls_off[c] : 0u, real ? img.cls_off[c + 1] - img.cls_off[c] : 0u, 0u);
-  }
+  // scan records of the bit-plane kernel: one per ENTRY (class-major, the order of the entry ids) carrying the planes of its
+  // class, so that a scan hit is a (query, entry) pair -- classes with several entries (8 % of eng.aspell) are tested once per
+  // entry, and the hit expansion has no entries-per-class loop (it ran as long as the largest class among 64 hits)
+  std::vector<uint4> srec(2 * ((size_t)img.nentries + 1), make_uint4(0u, 0u, 0u, 0u));
+  for (uint32_t c = 0; c < img.nclasses; ++c)
+    for (uint32_t e = img.cls_off[c]; e < img.cls_off[c + 1]; ++e) {
+      srec[2 * (size_t)e] = make_uint4(img.cls_bits[c], img.cls_bits[(size_t)img.cstride + c], img.cls_bits[2 * (size_t)img.cstride + c],
+                                       img.cls_bits[3 * (size_t)img.cstride + c]);
+      srec[2 * (size_t)e + 1] = make_uint4(img.cls_len[c], c, 0u, 0u);
+    }
+  srec[2 * (size_t)img.nentries + 1] = make_uint4(255u, 0xFFFFFFFFu, 0u, 0u);  // the padding record
   std::vector<uint4> sig2(img.sig_lo.size());  // {signature, first class of the run, classes in the run}
   for (size_t i = 0; i < sig2.size(); ++i)
     sig2[i] = make_uint4(img.sig_lo[i], img.sig_hi[i], img.sig_cbeg[i], i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] - img.sig_cbeg[i] : 0u);
@@ -238,11 +242,17 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
   for (size_t bk = sig2.size() / 64; 2 * bk + 1 < sblk.size(); ++bk) sblk[2 * bk + 1] = make_uint4(0u, 0u, 0u, 0u);
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
+  std::vector<uint4> sig2e(sig2.size());  // {signature, first entry of the run, entries in the run}
+  for (size_t i = 0; i < sig2.size(); ++i) {
+    const uint32_t c0 = std::min(img.sig_cbeg[i], img.nclasses), c1 = std::min(i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] : img.nclasses, img.nclasses);
+    sig2e[i] = make_uint4(img.sig_lo[i], img.sig_hi[i], off[c0], off[c1] - off[c0]);
+  }
   if ((rc = upload(&d->cls_planes, img.cls_planes.data(), img.cls_planes.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_bits, img.cls_bits.data(), img.cls_bits.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_len, img.cls_len.data(), img.cls_len.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
-      (rc = upload(&d->cls_rec, crec.data(), crec.size(), err, &d->bytes)) ||
+      (rc = upload(&d->scan_rec, srec.data(), srec.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sig_e, sig2e.data(), sig2e.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig, sig2.data(), sig2.size(), err, &d->bytes)) ||
       (rc = upload(&d->sigblk, sblk.data(), sblk.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_cbeg, img.sig_cbeg.data(), img.sig_cbeg.size(), err, &d->bytes)) ||
@@ -267,7 +277,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->cls_rec, (void*)d->sig, (void*)d->sigblk, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sig, (void*)d->sigblk, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
     if (p) pool_free(p);
@@ -683,11 +693,18 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     if (!b->tiles.empty()) {
       ScanArgs A;
       A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
-      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.cls_rec = dl->cls_rec; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
-      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
+      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
+      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
       { const char* e = getenv("ANX_SCAN_WALK"); A.hier = (e && strcmp(e, "flat") == 0) ? 0 : 1; }
+      { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; A.chunk = v >= 32 && v <= 1024 ? (uint32_t)v : SCAN_CHUNK; }
       A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
       A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
+      A.qpairs = nullptr;
+      if (b->count_pairs) {
+        if (!b->qpairs && (rc = dalloc(&b->qpairs, nq, err))) return rc;
+        HIP_TRY(hipMemsetAsync(b->qpairs, 0, nq * sizeof(uint32_t), st));
+        A.qpairs = b->qpairs;
+      }
       { const char* e = getenv("ANX_SCAN_DBG"); A.dbg = e ? atoi(e) : 0; }  // read per run: tools/scan_probe.py switches it between runs
       const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
       switch (dl->nplanes) {
@@ -1068,6 +1085,29 @@ int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, siz
   return ANX_OK;
 }
 
+// Scored pairs per input query, counted by the scan of a PRODUCTION run (pairs that fail the DL's length test are only
+// counted there, never materialised): the batch is run once more with the per-query counters switched on.
+int batch_pair_counts(const HostModel& m, const DeviceLexicon* dl, Batch* b, uint32_t** out, std::string& err) {
+  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  HIP_TRY(hipSetDevice(b->device));
+  const bool keep = b->keep_all_pairs;
+  b->keep_all_pairs = false;
+  b->count_pairs = true;
+  const int rc = batch_run(m, dl, b, b->last_stream, err);
+  b->count_pairs = false;
+  b->keep_all_pairs = keep;
+  if (rc) return rc;
+  uint32_t* res = static_cast<uint32_t*>(calloc(std::max<size_t>(1, b->n_input), sizeof(uint32_t)));
+  if (!res) { err = "out of memory"; return ANX_EINVAL; }
+  if (b->nq) {
+    std::vector<uint32_t> h(b->nq);
+    if (hipMemcpy(h.data(), b->qpairs, b->nq * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { free(res); err = "hipMemcpy failed"; return ANX_ENODEVICE; }
+    for (size_t s = 0; s < b->nq; ++s) res[b->order[s]] = h[s];
+  }
+  *out = res;
+  return ANX_OK;
+}
+
 void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 
 void batch_free(Batch* b) {
@@ -1078,7 +1118,7 @@ void batch_free(Batch* b) {
   if (b->async_pending) (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(b->async_stream));
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
-                  (void*)b->qmaxfreq, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
+                  (void*)b->qmaxfreq, (void*)b->qpairs, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) pool_free(p);
   for (auto& e : b->ev)

@@ -38,7 +38,8 @@ struct DeviceLexicon {
   uint32_t* cls_bits = nullptr;    // [NBITPLANES][cstride] thermometer planes (bit s of plane t: count_s > t), nsym <= 32
   uint8_t* cls_len = nullptr;      // [cstride]
   uint32_t* cls_off = nullptr;
-  uint4* cls_rec = nullptr;        // [cstride][2] {4 planes} {len, first entry, entries, 0}: ScanArgs::cls_rec
+  uint4* scan_rec = nullptr;       // [E + 1][2] per entry {4 planes of its class} {len, class, 0, 0}: ScanArgs::scan_rec
+  uint4* sig_e = nullptr;          // [nsig_pad] signature table with entry runs (ScanArgs::sig_e)
   uint4* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage): {groups 0-3, groups 4-7, first class of the run, classes}
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint4* sigblk = nullptr;         // [nsig_pad / 64][2] bounding box of every 64-signature block (ScanArgs::sigblk)
@@ -107,6 +108,8 @@ struct Batch {
   uint32_t* soff = nullptr;        // nq+1, exclusive scan of qsurv
   uint32_t* qcur = nullptr;
   uint32_t* qmaxfreq = nullptr;
+  uint32_t* qpairs = nullptr;      // per query: scored pairs of the last run (only when count_pairs is set)
+  bool count_pairs = false;
   uint32_t* scan_tmp = nullptr;
   uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
   double* p_score = nullptr;       // per pair-list slot: score of the pairs that went through a DL kernel

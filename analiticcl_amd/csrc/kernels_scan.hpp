@@ -31,6 +31,7 @@ struct WaveOut {
   uint32_t split;       // run indices < split go to [base..), the rest to [nbase..)
   uint32_t rbase, rend; // this wave's region of the pair list: slots [rbase, rend)
   uint32_t* ctr;        // the region's counter block
+  uint32_t chunk;       // slots reserved per global atomic
 };
 // Wave-wide exclusive prefix sum of ntot + chunk reservation.  Returns this lane's first index g in the
 // wave's appended run; wave_slot(g) maps run indices to pair-list slots.  A run that does not fit in the
@@ -55,7 +56,7 @@ __device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane
   w.split = w.left;
   if (total > w.left) {
     const uint32_t rest = total - w.left;
-    const uint32_t need = rest > SCAN_CHUNK ? rest : SCAN_CHUNK;
+    const uint32_t need = rest > w.chunk ? rest : w.chunk;
     uint32_t b = 0;
     if (lane == 0) b = atomicAdd(&w.ctr[RC_RAW], need);
     w.nbase = w.rbase + __shfl(b, 0);
@@ -68,7 +69,7 @@ __device__ inline uint32_t wave_slot(const WaveOut& w, uint32_t g) {
 __device__ inline void wave_commit(WaveOut& w, uint32_t total) {
   if (total > w.left) {
     const uint32_t rest = total - w.left;
-    const uint32_t need = rest > SCAN_CHUNK ? rest : SCAN_CHUNK;
+    const uint32_t need = rest > w.chunk ? rest : w.chunk;
     w.base = w.nbase + rest;
     w.left = need - rest;
   } else {
@@ -90,22 +91,27 @@ struct ScanArgs {
   const uint32_t* q_cv;
   const uint32_t* cls_bits;
   const uint32_t* cls_planes;
-  const uint4* cls_rec;     // [cstride][2] {4 thermometer planes} {len, first entry, entries, 0} (bit-plane kernel)
+  const uint4* scan_rec;    // [E + 1][2] per ENTRY {4 thermometer planes of its class} {len, class, 0, 0} (bit-plane kernel)
+  uint32_t pad_rec;         // = E: a never-matching padding record (planes 0, len 255)
   uint32_t cstride;
-  uint32_t pad_class;   // a never-matching padding class (bits 0, counts 0xFF, len 255)
+  uint32_t pad_class;   // a never-matching padding class (counts 0xFF, len 255; count-vector kernel)
   const uint8_t* cls_len;
   const uint32_t* cls_off;
   const uint4* sig;         // signature table: {groups 0-3, groups 4-7 packed as bytes, first class of the run, classes}
+  const uint4* sig_e;       // the same with the run as scan records: {.., .., first entry of the run, entries} (bit-plane kernel)
   const uint32_t* sig_cbeg;
   const uint4* sigblk;      // [blocks][2] per 64-signature block: {group minima lo, hi, group maxima lo, hi} {sum(max) - sum(min), -, -, -}
   int hier;                 // two-level signature walk (ANX_SCAN_WALK=flat: every block of the window)
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
+  uint32_t chunk;       // pair-list slots a wave reserves per global atomic (SCAN_CHUNK; ANX_SCAN_CHUNK)
   uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
   const uint32_t* qexact;  // per query: class id of its exact anagram class (0xFFFFFFFF = none); stop mode only
   int want_exact;
   int drop_len;             // do not materialise pairs with |len_q - len_c| > d: damerau_levenshtein returns None for them at its
                             // first test (src/distance.rs:109-130); they are only counted as scored pairs
+  uint32_t* qpairs;         // per query: scored pairs of THIS run, counted where they are produced (materialised or only counted);
+                            // nullptr in normal runs (anx_batch_pair_counts: the per-query check of the production pair list)
   int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
 };
 
@@ -135,7 +141,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   uint2* __restrict__ raw = A.raw;
   const uint32_t cstride = A.cstride;
   const uint32_t region = item % SCAN_REGIONS;
-  WaveOut wo{0, 0, 0, 0, 0, region * A.region_cap, (region + 1) * A.region_cap, A.rctr + region * RC_STRIDE};
+  WaveOut wo{0, 0, 0, 0, 0, region * A.region_cap, (region + 1) * A.region_cap, A.rctr + region * RC_STRIDE, A.chunk};
   uint32_t ns = 0;  // staged class ids (wave-uniform)
   uint32_t nchunks = 0;
   {  // the tile's query words -> LDS: the comparison loop reads them back as broadcasts into VGPRs
@@ -149,25 +155,34 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   auto flush = [&]() {
     for (uint32_t r0 = 0; r0 < nhits; r0 += 64) {
       const uint32_t idx = r0 + lane;
-      uint32_t c = 0, m = 0, e0 = 0, ne = 0, qb = 0;
+      uint32_t c = 0, m = 0, e0 = 0, ne = 0, qb = 0;   // c: class id (stop mode / SAD path); pairs = queries of m x entries [e0, e0 + ne)
       if (idx < nhits) {
         c = hits[2 * idx];
         m = hits[2 * idx + 1];
-        qb = (c >> 27) << 5;
-        c &= (1u << 27) - 1u;
-        uint32_t lc;
+        qb = ((c >> 27) & 1u) << 5;
+        bool count_only;
         if (BITS) {
-          const uint4 mt = A.cls_rec[2 * (size_t)c + 1];
-          lc = mt.x;
-          e0 = mt.y;
-          ne = mt.z;
+          // one scan record per lexicon ENTRY (the planes of its class): a hit is a (query, entry) pair already, there is no
+          // entries-per-class loop and no class gather here; bit 28 = "fails the DL's length test" was set by the test lane
+          count_only = (c >> 28) & 1u;
+          e0 = c & ((1u << 27) - 1u);
+          ne = 1;
+          c = (A.want_exact || A.qpairs) ? A.scan_rec[2 * (size_t)e0 + 1].y : 0u;  // class of the entry (rare modes only)
         } else {
-          lc = cls_len[c];
+          c &= (1u << 27) - 1u;
+          const uint32_t lc = cls_len[c];
           e0 = cls_off[c];
           ne = cls_off[c + 1] - e0;
+          const uint32_t diff = lc > t.lq ? lc - t.lq : t.lq - lc;
+          count_only = A.drop_len && diff > t.d;
         }
-        const uint32_t diff = lc > t.lq ? lc - t.lq : t.lq - lc;
-        if (A.drop_len && diff > t.d) {  // every pair of this class fails the length test of the DL: count, do not emit
+        if (A.qpairs) {  // per-query pair counts of this very run (StopAtExactMatch: only the exact class counts when there is one)
+          for (uint32_t mm = m; mm; mm &= mm - 1u) {
+            const uint32_t q = t.q0 + qb + (uint32_t)__ffs((int)mm) - 1u;
+            if (!A.want_exact || A.qexact[q] == 0xFFFFFFFFu || A.qexact[q] == c) atomicAdd(&A.qpairs[q], ne);
+          }
+        }
+        if (count_only) {  // every pair of this class fails the length test of the DL: count, do not emit
           counted_only += (uint32_t)__popc(m) * ne;
           m = 0;
         }
@@ -214,14 +229,16 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const uint32_t idx = (uint32_t)j * 64u + lane;
-      cid[j] = idx < ns ? stage[idx] : A.pad_class;
+      cid[j] = idx < ns ? stage[idx] : (BITS ? A.pad_rec : A.pad_class);
       int32_t lc;
-      if (BITS) {  // one 32-B class record {4 planes} {len, first entry, entries, -} instead of T + 3 gathers
-        const uint4 pl = A.cls_rec[2 * (size_t)cid[j]], mt = A.cls_rec[2 * (size_t)cid[j] + 1];
+      if (BITS) {  // one 32-B scan record per entry {4 planes of its class} {len, class, -, -} instead of T + 3 gathers
+        const uint4 pl = A.scan_rec[2 * (size_t)cid[j]], mt = A.scan_rec[2 * (size_t)cid[j] + 1];
         const uint32_t plw[4] = {pl.x, pl.y, pl.z, pl.w};
 #pragma unroll
         for (int p = 0; p < W; ++p) cw[j][p] = plw[p];
         lc = (int32_t)mt.x;
+        const int32_t diff = lc > (int32_t)t.lq ? lc - (int32_t)t.lq : (int32_t)t.lq - lc;
+        if (A.drop_len && diff > (int32_t)t.d) cid[j] |= 1u << 28;  // its pairs fail the DL's length test: counted, not emitted
       } else {
 #pragma unroll
         for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
@@ -304,7 +321,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         if (cnt) {  // wave-uniform
           if (nz) {
             const uint32_t pos = nhits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-            hits[2 * pos] = cid[j] | ((qb >> 5) << 27);
+            hits[2 * pos] = cid[j] | ((qb >> 5) << 27);  // entry (bit-plane path) or class id, pass, count-only flag
             hits[2 * pos + 1] = __brev(hm[j]) >> (32u - npass);  // shift-in order -> bit b = query b of the pass
           }
           nhits += cnt;
@@ -345,6 +362,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       }
     }
   };
+  const uint4* __restrict__ sigtab = BITS ? A.sig_e : A.sig;  // runs of scan records (entries) / of classes
   if (A.hier) {
     // Two-level walk: one 32-byte summary per block = bounding box (per-group minimum and maximum) of its 64 signatures.
     // distance(signature, box) = sum_g max(0, min_g - q_g) + max(0, q_g - max_g) is a lower bound of the L1 distance to every
@@ -362,16 +380,16 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       }
       unsigned long long mb = __ballot(okb);
       if (!mb) continue;
-      uint4 sg_next = A.sig[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
+      uint4 sg_next = sigtab[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
       while (mb) {
         mb &= mb - 1;
         const uint4 sg = sg_next;  // the next candidate block is loaded while this one is tested and staged
-        if (mb) sg_next = A.sig[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
+        if (mb) sg_next = sigtab[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
         test_block(sg);
       }
     }
   } else {
-    const uint4* __restrict__ sigp = A.sig + t.s0 + lane;
+    const uint4* __restrict__ sigp = sigtab + t.s0 + lane;
     uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
     for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
       const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load

@@ -90,10 +90,32 @@ class SearchParameters:
     def to_dict(self) -> dict:
         return {k: getattr(self, k) for k in self._defaults}
 
+    # getters of the pyo3 class (bindings/python/src/lib.rs:261-345, analiticcl.pyi:75-137)
+    @staticmethod
+    def _threshold_value(v):
+        """Absolute -> int, Ratio -> float, RatioWithLimit -> {"ratio", "limit"} (bindings/python/src/lib.rs:261-292)."""
+        if isinstance(v, (tuple, list)):
+            return {"ratio": float(v[0]), "limit": int(v[1])}
+        return v
 
-for _k in SearchParameters._defaults:
-    setattr(SearchParameters, "get_" + _k, (lambda k: lambda self: getattr(self, k))(_k))
-SearchParameters.get_edit_distance = lambda self: self.max_edit_distance  # name used by analiticcl.pyi
+    def get_max_anagram_distance(self): return self._threshold_value(self.max_anagram_distance)
+    def get_max_edit_distance(self): return self._threshold_value(self.max_edit_distance)
+    def get_edit_distance(self): return self.get_max_edit_distance()  # the name analiticcl.pyi:81 documents
+    def get_max_matches(self) -> int: return int(self.max_matches)
+    def get_score_threshold(self) -> float: return float(self.score_threshold)
+    def get_cutoff_threshold(self) -> float: return float(self.cutoff_threshold)
+    def get_stop_criterion(self) -> bool: return bool(self.stop_criterion)
+    def get_max_ngram(self) -> int: return int(self.max_ngram)
+    def get_lm_order(self) -> int: return int(self.lm_order)
+    def get_max_seq(self) -> int: return int(self.max_seq)
+    def get_single_thread(self) -> bool: return bool(self.single_thread)
+    def get_context_weight(self) -> float: return float(self.context_weight)
+    def get_variantmodel_weight(self) -> float: return float(self.variantmodel_weight)
+    def get_lm_weight(self) -> float: return float(self.lm_weight)
+    def get_contextrules_weight(self) -> float: return float(self.contextrules_weight)
+    def get_freq_weight(self) -> float: return float(self.freq_weight)
+    def get_consolidate_matches(self) -> bool: return bool(self.consolidate_matches)
+    def get_unicodeoffsets(self) -> bool: return bool(self.unicodeoffsets)
 
 
 class VocabParams:
@@ -228,6 +250,16 @@ class Batch:
                      pairs[i].suffixlen, pairs[i].samecase, pairs[i].score) for i in range(n.value)]
         finally:
             L.lib().anx_pairs_free(pairs)
+
+    def pair_counts(self):
+        """Scored pairs per input, counted by the scan of a production run (anx_batch_pair_counts) -> numpy uint32[n]."""
+        import numpy as np
+        out = C.POINTER(C.c_uint32)()
+        L.check(L.lib().anx_batch_pair_counts(self.h, C.byref(out)))
+        try:
+            return np.ctypeslib.as_array(out, shape=(max(self.n, 1),))[:self.n].copy()
+        finally:
+            L.lib().anx_counts_free(out)
 
     def export_topk(self, device_ptr: int, stride: int, stream: int = 0):
         L.check(L.lib().anx_batch_export_topk(self.h, C.c_void_p(device_ptr), stride, C.c_void_p(stream)))
@@ -558,6 +590,14 @@ class VariantModel:
         return s.decode("utf-8")
 
     # -- confusables: host-side rescoring of the ranked lists ---------------
+    def read_lm(self, filename: str):
+        """Language-model n-gram counts: read_vocabulary with VocabType::LM (bindings/python/src/lib.rs:659-667)."""
+        self.read_vocabulary(filename, VocabParams(vocabtype="LM"))
+
+    def read_confusiblelist(self, filename: str):
+        """The spelling the reference's Python API uses (analiticcl.pyi:283, bindings/python/src/lib.rs read_confusiblelist)."""
+        self.read_confusablelist(filename)
+
     def read_confusablelist(self, filename: str):
         L.check(L.lib().anx_model_read_confusablelist(self.h, _b(filename)))
 

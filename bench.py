@@ -70,12 +70,23 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the export + gather code at N=1 too (testing)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as a fresh child (nothing here has touched the
+        # GPU yet -- a process that has initialised HIP must not be replaced) and relay its output and exit code
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or run `python bench.py --gpus {args.gpus}` alone")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the variant-query path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -121,8 +132,10 @@ def main():
                 gather.submit(i, used)
                 gather_bytes[0] = used
                 step_no[0] += 1
-            except Exception as e:  # noqa: BLE001 -- keep the compute measurement; the JSON line says what happened
-                gather_error[0] = repr(e)[:200]
+            except Exception as e:  # noqa: BLE001
+                if world > 1:  # the other ranks keep posting collectives: a rank that stops would leave them mismatched
+                    raise
+                gather_error[0] = repr(e)[:200]  # N=1 (--force-gather): keep the compute measurement, the JSON line says what happened
                 sys.stderr.write(f"[bench] rank {rank}: result gather disabled: {gather_error[0]}\n")
 
     def drain():
@@ -130,6 +143,8 @@ def main():
             try:
                 gather.flush()
             except Exception as e:  # noqa: BLE001
+                if world > 1:
+                    raise
                 gather_error[0] = repr(e)[:200]
                 sys.stderr.write(f"[bench] rank {rank}: result gather failed in flush: {gather_error[0]}\n")
 
@@ -170,57 +185,105 @@ def main():
         for k in stage_ms:
             stage_ms[k] /= max(args.steps, 1)
         # ---- roofline of the dominant kernel (per launch, rank 0) --------------------------------------
-        # Two kernels take ~40 % each (profiles/r01_final_kernel_trace.md); the slower one of THIS run is reported (ties below).
+        # The dominant kernel = the slowest kernel of THIS run (k_scan_bits or k_filter_score, HIP events around each launch on
+        # the launch stream: anx_batch_stats.ms_scan_kernel / ms_filter_score_kernel); "per_kernel" carries both.
         # Algorithmic bytes per launch:
-        #  k_scan_bits: query planes 16 B/query + tile descriptors 36 B/tile + class record, signature 44 B/class
-        #               (each once per launch) + pair list out 8 B/pair;
-        #  k_filter_score: SURVEY.md section 8(d)'s per-pair figure Lpad + 32 B (pair record 8 + entry row Lpad + entry meta 8
-        #               + result 16) x scored pairs.
-        # SURVEY.md section 8(d)'s whole-path figure, pairs*(Lpad+32) + queries*208, is reported next to it as "pipeline".
+        #  k_scan_bits: query planes 16 B/query + tile descriptors 44 B/tile + class record, signature 44 B/class
+        #               (each once per launch) + pair list out 8 B/slot;
+        #  k_filter_score: what the kernel has to touch per materialised pair-list slot: pair record 8 B + query / entry
+        #               symbols and lengths 16 + 8 B, plus 16 B of survivor record per pair that passes the score threshold.
+        #               SURVEY.md section 8(d)'s literal figure (Lpad + 32 B for EVERY scored pair, i.e. 16 B of result per pair
+        #               although only survivors are written) is reported next to it as "survey_model".
+        # SURVEY.md section 8(d)'s whole-path figure, pairs*(Lpad+32) + queries*208, is reported as "pipeline".
         lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
         n_classes = model.num_classes()
-        scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 36 + n_classes * 44 + st["n_pairs"] * 8
-        # pairs that fail the DL's length test are counted by the scan but never materialised: only the slots the kernel reads
-        fs_bytes = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
+        scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 44 + n_classes * 44 + st["n_pair_slots"] * 8
+        fs_bytes = st["n_pair_slots"] * (8 + lpad + 8) + st["n_survivors"] * 16
+        fs_bytes_survey = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
         scan_ms, fs_ms = sum_scan_kernel_ms / max(args.steps, 1), sum_fs_kernel_ms / max(args.steps, 1)
-        # the two take the same time within the variation between runs and boxes (k_scan_bits 1.49-1.62 ms, k_filter_score
-        # 1.44-1.46 ms on five boxes): within 5 % the entry goes to the kernel that moves more algorithmic bytes, so the
-        # headline does not flip between runs; "per_kernel" always carries both
-        if fs_ms > scan_ms or (scan_ms > 0 and (scan_ms - fs_ms) / scan_ms < 0.05 and fs_bytes >= scan_bytes):
+        if fs_ms > scan_ms:
             kname, kbytes, kms = "k_filter_score", fs_bytes, fs_ms
         else:
             kname, kbytes, kms = "k_scan_bits", scan_bytes, scan_ms
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         pipeline_bytes = st["n_pairs"] * (lpad + 32) + st["n_queries"] * 208
         pipeline_gbs = pipeline_bytes / (stage_ms["ms_total"] * 1e-3) / 1e9 if stage_ms["ms_total"] > 0 else 0.0
-        # the bound that actually binds the scan: VALU issue.  Per 256 class tests of T planes the inner loop issues
-        # T*4 v_and_b32 (2.2 cycles, tools/ubench_valu.hip) + T*4 v_bcnt_u32_b32 (4.3) + 4 v_alignbit_b32 (4.3) + 1 ds_read.
+        # The bound that actually binds both kernels is VALU issue (89 % / 77 % VALU-active, profiles/): the floor below counts
+        # only the instructions the algorithm cannot do without, at the measured issue cost per wave-instruction per SIMD
+        # (tools/ubench_valu.hip: 2-operand ops 2.2 cycles, VOP3 ops such as v_bcnt / v_alignbit / v_sad_u8 4.3), over the
+        # 1024 SIMDs at 2.4 GHz.
+        #  scan: per 256 class tests of T planes T*4 v_and_b32 + T*4 v_bcnt_u32_b32 + 4 v_alignbit_b32.
+        SIMD_HZ = 1024 * 2.4e9
         kinds = st["n_tests_kind"]
         issue_cycles = (kinds[0] * (8 * 4.3 + 4.3) * 4 + sum(kinds[t] * (t * 4 * 6.5 + 4 * 4.3) for t in range(1, 5))) / 256.0
-        valu_floor_ms = issue_cycles / (1024 * 2.4e9) * 1e3
-        traffic = None  # HBM bytes per launch of that kernel from the committed PMC passes (same workload only)
+        valu_floor_ms = issue_cycles / SIMD_HZ * 1e3
+        #  filter_score, per wave of 64 (DESIGN.md section 5 K2+K3): SWAR band filter of every slot: (2d+1) shifts x NW words x
+        #  (alignbyte, xor, and, add, or3, and | alignbyte, and) = 24 cycles, the unshifted one 15.4, + 8 (and, bcnt) popcounts;
+        #  band DL of every selected pair: rows x (2d+1) cells x (2 min, 2 add, cmp, cndmask = 16 cycles), rows ~ mean query length;
+        #  tail of every DL survivor (LCS diagonal walk, prefix, suffix, f64 score) ~ 300 instructions = 900 cycles.
+        dd = args.edit_distance
+        nw = 4 if args.max_len <= 16 else 8
+        mean_len = sum(len(q) for q in queries[:20000]) / min(len(queries), 20000)
+        fs_cycles = (st["n_pair_slots"] / 64.0) * ((15.4 + 2 * dd * 24.0) * nw + 8 * 6.5) \
+            + (st["n_selected"] / 64.0) * (mean_len * (2 * dd + 1) * 16.0) + (st["n_survivors"] / 64.0) * 900.0
+        fs_valu_floor_ms = fs_cycles / SIMD_HZ * 1e3
+        # HBM bytes per launch of that kernel from the committed PMC passes: only for the same workload AND the same kernel
+        # sources (the profile is tagged with a hash of csrc/*.hip, *.hpp; stale numbers are dropped)
+        traffic, traffic_src = None, None
         try:
             if (args.lexicon, args.max_len, args.anagram_distance, args.edit_distance, args.queries) == ("eng", 16, 3, 2, 1_000_000):
-                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
-                    traffic = json.load(f)["kernels"][kname]["traffic_bytes"]
+                import glob
+                import hashlib
+                h = hashlib.sha256()
+                for f in sorted(glob.glob(os.path.join(REPO, "analiticcl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "analiticcl_amd", "csrc", "*.hpp"))):
+                    with open(f, "rb") as fh:
+                        h.update(fh.read())
+                for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                    with open(cand) as f:
+                        pj = json.load(f)
+                    if pj.get("kernel_src_sha256") == h.hexdigest():
+                        traffic, traffic_src = pj["kernels"][kname]["traffic_bytes"], os.path.basename(cand)
+                        break
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": kms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": kms,
                     "algorithmic_bytes_per_launch": kbytes,
-                    "note": "integer scan / DL path: VALU-issue and L2-gather bound, below the HBM roof (DESIGN.md section 5)",
+                    "note": "integer scan / DL path: both kernels are VALU-issue bound, far below the HBM roof (DESIGN.md section 5); "
+                            "valu_issue_frac = algorithmic instruction floor / measured kernel time",
                     "kernels_ms": {"k_scan_bits": scan_ms, "k_filter_score": fs_ms},
-                    # both candidates for "dominant" (they take ~1.6 ms each; which one is slower varies by run)
                     "per_kernel": {name: {"avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
                                           "achieved": (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
-                                          "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0)}
-                                   for name, nbytes, ms in (("k_scan_bits", scan_bytes, scan_ms), ("k_filter_score", fs_bytes, fs_ms))},
+                                          "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0),
+                                          "valu_issue_floor_ms": fl, "valu_issue_frac": (fl / ms if ms > 0 else 0.0)}
+                                   for name, nbytes, ms, fl in (("k_scan_bits", scan_bytes, scan_ms, valu_floor_ms),
+                                                                ("k_filter_score", fs_bytes, fs_ms, fs_valu_floor_ms))},
+                    "k_filter_score_survey_model": {"algorithmic_bytes_per_launch": fs_bytes_survey,
+                                                    "frac": (fs_bytes_survey / (fs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fs_ms > 0 else 0.0)},
                     "pipeline_algorithmic_bytes": pipeline_bytes, "pipeline_gbs": pipeline_gbs,
                     "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
                     "scan_valu_issue_floor_ms": valu_floor_ms,
                     "scan_valu_issue_frac": valu_floor_ms / scan_ms if scan_ms > 0 else 0.0,
                     "scan_class_tests_per_s": st["n_class_tests"] / (scan_ms * 1e-3) if scan_ms > 0 else 0.0,
-                    "scan_tests_by_planes": kinds}
+                    "scan_tests_by_planes": kinds, "scan_tiles": st["n_scan_blocks"]}
+        # ---- end to end from host strings (never `value`): encode + upload, device run, download of the ranked rows ------
+        e2e = None
+        if world == 1:
+            reps = []
+            for _ in range(3):
+                t = time.perf_counter()
+                b2 = model.encode_batch(queries, params)
+                t1 = time.perf_counter()
+                b2.run(stream.cuda_stream)
+                t2 = time.perf_counter()
+                arrs = b2.fetch_arrays()
+                t3 = time.perf_counter()
+                b2.free()
+                reps.append((t3 - t, t1 - t, t2 - t1, t3 - t2, int(arrs[0][-1])))
+            best = min(reps)
+            e2e = {"queries_per_s": args.queries / best[0], "s_per_batch": best[0], "encode_upload_s": best[1], "run_s": best[2],
+                   "download_s": best[3], "rows": best[4],
+                   "what": "Python strings -> anx_batch_encode_packed -> run -> numpy result arrays on the host, best of 3, one batch at a time"}
         # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
         cpu = None
         ncores = usable_cores()
@@ -255,6 +318,11 @@ def main():
             "metric": baseline_metric(),
             "value": pairs * args.steps / elapsed, "unit": "pairs/s",
             "queries_per_s": nq * args.steps / elapsed,
+            # `value` counts the reference's scored pairs (every damerau_levenshtein call of gather_instances, src/lib.rs:1343);
+            # 16 % of them fail its length test and are only counted, 2/3 of the rest are rejected by the exact prefilter:
+            "dp_pairs_per_s": st["n_selected"] * world * args.steps / elapsed,       # pairs that ran the banded DL
+            "lcs_pairs_per_s": st["n_survivors"] * world * args.steps / elapsed,     # ... and the LCS / prefix / suffix tail
+            "e2e_queries_per_s": e2e["queries_per_s"] if e2e else None, "e2e": e2e,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",

@@ -176,6 +176,14 @@ int anx_batch_fetch(const anx_batch *, anx_result **out_rows, size_t **out_offse
 /* every scored pair of the batch (order unspecified within a query) */
 int anx_batch_fetch_pairs(const anx_batch *, anx_pair **out_pairs, size_t *out_n);
 void anx_pairs_free(anx_pair *);
+/* Scored pairs per input (counts[n], malloc'd, release with anx_counts_free): the number of damerau_levenshtein calls the
+ * reference's gather_instances makes for that input (src/lib.rs:1311-1402, one per instance of every anagram class
+ * find_nearest_anahashes returned; StopAtExactMatch: of the exact class only when it exists, src/lib.rs:1164-1173).
+ * Counted by the scan kernel of a PRODUCTION run -- pairs that fail the DL's length test are only counted there, never
+ * materialised -- so this is the per-query check of the production pair list (anx_batch_fetch_pairs re-runs with every
+ * pair materialised).  Re-runs the batch. */
+int anx_batch_pair_counts(anx_batch *, uint32_t **out_counts);
+void anx_counts_free(uint32_t *);
 /* write fixed-stride ranked records (stride records per query, batch order) into a DEVICE buffer of
  * n*stride*sizeof(anx_topk_record) bytes (e.g. a torch tensor) -- the payload of the multi-GPU gather */
 int anx_batch_export_topk(const anx_batch *, void *device_dst, uint32_t stride, void *stream);

@@ -13,6 +13,7 @@ Batch* batch_encode(const HostModel&, const DeviceLexicon*, const char* const*, 
 int batch_run(const HostModel&, const DeviceLexicon*, Batch*, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_fetch(const HostModel&, const DeviceLexicon*, const Batch*, anx_result**, size_t**, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_fetch_pairs(const HostModel&, const DeviceLexicon*, const Batch*, anx_pair**, size_t*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
+int batch_pair_counts(const HostModel&, const DeviceLexicon*, Batch*, uint32_t**, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_export_topk(const DeviceLexicon*, const Batch*, void*, uint32_t, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_export_compact(const DeviceLexicon*, const Batch*, void*, size_t, void*, size_t*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 void batch_stats(const Batch*, anx_batch_stats*) {}

@@ -96,7 +96,10 @@ def test_oracle_spot_check(setup, data_dir):
     o.build()
     op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
     rng = np.random.default_rng(5)
+    counts = _b.pair_counts()   # per-query scored pairs of a production run of the whole 1 M batch
+    assert int(counts.sum()) == _st["n_pairs"]
     for i in rng.choice(N, 1500, replace=False):
-        exp = o.find_variants(qs[i], op)
+        exp, _pairs, npairs, _ncls = o.find_variants(qs[i], op, want_pairs=True, cap=1 << 12)
         got = [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
         assert got == exp, qs[i]
+        assert int(counts[i]) == npairs, qs[i]

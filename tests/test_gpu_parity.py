@@ -48,6 +48,10 @@ def compare_batch(g, o, queries, gp, op, check_pairs=True):
     b.run()
     res = b.fetch()
     stats = b.stats()
+    # scored pairs per query as the PRODUCTION run's scan counts them (pairs failing the DL's length test are counted there
+    # without being materialised); fetch_pairs below re-runs with every pair materialised
+    counts = b.pair_counts()
+    assert int(counts.sum()) == stats["n_pairs"]
     pairs_by_q = {}
     if check_pairs:
         for (q, vid, ld, lcs, pre, suf, same, _score) in b.fetch_pairs():
@@ -60,6 +64,7 @@ def compare_batch(g, o, queries, gp, op, check_pairs=True):
             continue
         ores, opairs, npairs, _ncls = o.find_variants(text, op, want_pairs=True, cap=1 << 17)
         total_pairs += npairs
+        assert int(counts[i]) == npairs, (text, int(counts[i]), npairs)
         got = res[i]
         assert [v for v, _, _ in got] == [v for v, _, _ in ores], (text, got[:5], ores[:5])
         for (gv, gd, gf), (ov, od, of) in zip(got, ores):

@@ -400,3 +400,27 @@ def test_cli_index_cache_roundtrip(data_dir, tmp_path, capsys):
         assert cache.exists()
     assert outs[0] == outs[1]
     assert outs[0][0].startswith("seperate\tseparate\t0.734375\t") and '"input": "recieve"' in outs[0][1]
+
+
+def test_python_binding_multiple_lexicons(data_dir, tmp_path):
+    """The reference's only Python-binding test (/root/reference/bindings/python/tests/tests.py:12-36, values and the two
+    word lists transcribed): two lexicons, find_all_matches with max_edit_distance=3 / max_ngram=1, every match's best
+    variant and the `lexicons` attribution of that variant."""
+    amph = tmp_path / "amphibians.tsv"
+    amph.write_text("axolotl\nfrog\nnewt\nsalamander\ntoad", encoding="utf-8")   # no trailing newline, as in the reference file
+    rept = tmp_path / "reptiles.tsv"
+    rept.write_text("iguana\nlizard\nsnake\nturtle", encoding="utf-8")
+    model = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), debug=False)
+    model.read_lexicon(str(amph))
+    model.read_lexicon(str(rept))
+    model.build()
+    results = model.find_all_matches("Salamander lizard frog snake toad", A.SearchParameters(max_edit_distance=3, max_ngram=1))
+    assert len(results) == 5
+    for result, orig_term, lexicon, lex_term in ((results[0], "Salamander", amph, "salamander"), (results[1], "lizard", rept, "lizard"),
+                                                 (results[2], "frog", amph, "frog"), (results[3], "snake", rept, "snake"),
+                                                 (results[4], "toad", amph, "toad")):
+        assert result["input"] == orig_term
+        assert len(result["variants"]) > 0
+        best_match = result["variants"][0]
+        assert best_match["text"] == lex_term
+        assert best_match["lexicons"] == [str(lexicon)]
