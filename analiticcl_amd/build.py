@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build(force: bool = False) -> str:
     csrc = os.path.join(HERE, "csrc")
-    args = ["make", "-C", csrc, "-s"]
+    args = ["make", "-C", csrc, "-s", "-j8"]
     if force:
         subprocess.check_call(args + ["clean"])
     subprocess.check_call(args)

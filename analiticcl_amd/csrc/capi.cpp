@@ -212,7 +212,9 @@ int anx_model_to_device(anx_model* m, int device) {
   anx::lexicon_free(m->dev);
   m->dev = nullptr;
   std::string err;
-  m->dev = anx::lexicon_upload(m->host.lex, device, err);
+  anx::EncodeTables et;
+  anx::build_encode_tables(m->host.alphabet, et);
+  m->dev = anx::lexicon_upload(m->host.lex, et, device, err);
   return m->dev ? ANX_OK : fail(ANX_ENODEVICE, err);
 }
 int anx_model_build(anx_model* m, int device) {
@@ -479,17 +481,23 @@ int anx_edit_script(const char* source, const char* target, char* out, int cap) 
   return (int)s.size();
 }
 
+// device parameters of a batch: with confusables the cutoff (and in early mode the crop) follows the host-side rescoring
+static anx_params device_params(const anx_model* m, const anx_params* p, bool* rescore) {
+  anx_params dp = *p;
+  *rescore = !m->host.confusables.empty();
+  if (*rescore) {
+    dp.cutoff_threshold = 0.0;                               // the cutoff follows the late rescoring (src/lib.rs:1591-1622)
+    if (m->host.confusables_before_pruning) dp.max_matches = 0;  // early: crop after rescoring as well (src/lib.rs:1505-1589)
+  }
+  return dp;
+}
 anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p) {
   if (!m || (!utf8 && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
   if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_variants()"); return nullptr; }
   std::string err;
   int code = ANX_OK;
-  anx_params dp = *p;
-  const bool rescore = !m->host.confusables.empty();
-  if (rescore) {
-    dp.cutoff_threshold = 0.0;                               // the cutoff follows the late rescoring (src/lib.rs:1591-1622)
-    if (m->host.confusables_before_pruning) dp.max_matches = 0;  // early: crop after rescoring as well (src/lib.rs:1505-1589)
-  }
+  bool rescore;
+  const anx_params dp = device_params(m, p, &rescore);
   anx::Batch* b = anx::batch_encode(m->host, m->dev, utf8, n, dp, err, &code);
   if (!b) { fail(code ? code : ANX_ENODEVICE, err); return nullptr; }
   anx_batch* h = new anx_batch();
@@ -505,18 +513,36 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
 }
 anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t blob_len, size_t n, const anx_params* p) {
   if (!m || (!blob && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
+  if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_variants()"); return nullptr; }
   if (n && (blob_len == 0 || blob[blob_len - 1] != '\0')) { fail(ANX_EINVAL, "packed inputs must end with a NUL byte"); return nullptr; }
-  std::vector<const char*> ptrs;
-  ptrs.reserve(n);
+  if (blob_len >= ((size_t)1 << 32)) { fail(ANX_ELIMIT, "inputs exceed 4 GB per batch: split the batch"); return nullptr; }
+  // offsets of the n strings: the buffer goes to the device as it is (the device-side encoder reads the bytes there)
+  std::vector<uint32_t> off;
+  off.reserve(n + 1);
   const char* cur = blob;
   const char* end = blob + blob_len;
-  while (ptrs.size() < n && cur < end) {
-    ptrs.push_back(cur);
-    const void* z = memchr(cur, 0, (size_t)(end - cur));
-    cur = static_cast<const char*>(z) + 1;
+  while (off.size() < n && cur < end) {
+    off.push_back((uint32_t)(cur - blob));
+    cur = static_cast<const char*>(memchr(cur, 0, (size_t)(end - cur))) + 1;
   }
-  if (ptrs.size() != n) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); return nullptr; }
-  return anx_batch_encode(m, ptrs.data(), n, p);
+  if (off.size() != n) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); return nullptr; }
+  off.push_back((uint32_t)(cur - blob));
+  std::string err;
+  int code = ANX_OK;
+  bool rescore;
+  const anx_params dp = device_params(m, p, &rescore);
+  anx::Batch* b = anx::batch_encode_spans(m->host, m->dev, blob, off.data(), n, dp, err, &code);
+  if (!b) { fail(code ? code : ANX_ENODEVICE, err); return nullptr; }
+  anx_batch* h = new anx_batch();
+  h->model = m;
+  h->b = b;
+  h->rescore = rescore;
+  h->params = *p;
+  if (rescore) {
+    h->inputs.reserve(n);
+    for (size_t i = 0; i < n; ++i) h->inputs.emplace_back(blob + off[i]);
+  }
+  return h;
 }
 int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
   if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");

@@ -1,0 +1,449 @@
+// encode.hip -- device-side query encoder of the anx engine (gfx950 / CDNA4).
+//
+// Replaces, for a whole batch at once, what the reference does per input at the top of find_variants()
+// (/root/reference/src/lib.rs:972-1012): normalize_to_alphabet / the count vector behind anahash (src/anahash.rs:16-80),
+// the threshold clamps (src/lib.rs:982-1012), plus what the scan kernels want on top of it: thermometer planes, group
+// signature, the (scan kernel, length, signature, kind) order, tiles in longest-processing-time order, and (StopAtExactMatch,
+// src/lib.rs:1164-1173) the exact anagram class of every query.  The host only hands over the input bytes and their offsets.
+//   k_enc_strings : one lane per input string: greedy first-match alphabet walk (class order, member order; multi-character
+//                   members consume their characters), codes, count vector, planes, signature, clamps, first-char case
+//   3 x radix sort: stable LSD over (kind) (signature) (scan kernel, length) -- rocPRIM device radix sort (plumbing)
+//   k_enc_gather  : sorted position -> query records, rows, planes, count vectors, exact class
+//   k_tile_*      : segment heads -> tiles of <= SCAN_TQ queries -> LPT order (one more radix sort)
+// The threaded host encoder in engine.hip (ANX_ENCODE=host) produces the same arrays and is kept as the A/B reference.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "engine_internal.h"
+
+namespace anx {
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      err = std::string(#expr) + ": " + hipGetErrorString(_e);                                 \
+      return ANX_ENODEVICE;                                                                    \
+    }                                                                                          \
+  } while (0)
+
+#include "kernels_common.hpp"
+
+struct EncArgs {
+  const uint8_t* blob;      // input bytes; string i = [off[i], off[i+1] - 1), one separator byte behind it
+  const uint32_t* off;      // [n + 1]
+  uint32_t n;
+  DevAlphabet al;
+  int A;                    // alphabet classes; symbol slots 0..A (slot A = unknown), norm code of unknown = A + 1
+  int NP;                   // count-vector dwords
+  int bits_ok;              // nsym <= 32: thermometer planes usable
+  anx_threshold kth, dth;
+  uint8_t* codes;           // [blob bytes] norm codes of string i at codes[off[i] ..]
+  uint32_t* meta;           // [n] len | k<<8 | d<<16 | first_is_lower<<24 ; 0 = not encodable
+  uint32_t* bits;           // [n][NBITPLANES]
+  unsigned long long* sig;  // [n]
+  uint32_t* kind;           // [n]
+  uint32_t* cv;             // [n][NP] zero-initialised
+  uint32_t* slen;           // [n] sort key (scan kernel, length); 0xFFFF = not encodable (sorts last)
+  uint32_t* ctr;            // [0] max len, [1] max d, [2] encodable inputs
+};
+
+__device__ inline int dev_u8len(uint32_t c) { return c < 0x80u ? 1 : (c >> 5) == 0x6u ? 2 : (c >> 4) == 0xEu ? 3 : (c >> 3) == 0x1Eu ? 4 : 1; }
+
+__device__ inline int dev_clamp_threshold(const anx_threshold& t, int len, int absolute_max) {  // host_model.cpp clamp_threshold
+  if (t.kind == ANX_RATIO || t.kind == ANX_RATIO_WITH_LIMIT) {
+    const float v = floorf((float)len * t.ratio);
+    const int x = v < 0.0f ? 0 : v > 255.0f ? 255 : (int)v;
+    const int lim = t.kind == ANX_RATIO ? absolute_max : (int)t.value;
+    return x < lim ? x : lim;
+  }
+  const int half = len / 2 < 255 ? len / 2 : 255;
+  return (int)t.value < half ? (int)t.value : half;
+}
+
+__global__ __launch_bounds__(256) void k_enc_strings(EncArgs a) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t len = 0, d = 0, ok = 0;
+  if (i < a.n) {
+    const uint32_t begin = a.off[i], end = a.off[i + 1] - 1u;
+    const uint8_t* __restrict__ s = a.blob;
+    uint32_t n = 0, skip = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, over = 0;
+    unsigned long long sig = 0;
+    uint8_t* cvb = reinterpret_cast<uint8_t*>(a.cv) + (size_t)i * (size_t)a.NP * 4u;
+    bool too_long = false;
+    for (uint32_t pos = begin; pos < end; pos += (uint32_t)dev_u8len(s[pos])) {
+      if (skip) { --skip; continue; }
+      const uint32_t b = s[pos];
+      int hit = a.al.fast[b];
+      if (hit == -2) {  // members starting with this byte, in (class, member) file order: the first that matches wins
+        hit = -1;
+        for (uint32_t c = a.al.coff[b]; c < a.al.coff[b + 1]; ++c) {
+          const uint4 cd = a.al.cand[c];  // {class, characters, bytes, offset into the byte pool}
+          if (pos + cd.z > end) continue;
+          bool eq = true;
+          for (uint32_t x = 0; x < cd.z; ++x) eq = eq && s[pos + x] == a.al.bytes[cd.w + x];
+          if (eq) { hit = (int)cd.x; skip = cd.y - 1u; break; }
+        }
+      }
+      if (n >= (uint32_t)kMaxSymbols) { too_long = true; break; }
+      const uint32_t slot = hit >= 0 ? (uint32_t)hit : (uint32_t)a.A;               // src/anahash.rs:42
+      a.codes[begin + n] = (uint8_t)(hit >= 0 ? hit : a.A + 1);                     // src/anahash.rs:76
+      ++n;
+      cvb[slot] = (uint8_t)(cvb[slot] + 1u);
+      if (a.bits_ok) {  // bit-sliced saturating counter: plane t has the bit iff count > t
+        const uint32_t bit = 1u << slot;
+        over |= p4 & bit;
+        p4 |= p3 & bit; p3 |= p2 & bit; p2 |= p1 & bit; p1 |= bit;
+      }
+      sig += 1ull << (8u * a.al.sym_group[slot]);
+    }
+    uint32_t meta = 0, slen = 0xFFFFu, kind = 0;
+    if (!too_long && n > 0) {
+      int fl;
+      {  // char::is_lowercase on the first character of the ORIGINAL string (src/lib.rs:1367-1377)
+        const uint32_t avail = end - begin;
+        int l = dev_u8len(s[begin]);
+        if ((uint32_t)l > avail) l = 1;
+        uint32_t cp = s[begin];
+        if (l == 2) cp = ((cp & 0x1Fu) << 6) | (s[begin + 1] & 0x3Fu);
+        else if (l == 3) cp = ((cp & 0x0Fu) << 12) | ((s[begin + 1] & 0x3Fu) << 6) | (s[begin + 2] & 0x3Fu);
+        else if (l == 4) cp = ((cp & 0x07u) << 18) | ((s[begin + 1] & 0x3Fu) << 12) | ((s[begin + 2] & 0x3Fu) << 6) | (s[begin + 3] & 0x3Fu);
+        int lo = 0, hi = (int)a.al.nlower - 1;
+        fl = 0;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const uint2 r = a.al.lower[mid];
+          if (cp < r.x) hi = mid - 1;
+          else if (cp > r.y) lo = mid + 1;
+          else { fl = 1; break; }
+        }
+      }
+      const int k = dev_clamp_threshold(a.kth, (int)n, kMaxAnagramDistance);
+      const int dd = dev_clamp_threshold(a.dth, (int)n, kMaxEditDistance);
+      meta = n | ((uint32_t)k << 8) | ((uint32_t)dd << 16) | ((uint32_t)fl << 24);
+      kind = (a.bits_ok && !over) ? (p4 ? 4u : p3 ? 3u : p2 ? 2u : 1u) : 0u;
+      slen = (kind ? 256u : 0u) + n;
+      len = n; d = (uint32_t)dd; ok = 1;
+    }
+    a.meta[i] = meta;
+    a.kind[i] = kind;
+    a.slen[i] = slen;
+    a.sig[i] = sig;
+    a.bits[i * NBITPLANES + 0] = p1; a.bits[i * NBITPLANES + 1] = p2; a.bits[i * NBITPLANES + 2] = p3; a.bits[i * NBITPLANES + 3] = p4;
+  }
+  // wave maxima / counts -> one atomic per wave (a single counter word sustains only ~88 M atomics/s)
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    len = max(len, (uint32_t)__shfl_xor((int)len, o));
+    d = max(d, (uint32_t)__shfl_xor((int)d, o));
+  }
+  const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicMax(&a.ctr[0], len);
+    atomicMax(&a.ctr[1], d);
+    atomicAdd(&a.ctr[2], cnt);
+  }
+}
+
+__global__ void k_iota(uint32_t* p, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+template <typename T>
+__global__ void k_gather(const T* __restrict__ src, const uint32_t* __restrict__ perm, T* __restrict__ dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[perm[i]];
+}
+
+struct GatherArgs {
+  uint32_t nq, qw;
+  int NP, want_exact;
+  const uint32_t* perm;     // sorted position -> input index
+  const uint32_t* off;
+  const uint8_t* codes;
+  const uint32_t *meta, *bits, *kind, *cv;
+  const unsigned long long* sig;
+  // outputs (sorted order)
+  uint4* q_rec; uint4* q_rows; uint32_t *q_bits, *q_cv, *q_meta, *q_orig, *qexact, *s_kind;
+  unsigned long long* s_sig;
+  // exact-class lookup (StopAtExactMatch)
+  const uint4* sigtab; const uint32_t* siglen_begin; const uint32_t* cls_planes; uint32_t cstride;
+};
+__global__ __launch_bounds__(256) void k_enc_gather(GatherArgs g) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= g.nq) return;
+  const uint32_t i = g.perm[s];
+  const uint32_t meta = g.meta[i], len = meta & 0xFFu;
+  const unsigned long long sig = g.sig[i];
+  g.q_meta[s] = meta;
+  g.q_orig[s] = i;
+  g.s_kind[s] = g.kind[i];
+  g.s_sig[s] = sig;
+#pragma unroll
+  for (int t = 0; t < NBITPLANES; ++t) g.q_bits[(size_t)s * NBITPLANES + t] = g.bits[(size_t)i * NBITPLANES + t];
+  for (int p = 0; p < g.NP; ++p) g.q_cv[(size_t)s * g.NP + p] = g.cv[(size_t)i * g.NP + p];
+  const uint8_t* __restrict__ src = g.codes + g.off[i];
+  for (uint32_t w = 0; w < g.qw; ++w) {  // rows padded with bytes that equal nothing (0xFE; kernels_score.hpp)
+    uint32_t v[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      uint32_t word = 0;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const uint32_t idx = w * 16u + (uint32_t)x * 4u + (uint32_t)y;
+        word |= (idx < len ? (uint32_t)src[idx] : 0xFEu) << (8 * y);
+      }
+      v[x] = word;
+    }
+    const uint4 row = make_uint4(v[0], v[1], v[2], v[3]);
+    g.q_rows[(size_t)s * g.qw + w] = row;
+    if (w == 0) { g.q_rec[2 * (size_t)s] = row; g.q_rec[2 * (size_t)s + 1] = make_uint4(meta, 0u, 0u, 0u); }
+  }
+  uint32_t xc = 0xFFFFFFFFu;
+  if (g.want_exact) {  // the exact anagram class: the run of this signature in its charcount range, then the count vectors
+    int lo = (int)g.siglen_begin[len], hi = (int)g.siglen_begin[len + 1] - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const uint4 r = g.sigtab[mid];  // {sig lo, sig hi, first class, classes}
+      const unsigned long long v = (unsigned long long)r.x | (unsigned long long)r.y << 32;
+      if (sig < v) hi = mid - 1;
+      else if (sig > v) lo = mid + 1;
+      else {
+        for (uint32_t c = r.z; c < r.z + r.w && xc == 0xFFFFFFFFu; ++c) {
+          bool eq = true;
+          for (int p = 0; p < g.NP; ++p) eq = eq && g.cls_planes[(size_t)p * g.cstride + c] == g.cv[(size_t)i * g.NP + p];
+          if (eq) xc = c;
+        }
+        break;
+      }
+    }
+  }
+  g.qexact[s] = xc;
+}
+
+// ---- tiles ------------------------------------------------------------------------------------------------------------
+struct TileArgs {
+  uint32_t nq, tq;
+  const uint32_t *q_meta, *s_kind;
+  const unsigned long long* s_sig;
+  const uint32_t* siglen_begin;
+  uint32_t* head;       // [nq] s if s starts a (scan kernel, length, signature) segment else 0  -> (max-scan) segment start
+  uint32_t* tcount;     // [nq + 1] tiles started at s -> (exclusive scan) first tile index
+  Tile* tiles;          // unsorted
+  unsigned long long* tkey;  // LPT sort key
+  uint32_t* ctr;        // [3] = SAD tiles
+};
+__device__ inline bool same_segment(const TileArgs& t, uint32_t a, uint32_t b) {
+  return (t.s_kind[a] == 0) == (t.s_kind[b] == 0) && (t.q_meta[a] & 0xFFu) == (t.q_meta[b] & 0xFFu) && t.s_sig[a] == t.s_sig[b];
+}
+__device__ inline void tile_window(const TileArgs& t, uint32_t s, uint32_t& s0, uint32_t& s1, uint32_t& step, uint32_t& nparts) {
+  const uint32_t meta = t.q_meta[s], lq = meta & 0xFFu, k = (meta >> 8) & 0xFFu;
+  const int lo = max(1, (int)lq - (int)k), hi = min(kMaxSymbols, (int)lq + (int)k);
+  s0 = t.siglen_begin[lo] & ~63u;
+  s1 = (t.siglen_begin[hi + 1] + 63u) & ~63u;
+  const uint32_t nsplit = t.s_kind[s] == 0 ? 8u : 1u;  // count-vector tiles: the window split over 8 waves (engine.hip)
+  step = (((s1 - s0) + nsplit - 1u) / nsplit + 63u) & ~63u;
+  nparts = 0;
+  for (uint32_t part = 0; part < nsplit; ++part) {
+    const uint32_t a0 = s0 + part * step, a1 = min(s1, a0 + step);
+    if (a0 >= a1 && part) break;
+    ++nparts;
+  }
+}
+__global__ __launch_bounds__(256) void k_tile_heads(TileArgs t) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= t.nq) return;
+  t.head[s] = (s > 0 && !same_segment(t, s, s - 1)) ? s : 0u;
+}
+__global__ __launch_bounds__(256) void k_tile_count(TileArgs t) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s > t.nq) return;
+  uint32_t c = 0;
+  if (s < t.nq && (s - t.head[s]) % t.tq == 0) {  // head[] holds the segment start after the max-scan
+    uint32_t s0, s1, step, nparts;
+    tile_window(t, s, s0, s1, step, nparts);
+    c = nparts;
+  }
+  t.tcount[s] = c;
+}
+__global__ __launch_bounds__(256) void k_tile_emit(TileArgs t) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= t.nq || (s - t.head[s]) % t.tq != 0) return;
+  uint32_t tn = 1, ke[3] = {0, 0, 0};
+  for (uint32_t kd = t.s_kind[s]; kd >= 1 && kd <= 3; ++kd) ke[kd - 1]++;
+  while (tn < t.tq && s + tn < t.nq && same_segment(t, s, s + tn)) {
+    for (uint32_t kd = t.s_kind[s + tn]; kd >= 1 && kd <= 3; ++kd) ke[kd - 1]++;
+    ++tn;
+  }
+  const bool sad = t.s_kind[s] == 0;
+  const uint32_t meta = t.q_meta[s], lq = meta & 0xFFu, k = (meta >> 8) & 0xFFu, d = (meta >> 16) & 0xFFu;
+  uint32_t s0, s1, step, nparts;
+  tile_window(t, s, s0, s1, step, nparts);
+  const unsigned long long sig = t.s_sig[s];
+  const uint32_t base = t.tcount[s];
+  for (uint32_t part = 0; part < nparts; ++part) {
+    const uint32_t a0 = s0 + part * step, a1 = min(s1, a0 + step);
+    Tile tl;
+    tl.q0 = s; tl.nq = tn; tl.s0 = a0; tl.s1 = a1; tl.k = k; tl.lq = lq; tl.sig_lo = (uint32_t)sig; tl.sig_hi = (uint32_t)(sig >> 32);
+    tl.kind = sad ? 0u : 1u; tl.d = d; tl.kend = sad ? 0u : (ke[0] | ke[1] << 8 | ke[2] << 16);
+    t.tiles[base + part] = tl;
+    // longest-processing-time first, bit-plane tiles before the count-vector ones: ascending key, stable
+    const unsigned long long cost = (unsigned long long)tn * (a1 - a0 + 64u);
+    t.tkey[base + part] = ((unsigned long long)(sad ? 1u : 0u) << 63) | (0x7FFFFFFFFFFFFFFFull - cost);
+  }
+  if (sad) atomicAdd(&t.ctr[3], nparts);
+}
+
+// ---- host driver --------------------------------------------------------------------------------------------------------
+namespace {
+struct Scratch {  // pool blocks released together
+  std::vector<void*> blocks;
+  template <typename T>
+  int get(T** p, size_t count, std::string& err) {
+    void* q = nullptr;
+    HIP_TRY(pool_malloc(&q, std::max<size_t>(count * sizeof(T), 16)));
+    blocks.push_back(q);
+    *p = static_cast<T*>(q);
+    return ANX_OK;
+  }
+  ~Scratch() { for (void* q : blocks) pool_free(q); }
+};
+template <typename K>
+int sort_pairs(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, Scratch& sc, hipStream_t st,
+               std::string& err) {
+  size_t bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, st));
+  char* tmp = nullptr;
+  int rc = sc.get(&tmp, bytes + 16, err);
+  if (rc) return rc;
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, b0, b1, st));
+  return ANX_OK;
+}
+template <typename T>
+int balloc(T** dst, size_t count, std::string& err) {
+  HIP_TRY(pool_malloc(reinterpret_cast<void**>(dst), std::max<size_t>(count * sizeof(T), 16)));
+  return ANX_OK;
+}
+}  // namespace
+
+// Fills the query and tile arrays of `b` (device) from the packed inputs.  Returns ANX_OK or an error code.
+int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, const uint32_t* off, size_t n,
+                        const anx_params& p, std::string& err) {
+  const uint32_t n32 = (uint32_t)n;
+  const size_t blob_len = n ? off[n] : 0;
+  const int NP = dl->nplanes;
+  hipStream_t st = nullptr;
+  Scratch sc;
+  int rc;
+  uint8_t *d_blob = nullptr, *d_codes = nullptr;
+  uint32_t *d_off = nullptr, *d_meta = nullptr, *d_bits = nullptr, *d_kind = nullptr, *d_cv = nullptr, *d_slen = nullptr, *d_ctr = nullptr;
+  unsigned long long* d_sig = nullptr;
+  if ((rc = sc.get(&d_blob, blob_len + 16, err)) || (rc = sc.get(&d_codes, blob_len + 16, err)) || (rc = sc.get(&d_off, n + 1, err)) ||
+      (rc = sc.get(&d_meta, n, err)) || (rc = sc.get(&d_bits, n * NBITPLANES, err)) || (rc = sc.get(&d_kind, n, err)) ||
+      (rc = sc.get(&d_cv, n * (size_t)NP, err)) || (rc = sc.get(&d_slen, n, err)) || (rc = sc.get(&d_sig, n, err)) || (rc = sc.get(&d_ctr, 8, err)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_off, off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_cv, 0, n * (size_t)NP * 4, st));
+  HIP_TRY(hipMemsetAsync(d_ctr, 0, 8 * sizeof(uint32_t), st));
+  EncArgs ea;
+  ea.blob = d_blob; ea.off = d_off; ea.n = n32; ea.al = dl->alpha; ea.A = m.alphabet.size(); ea.NP = NP;
+  ea.bits_ok = (dl->nsym <= 32 && !(getenv("ANX_SCAN") && strcmp(getenv("ANX_SCAN"), "sad") == 0)) ? 1 : 0;
+  ea.kth = p.max_anagram_distance; ea.dth = p.max_edit_distance;
+  ea.codes = d_codes; ea.meta = d_meta; ea.bits = d_bits; ea.sig = d_sig; ea.kind = d_kind; ea.cv = d_cv; ea.slen = d_slen; ea.ctr = d_ctr;
+  const dim3 gn((n32 + 255) / 256);
+  hipLaunchKernelGGL(k_enc_strings, gn, dim3(256), 0, st, ea);
+  // ---- (scan kernel, length, signature, kind) order: three stable LSD passes over the keys, least significant first ----
+  uint32_t *perm_a = nullptr, *perm_b = nullptr, *k32_a = nullptr, *k32_b = nullptr;
+  unsigned long long *k64_a = nullptr, *k64_b = nullptr;
+  if ((rc = sc.get(&perm_a, n, err)) || (rc = sc.get(&perm_b, n, err)) || (rc = sc.get(&k32_a, n, err)) || (rc = sc.get(&k32_b, n, err)) ||
+      (rc = sc.get(&k64_a, n, err)) || (rc = sc.get(&k64_b, n, err)))
+    return rc;
+  hipLaunchKernelGGL(k_iota, gn, dim3(256), 0, st, perm_a, n32);
+  if ((rc = sort_pairs(d_kind, k32_b, perm_a, perm_b, n, 0, 3, sc, st, err))) return rc;                 // kind (0..4)
+  hipLaunchKernelGGL(k_gather<unsigned long long>, gn, dim3(256), 0, st, d_sig, perm_b, k64_a, n32);
+  if ((rc = sort_pairs(k64_a, k64_b, perm_b, perm_a, n, 0, 64, sc, st, err))) return rc;                 // signature
+  hipLaunchKernelGGL(k_gather<uint32_t>, gn, dim3(256), 0, st, d_slen, perm_a, k32_a, n32);
+  if ((rc = sort_pairs(k32_a, k32_b, perm_a, perm_b, n, 0, 16, sc, st, err))) return rc;                 // (scan kernel, length); 0xFFFF last
+  const uint32_t* perm = perm_b;
+  uint32_t h_ctr[8];
+  HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint32_t nq = h_ctr[2];
+  b->nq = nq;
+  b->dmax = h_ctr[1];
+  b->qw = (std::max<uint32_t>(h_ctr[0], 1u) + 15u) / 16u;
+  // ---- query arrays in sorted order -------------------------------------------------------------------------------------
+  uint32_t* s_kind = nullptr;
+  unsigned long long* s_sig = nullptr;
+  if ((rc = sc.get(&s_kind, nq, err)) || (rc = sc.get(&s_sig, nq, err))) return rc;
+  if ((rc = balloc(&b->q_rec, 2 * (size_t)nq, err)) || (rc = balloc(&b->qexact, nq, err)) || (rc = balloc(&b->q_cv, (size_t)nq * NP, err)) ||
+      (rc = balloc(&b->q_bits, (size_t)nq * NBITPLANES, err)) || (rc = balloc(&b->q_rows, (size_t)nq * b->qw, err)) ||
+      (rc = balloc(&b->q_meta, nq, err)) || (rc = balloc(&b->q_orig, nq, err)))
+    return rc;
+  b->ntiles = 0;
+  b->n_sad_tiles = 0;
+  if (nq == 0) { HIP_TRY(hipStreamSynchronize(st)); return ANX_OK; }
+  GatherArgs ga;
+  ga.nq = nq; ga.qw = b->qw; ga.NP = NP; ga.want_exact = p.stop_at_exact_match ? 1 : 0;
+  ga.perm = perm; ga.off = d_off; ga.codes = d_codes; ga.meta = d_meta; ga.bits = d_bits; ga.kind = d_kind; ga.cv = d_cv; ga.sig = d_sig;
+  ga.q_rec = b->q_rec; ga.q_rows = b->q_rows; ga.q_bits = b->q_bits; ga.q_cv = b->q_cv; ga.q_meta = b->q_meta; ga.q_orig = b->q_orig;
+  ga.qexact = b->qexact; ga.s_kind = s_kind; ga.s_sig = s_sig;
+  ga.sigtab = dl->sig; ga.siglen_begin = dl->alpha.siglen_begin; ga.cls_planes = dl->cls_planes; ga.cstride = dl->cstride;
+  const dim3 gq((nq + 255) / 256);
+  hipLaunchKernelGGL(k_enc_gather, gq, dim3(256), 0, st, ga);
+  // ---- tiles --------------------------------------------------------------------------------------------------------------
+  TileArgs ta;
+  { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; ta.tq = v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }
+  ta.nq = nq; ta.q_meta = b->q_meta; ta.s_kind = s_kind; ta.s_sig = s_sig; ta.siglen_begin = dl->alpha.siglen_begin; ta.ctr = d_ctr;
+  uint32_t *d_head = nullptr, *d_tcount = nullptr;
+  if ((rc = sc.get(&d_head, nq, err)) || (rc = sc.get(&d_tcount, (size_t)nq + 1, err))) return rc;
+  ta.head = d_head; ta.tcount = d_tcount; ta.tiles = nullptr; ta.tkey = nullptr;
+  hipLaunchKernelGGL(k_tile_heads, gq, dim3(256), 0, st, ta);
+  {
+    size_t bytes = 0;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, d_head, d_head, (size_t)nq, rocprim::maximum<uint32_t>(), st));
+    char* tmp = nullptr;
+    if ((rc = sc.get(&tmp, bytes + 16, err))) return rc;
+    HIP_TRY(rocprim::inclusive_scan(tmp, bytes, d_head, d_head, (size_t)nq, rocprim::maximum<uint32_t>(), st));
+  }
+  hipLaunchKernelGGL(k_tile_count, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ta);
+  {
+    size_t bytes = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, d_tcount, d_tcount, 0u, (size_t)nq + 1, rocprim::plus<uint32_t>(), st));
+    char* tmp = nullptr;
+    if ((rc = sc.get(&tmp, bytes + 16, err))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp, bytes, d_tcount, d_tcount, 0u, (size_t)nq + 1, rocprim::plus<uint32_t>(), st));
+  }
+  uint32_t ntiles = 0;
+  HIP_TRY(hipMemcpyAsync(&ntiles, d_tcount + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  Tile *t_unsorted = nullptr;
+  unsigned long long *tkey_a = nullptr, *tkey_b = nullptr;
+  uint32_t *tperm_a = nullptr, *tperm_b = nullptr;
+  if ((rc = sc.get(&t_unsorted, ntiles, err)) || (rc = sc.get(&tkey_a, ntiles, err)) || (rc = sc.get(&tkey_b, ntiles, err)) ||
+      (rc = sc.get(&tperm_a, ntiles, err)) || (rc = sc.get(&tperm_b, ntiles, err)) || (rc = balloc(&b->d_tiles, ntiles, err)))
+    return rc;
+  ta.tiles = t_unsorted; ta.tkey = tkey_a;
+  hipLaunchKernelGGL(k_tile_emit, gq, dim3(256), 0, st, ta);
+  if (ntiles) {
+    const dim3 gt((ntiles + 255) / 256);
+    hipLaunchKernelGGL(k_iota, gt, dim3(256), 0, st, tperm_a, ntiles);
+    if ((rc = sort_pairs(tkey_a, tkey_b, tperm_a, tperm_b, ntiles, 0, 64, sc, st, err))) return rc;
+    hipLaunchKernelGGL(k_gather<Tile>, gt, dim3(256), 0, st, t_unsorted, tperm_b, b->d_tiles, ntiles);
+  }
+  HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  b->ntiles = ntiles;
+  b->n_sad_tiles = h_ctr[3];
+  return ANX_OK;
+}
+
+}  // namespace anx

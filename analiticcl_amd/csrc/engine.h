@@ -12,12 +12,15 @@ struct DeviceLexicon;  // HBM-resident SoA lexicon
 struct Batch;          // encoded queries + pipeline buffers + results, HBM-resident
 
 int device_count(std::string& err);
-DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& err);
+DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, int device, std::string& err);
 void lexicon_free(DeviceLexicon*);
 void device_pool_trim(int device);  // hands the cached scratch blocks of the device back to the driver
 
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
                     const anx_params& p, std::string& err, int* code);
+// the same with the inputs in one buffer: input i = blob[off[i] .. off[i+1] - 1), followed by one NUL byte
+Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, const uint32_t* off, size_t n,
+                          const anx_params& p, std::string& err, int* code);
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err);

@@ -24,7 +24,7 @@
 #include <thread>
 #include <type_traits>
 
-#include "engine.h"
+#include "engine_internal.h"
 
 namespace anx {
 
@@ -82,6 +82,7 @@ DevPool& pool_of(int device) {
   static DevPool pools[64];
   return pools[device >= 0 && device < 64 ? device : 0];
 }
+}  // namespace
 hipError_t pool_malloc(void** p, size_t bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -132,7 +133,7 @@ void pool_free(void* p) {
   }
   (void)hipFree(p);
 }
-void pool_trim(int device) {
+static void pool_trim(int device) {
   DevPool& pl = pool_of(device);
   std::vector<void*> drop;
   {
@@ -143,7 +144,6 @@ void pool_trim(int device) {
   }
   for (void* d : drop) (void)hipFree(d);
 }
-}  // namespace
 void device_pool_trim(int device) { if (hipSetDevice(device) == hipSuccess) pool_trim(device); }
 
 // Host staging array WITHOUT value-initialisation: the threaded fill loops write every element, so the pages are first
@@ -177,7 +177,7 @@ static int dalloc(T** dst, size_t count, std::string& err) {
   return ANX_OK;
 }
 
-DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& err) {
+DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, int device, std::string& err) {
   int n = device_count(err);
   if (n <= 0) {
     if (err.empty()) err = "no HIP device available";
@@ -267,10 +267,18 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, int device, std::string& 
       (rc = upload(&d->var_target, img.var_target.data(), img.var_target.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_target_freq, img.var_target_freq.data(), img.var_target_freq.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_score, img.var_score.data(), img.var_score.size(), err, &d->bytes)) ||
-      (rc = upload(reinterpret_cast<uint8_t**>(&d->rows), img.rows.data(), img.rows.size(), err, &d->bytes))) {
+      (rc = upload(reinterpret_cast<uint8_t**>(&d->rows), img.rows.data(), img.rows.size(), err, &d->bytes)) ||
+      // tables of the device-side query encoder (encode.hip): flattened alphabet, symbol groups, lowercase ranges
+      (rc = upload(&d->alpha.fast, et.fast, 256, err, &d->bytes)) || (rc = upload(&d->alpha.coff, et.coff, 257, err, &d->bytes)) ||
+      (rc = upload(reinterpret_cast<uint32_t**>(&d->alpha.cand), et.cand.data(), et.cand.size(), err, &d->bytes)) ||
+      (rc = upload(&d->alpha.bytes, et.bytes.data(), et.bytes.size(), err, &d->bytes)) ||
+      (rc = upload(&d->alpha.sym_group, img.sym_group.data(), img.sym_group.size(), err, &d->bytes)) ||
+      (rc = upload(reinterpret_cast<uint32_t**>(&d->alpha.lower), et.lower.data(), et.lower.size(), err, &d->bytes)) ||
+      (rc = upload(&d->alpha.siglen_begin, img.siglen_begin, kMaxSymbols + 2, err, &d->bytes))) {
     lexicon_free(d);
     return nullptr;
   }
+  d->alpha.nlower = (uint32_t)(et.lower.size() / 2);
   return d;
 }
 
@@ -279,7 +287,8 @@ void lexicon_free(DeviceLexicon* d) {
   (void)hipSetDevice(d->device);
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sig, (void*)d->sigblk, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
-                  (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows})
+                  (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
+                  (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
     if (p) pool_free(p);
   bool last;
   { DevPool& pl = pool_of(d->device); std::lock_guard<std::mutex> g(pl.mu); last = --pl.lexicons <= 0; }
@@ -292,19 +301,13 @@ static int scan_mode() {  // ANX_SCAN=sad forces the general count-vector kernel
   return (e && strcmp(e, "sad") == 0) ? 1 : 0;
 }
 
-Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
-                    const anx_params& p, std::string& err, int* code) {
-  *code = ANX_OK;
-  if (!dl) { err = "model is not resident on a device (no HIP device / anx_model_to_device not called)"; *code = ANX_ENODEVICE; return nullptr; }
-  if (hipSetDevice(dl->device) != hipSuccess) { err = "hipSetDevice failed"; *code = ANX_ENODEVICE; return nullptr; }
+// The threaded HOST encoder (ANX_ENCODE=host): the A/B reference of the device-side encoder in encode.hip, same arrays.
+static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* const* utf8, size_t n, const anx_params& p,
+                       std::string& err) {
   static const bool timing = getenv("ANX_ENCODE_TIMING") != nullptr;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();
   auto lap = [&](const char* what) { if (timing) { const double t = tnow(); fprintf(stderr, "[anx encode] %-28s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
-  Batch* b = new Batch();
-  b->device = dl->device;
-  b->params = p;
-  b->n_input = n;
   b->status.assign(n, 0);
   const int NP = dl->nplanes;
   const bool bits_ok = dl->nsym <= 32 && !scan_mode();
@@ -573,20 +576,23 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
       (rc = upload(&b->q_bits, h_bits.data(), h_bits.size(), err, nullptr)) ||
       (rc = upload(reinterpret_cast<uint8_t**>(&b->q_rows), h_rows.data(), h_rows.size(), err, nullptr)) ||
       (rc = upload(&b->q_meta, h_meta.data(), nq, err, nullptr)) || (rc = upload(&b->q_orig, h_orig.data(), nq, err, nullptr)) ||
-      (rc = upload(&b->d_tiles, b->tiles.data(), b->tiles.size(), err, nullptr))) {
-    *code = rc;
-    batch_free(b);
-    return nullptr;
-  }
+      (rc = upload(&b->d_tiles, b->tiles.data(), b->tiles.size(), err, nullptr)))
+    return rc;
+  b->ntiles = (uint32_t)b->tiles.size();
+  std::vector<Tile>().swap(b->tiles);
   lap("uploads");
+  return ANX_OK;
+}
+
+// what every batch needs besides its query arrays: counters, per-query accumulators, the quotient table, events
+static int encode_tail(Batch* b, std::string& err) {
+  const size_t nq = b->nq;
+  int rc;
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
   if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->lctr, 3 * SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
-      (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err))) {
-    *code = rc;
-    batch_free(b);
-    return nullptr;
-  }
+      (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err)))
+    return rc;
   {
     std::vector<double> quot(33 * 33, 0.0);
     for (int x = 0; x <= 32; ++x)
@@ -594,14 +600,81 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
         volatile double num = (double)x, den = (double)L;  // a real division at run time, as the reference does
         quot[(size_t)x * 33 + L] = num / den;
       }
-    if (hipMemcpy(b->quot, quot.data(), quot.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
+    HIP_TRY(hipMemcpy(b->quot, quot.data(), quot.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  for (auto& e : b->ev)
-    if (hipEventCreate(&e) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
-  if (hipEventCreate(&b->ev_fs0) != hipSuccess || hipEventCreate(&b->ev_fs1) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
-  if (hipEventCreate(&b->ev_scan0) != hipSuccess) { err = "hipEventCreate failed"; *code = ANX_ENODEVICE; batch_free(b); return nullptr; }
-  lap("device allocations");
+  for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipEventCreate(&b->ev_fs0));
+  HIP_TRY(hipEventCreate(&b->ev_fs1));
+  HIP_TRY(hipEventCreate(&b->ev_scan0));
+  return ANX_OK;
+}
+
+Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, const uint32_t* off, size_t n,
+                          const anx_params& p, std::string& err, int* code) {
+  *code = ANX_OK;
+  if (!dl) { err = "model is not resident on a device (no HIP device / anx_model_to_device not called)"; *code = ANX_ENODEVICE; return nullptr; }
+  if (hipSetDevice(dl->device) != hipSuccess) { err = "hipSetDevice failed"; *code = ANX_ENODEVICE; return nullptr; }
+  if (n >= (1u << 27)) { err = "more than 2^27 inputs per batch"; *code = ANX_ELIMIT; return nullptr; }
+  Batch* b = new Batch();
+  b->device = dl->device;
+  b->params = p;
+  b->n_input = n;
+  const char* mode = getenv("ANX_ENCODE");  // "host": the threaded host encoder (A/B reference); read per call
+  int rc;
+  if (mode && strcmp(mode, "host") == 0) {
+    std::vector<const char*> ptrs(n);
+    for (size_t i = 0; i < n; ++i) ptrs[i] = blob + off[i];  // every span is followed by a NUL byte
+    rc = encode_host(m, dl, b, ptrs.data(), n, p, err);
+  } else {
+    rc = batch_encode_device(m, dl, b, blob, off, n, p, err);
+  }
+  if (!rc) rc = encode_tail(b, err);
+  if (rc) { *code = rc; batch_free(b); return nullptr; }
   return b;
+}
+
+// n NUL-terminated strings -> one buffer + offsets (threaded), then batch_encode_spans
+Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n, const anx_params& p,
+                    std::string& err, int* code) {
+  std::vector<uint32_t> off(n + 1, 0);
+  unsigned nthreads = std::max(1u, std::min(16u, usable_hw_threads()));
+  if (n < 16384) nthreads = 1;
+  std::vector<size_t> part(nthreads + 1, 0);
+  auto run_threads = [&](const std::function<void(unsigned, size_t, size_t)>& f) {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; ++t) {
+      const size_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+      if (nthreads == 1) f(0, lo, hi);
+      else th.emplace_back(f, t, lo, hi);
+    }
+    for (auto& x : th) x.join();
+  };
+  std::vector<uint32_t> lens(n);
+  bool too_big = false;
+  run_threads([&](unsigned t, size_t lo, size_t hi) {
+    size_t sum = 0;
+    for (size_t i = lo; i < hi; ++i) {
+      const size_t l = utf8[i] ? strlen(utf8[i]) : 0;  // a NULL input encodes like an empty one: no results
+      if (l >= (1u << 28)) too_big = true;
+      lens[i] = (uint32_t)l;
+      sum += l + 1;
+    }
+    part[t + 1] = sum;
+  });
+  for (unsigned t = 0; t < nthreads; ++t) part[t + 1] += part[t];
+  if (too_big || part[nthreads] >= ((size_t)1 << 32)) { err = "inputs exceed 4 GB per batch: split the batch"; *code = ANX_ELIMIT; return nullptr; }
+  HostBuf<char> blob(part[nthreads] + 1);
+  run_threads([&](unsigned t, size_t lo, size_t hi) {
+    size_t pos = part[t];
+    for (size_t i = lo; i < hi; ++i) {
+      off[i] = (uint32_t)pos;
+      if (lens[i]) memcpy(&blob[pos], utf8[i], lens[i]);
+      blob[pos + lens[i]] = '\0';
+      pos += (size_t)lens[i] + 1;
+    }
+  });
+  off[n] = (uint32_t)part[nthreads];
+  return batch_encode_spans(m, dl, blob.data(), off.data(), n, p, err, code);
 }
 
 static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, hipStream_t st, uint32_t* maxout = nullptr) {
@@ -679,7 +752,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   if (nq == 0) { b->ran = true; return ANX_OK; }
   const int stop = b->params.stop_at_exact_match ? 1 : 0;
   int rc;
-  if (b->raw_cap == 0 && (rc = ensure_raw(b, (nq * (size_t)140 + b->tiles.size() * SCAN_CHUNK) / SCAN_REGIONS + 4096, err)))
+  if (b->raw_cap == 0 && (rc = ensure_raw(b, (nq * (size_t)140 + (size_t)b->ntiles * SCAN_CHUNK) / SCAN_REGIONS + 4096, err)))
     return rc;
   uint32_t h_counters[CTR_N];
   std::vector<uint32_t> h_rctr(SCAN_REGIONS * RC_STRIDE);
@@ -689,10 +762,10 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(b->rctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
-    if (b->tiles.empty()) { HIP_TRY(hipEventRecord(b->ev_scan0, st)); HIP_TRY(hipEventRecord(b->ev[5], st)); }
-    if (!b->tiles.empty()) {
+    if (b->ntiles == 0) { HIP_TRY(hipEventRecord(b->ev_scan0, st)); HIP_TRY(hipEventRecord(b->ev[5], st)); }
+    if (b->ntiles) {
       ScanArgs A;
-      A.tiles = b->d_tiles; A.ntiles = (uint32_t)b->tiles.size(); A.q_bits = b->q_bits; A.q_cv = b->q_cv;
+      A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
       A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
       A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
       { const char* e = getenv("ANX_SCAN_WALK"); A.hier = (e && strcmp(e, "flat") == 0) ? 0 : 1; }
@@ -924,7 +997,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   s.n_pairs = b->n_pairs;
   s.n_class_tests = b->n_class_tests;
   s.n_results = total_results;
-  s.n_scan_blocks = b->tiles.size();
+  s.n_scan_blocks = b->ntiles;
   for (int i = 0; i <= NBITPLANES; ++i) s.n_tests_kind[i] = b->n_tests_kind[i];
   s.n_pair_slots = n_slots;
   s.n_survivors = total_surv;
@@ -986,6 +1059,15 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
   return ANX_OK;
 }
 
+// sorted position -> input index on the host (the device-side encoder only leaves it in q_orig): downloaded on first use
+static int ensure_order(const Batch* cb, std::string& err) {
+  Batch* b = const_cast<Batch*>(cb);
+  if (b->order.size() == b->nq) return ANX_OK;
+  b->order.resize(b->nq);
+  if (b->nq) HIP_TRY(hipMemcpy(b->order.data(), b->q_orig, b->nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return ANX_OK;
+}
+
 int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* cb, anx_pair** out, size_t* n,
                       std::string& err) {
   if (!cb->ran) { err = "batch has not been run"; return ANX_EINVAL; }
@@ -999,6 +1081,7 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
     if (rc) return rc;
   }
   const Batch* b = cb;
+  { const int rc = ensure_order(b, err); if (rc) return rc; }
   const size_t R = b->n_raw;
   anx_pair* res = static_cast<anx_pair*>(malloc(std::max<size_t>(1, (size_t)b->n_pairs) * sizeof(anx_pair)));
   if (!res) { err = "out of memory"; return ANX_EINVAL; }
@@ -1097,6 +1180,7 @@ int batch_pair_counts(const HostModel& m, const DeviceLexicon* dl, Batch* b, uin
   b->count_pairs = false;
   b->keep_all_pairs = keep;
   if (rc) return rc;
+  { const int rc2 = ensure_order(b, err); if (rc2) return rc2; }
   uint32_t* res = static_cast<uint32_t*>(calloc(std::max<size_t>(1, b->n_input), sizeof(uint32_t)));
   if (!res) { err = "out of memory"; return ANX_EINVAL; }
   if (b->nq) {

@@ -177,6 +177,25 @@ int Alphabet::scan_into(const char* text, size_t nbytes, int16_t* out, int cap) 
   return n;
 }
 
+void build_encode_tables(const Alphabet& a, EncodeTables& out) {
+  out.cand.clear();
+  out.bytes.clear();
+  for (int b = 0; b < 256; ++b) {
+    out.fast[b] = a.fast[b];
+    out.coff[b] = (uint32_t)(out.cand.size() / 4);
+    for (const Alphabet::Cand& cd : a.by_first[b]) {
+      out.cand.push_back((uint32_t)cd.cls);
+      out.cand.push_back((uint32_t)cd.m->nchars);
+      out.cand.push_back((uint32_t)cd.m->bytes.size());
+      out.cand.push_back((uint32_t)out.bytes.size());
+      out.bytes.insert(out.bytes.end(), cd.m->bytes.begin(), cd.m->bytes.end());
+    }
+  }
+  out.coff[256] = (uint32_t)(out.cand.size() / 4);
+  out.lower.clear();
+  for (int i = 0; i < anx_uc_lower_n; ++i) { out.lower.push_back(anx_uc_lower[i][0]); out.lower.push_back(anx_uc_lower[i][1]); }
+}
+
 bool Alphabet::scan(const char* text, size_t nbytes, std::vector<int16_t>& out) const {
   int16_t buf[kMaxSymbols];
   const int n = scan_into(text, nbytes, buf, kMaxSymbols);

@@ -40,6 +40,15 @@ struct Alphabet {
 };
 
 bool parse_alphabet(const std::string& tsv, Alphabet& out, std::string& err);  // src/lib.rs:369-407
+// The alphabet flattened for the device-side query encoder (encode.hip), plus the char::is_lowercase ranges
+struct EncodeTables {
+  int16_t fast[256];            // Alphabet::fast
+  uint32_t coff[257];           // candidate range per first byte
+  std::vector<uint32_t> cand;   // 4 words per candidate: class, characters, bytes, offset into `bytes`; (class, member) file order
+  std::vector<uint8_t> bytes;   // member byte pool
+  std::vector<uint32_t> lower;  // 2 words per inclusive code point range
+};
+void build_encode_tables(const Alphabet& a, EncodeTables& out);
 bool first_char_is_lowercase(const char* utf8);  // char::is_lowercase on text.chars().next()
 bool is_alphabetic_cp(uint32_t cp);              // char::is_alphabetic (L* + Nl; see oracle/gen_unicode.py)
 uint32_t utf8_decode_at(const char* s, size_t avail, int* len);

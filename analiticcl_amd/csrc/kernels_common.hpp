@@ -29,6 +29,17 @@ struct EntRec {   // per-entry attributes k_compact needs, one 16-B gather
   uint32_t vocab, freq, order, meta;
 };
 
+struct DevAlphabet {  // tables of the device-side query encoder (encode.hip), device pointers
+  int16_t* fast = nullptr;         // [256] per first byte: class of a one-byte member that always matches, -1 none, -2 try the candidates
+  uint32_t* coff = nullptr;        // [257] candidate range per first byte
+  uint4* cand = nullptr;           // {class, characters, bytes, offset into `bytes`}, (class, member) file order per first byte
+  uint8_t* bytes = nullptr;        // member byte pool
+  uint8_t* sym_group = nullptr;    // [count-vector bytes] signature group of every symbol slot
+  uint2* lower = nullptr;          // inclusive code point ranges of char::is_lowercase
+  uint32_t nlower = 0;
+  uint32_t* siglen_begin = nullptr;  // [kMaxSymbols + 2] signature range per charcount
+};
+
 struct DeviceLexicon {
   int device = 0;
   int nplanes = 0;      // count-vector dwords (SAD path)
@@ -56,6 +67,7 @@ struct DeviceLexicon {
   double* var_score = nullptr;
   int any_variants = 0;
   uint4* rows = nullptr;
+  DevAlphabet alpha;
   size_t bytes = 0;
 };
 
@@ -81,10 +93,11 @@ struct Batch {
   size_t nq = 0;            // encoded queries
   anx_params params;
   // host side
-  std::vector<uint32_t> order;     // sorted position -> original index
+  std::vector<uint32_t> order;     // sorted position -> original index (downloaded from q_orig on first use)
   std::vector<int32_t> status;     // per original query: 0 ok, ANX_EEMPTY, ANX_ELIMIT
   size_t n_input = 0;
-  std::vector<Tile> tiles;         // in launch order: bit-plane kinds, then the SAD kind; each by decreasing cost
+  std::vector<Tile> tiles;         // host encoder only, emptied after the upload
+  uint32_t ntiles = 0;             // d_tiles, in launch order: bit-plane tiles, then the count-vector (SAD) ones; each by decreasing cost
   uint32_t n_sad_tiles = 0;
   uint32_t qw = 1;                 // uint4 words per query row
   uint32_t dmax = 0;

@@ -4,10 +4,13 @@
 
 namespace anx {
 int device_count(std::string& err) { err = "stub: no device"; return 0; }
-DeviceLexicon* lexicon_upload(const LexiconImage&, int, std::string& err) { err = "stub: no device"; return nullptr; }
+DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, int, std::string& err) { err = "stub: no device"; return nullptr; }
 void lexicon_free(DeviceLexicon*) {}
 void device_pool_trim(int) {}
 Batch* batch_encode(const HostModel&, const DeviceLexicon*, const char* const*, size_t, const anx_params&, std::string& err, int* code) {
+  err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
+}
+Batch* batch_encode_spans(const HostModel&, const DeviceLexicon*, const char*, const uint32_t*, size_t, const anx_params&, std::string& err, int* code) {
   err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
 }
 int batch_run(const HostModel&, const DeviceLexicon*, Batch*, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
