@@ -113,6 +113,8 @@ def lib():
         "anx_model_build": (C.c_int, [vp, C.c_int]),
         "anx_model_save_index": (C.c_int, [vp, cp]),
         "anx_model_load_index": (C.c_int, [vp, cp, C.c_int]),
+        "anx_model_set_index_tag": (C.c_int, [vp, cp]),
+        "anx_index_read_tag": (C.c_void_p, [cp]),
         "anx_model_num_lexicons": (u64, [vp]),
         "anx_model_lexicon_name": (cp, [vp, u64]),
         "anx_model_to_device": (C.c_int, [vp, C.c_int]),

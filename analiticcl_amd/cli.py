@@ -122,11 +122,33 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
+def _index_tag(a) -> str:
+    """What --index-cache binds the image to: every resource file that enters build() (kind, path, size, SHA-256 of the content),
+    in the order given."""
+    import hashlib
+    import json
+    import os
+    items = []
+    for kind in ("lexicon", "variants", "errors", "lm"):
+        for f in getattr(a, kind):
+            h = hashlib.sha256()
+            with open(f, "rb") as fh:
+                for chunk in iter(lambda: fh.read(1 << 20), b""):
+                    h.update(chunk)
+            items.append([kind, os.path.abspath(f), os.path.getsize(f), h.hexdigest()])
+    return json.dumps({"resources": items, "argv_order": [t for t in sys.argv if t in ("--lexicon", "-l", "--variants", "-V", "--errors", "-E")]},
+                      sort_keys=True)
+
+
 def make_model(a) -> VariantModel:
     weights = Weights(ld=a.weight_ld, lcs=a.weight_lcs, prefix=a.weight_prefix, suffix=a.weight_suffix, case=a.weight_case)
     model = VariantModel(a.alphabet, weights, device=a.device)
     import os
-    if a.index_cache and os.path.exists(a.index_cache):
+    # The image is bound to what it was built from: alphabet (checked by the library), the resource files in command-line
+    # order with their sizes and content hashes, and the vocabulary parameters -- an edited lexicon, another variant list or LM
+    # makes the tag differ and the model is rebuilt (the reference rebuilds on every start, so it can never be stale)
+    tag = _index_tag(a) if a.index_cache else None
+    if a.index_cache and os.path.exists(a.index_cache) and VariantModel.index_tag_of(a.index_cache) == tag:
         model.load_index(a.index_cache)
         for filename in a.confusables:
             model.read_confusablelist(filename)
@@ -161,6 +183,7 @@ def make_model(a) -> VariantModel:
         model.read_contextrules(filename)
     model.build()
     if a.index_cache:
+        model.set_index_tag(tag)
         model.save_index(a.index_cache)
     if a.early_confusables:
         model.set_confusables_before_pruning()

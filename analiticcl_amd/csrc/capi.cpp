@@ -233,6 +233,21 @@ int anx_model_save_index(const anx_model* m, const char* path) {
   const int rc = m->host.save_index(path, err);
   return rc ? fail(rc, err) : ANX_OK;
 }
+int anx_model_set_index_tag(anx_model* m, const char* tag) {
+  if (!m || !tag) return fail(ANX_EINVAL, "NULL argument");
+  m->host.index_tag = tag;
+  return ANX_OK;
+}
+char* anx_index_read_tag(const char* path) {
+  if (!path) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
+  std::string tag, err;
+  const int rc = anx::index_read_tag(path, &tag, err);
+  if (rc) { fail(rc, err); return nullptr; }
+  char* out = static_cast<char*>(malloc(tag.size() + 1));
+  if (!out) { fail(ANX_EINVAL, "out of memory"); return nullptr; }
+  memcpy(out, tag.c_str(), tag.size() + 1);
+  return out;
+}
 int anx_model_load_index(anx_model* m, const char* path, int device) {
   if (!m || !path) return fail(ANX_EINVAL, "NULL argument");
   std::string err;
@@ -646,7 +661,7 @@ int anx_find_variants_batch(const anx_model* m, const char* const* utf8, size_t 
   return ANX_OK;
 }
 void anx_results_free(anx_result* rows, size_t* offsets) {
-  free(rows);
+  anx::host_result_free(rows);  // a cached pinned buffer of batch_fetch, or a malloc block
   free(offsets);
 }
 

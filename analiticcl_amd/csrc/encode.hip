@@ -13,7 +13,9 @@
 // The threaded host encoder in engine.hip (ANX_ENCODE=host) produces the same arrays and is kept as the A/B reference.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -335,12 +337,24 @@ int balloc(T** dst, size_t count, std::string& err) {
 // Fills the query and tile arrays of `b` (device) from the packed inputs.  Returns ANX_OK or an error code.
 int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, const uint32_t* off, size_t n,
                         const anx_params& p, std::string& err) {
+  static const bool timing = getenv("ANX_ENCODE_TIMING") != nullptr;
+  double t_prev = 0.0;
+  auto tnow = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+  if (timing) t_prev = tnow();
+  auto lap = [&](const char* what) { if (timing) { (void)hipDeviceSynchronize(); const double t = tnow(); fprintf(stderr, "[anx encode/device] %-24s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
   const uint32_t n32 = (uint32_t)n;
   const size_t blob_len = n ? off[n] : 0;
   const int NP = dl->nplanes;
   hipStream_t st = nullptr;
   Scratch sc;
   int rc;
+  if (n == 0) {  // nothing to encode: empty query arrays (the launches below do not take an empty grid)
+    b->nq = 0; b->dmax = 0; b->qw = 1; b->ntiles = 0; b->n_sad_tiles = 0;
+    if ((rc = balloc(&b->q_rec, 0, err)) || (rc = balloc(&b->qexact, 0, err)) || (rc = balloc(&b->q_cv, 0, err)) || (rc = balloc(&b->q_bits, 0, err)) ||
+        (rc = balloc(&b->q_rows, 0, err)) || (rc = balloc(&b->q_meta, 0, err)) || (rc = balloc(&b->q_orig, 0, err)) || (rc = balloc(&b->d_tiles, 0, err)))
+      return rc;
+    return ANX_OK;
+  }
   uint8_t *d_blob = nullptr, *d_codes = nullptr;
   uint32_t *d_off = nullptr, *d_meta = nullptr, *d_bits = nullptr, *d_kind = nullptr, *d_cv = nullptr, *d_slen = nullptr, *d_ctr = nullptr;
   unsigned long long* d_sig = nullptr;
@@ -358,7 +372,9 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   ea.kth = p.max_anagram_distance; ea.dth = p.max_edit_distance;
   ea.codes = d_codes; ea.meta = d_meta; ea.bits = d_bits; ea.sig = d_sig; ea.kind = d_kind; ea.cv = d_cv; ea.slen = d_slen; ea.ctr = d_ctr;
   const dim3 gn((n32 + 255) / 256);
+  lap("alloc + H2D");
   hipLaunchKernelGGL(k_enc_strings, gn, dim3(256), 0, st, ea);
+  lap("k_enc_strings");
   // ---- (scan kernel, length, signature, kind) order: three stable LSD passes over the keys, least significant first ----
   uint32_t *perm_a = nullptr, *perm_b = nullptr, *k32_a = nullptr, *k32_b = nullptr;
   unsigned long long *k64_a = nullptr, *k64_b = nullptr;
@@ -375,6 +391,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   uint32_t h_ctr[8];
   HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  lap("3 radix sorts");
   const uint32_t nq = h_ctr[2];
   b->nq = nq;
   b->dmax = h_ctr[1];
@@ -389,7 +406,11 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
     return rc;
   b->ntiles = 0;
   b->n_sad_tiles = 0;
-  if (nq == 0) { HIP_TRY(hipStreamSynchronize(st)); return ANX_OK; }
+  if (nq == 0) {
+    if ((rc = balloc(&b->d_tiles, 0, err))) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return ANX_OK;
+  }
   GatherArgs ga;
   ga.nq = nq; ga.qw = b->qw; ga.NP = NP; ga.want_exact = p.stop_at_exact_match ? 1 : 0;
   ga.perm = perm; ga.off = d_off; ga.codes = d_codes; ga.meta = d_meta; ga.bits = d_bits; ga.kind = d_kind; ga.cv = d_cv; ga.sig = d_sig;
@@ -398,6 +419,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   ga.sigtab = dl->sig; ga.siglen_begin = dl->alpha.siglen_begin; ga.cls_planes = dl->cls_planes; ga.cstride = dl->cstride;
   const dim3 gq((nq + 255) / 256);
   hipLaunchKernelGGL(k_enc_gather, gq, dim3(256), 0, st, ga);
+  lap("k_enc_gather");
   // ---- tiles --------------------------------------------------------------------------------------------------------------
   TileArgs ta;
   { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; ta.tq = v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }
@@ -443,6 +465,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   HIP_TRY(hipGetLastError());
   b->ntiles = ntiles;
   b->n_sad_tiles = h_ctr[3];
+  lap("tiles");
   return ANX_OK;
 }
 

@@ -14,7 +14,10 @@ struct Batch;          // encoded queries + pipeline buffers + results, HBM-resi
 int device_count(std::string& err);
 DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, int device, std::string& err);
 void lexicon_free(DeviceLexicon*);
-void device_pool_trim(int device);  // hands the cached scratch blocks of the device back to the driver
+void device_pool_trim(int device);  // hands the cached scratch blocks of the device (and the pinned result buffers) back to the driver
+// result rows of batch_fetch live in cached pinned host buffers: release them with host_result_free (falls back to free())
+void* host_result_alloc(size_t bytes);
+void host_result_free(void* p);
 
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
                     const anx_params& p, std::string& err, int* code);

@@ -144,7 +144,85 @@ static void pool_trim(int device) {
   }
   for (void* d : drop) (void)hipFree(d);
 }
-void device_pool_trim(int device) { if (hipSetDevice(device) == hipSuccess) pool_trim(device); }
+// Pinned host buffers for the downloaded results.  A fresh malloc'd buffer of 141 MB (1 M queries of config 2) is pageable and
+// untouched: the D2H copy is staged and page-faults its way through it (~20 ms); a pinned buffer takes the rows at PCIe speed.
+// Pinning costs more than the copy, so freed buffers are kept (anx_results_free returns them here) up to ANX_PINNED_CACHE_MB
+// (default 1024); anx_device_pool_trim releases them.  Without a HIP device the buffers are plain malloc blocks.
+namespace {
+struct HostCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  std::unordered_map<void*, std::pair<size_t, bool>> live;  // every block handed out or cached: (bytes, pinned)
+  size_t cached = 0;
+};
+HostCache& host_cache() { static HostCache c; return c; }
+size_t host_cache_limit() {
+  static const size_t lim = []() { const char* e = getenv("ANX_PINNED_CACHE_MB"); const long long v = e ? atoll(e) : -1; return v >= 0 ? (size_t)v << 20 : (size_t)1 << 30; }();
+  return lim;
+}
+}  // namespace
+void* host_result_alloc(size_t bytes) {
+  HostCache& hc = host_cache();
+  bytes = (std::max<size_t>(bytes, 64) + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);  // whole MB: a few distinct sizes
+  {
+    std::lock_guard<std::mutex> g(hc.mu);
+    auto it = hc.free_blocks.lower_bound(bytes);
+    if (it != hc.free_blocks.end() && it->first <= 2 * bytes) {
+      void* p = it->second;
+      hc.cached -= it->first;
+      hc.free_blocks.erase(it);
+      return p;
+    }
+  }
+  void* p = nullptr;
+  bool pinned = hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p;
+  if (!pinned) {
+    (void)hipGetLastError();
+    p = malloc(bytes);
+    if (!p) return nullptr;
+  }
+  std::lock_guard<std::mutex> g(hc.mu);
+  hc.live[p] = std::make_pair(bytes, pinned);
+  return p;
+}
+void host_result_free(void* p) {
+  if (!p) return;
+  HostCache& hc = host_cache();
+  size_t bytes = 0;
+  bool pinned = false, known = false;
+  {
+    std::lock_guard<std::mutex> g(hc.mu);
+    auto it = hc.live.find(p);
+    if (it != hc.live.end()) {
+      known = true;
+      bytes = it->second.first;
+      pinned = it->second.second;
+      if (pinned && hc.cached + bytes <= host_cache_limit()) {
+        hc.free_blocks.emplace(bytes, p);
+        hc.cached += bytes;
+        return;
+      }
+      hc.live.erase(it);
+    }
+  }
+  if (known && pinned) (void)hipHostFree(p);
+  else free(p);  // a malloc block (also: rows assembled by anx_find_variants_batch from several device batches)
+}
+static void host_cache_trim() {
+  HostCache& hc = host_cache();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(hc.mu);
+    for (auto& kv : hc.free_blocks) { drop.push_back(kv.second); hc.live.erase(kv.second); }
+    hc.free_blocks.clear();
+    hc.cached = 0;
+  }
+  for (void* p : drop) (void)hipHostFree(p);
+}
+void device_pool_trim(int device) {
+  if (hipSetDevice(device) == hipSuccess) pool_trim(device);
+  host_cache_trim();
+}
 
 // Host staging array WITHOUT value-initialisation: the threaded fill loops write every element, so the pages are first
 // touched (and faulted in) by the worker threads instead of being zero-filled by the calling thread (a million queries
@@ -1021,8 +1099,8 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
   HIP_TRY(hipSetDevice(b->device));
   const size_t n = b->n_input;
   size_t* off = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
-  anx_result* out = static_cast<anx_result*>(malloc(std::max<size_t>(1, b->n_results) * sizeof(anx_result)));
-  if (!off || !out) { free(off); free(out); err = "out of memory"; return ANX_EINVAL; }
+  anx_result* out = static_cast<anx_result*>(host_result_alloc(std::max<size_t>(1, b->n_results) * sizeof(anx_result)));
+  if (!off || !out) { free(off); host_result_free(out); err = "out of memory"; return ANX_EINVAL; }
   int rc = ANX_OK;
   if (b->nq && b->n_results) {
     // the device lays the rows out in the caller's input order (counts scattered to the original indices, exclusive
@@ -1053,7 +1131,7 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
     if (rc) (void)hipStreamSynchronize(st);  // nothing of this call may still be in flight when its blocks return to the pool
     for (void* p : {(void*)d_cnt, (void*)d_off, (void*)d_tmp, (void*)d_out}) pool_free(p);
   }
-  if (rc) { free(off); free(out); return rc; }
+  if (rc) { free(off); host_result_free(out); return rc; }
   *rows = out;
   *offs = off;
   return ANX_OK;

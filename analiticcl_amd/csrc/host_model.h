@@ -195,6 +195,7 @@ class HostModel {
                   const anx_vocab_params& p, uint8_t lexicon_index);  // src/lib.rs:460-514
   int read_variants(const char* path, const anx_vocab_params& p, bool transparent, std::string& err);  // :772-897
   int build_index(std::string& err);  // src/lib.rs:192-245
+  std::string index_tag;  // stored in / read from the index image: what the caller built it from (anx_model_set_index_tag)
   int save_index(const std::string& path, std::string& err) const;  // index_cache.cpp: image of the built model
   int load_index(const std::string& path, std::string& err);        // instead of read_vocabulary + build_index
   bool has(const char* text) const;   // src/lib.rs:331-338
@@ -208,6 +209,7 @@ class HostModel {
 };
 
 // threshold clamps of find_variants (src/lib.rs:982-994, 1000-1012)
+int index_read_tag(const std::string& path, std::string* tag, std::string& err);  // index_cache.cpp
 int clamp_threshold(const anx_threshold& t, int len, int absolute_max);
 
 }  // namespace anx

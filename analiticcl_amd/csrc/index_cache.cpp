@@ -4,6 +4,7 @@
 // the vocabulary with the reference's id assignment and the SoA lexicon image the GPU consumes -- is written once
 // and read back with plain freads.  The file is bound to the alphabet it was built with (its members are stored and
 // compared on load) and to this library's layout version.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -12,7 +13,7 @@
 namespace anx {
 namespace {
 
-constexpr char kMagic[8] = {'A', 'N', 'X', 'I', 'D', 'X', '0', '2'};
+constexpr char kMagic[8] = {'A', 'N', 'X', 'I', 'D', 'X', '0', '3'};
 
 struct Writer {
   FILE* f;
@@ -62,6 +63,7 @@ int HostModel::save_index(const std::string& path, std::string& err) const {
   w.raw(kMagic, sizeof kMagic);
   w.pod<uint32_t>(kSigGroups);
   w.str(alphabet_fingerprint(alphabet));
+  w.str(index_tag);  // the caller's description of what the image was built from (anx_model_set_index_tag)
   w.pod<uint8_t>(have_freq ? 1 : 0);
   w.pod<uint64_t>(lexicons.size());
   for (const std::string& l : lexicons) w.str(l);
@@ -109,6 +111,7 @@ int HostModel::load_index(const std::string& path, std::string& err) {
     err = path + " was built with a different alphabet";
     return ANX_EINVAL;
   }
+  r.str(index_tag);
   uint8_t b8 = 0;
   uint64_t n = 0;
   r.pod(b8); have_freq = b8 != 0;
@@ -143,9 +146,41 @@ int HostModel::load_index(const std::string& path, std::string& err) {
   r.vec(x.var_target_freq); r.vec(x.var_score); r.vec(x.ent_rowoff); r.vec(x.ent_order); r.vec(x.rows);
   r.vec(x.sym_group); r.vec(x.sig_lo); r.vec(x.sig_hi); r.vec(x.sig_cbeg);
   r.raw(magic, sizeof magic);
-  const bool ok = r.ok && memcmp(magic, kMagic, sizeof kMagic) == 0 && x.nsym == alphabet.size() + 1 &&
-                  x.cls_len.size() == x.cstride && x.cls_off.size() == (size_t)x.nclasses + 1 &&
-                  x.ent_vocab.size() == x.nentries && x.cls_planes.size() == (size_t)x.nplanes * x.cstride;
+  // Every array the upload and the kernels index is checked against the counts it must agree with, and every offset array
+  // for monotonicity and range: a corrupt or foreign image must not make lexicon_upload or a kernel read out of bounds.
+  auto monotone = [](const std::vector<uint32_t>& v, size_t n, uint64_t last) {
+    if (v.size() != n) return false;
+    for (size_t i = 1; i < v.size(); ++i)
+      if (v[i] < v[i - 1]) return false;
+    return v.empty() ? last == 0 : v.back() == last;
+  };
+  auto below = [](const std::vector<uint32_t>& v, uint64_t bound) {
+    for (uint32_t a : v)
+      if (a >= bound) return false;
+    return true;
+  };
+  bool ok = r.ok && memcmp(magic, kMagic, sizeof kMagic) == 0 && x.nsym == alphabet.size() + 1 && x.nplanes > 0 && x.nplanes <= 64 &&
+            x.nplanes * 4 >= x.nsym && x.cstride >= x.nclasses && x.cstride % 2048 == 0 && x.nsigs <= x.sig_lo.size() &&
+            x.cls_len.size() == x.cstride && x.cls_planes.size() == (size_t)x.nplanes * x.cstride && x.cls_bits.size() == (size_t)4 * x.cstride &&
+            monotone(x.cls_off, (size_t)x.nclasses + 1, x.nentries) &&
+            x.ent_vocab.size() == x.nentries && x.ent_freq.size() == x.nentries && x.ent_meta.size() == x.nentries &&
+            x.ent_rowoff.size() == x.nentries && x.ent_order.size() == x.nentries &&
+            monotone(x.ent_var_off, (size_t)x.nentries + 1, x.var_target.size()) && x.var_target_freq.size() == x.var_target.size() &&
+            x.var_score.size() == x.var_target.size() && below(x.var_target, decoder.size()) && below(x.ent_vocab, decoder.size()) &&
+            below(x.ent_order, std::max<uint64_t>(x.nentries, 1)) && x.rows.size() % 16 == 0 &&
+            x.sym_group.size() == (size_t)x.nplanes * 4 && x.sig_lo.size() % 64 == 0 && x.sig_hi.size() == x.sig_lo.size() &&
+            x.sig_cbeg.size() == x.sig_lo.size() + 1;
+  if (ok) {
+    for (uint8_t g : x.sym_group) ok = ok && g < 8;
+    for (size_t i = 0; i < x.sig_cbeg.size(); ++i) ok = ok && x.sig_cbeg[i] <= x.nclasses && (i == 0 || x.sig_cbeg[i] >= x.sig_cbeg[i - 1]);
+    for (int c = 0; c <= kMaxSymbols; ++c)
+      ok = ok && x.siglen_begin[c] <= x.siglen_begin[c + 1] && x.siglen_begin[c + 1] <= x.nsigs && x.bucket_begin[c] <= x.bucket_begin[c + 1] &&
+           x.bucket_begin[c + 1] <= x.nclasses;
+    for (uint32_t e = 0; ok && e < x.nentries; ++e) {  // token rows: inside the row pool, padded to 16-byte words
+      const size_t len = x.ent_meta[e] & 0xFFu, padded = std::max<size_t>(16, (len + 15) / 16 * 16);
+      ok = (size_t)x.ent_rowoff[e] * 16 + padded <= x.rows.size();
+    }
+  }
   fclose(f);
   if (!ok) {
     decoder.clear();
@@ -167,6 +202,23 @@ int HostModel::load_index(const std::string& path, std::string& err) {
   }
   build_lm();
   built = true;
+  return ANX_OK;
+}
+
+// The tag of an image without loading it (ANX_OK and *tag, or an error code)
+int index_read_tag(const std::string& path, std::string* tag, std::string& err) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { err = "cannot open " + path; return ANX_EIO; }
+  Reader r{f};
+  char magic[8];
+  r.raw(magic, sizeof magic);
+  uint32_t groups = 0;
+  r.pod(groups);
+  std::string fp;
+  r.str(fp);
+  r.str(*tag);
+  fclose(f);
+  if (!r.ok || memcmp(magic, kMagic, sizeof kMagic) != 0) { err = path + " is not an index image of this library version"; return ANX_EINVAL; }
   return ANX_OK;
 }
 

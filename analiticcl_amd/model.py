@@ -182,12 +182,15 @@ def _offsets(offs, n: int) -> List[int]:
 class Batch:
     """A batch of queries encoded and resident in HBM (anx_batch_*): encode once, run many times."""
 
-    def __init__(self, model: "VariantModel", inputs: Sequence[str], params: SearchParameters):
+    def __init__(self, model: "VariantModel", inputs: Sequence[str], params: SearchParameters, packed: Optional[bytes] = None,
+                 n: Optional[int] = None):
+        """inputs: the query strings; or packed + n: the same as ONE bytes object, every input followed by a NUL byte (what a
+        caller that reads its queries from a file or a socket already has: the buffer goes to the device as it is)."""
         self.model = model
-        self.n = len(inputs)
         cp = params._c()
         # one NUL-terminated buffer instead of a pointer array (anx_batch_encode_packed)
-        blob = _pack(inputs)
+        blob = _pack(inputs) if packed is None else packed
+        self.n = len(inputs) if packed is None else int(n)
         self.h = L.lib().anx_batch_encode_packed(model.h, blob, len(blob), self.n, C.byref(cp))
         if not self.h:
             raise L.AnxError(L.ANX_ENODEVICE if "device" in L.last_error() else L.ANX_EINVAL, L.last_error())
@@ -341,6 +344,21 @@ class VariantModel:
         self.__dict__.pop("_vocab_cache", None)
         L.check(L.lib().anx_model_build(self.h, self.device))
 
+    def set_index_tag(self, tag: str):
+        """Stored in the image save_index writes: what the model was built from (see index_tag_of)."""
+        L.check(L.lib().anx_model_set_index_tag(self.h, _b(tag)))
+
+    @staticmethod
+    def index_tag_of(filename: str) -> Optional[str]:
+        """The tag of an index image without loading it; None if the file is not an image of this library version."""
+        p = L.lib().anx_index_read_tag(_b(filename))
+        if not p:
+            return None
+        try:
+            return C.string_at(p).decode("utf-8", "replace")
+        finally:
+            L.lib().anx_string_free(p)
+
     def save_index(self, filename: str):
         """Write the built model (vocabulary + the lexicon image the GPU consumes) to disk (anx_model_save_index)."""
         L.check(L.lib().anx_model_save_index(self.h, _b(filename)))
@@ -387,6 +405,10 @@ class VariantModel:
         return int(buf.value)
 
     # -- the hot path ---------------------------------------------------------------------------------
+    def encode_packed(self, packed: bytes, n: int, params: SearchParameters) -> Batch:
+        """encode_batch for n inputs already packed into one bytes object, each followed by a NUL byte."""
+        return Batch(self, (), params, packed=packed, n=n)
+
     def encode_batch(self, inputs: Sequence[str], params: SearchParameters) -> Batch:
         return Batch(self, inputs, params)
 

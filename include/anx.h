@@ -131,6 +131,12 @@ int anx_model_build(anx_model *, int device);
  * on every start (src/lib.rs:192-245).  Confusables are not part of the image. */
 int anx_model_save_index(const anx_model *, const char *path);
 int anx_model_load_index(anx_model *, const char *path, int device);
+/* The image stores a caller-chosen tag (any UTF-8 string; default empty) describing what it was built from -- e.g. the list of
+ * resource files with sizes and content hashes -- so that a front end can tell a stale image from a current one before loading
+ * it (`analiticcl_amd` CLI: --index-cache rebuilds when the tag differs).  set: before anx_model_save_index; read: the tag of
+ * an image file without loading it, as a malloc'd string (anx_string_free), or NULL + anx_last_error(). */
+int anx_model_set_index_tag(anx_model *, const char *tag_utf8);
+char *anx_index_read_tag(const char *path);
 /* names of the lexicons read so far (VariantModel::lexicons, src/lib.rs:84): bit i of a vocab item's lexindex */
 uint64_t anx_model_num_lexicons(const anx_model *);
 const char *anx_model_lexicon_name(const anx_model *, uint64_t i);

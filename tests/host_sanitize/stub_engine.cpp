@@ -1,5 +1,6 @@
 // Device side replaced by "no device" stubs so that the HOST code of libanx (model, index, confusables, context rules,
 // index image, formatters, C ABI) can run under AddressSanitizer / UBSan on a box without a GPU.  Test infrastructure.
+#include <cstdlib>
 #include "../../analiticcl_amd/csrc/engine.h"
 
 namespace anx {
@@ -7,6 +8,8 @@ int device_count(std::string& err) { err = "stub: no device"; return 0; }
 DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, int, std::string& err) { err = "stub: no device"; return nullptr; }
 void lexicon_free(DeviceLexicon*) {}
 void device_pool_trim(int) {}
+void* host_result_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void host_result_free(void* p) { free(p); }
 Batch* batch_encode(const HostModel&, const DeviceLexicon*, const char* const*, size_t, const anx_params&, std::string& err, int* code) {
   err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
 }

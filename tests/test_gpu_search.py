@@ -400,6 +400,18 @@ def test_cli_index_cache_roundtrip(data_dir, tmp_path, capsys):
         assert cache.exists()
     assert outs[0] == outs[1]
     assert outs[0][0].startswith("seperate\tseparate\t0.734375\t") and '"input": "recieve"' in outs[0][1]
+    # a stale image must not be used: the same cache file with an EDITED lexicon (the misspelling itself added) is rebuilt
+    lex2 = tmp_path / "edited.lexicon"
+    with open(os.path.join(data_dir, "eng.aspell.lexicon"), encoding="utf-8") as f:
+        lex2.write_text(f.read() + "seperate\n", encoding="utf-8")
+    base2 = ["--lexicon", str(lex2), "--alphabet", os.path.join(data_dir, "simple.alphabet.tsv"), "--index-cache", str(cache)]
+    tag_before = A.VariantModel.index_tag_of(str(cache))
+    assert cli.main(["query"] + base2 + [str(inp)]) == 0
+    assert capsys.readouterr().out.startswith("seperate\tseperate\t1\t")
+    assert A.VariantModel.index_tag_of(str(cache)) != tag_before          # rewritten for the new resource list
+    assert cli.main(["query"] + base + [str(inp)]) == 0                   # and back: rebuilt again, not served from the edited image
+    assert capsys.readouterr().out == outs[0][0]
+    assert A.VariantModel.index_tag_of(str(tmp_path / "nonexistent.idx")) is None
 
 
 def test_python_binding_multiple_lexicons(data_dir, tmp_path):

@@ -19,7 +19,12 @@ m.build()
 maxlen, dd = (24, 3) if lexname == "nld" else (16, 2)
 qs = synth.make_queries(synth.load_lexicon_words(d[lexname]), 1000000, max_len=maxlen)
 p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=dd, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
-for rep in range(2):
+for rep in range(3):
     t = time.time(); b = m.encode_batch(qs, p); t1 = time.time(); b.run(); t2 = time.time(); r = b.fetch_arrays(); t3 = time.time()
-    print("encode %.3f s  run %.3f s  fetch%s %.3f s  -> %.2f M queries/s end to end" % (t1 - t, t2 - t1, " + rescoring" if conf else "", t3 - t2, 1.0 / (t3 - t)))
-    b.free()
+    print("from a list of str: encode %.3f s  run %.3f s  fetch%s %.3f s  -> %.2f M queries/s end to end" % (t1 - t, t2 - t1, " + rescoring" if conf else "", t3 - t2, 1.0 / (t3 - t)))
+    b.free(); del r
+packed = ("\0".join(qs) + "\0").encode("utf-8")
+for rep in range(4):
+    t = time.time(); b = m.encode_packed(packed, len(qs), p); t1 = time.time(); b.run(); t2 = time.time(); r = b.fetch_arrays(); t3 = time.time()
+    print("from a packed buffer: encode %.4f s  run %.4f s  fetch%s %.4f s  -> %.2f M queries/s end to end" % (t1 - t, t2 - t1, " + rescoring" if conf else "", t3 - t2, 1.0 / (t3 - t)))
+    b.free(); del r
