@@ -151,6 +151,8 @@ def lib():
         "anx_batch_encode": (vp, [vp, C.POINTER(cp), sz, C.POINTER(Params)]),
         "anx_batch_encode_packed": (vp, [vp, C.c_char_p, sz, sz, C.POINTER(Params)]),
         "anx_batch_run": (C.c_int, [vp, vp, vp]),
+        "anx_batch_run_async": (C.c_int, [vp, vp, vp]),
+        "anx_batch_wait": (C.c_int, [vp, vp]),
         "anx_batch_fetch": (C.c_int, [vp, C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
         "anx_batch_fetch_pairs": (C.c_int, [vp, C.POINTER(C.POINTER(Pair)), C.POINTER(sz)]),
         "anx_pairs_free": (None, [C.POINTER(Pair)]),

@@ -565,6 +565,18 @@ int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
   int rc = anx::batch_run(m->host, m->dev, b->b, stream, err);
   return rc ? fail(rc, err) : ANX_OK;
 }
+int anx_batch_run_async(const anx_model* m, anx_batch* b, void* stream) {
+  if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");
+  std::string err;
+  int rc = anx::batch_run_async(m->host, m->dev, b->b, stream, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
+int anx_batch_wait(const anx_model* m, anx_batch* b) {
+  if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");
+  std::string err;
+  int rc = anx::batch_wait(m->host, m->dev, b->b, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
 int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   if (!b || !rows || !offs) return fail(ANX_EINVAL, "NULL argument");
   std::string err;

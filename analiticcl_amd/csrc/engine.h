@@ -25,6 +25,9 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, const uint32_t* off, size_t n,
                           const anx_params& p, std::string& err, int* code);
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
+// the same in two halves: enqueue on `stream` and return / wait for it (statistics, results usable afterwards)
+int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
+int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::string& err);
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err);
 int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_pair** out, size_t* n,

@@ -684,6 +684,7 @@ static int encode_tail(Batch* b, std::string& err) {
   HIP_TRY(hipEventCreate(&b->ev_fs0));
   HIP_TRY(hipEventCreate(&b->ev_fs1));
   HIP_TRY(hipEventCreate(&b->ev_scan0));
+  HIP_TRY(hipEventCreate(&b->ev_done));
   return ANX_OK;
 }
 
@@ -816,7 +817,17 @@ static int ensure_surv(Batch* b, size_t cap, std::string& err) {
   return ANX_OK;
 }
 
-int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
+// ---- one run of the pipeline = batch_launch (everything enqueued on the stream, NO host round trip in between) + batch_finish
+// (wait for the read-back, check the capacities the launch assumed, statistics).  The launch sizes its grids and buffers from the
+// previous run of the batch (first run: estimates); every kernel bounds-checks its appends, the fills come back with the one
+// read-back at the end, and a run whose assumptions did not hold is repeated with the measured sizes.
+enum { HR_RCTR = 0, HR_SCTR = SCAN_REGIONS * RC_STRIDE, HR_LCTR = 2 * SCAN_REGIONS * RC_STRIDE, HR_CTR = 5 * SCAN_REGIONS * RC_STRIDE,
+       HR_TOTAL_SURV = HR_CTR + CTR_N, HR_TOTAL_RESULTS = HR_TOTAL_SURV + 1, HR_N = HR_TOTAL_RESULTS + 1 };
+
+// ANX_CAP_DIV=n (tests): the first-run capacity ESTIMATES are divided by n, so that the overflow -> regrow -> repeat path runs
+static size_t cap_div() { const char* e = getenv("ANX_CAP_DIV"); const long v = e ? atol(e) : 0; return v > 1 ? (size_t)v : 1; }
+
+static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
   if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
   if (b->nq >= (1u << 27) || dl->nentries >= (1u << 27)) { err = "more than 2^27 queries per batch or lexicon entries (32-bit record offsets)"; return ANX_ELIMIT; }
   HIP_TRY(hipSetDevice(dl->device));
@@ -824,74 +835,54 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   const uint32_t nq = (uint32_t)b->nq;
   b->last_stream = stream;
   b->ran = false;
+  b->launched = false;
   b->ran_keep_all = b->keep_all_pairs;  // the run that also stores the per-slot outputs the debug fetch of every pair reads
   b->n_pairs = b->n_results = b->n_surv = 0;
   b->n_raw = 0;
   if (nq == 0) { b->ran = true; return ANX_OK; }
   const int stop = b->params.stop_at_exact_match ? 1 : 0;
   int rc;
-  if (b->raw_cap == 0 && (rc = ensure_raw(b, (nq * (size_t)140 + (size_t)b->ntiles * SCAN_CHUNK) / SCAN_REGIONS + 4096, err)))
+  if (b->raw_cap == 0 && (rc = ensure_raw(b, (nq * (size_t)140 + (size_t)b->ntiles * SCAN_CHUNK) / SCAN_REGIONS / cap_div() + 4096, err)))
     return rc;
-  uint32_t h_counters[CTR_N];
-  std::vector<uint32_t> h_rctr(SCAN_REGIONS * RC_STRIDE);
+  if (!b->h_read) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_read), HR_N * sizeof(uint32_t), hipHostMallocDefault));
+  const uint32_t region_cap = 1u << b->region_shift;
+  // slots per region the scoring grid covers: the previous fill + 1/8 (first run: the whole region; blocks beyond a region's
+  // fill return at once)
+  const uint32_t fill_cap = b->prev_maxfill ? (uint32_t)std::min<size_t>(region_cap, (size_t)b->prev_maxfill + (b->prev_maxfill >> 3) + FS_BLK) : region_cap;
+  b->fill_cap_launched = fill_cap;
   HIP_TRY(hipEventRecord(b->ev[0], st));
   // ---- scan ------------------------------------------------------------------------------------------
-  uint32_t maxfill = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(b->rctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
-    if (b->ntiles == 0) { HIP_TRY(hipEventRecord(b->ev_scan0, st)); HIP_TRY(hipEventRecord(b->ev[5], st)); }
-    if (b->ntiles) {
-      ScanArgs A;
-      A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
-      A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
-      A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
-      { const char* e = getenv("ANX_SCAN_WALK"); A.hier = (e && strcmp(e, "flat") == 0) ? 0 : 1; }
-      { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; A.chunk = v >= 32 && v <= 1024 ? (uint32_t)v : SCAN_CHUNK; }
-      A.raw = b->raw; A.region_cap = 1u << b->region_shift; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
-      A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
-      A.qpairs = nullptr;
-      if (b->count_pairs) {
-        if (!b->qpairs && (rc = dalloc(&b->qpairs, nq, err))) return rc;
-        HIP_TRY(hipMemsetAsync(b->qpairs, 0, nq * sizeof(uint32_t), st));
-        A.qpairs = b->qpairs;
-      }
-      { const char* e = getenv("ANX_SCAN_DBG"); A.dbg = e ? atoi(e) : 0; }  // read per run: tools/scan_probe.py switches it between runs
-      const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
-      switch (dl->nplanes) {
-        case 8: launch_scan<8>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-        case 16: launch_scan<16>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-        case 24: launch_scan<24>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-        case 32: launch_scan<32>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-        default: launch_scan<42>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-      }
+  HIP_TRY(hipMemsetAsync(b->counters, 0, CTR_N * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(b->rctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
+  if (b->ntiles == 0) { HIP_TRY(hipEventRecord(b->ev_scan0, st)); HIP_TRY(hipEventRecord(b->ev[5], st)); }
+  if (b->ntiles) {
+    ScanArgs A;
+    A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
+    A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
+    A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
+    { const char* e = getenv("ANX_SCAN_WALK"); A.hier = (e && strcmp(e, "flat") == 0) ? 0 : 1; }
+    { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; A.chunk = v >= 32 && v <= 1024 ? (uint32_t)v : SCAN_CHUNK; }
+    A.raw = b->raw; A.region_cap = region_cap; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
+    A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
+    A.qpairs = nullptr;
+    if (b->count_pairs) {
+      if (!b->qpairs && (rc = dalloc(&b->qpairs, nq, err))) return rc;
+      HIP_TRY(hipMemsetAsync(b->qpairs, 0, nq * sizeof(uint32_t), st));
+      A.qpairs = b->qpairs;
     }
-    HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->rctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    maxfill = 0;
-    for (uint32_t r = 0; r < SCAN_REGIONS; ++r) maxfill = std::max(maxfill, h_rctr[r * RC_STRIDE + RC_RAW]);
-    if (maxfill <= (1u << b->region_shift)) break;
-    if (attempt == 1) { err = "pair list overflow after regrow"; return ANX_ENODEVICE; }
-    if ((rc = ensure_raw(b, (size_t)maxfill + (maxfill >> 3) + 4096, err))) return rc;
+    { const char* e = getenv("ANX_SCAN_DBG"); A.dbg = e ? atoi(e) : 0; }  // read per run: tools/scan_probe.py switches it between runs
+    const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
+    switch (dl->nplanes) {
+      case 8: launch_scan<8>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      case 16: launch_scan<16>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      case 24: launch_scan<24>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      case 32: launch_scan<32>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      default: launch_scan<42>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+    }
   }
+  HIP_TRY(hipMemcpyAsync(b->h_read + HR_RCTR, b->rctr, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(b->ev[1], st));
-  uint64_t n_valid = 0, n_slots = 0;
-  b->n_class_tests = 0;
-  for (int i = 0; i <= NBITPLANES; ++i) b->n_tests_kind[i] = 0;
-  for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
-    const uint32_t* c = &h_rctr[r * RC_STRIDE];
-    b->region_fill[r] = c[RC_RAW];
-    n_slots += c[RC_RAW];
-    n_valid += c[RC_VALID];
-    for (int i = 0; i <= NBITPLANES; ++i) {
-      uint64_t v;
-      memcpy(&v, c + RC_TESTS + 2 * i, sizeof v);
-      b->n_tests_kind[i] += v;
-      b->n_class_tests += v;
-    }
-  }
-  const uint32_t nraw = maxfill ? (uint32_t)(SCAN_REGIONS << b->region_shift) : 0;  // slot space (regions are sparse)
-  b->n_raw = nraw;
+  b->n_raw = (uint32_t)(SCAN_REGIONS << b->region_shift);  // slot space (regions are sparse)
   // ---- score -----------------------------------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(b->qsurv, 0, nq * sizeof(uint32_t), st));
   HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
@@ -921,18 +912,22 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   // fused prefilter + register DL (ANX_PREFILTER=0 disables the filter: every length-compatible pair goes to the DL)
   SurvOut so{nullptr, b->sctr, 0};
   const bool have_long_q = b->qw > 1;
-  if (nraw) {
+  {
     static const int enable_filter = []() { const char* e = getenv("ANX_PREFILTER"); return (e && e[0] == '0') ? 0 : 1; }();
     static const int enable_fast = []() { const char* e = getenv("ANX_SCORE_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
     const int fastD = (enable_fast && d >= 1 && d <= 3) ? (int)d : 0;
-    // survivor records: region r of the survivor list takes the survivors of region r of the pair list (<= maxfill)
-    if ((size_t)maxfill > b->surv_region_cap) {
-      if (b->surv) pool_free(b->surv);
-      b->surv = nullptr;
-      b->surv_region_cap = 0;
-      const size_t need = (size_t)maxfill + (maxfill >> 3) + 256;
-      if ((rc = dalloc(&b->surv, need * SCAN_REGIONS, err))) return rc;
-      b->surv_region_cap = need;
+    // survivor records: region r of the survivor list takes the survivors of region r of the pair list.  Sized from the
+    // previous run (first run: half the slots the grid covers -- ~10 % of the slots survive on config 2); an overflow is
+    // detected by batch_finish and the run repeated with the measured size
+    {
+      const size_t need = b->prev_surv_fill ? (size_t)b->prev_surv_fill + (b->prev_surv_fill >> 3) + 256 : (size_t)fill_cap / 2 / cap_div() + 256;
+      if (need > b->surv_region_cap) {
+        if (b->surv) pool_free(b->surv);
+        b->surv = nullptr;
+        b->surv_region_cap = 0;
+        if ((rc = dalloc(&b->surv, need * SCAN_REGIONS, err))) return rc;
+        b->surv_region_cap = need;
+      }
     }
     so.list = b->surv;
     so.region_cap = (uint32_t)b->surv_region_cap;
@@ -940,15 +935,18 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     // batch has such queries) and everything else (longer strings, d > 3, or the few long candidates of a short-query
     // batch: for those the general kernel is cheaper than the 8-word one, measured 0.10 vs 0.22 ms on config 2)
     const bool need_lists = !fastD || have_long_q || dl->max_len > 16;
-    if (need_lists && (size_t)maxfill > b->list_cap) {
-      for (void* p : {(void*)b->list8, (void*)b->listg, (void*)b->listw})
-        if (p) pool_free(p);
-      b->list8 = b->listg = b->listw = nullptr;
-      b->list_cap = 0;
-      const size_t need = (size_t)maxfill + (maxfill >> 3) + 256;
-      if ((rc = dalloc(&b->list8, need * SCAN_REGIONS, err)) || (rc = dalloc(&b->listg, need * SCAN_REGIONS, err)) ||
-          (rc = dalloc(&b->listw, need * SCAN_REGIONS, err))) return rc;
-      b->list_cap = need;
+    if (need_lists) {
+      // without the inline DL (d > 3) every length-compatible pair goes to the general list; else the prefilter passes ~1/3
+      const size_t need = b->prev_list_fill ? (size_t)b->prev_list_fill + (b->prev_list_fill >> 3) + 256 : (fastD ? (size_t)fill_cap / 2 : (size_t)fill_cap) / cap_div() + 256;
+      if (need > b->list_cap) {
+        for (void* p : {(void*)b->list8, (void*)b->listg, (void*)b->listw})
+          if (p) pool_free(p);
+        b->list8 = b->listg = b->listw = nullptr;
+        b->list_cap = 0;
+        if ((rc = dalloc(&b->list8, need * SCAN_REGIONS, err)) || (rc = dalloc(&b->listg, need * SCAN_REGIONS, err)) ||
+            (rc = dalloc(&b->listw, need * SCAN_REGIONS, err))) return rc;
+        b->list_cap = need;
+      }
     }
     HIP_TRY(hipMemsetAsync(b->sctr, 0, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(b->lctr, 0, 3 * SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), st));
@@ -958,8 +956,8 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand};
     FilterArgs fa;
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
-    fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr;
-    const dim3 fgrid(((maxfill + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
+    fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap;
+    const dim3 fgrid(((fill_cap + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
     HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
     // batches without long queries defer the 8-word prefilter of their few wide pairs (a 17..19-symbol candidate) to
     // k_filter_wide: without that state the fused kernel fits 8 waves per SIMD
@@ -977,7 +975,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
       else hipLaunchKernelGGL((k_filter_score<0, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
     }
     HIP_TRY(hipEventRecord(b->ev_fs1, st));
-    if (need_lists) {  // the list fills are only known on the device: grids cover the fullest pair-list region
+    if (need_lists) {  // the list fills are only known on the device: fixed grids walk the lists in strides
       const dim3 lgrid(LIST_P * SCAN_REGIONS);
       if (split_wide && enable_filter) hipLaunchKernelGGL(k_filter_wide, lgrid, dim3(256), 0, st, lw, fa, pa, sa, fastD, l8, lg);
       if (fastD && have_long_q) {
@@ -998,34 +996,21 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   ra.have_freq = m.have_freq ? 1 : 0;
   ra.any_variants = dl->any_variants;
   exclusive_scan(b->qsurv, nq, b->soff, b->scan_tmp, st);
-  uint32_t total_surv = 0, total_results = 0, surv_fill = 0;
-  uint64_t nsel = 0;
-  auto read_counts = [&]() -> int {  // (the only read-back between the scan and the end of the run)
-    HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_counters, b->counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
-    if (nraw) HIP_TRY(hipMemcpyAsync(h_rctr.data(), b->sctr, h_rctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    return ANX_OK;
-  };
-  auto use_counts = [&]() {
-    b->n_pairs = n_valid - h_counters[CTR_SKIPPED];
-    b->n_surv = total_surv;
-    surv_fill = 0;
-    nsel = 0;
-    if (nraw)
-      for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
-        surv_fill = std::max(surv_fill, h_rctr[r * RC_STRIDE]);
-        nsel += h_rctr[r * RC_STRIDE + 1];
-      }
-    b->n_sel = nsel;
-  };
+  HIP_TRY(hipMemcpyAsync(b->qcur, b->soff, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));  // cursors of the compaction
   if (dl->any_variants) {
-    // variant lists: a survivor expands to several rows; the grid of k_compact comes from the survivor counts
-    HIP_TRY(hipMemcpyAsync(b->qcur, b->soff, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));  // cursors of k_compact
-    if ((rc = read_counts())) return rc;
+    // variant lists: a survivor expands to several rows; the row buffer and the grid of k_compact come from the survivor
+    // counts, so this (rare) configuration keeps one host round trip in the middle of the run
+    uint32_t total_surv = 0;
+    HIP_TRY(hipMemcpyAsync(&total_surv, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b->h_read + HR_SCTR, b->sctr, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    use_counts();
+    uint32_t surv_fill = 0;
+    for (uint32_t r = 0; r < SCAN_REGIONS; ++r) surv_fill = std::max(surv_fill, b->h_read[HR_SCTR + r * RC_STRIDE]);
+    if ((size_t)surv_fill > b->surv_region_cap) {  // survivor records were dropped: nothing of this run is used (batch_finish repeats it)
+      surv_fill = 0;
+      HIP_TRY(hipMemsetAsync(b->counters + CTR_OVERFLOW, 0xFF, sizeof(uint32_t), st));
+    }
     if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
-    if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
     if (surv_fill) {
       CompactArgs ca{m.have_freq ? 1 : 0, dl->any_variants};
       hipLaunchKernelGGL(k_compact, dim3(((surv_fill + 255) / 256) * SCAN_REGIONS), dim3(256), 0, st, b->surv, b->sctr,
@@ -1034,41 +1019,89 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
     }
     HIP_TRY(hipEventRecord(b->ev[3], st));
     hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
-                       b->qexpand, ra, b->t_key, b->r_rows, b->r_count, 0xFFFFFFFFu);
-    exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st, b->counters + CTR_MAXROWS);
-    HIP_TRY(hipEventRecord(b->ev[4], st));
-    HIP_TRY(hipMemcpyAsync(&total_results, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&h_counters[CTR_MAXROWS], b->counters + CTR_MAXROWS, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+                       b->qexpand, ra, b->t_key, b->r_rows, b->r_count, 0xFFFFFFFFu, b->counters + CTR_OVERFLOW);
   } else {
     // No host round trip between scoring and ranking: the row buffers keep the size of the previous run (first run:
-    // an estimate), the kernels check the total on the device, and in the rare case it does not fit the host grows the
-    // buffers and repeats compaction + ranking.
-    for (int attempt = 0;; ++attempt) {
-      if (b->surv_cap == 0 && (rc = ensure_surv(b, (size_t)nq * 16 + 1024, err))) return rc;
-      const uint32_t row_cap = (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu);
-      HIP_TRY(hipMemcpyAsync(b->qcur, b->soff, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));  // cursors of the compaction
-      if (nraw)
-        hipLaunchKernelGGL(k_compact_grouped, dim3(COMPACT_P * SCAN_REGIONS), dim3(COMPACT_B), 0, st, b->surv, b->sctr,
-                           (uint32_t)b->surv_region_cap, m.have_freq ? 1 : 0, b->qcur, dl->ent_rec, b->c_rows, b->soff + nq, row_cap);
-      HIP_TRY(hipEventRecord(b->ev[3], st));
-      hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
-                         b->qexpand, ra, b->t_key, b->r_rows, b->r_count, row_cap);
-      exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st, b->counters + CTR_MAXROWS);
-      HIP_TRY(hipEventRecord(b->ev[4], st));
-      if ((rc = read_counts())) return rc;
-      HIP_TRY(hipMemcpyAsync(&total_results, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      use_counts();
-      if (surv_fill > b->surv_region_cap) { err = "survivor region overflow"; return ANX_ENODEVICE; }  // cannot happen: see the sizing above
-      if ((size_t)total_surv <= b->surv_cap) break;
-      if (attempt == 1) { err = "candidate rows do not fit after regrow"; return ANX_ENODEVICE; }
-      if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
-    }
+    // an estimate), the kernels check the total on the device, and batch_finish repeats the run if it did not fit.
+    if (b->surv_cap == 0 && (rc = ensure_surv(b, (size_t)nq * 16 / cap_div() + 1024, err))) return rc;
+    const uint32_t row_cap = (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(k_compact_grouped, dim3(COMPACT_P * SCAN_REGIONS), dim3(COMPACT_B), 0, st, b->surv, b->sctr,
+                       (uint32_t)b->surv_region_cap, m.have_freq ? 1 : 0, b->qcur, dl->ent_rec, b->c_rows, b->soff + nq, row_cap,
+                       b->counters + CTR_OVERFLOW);
+    HIP_TRY(hipEventRecord(b->ev[3], st));
+    hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
+                       b->qexpand, ra, b->t_key, b->r_rows, b->r_count, row_cap, b->counters + CTR_OVERFLOW);
   }
+  exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st, b->counters + CTR_MAXROWS);
+  HIP_TRY(hipEventRecord(b->ev[4], st));
+  // ---- the read-back of the run --------------------------------------------------------------------------
+  HIP_TRY(hipMemcpyAsync(b->h_read + HR_SCTR, b->sctr, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_read + HR_LCTR, b->lctr, 3 * SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_read + HR_CTR, b->counters, CTR_N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_read + HR_TOTAL_SURV, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_read + HR_TOTAL_RESULTS, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(b->ev_done, st));
   HIP_TRY(hipGetLastError());
+  b->launched = true;
+  return ANX_OK;
+}
+
+// Waits for the launched run.  Returns ANX_OK with *retry = false when the run stands; *retry = true when a capacity the launch
+// assumed was exceeded (the buffers have been regrown: launch again).
+static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, bool* retry, std::string& err) {
+  (void)m;
+  *retry = false;
+  if (!b->launched) return ANX_OK;  // empty batch
+  HIP_TRY(hipSetDevice(dl->device));
+  HIP_TRY(hipEventSynchronize(b->ev_done));
+  b->launched = false;
+  const uint32_t nq = (uint32_t)b->nq;
+  const uint32_t* h = b->h_read;
+  uint32_t maxfill = 0, surv_fill = 0, list_fill = 0;
+  uint64_t n_valid = 0, n_slots = 0, nsel = 0;
+  b->n_class_tests = 0;
+  for (int i = 0; i <= NBITPLANES; ++i) b->n_tests_kind[i] = 0;
+  for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
+    const uint32_t* c = h + HR_RCTR + r * RC_STRIDE;
+    maxfill = std::max(maxfill, c[RC_RAW]);
+    b->region_fill[r] = c[RC_RAW];
+    n_slots += c[RC_RAW];
+    n_valid += c[RC_VALID];
+    for (int i = 0; i <= NBITPLANES; ++i) {
+      uint64_t v;
+      memcpy(&v, c + RC_TESTS + 2 * i, sizeof v);
+      b->n_tests_kind[i] += v;
+      b->n_class_tests += v;
+    }
+    surv_fill = std::max(surv_fill, h[HR_SCTR + r * RC_STRIDE]);
+    nsel += h[HR_SCTR + r * RC_STRIDE + 1];
+    for (int l = 0; l < 3; ++l) list_fill = std::max(list_fill, h[HR_LCTR + (l * SCAN_REGIONS + r) * RC_STRIDE]);
+  }
+  const uint32_t total_surv = h[HR_TOTAL_SURV], total_results = h[HR_TOTAL_RESULTS];
+  // ---- did the run fit what the launch assumed? ------------------------------------------------------------
+  int rc;
+  bool again = false;
+  if (maxfill > (1u << b->region_shift)) {  // pair list
+    if ((rc = ensure_raw(b, (size_t)maxfill + (maxfill >> 3) + 4096, err))) return rc;
+    again = true;
+  }
+  if (maxfill > b->fill_cap_launched) again = true;  // slots the scoring grid did not cover
+  if ((size_t)surv_fill > b->surv_region_cap) again = true;
+  if (list_fill && (size_t)list_fill > b->list_cap) again = true;
+  if (!dl->any_variants && (size_t)total_surv > b->surv_cap) {
+    if ((rc = ensure_surv(b, (size_t)total_surv + (total_surv >> 2) + 1024, err))) return rc;
+    again = true;
+  }
+  b->prev_maxfill = std::max(b->prev_maxfill, maxfill);
+  b->prev_surv_fill = std::max(b->prev_surv_fill, surv_fill);
+  b->prev_list_fill = std::max(b->prev_list_fill, list_fill);
+  if (again) { *retry = true; return ANX_OK; }
+  if (maxfill == 0) b->n_raw = 0;
+  b->n_pairs = n_valid - h[HR_CTR + CTR_SKIPPED];
+  b->n_surv = total_surv;
+  b->n_sel = nsel;
   b->n_results = total_results;
-  b->max_rows = h_counters[CTR_MAXROWS];
+  b->max_rows = h[HR_CTR + CTR_MAXROWS];
   b->ran = true;
   anx_batch_stats& s = b->stats;
   s.n_queries = nq;
@@ -1086,9 +1119,28 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   (void)hipEventElapsedTime(&s.ms_rank, b->ev[3], b->ev[4]);
   (void)hipEventElapsedTime(&s.ms_total, b->ev[0], b->ev[4]);
   (void)hipEventElapsedTime(&s.ms_scan_kernel, b->ev_scan0, b->ev[5]);
-  s.ms_filter_score_kernel = 0.0f;
-  if (nraw) (void)hipEventElapsedTime(&s.ms_filter_score_kernel, b->ev_fs0, b->ev_fs1);
+  (void)hipEventElapsedTime(&s.ms_filter_score_kernel, b->ev_fs0, b->ev_fs1);
   return ANX_OK;
+}
+
+// asynchronous form: enqueue the run on `stream` and return; batch_wait completes it (repeating it synchronously in the rare
+// case a capacity estimate did not hold).  Several batches in flight on different streams overlap the latency-bound tail of
+// one run (compaction, ranking) with the scan of the next.
+int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
+  return batch_launch(m, dl, b, stream, err);
+}
+int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::string& err) {
+  for (int attempt = 0;; ++attempt) {
+    bool retry = false;
+    int rc = batch_finish(m, dl, b, &retry, err);
+    if (rc || !retry) return rc;
+    if (attempt == 3) { err = "the run did not fit its buffers after three regrows"; return ANX_ENODEVICE; }
+    if ((rc = batch_launch(m, dl, b, b->last_stream, err))) return rc;
+  }
+}
+int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
+  const int rc = batch_launch(m, dl, b, stream, err);
+  return rc ? rc : batch_wait(m, dl, b, err);
 }
 
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
@@ -1278,6 +1330,7 @@ void batch_free(Batch* b) {
   // the export kernels are asynchronous on the caller's stream and read this batch's buffers: they must have finished
   // before the blocks go back to the pool, where another batch / thread / stream may take them at once
   if (b->async_pending) (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(b->async_stream));
+  if (b->launched) (void)hipEventSynchronize(b->ev_done);  // a run enqueued with batch_run_async and never waited for
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->qpairs, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
@@ -1286,6 +1339,8 @@ void batch_free(Batch* b) {
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
+  if (b->ev_done) (void)hipEventDestroy(b->ev_done);
+  if (b->h_read) (void)hipHostFree(b->h_read);
   if (b->ev_fs0) (void)hipEventDestroy(b->ev_fs0);
   if (b->ev_fs1) (void)hipEventDestroy(b->ev_fs1);
   delete b;

@@ -71,7 +71,7 @@ struct DeviceLexicon {
   size_t bytes = 0;
 };
 
-enum { CTR_SKIPPED = 2, CTR_MAXROWS = 3 /* longest ranked list of the run */, CTR_N = 8 };
+enum { CTR_SKIPPED = 2, CTR_MAXROWS = 3 /* longest ranked list of the run */, CTR_OVERFLOW = 4 /* survivor records dropped */, CTR_N = 8 };
 
 struct SurvRow {  // one candidate result row of a query (k_compact -> k_rank); 32 B, written / read as two 16-B words
   double score;            // dist_score (times the variant score for expanded rows)
@@ -158,6 +158,11 @@ struct Batch {
   hipEvent_t ev[6] = {};
   hipEvent_t ev_scan0 = nullptr;   // just before the scan kernels (after the counter memsets)
   hipEvent_t ev_fs0 = nullptr, ev_fs1 = nullptr;  // around k_filter_score
+  hipEvent_t ev_done = nullptr;    // after the read-back of a launched run
+  uint32_t* h_read = nullptr;      // pinned: counters of the launched run (engine.hip HR_*)
+  bool launched = false;           // a run is enqueued and not yet finished
+  uint32_t fill_cap_launched = 0;  // slots per region the scoring grid of the launched run covers
+  uint32_t prev_maxfill = 0, prev_surv_fill = 0, prev_list_fill = 0;  // largest fills seen by earlier runs of this batch
   anx_batch_stats stats = {};
 };
 

@@ -55,10 +55,15 @@ constexpr uint32_t COMPACT_P = 16;                      // blocks per region: ea
 __global__ __launch_bounds__(COMPACT_B) void k_compact_grouped(const SurvRec* __restrict__ surv, const uint32_t* __restrict__ sctr,
                                                                uint32_t region_cap, int have_freq, uint32_t* __restrict__ qcur,
                                                                const EntRec* __restrict__ ent_rec, SurvRow* __restrict__ c_rows,
-                                                               const uint32_t* __restrict__ total_rows, uint32_t row_cap) {
+                                                               const uint32_t* __restrict__ total_rows, uint32_t row_cap, uint32_t* __restrict__ overflow) {
   __shared__ uint32_t h_key[COMPACT_H], h_cnt[COMPACT_H], h_base[COMPACT_H];
   if (*total_rows > row_cap) return;
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = sctr[region * RC_STRIDE];
+  const uint32_t region = blockIdx.x % SCAN_REGIONS;
+  uint32_t fill = sctr[region * RC_STRIDE];
+  if (fill > region_cap) {  // survivors were dropped: the per-query counts no longer match the records; ranking is skipped and
+    fill = region_cap;      // the host repeats the run with a larger survivor list
+    if (threadIdx.x == 0) *overflow = 1u;
+  }
   for (uint32_t i0 = (blockIdx.x / SCAN_REGIONS) * COMPACT_B; i0 < fill; i0 += COMPACT_P * COMPACT_B) {  // block-uniform
     for (uint32_t h = threadIdx.x; h < COMPACT_H; h += COMPACT_B) { h_key[h] = 0xFFFFFFFFu; h_cnt[h] = 0; }
     __syncthreads();
@@ -457,9 +462,11 @@ __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __res
                                               const uint32_t* __restrict__ qmaxfreq,
                                               const uint32_t* __restrict__ qexpand, RankArgs a,
                                               double* __restrict__ t_key, DevRow* __restrict__ r_rows,
-                                              uint32_t* __restrict__ r_count, uint32_t row_cap) {
+                                              uint32_t* __restrict__ r_count, uint32_t row_cap, const uint32_t* __restrict__ overflow) {
   __shared__ __attribute__((aligned(16))) uint8_t s_raw[4 * RANK_WAVE_BYTES];
-  if (soff[nq] > row_cap) return;  // more candidate rows than c_rows / r_rows hold: the host grows them and repeats (k_compact_grouped)
+  // more candidate rows than c_rows / r_rows hold, or survivor records dropped (k_compact_grouped): the host grows the buffers
+  // and repeats the run; nothing of this one is used
+  if (soff[nq] > row_cap || *overflow) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   uint8_t* wl = s_raw + wid * RANK_WAVE_BYTES;
   const uint32_t qbase = (blockIdx.x * 4 + wid) * RANK_QPW;

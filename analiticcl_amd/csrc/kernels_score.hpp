@@ -422,6 +422,7 @@ struct FilterArgs {
   int use_nw8;              // selected pairs of 17..32 symbols go to list8 (else to the general list)
   uint32_t* counters;
   uint32_t* stat_ctr;       // [SCAN_REGIONS][RC_STRIDE], word 1: selected pairs
+  uint32_t fill_cap;        // slots per region the grid covers (a region filled beyond it makes batch_finish repeat the run)
 };
 // WIDE = true: the 8-word prefilter of pairs with a string of 17..32 symbols runs inline (batches with such queries: many
 // wide pairs).  WIDE = false (every query <= 16 symbols, so only the few pairs with a 17..19-symbol candidate are wide):
@@ -556,7 +557,7 @@ constexpr uint32_t LIST_P = 64;  // blocks per region of the slot-list kernels
 // The 8-word band-match prefilter of the wide pairs k_filter_score<D, false> deferred (listw): survivors go to the slot
 // list of the 8-word kernel (fastD > 0 and the batch uses it) or of the general kernel.
 __global__ __launch_bounds__(256) void k_filter_wide(SlotList in, FilterArgs f, PairArgs A, ScoreArgs a, int fastD, SlotList list8, SlotList listg) {
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = in.ctr[region * RC_STRIDE], lane = threadIdx.x & 63;
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = min(in.ctr[region * RC_STRIDE], in.region_cap), lane = threadIdx.x & 63;  // (a list filled beyond its capacity makes the host repeat the run)
   uint32_t nselected = 0;  // wave-uniform
   for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += LIST_P) {  // block-uniform
     const uint32_t i = blk * 256 + threadIdx.x;
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, Sc
   __shared__ uint32_t s_str[256 * 17];
   // LIST_P blocks per region walk the region's slot list in strides: the list fills are only known on the device, and a
   // grid sized for the fullest possible list would consist of ~400 k empty blocks (0.08 ms of dispatch on config 2)
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = in.ctr[region * RC_STRIDE];
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = min(in.ctr[region * RC_STRIDE], in.region_cap);
   for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += LIST_P) {  // block-uniform
     const uint32_t i = blk * 256 + threadIdx.x;
     const bool active = i < n;
@@ -612,7 +613,7 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
   uint32_t* __restrict__ qmaxfreq = A.qmaxfreq;
   uint32_t* __restrict__ qsurv = A.qsurv;
   uint32_t* __restrict__ qexpand = A.qexpand;
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, nsel = in.ctr[region * RC_STRIDE];
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, nsel = min(in.ctr[region * RC_STRIDE], in.region_cap);
   for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * blockDim.x < nsel; blk += LIST_P) {  // block-uniform; see k_score_fast8
   const uint32_t i_sel = blk * blockDim.x + threadIdx.x;
   bool keep = false;

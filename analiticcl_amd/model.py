@@ -199,6 +199,13 @@ class Batch:
     def run(self, stream: int = 0):
         L.check(L.lib().anx_batch_run(self.model.h, self.h, C.c_void_p(stream)))
 
+    def run_async(self, stream: int = 0):
+        """Enqueue the run on `stream` and return (anx_batch_run_async); wait() completes it."""
+        L.check(L.lib().anx_batch_run_async(self.model.h, self.h, C.c_void_p(stream)))
+
+    def wait(self):
+        L.check(L.lib().anx_batch_wait(self.model.h, self.h))
+
     def stats(self) -> dict:
         s = L.BatchStats()
         L.check(L.lib().anx_batch_get_stats(self.h, C.byref(s)))

@@ -89,7 +89,11 @@ class CompactGather:
         self.send = [torch.empty(capacity, dtype=torch.uint8, device=device) for _ in range(depth)]
         self.size_dev = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(depth)]
         self.recv = self.sizes = None
-        if rank == dst and world > 1:
+        # with an initialised process group the size exchange runs at world 1 too (one rank gathering from itself): that is
+        # what a one-GPU box can exercise of the RCCL path
+        import torch.distributed as dist
+        self.collective = world > 1 or (dist.is_available() and dist.is_initialized())
+        if rank == dst and self.collective:
             self.recv = [[torch.empty(capacity, dtype=torch.uint8, device=device) if r != dst else None
                           for r in range(world)] for _ in range(depth)]
             self.sizes = [[torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)] for _ in range(depth)]
@@ -113,7 +117,7 @@ class CompactGather:
         import torch.distributed as dist
 
         self.used[slot] = used
-        if self.world == 1:
+        if not self.collective:
             self.got[slot] = [used]
             return
         while self.order:  # payloads of earlier steps: their sizes were exchanged while this step computed

@@ -7,7 +7,8 @@ Workload (BASELINE.json configs[1]): eng.aspell lexicon (119 773 entries / 108 8
 simple.alphabet, 1 M synthetic queries of length <= 16 (generator: SURVEY.md section 8(d), seed 20240601 + rank),
 CLI defaults with max-edit-distance 2 (k=3, d=2, n=10, score threshold 0.25, cutoff 2.0).
 A "step" = one pass of the device pipeline (anagram scan -> pair grouping -> DL/LCS/prefix/suffix scoring ->
-ranking) over the whole resident query batch.  Inputs are encoded and uploaded once, before the timed region.
+ranking) over the whole resident query batch.  Inputs are encoded and uploaded once, before the timed region; two resident
+copies alternate on one stream so that the next step is enqueued while the current one runs (no host round trip inside a run).
 With N>1 every rank processes its own 1 M-query shard (weak scaling, no data-path collective) and the ranked
 compact top-k records (offsets + the rows in use) are gathered to rank 0 over RCCL once per step.
 
@@ -68,6 +69,7 @@ def main():
     ap.add_argument("--edit-distance", type=int, default=2)
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the export + gather code at N=1 too (testing)")
+    ap.add_argument("--check-gather", action="store_true", help="rank 0: decode its own gathered export of the last step and compare it with fetch()")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -90,7 +92,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the variant-query path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "WORLD_SIZE" in os.environ  # under a launcher the process group is set up at N=1 too (RCCL init + the
+    if use_dist:                                          # collectives below run with one rank: what a one-GPU box can exercise)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -106,8 +109,12 @@ def main():
     params = A.SearchParameters(max_anagram_distance=args.anagram_distance, max_edit_distance=args.edit_distance, max_matches=10,
                                 score_threshold=0.25, cutoff_threshold=2.0)
     t_enc = time.time()
-    batch = model.encode_batch(queries, params)  # host encode + H2D, outside the timed region
+    batch = model.encode_batch(queries, params)  # encode + H2D, outside the timed region
     t_enc = time.time() - t_enc
+    # Two resident copies of the batch alternate, so that step i+1 is enqueued while step i still runs: a run has no host round
+    # trip inside (anx_batch_run_async), the one read-back at its end is waited for a step later, and the stream never idles
+    # between steps.  ONE stream: the kernels of consecutive steps do not overlap, the per-kernel HIP-event times stay clean.
+    batches = [batch, model.encode_batch(queries, params)]
     stride = 11  # max_matches + 1 records per query (crop tie rule can return max_matches + 1)
     stream = torch.cuda.current_stream()
     do_gather = (world > 1 or args.force_gather) and not args.no_gather
@@ -119,17 +126,29 @@ def main():
     gather = shard.CompactGather(shard.compact_capacity(args.queries, stride + 5), "cuda", rank, world) if do_gather else None
     step_no = [0]
     gather_bytes = [0]
-
     gather_error = [None]
+    stage_ms = {"ms_scan": 0.0, "ms_group": 0.0, "ms_score": 0.0, "ms_rank": 0.0, "ms_total": 0.0}
+    kernel_ms = {"ms_scan_kernel": 0.0, "ms_filter_score_kernel": 0.0}
+    finished = [0]
+    inflight = []  # (batch index, hip stream) in launch order
 
-    def step():
-        batch.run(stream.cuda_stream)
+    def finish_oldest(collect):
+        i, hs = inflight.pop(0)
+        b = batches[i]
+        b.wait()
+        if collect:
+            st = b.stats()  # HIP-event times recorded by the library on the launch stream for this run
+            for k in stage_ms:
+                stage_ms[k] += st[k]
+            for k in kernel_ms:
+                kernel_ms[k] += st[k]
+            finished[0] += 1
         if do_gather and gather_error[0] is None:
             try:
-                i = step_no[0] & 1
-                buf = gather.acquire(i)        # the stream waits for the transfer that last used this buffer
-                used = batch.export_compact(buf.data_ptr(), buf.numel(), stream.cuda_stream)
-                gather.submit(i, used)
+                j = step_no[0] & 1
+                buf = gather.acquire(j)        # the stream waits for the transfer that last used this buffer
+                used = b.export_compact(buf.data_ptr(), buf.numel(), hs)
+                gather.submit(j, used)
                 gather_bytes[0] = used
                 step_no[0] += 1
             except Exception as e:  # noqa: BLE001
@@ -138,7 +157,16 @@ def main():
                 gather_error[0] = repr(e)[:200]  # N=1 (--force-gather): keep the compute measurement, the JSON line says what happened
                 sys.stderr.write(f"[bench] rank {rank}: result gather disabled: {gather_error[0]}\n")
 
-    def drain():
+    def step(k, hs, collect):
+        i = k & 1
+        if any(x[0] == i for x in inflight):
+            finish_oldest(collect)     # the previous run of this copy (two steps ago)
+        batches[i].run_async(hs)
+        inflight.append((i, hs))
+
+    def drain(collect):
+        while inflight:
+            finish_oldest(collect)
         if do_gather and gather_error[0] is None:
             try:
                 gather.flush()
@@ -148,39 +176,55 @@ def main():
                 gather_error[0] = repr(e)[:200]
                 sys.stderr.write(f"[bench] rank {rank}: result gather failed in flush: {gather_error[0]}\n")
 
-    def barrier():
-        drain()
+    def barrier(collect=False):
+        drain(collect)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k, stream.cuda_stream, False)
     barrier()
-    stage_ms = {"ms_scan": 0.0, "ms_group": 0.0, "ms_score": 0.0, "ms_rank": 0.0, "ms_total": 0.0}
-    sum_scan_kernel_ms = 0.0
-    sum_fs_kernel_ms = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        st = batch.stats()  # HIP-event times recorded by the library on the launch stream for this run
-        for k in stage_ms:
-            stage_ms[k] += st[k]
-        sum_scan_kernel_ms += st["ms_scan_kernel"]
-        sum_fs_kernel_ms += st["ms_filter_score_kernel"]
-    barrier()
+    for k in range(args.steps):
+        step(k, stream.cuda_stream, True)
+    barrier(True)
     elapsed = time.perf_counter() - t0
+    assert finished[0] == args.steps
+    sum_scan_kernel_ms, sum_fs_kernel_ms = kernel_ms["ms_scan_kernel"], kernel_ms["ms_filter_score_kernel"]
+    # ---- after the timed region: the same steps with the two copies on TWO streams, so that the latency-bound tail of one run
+    # (compaction, ranking) overlaps the scan of the next (reported as "overlapped"; never `value`) ------------------------
+    overlapped = None
+    if world == 1 and not do_gather:
+        s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for k in range(2):
+            step(k, s2[k & 1].cuda_stream, False)
+        barrier()
+        t1 = time.perf_counter()
+        nov = max(4, args.steps)
+        for k in range(nov):
+            step(k, s2[k & 1].cuda_stream, False)
+        barrier()
+        overlapped = (time.perf_counter() - t1) / nov
     st = batch.stats()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(st["n_pairs"]), float(st["n_queries"]), float(st["n_class_tests"])],
                        dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     pairs, nq, tests = (float(x) for x in tot.tolist())
 
+    gather_check = None
+    if rank == 0 and do_gather and args.check_gather and gather_error[0] is None:
+        last = (step_no[0] - 1) & 1
+        mine = gather.result(last)[0]           # rank 0's own export as it sits in the gather buffers
+        dec = shard.decode_compact(mine, args.queries)
+        ref = batches[0].fetch()
+        bad = sum(1 for a_, b_ in zip(dec, ref) if [(v, d) for v, d, _f in a_] != [(v, d) for v, d, _f in b_])
+        gather_check = "ok" if bad == 0 and len(dec) == len(ref) else f"{bad} of {len(ref)} inputs differ"
     if rank == 0:
         for k in stage_ms:
             stage_ms[k] /= max(args.steps, 1)
@@ -328,6 +372,9 @@ def main():
             "dp_pairs_per_s": st["n_selected"] * world * args.steps / elapsed,       # pairs that ran the banded DL
             "lcs_pairs_per_s": st["n_survivors"] * world * args.steps / elapsed,     # ... and the LCS / prefix / suffix tail
             "e2e_queries_per_s": e2e["queries_per_s"] if e2e else None, "e2e": e2e,
+            "overlapped": ({"ms_per_step": overlapped * 1e3, "pairs_per_s": pairs / overlapped, "queries_per_s": nq / overlapped,
+                            "what": "the same steps with the two resident copies of the batch on two HIP streams (compaction + ranking of one run "
+                                    "under the scan of the next), measured after the timed region"} if overlapped else None),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -341,10 +388,11 @@ def main():
                        + (f", result gather FAILED on rank 0: {gather_error[0]}" if gather_error[0] else "")},
             "stage_ms": {"scan": stage_ms["ms_scan"], "score": stage_ms["ms_score"], "compact": stage_ms["ms_group"], "rank": stage_ms["ms_rank"], "total": stage_ms["ms_total"]},
             "pair_slots": st["n_pair_slots"], "dl_pairs": st["n_selected"], "survivors": st["n_survivors"], "results": st["n_results"], "encode_upload_s": t_enc,
+            "gather_error": gather_error[0], "gather_check": gather_check, "process_group": ("nccl" if use_dist else None),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -178,6 +178,14 @@ anx_batch *anx_batch_encode(const anx_model *, const char *const *utf8, size_t n
 anx_batch *anx_batch_encode_packed(const anx_model *, const char *blob, size_t blob_len, size_t n, const anx_params *);
 /* `stream` is a hipStream_t (NULL = the default stream). Asynchronous except for one count read-back. */
 int anx_batch_run(const anx_model *, anx_batch *, void *stream);
+/* The same in two halves.  run_async enqueues the whole pipeline on `stream` and returns (no host round trip inside a run: grids
+ * and buffers are sized from the batch's previous run or from estimates, every kernel bounds-checks, one read-back at the end);
+ * wait completes it -- in the rare case an estimate did not hold it regrows the buffers and repeats the run synchronously.
+ * Batches in flight on different streams overlap: the latency-bound tail of one run (compaction, ranking) runs under the scan
+ * of the next.  anx_batch_run == run_async + wait.  (The reference's counterpart is the rayon fan-out over inputs,
+ * src/bin/analiticcl.rs:445-448: independent calls in flight at once.) */
+int anx_batch_run_async(const anx_model *, anx_batch *, void *stream);
+int anx_batch_wait(const anx_model *, anx_batch *);
 int anx_batch_fetch(const anx_batch *, anx_result **out_rows, size_t **out_offsets);
 /* every scored pair of the batch (order unspecified within a query) */
 int anx_batch_fetch_pairs(const anx_batch *, anx_pair **out_pairs, size_t *out_n);

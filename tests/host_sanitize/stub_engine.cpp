@@ -17,6 +17,8 @@ Batch* batch_encode_spans(const HostModel&, const DeviceLexicon*, const char*, c
   err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
 }
 int batch_run(const HostModel&, const DeviceLexicon*, Batch*, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
+int batch_run_async(const HostModel&, const DeviceLexicon*, Batch*, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
+int batch_wait(const HostModel&, const DeviceLexicon*, Batch*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_fetch(const HostModel&, const DeviceLexicon*, const Batch*, anx_result**, size_t**, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_fetch_pairs(const HostModel&, const DeviceLexicon*, const Batch*, anx_pair**, size_t*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_pair_counts(const HostModel&, const DeviceLexicon*, Batch*, uint32_t**, std::string& err) { err = "stub"; return ANX_ENODEVICE; }

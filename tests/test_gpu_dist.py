@@ -82,3 +82,22 @@ def test_two_ranks_shard_export_gather():
         for got, exp in zip(merged, whole):
             assert [(v, d) for v, d, _ in got] == [(v, d) for v, d, _ in exp]
             assert all(abs(a[2] - c[2]) < 1e-6 for a, c in zip(got, exp))
+
+
+def test_bench_rccl_path_world1():
+    """What a one-GPU box can exercise of bench.py's RCCL path: launched by torch.distributed.run with ONE rank, the process
+    group is initialised with backend nccl (= RCCL), the size exchange of the compact gather, the all-reduces and barriers run
+    over it, and rank 0's gathered export decodes to the rows fetch() returns.  N > 1 needs a multi-GPU node (the driver's)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "1", "--force-gather", "--check-gather",
+           "--steps", "3", "--warmup", "1", "--queries", "200000", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    js = json.loads(line)
+    assert js["process_group"] == "nccl" and js["gather_error"] is None and js["gather_check"] == "ok"
+    assert "RCCL gather" in js["config"]["parallelism"] and js["n_gpus"] == 1 and js["value"] > 0

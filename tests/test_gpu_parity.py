@@ -471,3 +471,33 @@ def test_concurrent_calls_from_host_threads(eng):
         t.join()
     assert not errors
     assert got == expected
+
+
+def test_capacity_overflow_regrow_repeats_the_run(eng, monkeypatch):
+    """A run is launched with capacity estimates (pair list, scoring grid, survivor list, slot lists, candidate rows) and read
+    back once at its end; when an estimate did not hold, the buffers are regrown and the run repeated.  With the estimates
+    divided by 64 (ANX_CAP_DIV) every one of them overflows: results must equal those of the normally sized run."""
+    import numpy as np
+    g, _o = eng
+    words = synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz"))
+    for max_len, kw in ((16, dict(max_anagram_distance=3, max_edit_distance=2, max_matches=10)),
+                        (28, dict(max_anagram_distance=3, max_edit_distance=3, max_matches=10)),
+                        (20, dict(max_anagram_distance=4, max_edit_distance=4, max_matches=5))):
+        qs = synth.make_queries(words, 60000, max_len=max_len, seed=77)
+        p = A.SearchParameters(**kw)
+        b = g.encode_batch(qs, p)
+        b.run()
+        ref, st = b.fetch_arrays(), b.stats()
+        b.free()
+        monkeypatch.setenv("ANX_CAP_DIV", "64")
+        b = g.encode_batch(qs, p)
+        b.run()
+        got, st2 = b.fetch_arrays(), b.stats()
+        b.run()   # second run of the same batch: sized from the first
+        got3 = b.fetch_arrays()
+        b.free()
+        monkeypatch.delenv("ANX_CAP_DIV")
+        for x, y, z in zip(ref, got, got3):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+        for k in ("n_pairs", "n_results", "n_survivors", "n_selected", "n_class_tests"):
+            assert st[k] == st2[k], k
