@@ -57,9 +57,17 @@ def rust_lines(data: str) -> List[str]:
     return [p[:-1] if p.endswith("\r") else p for p in parts]
 
 
+_LOWERCASE = None
+
+
 def is_lowercase(ch: str) -> bool:
-    """char::is_lowercase (Unicode Lowercase property) == Python str.islower() on one char."""
-    return ch.islower()
+    """char::is_lowercase = the Unicode derived property Lowercase (Ll + Other_Lowercase); same database as is_alphabetic
+    (Python's str.islower() is the same property of Unicode 13: three code points differ)."""
+    global _LOWERCASE
+    if _LOWERCASE is None:
+        import regex
+        _LOWERCASE = regex.compile(r"\p{Lowercase}")
+    return not (0xD800 <= ord(ch) <= 0xDFFF) and _LOWERCASE.match(ch) is not None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -842,10 +850,18 @@ class Match:  # src/search.rs:40-68
     seqnr: List[int] = field(default_factory=list)
 
 
+_ALPHABETIC = None
+
+
 def is_alphabetic(ch: str) -> bool:
-    """char::is_alphabetic. Python's isalpha() covers the L* categories; Rust's Alphabetic additionally has Nl and
-    Other_Alphabetic -- irrelevant for the pinned tests, documented as a limit."""
-    return ch.isalpha()
+    """char::is_alphabetic = the Unicode derived property Alphabetic (L* + Nl + Other_Alphabetic), from the `regex` module's
+    Unicode database (the newest in this image); tests/test_unicode_tables_cpu.py cross-checks the compiled range tables
+    against perl's database and Python's unicodedata."""
+    global _ALPHABETIC
+    if _ALPHABETIC is None:
+        import regex
+        _ALPHABETIC = regex.compile(r"\p{Alphabetic}")
+    return not (0xD800 <= ord(ch) <= 0xDFFF) and _ALPHABETIC.match(ch) is not None
 
 
 def _byte_offsets(text: str) -> List[int]:
