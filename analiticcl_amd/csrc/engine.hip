@@ -297,27 +297,6 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
   std::vector<uint4> sig2(img.sig_lo.size());  // {signature, first class of the run, classes in the run}
   for (size_t i = 0; i < sig2.size(); ++i)
     sig2[i] = make_uint4(img.sig_lo[i], img.sig_hi[i], img.sig_cbeg[i], i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] - img.sig_cbeg[i] : 0u);
-  // bounding boxes of the 64-signature blocks (two-level walk of k_scan): per-group minimum and maximum over the real
-  // signatures of the block; a block of padding only gets a box nothing is near to
-  std::vector<uint4> sblk(2 * (sig2.size() / 64 + 64), make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
-  for (size_t bk = 0; bk < sig2.size() / 64; ++bk) {
-    uint8_t mn[8], mx[8];
-    memset(mn, 0xFF, 8); memset(mx, 0, 8);
-    bool any = false;
-    for (size_t i = bk * 64; i < bk * 64 + 64 && i < img.nsigs; ++i) {
-      any = true;
-      const uint64_t v = (uint64_t)img.sig_lo[i] | (uint64_t)img.sig_hi[i] << 32;
-      for (int g = 0; g < 8; ++g) { const uint8_t x = (uint8_t)(v >> (8 * g)); mn[g] = std::min(mn[g], x); mx[g] = std::max(mx[g], x); }
-    }
-    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, slack = 0;
-    if (any) {
-      memcpy(&w[0], mn, 4); memcpy(&w[1], mn + 4, 4); memcpy(&w[2], mx, 4); memcpy(&w[3], mx + 4, 4);
-      for (int g = 0; g < 8; ++g) slack += (uint32_t)(mx[g] - mn[g]);
-    }
-    sblk[2 * bk] = make_uint4(w[0], w[1], w[2], w[3]);
-    sblk[2 * bk + 1] = make_uint4(slack, 0u, 0u, 0u);
-  }
-  for (size_t bk = sig2.size() / 64; 2 * bk + 1 < sblk.size(); ++bk) sblk[2 * bk + 1] = make_uint4(0u, 0u, 0u, 0u);
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
   std::vector<uint4> sig2e(sig2.size());  // {signature, first entry of the run, entries in the run}
@@ -332,7 +311,6 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
       (rc = upload(&d->scan_rec, srec.data(), srec.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_e, sig2e.data(), sig2e.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig, sig2.data(), sig2.size(), err, &d->bytes)) ||
-      (rc = upload(&d->sigblk, sblk.data(), sblk.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_cbeg, img.sig_cbeg.data(), img.sig_cbeg.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_vocab, img.ent_vocab.data(), img.ent_vocab.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_freq, img.ent_freq.data(), img.ent_freq.size(), err, &d->bytes)) ||
@@ -363,7 +341,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sig, (void*)d->sigblk, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
@@ -859,8 +837,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     ScanArgs A;
     A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
     A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
-    A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sigblk = dl->sigblk;
-    { const char* e = getenv("ANX_SCAN_WALK"); A.hier = (e && strcmp(e, "flat") == 0) ? 0 : 1; }
+    A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg;
     { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; A.chunk = v >= 32 && v <= 1024 ? (uint32_t)v : SCAN_CHUNK; }
     A.raw = b->raw; A.region_cap = region_cap; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
     A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
@@ -957,6 +934,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     FilterArgs fa;
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
     fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap;
+    { const char* e = getenv("ANX_LEN_SPLIT"); fa.len_split = e ? (uint32_t)atoi(e) : 9u; }  // ~ the median query length of word lists
     const dim3 fgrid(((fill_cap + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
     HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
     // batches without long queries defer the 8-word prefilter of their few wide pairs (a 17..19-symbol candidate) to

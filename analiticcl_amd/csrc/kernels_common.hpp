@@ -53,7 +53,6 @@ struct DeviceLexicon {
   uint4* sig_e = nullptr;          // [nsig_pad] signature table with entry runs (ScanArgs::sig_e)
   uint4* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage): {groups 0-3, groups 4-7, first class of the run, classes}
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
-  uint4* sigblk = nullptr;         // [nsig_pad / 64][2] bounding box of every 64-signature block (ScanArgs::sigblk)
   uint32_t* ent_vocab = nullptr;
   uint32_t* ent_freq = nullptr;
   uint32_t* ent_meta = nullptr;

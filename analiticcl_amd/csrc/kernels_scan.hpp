@@ -100,8 +100,6 @@ struct ScanArgs {
   const uint4* sig;         // signature table: {groups 0-3, groups 4-7 packed as bytes, first class of the run, classes}
   const uint4* sig_e;       // the same with the run as scan records: {.., .., first entry of the run, entries} (bit-plane kernel)
   const uint32_t* sig_cbeg;
-  const uint4* sigblk;      // [blocks][2] per 64-signature block: {group minima lo, hi, group maxima lo, hi} {sum(max) - sum(min), -, -, -}
-  int hier;                 // two-level signature walk (ANX_SCAN_WALK=flat: every block of the window)
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
   uint32_t chunk;       // pair-list slots a wave reserves per global atomic (SCAN_CHUNK; ANX_SCAN_CHUNK)
@@ -362,41 +360,17 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       }
     }
   };
+  // A two-level walk (bounding boxes of the 64-signature blocks, also with a k-d ordering of the signatures) was built and
+  // measured in round 2: an L1 ball of radius k in 6-8 small-integer dimensions touches 78-87 % of the blocks of the window
+  // (tools/kdsim.py), so nothing is skipped; the flat walk below stays.
   const uint4* __restrict__ sigtab = BITS ? A.sig_e : A.sig;  // runs of scan records (entries) / of classes
-  if (A.hier) {
-    // Two-level walk: one 32-byte summary per block = bounding box (per-group minimum and maximum) of its 64 signatures.
-    // distance(signature, box) = sum_g max(0, min_g - q_g) + max(0, q_g - max_g) is a lower bound of the L1 distance to every
-    // signature inside, and with max(0, x) = (|x| + x) / 2 it is (SAD(min, q) + SAD(max, q) - slack) / 2, slack = sum(max) -
-    // sum(min): a block is visited iff SAD(min, q) + SAD(max, q) <= 2k + slack.  64 summaries per step.
-    const uint32_t b0 = t.s0 >> 6, b1 = t.s1 >> 6;
-    for (uint32_t bb = b0; bb < b1; bb += 64) {
-      const uint32_t blk = bb + lane;
-      bool okb = false;
-      if (blk < b1) {
-        const uint4 box = A.sigblk[2 * (size_t)blk], bx2 = A.sigblk[2 * (size_t)blk + 1];
-        const uint32_t sad = __builtin_amdgcn_sad_u8(box.x, t.sig_lo, __builtin_amdgcn_sad_u8(box.y, t.sig_hi,
-                             __builtin_amdgcn_sad_u8(box.z, t.sig_lo, __builtin_amdgcn_sad_u8(box.w, t.sig_hi, 0u))));
-        okb = sad <= 2u * t.k + bx2.x;
-      }
-      unsigned long long mb = __ballot(okb);
-      if (!mb) continue;
-      uint4 sg_next = sigtab[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
-      while (mb) {
-        mb &= mb - 1;
-        const uint4 sg = sg_next;  // the next candidate block is loaded while this one is tested and staged
-        if (mb) sg_next = sigtab[((size_t)(bb + (uint32_t)__ffsll((long long)mb) - 1u) << 6) + lane];
-        test_block(sg);
-      }
-    }
-  } else {
-    const uint4* __restrict__ sigp = sigtab + t.s0 + lane;
-    uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-    for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
-      const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
-      sigp += 64;
-      if (sb + 64 < t.s1) sg_next = *sigp;
-      test_block(sg);
-    }
+  const uint4* __restrict__ sigp = sigtab + t.s0 + lane;
+  uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+  for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
+    const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
+    sigp += 64;
+    if (sb + 64 < t.s1) sg_next = *sigp;
+    test_block(sg);
   }
   if (ns) process();
   flush();
