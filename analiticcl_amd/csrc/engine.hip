@@ -934,7 +934,6 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     FilterArgs fa;
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
     fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap;
-    { const char* e = getenv("ANX_LEN_SPLIT"); fa.len_split = e ? (uint32_t)atoi(e) : 9u; }  // ~ the median query length of word lists
     const dim3 fgrid(((fill_cap + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
     HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
     // batches without long queries defer the 8-word prefilter of their few wide pairs (a 17..19-symbol candidate) to

@@ -423,7 +423,6 @@ struct FilterArgs {
   uint32_t* counters;
   uint32_t* stat_ctr;       // [SCAN_REGIONS][RC_STRIDE], word 1: selected pairs
   uint32_t fill_cap;        // slots per region the grid covers (a region filled beyond it makes batch_finish repeat the run)
-  uint32_t len_split;       // inline pairs are queued in two length classes: query length <= len_split / longer
 };
 // WIDE = true: the 8-word prefilter of pairs with a string of 17..32 symbols runs inline (batches with such queries: many
 // wide pairs).  WIDE = false (every query <= 16 symbols, so only the few pairs with a 17..19-symbol candidate are wide):
@@ -431,17 +430,14 @@ struct FilterArgs {
 // register count of this kernel (72 VGPRs with it, 43 / 52 / 69 for D = 1 / 2 / 3 without: 8 waves per SIMD instead of 7).
 template <int D, bool WIDE>
 __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg, SlotList listw) {
-  // queued pairs as offsets from the block's first slot: pairs with a SHORT query fill the array from the front, the others from
-  // the back (s_n[0], s_n[1] entries) -- the DL's row loop runs to the longest query of the wave, so waves of one length class
-  // skip the rows the mixed ones idled through
-  __shared__ uint16_t s_q[FS_BLK];
-  __shared__ uint32_t s_n[2];
+  __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
+  __shared__ uint32_t s_n;
   __shared__ uint32_t s_str[256 * 9];
   // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
   // counter word sustains only ~88 M atomics/s)
   const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * FS_BLK;
   if (base >= fill) return;  // block-uniform
-  if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   uint32_t nselected = 0;  // wave-uniform
@@ -495,21 +491,13 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     const bool inl = selected && D > 0 && lq <= 16 && lc <= 16 && d <= D;
     const bool to8 = selected && !inl && !tow && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
     const bool tog = selected && !inl && !tow && !to8;
-    const bool longq = lq > (int)f.len_split;
-    const unsigned long long mi = __ballot(inl && !longq), ml = __ballot(inl && longq);
-    if (mi) {  // wave-uniform: queue the inline pairs with a short query, from the front
+    const unsigned long long mi = __ballot(inl);
+    if (mi) {  // wave-uniform: queue the inline pairs
       const int first = __ffsll((long long)mi) - 1;
       uint32_t qb = 0;
-      if ((int)lane == first) qb = atomicAdd(&s_n[0], (uint32_t)__popcll(mi));
+      if ((int)lane == first) qb = atomicAdd(&s_n, (uint32_t)__popcll(mi));
       qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
-      if (inl && !longq) s_q[qb + (uint32_t)__popcll(mi & ((1ull << lane) - 1ull))] = (uint16_t)(r * 256 + threadIdx.x);
-    }
-    if (ml) {  // ... and the ones with a long query, from the back
-      const int first = __ffsll((long long)ml) - 1;
-      uint32_t qb = 0;
-      if ((int)lane == first) qb = atomicAdd(&s_n[1], (uint32_t)__popcll(ml));
-      qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
-      if (inl && longq) s_q[FS_BLK - 1u - (qb + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull)))] = (uint16_t)(r * 256 + threadIdx.x);
+      if (inl) s_q[qb + (uint32_t)__popcll(mi & ((1ull << lane) - 1ull))] = (uint16_t)(r * 256 + threadIdx.x);
     }
     slot_append(list8, region, to8, p);
     slot_append(listg, region, tog, p);
@@ -528,15 +516,13 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     // separates a round's reads from its writes).  Phase 2b: LCS / prefix / suffix / score of the survivors in dense
     // rounds -- the tail costs as much as the DL itself and would otherwise run with a third of its lanes.
     constexpr int DD = D > 0 ? D : 1;
-    // rounds over the short-query entries [0, nf), then over the long-query ones [FS_BLK - nb, FS_BLK), both ascending: the
-    // survivor entries (<= one per entry read so far) are written from the front and never reach an unread entry
-    const uint32_t nf = s_n[0], nb = s_n[1], nfr = (nf + 255u) & ~255u, n = nfr + nb;
+    const uint32_t n = s_n;
     __shared__ uint32_t s_m;
     if (threadIdx.x == 0) s_m = 0;
     for (uint32_t r0 = 0; r0 < n; r0 += 256) {  // block-uniform trip count
       const uint32_t i = r0 + threadIdx.x;
-      const bool active = r0 < nfr ? i < nf : i < n;
-      const uint32_t off = active ? s_q[r0 < nfr ? i : FS_BLK - nb + (i - nfr)] : 0u;
+      const bool active = i < n;
+      const uint32_t off = active ? s_q[i] : 0u;
       __syncthreads();
       const uint32_t p = (region << f.region_shift) + base + off;
       PairRegs<4> r;

@@ -15,7 +15,7 @@ g = A.VariantModel(p["alphabet"], A.Weights(), device=0); g.read_lexicon(p[lex])
 qs = synth.make_queries(synth.load_lexicon_words(p[lex]), nq, max_len=maxlen, seed=synth.SEED)
 b = g.encode_batch(qs, A.SearchParameters(max_anagram_distance=3, max_edit_distance=d, max_matches=10))
 def run(label, env):
-    for k in ("ANX_SCAN_DBG", "ANX_SCORE_DBG", "ANX_LEN_SPLIT"): os.environ.pop(k, None)
+    for k in ("ANX_SCAN_DBG", "ANX_SCORE_DBG"): os.environ.pop(k, None)
     os.environ.update(env)
     for _ in range(2): b.run()
     acc = {}
@@ -28,6 +28,4 @@ for v in (8, 1, 2, 4):
     run(f"scan dbg={v}", {"ANX_SCAN_DBG": str(v)})
 for v in (1, 2):
     run(f"score dbg={v}", {"ANX_SCORE_DBG": str(v)})
-for v in (0, 6, 7, 8, 9, 10, 11, 12):
-    run(f"len split={v}", {"ANX_LEN_SPLIT": str(v)})
 run("default again", {})
