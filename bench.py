@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--edit-distance", type=int, default=2)
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the export + gather code at N=1 too (testing)")
+    ap.add_argument("--timed-only", action="store_true", help="skip the passes after the timed region (two-stream overlap, end to end, CPU baseline): for rocprofv3 runs")
     ap.add_argument("--check-gather", action="store_true", help="rank 0: decode its own gathered export of the last step and compare it with fetch()")
     args = ap.parse_args()
 
@@ -196,7 +197,7 @@ def main():
     # ---- after the timed region: the same steps with the two copies on TWO streams, so that the latency-bound tail of one run
     # (compaction, ranking) overlaps the scan of the next (reported as "overlapped"; never `value`) ------------------------
     overlapped = None
-    if world == 1 and not do_gather:
+    if world == 1 and not do_gather and not args.timed_only:
         s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
         for k in range(2):
             step(k, s2[k & 1].cuda_stream, False)
@@ -312,7 +313,7 @@ def main():
                     "scan_tests_by_planes": kinds, "scan_tiles": st["n_scan_blocks"]}
         # ---- end to end from host strings (never `value`): encode + upload, device run, download of the ranked rows ------
         e2e = None
-        if world == 1:
+        if world == 1 and not args.timed_only:
             reps = []
             # the queries as ONE host buffer, every string followed by a NUL byte: what a caller that reads its input from a
             # file or a socket holds (the reference's CLI reads lines the same way, src/bin/analiticcl.rs:416-448); building it
@@ -336,7 +337,7 @@ def main():
         # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
         cpu = None
         ncores = usable_cores()
-        if args.cpu_sample != 0 and world == 1:  # reported at N=1 only
+        if args.cpu_sample != 0 and world == 1 and not args.timed_only:  # reported at N=1 only
             from oracle import cwrap as O
             om = O.OracleModel(alphabet_path=paths["alphabet"])
             om.read_lexicon(paths[args.lexicon])

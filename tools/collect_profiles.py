@@ -1,5 +1,7 @@
-"""gpurun_out/meas/* (written by tools/measure_round.sh on the GPU box) -> profiles/r01_final_*.{md,json}"""
-import json, os, re, shutil
+"""gpurun_out/meas/* (written by tools/measure_round.sh on the GPU box) -> profiles/<round>_final_*.{md,json}
+usage: collect_profiles.py [round tag, default r02]"""
+import glob, hashlib, json, os, re, shutil, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M = os.path.join(R, "gpurun_out", "meas")
 pmc = open(os.path.join(M, "pmc.md")).read()
@@ -17,17 +19,20 @@ for name, blk in blocks():
     if va and g and name in ("k_scan_bits", "k_filter_score", "k_rank", "k_compact", "k_compact_grouped"):
         lines.append(f"# {name}: VALU-active = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = {va*4/(g/8*1024)*100:.0f} %; "
                      f"{vi/1e6:.0f} M VALU + {si/1e6:.0f} M SALU wave-instructions; HBM traffic 2*{f/1024:.0f} MB + {w/1024:.0f} MB = {(2*f+w)/1048576:.2f} GB per launch")
-hdr = ("# Round 1 final -- rocprofv3 --pmc passes (separate runs, --kernel-trace only), python3 bench.py --steps 2 --warmup 1 --cpu-sample 0\n"
+hdr = (f"# Round {int(TAG[1:])} final -- rocprofv3 --pmc passes (separate runs, --kernel-trace only), python3 bench.py --steps 2 --warmup 1 --cpu-sample 0\n"
        "# recipe: tools/measure_round.sh; passes: {SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU} "
        "{SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE} {FETCH_SIZE} {WRITE_SIZE}\n"
        "# FETCH_SIZE / WRITE_SIZE are in KB; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles.\n" + "\n".join(lines) + "\n\n")
-open(os.path.join(R, "profiles", "r01_final_pmc.md"), "w").write(hdr + pmc)
-json.dump({"source": "profiles/r01_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py config 2, 1M queries)",
+open(os.path.join(R, "profiles", f"{TAG}_final_pmc.md"), "w").write(hdr + pmc)
+sha = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(R, "analiticcl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(R, "analiticcl_amd", "csrc", "*.hpp"))):
+    sha.update(open(f, "rb").read())
+json.dump({"kernel_src_sha256": sha.hexdigest(), "source": f"profiles/{TAG}_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py config 2, 1M queries)",
            "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024; the x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (calibrated there for 16 B/lane streams; narrower loads make the read side an upper bound)",
-           "kernels": kern}, open(os.path.join(R, "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+           "kernels": kern}, open(os.path.join(R, "profiles", f"{TAG}_pmc_traffic.json"), "w"), indent=1)
 kt = open(os.path.join(M, "kernel_trace.md")).read()
-open(os.path.join(R, "profiles", "r01_final_kernel_trace.md"), "w").write(
-    "# Round 1 final -- rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 (7 runs of the pipeline; tools/measure_round.sh)\n"
+open(os.path.join(R, "profiles", f"{TAG}_final_kernel_trace.md"), "w").write(
+    f"# Round {int(TAG[1:])} final -- rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 (7 runs of the pipeline; tools/measure_round.sh)\n"
     "# config 2: eng.aspell, 1M queries len<=16, k=3 d=2 n=10; summarised from the rocpd database by profiles/summarize_rocpd.py\n\n" + kt)
-shutil.copy(os.path.join(M, "bench_default.json"), os.path.join(R, "profiles", "r01_bench.json"))
+shutil.copy(os.path.join(M, "bench_default.json"), os.path.join(R, "profiles", f"{TAG}_bench.json"))
 print("\n".join(lines))
