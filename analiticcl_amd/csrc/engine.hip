@@ -811,9 +811,12 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   HIP_TRY(hipSetDevice(dl->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint32_t nq = (uint32_t)b->nq;
+  if (b->launched) {  // a run enqueued with anx_batch_run_async and never waited for: its events and read-back buffer are reused
+    HIP_TRY(hipEventSynchronize(b->ev_done));
+    b->launched = false;
+  }
   b->last_stream = stream;
   b->ran = false;
-  b->launched = false;
   b->ran_keep_all = b->keep_all_pairs;  // the run that also stores the per-slot outputs the debug fetch of every pair reads
   b->n_pairs = b->n_results = b->n_surv = 0;
   b->n_raw = 0;

@@ -446,35 +446,28 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     if (base + r * 256 >= fill) break;  // block-uniform
     const uint32_t p = (region << f.region_shift) + idx;
     const bool live = idx < fill;
-    bool selected = false, stop_skipped = false, invalid = false;
-    int d = 0, lq = 0, lc = 0;
-    bool filt = false, wide = false;
+    // Straight-line loads: a lane without a pair (beyond the region's fill, unused chunk tail, StopAtExactMatch drop) reads
+    // slot / query / entry 0 instead of being masked off -- 98 % of the lanes have a pair, and the exec-mask bookkeeping of
+    // nested branches around the loads cost more than the few wasted gathers; its verdict is masked by `selected`.
+    const uint2 rp = A.raw[live ? p : (region << f.region_shift)];
+    const bool invalid = !live || rp.x == RAW_INVALID;  // unused chunk tail
+    bool skip = invalid;
+    if (f.stop)  // StopAtExactMatch: a non-exact class of a query that has an exact one (wave-uniform branch)
+      skip = invalid || (!(rp.y & 0x80000000u) && f.qexact[invalid ? 0u : rp.x] != 0xFFFFFFFFu);
+    const bool stop_skipped = skip && !invalid;
+    const uint32_t q = skip ? 0u : rp.x, e = skip ? 0u : (rp.y & 0x7FFFFFFFu);
     // the first 16 symbols of both strings come with the records (rows are padded with bytes that equal nothing:
-    // query 0xFE, candidate 0xFF); lanes without a pair keep zeros, their verdict is masked by `filt`
-    uint4 Q = make_uint4(0, 0, 0, 0), C = make_uint4(0, 0, 0, 0);
-    uint32_t q = 0, crow = 0;
-    if (live) {
-      const uint2 rp = A.raw[p];
-      q = rp.x;
-      const uint32_t e = rp.y & 0x7FFFFFFFu;
-      invalid = q == RAW_INVALID;
-      // unused chunk tail, or (StopAtExactMatch) a non-exact class of a query that has an exact one
-      const bool skip = invalid || (f.stop && !(rp.y & 0x80000000u) && f.qexact[q] != 0xFFFFFFFFu);
-      stop_skipped = skip && !invalid;
-      if (!skip) {
-        Q = rec32(A.q_rec, q)[0];  // 32-B records: one line each
-        const uint4 QM = rec32(A.q_rec, q)[1];
-        C = rec32(A.e_rec, e)[0];
-        const uint4 CM = rec32(A.e_rec, e)[1];
-        const uint32_t qm = QM.x, em = CM.x;
-        crow = CM.y;
-        lq = qm & 0xFF; d = (qm >> 16) & 0xFF; lc = em & 0xFF;
-        const int diff = lq > lc ? lq - lc : lc - lq;
-        selected = diff <= d;
-        filt = selected && f.enable && d <= 3 && lq <= 32 && lc <= 32;
-        wide = filt && (lq > 16 || lc > 16);
-      }
-    }
+    // query 0xFE, candidate 0xFF)
+    const uint4 Q = rec32(A.q_rec, q)[0];  // 32-B records: one line each
+    const uint4 QM = rec32(A.q_rec, q)[1];
+    const uint4 C = rec32(A.e_rec, e)[0];
+    const uint4 CM = rec32(A.e_rec, e)[1];
+    const uint32_t crow = CM.y;
+    const int lq = QM.x & 0xFF, d = (QM.x >> 16) & 0xFF, lc = CM.x & 0xFF;
+    const int diff = lq > lc ? lq - lc : lc - lq;
+    bool selected = !skip && diff <= d;
+    const bool filt = selected && f.enable && d <= 3 && lq <= 32 && lc <= 32;
+    const bool wide = filt && (lq > 16 || lc > 16);
     if (WIDE && __any(wide)) {  // wave-uniform, rare: some pair of the wave has a string of 17..32 symbols
       uint32_t q8[8] = {Q.x, Q.y, Q.z, Q.w, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
       uint32_t c10[10] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};

@@ -501,3 +501,35 @@ def test_capacity_overflow_regrow_repeats_the_run(eng, monkeypatch):
             assert np.array_equal(x, y) and np.array_equal(x, z)
         for k in ("n_pairs", "n_results", "n_survivors", "n_selected", "n_class_tests"):
             assert st[k] == st2[k], k
+
+
+def test_async_runs_on_two_streams_equal_synchronous_runs(eng):
+    """anx_batch_run_async / anx_batch_wait: two batches in flight on two HIP streams (the tail of one run under the scan of the
+    other), relaunching a batch without waiting for its previous run, and fetching only after wait()."""
+    import numpy as np
+    import torch
+    g, _o = eng
+    words = synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz"))
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    qa, qb = synth.make_queries(words, 50000, max_len=16, seed=5), synth.make_queries(words, 70000, max_len=24, seed=6)
+    ref = []
+    for qs in (qa, qb):
+        b = g.encode_batch(qs, p)
+        b.run()
+        ref.append(b.fetch_arrays())
+        b.free()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ba, bb = g.encode_batch(qa, p), g.encode_batch(qb, p)
+    for _ in range(3):
+        ba.run_async(s1.cuda_stream)
+        bb.run_async(s2.cuda_stream)
+    with pytest.raises(A.AnxError):
+        ba.fetch_arrays()                     # not waited for yet
+    ba.run_async(s1.cuda_stream)              # relaunch without wait: the library waits for the previous run itself
+    ba.wait()
+    bb.wait()
+    for b, r in ((ba, ref[0]), (bb, ref[1])):
+        got = b.fetch_arrays()
+        for x, y in zip(got, r):
+            assert np.array_equal(x, y)
+        b.free()
