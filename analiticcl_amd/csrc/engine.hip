@@ -938,21 +938,26 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
     fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap;
     const dim3 fgrid(((fill_cap + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
+    {
+      const FsCold cold{sa, so, l8, lg, lw};
+      if (!b->d_cold && (rc = dalloc(reinterpret_cast<char**>(&b->d_cold), sizeof(FsCold), err))) return rc;
+      HIP_TRY(hipMemcpyAsync(b->d_cold, &cold, sizeof cold, hipMemcpyHostToDevice, st));  // pageable source: staged before the call returns
+    }
     HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
     // batches without long queries defer the 8-word prefilter of their few wide pairs (a 17..19-symbol candidate) to
     // k_filter_wide: without that state the fused kernel fits 8 waves per SIMD
     static const int enable_split = []() { const char* e = getenv("ANX_FS_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool split_wide = !have_long_q && enable_split;
     if (split_wide) {
-      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
-      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
-      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
-      else hipLaunchKernelGGL((k_filter_score<0, false>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
+      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
+      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
+      else hipLaunchKernelGGL((k_filter_score<0, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
     } else {
-      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
-      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
-      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
-      else hipLaunchKernelGGL((k_filter_score<0, true>), fgrid, dim3(256), 0, st, fa, pa, sa, so, l8, lg, lw);
+      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
+      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
+      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
+      else hipLaunchKernelGGL((k_filter_score<0, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
     }
     HIP_TRY(hipEventRecord(b->ev_fs1, st));
     if (need_lists) {  // the list fills are only known on the device: fixed grids walk the lists in strides
@@ -1313,7 +1318,7 @@ void batch_free(Batch* b) {
   if (b->launched) (void)hipEventSynchronize(b->ev_done);  // a run enqueued with batch_run_async and never waited for
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
-                  (void*)b->qmaxfreq, (void*)b->qpairs, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
+                  (void*)b->qmaxfreq, (void*)b->d_cold, (void*)b->qpairs, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
     if (p) pool_free(p);
   for (auto& e : b->ev)

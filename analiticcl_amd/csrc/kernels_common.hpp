@@ -120,6 +120,7 @@ struct Batch {
   uint32_t* soff = nullptr;        // nq+1, exclusive scan of qsurv
   uint32_t* qcur = nullptr;
   uint32_t* qmaxfreq = nullptr;
+  void* d_cold = nullptr;          // FsCold of the last launch (k_filter_score's rarely used arguments)
   uint32_t* qpairs = nullptr;      // per query: scored pairs of the last run (only when count_pairs is set)
   bool count_pairs = false;
   uint32_t* scan_tmp = nullptr;

@@ -428,8 +428,19 @@ struct FilterArgs {
 // wide pairs).  WIDE = false (every query <= 16 symbols, so only the few pairs with a 17..19-symbol candidate are wide):
 // wide pairs are appended unfiltered to listw and k_filter_wide prefilters them -- the 8-word SWAR state is what sets the
 // register count of this kernel (72 VGPRs with it, 43 / 52 / 69 for D = 1 / 2 / 3 without: 8 waves per SIMD instead of 7).
+// arguments the prefilter rounds hardly touch (score weights, survivor / slot lists) live in device memory and are read where
+// they are used: as by-value kernel arguments they stayed in SGPRs over the 16 unrolled rounds and pushed 20 SGPRs into VGPR
+// lanes (a v_readlane per use)
+struct FsCold {
+  ScoreArgs a;
+  SurvOut so;
+  SlotList list8, listg, listw;
+};
 template <int D, bool WIDE>
-__global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so, SlotList list8, SlotList listg, SlotList listw) {
+__global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, const FsCold* __restrict__ cold) {
+  const ScoreArgs& a = cold->a;
+  const SurvOut& so = cold->so;
+  const SlotList &list8 = cold->list8, &listg = cold->listg, &listw = cold->listw;
   __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
   __shared__ uint32_t s_n;
   __shared__ uint32_t s_str[256 * 9];
@@ -475,8 +486,20 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       if (wide && lc > 16) { const uint4 C1 = A.rows[crow + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
       if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
     } else if (__any(filt && !wide)) {
-      const uint32_t q4[4] = {Q.x, Q.y, Q.z, Q.w}, c6[6] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu};
-      if (band_bound_rejects<4>(q4, c6, filt && !wide, d, lq, lc)) selected = false;
+      // as many 4-symbol words as the longest string of the WAVE needs (its 64 slots come from one scan chunk, i.e. one tile
+      // and one query length: 23 % of the bench queries fit 2 words with their candidates, 54 % more fit 3)
+      const bool f4 = filt && !wide;
+      const int ml = lq > lc ? lq : lc;
+      if (__any(f4 && ml > 12)) {
+        const uint32_t q4[4] = {Q.x, Q.y, Q.z, Q.w}, c6[6] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu};
+        if (band_bound_rejects<4>(q4, c6, f4, d, lq, lc)) selected = false;
+      } else if (__any(f4 && ml > 8)) {
+        const uint32_t q3[3] = {Q.x, Q.y, Q.z}, c5[5] = {0xFFFFFFFFu, C.x, C.y, C.z, 0xFFFFFFFFu};
+        if (band_bound_rejects<3>(q3, c5, f4, d, lq, lc)) selected = false;
+      } else {
+        const uint32_t q2[2] = {Q.x, Q.y}, c4[4] = {0xFFFFFFFFu, C.x, C.y, 0xFFFFFFFFu};
+        if (band_bound_rejects<2>(q2, c4, f4, d, lq, lc)) selected = false;
+      }
     }
     const bool tow = !WIDE && wide;  // prefiltered later by k_filter_wide (which also counts it as selected if it passes)
     if (a.store_pairs && live && !selected && !tow)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
