@@ -329,6 +329,7 @@ def main():
                 t3 = time.perf_counter()
                 b2.free()
                 reps.append((t3 - t, t1 - t, t2 - t1, t3 - t2, int(arrs[0][-1])))
+                del arrs  # the rows live in a pinned buffer of the library's cache: released here, reused by the next fetch
             best = min(reps)
             # the same with two host threads, each running encode -> run -> fetch on its own batches and its own stream (the
             # library is thread-safe on one model): uploads, kernels and downloads of different batches overlap
@@ -339,7 +340,8 @@ def main():
                 for _ in range(per):
                     bb = model.encode_packed(packed, len(queries), params)
                     bb.run(st2.cuda_stream)
-                    bb.fetch_arrays()
+                    res = bb.fetch_arrays()
+                    del res
                     bb.free()
             worker()  # warm the pools of a second set of buffers
             t = time.perf_counter()
