@@ -240,16 +240,21 @@ struct TileArgs {
   Tile* tiles;          // unsorted
   unsigned long long* tkey;  // LPT sort key
   uint32_t* ctr;        // [3] = SAD tiles
+  const uint32_t* ball_tab;  // ball_off[13] ++ ball_n[13] (DeviceLexicon::ball_tab)
+  int probe;            // tiles may probe the signature hash table (ANX_SCAN_WALK=flat: never)
 };
 __device__ inline bool same_segment(const TileArgs& t, uint32_t a, uint32_t b) {
   return (t.s_kind[a] == 0) == (t.s_kind[b] == 0) && (t.q_meta[a] & 0xFFu) == (t.q_meta[b] & 0xFFu) && t.s_sig[a] == t.s_sig[b];
 }
-__device__ inline void tile_window(const TileArgs& t, uint32_t s, uint32_t& s0, uint32_t& s1, uint32_t& step, uint32_t& nparts) {
+__device__ inline void tile_window(const TileArgs& t, uint32_t s, uint32_t& s0, uint32_t& s1, uint32_t& step, uint32_t& nparts,
+                                   uint32_t& ball0, uint32_t& balln) {
   const uint32_t meta = t.q_meta[s], lq = meta & 0xFFu, k = (meta >> 8) & 0xFFu;
   const int lo = max(1, (int)lq - (int)k), hi = min(kMaxSymbols, (int)lq + (int)k);
   s0 = t.siglen_begin[lo] & ~63u;
   s1 = (t.siglen_begin[hi + 1] + 63u) & ~63u;
-  const uint32_t nsplit = t.s_kind[s] == 0 ? 8u : 1u;  // count-vector tiles: the window split over 8 waves (engine.hip)
+  ball0 = balln = 0;  // hash-table probes with the L1 ball of signature offsets instead of the window walk (engine.hip)
+  if (t.probe && k <= 12u && tile_probes(t.ball_tab[13 + k], s1 - s0, t.s_sig[s])) { ball0 = t.ball_tab[k]; balln = t.ball_tab[13 + k]; }
+  const uint32_t nsplit = (t.s_kind[s] == 0 && !balln) ? 8u : 1u;  // count-vector tiles: the window split over 8 waves (engine.hip)
   step = (((s1 - s0) + nsplit - 1u) / nsplit + 63u) & ~63u;
   nparts = 0;
   for (uint32_t part = 0; part < nsplit; ++part) {
@@ -268,8 +273,8 @@ __global__ __launch_bounds__(256) void k_tile_count(TileArgs t) {
   if (s > t.nq) return;
   uint32_t c = 0;
   if (s < t.nq && (s - t.head[s]) % t.tq == 0) {  // head[] holds the segment start after the max-scan
-    uint32_t s0, s1, step, nparts;
-    tile_window(t, s, s0, s1, step, nparts);
+    uint32_t s0, s1, step, nparts, ball0, balln;
+    tile_window(t, s, s0, s1, step, nparts, ball0, balln);
     c = nparts;
   }
   t.tcount[s] = c;
@@ -285,8 +290,8 @@ __global__ __launch_bounds__(256) void k_tile_emit(TileArgs t) {
   }
   const bool sad = t.s_kind[s] == 0;
   const uint32_t meta = t.q_meta[s], lq = meta & 0xFFu, k = (meta >> 8) & 0xFFu, d = (meta >> 16) & 0xFFu;
-  uint32_t s0, s1, step, nparts;
-  tile_window(t, s, s0, s1, step, nparts);
+  uint32_t s0, s1, step, nparts, ball0, balln;
+  tile_window(t, s, s0, s1, step, nparts, ball0, balln);
   const unsigned long long sig = t.s_sig[s];
   const uint32_t base = t.tcount[s];
   for (uint32_t part = 0; part < nparts; ++part) {
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(256) void k_tile_emit(TileArgs t) {
     Tile tl;
     tl.q0 = s; tl.nq = tn; tl.s0 = a0; tl.s1 = a1; tl.k = k; tl.lq = lq; tl.sig_lo = (uint32_t)sig; tl.sig_hi = (uint32_t)(sig >> 32);
     tl.kind = sad ? 0u : 1u; tl.d = d; tl.kend = sad ? 0u : (ke[0] | ke[1] << 8 | ke[2] << 16);
+    tl.ball0 = ball0; tl.balln = balln;
     t.tiles[base + part] = tl;
     // longest-processing-time first, bit-plane tiles before the count-vector ones: ascending key, stable
     const unsigned long long cost = (unsigned long long)tn * (a1 - a0 + 64u);
@@ -424,6 +430,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   TileArgs ta;
   { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; ta.tq = v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }
   ta.nq = nq; ta.q_meta = b->q_meta; ta.s_kind = s_kind; ta.s_sig = s_sig; ta.siglen_begin = dl->alpha.siglen_begin; ta.ctr = d_ctr;
+  ta.ball_tab = dl->ball_tab; ta.probe = probe_enabled() ? 1 : 0;
   uint32_t *d_head = nullptr, *d_tcount = nullptr;
   if ((rc = sc.get(&d_head, nq, err)) || (rc = sc.get(&d_tcount, (size_t)nq + 1, err))) return rc;
   ta.head = d_head; ta.tcount = d_tcount; ta.tiles = nullptr; ta.tkey = nullptr;

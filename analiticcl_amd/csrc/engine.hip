@@ -299,6 +299,53 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
     sig2[i] = make_uint4(img.sig_lo[i], img.sig_hi[i], img.sig_cbeg[i], i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] - img.sig_cbeg[i] : 0u);
   std::vector<uint32_t> off = img.cls_off;
   if (off.empty()) off.push_back(0);
+  // Signature hash table + L1 balls of signature offsets: instead of walking the whole +-k charcount window of the signature
+  // table (thousands of steps on a large lexicon) a scan tile enumerates the offsets d with sum |d_g| <= k, adds each to its own
+  // signature and probes the table: 377 probes for 6 groups and k = 3, whatever the size of the lexicon.
+  uint32_t hmask = 64;
+  while (hmask < 4 * (uint32_t)img.nsigs) hmask <<= 1;
+  std::vector<uint4> shash;
+  for (;; hmask <<= 1) {  // every key within 16 probes of its home slot
+    shash.assign(hmask, make_uint4(0u, 0u, 0u, 0u));
+    bool ok = true;
+    for (uint32_t i = 0; i < img.nsigs && ok; ++i) {
+      uint32_t h = sig_hash(img.sig_lo[i], img.sig_hi[i]) & (hmask - 1);
+      int probes = 0;
+      while (shash[h].w && probes < 16) { h = (h + 1) & (hmask - 1); ++probes; }
+      if (probes == 16) ok = false;
+      else shash[h] = make_uint4(img.sig_lo[i], img.sig_hi[i], i, 1u);
+    }
+    if (ok) break;
+  }
+  d->hash_mask = hmask - 1;
+  std::vector<unsigned long long> ball;
+  {
+    int ng = 1;
+    for (uint8_t g : img.sym_group) ng = std::max(ng, (int)g + 1);
+    for (int k = 0; k <= 12; ++k) {
+      std::vector<unsigned long long> cur;
+      int8_t dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      bool too_big = false;
+      std::function<void(int, int)> rec = [&](int g, int left) {
+        if (too_big) return;
+        if (g == ng) {
+          unsigned long long v = 0;
+          for (int i = 0; i < 8; ++i) v |= (unsigned long long)(uint8_t)dv[i] << (8 * i);
+          cur.push_back(v);
+          if (cur.size() > BALL_MAX) too_big = true;
+          return;
+        }
+        for (int x = -left; x <= left; ++x) { dv[g] = (int8_t)x; rec(g + 1, left - (x < 0 ? -x : x)); }
+        dv[g] = 0;
+      };
+      rec(0, k);
+      d->ball_off[k] = (uint32_t)ball.size();
+      d->ball_n[k] = too_big ? 0u : (uint32_t)cur.size();
+      if (!too_big) ball.insert(ball.end(), cur.begin(), cur.end());
+    }
+  }
+  std::vector<uint32_t> btab(26);
+  for (int k = 0; k <= 12; ++k) { btab[k] = d->ball_off[k]; btab[13 + k] = d->ball_n[k]; }
   std::vector<uint4> sig2e(sig2.size());  // {signature, first entry of the run, entries in the run}
   for (size_t i = 0; i < sig2.size(); ++i) {
     const uint32_t c0 = std::min(img.sig_cbeg[i], img.nclasses), c1 = std::min(i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] : img.nclasses, img.nclasses);
@@ -310,6 +357,9 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
       (rc = upload(&d->scan_rec, srec.data(), srec.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_e, sig2e.data(), sig2e.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sighash, shash.data(), shash.size(), err, &d->bytes)) ||
+      (rc = upload(&d->ball, ball.data(), ball.size(), err, &d->bytes)) ||
+      (rc = upload(&d->ball_tab, btab.data(), btab.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig, sig2.data(), sig2.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_cbeg, img.sig_cbeg.data(), img.sig_cbeg.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_vocab, img.ent_vocab.data(), img.ent_vocab.size(), err, &d->bytes)) ||
@@ -341,7 +391,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sighash, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
@@ -582,7 +632,10 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
     // The count-vector (SAD) tiles are rare (queries with a symbol more than NBITPLANES times) and run as a launch of
     // their own: a handful of waves whose time is the latency of ONE wave walking the whole signature window.  Their
     // windows are therefore split over several waves (disjoint signature ranges = disjoint classes: same pairs).
-    const uint32_t nsplit = sad ? 8u : 1u;
+    // probe the signature hash table with the L1 ball of offsets when that is cheaper than walking the window (engine: lexicon_upload)
+    uint32_t ball0 = 0, balln = 0;
+    if (probe_enabled() && k <= 12 && tile_probes(dl->ball_n[k], s1 - s0, h_sig[i])) { ball0 = dl->ball_off[k]; balln = dl->ball_n[k]; }
+    const uint32_t nsplit = (sad && !balln) ? 8u : 1u;
     const uint32_t step = (((s1 - s0) + nsplit - 1) / nsplit + 63u) & ~63u;
     for (size_t s = i; s < j; s += tq) {
       const uint32_t tn = (uint32_t)std::min<size_t>(tq, j - s);
@@ -594,7 +647,7 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
         const uint32_t a0 = s0 + part * step, a1 = std::min(s1, a0 + step);
         if (a0 >= a1 && part) break;
         b->tiles.push_back(Tile{(uint32_t)s, tn, a0, a1, k, lq, (uint32_t)h_sig[i], (uint32_t)(h_sig[i] >> 32), sad ? 0u : 1u,
-                                (h_meta[i] >> 16) & 0xFFu, kend});
+                                (h_meta[i] >> 16) & 0xFFu, kend, ball0, balln});
       }
     }
     i = j;
@@ -840,7 +893,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     ScanArgs A;
     A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
     A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
-    A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg;
+    A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
     { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; A.chunk = v >= 32 && v <= 1024 ? (uint32_t)v : SCAN_CHUNK; }
     A.raw = b->raw; A.region_cap = region_cap; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
     A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;

@@ -14,7 +14,10 @@ struct Tile {           // <= SCAN_TQ queries of one length and one signature (b
   uint32_t kind;        // 0 = SAD body (count vectors), 1 = bit-plane body
   uint32_t d;           // clamped edit distance for this length
   uint32_t kend;        // bit-plane tiles: end (within the tile) of the queries of kind 1 | kind 2 << 8 | kind 3 << 16; the rest are kind 4
+  uint32_t ball0, balln;  // balln > 0: probe the signature hash table with the balln offsets ball[ball0 ..] instead of walking [s0, s1)
 };
+constexpr uint32_t BALL_MAX = 4096;   // largest L1 ball of signature offsets enumerated (per k; larger k walk the window)
+constexpr uint32_t SIG_BYTE_MAX = 120;  // group sums above this take the walk (byte-wise SWAR add of an offset must not overflow)
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
 constexpr uint32_t SCAN_TQ = 64;         // queries per tile (= per wave), compared in passes of 32 (one hit-mask bit each)
@@ -51,6 +54,11 @@ struct DeviceLexicon {
   uint32_t* cls_off = nullptr;
   uint4* scan_rec = nullptr;       // [E + 1][2] per entry {4 planes of its class} {len, class, 0, 0}: ScanArgs::scan_rec
   uint4* sig_e = nullptr;          // [nsig_pad] signature table with entry runs (ScanArgs::sig_e)
+  uint4* sighash = nullptr;        // open-addressing table {sig lo, sig hi, signature index, 1}; empty slots are 0 (ScanArgs::sighash)
+  uint32_t hash_mask = 0;
+  unsigned long long* ball = nullptr;  // signature offsets (8 x int8) with sum |offset| <= k, for k = 0..12 back to back
+  uint32_t* ball_tab = nullptr;    // device copy of ball_off[13] ++ ball_n[13]
+  uint32_t ball_off[13] = {}, ball_n[13] = {};  // per k; ball_n = 0: no ball (walk)
   uint4* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage): {groups 0-3, groups 4-7, first class of the run, classes}
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint32_t* ent_vocab = nullptr;

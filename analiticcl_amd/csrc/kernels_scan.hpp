@@ -99,6 +99,9 @@ struct ScanArgs {
   const uint32_t* cls_off;
   const uint4* sig;         // signature table: {groups 0-3, groups 4-7 packed as bytes, first class of the run, classes}
   const uint4* sig_e;       // the same with the run as scan records: {.., .., first entry of the run, entries} (bit-plane kernel)
+  const uint4* sighash;     // open-addressing table {sig lo, sig hi, signature index, 1}; empty = 0
+  uint32_t hash_mask;
+  const unsigned long long* ball;  // signature offsets (8 x int8) of the L1 balls, Tile::ball0 / balln index it
   const uint32_t* sig_cbeg;
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
@@ -334,12 +337,12 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   // least the length difference > k, and the table is padded with never-matching entries).
   // One 16-byte record per signature: the run (first class, count) comes with the signature, so a matching step does not
   // wait for a second, dependent load.
-  auto test_block = [&](const uint4 sg) {  // the 64 signatures of one block, one per lane: stage the class runs of the compatible ones
-    const bool ok = __builtin_amdgcn_sad_u8(sg.x, t.sig_lo, __builtin_amdgcn_sad_u8(sg.y, t.sig_hi, 0u)) <= t.k;
+  // stages the class / record runs (cb, n) of the lanes with ok: scalar loop over the ballot mask
+  auto stage_runs = [&](bool ok, uint32_t cb, uint32_t n) {
     unsigned long long m = __ballot(ok);
     if (!m || (A.dbg & 4)) return;
-    const uint32_t cb = ok ? sg.z : 0u, n = ok ? sg.w : 0u;
-    while (m) {  // scalar loop over the compatible signatures of this step
+    if (!ok) { cb = 0u; n = 0u; }
+    while (m) {
       const int i = __ffsll((long long)m) - 1;
       m &= m - 1;
       uint32_t cbi = (uint32_t)__builtin_amdgcn_readlane((int)cb, i), ni = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
@@ -360,17 +363,50 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       }
     }
   };
-  // A two-level walk (bounding boxes of the 64-signature blocks, also with a k-d ordering of the signatures) was built and
-  // measured in round 2: an L1 ball of radius k in 6-8 small-integer dimensions touches 78-87 % of the blocks of the window
-  // (tools/kdsim.py), so nothing is skipped; the flat walk below stays.
   const uint4* __restrict__ sigtab = BITS ? A.sig_e : A.sig;  // runs of scan records (entries) / of classes
-  const uint4* __restrict__ sigp = sigtab + t.s0 + lane;
-  uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-  for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
-    const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
-    sigp += 64;
-    if (sb + 64 < t.s1) sg_next = *sigp;
-    test_block(sg);
+  if (t.balln) {
+    // Signatures within L1 distance k of the tile's: enumerated, not searched.  Lane i adds offset i of the ball (sum |d_g| <= k)
+    // to the tile's signature byte-wise and looks the result up in the hash table of the lexicon's signatures -- 377 probes for
+    // 6 groups and k = 3 whatever the size of the lexicon, against a walk over every signature of the +-k charcount window.
+    const unsigned long long H = 0x8080808080808080ull;
+    const unsigned long long sq = (unsigned long long)t.sig_lo | (unsigned long long)t.sig_hi << 32;  // every byte <= SIG_BYTE_MAX
+    for (uint32_t base = 0; base < t.balln; base += 64) {
+      const uint32_t i = base + lane;
+      bool found = false;
+      uint32_t sidx = 0;
+      if (i < t.balln) {
+        const unsigned long long dl = A.ball[t.ball0 + i];
+        const unsigned long long r = ((sq & ~H) + (dl & ~H)) ^ ((sq ^ dl) & H);  // byte-wise sum, no carry between bytes
+        if (!(r & (r << 1) & H)) {  // a byte >= 0xC0 is a negative group sum: no such signature
+          const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
+          uint32_t h = sig_hash(lo, hi) & A.hash_mask;
+          for (int p = 0; p < 17; ++p) {
+            const uint4 e = A.sighash[h];
+            if (!e.w) break;
+            if (e.x == lo && e.y == hi) { found = true; sidx = e.z; break; }
+            h = (h + 1u) & A.hash_mask;
+          }
+        }
+      }
+      uint4 sg = make_uint4(0u, 0u, 0u, 0u);
+      if (found) sg = sigtab[sidx];
+      stage_runs(found, sg.z, sg.w);
+    }
+  } else {
+    // The flat walk: every signature of the +-k charcount window [s0, s1) (aligned to 64-signature blocks: the other
+    // signatures of the edge blocks belong to other charcounts, so their L1 distance to the tile's signature is at least
+    // the length difference > k; the table is padded with never-matching entries), 64 per step, one 16-byte record per
+    // signature loaded one step ahead.  A two-level walk over block bounding boxes was measured and removed in round 2: an
+    // L1 ball of radius k in 6-8 small-integer dimensions touches 78-87 % of the blocks (tools/kdsim.py).
+    const uint4* __restrict__ sigp = sigtab + t.s0 + lane;
+    uint4 sg_next = t.s0 < t.s1 ? *sigp : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+    for (uint32_t sb = t.s0; sb < t.s1; sb += 64) {
+      const uint4 sg = sg_next;  // loaded one step ahead: the step's test does not wait for its own load
+      sigp += 64;
+      if (sb + 64 < t.s1) sg_next = *sigp;
+      const bool ok = __builtin_amdgcn_sad_u8(sg.x, t.sig_lo, __builtin_amdgcn_sad_u8(sg.y, t.sig_hi, 0u)) <= t.k;
+      stage_runs(ok, sg.z, sg.w);
+    }
   }
   if (ns) process();
   flush();
@@ -406,7 +442,7 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   if (item >= A.ntiles) return;
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
-  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10];
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12];
   scan_tile<BITS, NP>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid]);
 }
 // <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,

@@ -98,3 +98,31 @@ def test_million_queries_device_equals_host(eng, data_dir):
     words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
     qs = synth.make_queries(words, 1_000_000, max_len=16, seed=synth.SEED)
     run_both(eng, qs, A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10))
+
+
+@pytest.mark.parametrize("kw", [dict(max_anagram_distance=3, max_edit_distance=2, max_matches=10),
+                                dict(max_anagram_distance=5, max_edit_distance=3, max_matches=10),
+                                dict(max_anagram_distance=7, max_edit_distance=4, max_matches=5),
+                                dict(max_anagram_distance=3, max_edit_distance=2, max_matches=10, stop_criterion=True)])
+def test_hash_probe_walk_equals_flat_walk(eng, data_dir, monkeypatch, kw):
+    """Candidate signatures two ways: enumerating the L1 ball of signature offsets and probing the hash table of the lexicon's
+    signatures (default when the ball is smaller than the window) against the flat walk over the +-k charcount window
+    (ANX_SCAN_WALK=flat).  Same pairs per query, same results; k = 7 has no ball (too large) and walks either way."""
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    qs = SPECIAL + synth.make_queries(words, 30000, max_len=28, seed=43) + ["a" * 130 + "b" * 125, "e" * 200]
+    p = A.SearchParameters(**kw)
+    out = {}
+    for mode in ("probe", "flat"):
+        if mode == "flat":
+            monkeypatch.setenv("ANX_SCAN_WALK", "flat")
+        b = eng.encode_batch(qs, p)
+        b.run()
+        out[mode] = (b.fetch_arrays(), b.stats(), b.pair_counts())
+        b.free()
+        monkeypatch.delenv("ANX_SCAN_WALK", raising=False)
+    (pa, ps, pc), (fa, fs, fc) = out["probe"], out["flat"]
+    for x, y in zip(pa, fa):
+        assert np.array_equal(x, y)
+    assert np.array_equal(pc, fc)
+    for k in ("n_queries", "n_pairs", "n_class_tests", "n_results", "n_survivors"):
+        assert ps[k] == fs[k], k
