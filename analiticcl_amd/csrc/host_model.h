@@ -121,8 +121,9 @@ struct LexiconImage {
   std::vector<uint32_t> sig_cbeg;       // [nsig_pad+1] first class of the run (padding: nclasses)
   uint32_t siglen_begin[kMaxSymbols + 2];  // signature range per charcount
 };
-constexpr int kSigGroups = 6;  // measured on eng.aspell k<=3: 6 groups -> 4.6 k class tests / query of 68 k in the
-                               // charcount window (8 -> 1.9 k, but 2.5x more signatures and 3x more query tiles)
+constexpr int kSigGroups = 7;  // measured (round 2, hash-probe walk): eng.aspell k=3 d=2, 1 M queries: 6 groups 5.45 k record tests per
+                               // query, 37.8 k tiles, 3.33 ms per step; 7: 4.14 k tests, 56.6 k tiles, 3.22 ms; 8: 2.35 k tests,
+                               // 96 k tiles, 3.48 ms.  1 M-entry lexicon, 1.25 M queries: 13.5 / 12.2 / 13.8 ms
 uint64_t signature_of(const uint8_t* cv, size_t n, const std::vector<uint8_t>& sym_group);
 
 struct Confusable {  // src/confusables.rs:5-11; one edit-script pattern with '|' options per instruction

@@ -124,5 +124,5 @@ def test_hash_probe_walk_equals_flat_walk(eng, data_dir, monkeypatch, kw):
     for x, y in zip(pa, fa):
         assert np.array_equal(x, y)
     assert np.array_equal(pc, fc)
-    for k in ("n_queries", "n_pairs", "n_class_tests", "n_results", "n_survivors"):
+    for k in ("n_queries", "n_pairs", "n_results", "n_survivors"):   # (n_class_tests counts chunk padding, which depends on the staging order)
         assert ps[k] == fs[k], k
