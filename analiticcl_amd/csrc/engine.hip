@@ -304,16 +304,19 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
   // signature and probes the table: 377 probes for 6 groups and k = 3, whatever the size of the lexicon.
   uint32_t hmask = 64;
   while (hmask < 4 * (uint32_t)img.nsigs) hmask <<= 1;
-  std::vector<uint4> shash;
+  std::vector<uint4> shash, shash_e;  // {sig lo, sig hi, first class / first entry of the run, classes / entries}; count 0 = empty slot
   for (;; hmask <<= 1) {  // every key within 16 probes of its home slot
     shash.assign(hmask, make_uint4(0u, 0u, 0u, 0u));
+    shash_e.assign(hmask, make_uint4(0u, 0u, 0u, 0u));
     bool ok = true;
     for (uint32_t i = 0; i < img.nsigs && ok; ++i) {
       uint32_t h = sig_hash(img.sig_lo[i], img.sig_hi[i]) & (hmask - 1);
       int probes = 0;
       while (shash[h].w && probes < 16) { h = (h + 1) & (hmask - 1); ++probes; }
-      if (probes == 16) ok = false;
-      else shash[h] = make_uint4(img.sig_lo[i], img.sig_hi[i], i, 1u);
+      if (probes == 16) { ok = false; break; }
+      const uint32_t c0 = img.sig_cbeg[i], c1 = img.sig_cbeg[i + 1];  // a signature's run holds at least one class, a class one entry
+      shash[h] = make_uint4(img.sig_lo[i], img.sig_hi[i], c0, c1 - c0);
+      shash_e[h] = make_uint4(img.sig_lo[i], img.sig_hi[i], img.cls_off[c0], img.cls_off[c1] - img.cls_off[c0]);
     }
     if (ok) break;
   }
@@ -358,6 +361,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
       (rc = upload(&d->scan_rec, srec.data(), srec.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_e, sig2e.data(), sig2e.size(), err, &d->bytes)) ||
       (rc = upload(&d->sighash, shash.data(), shash.size(), err, &d->bytes)) ||
+      (rc = upload(&d->sighash_e, shash_e.data(), shash_e.size(), err, &d->bytes)) ||
       (rc = upload(&d->ball, ball.data(), ball.size(), err, &d->bytes)) ||
       (rc = upload(&d->ball_tab, btab.data(), btab.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig, sig2.data(), sig2.size(), err, &d->bytes)) ||
@@ -391,7 +395,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sighash, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sighash, (void*)d->sighash_e, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
@@ -893,7 +897,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     ScanArgs A;
     A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
     A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
-    A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
+    A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.sighash_e = dl->sighash_e; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
     { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; A.chunk = v >= 32 && v <= 1024 ? (uint32_t)v : SCAN_CHUNK; }
     A.raw = b->raw; A.region_cap = region_cap; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
     A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;

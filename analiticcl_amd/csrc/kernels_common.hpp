@@ -54,7 +54,8 @@ struct DeviceLexicon {
   uint32_t* cls_off = nullptr;
   uint4* scan_rec = nullptr;       // [E + 1][2] per entry {4 planes of its class} {len, class, 0, 0}: ScanArgs::scan_rec
   uint4* sig_e = nullptr;          // [nsig_pad] signature table with entry runs (ScanArgs::sig_e)
-  uint4* sighash = nullptr;        // open-addressing table {sig lo, sig hi, signature index, 1}; empty slots are 0 (ScanArgs::sighash)
+  uint4* sighash = nullptr;        // open-addressing table {sig lo, sig hi, first class of the run, classes}; empty slots are 0
+  uint4* sighash_e = nullptr;      // the same slots with the run as scan records {.., .., first entry, entries} (bit-plane scan)
   uint32_t hash_mask = 0;
   unsigned long long* ball = nullptr;  // signature offsets (8 x int8) with sum |offset| <= k, for k = 0..12 back to back
   uint32_t* ball_tab = nullptr;    // device copy of ball_off[13] ++ ball_n[13]

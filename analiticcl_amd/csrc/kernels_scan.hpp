@@ -99,7 +99,8 @@ struct ScanArgs {
   const uint32_t* cls_off;
   const uint4* sig;         // signature table: {groups 0-3, groups 4-7 packed as bytes, first class of the run, classes}
   const uint4* sig_e;       // the same with the run as scan records: {.., .., first entry of the run, entries} (bit-plane kernel)
-  const uint4* sighash;     // open-addressing table {sig lo, sig hi, signature index, 1}; empty = 0
+  const uint4* sighash;     // open-addressing table {sig lo, sig hi, first class of the run, classes}; count 0 = empty
+  const uint4* sighash_e;   // the same slots with entry runs (bit-plane kernel)
   uint32_t hash_mask;
   const unsigned long long* ball;  // signature offsets (8 x int8) of the L1 balls, Tile::ball0 / balln index it
   const uint32_t* sig_cbeg;
@@ -370,27 +371,26 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     // 6 groups and k = 3 whatever the size of the lexicon, against a walk over every signature of the +-k charcount window.
     const unsigned long long H = 0x8080808080808080ull;
     const unsigned long long sq = (unsigned long long)t.sig_lo | (unsigned long long)t.sig_hi << 32;  // every byte <= SIG_BYTE_MAX
+    const uint4* __restrict__ htab = BITS ? A.sighash_e : A.sighash;
     for (uint32_t base = 0; base < t.balln; base += 64) {
       const uint32_t i = base + lane;
       bool found = false;
-      uint32_t sidx = 0;
+      uint32_t first = 0, count = 0;
       if (i < t.balln) {
         const unsigned long long dl = A.ball[t.ball0 + i];
         const unsigned long long r = ((sq & ~H) + (dl & ~H)) ^ ((sq ^ dl) & H);  // byte-wise sum, no carry between bytes
         if (!(r & (r << 1) & H)) {  // a byte >= 0xC0 is a negative group sum: no such signature
           const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
           uint32_t h = sig_hash(lo, hi) & A.hash_mask;
-          for (int p = 0; p < 17; ++p) {
-            const uint4 e = A.sighash[h];
+          for (int p = 0; p < 17; ++p) {  // the table is built with every key within 16 slots of its home
+            const uint4 e = htab[h];
             if (!e.w) break;
-            if (e.x == lo && e.y == hi) { found = true; sidx = e.z; break; }
+            if (e.x == lo && e.y == hi) { found = true; first = e.z; count = e.w; break; }
             h = (h + 1u) & A.hash_mask;
           }
         }
       }
-      uint4 sg = make_uint4(0u, 0u, 0u, 0u);
-      if (found) sg = sigtab[sidx];
-      stage_runs(found, sg.z, sg.w);
+      stage_runs(found, first, count);
     }
   } else {
     // The flat walk: every signature of the +-k charcount window [s0, s1) (aligned to 64-signature blocks: the other
