@@ -401,11 +401,21 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
             arena.push_back('\0');
           }
       }
-      std::vector<const char*> ptrs(nseg);
-      for (size_t i = 0; i < nseg; ++i) ptrs[i] = arena.data() + seg_off[i];
       anx_result* rows = nullptr;
       size_t* offs = nullptr;
-      const int rc = anx_find_variants_batch(model, ptrs.data(), nseg, &sp->base, &rows, &offs);
+      int rc;
+      if (nseg <= ((size_t)4 << 20) && arena.size() < ((size_t)1 << 32)) {
+        // the arena IS the packed form of the batch (every segment followed by a NUL byte): it goes to the device as it is
+        anx_batch* bt = anx_batch_encode_packed(model, arena.data(), arena.size(), nseg, &sp->base);
+        rc = bt ? anx_batch_run(model, bt, nullptr) : ANX_EINVAL;
+        if (bt && rc == ANX_OK) rc = anx_batch_fetch(bt, &rows, &offs);
+        if (bt) anx_batch_free(bt);
+        if (!bt) { free_kept(); return ANX_ENODEVICE; }  // the message of the failed encode stays in anx_last_error()
+      } else {  // more segments than one device batch holds: the pointer form splits them
+        std::vector<const char*> ptrs(nseg);
+        for (size_t i = 0; i < nseg; ++i) ptrs[i] = arena.data() + seg_off[i];
+        rc = anx_find_variants_batch(model, ptrs.data(), nseg, &sp->base, &rows, &offs);
+      }
       if (rc != ANX_OK) { free_kept(); return rc; }
       kept.push_back(OrderRows{rows, offs});
       size_t i = 0;
