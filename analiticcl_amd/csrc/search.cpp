@@ -132,52 +132,6 @@ struct OutSym {  // OutputSymbol, src/search.rs:133-150
   size_t boundary_index;
 };
 
-// lm_score_tokens (src/lib.rs:2632-2674): f32 log-probability, f64 perplexity; token -1 = out of vocabulary
-void lm_score_tokens(const HostModel& m, const std::vector<int64_t>& tokens, float* logprob_out, double* ppl_out) {
-  const float SMOOTH = -13.815510557964274f;  // src/search.rs:4
-  float logprob = 0.0f;
-  size_t n = 0;
-  for (size_t i = 1; i < tokens.size(); ++i) {
-    if (tokens[i - 1] >= 0 && tokens[i] >= 0) {
-      const uint64_t bg[2] = {(uint64_t)tokens[i - 1], (uint64_t)tokens[i]};
-      auto pit = m.unigrams.find(bg[0]);
-      const uint32_t priorcount = pit == m.unigrams.end() ? 1u : pit->second;
-      auto jit = m.bigrams.find((bg[0] << 32) | (bg[1] & 0xFFFFFFFFull));
-      if (jit != m.bigrams.end()) {
-        if (priorcount < jit->second) logprob += logf((float)jit->second);
-        else logprob += logf((float)jit->second / (float)priorcount);
-      } else logprob += SMOOTH;
-    } else logprob += SMOOTH;
-    ++n;
-  }
-  *logprob_out = logprob;
-  *ppl_out = -1.0 / (double)n * (double)logprob;
-}
-// lm_score (src/lib.rs:2580-2629)
-void lm_score(const HostModel& m, const char* text, const std::vector<OutSym>& seq, const Span* bs, float* lp, double* ppl) {
-  std::vector<int64_t> tokens;
-  auto push_item = [&](uint64_t id) {  // into_ngram(id), precomputed by build_lm
-    for (uint32_t k = m.ngram_off[id]; k < m.ngram_off[id + 1]; ++k) tokens.push_back((int64_t)m.ngram_ids[k]);
-  };
-  tokens.push_back(0);  // BOS
-  for (const OutSym& o : seq) {
-    if (o.vocab_id == 0) tokens.push_back(-1);
-    else push_item(o.vocab_id);
-    const Span& nb = bs[o.boundary_index];
-    // the boundary text, trimmed, as a token of its own (src/lib.rs:2600-2620); a single space needs no string
-    if (!(nb.end - nb.begin == 1 && text[nb.begin] == ' ') && nb.end > nb.begin) {
-      const std::string bt = anx::trim_whitespace(std::string(text + nb.begin, nb.end - nb.begin));
-      if (!bt.empty()) {
-        auto it = m.encoder.find(bt);
-        if (it != m.encoder.end()) push_item(it->second);
-        else tokens.push_back(-1);
-      }
-    }
-  }
-  tokens.push_back(1);  // EOS
-  lm_score_tokens(m, tokens, lp, ppl);
-}
-
 // most_likely_sequence (src/lib.rs:2088-2495).  The reference decodes with rustfst's
 // shortest_path(nshortest = max_seq) over a lattice whose states are the boundaries; this is the exact k-best over the
 // same DAG.  The order among equal-cost paths is rustfst-internal in the reference and is not pinned.
@@ -255,14 +209,63 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   float best_cost = (float)(nb - 1) * 2.0f;
   std::vector<double> ppls(paths.size(), 0.0), ctx(paths.size(), 1.0);
   std::vector<std::vector<std::vector<anx::PatternMatchResult>>> ctx_results(use_rules ? paths.size() : 0);
-  std::vector<OutSym> seq;
   std::vector<std::pair<uint64_t, uint32_t>> idseq;
+  // LM scoring of up to max_seq paths of one lattice: the paths share almost all of their bigrams, so the tokens of every
+  // symbol (its n-gram parts + the boundary text behind it, src/lib.rs:2580-2629) are looked up once, and every bigram term
+  // (src/lib.rs:2632-2674) once per lattice; the f32 sum runs over the same terms in the same order as lm_score_tokens.
+  std::vector<uint32_t> tok_off;
+  std::vector<int64_t> tok;
+  struct Term { int64_t a, b; float v; bool used; };
+  std::vector<Term> memo;
+  size_t memo_used = 0;
+  auto term = [&](int64_t a, int64_t b) -> float {
+    const float SMOOTH = -13.815510557964274f;  // src/search.rs:4
+    if (a < 0 || b < 0) return SMOOTH;
+    size_t h = ((uint64_t)a * 0x9E3779B97F4A7C15ull ^ (uint64_t)b * 0xC2B2AE3D27D4EB4Full) >> 54;  // 1024 slots
+    for (;; h = (h + 1) & 1023) {
+      Term& t = memo[h];
+      if (t.used && t.a == a && t.b == b) return t.v;
+      if (!t.used) {
+        auto pit = m.unigrams.find((uint64_t)a);
+        const uint32_t priorcount = pit == m.unigrams.end() ? 1u : pit->second;
+        auto jit = m.bigrams.find(((uint64_t)a << 32) | ((uint64_t)b & 0xFFFFFFFFull));
+        float v = SMOOTH;
+        if (jit != m.bigrams.end()) v = priorcount < jit->second ? logf((float)jit->second) : logf((float)jit->second / (float)priorcount);
+        if (memo_used < 768) { t = Term{a, b, v, true}; ++memo_used; }  // a full table stops caching, never loops
+        return v;
+      }
+    }
+  };
+  if (use_lm) {
+    memo.assign(1024, Term{0, 0, 0.0f, false});
+    tok_off.assign(symbols.size() + 1, 0);
+    for (size_t sy = 1; sy < symbols.size(); ++sy) {
+      tok_off[sy] = (uint32_t)tok.size();
+      const OutSym& o = symbols[sy];
+      if (o.vocab_id == 0) tok.push_back(-1);
+      else for (uint32_t k = m.ngram_off[o.vocab_id]; k < m.ngram_off[o.vocab_id + 1]; ++k) tok.push_back((int64_t)m.ngram_ids[k]);
+      const Span& nbs = bs[o.boundary_index];
+      if (!(nbs.end - nbs.begin == 1 && text[nbs.begin] == ' ') && nbs.end > nbs.begin) {
+        const std::string bt = anx::trim_whitespace(std::string(text + nbs.begin, nbs.end - nbs.begin));
+        if (!bt.empty()) {
+          auto it = m.encoder.find(bt);
+          if (it != m.encoder.end()) for (uint32_t k = m.ngram_off[it->second]; k < m.ngram_off[it->second + 1]; ++k) tok.push_back((int64_t)m.ngram_ids[k]);
+          else tok.push_back(-1);
+        }
+      }
+    }
+    tok_off[symbols.size()] = (uint32_t)tok.size();
+  }
   for (size_t i = 0; i < paths.size(); ++i) {
     if (use_lm) {
-      seq.clear();
-      for (long sy : paths[i].syms) seq.push_back(symbols[(size_t)sy]);
-      float lp;
-      lm_score(m, text, seq, bs, &lp, &ppls[i]);
+      float logprob = 0.0f;
+      size_t n = 0;
+      int64_t prev = 0;  // BOS
+      for (long sy : paths[i].syms)
+        for (uint32_t k = tok_off[(size_t)sy]; k < tok_off[(size_t)sy + 1]; ++k) { logprob += term(prev, tok[k]); ++n; prev = tok[k]; }
+      logprob += term(prev, 1);  // EOS
+      ++n;
+      ppls[i] = -1.0 / (double)n * (double)logprob;
       if (ppls[i] < best_ppl) best_ppl = ppls[i];
     }
     if (use_rules) {  // src/lib.rs:2345-2363, 2505-2518
