@@ -149,14 +149,21 @@ def make_model(a) -> VariantModel:
     # makes the tag differ and the model is rebuilt (the reference rebuilds on every start, so it can never be stale)
     tag = _index_tag(a) if a.index_cache else None
     if a.index_cache and os.path.exists(a.index_cache) and VariantModel.index_tag_of(a.index_cache) == tag:
-        model.load_index(a.index_cache)
-        for filename in a.confusables:
-            model.read_confusablelist(filename)
-        for filename in a.contextrules:
-            model.read_contextrules(filename)
-        if a.early_confusables:
-            model.set_confusables_before_pruning()
-        return model
+        try:
+            model.load_index(a.index_cache)
+            loaded = True
+        except Exception as e:  # noqa: BLE001 -- another layout (e.g. signature groups), another alphabet, a damaged file: rebuild
+            sys.stderr.write(f"[analiticcl_amd] {a.index_cache}: {e}; rebuilding the index\n")
+            loaded = False
+            model = VariantModel(a.alphabet, weights, device=a.device)
+        if loaded:
+            for filename in a.confusables:
+                model.read_confusablelist(filename)
+            for filename in a.contextrules:
+                model.read_contextrules(filename)
+            if a.early_confusables:
+                model.set_confusables_before_pruning()
+            return model
     # resources in command-line order (bin:1020-1068): lexicons, variant lists, error lists
     order = []
     argv = sys.argv
