@@ -359,6 +359,20 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       // Count-vector path (and ANX_SCAN_HITLIST=1): the non-empty (class, hit mask) pairs are appended to the wave's LDS hit
       // list; flush() expands the list one entry per lane whenever it gets full (and at the end of the tile), so the expansion
       // rounds run with full waves.  Mask bit b = query qb + b of the tile.
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const bool nz = hm[j] != 0;
+        const unsigned long long bm = __ballot(nz);
+        const uint32_t cnt = (uint32_t)__popcll(bm);
+        if (cnt) {  // wave-uniform
+          if (nz) {
+            const uint32_t pos = nhits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            hits[2 * pos] = cid[j] | ((qb >> 5) << 27);  // entry (bit-plane path) or class id, pass, count-only flag
+            hits[2 * pos + 1] = __brev(hm[j]) >> (32u - npass);  // shift-in order -> bit b = query b of the pass
+          }
+          nhits += cnt;
+        }
+      }
       if (nhits > SCAN_HITS - CHUNK) flush();  // a pass adds at most CHUNK entries
     }
   };
