@@ -112,7 +112,6 @@ struct ScanArgs {
   int want_exact;
   int drop_len;             // do not materialise pairs with |len_q - len_c| > d: damerau_levenshtein returns None for them at its
                             // first test (src/distance.rs:109-130); they are only counted as scored pairs
-  int hitlist;              // bit-plane path: keep the round-1 LDS hit list instead of emitting a pass's pairs directly (A/B)
   uint32_t* qpairs;         // per query: scored pairs of THIS run, counted where they are produced (materialised or only counted);
                             // nullptr in normal runs (anx_batch_pair_counts: the per-query check of the production pair list)
   int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
@@ -313,52 +312,9 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         any |= hm[j];
       }
       if (__ballot(any != 0) == 0ull || (A.dbg & 8)) continue;  // wave-uniform (dbg 8: timing without the expansion)
-      if (BITS && !A.hitlist) {
-        // Bit-plane path: a hit is one (query, entry) pair, so the pairs of the pass go straight from the hit masks into the
-        // wave's chunk of the pair list -- no LDS hit list, no second pass over it.  Per record slot j the lanes loop over
-        // their set bits (the wave runs max-over-lanes popcount iterations: 2-3 at 1.3 % hits).
-        uint32_t mm[CPL], ncls[CPL];
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          uint32_t m = __brev(hm[j]) >> (32u - npass);  // shift-in order -> bit b = query b of the pass
-          const uint32_t e = cid[j] & ((1u << 27) - 1u);
-          ncls[j] = (m && (A.want_exact || A.qpairs)) ? A.scan_rec[2 * (size_t)e + 1].y : 0u;  // class of the entry (rare modes only)
-          if (A.qpairs) {  // per-query pair counts of this very run (StopAtExactMatch: only the exact class counts when there is one)
-            for (uint32_t x = m; x; x &= x - 1u) {
-              const uint32_t q = t.q0 + qb + (uint32_t)__ffs((int)x) - 1u;
-              if (!A.want_exact || A.qexact[q] == 0xFFFFFFFFu || A.qexact[q] == ncls[j]) atomicAdd(&A.qpairs[q], 1u);
-            }
-          }
-          if ((cid[j] >> 28) & 1u) {  // every pair of this record fails the length test of the DL: count, do not emit
-            counted_only += (uint32_t)__popc(m);
-            m = 0;
-          }
-          mm[j] = m;
-          cnt += (uint32_t)__popc(m);
-        }
-        uint32_t total;
-        uint32_t g = wave_reserve(wo, cnt, lane, &total);
-        if (total) {  // wave-uniform
-          const bool fits = total <= wo.split && wo.base + total <= wo.rend;  // the common case: no spill select, no bounds test
-#pragma unroll
-          for (int j = 0; j < CPL; ++j) {
-            if (!__ballot(mm[j] != 0)) continue;  // wave-uniform
-            const uint32_t e = cid[j] & ((1u << 27) - 1u);
-            for (uint32_t m = mm[j]; m; m &= m - 1u, ++g) {
-              const uint32_t q = t.q0 + qb + (uint32_t)__ffs((int)m) - 1u;
-              const uint32_t exact = (A.want_exact && A.qexact[q] == ncls[j]) ? 0x80000000u : 0u;  // src/lib.rs:1164-1173
-              const uint32_t pos = fits ? wo.base + g : wave_slot(wo, g);
-              if (fits || pos < wo.rend) raw[pos] = make_uint2(q, e | exact);
-            }
-          }
-          wave_commit(wo, total);
-        }
-        continue;
-      }
-      // Count-vector path (and ANX_SCAN_HITLIST=1): the non-empty (class, hit mask) pairs are appended to the wave's LDS hit
-      // list; flush() expands the list one entry per lane whenever it gets full (and at the end of the tile), so the expansion
-      // rounds run with full waves.  Mask bit b = query qb + b of the tile.
+      // The non-empty (class, hit mask) pairs are appended to the wave's LDS hit list; flush() expands the list one
+      // entry per lane whenever it gets full (and at the end of the tile), so the expansion rounds run with full
+      // waves and the loop runs max-over-entries popcount times.  Mask bit b = query qb + b of the tile.
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         const bool nz = hm[j] != 0;
