@@ -320,7 +320,9 @@ struct Scratch {  // pool blocks released together
     *p = static_cast<T*>(q);
     return ANX_OK;
   }
-  ~Scratch() { for (void* q : blocks) pool_free(q); }
+  // the blocks go back to the pool, where another batch may take them at once: nothing enqueued by this call (default stream)
+  // may still be using them -- the normal path has synchronised already, an error path has not
+  ~Scratch() { (void)hipStreamSynchronize(nullptr); for (void* q : blocks) pool_free(q); }
 };
 template <typename K>
 int sort_pairs(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, Scratch& sc, hipStream_t st,
