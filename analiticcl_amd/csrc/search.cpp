@@ -139,7 +139,11 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
                           size_t end_offset, const anx_search_params& p, std::vector<Span>& out) {
   struct Arc { float cost; size_t dst; long sym; };
   const size_t nstates = nb + 1;
-  std::vector<std::vector<Arc>> arcs(nstates);
+  // per-thread buffers that keep their capacity from one stretch to the next: the candidate lists of a state grow to thousands
+  // of nodes, and growing them afresh for each of the ~90 k stretches of a 12 MB text was a third of the decoding time
+  static thread_local std::vector<std::vector<Arc>> arcs;
+  if (arcs.size() < nstates) arcs.resize(nstates);
+  for (size_t i = 0; i < nstates; ++i) arcs[i].clear();
   std::vector<OutSym> symbols(1);
   std::vector<size_t> finals;
   for (size_t i = 0; i < nb; ++i)
@@ -171,7 +175,9 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   // topological order by index, so best[s] is final (sorted, cut to K) before it is expanded.
   struct Node { float cost; uint32_t ps, pr; long sym; uint32_t seq; };
   const size_t K = std::max<uint32_t>(1, p.max_seq);
-  std::vector<std::vector<Node>> best(nstates);
+  static thread_local std::vector<std::vector<Node>> best;
+  if (best.size() < nstates) best.resize(nstates);
+  for (size_t i = 0; i < nstates; ++i) best[i].clear();
   best[0].push_back(Node{0.0f, UINT32_MAX, 0, -1, 0});  // the start node
   // the K cheapest candidates in stable order (= stable sort by cost, cut at K): selection by (cost, insertion index)
   // costs O(n) for the n >> K candidates of a state instead of O(n log n)
@@ -195,9 +201,12 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   std::vector<Node> ends;
   for (size_t f : finals) ends.insert(ends.end(), best[f].begin(), best[f].end());
   keep_k_best(ends);
-  std::vector<Path> paths(ends.size());
-  for (size_t i = 0; i < ends.size(); ++i) {
+  static thread_local std::vector<Path> paths;  // (capacity of the symbol lists kept across stretches)
+  const size_t npaths = ends.size();
+  if (paths.size() < npaths) paths.resize(npaths);
+  for (size_t i = 0; i < npaths; ++i) {
     paths[i].cost = ends[i].cost;
+    paths[i].syms.clear();
     for (Node cur = ends[i]; cur.ps != UINT32_MAX; cur = best[cur.ps][cur.pr])
       if (cur.sym >= 0) paths[i].syms.push_back(cur.sym);
     std::reverse(paths[i].syms.begin(), paths[i].syms.end());
@@ -207,8 +216,8 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   const bool use_rules = !m.context_rules.empty();
   double best_ppl = 999999.0, best_ctx = 0.0;
   float best_cost = (float)(nb - 1) * 2.0f;
-  std::vector<double> ppls(paths.size(), 0.0), ctx(paths.size(), 1.0);
-  std::vector<std::vector<std::vector<anx::PatternMatchResult>>> ctx_results(use_rules ? paths.size() : 0);
+  std::vector<double> ppls(npaths, 0.0), ctx(npaths, 1.0);
+  std::vector<std::vector<std::vector<anx::PatternMatchResult>>> ctx_results(use_rules ? npaths : 0);
   std::vector<std::pair<uint64_t, uint32_t>> idseq;
   // LM scoring of up to max_seq paths of one lattice: the paths share almost all of their bigrams, so the tokens of every
   // symbol (its n-gram parts + the boundary text behind it, src/lib.rs:2580-2629) are looked up once, and every bigram term
@@ -256,7 +265,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     }
     tok_off[symbols.size()] = (uint32_t)tok.size();
   }
-  for (size_t i = 0; i < paths.size(); ++i) {
+  for (size_t i = 0; i < npaths; ++i) {
     if (use_lm) {
       float logprob = 0.0f;
       size_t n = 0;
@@ -282,7 +291,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   const bool shortcut = (!m.have_lm || p.lm_weight == 0.0f) && (!use_rules || p.contextrules_weight == 0.0f);
   double best_score = -99999999.0;
   long best_i = -1;
-  for (size_t i = 0; i < paths.size(); ++i) {
+  for (size_t i = 0; i < npaths; ++i) {
     const double norm_lm = use_lm ? std::log(best_ppl / ppls[i]) : 0.0;
     const double norm_var = std::log((double)best_cost / (double)paths[i].cost);
     const double norm_ctx = std::log(ctx[i] / best_ctx);
