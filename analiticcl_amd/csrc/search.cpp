@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "host_model.h"
@@ -179,28 +180,46 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   if (best.size() < nstates) best.resize(nstates);
   for (size_t i = 0; i < nstates; ++i) best[i].clear();
   best[0].push_back(Node{0.0f, UINT32_MAX, 0, -1, 0});  // the start node
-  // the K cheapest candidates in stable order (= stable sort by cost, cut at K): selection by (cost, insertion index)
-  // costs O(n) for the n >> K candidates of a state instead of O(n log n)
-  auto keep_k_best = [K](std::vector<Node>& v) {
-    for (size_t i = 0; i < v.size(); ++i) v[i].seq = (uint32_t)i;
-    auto cmp = [](const Node& a, const Node& b) { return a.cost < b.cost || (a.cost == b.cost && a.seq < b.seq); };
+  // The K cheapest candidates of a state in stable order (= stable sort by cost, cut at K) = the K smallest under
+  // (cost, insertion number).  A state's candidate list never holds more than 2K nodes: when it reaches 2K it is cut to its K
+  // best and the K-th cost becomes the state's bound; a later candidate at or above the bound can never enter the K best (ties
+  // go to the earlier insertion), and since best[s] is sorted the expansion of an arc stops at the first such candidate.
+  auto cmp = [](const Node& a, const Node& b) { return a.cost < b.cost || (a.cost == b.cost && a.seq < b.seq); };
+  auto cut_to_k = [K, &cmp](std::vector<Node>& v) {
     if (v.size() > K) {
       std::nth_element(v.begin(), v.begin() + (long)K, v.end(), cmp);
       v.resize(K);
     }
-    std::sort(v.begin(), v.end(), cmp);
   };
+  static thread_local std::vector<float> bound;
+  static thread_local std::vector<uint32_t> nseq;
+  bound.assign(nstates, std::numeric_limits<float>::infinity());
+  nseq.assign(nstates, 0u);
   for (size_t s = 0; s < nstates; ++s) {
     if (best[s].empty()) continue;
-    keep_k_best(best[s]);
-    for (const Arc& a : arcs[s])
-      for (size_t r = 0; r < best[s].size(); ++r)
-        best[a.dst].push_back(Node{best[s][r].cost + a.cost, (uint32_t)s, (uint32_t)r, a.sym, 0});
+    cut_to_k(best[s]);
+    std::sort(best[s].begin(), best[s].end(), cmp);
+    for (const Arc& a : arcs[s]) {
+      std::vector<Node>& dv = best[a.dst];
+      for (size_t r = 0; r < best[s].size(); ++r) {
+        const float c = best[s][r].cost + a.cost;
+        if (c >= bound[a.dst]) break;
+        dv.push_back(Node{c, (uint32_t)s, (uint32_t)r, a.sym, nseq[a.dst]++});
+        if (dv.size() >= 2 * K) {
+          cut_to_k(dv);
+          float mx = dv[0].cost;
+          for (const Node& x : dv) mx = std::max(mx, x.cost);
+          bound[a.dst] = mx;
+        }
+      }
+    }
   }
   struct Path { float cost; std::vector<long> syms; };
   std::vector<Node> ends;
   for (size_t f : finals) ends.insert(ends.end(), best[f].begin(), best[f].end());
-  keep_k_best(ends);
+  for (size_t i = 0; i < ends.size(); ++i) ends[i].seq = (uint32_t)i;
+  cut_to_k(ends);
+  std::sort(ends.begin(), ends.end(), cmp);
   static thread_local std::vector<Path> paths;  // (capacity of the symbol lists kept across stretches)
   const size_t npaths = ends.size();
   if (paths.size() < npaths) paths.resize(npaths);
