@@ -284,15 +284,37 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     }
     tok_off[symbols.size()] = (uint32_t)tok.size();
   }
+  struct LmState { float lp; uint32_t n; int64_t prev; bool done; };
+  static thread_local std::vector<std::vector<LmState>> lmst;
+  std::vector<std::pair<uint32_t, uint32_t>> chain;
+  if (use_lm) {
+    if (lmst.size() < nstates) lmst.resize(nstates);
+    for (size_t st = 0; st < nstates; ++st) lmst[st].assign(best[st].size(), LmState{0.0f, 0u, 0, false});
+  }
   for (size_t i = 0; i < npaths; ++i) {
     if (use_lm) {
-      float logprob = 0.0f;
-      size_t n = 0;
-      int64_t prev = 0;  // BOS
-      for (long sy : paths[i].syms)
-        for (uint32_t k = tok_off[(size_t)sy]; k < tok_off[(size_t)sy + 1]; ++k) { logprob += term(prev, tok[k]); ++n; prev = tok[k]; }
-      logprob += term(prev, 1);  // EOS
-      ++n;
+      // the running f32 sum of a path prefix belongs to the lattice node it ends in (every node has ONE parent), so it is
+      // computed once per node on the final paths, not once per path: the same additions in the same order
+      auto extend = [&](const LmState& from, long sy) {
+        LmState r = from;
+        if (sy >= 0)
+          for (uint32_t k = tok_off[(size_t)sy]; k < tok_off[(size_t)sy + 1]; ++k) { r.lp += term(r.prev, tok[k]); ++r.n; r.prev = tok[k]; }
+        r.done = true;
+        return r;
+      };
+      // walk up to the first node whose prefix is known, then back down
+      chain.clear();
+      uint32_t cs = ends[i].ps, cr = ends[i].pr;
+      while (cs != UINT32_MAX && !lmst[cs][cr].done) { chain.emplace_back(cs, cr); const Node& nd = best[cs][cr]; cs = nd.ps; cr = nd.pr; }
+      LmState cur = cs == UINT32_MAX ? LmState{0.0f, 0u, 0, true} : lmst[cs][cr];  // the start node: BOS, nothing summed yet
+      for (size_t c = chain.size(); c-- > 0;) {
+        const Node& nd = best[chain[c].first][chain[c].second];
+        cur = nd.ps == UINT32_MAX ? LmState{0.0f, 0u, 0, true} : extend(cur, nd.sym);
+        lmst[chain[c].first][chain[c].second] = cur;
+      }
+      cur = extend(cur, ends[i].sym);
+      const float logprob = cur.lp + term(cur.prev, 1);  // EOS
+      const size_t n = (size_t)cur.n + 1;
       ppls[i] = -1.0 / (double)n * (double)logprob;
       if (ppls[i] < best_ppl) best_ppl = ppls[i];
     }
