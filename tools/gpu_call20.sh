@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/call21
+O=$R/gpurun_out/call22
 mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_search.py tests/test_gpu_config4.py -q -x > $O/pytest_s.log 2>&1; echo "pytest search rc=$?" | tee -a $O/summary.txt
