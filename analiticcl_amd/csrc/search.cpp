@@ -30,6 +30,10 @@ int anx_fail(int code, const std::string& msg);         // capi.cpp
 namespace {
 
 using anx::HostModel;
+std::atomic<uint64_t> g_lat_ns[6];  // ANX_SEARCH_TIMING: time inside most_likely_sequence by part, all threads
+static const bool g_lat_timing = getenv("ANX_SEARCH_TIMING") != nullptr;
+inline uint64_t lat_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct LatLap { uint64_t t; LatLap() : t(g_lat_timing ? lat_now() : 0) {} void lap(int i) { if (g_lat_timing) { const uint64_t n = lat_now(); g_lat_ns[i] += n - t; t = n; } } };
 
 struct RowView {  // the ranked variants of a segment: a range of one n-gram order's result array (kept until the end)
   const anx_result* p = nullptr;
@@ -138,6 +142,7 @@ struct OutSym {  // OutputSymbol, src/search.rs:133-150
 // same DAG.  The order among equal-cost paths is rustfst-internal in the reference and is not pinned.
 void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span>& matches, const Span* bs, size_t nb,
                           size_t end_offset, const anx_search_params& p, std::vector<Span>& out) {
+  LatLap lat;
   struct Arc { float cost; size_t dst; long sym; };
   const size_t nstates = nb + 1;
   // per-thread buffers that keep their capacity from one stretch to the next: the candidate lists of a state grow to thousands
@@ -172,6 +177,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   }
   for (size_t i = 0; i < nb; ++i) arcs[i].push_back(Arc{100.0f, i + 1, -1});  // failsafe epsilon transitions
   if (symbols.size() == 1 || finals.empty()) { out.insert(out.end(), matches.begin(), matches.end()); return; }
+  lat.lap(0);
   // k-best paths into every state, kept as back-pointers (source state, rank there, symbol); states are in
   // topological order by index, so best[s] is final (sorted, cut to K) before it is expanded.
   struct Node { float cost; uint32_t ps, pr; long sym; uint32_t seq; };
@@ -214,6 +220,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
       }
     }
   }
+  lat.lap(1);
   struct Path { float cost; std::vector<long> syms; };
   std::vector<Node> ends;
   for (size_t f : finals) ends.insert(ends.end(), best[f].begin(), best[f].end());
@@ -230,6 +237,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
       if (cur.sym >= 0) paths[i].syms.push_back(cur.sym);
     std::reverse(paths[i].syms.begin(), paths[i].syms.end());
   }
+  lat.lap(2);
   // rerank (src/lib.rs:2318-2425)
   const bool use_lm = m.have_lm && p.lm_weight > 0.0f;
   const bool use_rules = !m.context_rules.empty();
@@ -329,6 +337,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     if (paths[i].cost < best_cost) best_cost = paths[i].cost;
     if (ctx[i] > best_ctx) best_ctx = ctx[i];
   }
+  lat.lap(3);
   const bool shortcut = (!m.have_lm || p.lm_weight == 0.0f) && (!use_rules || p.contextrules_weight == 0.0f);
   double best_score = -99999999.0;
   long best_i = -1;
@@ -353,6 +362,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
         if (pm.tag >= 0) r.tags.emplace_back((uint16_t)pm.tag, pm.seqnr);
     out.push_back(std::move(r));
   }
+  lat.lap(4);
 }
 
 struct Stretch {  // one hard-boundary "batch" of the reference (src/lib.rs:1821-1940)
@@ -524,6 +534,10 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     for (Span& s : decoded[si]) dst.push_back(std::move(s));
   }
   lap("lattice + LM");
+  if (timing) {
+    static const char* names[5] = {"arcs", "k-best", "paths", "LM + rules", "select + output"};
+    for (int i = 0; i < 5; ++i) fprintf(stderr, "[anx search]   lattice part %-16s %8.2f ms (summed over threads)\n", names[i], (double)g_lat_ns[i].exchange(0) * 1e-6);
+  }
   size_t total = 0, total_rows = 0, total_tags = 0;
   for (auto& v : per_text) { total += v.size(); for (auto& s : v) { total_rows += s.variants.size(); total_tags += s.tags.size(); } }
   anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, total_tags) * sizeof(anx_match_tag))) : nullptr;
