@@ -428,10 +428,50 @@ int HostModel::read_confusablelist(const std::string& path, std::string& err) { 
   return ANX_OK;
 }
 
+namespace {
+// A pattern can only be found in the edit script of (input -> candidate) if every instruction has an option that occurs in the
+// string the instruction's text is taken from: a deletion's text is a piece of the input, an insertion's a piece of the
+// candidate, an equality's a piece of both (found_in compares the option with the end / start / whole of that text); with `$`
+// the last diff is the end of the strings.  Necessary, not sufficient: it only decides whether the edit script is worth
+// computing -- on BASELINE configs[2] most ranked rows cannot match any of the patterns.
+struct CharSet { uint64_t w[2] = {0, 0}; bool other = false; };  // ASCII presence bits; `other`: some non-ASCII character
+CharSet charset_of(const U& s) {
+  CharSet cs;
+  for (char32_t ch : s) {
+    if (ch < 128) cs.w[ch >> 6] |= 1ull << (ch & 63);
+    else cs.other = true;
+  }
+  return cs;
+}
+bool occurs(const U& opt, const U& s, const CharSet& cs) {
+  if (opt.size() == 1 && opt[0] < 128) return (cs.w[opt[0] >> 6] >> (opt[0] & 63)) & 1ull;
+  return s.find(opt) != U::npos;
+}
+bool may_match(const Confusable& c, const U& in, const CharSet& ins, const U& cand, const CharSet& cs) {
+  const size_t l = c.ops.size();
+  for (size_t k = 0; k < l; ++k) {
+    bool any = false;
+    for (const U& opt : c.options[k]) {
+      bool ok = (c.ops[k] == '+' || occurs(opt, in, ins)) && (c.ops[k] == '-' || occurs(opt, cand, cs));
+      if (ok && c.strictend && k == l - 1 && c.ops[k] != '=')  // the last diff ends the script: its text ends the string
+        ok = ends_with(c.ops[k] == '+' ? cand : in, opt);
+      if (ok) { any = true; break; }
+    }
+    if (!any) return false;
+  }
+  return true;
+}
+}  // namespace
+
 double HostModel::confusable_weight(const std::string& input, uint64_t candidate) const {  // src/lib.rs:1733-1756
   double weight = 1.0;
   if (candidate >= decoder.size()) return weight;
-  const Diffs script = edit_script(to_u32(input), to_u32(decoder[candidate].text));
+  const U in = to_u32(input), cand = to_u32(decoder[candidate].text);
+  const CharSet ins = charset_of(in), cs = charset_of(cand);
+  bool any = false;
+  for (const Confusable& c : confusables) any = any || may_match(c, in, ins, cand, cs);
+  if (!any) return weight;  // no pattern can be in the script: not computed
+  const Diffs script = edit_script(in, cand);
   for (const Confusable& c : confusables)
     if (found_in(c, script)) weight *= c.weight;
   return weight;
