@@ -110,6 +110,7 @@ def lib():
         "anx_model_read_confusablelist": (C.c_int, [vp, cp]),
         "anx_model_set_confusables_before_pruning": (None, [vp]),
         "anx_edit_script": (C.c_int, [cp, cp, C.c_char_p, C.c_int]),
+        "anx_model_confusable_weight": (C.c_int, [vp, cp, u64, C.POINTER(C.c_double)]),
         "anx_model_build": (C.c_int, [vp, C.c_int]),
         "anx_model_save_index": (C.c_int, [vp, cp]),
         "anx_model_load_index": (C.c_int, [vp, cp, C.c_int]),

@@ -488,6 +488,12 @@ const char* anx_model_tag_name(const anx_model* m, size_t index) {
 void anx_model_set_confusables_before_pruning(anx_model* m) {
   if (m) m->host.confusables_before_pruning = true;
 }
+int anx_model_confusable_weight(const anx_model* m, const char* input, uint64_t vocab_id, double* out) {
+  if (!m || !input || !out) return fail(ANX_EINVAL, "NULL argument");
+  if (vocab_id >= m->host.decoder.size()) return fail(ANX_EINVAL, "no such vocabulary item");
+  *out = m->host.confusable_weight(input, vocab_id);
+  return ANX_OK;
+}
 int anx_edit_script(const char* source, const char* target, char* out, int cap) {
   if (!source || !target || !out) return fail(ANX_EINVAL, "NULL argument");
   const std::string s = anx::edit_script_string(source, target);

@@ -633,5 +633,12 @@ class VariantModel:
     def add_to_confusables(self, editscript: str, weight: float):
         L.check(L.lib().anx_model_add_to_confusables(self.h, _b(editscript), float(weight)))
 
+    def compute_confusable_weight(self, input: str, vocab_id: int) -> float:
+        """compute_confusable_weight (src/lib.rs:1733-1756): product of the weights of the confusable patterns found in the edit
+        script input -> vocabulary item."""
+        w = C.c_double(1.0)
+        L.check(L.lib().anx_model_confusable_weight(self.h, _b(input), int(vocab_id), C.byref(w)))
+        return w.value
+
     def set_confusables_before_pruning(self):
         L.lib().anx_model_set_confusables_before_pruning(self.h)

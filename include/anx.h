@@ -250,6 +250,9 @@ int anx_model_read_confusablelist(anx_model *, const char *path);
 void anx_model_set_confusables_before_pruning(anx_model *);
 /* shortest_edit_script(source, target, false, false, false) in sesdiff notation, e.g. "=[hu]-[y]+[i]=[s]" */
 int anx_edit_script(const char *source, const char *target, char *out, int cap);
+/* compute_confusable_weight(input, candidate), src/lib.rs:1733-1756: the product of the weights of the patterns found in the
+ * edit script input -> text of the vocabulary item (1.0 if none).  Host only. */
+int anx_model_confusable_weight(const anx_model *, const char *input_utf8, uint64_t vocab_id, double *out_weight);
 
 /* ---- search mode: the main caller of the hot path -------------------------------
  * VariantModel::find_all_matches(&self, text, &SearchParameters) -> Vec<Match>, src/lib.rs:1790, for n texts at once.

@@ -121,3 +121,37 @@ def test_composed_confusable_oracle_equals_twin(data_dir):
             assert got == exp, (q, got[:3], exp[:3])
             fired += any(CO.confusable_weight(confs, q, o.text(v)) != 1.0 for v, _d, _f in got)
     assert fired > 20
+
+
+def test_product_confusable_weight_equals_twin(data_dir):
+    """anx_model_confusable_weight (host: screen + edit script + pattern matcher) against the twin's compute_confusable_weight
+    on 6000 (misspelling, word) pairs and patterns of every shape: plain, multi-character, alternatives, context, `^`, `$`,
+    single-instruction equalities.  The screen that skips the edit script when no pattern can match must never change a weight."""
+    import os
+    import random
+    import analiticcl_amd as A
+    from analiticcl_amd import synth
+    pats = [("-[y]+[i]", 1.1), ("-[i]+[y]", 1.2), ("-[ck]+[k]", 1.05), ("-[c]+[k]", 1.3), ("-[ae]+[e]", 1.15), ("-[s]+[z]", 0.9),
+            ("=[c|k]-[y]+[i]", 1.07), ("+[e]$", 0.95), ("^-[h]", 0.8), ("-[e]$", 0.85), ("^+[s]", 1.25), ("=[t]+[t]", 1.4),
+            ("-[e]=[r]", 0.7), ("+[s]", 0.97), ("=[ing]$", 1.01), ("^=[un]", 1.02), ("-[a|e|i]+[o|u]", 1.11), ("+[é]", 1.5),
+            ("=[a]", 1.001), ("^=[b]-[a]", 1.6)]
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))[::29][:4000] + ["café", "cafe", "naïve"]
+    tw = T.VariantModel(T.read_alphabet(os.path.join(data_dir, "simple.alphabet.tsv")))
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights())
+    ids = []
+    for w in words:
+        ids.append(tw.add_to_vocabulary(w))
+        assert g.add_to_vocabulary(w) == ids[-1]
+    for pat, wt in pats:
+        tw.add_to_confusables(pat, wt)
+        g.add_to_confusables(pat, wt)
+    rng = random.Random(13)
+    qs = synth.make_queries(words, 6000, max_len=20, seed=17)
+    fired = 0
+    for q in qs:
+        near = min(rng.sample(range(len(words)), 30), key=lambda i: abs(len(words[i]) - len(q)) + sum(a != b for a, b in zip(words[i], q)))
+        for i in (near, rng.randrange(len(words))):
+            exp = tw.compute_confusable_weight(q, ids[i])
+            assert g.compute_confusable_weight(q, ids[i]) == exp, (q, words[i])
+            fired += exp != 1.0
+    assert fired > 1000
