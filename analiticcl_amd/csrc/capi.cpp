@@ -57,7 +57,14 @@ static void rescore_with_confusables(const anx::HostModel& m, const std::vector<
       anx_result* v = rows + offs[i];
       const size_t cnt = offs[i + 1] - offs[i];
       // the weight belongs to the matched item: the variant itself for rows reached through a variant list
-      for (size_t k = 0; k < cnt; ++k) v[k].dist_score *= m.confusable_weight(inputs[i], v[k].via != ANX_NO_VIA ? v[k].via : v[k].vocab_id);
+      uint64_t ids[64];
+      double wts[64];
+      for (size_t k0 = 0; k0 < cnt; k0 += 64) {
+        const size_t kn = std::min<size_t>(64, cnt - k0);
+        for (size_t k = 0; k < kn; ++k) ids[k] = v[k0 + k].via != ANX_NO_VIA ? v[k0 + k].via : v[k0 + k].vocab_id;
+        m.confusable_weights(inputs[i], ids, kn, wts);
+        for (size_t k = 0; k < kn; ++k) v[k0 + k].dist_score *= wts[k];
+      }
       std::stable_sort(v, v + cnt, [&](const anx_result& a, const anx_result& b) {  // rank_cmp, src/types.rs:344-365
         if (fw > 0.0f) return vr_score(a, fw) > vr_score(b, fw);
         if (a.dist_score != b.dist_score) return a.dist_score > b.dist_score;

@@ -463,18 +463,48 @@ bool may_match(const Confusable& c, const U& in, const CharSet& ins, const U& ca
 }
 }  // namespace
 
-double HostModel::confusable_weight(const std::string& input, uint64_t candidate) const {  // src/lib.rs:1733-1756
-  double weight = 1.0;
-  if (candidate >= decoder.size()) return weight;
-  const U in = to_u32(input), cand = to_u32(decoder[candidate].text);
-  const CharSet ins = charset_of(in), cs = charset_of(cand);
-  bool any = false;
-  for (const Confusable& c : confusables) any = any || may_match(c, in, ins, cand, cs);
-  if (!any) return weight;  // no pattern can be in the script: not computed
-  const Diffs script = edit_script(in, cand);
-  for (const Confusable& c : confusables)
-    if (found_in(c, script)) weight *= c.weight;
-  return weight;
+struct HostModel::ConfCache {
+  std::vector<U> text;
+  std::vector<CharSet> cs;
+};
+
+void HostModel::confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const {  // src/lib.rs:1733-1756
+  std::shared_ptr<ConfCache> held = std::atomic_load(&conf_cache);
+  if (!held || held->text.size() != decoder.size()) {  // first use, or the vocabulary grew since (items are only ever appended)
+    std::lock_guard<std::mutex> g(conf_cache_mu);
+    held = std::atomic_load(&conf_cache);
+    if (!held || held->text.size() != decoder.size()) {
+      auto cc = std::make_shared<ConfCache>();
+      cc->text.resize(decoder.size());
+      cc->cs.resize(decoder.size());
+      for (size_t i = 0; i < decoder.size(); ++i) { cc->text[i] = to_u32(decoder[i].text); cc->cs[i] = charset_of(cc->text[i]); }
+      std::atomic_store(&conf_cache, cc);
+      held = cc;
+    }
+  }
+  const ConfCache& cc = *held;
+  const U in = to_u32(input);
+  const CharSet ins = charset_of(in);
+  for (size_t k = 0; k < n; ++k) {
+    double weight = 1.0;
+    if (ids[k] < cc.text.size()) {
+      const U& cand = cc.text[ids[k]];
+      bool any = false;
+      for (const Confusable& c : confusables) any = any || may_match(c, in, ins, cand, cc.cs[ids[k]]);
+      if (any) {  // else no pattern can be in the script: not computed
+        const Diffs script = edit_script(in, cand);
+        for (const Confusable& c : confusables)
+          if (found_in(c, script)) weight *= c.weight;
+      }
+    }
+    out[k] = weight;
+  }
+}
+
+double HostModel::confusable_weight(const std::string& input, uint64_t candidate) const {
+  double w = 1.0;
+  confusable_weights(input, &candidate, 1, &w);
+  return w;
 }
 
 }  // namespace anx

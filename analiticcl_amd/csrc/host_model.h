@@ -3,6 +3,8 @@
 // (/root/reference/src/lib.rs:50-245, 369-407, 519-568, 900-967; src/anahash.rs:16-80; src/vocab.rs).
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -178,6 +180,12 @@ class HostModel {
   int add_to_confusables(const std::string& script, double weight, std::string& err);
   int read_confusablelist(const std::string& path, std::string& err);
   double confusable_weight(const std::string& input, uint64_t candidate) const;
+  // the same for the n ranked rows of one input (ids[k] -> out[k]): the input is decoded once, the vocabulary texts come from a
+  // decoded copy built on first use
+  void confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const;
+  struct ConfCache;                                   // UTF-32 texts + character sets of the vocabulary (confusables.cpp)
+  mutable std::shared_ptr<ConfCache> conf_cache;
+  mutable std::mutex conf_cache_mu;
   bool have_lm = false;
   std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
   std::unordered_map<uint64_t, uint32_t> unigrams, bigrams;  // the two orders lm_score_tokens looks up (id, id1 << 32 | id2)
