@@ -469,17 +469,18 @@ struct HostModel::ConfCache {
 };
 
 void HostModel::confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const {  // src/lib.rs:1733-1756
-  std::shared_ptr<ConfCache> held = std::atomic_load(&conf_cache);
+  const ConfCache* held = conf_cache.load(std::memory_order_acquire);
   if (!held || held->text.size() != decoder.size()) {  // first use, or the vocabulary grew since (items are only ever appended)
     std::lock_guard<std::mutex> g(conf_cache_mu);
-    held = std::atomic_load(&conf_cache);
+    held = conf_cache.load(std::memory_order_acquire);
     if (!held || held->text.size() != decoder.size()) {
       auto cc = std::make_shared<ConfCache>();
       cc->text.resize(decoder.size());
       cc->cs.resize(decoder.size());
       for (size_t i = 0; i < decoder.size(); ++i) { cc->text[i] = to_u32(decoder[i].text); cc->cs[i] = charset_of(cc->text[i]); }
-      std::atomic_store(&conf_cache, cc);
-      held = cc;
+      conf_cache_owned.push_back(cc);
+      conf_cache.store(cc.get(), std::memory_order_release);
+      held = cc.get();
     }
   }
   const ConfCache& cc = *held;

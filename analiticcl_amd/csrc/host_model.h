@@ -3,6 +3,7 @@
 // (/root/reference/src/lib.rs:50-245, 369-407, 519-568, 900-967; src/anahash.rs:16-80; src/vocab.rs).
 #pragma once
 #include <cstdint>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -184,7 +185,8 @@ class HostModel {
   // decoded copy built on first use
   void confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const;
   struct ConfCache;                                   // UTF-32 texts + character sets of the vocabulary (confusables.cpp)
-  mutable std::shared_ptr<ConfCache> conf_cache;
+  mutable std::atomic<const ConfCache*> conf_cache{nullptr};      // current copy (readers take no lock and no reference count)
+  mutable std::vector<std::shared_ptr<ConfCache>> conf_cache_owned;  // every copy ever published, released with the model
   mutable std::mutex conf_cache_mu;
   bool have_lm = false;
   std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
