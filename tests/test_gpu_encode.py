@@ -126,3 +126,17 @@ def test_hash_probe_walk_equals_flat_walk(eng, data_dir, monkeypatch, kw):
     assert np.array_equal(pc, fc)
     for k in ("n_queries", "n_pairs", "n_results", "n_survivors"):   # (n_class_tests counts chunk padding, which depends on the staging order)
         assert ps[k] == fs[k], k
+
+
+def test_random_bytes_device_equals_host_encoder(eng):
+    """Fuzz: 40 000 random byte strings (ASCII letters, alphabet punctuation, multi-character members, valid and broken UTF-8,
+    lengths 1..300, no NUL) through both encoders: identical rows, pair counts and tiles."""
+    import random
+    rng = random.Random(2024)
+    pieces = [bytes([c]) for c in range(1, 256)] + [b"''", b"``", "é".encode(), "ß".encode(), "日".encode(), "\U0001F600".encode(),
+                                                     b"e", b"a", b"s", b"t", b"n", b"i", b"r", b"o", b" ", b".", b"-", b"'"] * 6
+    qs = []
+    for _ in range(40000):
+        n = rng.choice((1, 2, 3, 5, 8, 8, 10, 12, 12, 16, 20, 30, 60, 150, 300))
+        qs.append(b"".join(rng.choice(pieces) for _ in range(rng.randrange(1, n + 1))))
+    run_both(eng, qs, A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10))
