@@ -544,22 +544,15 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
   if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_variants()"); return nullptr; }
   if (n && (blob_len == 0 || blob[blob_len - 1] != '\0')) { fail(ANX_EINVAL, "packed inputs must end with a NUL byte"); return nullptr; }
   if (blob_len >= ((size_t)1 << 32)) { fail(ANX_ELIMIT, "inputs exceed 4 GB per batch: split the batch"); return nullptr; }
-  // offsets of the n strings: the buffer goes to the device as it is (the device-side encoder reads the bytes there)
-  std::vector<uint32_t> off;
-  off.reserve(n + 1);
-  const char* cur = blob;
-  const char* end = blob + blob_len;
-  while (off.size() < n && cur < end) {
-    off.push_back((uint32_t)(cur - blob));
-    cur = static_cast<const char*>(memchr(cur, 0, (size_t)(end - cur))) + 1;
-  }
-  if (off.size() != n) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); return nullptr; }
-  off.push_back((uint32_t)(cur - blob));
+  // the buffer goes to the device as it is; the device-side encoder finds the strings' offsets there (the host only needs
+  // them when confusables are loaded: rescoring reads the input strings)
   std::string err;
   int code = ANX_OK;
   bool rescore;
   const anx_params dp = device_params(m, p, &rescore);
-  anx::Batch* b = anx::batch_encode_spans(m->host, m->dev, blob, off.data(), n, dp, err, &code);
+  std::vector<uint32_t> off;
+  if (rescore && !anx::packed_offsets(blob, blob_len, n, off)) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); return nullptr; }
+  anx::Batch* b = anx::batch_encode_spans(m->host, m->dev, blob, blob_len, rescore ? off.data() : nullptr, n, dp, err, &code);
   if (!b) { fail(code ? code : ANX_ENODEVICE, err); return nullptr; }
   anx_batch* h = new anx_batch();
   h->model = m;

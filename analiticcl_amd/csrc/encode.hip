@@ -163,6 +163,70 @@ __global__ void k_gather(const T* __restrict__ src, const uint32_t* __restrict__
   if (i < n) dst[i] = src[perm[i]];
 }
 
+// ---- offsets of NUL-separated strings (anx_batch_encode_packed hands over the buffer as it is) ----------------------------
+// The host used to walk the buffer with one memchr per string: 3 ms per million short strings, more than the whole encoder
+// on the device.  Two passes of 4096 bytes per block: count the zero bytes, (exclusive scan of the block counts), write
+// off[r + 1] = position after the r-th zero byte for r < n.  Zero test per byte, exact (no borrow between bytes):
+// a byte of ~(((x & 0x7F..) + 0x7F..) | x | 0x7F..) is 0x80 iff the byte of x is 0.
+constexpr uint32_t NUL_BLK = 4096;
+__device__ inline uint32_t zero_byte_flags(uint32_t x) {
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+// the 4 words of thread t of block b (bytes beyond len read as non-zero; the buffer is allocated in 16-byte multiples)
+__device__ inline void nul_flags(const uint8_t* __restrict__ blob, uint32_t len, uint32_t base, uint32_t (&f)[4]) {
+  f[0] = f[1] = f[2] = f[3] = 0;
+  if (base >= len) return;
+  const uint4 v = *reinterpret_cast<const uint4*>(blob + base);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t pos = base + 4u * (uint32_t)i;
+    if (pos >= len) break;
+    uint32_t x = w[i];
+    if (len - pos < 4u) x |= 0xFFFFFFFFu << (8u * (len - pos));
+    f[i] = zero_byte_flags(x);
+  }
+}
+__global__ __launch_bounds__(256) void k_nul_count(const uint8_t* __restrict__ blob, uint32_t len, uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ total) {
+  __shared__ uint32_t s_w[4];
+  uint32_t f[4];
+  nul_flags(blob, len, blockIdx.x * NUL_BLK + threadIdx.x * 16u, f);
+  uint32_t c = (uint32_t)(__popc(f[0]) + __popc(f[1]) + __popc(f[2]) + __popc(f[3]));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    counts[blockIdx.x] = t;
+    if (t) atomicAdd(total, t);
+  }
+}
+__global__ __launch_bounds__(256) void k_nul_emit(const uint8_t* __restrict__ blob, uint32_t len, const uint32_t* __restrict__ block_first,
+                                                  uint32_t n, uint32_t* __restrict__ off) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t base = blockIdx.x * NUL_BLK + threadIdx.x * 16u, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t f[4];
+  nul_flags(blob, len, base, f);
+  const uint32_t c = (uint32_t)(__popc(f[0]) + __popc(f[1]) + __popc(f[2]) + __popc(f[3]));
+  uint32_t incl = c;  // inclusive prefix over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+    if ((int)lane >= o) incl += up;
+  }
+  if (lane == 63) s_w[wid] = incl;
+  __syncthreads();
+  uint32_t r = block_first[blockIdx.x] + incl - c;  // rank of this thread's first zero byte
+  for (uint32_t w = 0; w < wid; ++w) r += s_w[w];
+  if (blockIdx.x == 0 && threadIdx.x == 0) off[0] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    for (uint32_t m = f[i]; m; m &= m - 1u, ++r)
+      if (r < n) off[r + 1] = base + 4u * (uint32_t)i + ((uint32_t)__ffs((int)m) >> 3);  // flag bit 8j+7 -> byte j, + 1
+}
+
 struct GatherArgs {
   uint32_t nq, qw;
   int NP, want_exact;
@@ -343,15 +407,16 @@ int balloc(T** dst, size_t count, std::string& err) {
 }  // namespace
 
 // Fills the query and tile arrays of `b` (device) from the packed inputs.  Returns ANX_OK or an error code.
-int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, const uint32_t* off, size_t n,
-                        const anx_params& p, std::string& err) {
+// off == nullptr: the n strings are the first n NUL-terminated spans of blob[0, blob_len); their offsets are found on the device.
+int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off,
+                        size_t n, const anx_params& p, std::string& err) {
   static const bool timing = getenv("ANX_ENCODE_TIMING") != nullptr;
   double t_prev = 0.0;
   auto tnow = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
   if (timing) t_prev = tnow();
   auto lap = [&](const char* what) { if (timing) { (void)hipDeviceSynchronize(); const double t = tnow(); fprintf(stderr, "[anx encode/device] %-24s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
   const uint32_t n32 = (uint32_t)n;
-  const size_t blob_len = n ? off[n] : 0;
+  const size_t blob_len = !n ? 0 : off ? off[n] : blob_bytes;
   const int NP = dl->nplanes;
   hipStream_t st = nullptr;
   Scratch sc;
@@ -371,9 +436,26 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
       (rc = sc.get(&d_cv, n * (size_t)NP, err)) || (rc = sc.get(&d_slen, n, err)) || (rc = sc.get(&d_sig, n, err)) || (rc = sc.get(&d_ctr, 8, err)))
     return rc;
   HIP_TRY(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_off, off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(d_cv, 0, n * (size_t)NP * 4, st));
   HIP_TRY(hipMemsetAsync(d_ctr, 0, 8 * sizeof(uint32_t), st));
+  if (off) {
+    HIP_TRY(hipMemcpyAsync(d_off, off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  } else {
+    const uint32_t nblk = (uint32_t)((blob_len + NUL_BLK - 1) / NUL_BLK);
+    uint32_t* d_cnt = nullptr;
+    if ((rc = sc.get(&d_cnt, nblk, err))) return rc;
+    hipLaunchKernelGGL(k_nul_count, dim3(nblk), dim3(256), 0, st, d_blob, (uint32_t)blob_len, d_cnt, d_ctr + 4);
+    size_t bytes = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, d_cnt, d_cnt, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), st));
+    char* tmp = nullptr;
+    if ((rc = sc.get(&tmp, bytes + 16, err))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp, bytes, d_cnt, d_cnt, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(k_nul_emit, dim3(nblk), dim3(256), 0, st, d_blob, (uint32_t)blob_len, d_cnt, n32, d_off);
+    uint32_t have = 0;  // the encoder below must not run over offsets that were never written
+    HIP_TRY(hipMemcpyAsync(&have, d_ctr + 4, sizeof have, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (have < n) { err = "packed inputs hold fewer strings than announced"; return ANX_EINVAL; }
+  }
   EncArgs ea;
   ea.blob = d_blob; ea.off = d_off; ea.n = n32; ea.al = dl->alpha; ea.A = m.alphabet.size(); ea.NP = NP;
   ea.bits_ok = (dl->nsym <= 32 && !(getenv("ANX_SCAN") && strcmp(getenv("ANX_SCAN"), "sad") == 0)) ? 1 : 0;

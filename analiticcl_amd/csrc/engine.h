@@ -21,9 +21,12 @@ void host_result_free(void* p);
 
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
                     const anx_params& p, std::string& err, int* code);
-// the same with the inputs in one buffer: input i = blob[off[i] .. off[i+1] - 1), followed by one NUL byte
-Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, const uint32_t* off, size_t n,
+// the same with the inputs in one buffer: input i = blob[off[i] .. off[i+1] - 1), followed by one NUL byte.  off == nullptr: the
+// inputs are the first n NUL-terminated spans of blob[0, blob_bytes) and the device finds their offsets itself
+Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
                           const anx_params& p, std::string& err, int* code);
+// offsets of the first n NUL-terminated spans of blob[0, len) (n + 1 values); false if there are fewer
+bool packed_offsets(const char* blob, size_t len, size_t n, std::vector<uint32_t>& off);
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
 // the same in two halves: enqueue on `stream` and return / wait for it (statistics, results usable afterwards)
 int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);

@@ -723,7 +723,25 @@ static int encode_tail(Batch* b, std::string& err) {
   return ANX_OK;
 }
 
-Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, const uint32_t* off, size_t n,
+bool packed_offsets(const char* blob, size_t len, size_t n, std::vector<uint32_t>& off) {
+  off.clear();
+  off.reserve(n + 1);
+  off.push_back(0);
+  // 8 bytes per step; a byte of z is 0x80 iff the byte of x is 0 (exact: no carry crosses a byte)
+  const unsigned long long L7 = 0x7F7F7F7F7F7F7F7Full;
+  size_t i = 0;
+  for (; i + 8 <= len && off.size() <= n; i += 8) {
+    unsigned long long x;
+    memcpy(&x, blob + i, 8);
+    for (unsigned long long z = ~(((x & L7) + L7) | x | L7); z && off.size() <= n; z &= z - 1)
+      off.push_back((uint32_t)(i + ((size_t)__builtin_ctzll(z) >> 3) + 1));
+  }
+  for (; i < len && off.size() <= n; ++i)
+    if (!blob[i]) off.push_back((uint32_t)(i + 1));
+  return off.size() == n + 1;
+}
+
+Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
                           const anx_params& p, std::string& err, int* code) {
   *code = ANX_OK;
   if (!dl) { err = "model is not resident on a device (no HIP device / anx_model_to_device not called)"; *code = ANX_ENODEVICE; return nullptr; }
@@ -736,11 +754,16 @@ Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const cha
   const char* mode = getenv("ANX_ENCODE");  // "host": the threaded host encoder (A/B reference); read per call
   int rc;
   if (mode && strcmp(mode, "host") == 0) {
+    std::vector<uint32_t> hoff;
+    if (!off) {
+      if (!packed_offsets(blob, blob_bytes, n, hoff)) { err = "packed inputs hold fewer strings than announced"; *code = ANX_EINVAL; batch_free(b); return nullptr; }
+      off = hoff.data();
+    }
     std::vector<const char*> ptrs(n);
     for (size_t i = 0; i < n; ++i) ptrs[i] = blob + off[i];  // every span is followed by a NUL byte
     rc = encode_host(m, dl, b, ptrs.data(), n, p, err);
   } else {
-    rc = batch_encode_device(m, dl, b, blob, off, n, p, err);
+    rc = batch_encode_device(m, dl, b, blob, blob_bytes, off, n, p, err);
   }
   if (!rc) rc = encode_tail(b, err);
   if (rc) { *code = rc; batch_free(b); return nullptr; }
@@ -788,7 +811,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     }
   });
   off[n] = (uint32_t)part[nthreads];
-  return batch_encode_spans(m, dl, blob.data(), off.data(), n, p, err, code);
+  return batch_encode_spans(m, dl, blob.data(), blob.size(), off.data(), n, p, err, code);
 }
 
 static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, hipStream_t st, uint32_t* maxout = nullptr) {

@@ -28,7 +28,7 @@ inline bool probe_enabled() { const char* e = getenv("ANX_SCAN_WALK"); return !(
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p);
 // device-side query encoder (encode.hip): fills the query and tile arrays of `b` from the packed inputs
-int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, const uint32_t* off, size_t n,
+int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
                         const anx_params& p, std::string& err);
 
 }  // namespace anx

@@ -307,9 +307,12 @@ class VariantModel:
         self.lexicons: List[str] = []
 
     def __del__(self):
-        if getattr(self, "h", None):
-            L.lib().anx_model_free(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                L.lib().anx_model_free(self.h)
+                self.h = None
+        except Exception:  # interpreter shutdown: the module globals are already gone
+            pass
 
     # -- loading -----------------------------------------------------------------------------------
     def read_vocabulary(self, filename: str, params: Optional[VocabParams] = None):

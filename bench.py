@@ -334,18 +334,22 @@ def main():
             # the same with two host threads, each running encode -> run -> fetch on its own batches and its own stream (the
             # library is thread-safe on one model): uploads, kernels and downloads of different batches overlap
             import threading
-            nthr, per = 2, 4
-            def worker():
-                st2 = torch.cuda.Stream()
+            nthr, per = 2, 8
+            streams2 = [torch.cuda.Stream() for _ in range(nthr)]
+            def worker(st2):
                 for _ in range(per):
                     bb = model.encode_packed(packed, len(queries), params)
                     bb.run(st2.cuda_stream)
                     res = bb.fetch_arrays()
                     del res
                     bb.free()
-            worker()  # warm the pools of a second set of buffers
+            th = [threading.Thread(target=worker, args=(x,)) for x in streams2]  # warm the pools of a second set of buffers
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
             t = time.perf_counter()
-            th = [threading.Thread(target=worker) for _ in range(nthr)]
+            th = [threading.Thread(target=worker, args=(x,)) for x in streams2]
             for x in th:
                 x.start()
             for x in th:

@@ -140,3 +140,37 @@ def test_random_bytes_device_equals_host_encoder(eng):
         n = rng.choice((1, 2, 3, 5, 8, 8, 10, 12, 12, 16, 20, 30, 60, 150, 300))
         qs.append(b"".join(rng.choice(pieces) for _ in range(rng.randrange(1, n + 1))))
     run_both(eng, qs, A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10))
+
+
+def test_packed_buffer_offsets_found_on_the_device(eng):
+    """anx_batch_encode_packed hands the NUL-separated buffer to the device, which finds the strings itself (k_nul_count /
+    k_nul_emit): empty strings, runs of NUL bytes, 0x01 bytes behind a NUL (the borrow case of a careless SWAR zero test),
+    strings that straddle the 4096-byte blocks and the 16-byte loads, a buffer holding more strings than announced (the rest is
+    ignored), one holding fewer (an error) -- against the char** entry point, whose offsets come from strlen on the host."""
+    import random
+    rng = random.Random(7)
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    words = ["seperate", "", "", "acommodate", "\x01", "\x01\x01x", "", "a" * 4090, "b" * 17, "", "c" * 4096, "d" * 15, "e" * 16, "wich", ""]
+    words += ["".join(rng.choice("etaoinshr\x01 ") for _ in range(rng.randrange(0, 40))) for _ in range(30000)]
+    want = eng.find_variants_ids(words, p)  # anx_find_variants_batch: char**
+    packed = b"".join(w.encode() + b"\0" for w in words)
+    for n in (len(words), len(words) - 1, 17, 1, 0):
+        b = eng.encode_packed(packed, n, p)
+        b.run()
+        assert b.fetch() == want[:n], n
+        b.free()
+    with pytest.raises(A.AnxError, match="fewer strings than announced"):
+        eng.encode_packed(packed, len(words) + 1, p)
+    with pytest.raises(A.AnxError, match="must end with a NUL"):
+        eng.encode_packed(packed[:-1], 3, p)
+    # the host encoder (A/B) takes the same buffer through the host-side offset scan
+    os.environ["ANX_ENCODE"] = "host"
+    try:
+        b = eng.encode_packed(packed, len(words), p)
+        b.run()
+        assert b.fetch() == want
+        b.free()
+        with pytest.raises(A.AnxError, match="fewer strings than announced"):
+            eng.encode_packed(packed, len(words) + 1, p)
+    finally:
+        os.environ.pop("ANX_ENCODE", None)
