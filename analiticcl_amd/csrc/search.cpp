@@ -178,18 +178,19 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   for (size_t i = 0; i < nb; ++i) arcs[i].push_back(Arc{100.0f, i + 1, -1});  // failsafe epsilon transitions
   if (symbols.size() == 1 || finals.empty()) { out.insert(out.end(), matches.begin(), matches.end()); return; }
   lat.lap(0);
-  // k-best paths into every state, kept as back-pointers (source state, rank there, symbol); states are in
-  // topological order by index, so best[s] is final (sorted, cut to K) before it is expanded.
+  // k-best paths into every state, kept as back-pointers (source state, rank there, symbol).  Arcs only run forward, so the
+  // states are in topological order by index and best[s] is final before any state behind it is built.
+  // The K best of a state = the K smallest of { best[src][r].cost + arc.cost } under (cost, source state, arc number, r) -- the
+  // order a stable sort by cost gives the candidates when they are listed arc by arc.  Per incoming arc the candidates are
+  // already sorted (best[src] is, and adding a constant is monotone in f32), so the K smallest come out of a K-way merge: a
+  // binary heap with one entry per incoming arc, keyed (cost, arc), K pops.  (Until round 2 every candidate below a running
+  // bound was materialised and the list cut with nth_element: 7.5 of the decoder's 9.8 s on a 12 MB text.)
   struct Node { float cost; uint32_t ps, pr; long sym; uint32_t seq; };
   const size_t K = std::max<uint32_t>(1, p.max_seq);
   static thread_local std::vector<std::vector<Node>> best;
   if (best.size() < nstates) best.resize(nstates);
   for (size_t i = 0; i < nstates; ++i) best[i].clear();
   best[0].push_back(Node{0.0f, UINT32_MAX, 0, -1, 0});  // the start node
-  // The K cheapest candidates of a state in stable order (= stable sort by cost, cut at K) = the K smallest under
-  // (cost, insertion number).  A state's candidate list never holds more than 2K nodes: when it reaches 2K it is cut to its K
-  // best and the K-th cost becomes the state's bound; a later candidate at or above the bound can never enter the K best (ties
-  // go to the earlier insertion), and since best[s] is sorted the expansion of an arc stops at the first such candidate.
   auto cmp = [](const Node& a, const Node& b) { return a.cost < b.cost || (a.cost == b.cost && a.seq < b.seq); };
   auto cut_to_k = [K, &cmp](std::vector<Node>& v) {
     if (v.size() > K) {
@@ -197,27 +198,43 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
       v.resize(K);
     }
   };
-  static thread_local std::vector<float> bound;
-  static thread_local std::vector<uint32_t> nseq;
-  bound.assign(nstates, std::numeric_limits<float>::infinity());
-  nseq.assign(nstates, 0u);
-  for (size_t s = 0; s < nstates; ++s) {
-    if (best[s].empty()) continue;
-    cut_to_k(best[s]);
-    std::sort(best[s].begin(), best[s].end(), cmp);
-    for (const Arc& a : arcs[s]) {
-      std::vector<Node>& dv = best[a.dst];
-      for (size_t r = 0; r < best[s].size(); ++r) {
-        const float c = best[s][r].cost + a.cost;
-        if (c >= bound[a.dst]) break;
-        dv.push_back(Node{c, (uint32_t)s, (uint32_t)r, a.sym, nseq[a.dst]++});
-        if (dv.size() >= 2 * K) {
-          cut_to_k(dv);
-          float mx = dv[0].cost;
-          for (const Node& x : dv) mx = std::max(mx, x.cost);
-          bound[a.dst] = mx;
-        }
+  struct In { float cost; uint32_t src; long sym; };
+  static thread_local std::vector<std::vector<In>> in;  // incoming arcs per state, ordered by (source state, arc number)
+  if (in.size() < nstates) in.resize(nstates);
+  for (size_t i = 0; i < nstates; ++i) in[i].clear();
+  for (size_t s = 0; s < nstates; ++s)
+    for (const Arc& a : arcs[s]) in[a.dst].push_back(In{a.cost, (uint32_t)s, a.sym});
+  struct Head { float cost; uint32_t arc, r; };
+  static thread_local std::vector<Head> heap;
+  auto before = [](const Head& a, const Head& b) { return a.cost < b.cost || (a.cost == b.cost && a.arc < b.arc); };
+  for (size_t d = 1; d < nstates; ++d) {
+    const std::vector<In>& inc = in[d];
+    heap.clear();
+    for (size_t ai = 0; ai < inc.size(); ++ai)
+      if (!best[inc[ai].src].empty()) heap.push_back(Head{best[inc[ai].src][0].cost + inc[ai].cost, (uint32_t)ai, 0u});
+    size_t hn = heap.size();
+    auto sift_down = [&](size_t i) {
+      const Head x = heap[i];
+      for (;;) {
+        size_t c = 2 * i + 1;
+        if (c >= hn) break;
+        if (c + 1 < hn && before(heap[c + 1], heap[c])) ++c;
+        if (!before(heap[c], x)) break;
+        heap[i] = heap[c];
+        i = c;
       }
+      heap[i] = x;
+    };
+    for (size_t i = hn / 2; i-- > 0;) sift_down(i);
+    std::vector<Node>& dv = best[d];
+    while (hn && dv.size() < K) {
+      const Head h = heap[0];
+      const In& a = inc[h.arc];
+      dv.push_back(Node{h.cost, a.src, h.r, a.sym, 0u});
+      const std::vector<Node>& sv = best[a.src];
+      if (h.r + 1 < sv.size()) heap[0] = Head{sv[h.r + 1].cost + a.cost, h.arc, h.r + 1};
+      else heap[0] = heap[--hn];
+      if (hn) sift_down(0);
     }
   }
   lat.lap(1);
