@@ -25,8 +25,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
 // inputs are the first n NUL-terminated spans of blob[0, blob_bytes) and the device finds their offsets itself
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
                           const anx_params& p, std::string& err, int* code);
-// offsets of the first n NUL-terminated spans of blob[0, len) (n + 1 values); false if there are fewer
-bool packed_offsets(const char* blob, size_t len, size_t n, std::vector<uint32_t>& off);
+
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
 // the same in two halves: enqueue on `stream` and return / wait for it (statistics, results usable afterwards)
 int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);

@@ -676,4 +676,22 @@ int clamp_threshold(const anx_threshold& t, int len, int absolute_max) {
   return std::min((int)t.value, half);
 }
 
+bool packed_offsets(const char* blob, size_t len, size_t n, std::vector<uint32_t>& off) {
+  off.clear();
+  off.reserve(n + 1);
+  off.push_back(0);
+  // 8 bytes per step; a byte of z is 0x80 iff the byte of x is 0 (exact: no carry crosses a byte)
+  const unsigned long long L7 = 0x7F7F7F7F7F7F7F7Full;
+  size_t i = 0;
+  for (; i + 8 <= len && off.size() <= n; i += 8) {
+    unsigned long long x;
+    memcpy(&x, blob + i, 8);
+    for (unsigned long long z = ~(((x & L7) + L7) | x | L7); z && off.size() <= n; z &= z - 1)
+      off.push_back((uint32_t)(i + ((size_t)__builtin_ctzll(z) >> 3) + 1));
+  }
+  for (; i < len && off.size() <= n; ++i)
+    if (!blob[i]) off.push_back((uint32_t)(i + 1));
+  return off.size() == n + 1;
+}
+
 }  // namespace anx

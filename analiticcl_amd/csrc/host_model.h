@@ -223,4 +223,8 @@ class HostModel {
 int index_read_tag(const std::string& path, std::string* tag, std::string& err);  // index_cache.cpp
 int clamp_threshold(const anx_threshold& t, int len, int absolute_max);
 
+// offsets of the first n NUL-terminated spans of blob[0, len) (n + 1 values); false if there are fewer (the host-side twin of
+// k_nul_count / k_nul_emit in encode.hip: used when the host needs the strings itself)
+bool packed_offsets(const char* blob, size_t len, size_t n, std::vector<uint32_t>& off);
+
 }  // namespace anx

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <iterator>
 #include <thread>
 #include <chrono>
 #include <cmath>
@@ -416,71 +417,94 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     return anx_fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_all_matches()");
   std::vector<std::vector<Span>> bounds(n);
   std::vector<Stretch> stretches;
-  for (size_t t = 0; t < n; ++t) {
-    const char* text = texts[t];
-    const size_t len = text ? strlen(text) : 0;
-    if (!len) continue;
-    find_boundaries(text, len, bounds[t]);
-    size_t begin = 0, begin_index = 0;
-    for (size_t i = 0; i < bounds[t].size(); ++i)
-      if (classify(text, bounds[t], i) == HARD && bounds[t][i].begin != begin) {
-        stretches.push_back(Stretch{t, begin, bounds[t][i].begin, begin_index, i + 1, {}});
-        begin = bounds[t][i].end;
-        begin_index = i + 1;
+  const unsigned hw = std::max(1u, std::min(64u, anx::usable_hw_threads()));
+  // work(lo, hi) over [0, count) in chunks handed to the host threads
+  auto parallel_for = [&](size_t count, size_t chunk, size_t serial_below, const std::function<void(size_t, size_t)>& work) {
+    if (count < serial_below || hw == 1) { work(0, count); return; }
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    for (unsigned t = 0; t < hw; ++t)
+      th.emplace_back([&]() {
+        for (;;) {
+          const size_t lo = next.fetch_add(chunk);
+          if (lo >= count) break;
+          work(lo, std::min(count, lo + chunk));
+        }
+      });
+    for (auto& x : th) x.join();
+  };
+  {
+    std::vector<std::vector<Stretch>> per_text_stretches(n);
+    parallel_for(n, 8, 64, [&](size_t lo, size_t hi) {
+      for (size_t t = lo; t < hi; ++t) {
+        const char* text = texts[t];
+        const size_t len = text ? strlen(text) : 0;
+        if (!len) continue;
+        find_boundaries(text, len, bounds[t]);
+        size_t begin = 0, begin_index = 0;
+        for (size_t i = 0; i < bounds[t].size(); ++i)
+          if (classify(text, bounds[t], i) == HARD && bounds[t][i].begin != begin) {
+            per_text_stretches[t].push_back(Stretch{t, begin, bounds[t][i].begin, begin_index, i + 1, {}});
+            begin = bounds[t][i].end;
+            begin_index = i + 1;
+          }
       }
+    });
+    size_t ns = 0;
+    for (auto& v : per_text_stretches) ns += v.size();
+    stretches.reserve(ns);
+    for (auto& v : per_text_stretches)
+      for (Stretch& x : v) stretches.push_back(std::move(x));
   }
   lap("boundaries");
   // one device batch per n-gram order; the result arrays stay alive until the output has been written
   struct OrderRows { anx_result* rows; size_t* offs; };
   std::vector<OrderRows> kept;
   auto free_kept = [&]() { for (OrderRows& o : kept) anx_results_free(o.rows, o.offs); kept.clear(); };
-  const unsigned hw = std::max(1u, std::min(64u, anx::usable_hw_threads()));
-  auto parallel_stretches = [&](const std::function<void(size_t, size_t)>& work) {
-    const size_t ns = stretches.size();
-    if (ns < 256 || hw == 1) { work(0, ns); return; }
-    std::vector<std::thread> th;
-    std::atomic<size_t> next{0};
-    const size_t chunk = 64;
-    for (unsigned t = 0; t < hw; ++t)
-      th.emplace_back([&]() {
-        for (;;) {
-          const size_t lo = next.fetch_add(chunk);
-          if (lo >= ns) break;
-          work(lo, std::min(ns, lo + chunk));
-        }
-      });
-    for (auto& x : th) x.join();
-  };
+  auto parallel_stretches = [&](const std::function<void(size_t, size_t)>& work) { parallel_for(stretches.size(), 64, 256, work); };
+  double seg_part[5] = {0, 0, 0, 0, 0};  // timing: n-grams, arena, device batch, row views, append
+  double seg_t = tnow();
+  auto seg_lap = [&](int i) { if (timing) { const double t = tnow(); seg_part[i] += t - seg_t; seg_t = t; } };
   for (uint32_t order = 1; order <= sp->max_ngram; ++order) {
+    seg_lap(4);
     std::vector<std::vector<Span>> cur(stretches.size());
     std::vector<std::vector<uint8_t>> lookup(stretches.size());  // per segment: goes to the device (not redundant)
+    // per stretch: first segment / first arena byte of its looked-up segments (counts first, prefix sums below)
+    std::vector<size_t> seg0(stretches.size() + 1, 0), byte0(stretches.size() + 1, 0);
     parallel_stretches([&](size_t lo, size_t hi) {
       for (size_t si = lo; si < hi; ++si) {
         Stretch& st = stretches[si];
         find_match_ngrams(texts[st.text_index], bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, cur[si]);
         lookup[si].resize(cur[si].size());
-        for (size_t k = 0; k < cur[si].size(); ++k) lookup[si][k] = (order == 1 || !redundant_match(cur[si][k], st.matches)) ? 1 : 0;
+        size_t ns = 0, nb = 0;
+        for (size_t k = 0; k < cur[si].size(); ++k) {
+          lookup[si][k] = (order == 1 || !redundant_match(cur[si][k], st.matches)) ? 1 : 0;
+          if (lookup[si][k]) { ++ns; nb += cur[si][k].end - cur[si][k].begin + 1; }
+        }
+        seg0[si + 1] = ns;
+        byte0[si + 1] = nb;
       }
     });
-    // all segments of this order in one NUL-separated arena
-    size_t nseg = 0, bytes = 0;
-    for (size_t si = 0; si < stretches.size(); ++si)
-      for (size_t k = 0; k < cur[si].size(); ++k)
-        if (lookup[si][k]) { ++nseg; bytes += cur[si][k].end - cur[si][k].begin + 1; }
+    for (size_t si = 0; si < stretches.size(); ++si) { seg0[si + 1] += seg0[si]; byte0[si + 1] += byte0[si]; }
+    const size_t nseg = seg0[stretches.size()], bytes = byte0[stretches.size()];
+    seg_lap(0);
     if (nseg) {
-      std::string arena;
-      arena.reserve(bytes);
-      std::vector<size_t> seg_off;
-      seg_off.reserve(nseg);
-      for (size_t si = 0; si < stretches.size(); ++si) {
-        const char* text = texts[stretches[si].text_index];
-        for (size_t k = 0; k < cur[si].size(); ++k)
-          if (lookup[si][k]) {
-            seg_off.push_back(arena.size());
-            arena.append(text + cur[si][k].begin, cur[si][k].end - cur[si][k].begin);
-            arena.push_back('\0');
-          }
-      }
+      // all segments of this order in one NUL-separated arena, every stretch writing its own part
+      std::vector<char> arena(bytes);
+      parallel_stretches([&](size_t lo, size_t hi) {
+        for (size_t si = lo; si < hi; ++si) {
+          const char* text = texts[stretches[si].text_index];
+          char* w = arena.data() + byte0[si];
+          for (size_t k = 0; k < cur[si].size(); ++k)
+            if (lookup[si][k]) {
+              const size_t l = cur[si][k].end - cur[si][k].begin;
+              memcpy(w, text + cur[si][k].begin, l);
+              w[l] = '\0';
+              w += l + 1;
+            }
+        }
+      });
+      seg_lap(1);
       anx_result* rows = nullptr;
       size_t* offs = nullptr;
       int rc;
@@ -493,25 +517,44 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         if (!bt) { free_kept(); return ANX_ENODEVICE; }  // the message of the failed encode stays in anx_last_error()
       } else {  // more segments than one device batch holds: the pointer form splits them
         std::vector<const char*> ptrs(nseg);
-        for (size_t i = 0; i < nseg; ++i) ptrs[i] = arena.data() + seg_off[i];
+        size_t i = 0;
+        for (size_t si = 0; si < stretches.size(); ++si) {
+          const char* w = arena.data() + byte0[si];
+          for (size_t k = 0; k < cur[si].size(); ++k)
+            if (lookup[si][k]) { ptrs[i++] = w; w += cur[si][k].end - cur[si][k].begin + 1; }
+        }
         rc = anx_find_variants_batch(model, ptrs.data(), nseg, &sp->base, &rows, &offs);
       }
       if (rc != ANX_OK) { free_kept(); return rc; }
       kept.push_back(OrderRows{rows, offs});
-      size_t i = 0;
-      for (size_t si = 0; si < stretches.size(); ++si)
+      seg_lap(2);
+    }
+    // row views + the order's segments behind the stretch's matches (moved, not copied)
+    const OrderRows* orows_cur = nseg ? &kept.back() : nullptr;
+    parallel_stretches([&](size_t lo, size_t hi) {
+      for (size_t si = lo; si < hi; ++si) {
+        size_t i = seg0[si];
         for (size_t k = 0; k < cur[si].size(); ++k)
           if (lookup[si][k]) {
             Span& sg = cur[si][k];
             sg.has_variants = true;
-            sg.variants = RowView{rows + offs[i], offs[i + 1] - offs[i]};
+            sg.variants = RowView{orows_cur->rows + orows_cur->offs[i], orows_cur->offs[i + 1] - orows_cur->offs[i]};
             ++i;
           }
-    }
-    for (size_t si = 0; si < stretches.size(); ++si)
-      stretches[si].matches.insert(stretches[si].matches.end(), cur[si].begin(), cur[si].end());
+        std::vector<Span>& mv = stretches[si].matches;
+        mv.insert(mv.end(), std::make_move_iterator(cur[si].begin()), std::make_move_iterator(cur[si].end()));
+        std::vector<Span>().swap(cur[si]);
+        std::vector<uint8_t>().swap(lookup[si]);
+      }
+    });
+    seg_lap(3);
   }
+  seg_lap(4);
   lap("segments + device batches");
+  if (timing) {
+    static const char* names[5] = {"n-grams", "arena", "device batch", "row views", "append"};
+    for (int i = 0; i < 5; ++i) fprintf(stderr, "[anx search]   segments part %-15s %8.2f ms\n", names[i], seg_part[i] * 1e3);
+  }
   // consolidate per stretch: the lattices are independent -> host threads (the reference: rayon over the segments and a
   // sequential loop over the stretches, src/lib.rs:1821-1940)
   std::vector<std::vector<Span>> decoded(stretches.size());
@@ -563,45 +606,54 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
   anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, total_rows) * sizeof(anx_result)));
   if (!om || !oo || !orows) { free(om); free(oo); free(orows); free(otags); free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
-  size_t w = 0, rw = 0, tw = 0;
+  // first match / row / tag of every text, then the texts are written side by side
+  std::vector<size_t> row0(n + 1, 0), tag0(n + 1, 0);
   for (size_t t = 0; t < n; ++t) {
-    oo[t] = w;
-    std::vector<size_t> cpmap;  // byte offset -> code point index (remap_offsets_to_unicodepoints, src/search.rs:527-546)
-    if (sp->unicodeoffsets && texts[t]) {
-      const size_t len = strlen(texts[t]);
-      cpmap.assign(len + 1, 0);
-      size_t cp = 0;
-      for (size_t i = 0; i < len;) {
-        int l;
-        anx::utf8_decode_at(texts[t] + i, len - i, &l);
-        for (int k = 0; k < l && i + (size_t)k < len; ++k) cpmap[i + (size_t)k] = cp;
-        i += (size_t)l;
-        ++cp;
-      }
-      cpmap[len] = cp;
-    }
-    for (const Span& s : per_text[t]) {
-      anx_match& o = om[w++];
-      o.begin = cpmap.empty() ? s.begin : cpmap[s.begin];
-      o.end = cpmap.empty() ? s.end : cpmap[s.end];
-      o.n = s.n;
-      o.selected = (s.has_variants && !s.variants.empty()) ? s.selected : -1;
-      o.var_begin = rw;
-      for (const anx_result& r : s.variants) orows[rw++] = r;
-      o.var_end = rw;
-      o.tag_begin = (uint32_t)tw;
-      if (otags)
-        for (const auto& tg : s.tags) otags[tw++] = anx_match_tag{tg.first, tg.second, 0};
-      o.tag_end = (uint32_t)tw;
-    }
+    size_t nr = 0, nt = 0;
+    for (const Span& sp_ : per_text[t]) { nr += sp_.variants.size(); nt += sp_.tags.size(); }
+    oo[t + 1] = oo[t] + per_text[t].size();
+    row0[t + 1] = row0[t] + nr;
+    tag0[t + 1] = tag0[t] + nt;
   }
-  oo[n] = w;
+  parallel_for(n, 8, 64, [&](size_t lo, size_t hi) {
+    for (size_t t = lo; t < hi; ++t) {
+      size_t w = oo[t], rw = row0[t], tw = tag0[t];
+      std::vector<size_t> cpmap;  // byte offset -> code point index (remap_offsets_to_unicodepoints, src/search.rs:527-546)
+      if (sp->unicodeoffsets && texts[t]) {
+        const size_t len = strlen(texts[t]);
+        cpmap.assign(len + 1, 0);
+        size_t cp = 0;
+        for (size_t i = 0; i < len;) {
+          int l;
+          anx::utf8_decode_at(texts[t] + i, len - i, &l);
+          for (int k = 0; k < l && i + (size_t)k < len; ++k) cpmap[i + (size_t)k] = cp;
+          i += (size_t)l;
+          ++cp;
+        }
+        cpmap[len] = cp;
+      }
+      for (const Span& s : per_text[t]) {
+        anx_match& o = om[w++];
+        o.begin = cpmap.empty() ? s.begin : cpmap[s.begin];
+        o.end = cpmap.empty() ? s.end : cpmap[s.end];
+        o.n = s.n;
+        o.selected = (s.has_variants && !s.variants.empty()) ? s.selected : -1;
+        o.var_begin = rw;
+        for (const anx_result& r : s.variants) orows[rw++] = r;
+        o.var_end = rw;
+        o.tag_begin = (uint32_t)tw;
+        if (otags)
+          for (const auto& tg : s.tags) otags[tw++] = anx_match_tag{tg.first, tg.second, 0};
+        o.tag_end = (uint32_t)tw;
+      }
+    }
+  });
   free_kept();
   lap("output");
   *out_matches = om;
   *out_offsets = oo;
   *out_rows = orows;
-  *out_n_rows = rw;
+  *out_n_rows = row0[n];
   if (out_tags) *out_tags = otags;
   return ANX_OK;
 }

@@ -71,6 +71,14 @@ int main(int argc, char** argv) {
   anx_params p; anx_default_params(&p);
   anx_result* rows = nullptr; size_t* ro = nullptr;
   CHECK(anx_find_variants_batch(m, q, 2, &p, &rows, &ro) == ANX_ENODEVICE);
+  // packed buffers: the host-side offset scan (confusables are loaded, so the host needs the strings for rescoring)
+  {
+    const char packed[] = "seperate\0\0\x01x\0acommodate\0longer than eight bytes\0";  // sizeof counts the terminator too
+    CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 1, 5, &p) == nullptr && strstr(anx_last_error(), "stub") != nullptr);
+    CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 1, 6, &p) == nullptr && strstr(anx_last_error(), "fewer strings") != nullptr);
+    CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 2, 2, &p) == nullptr && strstr(anx_last_error(), "must end with a NUL") != nullptr);
+    CHECK(anx_batch_encode_packed(m, packed, 0, 0, &p) == nullptr);
+  }
   anx_search_params sp; anx_default_search_params(&sp);
   anx_match* ms = nullptr; size_t* mo = nullptr; size_t nr = 0; anx_match_tag* tg = nullptr;
   CHECK(anx_find_all_matches_batch(m, q, 2, &sp, &ms, &mo, &rows, &nr, &tg) != ANX_OK);

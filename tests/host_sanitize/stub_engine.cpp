@@ -13,7 +13,7 @@ void host_result_free(void* p) { free(p); }
 Batch* batch_encode(const HostModel&, const DeviceLexicon*, const char* const*, size_t, const anx_params&, std::string& err, int* code) {
   err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
 }
-Batch* batch_encode_spans(const HostModel&, const DeviceLexicon*, const char*, const uint32_t*, size_t, const anx_params&, std::string& err, int* code) {
+Batch* batch_encode_spans(const HostModel&, const DeviceLexicon*, const char*, size_t, const uint32_t*, size_t, const anx_params&, std::string& err, int* code) {
   err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
 }
 int batch_run(const HostModel&, const DeviceLexicon*, Batch*, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
