@@ -151,8 +151,10 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   static thread_local std::vector<std::vector<Arc>> arcs;
   if (arcs.size() < nstates) arcs.resize(nstates);
   for (size_t i = 0; i < nstates; ++i) arcs[i].clear();
-  std::vector<OutSym> symbols(1);
-  std::vector<size_t> finals;
+  static thread_local std::vector<OutSym> symbols;
+  static thread_local std::vector<size_t> finals;
+  symbols.assign(1, OutSym{0, 0, -1, 0});
+  finals.clear();
   for (size_t i = 0; i < nb; ++i)
     if (bs[i].begin == end_offset || bs[i].end == end_offset) finals.push_back(i + 1);
   for (size_t mi = 0; mi < matches.size(); ++mi) {
@@ -239,38 +241,45 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     }
   }
   lat.lap(1);
-  struct Path { float cost; std::vector<long> syms; };
-  std::vector<Node> ends;
+  static thread_local std::vector<Node> ends;
+  ends.clear();
   for (size_t f : finals) ends.insert(ends.end(), best[f].begin(), best[f].end());
   for (size_t i = 0; i < ends.size(); ++i) ends[i].seq = (uint32_t)i;
   cut_to_k(ends);
   std::sort(ends.begin(), ends.end(), cmp);
-  static thread_local std::vector<Path> paths;  // (capacity of the symbol lists kept across stretches)
+  // the symbols of final path i, walked back over the back-pointers: only wanted for the path that wins (and, with context
+  // rules, for every path -- the rules look at whole sequences); costs and LM sums live on the lattice nodes
   const size_t npaths = ends.size();
-  if (paths.size() < npaths) paths.resize(npaths);
-  for (size_t i = 0; i < npaths; ++i) {
-    paths[i].cost = ends[i].cost;
-    paths[i].syms.clear();
+  auto path_syms = [&](size_t i, std::vector<long>& syms) {
+    syms.clear();
     for (Node cur = ends[i]; cur.ps != UINT32_MAX; cur = best[cur.ps][cur.pr])
-      if (cur.sym >= 0) paths[i].syms.push_back(cur.sym);
-    std::reverse(paths[i].syms.begin(), paths[i].syms.end());
-  }
+      if (cur.sym >= 0) syms.push_back(cur.sym);
+    std::reverse(syms.begin(), syms.end());
+  };
+  static thread_local std::vector<long> syms_tmp;
   lat.lap(2);
   // rerank (src/lib.rs:2318-2425)
   const bool use_lm = m.have_lm && p.lm_weight > 0.0f;
   const bool use_rules = !m.context_rules.empty();
   double best_ppl = 999999.0, best_ctx = 0.0;
   float best_cost = (float)(nb - 1) * 2.0f;
-  std::vector<double> ppls(npaths, 0.0), ctx(npaths, 1.0);
+  static thread_local std::vector<double> ppls, ctx;
+  ppls.assign(npaths, 0.0);
+  ctx.assign(npaths, 1.0);
   std::vector<std::vector<std::vector<anx::PatternMatchResult>>> ctx_results(use_rules ? npaths : 0);
   std::vector<std::pair<uint64_t, uint32_t>> idseq;
   // LM scoring of up to max_seq paths of one lattice: the paths share almost all of their bigrams, so the tokens of every
   // symbol (its n-gram parts + the boundary text behind it, src/lib.rs:2580-2629) are looked up once, and every bigram term
   // (src/lib.rs:2632-2674) once per lattice; the f32 sum runs over the same terms in the same order as lm_score_tokens.
-  std::vector<uint32_t> tok_off;
-  std::vector<int64_t> tok;
-  struct Term { int64_t a, b; float v; bool used; };
-  std::vector<Term> memo;
+  static thread_local std::vector<uint32_t> tok_off, btok_off;
+  static thread_local std::vector<int64_t> tok, btok;
+  struct Term { int64_t a, b; float v; uint32_t gen; };
+  static thread_local std::vector<Term> memo(1024, Term{0, 0, 0.0f, 0u});  // slots of earlier lattices are stale by their generation
+  static thread_local uint32_t memo_gen = 0;
+  // LM sum of the path prefix that ends in a lattice node, stamped with the lattice's generation (memo_gen): the per-node
+  // table is never cleared, only grown (clearing 250 nodes x 15 states per lattice was most of the LM time)
+  struct LmState { float lp; uint32_t n; int64_t prev; uint32_t gen; };
+  static thread_local std::vector<std::vector<LmState>> lmst;
   size_t memo_used = 0;
   auto term = [&](int64_t a, int64_t b) -> float {
     const float SMOOTH = -13.815510557964274f;  // src/search.rs:4
@@ -278,44 +287,57 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     size_t h = ((uint64_t)a * 0x9E3779B97F4A7C15ull ^ (uint64_t)b * 0xC2B2AE3D27D4EB4Full) >> 54;  // 1024 slots
     for (;; h = (h + 1) & 1023) {
       Term& t = memo[h];
-      if (t.used && t.a == a && t.b == b) return t.v;
-      if (!t.used) {
+      const bool used = t.gen == memo_gen;
+      if (used && t.a == a && t.b == b) return t.v;
+      if (!used) {
         auto pit = m.unigrams.find((uint64_t)a);
         const uint32_t priorcount = pit == m.unigrams.end() ? 1u : pit->second;
         auto jit = m.bigrams.find(((uint64_t)a << 32) | ((uint64_t)b & 0xFFFFFFFFull));
         float v = SMOOTH;
         if (jit != m.bigrams.end()) v = priorcount < jit->second ? logf((float)jit->second) : logf((float)jit->second / (float)priorcount);
-        if (memo_used < 768) { t = Term{a, b, v, true}; ++memo_used; }  // a full table stops caching, never loops
+        if (memo_used < 768) { t = Term{a, b, v, memo_gen}; ++memo_used; }  // a full table stops caching, never loops
         return v;
       }
     }
   };
   if (use_lm) {
-    memo.assign(1024, Term{0, 0, 0.0f, false});
+    if (++memo_gen == 0) {  // wrapped: nothing stale may look current
+      for (Term& t : memo) t.gen = 0;
+      for (auto& v : lmst) for (LmState& x : v) x.gen = 0;
+      memo_gen = 1;
+    }
+    // the tokens of the boundary text behind a symbol only depend on the boundary: once per boundary, not per symbol
+    btok.clear();
+    btok_off.assign(nb + 1, 0);
+    for (size_t bi = 0; bi < nb; ++bi) {
+      btok_off[bi] = (uint32_t)btok.size();
+      const Span& nbs = bs[bi];
+      if (!(nbs.end - nbs.begin == 1 && text[nbs.begin] == ' ') && nbs.end > nbs.begin) {
+        const std::string bt = anx::trim_whitespace(std::string(text + nbs.begin, nbs.end - nbs.begin));
+        if (!bt.empty()) {
+          auto it = m.encoder.find(bt);
+          if (it != m.encoder.end()) for (uint32_t k = m.ngram_off[it->second]; k < m.ngram_off[it->second + 1]; ++k) btok.push_back((int64_t)m.ngram_ids[k]);
+          else btok.push_back(-1);
+        }
+      }
+    }
+    btok_off[nb] = (uint32_t)btok.size();
+    tok.clear();
     tok_off.assign(symbols.size() + 1, 0);
     for (size_t sy = 1; sy < symbols.size(); ++sy) {
       tok_off[sy] = (uint32_t)tok.size();
       const OutSym& o = symbols[sy];
       if (o.vocab_id == 0) tok.push_back(-1);
       else for (uint32_t k = m.ngram_off[o.vocab_id]; k < m.ngram_off[o.vocab_id + 1]; ++k) tok.push_back((int64_t)m.ngram_ids[k]);
-      const Span& nbs = bs[o.boundary_index];
-      if (!(nbs.end - nbs.begin == 1 && text[nbs.begin] == ' ') && nbs.end > nbs.begin) {
-        const std::string bt = anx::trim_whitespace(std::string(text + nbs.begin, nbs.end - nbs.begin));
-        if (!bt.empty()) {
-          auto it = m.encoder.find(bt);
-          if (it != m.encoder.end()) for (uint32_t k = m.ngram_off[it->second]; k < m.ngram_off[it->second + 1]; ++k) tok.push_back((int64_t)m.ngram_ids[k]);
-          else tok.push_back(-1);
-        }
-      }
+      for (uint32_t k = btok_off[o.boundary_index]; k < btok_off[o.boundary_index + 1]; ++k) tok.push_back(btok[k]);
     }
     tok_off[symbols.size()] = (uint32_t)tok.size();
   }
-  struct LmState { float lp; uint32_t n; int64_t prev; bool done; };
-  static thread_local std::vector<std::vector<LmState>> lmst;
-  std::vector<std::pair<uint32_t, uint32_t>> chain;
+  static thread_local std::vector<std::pair<uint32_t, uint32_t>> chain;
   if (use_lm) {
     if (lmst.size() < nstates) lmst.resize(nstates);
-    for (size_t st = 0; st < nstates; ++st) lmst[st].assign(best[st].size(), LmState{0.0f, 0u, 0, false});
+    for (size_t st = 0; st < nstates; ++st)
+      if (lmst[st].size() < best[st].size()) lmst[st].resize(best[st].size(), LmState{0.0f, 0u, 0, 0u});
   }
   for (size_t i = 0; i < npaths; ++i) {
     if (use_lm) {
@@ -325,17 +347,17 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
         LmState r = from;
         if (sy >= 0)
           for (uint32_t k = tok_off[(size_t)sy]; k < tok_off[(size_t)sy + 1]; ++k) { r.lp += term(r.prev, tok[k]); ++r.n; r.prev = tok[k]; }
-        r.done = true;
+        r.gen = memo_gen;
         return r;
       };
       // walk up to the first node whose prefix is known, then back down
       chain.clear();
       uint32_t cs = ends[i].ps, cr = ends[i].pr;
-      while (cs != UINT32_MAX && !lmst[cs][cr].done) { chain.emplace_back(cs, cr); const Node& nd = best[cs][cr]; cs = nd.ps; cr = nd.pr; }
-      LmState cur = cs == UINT32_MAX ? LmState{0.0f, 0u, 0, true} : lmst[cs][cr];  // the start node: BOS, nothing summed yet
+      while (cs != UINT32_MAX && lmst[cs][cr].gen != memo_gen) { chain.emplace_back(cs, cr); const Node& nd = best[cs][cr]; cs = nd.ps; cr = nd.pr; }
+      LmState cur = cs == UINT32_MAX ? LmState{0.0f, 0u, 0, memo_gen} : lmst[cs][cr];  // the start node: BOS, nothing summed yet
       for (size_t c = chain.size(); c-- > 0;) {
         const Node& nd = best[chain[c].first][chain[c].second];
-        cur = nd.ps == UINT32_MAX ? LmState{0.0f, 0u, 0, true} : extend(cur, nd.sym);
+        cur = nd.ps == UINT32_MAX ? LmState{0.0f, 0u, 0, memo_gen} : extend(cur, nd.sym);
         lmst[chain[c].first][chain[c].second] = cur;
       }
       cur = extend(cur, ends[i].sym);
@@ -346,13 +368,14 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     }
     if (use_rules) {  // src/lib.rs:2345-2363, 2505-2518
       idseq.clear();
-      for (long sy : paths[i].syms) {
+      path_syms(i, syms_tmp);
+      for (long sy : syms_tmp) {
         const uint64_t id = symbols[(size_t)sy].vocab_id;
         idseq.emplace_back(id, id != 0 && id < m.decoder.size() ? m.decoder[id].lexindex : 0u);
       }
       ctx[i] = m.test_context_rules(idseq, ctx_results[i]);
     }
-    if (paths[i].cost < best_cost) best_cost = paths[i].cost;
+    if (ends[i].cost < best_cost) best_cost = ends[i].cost;
     if (ctx[i] > best_ctx) best_ctx = ctx[i];
   }
   lat.lap(3);
@@ -361,7 +384,7 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   long best_i = -1;
   for (size_t i = 0; i < npaths; ++i) {
     const double norm_lm = use_lm ? std::log(best_ppl / ppls[i]) : 0.0;
-    const double norm_var = std::log((double)best_cost / (double)paths[i].cost);
+    const double norm_var = std::log((double)best_cost / (double)ends[i].cost);
     const double norm_ctx = std::log(ctx[i] / best_ctx);
     double score;
     if (shortcut) score = norm_var;
@@ -370,7 +393,8 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
               ((double)p.lm_weight + (double)p.variantmodel_weight + (double)p.contextrules_weight);
     if (score > best_score || best_i < 0) { best_score = score; best_i = (long)i; }
   }
-  const std::vector<long>& best_syms = paths[(size_t)best_i].syms;
+  path_syms((size_t)best_i, syms_tmp);
+  const std::vector<long>& best_syms = syms_tmp;
   for (size_t j = 0; j < best_syms.size(); ++j) {
     const OutSym& o = symbols[(size_t)best_syms[j]];
     Span r = matches[o.match_index];
