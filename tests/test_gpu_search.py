@@ -128,10 +128,9 @@ def random_texts(words, phrases, n, seed):
     return texts
 
 
-@pytest.mark.parametrize("with_lm,with_rules", [(False, False), (True, False), (False, True), (True, True)])
-def test_random_texts_vs_twin(with_lm, with_rules):
-    """Markov-free small world: 3000 lexicon words (+ a bigram LM over them when with_lm), 200 random texts, the whole
-    batch in ONE anx_find_all_matches_batch call; every Match field must equal the twin's."""
+def build_world(with_lm, with_rules):
+    """3000 lexicon words + 300 indexed phrases (+ a bigram LM over the frequent words, + 300 context rules): the same model as
+    product (device), twin and oracle."""
     words = [w for w in synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz")) if w.isascii() and w.isalpha()][::37][:3000]
     rng = random.Random(11)
     tw = TwinOverOracle(T.TEST_ALPHABET)
@@ -175,10 +174,14 @@ def test_random_texts_vs_twin(with_lm, with_rules):
             tw.add_contextrule(pattern, score, list(tags), list(offs))
             g.add_contextrule(pattern, score, list(tags), list(offs))
         assert g.tags == tw.tags
-    texts = random_texts(words[:400] if with_lm else words, phrases, 200, 5 + int(with_lm))
+    return g, tw, words, phrases
+
+
+def compare_with_twin(g, tw, texts, max_seq):
+    """-> (matches with n > 1, tagged matches); every Match field of the product equals the twin's"""
     gp = A.SearchParameters(max_anagram_distance=2, max_edit_distance=2, max_matches=6, score_threshold=0.3,
-                            cutoff_threshold=0.0, max_ngram=3, max_seq=40)
-    tp = T.SearchParams(("abs", 2), ("abs", 2), 6, 0.3, 0.0, False, 0.0, max_ngram=3, max_seq=40)
+                            cutoff_threshold=0.0, max_ngram=3, max_seq=max_seq)
+    tp = T.SearchParams(("abs", 2), ("abs", 2), 6, 0.3, 0.0, False, 0.0, max_ngram=3, max_seq=max_seq)
     got = g.find_all_matches_ids(texts, gp)
     n_multi = n_tagged = 0
     for text, gm in zip(texts, got):
@@ -196,8 +199,34 @@ def test_random_texts_vs_twin(with_lm, with_rules):
             assert (m["tag"], m["seqnr"]) == (e.tag, e.seqnr), (text, e.text)
             n_multi += e.n > 1
             n_tagged += bool(e.tag)
+    return n_multi, n_tagged
+
+
+@pytest.mark.parametrize("with_lm,with_rules", [(False, False), (True, False), (False, True), (True, True)])
+def test_random_texts_vs_twin(with_lm, with_rules):
+    """Markov-free small world: 3000 lexicon words (+ a bigram LM over them when with_lm), 200 random texts, the whole
+    batch in ONE anx_find_all_matches_batch call; every Match field must equal the twin's."""
+    g, tw, words, phrases = build_world(with_lm, with_rules)
+    texts = random_texts(words[:400] if with_lm else words, phrases, 200, 5 + int(with_lm))
+    n_multi, n_tagged = compare_with_twin(g, tw, texts, 40)
     assert n_multi > 0  # the lattice did pick some bigram/trigram segments
     assert (n_tagged > 0) == with_rules
+
+
+@pytest.mark.parametrize("with_lm", [False, True])
+def test_long_stretches_vs_twin(with_lm):
+    """Stretches without a hard boundary (words separated by one space) of 60, 700 and 2300 words: long lattices through the
+    k-best merge, the per-node LM sums and the back-pointer walk; a small max_seq on all of them and the default 250 on the
+    first."""
+    g, tw, words, phrases = build_world(with_lm, False)
+    pool = synth.make_queries(words[:400], 3200, max_len=14, seed=21)
+    ph = synth.make_queries(phrases, 200, max_len=24, seed=22)
+    for i in range(0, len(pool), 9):
+        pool[i] = ph[i // 9 % len(ph)]
+    texts = [" ".join(pool[:60]), " ".join(pool[60:760]) + ".", " ".join(pool[760:3060])]
+    n_multi, _ = compare_with_twin(g, tw, texts, 6)
+    assert n_multi > 0
+    compare_with_twin(g, tw, texts[:1], 250)
 
 
 # -- context rules: tests/main.rs:1575-1800 (values transcribed) ----------------------------------------------------
