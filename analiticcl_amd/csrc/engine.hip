@@ -1010,17 +1010,21 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     // k_filter_wide: without that state the fused kernel fits 8 waves per SIMD
     static const int enable_split = []() { const char* e = getenv("ANX_FS_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool split_wide = !have_long_q && enable_split;
-    if (split_wide) {
-      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-      else hipLaunchKernelGGL((k_filter_score<0, false>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-    } else {
-      if (fastD == 1) hipLaunchKernelGGL((k_filter_score<1, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-      else if (fastD == 2) hipLaunchKernelGGL((k_filter_score<2, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-      else if (fastD == 3) hipLaunchKernelGGL((k_filter_score<3, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-      else hipLaunchKernelGGL((k_filter_score<0, true>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold));
-    }
+    // the one-add zero test of the prefilter needs every symbol code (classes, unknown = A + 1) below the masked paddings 0x7E / 0x7F
+    static const int enable_b7 = []() { const char* e = getenv("ANX_FS_B7"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool b7 = enable_b7 && m.alphabet.size() + 1 < 0x7E;
+#define ANX_FS_LAUNCH(DD, WW, BB) hipLaunchKernelGGL((k_filter_score<DD, WW, BB>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold))
+#define ANX_FS_PICK(WW, BB)                      \
+  do {                                           \
+    if (fastD == 1) ANX_FS_LAUNCH(1, WW, BB);    \
+    else if (fastD == 2) ANX_FS_LAUNCH(2, WW, BB); \
+    else if (fastD == 3) ANX_FS_LAUNCH(3, WW, BB); \
+    else ANX_FS_LAUNCH(0, WW, BB);               \
+  } while (0)
+    if (split_wide) { if (b7) ANX_FS_PICK(false, true); else ANX_FS_PICK(false, false); }
+    else { if (b7) ANX_FS_PICK(true, true); else ANX_FS_PICK(true, false); }
+#undef ANX_FS_PICK
+#undef ANX_FS_LAUNCH
     HIP_TRY(hipEventRecord(b->ev_fs1, st));
     if (need_lists) {  // the list fills are only known on the device: fixed grids walk the lists in strides
       const dim3 lgrid(LIST_P * SCAN_REGIONS);

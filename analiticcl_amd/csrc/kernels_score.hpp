@@ -31,7 +31,11 @@ __device__ inline uint32_t len_mask(int len, int k) {  // 0x80 in every byte pos
   return n >= 4 ? 0x80808080u : n <= 0 ? 0u : (0x80808080u & ((1u << (8 * n)) - 1u));
 }
 
-template <int DELTA, int NW>
+// B7: every byte of q and c is below 0x80 (alphabets of <= 124 classes, rows masked with 0x7F7F7F7F by the caller: the paddings
+// become 0x7E / 0x7F and still equal nothing).  Then x = q ^ c has no bit 7 and x + 0x7F7F7F7F sets bit 7 of exactly the
+// non-zero bytes without a carry between bytes: one v_add instead of v_and + v_add + v_or3 (13 of the 24 issue cycles a
+// word-shift costs are the zero test; only bit 7 of every byte of nz / nmA / nmB is ever looked at).
+template <int DELTA, int NW, bool B7>
 __device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], uint32_t off, uint32_t (&nmA)[NW],
                                     uint32_t (&nmB)[NW]) {
   // off: 0 for lanes that use this shift (d >= |DELTA|), all ones for the others (nothing matches at this shift)
@@ -45,7 +49,7 @@ __device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)
     else if (DELTA > 0) cs = __builtin_amdgcn_alignbyte(c[k + 2], c[k + 1], DELTA);
     else cs = __builtin_amdgcn_alignbyte(c[k + 1], c[k], 4 + DELTA);
     const uint32_t x = q[k] ^ cs;
-    nz[k + 1] = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | off;  // bit7 set where q[i] != c[i + DELTA] (v_or3)
+    nz[k + 1] = B7 ? ((x + 0x7F7F7F7Fu) | off) : (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | off);  // bit7 set where q[i] != c[i + DELTA]
     nmA[k] &= nz[k + 1];
   }
 #pragma unroll
@@ -60,15 +64,15 @@ __device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)
 // band-match bound: a symbol with no equal symbol of the other string within +-d positions costs at least one edit.
 // Rows are padded beyond their length with bytes that equal nothing (query 0xFE, candidate 0xFF), so the 4*NW - len
 // padding positions always count as unmatched and are subtracted instead of masked.
-template <int NW>
+template <int NW, bool B7 = false>
 __device__ inline bool band_bound_rejects(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], bool filt, int d, int lq, int lc) {
   uint32_t nmA[NW], nmB[NW];
 #pragma unroll
   for (int k = 0; k < NW; ++k) { nmA[k] = 0xFFFFFFFFu; nmB[k] = 0xFFFFFFFFu; }
-  filter_shift<0, NW>(q, c, 0u, nmA, nmB);
-  if (__any(filt && d >= 1)) { const uint32_t off = d >= 1 ? 0u : 0xFFFFFFFFu; filter_shift<1, NW>(q, c, off, nmA, nmB); filter_shift<-1, NW>(q, c, off, nmA, nmB); }
-  if (__any(filt && d >= 2)) { const uint32_t off = d >= 2 ? 0u : 0xFFFFFFFFu; filter_shift<2, NW>(q, c, off, nmA, nmB); filter_shift<-2, NW>(q, c, off, nmA, nmB); }
-  if (__any(filt && d >= 3)) { const uint32_t off = d >= 3 ? 0u : 0xFFFFFFFFu; filter_shift<3, NW>(q, c, off, nmA, nmB); filter_shift<-3, NW>(q, c, off, nmA, nmB); }
+  filter_shift<0, NW, B7>(q, c, 0u, nmA, nmB);
+  if (__any(filt && d >= 1)) { const uint32_t off = d >= 1 ? 0u : 0xFFFFFFFFu; filter_shift<1, NW, B7>(q, c, off, nmA, nmB); filter_shift<-1, NW, B7>(q, c, off, nmA, nmB); }
+  if (__any(filt && d >= 2)) { const uint32_t off = d >= 2 ? 0u : 0xFFFFFFFFu; filter_shift<2, NW, B7>(q, c, off, nmA, nmB); filter_shift<-2, NW, B7>(q, c, off, nmA, nmB); }
+  if (__any(filt && d >= 3)) { const uint32_t off = d >= 3 ? 0u : 0xFFFFFFFFu; filter_shift<3, NW, B7>(q, c, off, nmA, nmB); filter_shift<-3, NW, B7>(q, c, off, nmA, nmB); }
   int unA = lq - 4 * NW, unB = lc - 4 * NW;
 #pragma unroll
   for (int k = 0; k < NW; ++k) {
@@ -436,7 +440,7 @@ struct FsCold {
   SurvOut so;
   SlotList list8, listg, listw;
 };
-template <int D, bool WIDE>
+template <int D, bool WIDE, bool B7>
 __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, const FsCold* __restrict__ cold) {
   const ScoreArgs& a = cold->a;
   const SurvOut& so = cold->so;
@@ -490,15 +494,17 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       // and one query length: 23 % of the bench queries fit 2 words with their candidates, 54 % more fit 3)
       const bool f4 = filt && !wide;
       const int ml = lq > lc ? lq : lc;
+      // B7 (alphabets of <= 124 classes): symbols < 0x7E, the paddings 0xFE / 0xFF masked down to 0x7E / 0x7F
+      constexpr uint32_t M = B7 ? 0x7F7F7F7Fu : 0xFFFFFFFFu;
       if (__any(f4 && ml > 12)) {
-        const uint32_t q4[4] = {Q.x, Q.y, Q.z, Q.w}, c6[6] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu};
-        if (band_bound_rejects<4>(q4, c6, f4, d, lq, lc)) selected = false;
+        const uint32_t q4[4] = {Q.x & M, Q.y & M, Q.z & M, Q.w & M}, c6[6] = {M, C.x & M, C.y & M, C.z & M, C.w & M, M};
+        if (band_bound_rejects<4, B7>(q4, c6, f4, d, lq, lc)) selected = false;
       } else if (__any(f4 && ml > 8)) {
-        const uint32_t q3[3] = {Q.x, Q.y, Q.z}, c5[5] = {0xFFFFFFFFu, C.x, C.y, C.z, 0xFFFFFFFFu};
-        if (band_bound_rejects<3>(q3, c5, f4, d, lq, lc)) selected = false;
+        const uint32_t q3[3] = {Q.x & M, Q.y & M, Q.z & M}, c5[5] = {M, C.x & M, C.y & M, C.z & M, M};
+        if (band_bound_rejects<3, B7>(q3, c5, f4, d, lq, lc)) selected = false;
       } else {
-        const uint32_t q2[2] = {Q.x, Q.y}, c4[4] = {0xFFFFFFFFu, C.x, C.y, 0xFFFFFFFFu};
-        if (band_bound_rejects<2>(q2, c4, f4, d, lq, lc)) selected = false;
+        const uint32_t q2[2] = {Q.x & M, Q.y & M}, c4[4] = {M, C.x & M, C.y & M, M};
+        if (band_bound_rejects<2, B7>(q2, c4, f4, d, lq, lc)) selected = false;
       }
     }
     const bool tow = !WIDE && wide;  // prefiltered later by k_filter_wide (which also counts it as selected if it passes)
