@@ -262,14 +262,23 @@ def main():
         kinds = st["n_tests_kind"]
         issue_cycles = (kinds[0] * (8 * 4.3 + 4.3) * 4 + sum(kinds[t] * (t * 4 * 6.5 + 4 * 4.3) for t in range(1, 5))) / 256.0
         valu_floor_ms = issue_cycles / SIMD_HZ * 1e3
-        #  filter_score, per wave of 64 (DESIGN.md section 5 K2+K3): SWAR band filter of every slot: (2d+1) shifts x NW words x
-        #  (alignbyte, xor, and, add, or3, and | alignbyte, and) = 24 cycles, the unshifted one 15.4, + 8 (and, bcnt) popcounts;
+        #  filter_score, per wave of 64 (DESIGN.md section 5 K2+K3): SWAR band filter of every slot over as many 4-symbol words as
+        #  the pair needs (the kernel picks 2 / 3 / 4 per wave; estimated here from the query lengths as ceil((len + 1) / 4)):
+        #  per word the unshifted comparison + 2d shifted ones + 2 x (and, bcnt) popcounts.  Alphabets of <= 124 classes (7-bit
+        #  symbol codes, the kernel's B7 instances): 2 mask ands, unshifted (xor, add, and, and) = 8.8 cycles, shifted
+        #  (alignbyte, xor, add, and | alignbyte, and) = 17.4; otherwise unshifted (xor, and, add, or, and, and) = 15.4, shifted
+        #  (alignbyte, xor, and, add, or3, and | alignbyte, and) = 24.0.
         #  band DL of every selected pair: rows x (2d+1) cells x (2 min, 2 add, cmp, cndmask = 16 cycles), rows ~ mean query length;
         #  tail of every DL survivor (LCS diagonal walk, prefix, suffix, f64 score) ~ 300 instructions = 900 cycles.
         dd = args.edit_distance
         nw = 4 if args.max_len <= 16 else 8
-        mean_len = sum(len(q) for q in queries[:20000]) / min(len(queries), 20000)
-        fs_cycles = (st["n_pair_slots"] / 64.0) * ((15.4 + 2 * dd * 24.0) * nw + 8 * 6.5) \
+        sample_q = queries[:20000]
+        mean_len = sum(len(q) for q in sample_q) / max(len(sample_q), 1)
+        words = sum(min(nw, (len(q) + 1 + 3) // 4) for q in sample_q) / max(len(sample_q), 1)
+        from analiticcl_amd import _lib as _L
+        b7 = _L.lib().anx_model_alphabet_size(model.h) < 0x7E  # = classes + 1 = the largest symbol code (unknown): engine.hip's condition
+        c_mask, c_unshifted, c_shifted = (4.4, 8.8, 17.4) if b7 else (0.0, 15.4, 24.0)
+        fs_cycles = (st["n_pair_slots"] / 64.0) * ((c_mask + c_unshifted + 2 * dd * c_shifted + 2 * 6.5) * words) \
             + (st["n_selected"] / 64.0) * (mean_len * (2 * dd + 1) * 16.0) + (st["n_survivors"] / 64.0) * 900.0
         fs_valu_floor_ms = fs_cycles / SIMD_HZ * 1e3
         # HBM bytes per launch of that kernel from the committed PMC passes: only for the same workload AND the same kernel
