@@ -18,7 +18,7 @@ for name, blk in blocks():
         kern[name] = {"fetch_kb": f, "write_kb": w, "traffic_bytes": int((2 * f + w) * 1024)}
     if va and g and name in ("k_scan_bits", "k_filter_score", "k_rank", "k_compact", "k_compact_grouped"):
         lines.append(f"# {name}: VALU-active = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = {va*4/(g/8*1024)*100:.0f} %; "
-                     f"{vi/1e6:.0f} M VALU + {si/1e6:.0f} M SALU wave-instructions; HBM traffic 2*{f/1024:.0f} MB + {w/1024:.0f} MB = {(2*f+w)/1048576:.2f} GB per launch")
+                     f"{vi/1e6:.0f} M VALU + {si/1e6:.0f} M SALU wave-instructions; HBM traffic 2*{f/1024:.0f} MiB + {w/1024:.0f} MiB = {(2*f+w)*1024/1e9:.2f} GB per launch")
 hdr = (f"# Round {int(TAG[1:])} final -- rocprofv3 --pmc passes (separate runs, --kernel-trace only), python3 bench.py --steps 2 --warmup 1 --cpu-sample 0\n"
        "# recipe: tools/measure_round.sh; passes: {SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU} "
        "{SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE} {FETCH_SIZE} {WRITE_SIZE}\n"
