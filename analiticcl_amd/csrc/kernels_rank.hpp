@@ -355,14 +355,21 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
     const uint32_t fi = s_freq[i];
     const unsigned long long oi = s_ord[i];
     uint32_t rank = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-      const double kj = s_key[j];
-      const uint32_t fj = s_freq[j];
-      const unsigned long long oj = s_ord[j];
-      bool before;
-      if (sort_weighted) before = kj > ki || (kj == ki && oj < oi);
-      else before = kj > ki || (kj == ki && (fj > fi || (fj == fi && oj < oi)));
-      rank += before;
+    // every comparison is evaluated and the flags combined with bit operations: short-circuit && / || compiled to nested
+    // exec-masked branches, four per candidate; the wave-uniform choice of the order is taken outside the loop
+    if (sort_weighted) {
+      for (uint32_t j = 0; j < n; ++j) {
+        const double kj = s_key[j];
+        const unsigned long long oj = s_ord[j];
+        rank += (uint32_t)((kj > ki) | ((kj == ki) & (oj < oi)));
+      }
+    } else {
+      for (uint32_t j = 0; j < n; ++j) {
+        const double kj = s_key[j];
+        const uint32_t fj = s_freq[j];
+        const unsigned long long oj = s_ord[j];
+        rank += (uint32_t)((kj > ki) | ((kj == ki) & ((fj > fi) | ((fj == fi) & (oj < oi)))));
+      }
     }
     if (rank < M) {
       const SurvRow r = c_rows[seg0 + s_src[i]];
