@@ -373,7 +373,8 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
     }
     if (rank < M) {
       const SurvRow r = c_rows[seg0 + s_src[i]];
-      const double ff = max_freq > 0.0 ? (double)fi / max_freq : (double)fi;
+      // (without frequency information max_freq is 1 or 0: x / 1.0 == x, no f64 division)
+      const double ff = (a.have_freq && max_freq > 0.0) ? (double)fi / max_freq : (double)fi;
       r_rows[seg0 + rank] = DevRow{r.vocab, a.any_variants ? r.via : 0xFFFFFFFFu, r.score, ff};
       if (rank < (uint32_t)G) { s_sdist[rank] = r.score; s_sfreq[rank] = ff; }
     }
@@ -408,8 +409,11 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
       }
     }
     const bool docut = parallel_tail && a.cutoff_threshold >= 1.0;
-    const double best = docut ? result_score(s_sdist[0], s_sfreq[0], fw) : 0.0;
-    const unsigned long long cut = (__ballot(have && docut && gl >= 1 && (uint32_t)gl < len && si <= best / a.cutoff_threshold) >> gshift) & gmask;
+    // the best row's score over the cutoff: with `prune` it is `thr` from above, bit for bit (the sort key of a row is its
+    // result_score there, computed by the same expression from the same operands, and rank 0 holds the largest key)
+    double cutthr = thr;
+    if (docut && !prune) cutthr = result_score(s_sdist[0], s_sfreq[0], fw) / a.cutoff_threshold;
+    const unsigned long long cut = (__ballot(have && docut && gl >= 1 && (uint32_t)gl < len && si <= cutthr) >> gshift) & gmask;
     if (cut) len = (uint32_t)__ffsll((long long)cut) - 1;
     if (parallel_tail && gl == 0) r_count[q] = len;
   }
