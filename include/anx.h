@@ -174,7 +174,9 @@ void anx_results_free(anx_result *rows, size_t *offsets);
  * fetch  : download + convert.  anx_find_variants_batch == encode + run + fetch + free. */
 anx_batch *anx_batch_encode(const anx_model *, const char *const *utf8, size_t n, const anx_params *);
 /* the same with the n inputs packed into one buffer, each terminated by a NUL byte (saves building a pointer array
- * in bindings: 1 M Python strings take 0.27 s to marshal one by one, 0.03 s packed) */
+ * in bindings: 1 M Python strings take 0.27 s to marshal one by one, 0.03 s packed).  The buffer goes to the device as it
+ * is and the strings are found there (the first n NUL-terminated spans; anything behind them is ignored; fewer than n spans or
+ * a buffer that does not end with a NUL byte: ANX_EINVAL).  An input may not contain a NUL byte itself (as in the char** form). */
 anx_batch *anx_batch_encode_packed(const anx_model *, const char *blob, size_t blob_len, size_t n, const anx_params *);
 /* `stream` is a hipStream_t (NULL = the default stream). Asynchronous except for one count read-back. */
 int anx_batch_run(const anx_model *, anx_batch *, void *stream);
