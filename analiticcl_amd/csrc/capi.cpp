@@ -24,7 +24,8 @@ struct anx_batch {
   // rescoring in anx_batch_fetch needs the caller's parameters and the input texts
   bool rescore = false;
   anx_params params;
-  std::vector<std::string> inputs;
+  std::string in_text;            // the inputs, each followed by a NUL byte (one copy of the caller's buffer, not a string each)
+  std::vector<uint32_t> in_off;   // n + 1 offsets into in_text
 };
 
 static thread_local std::string g_err;
@@ -45,11 +46,11 @@ static double vr_score(const anx_result& r, float fw) {  // src/types.rs:335-341
   if (fw == 0.0f) return r.dist_score;
   return (r.dist_score + ((double)fw * r.freq_score)) / (1.0 + (double)fw);
 }
-static void rescore_with_confusables(const anx::HostModel& m, const std::vector<std::string>& inputs, const anx_params& p,
-                                     anx_result* rows, size_t* offs) {
+static void rescore_with_confusables(const anx::HostModel& m, const std::string& in_text, const std::vector<uint32_t>& in_off,
+                                     const anx_params& p, anx_result* rows, size_t* offs) {
   const float fw = p.freq_weight;
   const bool early = m.confusables_before_pruning;
-  const size_t n = inputs.size();
+  const size_t n = in_off.empty() ? 0 : in_off.size() - 1;
   std::vector<size_t> newlen(n, 0);
   // every input is independent: edit scripts, re-ranking and cut-off on host threads, in place inside the input's row range
   auto work = [&](size_t lo, size_t hi) {
@@ -62,7 +63,7 @@ static void rescore_with_confusables(const anx::HostModel& m, const std::vector<
       for (size_t k0 = 0; k0 < cnt; k0 += 64) {
         const size_t kn = std::min<size_t>(64, cnt - k0);
         for (size_t k = 0; k < kn; ++k) ids[k] = v[k0 + k].via != ANX_NO_VIA ? v[k0 + k].via : v[k0 + k].vocab_id;
-        m.confusable_weights(inputs[i], ids, kn, wts);
+        m.confusable_weights(in_text.data() + in_off[i], (size_t)(in_off[i + 1] - in_off[i]) - 1, ids, kn, wts);
         for (size_t k = 0; k < kn; ++k) v[k0 + k].dist_score *= wts[k];
       }
       std::stable_sort(v, v + cnt, [&](const anx_result& a, const anx_result& b) {  // rank_cmp, src/types.rs:344-365
@@ -534,8 +535,13 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
   h->rescore = rescore;
   h->params = *p;
   if (rescore) {
-    h->inputs.reserve(n);
-    for (size_t i = 0; i < n; ++i) h->inputs.emplace_back(utf8[i] ? utf8[i] : "");
+    h->in_off.reserve(n + 1);
+    h->in_off.push_back(0);
+    for (size_t i = 0; i < n; ++i) {
+      if (utf8[i]) h->in_text.append(utf8[i]);
+      h->in_text.push_back('\0');
+      h->in_off.push_back((uint32_t)h->in_text.size());
+    }
   }
   return h;
 }
@@ -560,8 +566,8 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
   h->rescore = rescore;
   h->params = *p;
   if (rescore) {
-    h->inputs.reserve(n);
-    for (size_t i = 0; i < n; ++i) h->inputs.emplace_back(blob + off[i]);
+    h->in_text.assign(blob, off[n]);  // the first n strings with their NUL bytes
+    h->in_off = std::move(off);
   }
   return h;
 }
@@ -588,7 +594,7 @@ int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   std::string err;
   int rc = anx::batch_fetch(b->model->host, b->model->dev, b->b, rows, offs, err);
   if (rc) return fail(rc, err);
-  if (b->rescore) rescore_with_confusables(b->model->host, b->inputs, b->params, *rows, *offs);
+  if (b->rescore) rescore_with_confusables(b->model->host, b->in_text, b->in_off, b->params, *rows, *offs);
   return ANX_OK;
 }
 int anx_batch_fetch_pairs(const anx_batch* b, anx_pair** out, size_t* n) {

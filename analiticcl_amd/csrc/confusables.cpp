@@ -15,46 +15,136 @@
 namespace anx {
 namespace {
 
-typedef std::u32string U;
-struct Diff { char op; U text; };  // '=', '-', '+'
-typedef std::vector<Diff> Diffs;
+typedef std::u32string U;  // long-lived text: patterns, the decoded vocabulary
 
-U to_u32(const std::string& s) {
+// The diff works on strings of a few dozen code points and builds / splices many short ones per call: with the default
+// allocator a ranked row cost ~1 us of malloc / free (u32string keeps 3 characters inline).  Everything a call to edit_script
+// allocates comes from a per-thread arena instead (pointer bump, nothing freed, reset at the start of the next call): the
+// result of a call is valid until the same thread calls edit_script again.
+struct Arena {
+  std::vector<std::unique_ptr<char[]>> chunks;
+  std::vector<size_t> sizes;
+  size_t chunk = 0, used = 0;
+  void* alloc(size_t n) {
+    n = (n + 15) & ~(size_t)15;
+    while (chunk < chunks.size() && used + n > sizes[chunk]) { ++chunk; used = 0; }
+    if (chunk == chunks.size()) {
+      const size_t sz = std::max<size_t>(n, (size_t)64 << 10);
+      chunks.emplace_back(new char[sz]);
+      sizes.push_back(sz);
+      used = 0;
+    }
+    void* p = chunks[chunk].get() + used;
+    used += n;
+    return p;
+  }
+  void reset() {
+    if (chunks.size() > 4) { chunks.resize(1); sizes.resize(1); }  // an unusually long input: give the memory back
+    chunk = 0;
+    used = 0;
+  }
+};
+Arena& arena() { static thread_local Arena a; return a; }
+template <class T>
+struct ArenaAlloc {
+  typedef T value_type;
+  ArenaAlloc() = default;
+  template <class V> ArenaAlloc(const ArenaAlloc<V>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(arena().alloc(n * sizeof(T))); }
+  void deallocate(T*, size_t) noexcept {}
+  template <class V> bool operator==(const ArenaAlloc<V>&) const { return true; }
+  template <class V> bool operator!=(const ArenaAlloc<V>&) const { return false; }
+};
+// Text inside one edit_script call: a (pointer, length) view of code points that live in the arena or in the two input
+// strings.  substr is a view of the same storage, concatenation writes new arena storage; nothing is ever modified in place, so
+// views stay valid for the whole call, and a Diff is a trivially copyable 24 bytes (the diff clean-ups insert into and erase
+// from the middle of the script all the time).
+struct AU {
+  static constexpr size_t npos = (size_t)-1;
+  const char32_t* p = nullptr;
+  size_t n = 0;
+  AU() = default;
+  AU(const char32_t* q, size_t len) : p(q), n(len) {}
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  const char32_t* data() const { return p; }
+  const char32_t* begin() const { return p; }
+  const char32_t* end() const { return p + n; }
+  char32_t operator[](size_t i) const { return p[i]; }
+  char32_t front() const { return p[0]; }
+  char32_t back() const { return p[n - 1]; }
+  void clear() { n = 0; }
+  AU substr(size_t pos, size_t len = npos) const { return AU(p + pos, std::min(len, n - pos)); }
+  int compare(size_t pos, size_t len, const AU& o, size_t opos, size_t olen) const {  // equal-length ranges only (common_overlap)
+    (void)olen;
+    return std::char_traits<char32_t>::compare(p + pos, o.p + opos, len);
+  }
+  size_t find(const AU& needle) const {
+    const char32_t* it = std::search(p, p + n, needle.p, needle.p + needle.n);
+    return it == p + n && needle.n ? npos : (size_t)(it - p);
+  }
+  static AU concat(const char32_t* a, size_t na, const char32_t* b, size_t nb) {
+    char32_t* q = static_cast<char32_t*>(arena().alloc((na + nb) * sizeof(char32_t) + 4));
+    if (na) memcpy(q, a, na * sizeof(char32_t));
+    if (nb) memcpy(q + na, b, nb * sizeof(char32_t));
+    return AU(q, na + nb);
+  }
+  AU& operator+=(const AU& o) { if (o.n) *this = concat(p, n, o.p, o.n); return *this; }
+  AU& operator+=(char32_t c) { *this = concat(p, n, &c, 1); return *this; }
+};
+AU operator+(const AU& a, const AU& b) { return AU::concat(a.p, a.n, b.p, b.n); }
+AU operator+(const AU& a, char32_t c) { return AU::concat(a.p, a.n, &c, 1); }
+bool operator==(const AU& a, const AU& b) { return a.n == b.n && std::char_traits<char32_t>::compare(a.p, b.p, a.n) == 0; }
+bool operator!=(const AU& a, const AU& b) { return !(a == b); }
+struct Diff { char op; AU text; };  // '=', '-', '+'
+typedef std::vector<Diff, ArenaAlloc<Diff>> Diffs;
+
+U to_u32(const char* s, size_t n) {
   U out;
-  for (size_t i = 0; i < s.size();) {
+  out.reserve(n);
+  for (size_t i = 0; i < n;) {
     int l;
-    out.push_back(utf8_decode_at(s.data() + i, s.size() - i, &l));
+    out.push_back(utf8_decode_at(s + i, n - i, &l));
     i += (size_t)l;
   }
   return out;
 }
-size_t common_prefix(const U& a, const U& b) {
+U to_u32(const std::string& s) { return to_u32(s.data(), s.size()); }
+template <class A, class B>
+bool same_text(const A& a, const B& b) { return a.size() == b.size() && std::char_traits<char32_t>::compare(a.data(), b.data(), a.size()) == 0; }
+template <class A, class B>
+size_t common_prefix(const A& a, const B& b) {
   const size_t n = std::min(a.size(), b.size());
   size_t i = 0;
   while (i < n && a[i] == b[i]) ++i;
   return i;
 }
-size_t common_suffix(const U& a, const U& b) {
+template <class A, class B>
+size_t common_suffix(const A& a, const B& b) {
   const size_t n = std::min(a.size(), b.size());
   size_t i = 0;
   while (i < n && a[a.size() - 1 - i] == b[b.size() - 1 - i]) ++i;
   return i;
 }
-size_t common_overlap(const U& a, const U& b) {  // longest suffix of a that is a prefix of b
+size_t common_overlap(const AU& a, const AU& b) {  // longest suffix of a that is a prefix of b
   for (size_t k = std::min(a.size(), b.size()); k > 0; --k)
     if (a.compare(a.size() - k, k, b, 0, k) == 0) return k;
   return 0;
 }
-bool ends_with(const U& s, const U& x) { return s.size() >= x.size() && s.compare(s.size() - x.size(), x.size(), x) == 0; }
-bool starts_with(const U& s, const U& x) { return s.size() >= x.size() && s.compare(0, x.size(), x) == 0; }
+template <class A, class B>
+bool ends_with(const A& s, const B& x) {
+  return s.size() >= x.size() && std::char_traits<char32_t>::compare(s.data() + (s.size() - x.size()), x.data(), x.size()) == 0;
+}
+template <class A, class B>
+bool starts_with(const A& s, const B& x) { return s.size() >= x.size() && std::char_traits<char32_t>::compare(s.data(), x.data(), x.size()) == 0; }
 
 void cleanup_merge(Diffs& d);
-Diffs diff_main(U a, U b);
+Diffs diff_main(AU a, AU b);
 
-Diffs bisect(const U& a, const U& b) {
+Diffs bisect(const AU& a, const AU& b) {
   const long n1 = (long)a.size(), n2 = (long)b.size();
   const long max_d = (n1 + n2 + 1) / 2, v_offset = max_d, v_length = 2 * max_d;
-  std::vector<long> v1((size_t)v_length, -1), v2((size_t)v_length, -1);
+  std::vector<long, ArenaAlloc<long>> v1((size_t)v_length, -1), v2((size_t)v_length, -1);
   v1[(size_t)v_offset + 1] = 0;
   v2[(size_t)v_offset + 1] = 0;
   const long delta = n1 - n2;
@@ -106,13 +196,13 @@ Diffs bisect(const U& a, const U& b) {
   return Diffs{{'-', a}, {'+', b}};
 }
 
-Diffs compute(const U& a, const U& b) {
+Diffs compute(const AU& a, const AU& b) {
   if (a.empty()) return b.empty() ? Diffs{} : Diffs{{'+', b}};
   if (b.empty()) return Diffs{{'-', a}};
-  const U& longt = a.size() > b.size() ? a : b;
-  const U& shortt = a.size() > b.size() ? b : a;
+  const AU& longt = a.size() > b.size() ? a : b;
+  const AU& shortt = a.size() > b.size() ? b : a;
   const size_t i = longt.find(shortt);
-  if (i != U::npos) {
+  if (i != AU::npos) {
     const char op = a.size() > b.size() ? '-' : '+';
     Diffs out;
     if (i) out.push_back({op, longt.substr(0, i)});
@@ -124,14 +214,14 @@ Diffs compute(const U& a, const U& b) {
   return bisect(a, b);
 }
 
-Diffs diff_main(U a, U b) {
+Diffs diff_main(AU a, AU b) {
   if (a == b) return a.empty() ? Diffs{} : Diffs{{'=', a}};
   const size_t p = common_prefix(a, b);
-  const U prefix = a.substr(0, p);
+  const AU prefix = a.substr(0, p);
   a = a.substr(p);
   b = b.substr(p);
   const size_t s = common_suffix(a, b);
-  const U suffix = a.substr(a.size() - s);
+  const AU suffix = a.substr(a.size() - s);
   a = a.substr(0, a.size() - s);
   b = b.substr(0, b.size() - s);
   Diffs d = compute(a, b);
@@ -142,10 +232,10 @@ Diffs diff_main(U a, U b) {
 }
 
 void cleanup_merge(Diffs& d) {
-  d.push_back({'=', U()});
+  d.push_back({'=', AU()});
   size_t pointer = 0;
   size_t count_delete = 0, count_insert = 0;
-  U text_delete, text_insert;
+  AU text_delete, text_insert;
   while (pointer < d.size()) {
     if (d[pointer].op == '+') { ++count_insert; text_insert += d[pointer].text; ++pointer; }
     else if (d[pointer].op == '-') { ++count_delete; text_delete += d[pointer].text; ++pointer; }
@@ -188,7 +278,7 @@ void cleanup_merge(Diffs& d) {
   pointer = 1;
   while (pointer + 1 < d.size()) {
     if (d[pointer - 1].op == '=' && d[pointer + 1].op == '=') {
-      const U prev_t = d[pointer - 1].text, cur_t = d[pointer].text, next_t = d[pointer + 1].text;
+      const AU prev_t = d[pointer - 1].text, cur_t = d[pointer].text, next_t = d[pointer + 1].text;
       if (!prev_t.empty() && ends_with(cur_t, prev_t)) {
         d[pointer].text = prev_t + cur_t.substr(0, cur_t.size() - prev_t.size());
         d[pointer + 1].text = prev_t + next_t;
@@ -208,14 +298,14 @@ void cleanup_merge(Diffs& d) {
 
 bool is_alnum(char32_t c) { return is_alphabetic_cp(c) || (c >= U'0' && c <= U'9'); }  // char::is_alphanumeric, ASCII digits
 bool is_space(char32_t c) { return c == U' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000; }
-int semantic_score(const U& one, const U& two) {
+int semantic_score(const AU& one, const AU& two) {
   if (one.empty() || two.empty()) return 6;
   const char32_t c1 = one.back(), c2 = two.front();
   const bool na1 = !is_alnum(c1), na2 = !is_alnum(c2);
   const bool ws1 = na1 && is_space(c1), ws2 = na2 && is_space(c2);
   const bool lb1 = ws1 && (c1 == U'\r' || c1 == U'\n'), lb2 = ws2 && (c2 == U'\r' || c2 == U'\n');
-  const bool bl1 = lb1 && (ends_with(one, U"\n\n") || ends_with(one, U"\n\r\n"));
-  const bool bl2 = lb2 && (starts_with(two, U"\n\n") || starts_with(two, U"\r\n\n") || starts_with(two, U"\n\r\n") || starts_with(two, U"\r\n\r\n"));
+  const bool bl1 = lb1 && (ends_with(one, U(U"\n\n")) || ends_with(one, U(U"\n\r\n")));
+  const bool bl2 = lb2 && (starts_with(two, U(U"\n\n")) || starts_with(two, U(U"\r\n\n")) || starts_with(two, U(U"\n\r\n")) || starts_with(two, U(U"\r\n\r\n")));
   if (bl1 || bl2) return 5;
   if (lb1 || lb2) return 4;
   if (na1 && !ws1 && ws2) return 3;
@@ -228,15 +318,15 @@ void cleanup_semantic_lossless(Diffs& d) {
   long pointer = 1;
   while (pointer + 1 < (long)d.size()) {
     if (d[(size_t)pointer - 1].op == '=' && d[(size_t)pointer + 1].op == '=') {
-      U eq1 = d[(size_t)pointer - 1].text, edit = d[(size_t)pointer].text, eq2 = d[(size_t)pointer + 1].text;
+      AU eq1 = d[(size_t)pointer - 1].text, edit = d[(size_t)pointer].text, eq2 = d[(size_t)pointer + 1].text;
       const size_t co = common_suffix(eq1, edit);
       if (co) {
-        const U cs = edit.substr(edit.size() - co);
+        const AU cs = edit.substr(edit.size() - co);
         eq1 = eq1.substr(0, eq1.size() - co);
         edit = cs + edit.substr(0, edit.size() - co);
         eq2 = cs + eq2;
       }
-      U b1 = eq1, be = edit, b2 = eq2;
+      AU b1 = eq1, be = edit, b2 = eq2;
       int best = semantic_score(eq1, edit) + semantic_score(edit, eq2);
       while (!edit.empty() && !eq2.empty() && edit[0] == eq2[0]) {
         eq1 += edit[0];
@@ -259,9 +349,9 @@ void cleanup_semantic_lossless(Diffs& d) {
 
 void cleanup_semantic(Diffs& d) {
   bool changes = false;
-  std::vector<long> equalities;
+  std::vector<long, ArenaAlloc<long>> equalities;
   bool have_last = false;
-  U last_eq;
+  AU last_eq;
   long pointer = 0;
   size_t li1 = 0, ld1 = 0, li2 = 0, ld2 = 0;
   while (pointer < (long)d.size()) {
@@ -293,7 +383,7 @@ void cleanup_semantic(Diffs& d) {
   size_t p = 1;
   while (p < d.size()) {
     if (d[p - 1].op == '-' && d[p].op == '+') {
-      const U deletion = d[p - 1].text, insertion = d[p].text;
+      const AU deletion = d[p - 1].text, insertion = d[p].text;
       const size_t o1 = common_overlap(deletion, insertion), o2 = common_overlap(insertion, deletion);
       if (o1 >= o2) {
         if (2 * o1 >= deletion.size() || 2 * o1 >= insertion.size()) {
@@ -314,15 +404,17 @@ void cleanup_semantic(Diffs& d) {
   }
 }
 
-Diffs edit_script(const U& a, const U& b) {
-  Diffs d = diff_main(a, b);
+Diffs edit_script(const U& a, const U& b) {  // the result lives in the calling thread's arena until its next call
+  arena().reset();
+  Diffs d = diff_main(AU(a.data(), a.size()), AU(b.data(), b.size()));  // views of the inputs: they outlive the call
   cleanup_semantic(d);
   cleanup_merge(d);
   d.erase(std::remove_if(d.begin(), d.end(), [](const Diff& x) { return x.text.empty(); }), d.end());
   return d;
 }
 
-std::string to_utf8(const U& s) {
+template <class S>
+std::string to_utf8(const S& s) {
   std::string out;
   for (char32_t c : s) {
     if (c < 0x80) out.push_back((char)c);
@@ -344,10 +436,10 @@ bool found_in(const Confusable& c, const Diffs& ref) {  // src/confusables.rs:47
       for (const U& s : c.options[matches]) {
         bool ok;
         if (op != '=') ok = ends_with(ref[i].text, s);
-        else if (matches == 0 && matches == l - 1) ok = s == ref[i].text;
+        else if (matches == 0 && matches == l - 1) ok = same_text(s, ref[i].text);
         else if (matches == 0) ok = ends_with(ref[i].text, s);
         else if (matches == l - 1) ok = starts_with(ref[i].text, s);
-        else ok = s == ref[i].text;
+        else ok = same_text(s, ref[i].text);
         if (ok) { found = true; break; }
       }
     if (!found) {
@@ -364,7 +456,8 @@ bool found_in(const Confusable& c, const Diffs& ref) {  // src/confusables.rs:47
 
 std::string edit_script_string(const std::string& source, const std::string& target) {
   std::string out;
-  for (const Diff& x : edit_script(to_u32(source), to_u32(target))) {
+  const U a = to_u32(source), b = to_u32(target);  // the script holds views of them
+  for (const Diff& x : edit_script(a, b)) {
     out.push_back(x.op);
     out.push_back('[');
     out += to_utf8(x.text);
@@ -398,6 +491,13 @@ int HostModel::add_to_confusables(const std::string& script, double weight, std:
         if (e == std::string::npos) break;
         pos = e + 1;
       }
+      Confusable::Screen sc;
+      sc.simple = true;
+      for (const U& o : opts) {
+        if (o.size() == 1 && o[0] < 128) sc.bits[o[0] >> 6] |= 1ull << (o[0] & 63);
+        else sc.simple = false;
+      }
+      c.screen.push_back(sc);
       c.options.push_back(std::move(opts));
       begin = i + 1;
     }
@@ -450,6 +550,15 @@ bool occurs(const U& opt, const U& s, const CharSet& cs) {
 bool may_match(const Confusable& c, const U& in, const CharSet& ins, const U& cand, const CharSet& cs) {
   const size_t l = c.ops.size();
   for (size_t k = 0; k < l; ++k) {
+    const bool tail = c.strictend && k == l - 1 && c.ops[k] != '=';
+    if (c.screen[k].simple && !tail) {  // one-character options: the same test on the presence bits of the two strings
+      const uint64_t* b = c.screen[k].bits;
+      uint64_t h0 = b[0], h1 = b[1];
+      if (c.ops[k] != '+') { h0 &= ins.w[0]; h1 &= ins.w[1]; }
+      if (c.ops[k] != '-') { h0 &= cs.w[0]; h1 &= cs.w[1]; }
+      if (!(h0 | h1)) return false;
+      continue;
+    }
     bool any = false;
     for (const U& opt : c.options[k]) {
       bool ok = (c.ops[k] == '+' || occurs(opt, in, ins)) && (c.ops[k] == '-' || occurs(opt, cand, cs));
@@ -468,7 +577,7 @@ struct HostModel::ConfCache {
   std::vector<CharSet> cs;
 };
 
-void HostModel::confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const {  // src/lib.rs:1733-1756
+void HostModel::confusable_weights(const char* input, size_t len, const uint64_t* ids, size_t n, double* out) const {  // src/lib.rs:1733-1756
   const ConfCache* held = conf_cache.load(std::memory_order_acquire);
   if (!held || held->text.size() != decoder.size()) {  // first use, or the vocabulary grew since (items are only ever appended)
     std::lock_guard<std::mutex> g(conf_cache_mu);
@@ -484,14 +593,26 @@ void HostModel::confusable_weights(const std::string& input, const uint64_t* ids
     }
   }
   const ConfCache& cc = *held;
-  const U in = to_u32(input);
+  const U in = to_u32(input, len);
   const CharSet ins = charset_of(in);
+  // the patterns whose deletions / equalities the INPUT can supply at all: the rows of an input are only screened against these
+  const Confusable* live[64];
+  size_t nlive = 0;
+  bool all_live = confusables.size() > 64;
+  if (!all_live)
+    for (const Confusable& c : confusables) {
+      bool ok = true;
+      for (size_t j = 0; j < c.ops.size() && ok; ++j)
+        if (c.ops[j] != '+' && c.screen[j].simple) ok = ((c.screen[j].bits[0] & ins.w[0]) | (c.screen[j].bits[1] & ins.w[1])) != 0;
+      if (ok) live[nlive++] = &c;
+    }
   for (size_t k = 0; k < n; ++k) {
     double weight = 1.0;
     if (ids[k] < cc.text.size()) {
       const U& cand = cc.text[ids[k]];
       bool any = false;
-      for (const Confusable& c : confusables) any = any || may_match(c, in, ins, cand, cc.cs[ids[k]]);
+      if (all_live) { for (const Confusable& c : confusables) any = any || may_match(c, in, ins, cand, cc.cs[ids[k]]); }
+      else for (size_t j = 0; j < nlive && !any; ++j) any = may_match(*live[j], in, ins, cand, cc.cs[ids[k]]);
       if (any) {  // else no pattern can be in the script: not computed
         const Diffs script = edit_script(in, cand);
         for (const Confusable& c : confusables)

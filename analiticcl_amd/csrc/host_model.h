@@ -134,6 +134,10 @@ struct Confusable {  // src/confusables.rs:5-11; one edit-script pattern with '|
   std::vector<std::vector<std::u32string>> options;
   double weight = 1.0;
   bool strictbegin = false, strictend = false;
+  // per instruction, for the screen that decides whether an edit script is worth computing (confusables.cpp may_match): the
+  // options as ASCII presence bits when every option is one ASCII character (`simple`)
+  struct Screen { uint64_t bits[2] = {0, 0}; bool simple = false; };
+  std::vector<Screen> screen;
 };
 std::string edit_script_string(const std::string& source, const std::string& target);  // sesdiff notation, for tests
 
@@ -183,7 +187,8 @@ class HostModel {
   double confusable_weight(const std::string& input, uint64_t candidate) const;
   // the same for the n ranked rows of one input (ids[k] -> out[k]): the input is decoded once, the vocabulary texts come from a
   // decoded copy built on first use
-  void confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const;
+  void confusable_weights(const char* input, size_t len, const uint64_t* ids, size_t n, double* out) const;
+  void confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const { confusable_weights(input.data(), input.size(), ids, n, out); }
   struct ConfCache;                                   // UTF-32 texts + character sets of the vocabulary (confusables.cpp)
   mutable std::atomic<const ConfCache*> conf_cache{nullptr};      // current copy (readers take no lock and no reference count)
   mutable std::vector<std::shared_ptr<ConfCache>> conf_cache_owned;  // every copy ever published, released with the model
