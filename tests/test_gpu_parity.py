@@ -533,3 +533,47 @@ def test_async_runs_on_two_streams_equal_synchronous_runs(eng):
         for x, y in zip(got, r):
             assert np.array_equal(x, y)
         b.free()
+
+
+def test_host_threads_share_one_model(eng):
+    """Four host threads, each encoding (packed entry point: device-side offsets + encoder on the null stream), running (own HIP
+    stream) and fetching its own batches of different shapes on ONE model, several times over: every result equals the one the
+    same batch gives alone.  (The device pool, the pinned result cache and the per-thread error state are what is shared.)"""
+    import threading
+
+    import numpy as np
+    import torch
+    g, _o = eng
+    words = synth.load_lexicon_words(os.path.join(synth.GOLDEN_DATA, "eng_aspell.lexicon.gz"))
+    shapes = [(30000, 16, 3, 2, 11), (45000, 24, 3, 3, 12), (20000, 12, 2, 1, 13), (60000, 16, 4, 2, 14)]
+    jobs = []
+    for n, maxlen, k, d, seed in shapes:
+        qs = synth.make_queries(words, n, max_len=maxlen, seed=seed)
+        p = A.SearchParameters(max_anagram_distance=k, max_edit_distance=d, max_matches=10)
+        b = g.encode_batch(qs, p)
+        b.run()
+        ref = b.fetch_arrays()
+        b.free()
+        jobs.append((("\0".join(qs) + "\0").encode(), n, p, ref))
+    errors = []
+
+    def worker(job):
+        packed, n, p, ref = job
+        try:
+            st = torch.cuda.Stream()
+            for _ in range(4):
+                b = g.encode_packed(packed, n, p)
+                b.run(st.cuda_stream)
+                got = b.fetch_arrays()
+                for x, y in zip(got, ref):
+                    assert np.array_equal(x, y)
+                del got
+                b.free()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
