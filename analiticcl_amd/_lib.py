@@ -119,6 +119,12 @@ def lib():
         "anx_model_num_lexicons": (u64, [vp]),
         "anx_model_lexicon_name": (cp, [vp, u64]),
         "anx_model_to_device": (C.c_int, [vp, C.c_int]),
+        "anx_model_to_devices": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int]),
+        "anx_model_num_replicas": (C.c_int, [vp]),
+        "anx_model_replica_device": (C.c_int, [vp, C.c_int]),
+        "anx_debug_set_switch": (C.c_int, [cp, cp]),
+        "anx_batch_num_shards": (C.c_int, [vp]),
+        "anx_batch_shard_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(sz), C.POINTER(sz)]),
         "anx_model_has": (C.c_int, [vp, cp]),
         "anx_model_vocab_size": (u64, [vp]),
         "anx_model_vocab_text": (cp, [vp, u64]),
@@ -174,6 +180,12 @@ def lib():
 
 
 EXPORTED = None
+
+
+def set_switch(name: str, value) -> None:
+    """anx_debug_set_switch: the A/B and test switches are read from the environment once, when the library is first used;
+    this changes one afterwards (value None = unset).  Tests use it instead of os.environ."""
+    check(lib().anx_debug_set_switch(name.encode(), None if value is None else str(value).encode()))
 
 
 def check(rc: int):

@@ -5,8 +5,11 @@ Same option names and defaults (note the CLI's own weight defaults 0.5/0.125/0.1
 k=3 d=2 n=10, bin:800-817), same TSV / JSON output (bin:21-187).  `query` reads one input per line and runs every
 `--batch-size` lines as ONE device batch (the reference: 1000-line rayon batches, bin:416-448); `search` groups lines
 into texts like bin:561-636 and decodes them with find_all_matches.  Not mirrored: learn / index modes,
---interactive buffering semantics (output is flushed per batch), --progress.  `--unicode-offsets` is accepted and,
-as in the reference (the flag is looked up under the wrong name, bin:1175), has no effect."""
+--interactive buffering semantics (output is flushed per batch).  `--progress` prints the reference's "@ N - processing speed
+was R items per second" lines to stderr after every batch (bin:638-654).  `--unicode-offsets` is accepted and, as in the reference
+(the flag is looked up under the wrong name, bin:1175), has no effect; `--allow-overlap`, `--lm-order` and `--weight-context` are
+accepted and ignored: the reference parses them into SearchParameters fields whose consumers are commented out or absent
+(src/lib.rs:1905-1907).  `--debug` / `-D` may stand before or after the mode."""
 import argparse
 import sys
 from decimal import Decimal
@@ -119,12 +122,38 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", type=int, default=None)
     p.add_argument("--single-thread", "-1", action="store_true", help="accepted for compatibility, no effect")
     p.add_argument("--interactive", "-x", action="store_true", help="one device batch per input line")
+    p.add_argument("--progress", action="store_true", help="Show progress (items per second on stderr after every batch)")
+    p.add_argument("--debug", "-D", type=int, default=0, help="debug level 0-4 (passed to the model)")
+    p.add_argument("--allow-overlap", action="store_true", help="accepted for compatibility, no effect (as in the reference)")
+    p.add_argument("--lm-order", "-L", type=int, default=3, help="accepted for compatibility: the LM is a bigram model (src/lib.rs:2580-2674)")
+    p.add_argument("--weight-context", type=float, default=0.0, help="accepted for compatibility, no effect (as in the reference)")
+    p.add_argument("--devices", default=None, help="comma-separated HIP device ordinals: one replica of the lexicon per device, batches are "
+                                                    "sharded over them inside this process (the reference's rayon fan-out, bin:445-448)")
     return p
+
+
+class Progress:
+    """show_progress (bin:638-654)"""
+
+    def __init__(self, enabled: bool):
+        import time
+        self.enabled, self.last, self.clock = enabled, time.time(), time.time
+
+    def show(self, seqnr: int, batchsize: int) -> None:
+        if not self.enabled:
+            return
+        now = self.clock()
+        elapsed_ms = int((now - self.last) * 1000)
+        if now <= self.last or seqnr <= 1 or elapsed_ms <= 0:
+            sys.stderr.write(f"@ {seqnr}\n")
+        else:
+            sys.stderr.write(f"@ {seqnr} - processing speed was {batchsize / (elapsed_ms / 1000.0):.0f} items per second\n")
+        self.last = now
 
 
 def _index_tag(a) -> str:
     """What --index-cache binds the image to: every resource file that enters build() (kind, path, size, SHA-256 of the content),
-    in the order given."""
+    in the order given.  (The vocabulary parameters are the CLI's fixed defaults per kind, so they are not part of the tag.)"""
     import hashlib
     import json
     import os
@@ -136,17 +165,19 @@ def _index_tag(a) -> str:
                 for chunk in iter(lambda: fh.read(1 << 20), b""):
                     h.update(chunk)
             items.append([kind, os.path.abspath(f), os.path.getsize(f), h.hexdigest()])
-    return json.dumps({"resources": items, "argv_order": [t for t in sys.argv if t in ("--lexicon", "-l", "--variants", "-V", "--errors", "-E")]},
-                      sort_keys=True)
+    flags = ("--lexicon", "-l", "--variants", "-V", "--errors", "-E")
+    order = [t.split("=", 1)[0] for t in sys.argv if t in flags or any(t.startswith(f + "=") for f in flags if f.startswith("--"))]
+    return json.dumps({"resources": items, "argv_order": order}, sort_keys=True)
 
 
 def make_model(a) -> VariantModel:
     weights = Weights(ld=a.weight_ld, lcs=a.weight_lcs, prefix=a.weight_prefix, suffix=a.weight_suffix, case=a.weight_case)
-    model = VariantModel(a.alphabet, weights, device=a.device)
+    devices = [int(x) for x in a.devices.split(",")] if a.devices else None
+    model = VariantModel(a.alphabet, weights, debug=a.debug, device=a.device, devices=devices)
     import os
-    # The image is bound to what it was built from: alphabet (checked by the library), the resource files in command-line
-    # order with their sizes and content hashes, and the vocabulary parameters -- an edited lexicon, another variant list or LM
-    # makes the tag differ and the model is rebuilt (the reference rebuilds on every start, so it can never be stale)
+    # The image is bound to what it was built from: alphabet (checked by the library) and the resource files in command-line
+    # order with their sizes and content hashes -- an edited lexicon, another variant list or LM makes the tag differ and the
+    # model is rebuilt (the reference rebuilds on every start, so it can never be stale)
     tag = _index_tag(a) if a.index_cache else None
     if a.index_cache and os.path.exists(a.index_cache) and VariantModel.index_tag_of(a.index_cache) == tag:
         try:
@@ -155,7 +186,7 @@ def make_model(a) -> VariantModel:
         except Exception as e:  # noqa: BLE001 -- another layout (e.g. signature groups), another alphabet, a damaged file: rebuild
             sys.stderr.write(f"[analiticcl_amd] {a.index_cache}: {e}; rebuilding the index\n")
             loaded = False
-            model = VariantModel(a.alphabet, weights, device=a.device)
+            model = VariantModel(a.alphabet, weights, debug=a.debug, device=a.device, devices=devices)
         if loaded:
             for filename in a.confusables:
                 model.read_confusablelist(filename)
@@ -220,6 +251,7 @@ def _lines(files):
 def run_query(model, params, a, out) -> None:
     seqnr = 0
     batch: List[str] = []
+    progress = Progress(a.progress)
 
     def flush():
         nonlocal seqnr
@@ -229,6 +261,7 @@ def run_query(model, params, a, out) -> None:
         out.write(model.query_output(batch, params, a.json, a.output_lexmatch, seqnr + 1))
         seqnr += len(batch)
         out.flush()
+        progress.show(seqnr, len(batch))  # bin:477-479
         batch.clear()
 
     limit = 1 if a.interactive else max(1, a.batch_size)
@@ -242,6 +275,7 @@ def run_query(model, params, a, out) -> None:
 def run_search(model, params, a, out) -> None:
     """process_search (bin:561-636): consecutive lines form one text up to an empty line (or one text per line)."""
     seqnr = 0
+    progress = Progress(a.progress)
     MAX_BATCHSIZE_SEARCH = 100  # bin:17
     lines = _lines(a.files)
     eof = False
@@ -267,6 +301,7 @@ def run_search(model, params, a, out) -> None:
         out.write(text_out)
         seqnr += nmatches
         out.flush()
+        progress.show(seqnr, nmatches)  # bin:631-634
 
 
 def main(argv=None) -> int:

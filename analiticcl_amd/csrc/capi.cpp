@@ -8,18 +8,73 @@
 
 #include "engine.h"
 #include <algorithm>
-#include <thread>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "host_model.h"
 
+// One replica of the lexicon = one device-resident copy + the stream and the host thread that drive it.  A model built with
+// anx_model_to_devices holds several (normally one per GPU of the node): the reference's fan-out over inputs
+// (src/bin/analiticcl.rs:445-448, src/lib.rs:1883) becomes contiguous input ranges, one per replica, run concurrently.
+namespace {
+struct Worker {  // a persistent host thread per replica: every HIP call of a shard is made from its replica's thread
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
+  Worker() {
+    th = std::thread([this]() {
+      for (;;) {
+        std::function<void()> f;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [this]() { return stop || !q.empty(); });
+          if (q.empty()) return;  // stop requested and nothing left
+          f = std::move(q.front());
+          q.pop_front();
+        }
+        f();
+      }
+    });
+  }
+  ~Worker() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+  void post(std::function<void()> f) {
+    { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(f)); }
+    cv.notify_one();
+  }
+};
+struct Replica {
+  anx::DeviceLexicon* dev = nullptr;
+  int device = -1;
+  void* stream = nullptr;              // non-blocking stream of the replica (multi-replica batches run on it)
+  std::unique_ptr<Worker> worker;      // only with more than one replica
+};
+struct Shard {  // the part of a batch one replica holds: inputs [lo, lo + n) of the call
+  int replica = 0;
+  anx::Batch* b = nullptr;
+  size_t lo = 0, n = 0;
+};
+}  // namespace
+
 struct anx_model {
   anx::HostModel host;
-  anx::DeviceLexicon* dev = nullptr;
+  anx::DeviceLexicon* dev = nullptr;   // == replicas[0].dev
+  std::vector<Replica> replicas;
 };
 struct anx_batch {
   const anx_model* model = nullptr;
-  anx::Batch* b = nullptr;
+  std::vector<Shard> shards;      // one per replica that got inputs, consecutive input ranges in input order (never empty)
+  size_t n_input = 0;
   // confusables loaded: the device ranks without the cutoff (late) or without crop and cutoff (early); the host
   // rescoring in anx_batch_fetch needs the caller's parameters and the input texts
   bool rescore = false;
@@ -174,9 +229,18 @@ anx_model* anx_model_new(const char* path, const anx_weights* weights, int debug
   ss << f.rdbuf();
   return anx_model_new_with_alphabet(ss.str().c_str(), weights, debug);
 }
+static void drop_replicas(anx_model* m) {
+  for (Replica& r : m->replicas) {
+    r.worker.reset();  // joins the replica's thread (its queue is empty: every call waits for its shards)
+    anx::stream_destroy(r.device, r.stream);
+    anx::lexicon_free(r.dev);
+  }
+  m->replicas.clear();
+  m->dev = nullptr;
+}
 void anx_model_free(anx_model* m) {
   if (!m) return;
-  anx::lexicon_free(m->dev);
+  drop_replicas(m);
   delete m;
 }
 int anx_model_read_vocabulary(anx_model* m, const char* path, const anx_vocab_params* p) {
@@ -214,24 +278,38 @@ int anx_model_read_variants(anx_model* m, const char* path, const anx_vocab_para
   int rc = m->host.read_variants(path, vp, transparent != 0, err);
   return rc ? fail(rc, err) : ANX_OK;
 }
-int anx_model_to_device(anx_model* m, int device) {
-  if (!m) return fail(ANX_EINVAL, "NULL model");
+int anx_model_to_devices(anx_model* m, const int* devices, int n) {
+  if (!m || (!devices && n > 0)) return fail(ANX_EINVAL, "NULL argument");
+  if (n < 1 || n > 64) return fail(ANX_EINVAL, "1..64 replicas");
   if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() first");
-  anx::lexicon_free(m->dev);
-  m->dev = nullptr;
+  drop_replicas(m);
   std::string err;
   anx::EncodeTables et;
   anx::build_encode_tables(m->host.alphabet, et);
-  m->dev = anx::lexicon_upload(m->host.lex, et, device, err);
-  return m->dev ? ANX_OK : fail(ANX_ENODEVICE, err);
+  for (int i = 0; i < n; ++i) {
+    Replica r;
+    r.device = devices[i];
+    r.dev = anx::lexicon_upload(m->host.lex, et, devices[i], err);
+    if (r.dev && n > 1 && !(r.stream = anx::stream_create(devices[i], err))) { anx::lexicon_free(r.dev); r.dev = nullptr; }
+    if (!r.dev) { drop_replicas(m); return fail(ANX_ENODEVICE, err); }
+    if (n > 1) r.worker.reset(new Worker());
+    m->replicas.push_back(std::move(r));
+  }
+  m->dev = m->replicas[0].dev;
+  return ANX_OK;
+}
+int anx_model_to_device(anx_model* m, int device) { return anx_model_to_devices(m, &device, 1); }
+int anx_model_num_replicas(const anx_model* m) { return m ? (int)m->replicas.size() : 0; }
+int anx_model_replica_device(const anx_model* m, int i) { return (m && i >= 0 && (size_t)i < m->replicas.size()) ? m->replicas[(size_t)i].device : -1; }
+int anx_debug_set_switch(const char* name, const char* value) {
+  return anx::set_switch(name, value) ? ANX_OK : fail(ANX_EINVAL, "unknown switch");
 }
 int anx_model_build(anx_model* m, int device) {
   if (!m) return fail(ANX_EINVAL, "NULL model");
   std::string err;
   int rc = m->host.build_index(err);
   if (rc) return fail(rc, err);
-  anx::lexicon_free(m->dev);
-  m->dev = nullptr;
+  drop_replicas(m);
   if (device < 0) return ANX_OK;
   return anx_model_to_device(m, device);
 }
@@ -261,8 +339,7 @@ int anx_model_load_index(anx_model* m, const char* path, int device) {
   std::string err;
   const int rc = m->host.load_index(path, err);
   if (rc) return fail(rc, err);
-  anx::lexicon_free(m->dev);
-  m->dev = nullptr;
+  drop_replicas(m);
   if (device < 0) return ANX_OK;
   return anx_model_to_device(m, device);
 }
@@ -510,6 +587,73 @@ int anx_edit_script(const char* source, const char* target, char* out, int cap) 
   return (int)s.size();
 }
 
+// ---- shards ------------------------------------------------------------------------------------------------------
+// Runs fn(shard index) for every shard of a batch: inline for one shard, else on the replicas' threads, all at once.  Returns the
+// first failure (code + message of the lowest failing shard).
+namespace {
+struct ShardErr { int code = ANX_OK; std::string msg; };
+int on_replicas(const anx_model* m, const std::vector<int>& replicas, const std::function<int(size_t, std::string&)>& fn) {
+  const size_t ns = replicas.size();
+  std::vector<ShardErr> res(ns);
+  if (ns == 1 && !m->replicas[(size_t)replicas[0]].worker) {
+    res[0].code = fn(0, res[0].msg);
+  } else {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t pending = ns;
+    for (size_t i = 0; i < ns; ++i)
+      m->replicas[(size_t)replicas[i]].worker->post([&, i]() {
+        res[i].code = fn(i, res[i].msg);
+        std::lock_guard<std::mutex> g(mu);
+        if (--pending == 0) cv.notify_one();
+      });
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&]() { return pending == 0; });
+  }
+  for (size_t i = 0; i < ns; ++i)
+    if (res[i].code != ANX_OK) return fail(res[i].code, ns > 1 ? "replica " + std::to_string(replicas[i]) + ": " + res[i].msg : res[i].msg);
+  return ANX_OK;
+}
+int on_shards(const anx_batch* b, const std::function<int(size_t, std::string&)>& fn) {
+  std::vector<int> reps(b->shards.size());
+  for (size_t i = 0; i < reps.size(); ++i) reps[i] = b->shards[i].replica;
+  return on_replicas(b->model, reps, fn);
+}
+// replicas a call of n inputs is spread over: all of them when every one gets at least ANX_SHARD_MIN inputs
+size_t shards_for(const anx_model* m, size_t n) {
+  const size_t R = m->replicas.size();
+  if (R <= 1) return 1;
+  const size_t smin = (size_t)std::max<long>(1, anx::switches().shard_min);
+  return std::max<size_t>(1, std::min(R, n / smin));
+}
+void free_shards(anx_batch* h) {
+  for (Shard& s : h->shards) anx::batch_free(s.b);
+  h->shards.clear();
+}
+// the stream a shard runs on: the caller's for a single-replica model, the replica's own otherwise
+void* shard_stream(const anx_batch* b, const Shard& s, void* caller) {
+  const Replica& r = b->model->replicas[(size_t)s.replica];
+  return r.stream ? r.stream : caller;
+}
+int check_batch(const anx_model* m, const anx_batch* b, void* stream) {
+  if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");
+  if (stream && m->replicas.size() > 1) return fail(ANX_EINVAL, "a multi-device model runs every replica on its own stream: pass NULL");
+  return ANX_OK;
+}
+// zero bytes of [p, p + len): 8 bytes per step (exact SWAR test)
+size_t count_nul(const char* p, size_t len) {
+  size_t c = 0, i = 0;
+  for (; i + 8 <= len; i += 8) {
+    uint64_t v;
+    memcpy(&v, p + i, 8);
+    const uint64_t t = ~(((v & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | v | 0x7F7F7F7F7F7F7F7Full);  // 0x80 in every zero byte
+    c += (size_t)__builtin_popcountll(t);
+  }
+  for (; i < len; ++i) c += p[i] == 0;
+  return c;
+}
+}  // namespace
+
 // device parameters of a batch: with confusables the cutoff (and in early mode the crop) follows the host-side rescoring
 static anx_params device_params(const anx_model* m, const anx_params* p, bool* rescore) {
   anx_params dp = *p;
@@ -520,20 +664,34 @@ static anx_params device_params(const anx_model* m, const anx_params* p, bool* r
   }
   return dp;
 }
+static int check_encode_args(const anx_model* m, const void* inputs, size_t n, const anx_params* p) {
+  if (!m || (!inputs && n) || !p) return fail(ANX_EINVAL, "NULL argument");
+  if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_variants()");
+  return ANX_OK;
+}
+static int check_resident(const anx_model* m) {  // there is no CPU fallback
+  if (m->replicas.empty()) return fail(ANX_ENODEVICE, "model is not resident on a device (no HIP device / anx_model_to_device not called)");
+  return ANX_OK;
+}
 anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p) {
-  if (!m || (!utf8 && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
-  if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_variants()"); return nullptr; }
-  std::string err;
-  int code = ANX_OK;
+  if (check_encode_args(m, utf8, n, p) || check_resident(m)) return nullptr;
   bool rescore;
   const anx_params dp = device_params(m, p, &rescore);
-  anx::Batch* b = anx::batch_encode(m->host, m->dev, utf8, n, dp, err, &code);
-  if (!b) { fail(code ? code : ANX_ENODEVICE, err); return nullptr; }
   anx_batch* h = new anx_batch();
   h->model = m;
-  h->b = b;
+  h->n_input = n;
   h->rescore = rescore;
   h->params = *p;
+  const size_t S = shards_for(m, n);
+  h->shards.resize(S);
+  for (size_t g = 0; g < S; ++g) { h->shards[g].replica = (int)g; h->shards[g].lo = n * g / S; h->shards[g].n = n * (g + 1) / S - n * g / S; }
+  const int rc = on_shards(h, [&](size_t g, std::string& err) {
+    Shard& s = h->shards[g];
+    int code = ANX_OK;
+    s.b = anx::batch_encode(m->host, m->replicas[(size_t)s.replica].dev, utf8 + s.lo, s.n, dp, err, &code);
+    return s.b ? ANX_OK : (code ? code : ANX_ENODEVICE);
+  });
+  if (rc) { free_shards(h); delete h; return nullptr; }
   if (rescore) {
     h->in_off.reserve(n + 1);
     h->in_off.push_back(0);
@@ -546,95 +704,215 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
   return h;
 }
 anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t blob_len, size_t n, const anx_params* p) {
-  if (!m || (!blob && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
-  if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_variants()"); return nullptr; }
+  if (check_encode_args(m, blob, n, p)) return nullptr;
   if (n && (blob_len == 0 || blob[blob_len - 1] != '\0')) { fail(ANX_EINVAL, "packed inputs must end with a NUL byte"); return nullptr; }
   if (blob_len >= ((size_t)1 << 32)) { fail(ANX_ELIMIT, "inputs exceed 4 GB per batch: split the batch"); return nullptr; }
   // the buffer goes to the device as it is; the device-side encoder finds the strings' offsets there (the host only needs
   // them when confusables are loaded: rescoring reads the input strings)
-  std::string err;
-  int code = ANX_OK;
   bool rescore;
   const anx_params dp = device_params(m, p, &rescore);
   std::vector<uint32_t> off;
   if (rescore && !anx::packed_offsets(blob, blob_len, n, off)) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); return nullptr; }
-  anx::Batch* b = anx::batch_encode_spans(m->host, m->dev, blob, blob_len, rescore ? off.data() : nullptr, n, dp, err, &code);
-  if (!b) { fail(code ? code : ANX_ENODEVICE, err); return nullptr; }
+  if (check_resident(m)) return nullptr;
   anx_batch* h = new anx_batch();
   h->model = m;
-  h->b = b;
+  h->n_input = n;
   h->rescore = rescore;
   h->params = *p;
+  const size_t S = shards_for(m, n);
+  h->shards.resize(S);
+  for (size_t g = 0; g < S; ++g) h->shards[g].replica = (int)g;
+  // Byte-balanced split: shard g takes the strings that START in bytes [pos[g], pos[g + 1]), where pos[g] is the first string
+  // start at or behind blob_len * g / S.  Each replica's thread counts the strings of its own slice (phase 1); the prefix sums give
+  // every shard its first input index, and the call's n cuts the tail ("the first n NUL-terminated spans").
+  std::vector<size_t> pos(S + 1, blob_len), cnt(S, 0);
+  pos[0] = 0;
+  if (S > 1) {
+    for (size_t g = 1; g < S; ++g) {
+      size_t t = blob_len * g / S;
+      if (t > 0 && blob[t - 1] != '\0') {
+        const void* z = memchr(blob + t, 0, blob_len - t);
+        t = z ? (size_t)(static_cast<const char*>(z) - blob) + 1 : blob_len;
+      }
+      pos[g] = std::max(t, pos[g - 1]);
+    }
+    int rc1 = on_shards(h, [&](size_t g, std::string&) { cnt[g] = count_nul(blob + pos[g], pos[g + 1] - pos[g]); return ANX_OK; });
+    (void)rc1;
+    size_t run = 0;
+    for (size_t g = 0; g < S; ++g) {
+      h->shards[g].lo = std::min(run, n);
+      h->shards[g].n = std::min(cnt[g], n - h->shards[g].lo);
+      run += cnt[g];
+    }
+    if (run < n) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); delete h; return nullptr; }
+  } else {
+    h->shards[0].lo = 0;
+    h->shards[0].n = n;
+  }
+  const int rc = on_shards(h, [&](size_t g, std::string& err) {
+    Shard& s = h->shards[g];
+    int code = ANX_OK;
+    const uint32_t* o = rescore ? off.data() + s.lo : nullptr;  // offsets relative to the whole buffer: rebased below
+    std::vector<uint32_t> rel;
+    const char* base = blob + pos[g];
+    size_t bytes = pos[g + 1] - pos[g];
+    if (o) {
+      rel.resize(s.n + 1);
+      for (size_t i = 0; i <= s.n; ++i) rel[i] = o[i] - o[0];
+      base = blob + o[0];
+      bytes = rel[s.n];
+      o = rel.data();
+    }
+    s.b = anx::batch_encode_spans(m->host, m->replicas[(size_t)s.replica].dev, base, bytes, o, s.n, dp, err, &code);
+    return s.b ? ANX_OK : (code ? code : ANX_ENODEVICE);
+  });
+  if (rc) { free_shards(h); delete h; return nullptr; }
   if (rescore) {
     h->in_text.assign(blob, off[n]);  // the first n strings with their NUL bytes
     h->in_off = std::move(off);
   }
   return h;
 }
-int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
-  if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");
-  std::string err;
-  int rc = anx::batch_run(m->host, m->dev, b->b, stream, err);
-  return rc ? fail(rc, err) : ANX_OK;
-}
 int anx_batch_run_async(const anx_model* m, anx_batch* b, void* stream) {
-  if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");
-  std::string err;
-  int rc = anx::batch_run_async(m->host, m->dev, b->b, stream, err);
-  return rc ? fail(rc, err) : ANX_OK;
+  if (int rc = check_batch(m, b, stream)) return rc;
+  return on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    return anx::batch_run_async(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
+  });
 }
 int anx_batch_wait(const anx_model* m, anx_batch* b) {
-  if (!m || !b || b->model != m) return fail(ANX_EINVAL, "batch does not belong to this model");
-  std::string err;
-  int rc = anx::batch_wait(m->host, m->dev, b->b, err);
-  return rc ? fail(rc, err) : ANX_OK;
+  if (int rc = check_batch(m, b, nullptr)) return rc;
+  return on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    return anx::batch_wait(m->host, m->replicas[(size_t)s.replica].dev, s.b, err);
+  });
+}
+int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
+  if (int rc = check_batch(m, b, stream)) return rc;
+  return on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    return anx::batch_run(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
+  });
 }
 int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   if (!b || !rows || !offs) return fail(ANX_EINVAL, "NULL argument");
-  std::string err;
-  int rc = anx::batch_fetch(b->model->host, b->model->dev, b->b, rows, offs, err);
-  if (rc) return fail(rc, err);
-  if (b->rescore) rescore_with_confusables(b->model->host, b->in_text, b->in_off, b->params, *rows, *offs);
+  // one row array for the whole call; every shard downloads straight into its slice (the sizes are known since the run)
+  const size_t n = b->n_input, S = b->shards.size();
+  std::vector<size_t> base(S + 1, 0);
+  for (size_t g = 0; g < S; ++g) base[g + 1] = base[g] + anx::batch_n_results(b->shards[g].b);
+  size_t* off = static_cast<size_t*>(malloc((n + 1) * sizeof(size_t)));
+  anx_result* out = static_cast<anx_result*>(anx::host_result_alloc(std::max<size_t>(1, base[S]) * sizeof(anx_result)));
+  if (!off || !out) { free(off); anx::host_result_free(out); return fail(ANX_EINVAL, "out of memory"); }
+  const int rc = on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    std::vector<size_t> tmp;  // a shard writes n + 1 offsets; its last one is the next shard's first (same value): keep the slices disjoint
+    size_t* dst = off + s.lo;
+    if (g + 1 < S) { tmp.resize(s.n + 1); dst = tmp.data(); }
+    const int r = anx::batch_fetch_into(s.b, out + base[g], dst, base[g], err);
+    if (r == ANX_OK && g + 1 < S && s.n) memcpy(off + s.lo, tmp.data(), s.n * sizeof(size_t));
+    return r;
+  });
+  if (rc) { free(off); anx::host_result_free(out); return rc; }
+  off[n] = base[S];
+  if (b->rescore) rescore_with_confusables(b->model->host, b->in_text, b->in_off, b->params, out, off);
+  *rows = out;
+  *offs = off;
   return ANX_OK;
 }
 int anx_batch_fetch_pairs(const anx_batch* b, anx_pair** out, size_t* n) {
   if (!b || !out || !n) return fail(ANX_EINVAL, "NULL argument");
-  std::string err;
-  int rc = anx::batch_fetch_pairs(b->model->host, b->model->dev, b->b, out, n, err);
-  return rc ? fail(rc, err) : ANX_OK;
+  const size_t S = b->shards.size();
+  std::vector<anx_pair*> part(S, nullptr);
+  std::vector<size_t> cnt(S, 0);
+  const int rc = on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    return anx::batch_fetch_pairs(b->model->host, b->model->replicas[(size_t)s.replica].dev, s.b, &part[g], &cnt[g], err);
+  });
+  if (rc) { for (anx_pair* p : part) free(p); return rc; }
+  if (S == 1) { *out = part[0]; *n = cnt[0]; return ANX_OK; }
+  size_t total = 0;
+  for (size_t c : cnt) total += c;
+  anx_pair* all = static_cast<anx_pair*>(malloc(std::max<size_t>(1, total) * sizeof(anx_pair)));
+  if (!all) { for (anx_pair* p : part) free(p); return fail(ANX_EINVAL, "out of memory"); }
+  size_t w = 0;
+  for (size_t g = 0; g < S; ++g) {
+    for (size_t i = 0; i < cnt[g]; ++i) { all[w] = part[g][i]; all[w].query += (uint32_t)b->shards[g].lo; ++w; }
+    free(part[g]);
+  }
+  *out = all;
+  *n = total;
+  return ANX_OK;
 }
 void anx_pairs_free(anx_pair* p) { free(p); }
 int anx_batch_pair_counts(anx_batch* b, uint32_t** out) {
   if (!b || !out) return fail(ANX_EINVAL, "NULL argument");
-  std::string err;
-  int rc = anx::batch_pair_counts(b->model->host, b->model->dev, b->b, out, err);
-  return rc ? fail(rc, err) : ANX_OK;
+  const size_t S = b->shards.size();
+  std::vector<uint32_t*> part(S, nullptr);
+  const int rc = on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    return anx::batch_pair_counts(b->model->host, b->model->replicas[(size_t)s.replica].dev, s.b, &part[g], err);
+  });
+  if (rc) { for (uint32_t* p : part) free(p); return rc; }
+  if (S == 1) { *out = part[0]; return ANX_OK; }
+  uint32_t* all = static_cast<uint32_t*>(calloc(std::max<size_t>(1, b->n_input), sizeof(uint32_t)));
+  if (!all) { for (uint32_t* p : part) free(p); return fail(ANX_EINVAL, "out of memory"); }
+  for (size_t g = 0; g < S; ++g) {
+    if (b->shards[g].n) memcpy(all + b->shards[g].lo, part[g], b->shards[g].n * sizeof(uint32_t));
+    free(part[g]);
+  }
+  *out = all;
+  return ANX_OK;
 }
 void anx_counts_free(uint32_t* p) { free(p); }
-int anx_batch_export_topk(const anx_batch* b, void* dst, uint32_t stride, void* stream) {
+static int check_export(const anx_batch* b) {
   if (!b) return fail(ANX_EINVAL, "NULL batch");
   if (b->rescore) return fail(ANX_EINVAL, "confusables are loaded: results are rescored on the host, use anx_batch_fetch");
+  if (b->shards.size() != 1) return fail(ANX_EINVAL, "the batch is spread over several replicas: export one shard at a time (anx_batch_shard_*)");
+  return ANX_OK;
+}
+int anx_batch_export_topk(const anx_batch* b, void* dst, uint32_t stride, void* stream) {
+  if (int rc = check_export(b)) return rc;
   std::string err;
-  int rc = anx::batch_export_topk(b->model->dev, b->b, dst, stride, stream, err);
+  int rc = anx::batch_export_topk(b->model->replicas[(size_t)b->shards[0].replica].dev, b->shards[0].b, dst, stride, stream, err);
   return rc ? fail(rc, err) : ANX_OK;
 }
 int anx_batch_export_compact(const anx_batch* b, void* dst, size_t capacity, void* stream, size_t* used) {
-  if (!b || !used) return fail(ANX_EINVAL, "NULL argument");
-  if (b->rescore) return fail(ANX_EINVAL, "confusables are loaded: results are rescored on the host, use anx_batch_fetch");
+  if (!used) return fail(ANX_EINVAL, "NULL argument");
+  if (int rc = check_export(b)) return rc;
   std::string err;
-  int rc = anx::batch_export_compact(b->model->dev, b->b, dst, capacity, stream, used, err);
+  int rc = anx::batch_export_compact(b->model->replicas[(size_t)b->shards[0].replica].dev, b->shards[0].b, dst, capacity, stream, used, err);
   return rc ? fail(rc, err) : ANX_OK;
+}
+int anx_batch_num_shards(const anx_batch* b) { return b ? (int)b->shards.size() : 0; }
+int anx_batch_shard_info(const anx_batch* b, int shard, int* device, size_t* first_input, size_t* n_inputs) {
+  if (!b || shard < 0 || (size_t)shard >= b->shards.size()) return fail(ANX_EINVAL, "no such shard");
+  const Shard& s = b->shards[(size_t)shard];
+  if (device) *device = b->model->replicas[(size_t)s.replica].device;
+  if (first_input) *first_input = s.lo;
+  if (n_inputs) *n_inputs = s.n;
+  return ANX_OK;
 }
 int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* s) {
   if (!b || !s) return fail(ANX_EINVAL, "NULL argument");
-  anx::batch_stats(b->b, s);
+  anx::batch_stats(b->shards[0].b, s);
+  for (size_t g = 1; g < b->shards.size(); ++g) {  // counts add up, times are those of the slowest replica
+    anx_batch_stats t;
+    anx::batch_stats(b->shards[g].b, &t);
+    s->n_queries += t.n_queries; s->n_pairs += t.n_pairs; s->n_class_tests += t.n_class_tests; s->n_results += t.n_results;
+    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected;
+    for (int i = 0; i < 5; ++i) s->n_tests_kind[i] += t.n_tests_kind[i];
+    s->ms_scan = std::max(s->ms_scan, t.ms_scan); s->ms_group = std::max(s->ms_group, t.ms_group); s->ms_score = std::max(s->ms_score, t.ms_score);
+    s->ms_rank = std::max(s->ms_rank, t.ms_rank); s->ms_total = std::max(s->ms_total, t.ms_total);
+    s->ms_scan_kernel = std::max(s->ms_scan_kernel, t.ms_scan_kernel); s->ms_filter_score_kernel = std::max(s->ms_filter_score_kernel, t.ms_filter_score_kernel);
+  }
   return ANX_OK;
 }
 void anx_device_pool_trim(int device) { anx::device_pool_trim(device); }
 
 void anx_batch_free(anx_batch* b) {
   if (!b) return;
-  anx::batch_free(b->b);
+  if (b->shards.size() > 1) (void)on_shards(b, [&](size_t g, std::string&) { anx::batch_free(b->shards[g].b); b->shards[g].b = nullptr; return ANX_OK; });
+  free_shards(b);
   delete b;
 }
 
@@ -642,13 +920,9 @@ int anx_find_variants_batch(const anx_model* m, const char* const* utf8, size_t 
                             anx_result** out_rows, size_t** out_offsets) {
   if (!out_rows || !out_offsets) return fail(ANX_EINVAL, "NULL output argument");
   // One device batch holds at most 2^31 pair-list slots (~10 M queries of BASELINE config 2): larger calls are run as
-  // consecutive device batches of kMaxQueriesPerBatch inputs and their CSR results concatenated.
-  size_t kMaxQueriesPerBatch = (size_t)4 << 20;
-  if (const char* e = getenv("ANX_MAX_BATCH")) {  // tests
-    const long v = atol(e);
-    if (v > 0) kMaxQueriesPerBatch = (size_t)v;
-  }
-  if (n <= kMaxQueriesPerBatch) {
+  // consecutive rounds of ANX_MAX_BATCH inputs per replica and their CSR results concatenated.
+  const size_t per_round = (size_t)anx::switches().max_batch * std::max<size_t>(1, m ? m->replicas.size() : 1);
+  if (n <= per_round) {
     anx_batch* b = anx_batch_encode(m, utf8, n, p);
     if (!b) return g_code ? g_code : ANX_EINVAL;
     int rc = anx_batch_run(m, b, nullptr);
@@ -660,8 +934,8 @@ int anx_find_variants_batch(const anx_model* m, const char* const* utf8, size_t 
   anx_result* rows = nullptr;
   size_t total = 0, cap = 0;
   if (!offs) return fail(ANX_EINVAL, "out of memory");
-  for (size_t lo = 0; lo < n; lo += kMaxQueriesPerBatch) {
-    const size_t cnt = std::min(kMaxQueriesPerBatch, n - lo);
+  for (size_t lo = 0; lo < n; lo += per_round) {
+    const size_t cnt = std::min(per_round, n - lo);
     anx_result* r = nullptr;
     size_t* o = nullptr;
     const int rc = anx_find_variants_batch(m, utf8 + lo, cnt, p, &r, &o);

@@ -374,8 +374,11 @@ __global__ __launch_bounds__(256) void k_tile_emit(TileArgs t) {
 
 // ---- host driver --------------------------------------------------------------------------------------------------------
 namespace {
-struct Scratch {  // pool blocks released together
+struct Scratch {  // pool blocks released together, and the private stream of the call
   std::vector<void*> blocks;
+  int device;
+  hipStream_t st;
+  explicit Scratch(int dev) : device(dev), st(encoder_stream_acquire(dev)) {}
   template <typename T>
   int get(T** p, size_t count, std::string& err) {
     void* q = nullptr;
@@ -384,9 +387,9 @@ struct Scratch {  // pool blocks released together
     *p = static_cast<T*>(q);
     return ANX_OK;
   }
-  // the blocks go back to the pool, where another batch may take them at once: nothing enqueued by this call (default stream)
-  // may still be using them -- the normal path has synchronised already, an error path has not
-  ~Scratch() { (void)hipStreamSynchronize(nullptr); for (void* q : blocks) pool_free(q); }
+  // the blocks go back to the pool, where another batch may take them at once: nothing enqueued by this call (on its own
+  // stream) may still be using them -- the normal path has synchronised already, an error path has not
+  ~Scratch() { (void)hipStreamSynchronize(st); for (void* q : blocks) pool_free(q); encoder_stream_release(device, st); }
 };
 template <typename K>
 int sort_pairs(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, Scratch& sc, hipStream_t st,
@@ -410,16 +413,16 @@ int balloc(T** dst, size_t count, std::string& err) {
 // off == nullptr: the n strings are the first n NUL-terminated spans of blob[0, blob_len); their offsets are found on the device.
 int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off,
                         size_t n, const anx_params& p, std::string& err) {
-  static const bool timing = getenv("ANX_ENCODE_TIMING") != nullptr;
+  const bool timing = switches().encode_timing != 0;
   double t_prev = 0.0;
   auto tnow = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
   if (timing) t_prev = tnow();
-  auto lap = [&](const char* what) { if (timing) { (void)hipDeviceSynchronize(); const double t = tnow(); fprintf(stderr, "[anx encode/device] %-24s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
+  Scratch sc(dl->device);
+  hipStream_t st = sc.st;  // private and non-blocking: encodes of other host threads and batches in flight do not serialise with this one
+  auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); const double t = tnow(); fprintf(stderr, "[anx encode/device] %-24s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
   const uint32_t n32 = (uint32_t)n;
   const size_t blob_len = !n ? 0 : off ? off[n] : blob_bytes;
   const int NP = dl->nplanes;
-  hipStream_t st = nullptr;
-  Scratch sc;
   int rc;
   if (n == 0) {  // nothing to encode: empty query arrays (the launches below do not take an empty grid)
     b->nq = 0; b->dmax = 0; b->qw = 1; b->ntiles = 0; b->n_sad_tiles = 0;
@@ -458,7 +461,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   }
   EncArgs ea;
   ea.blob = d_blob; ea.off = d_off; ea.n = n32; ea.al = dl->alpha; ea.A = m.alphabet.size(); ea.NP = NP;
-  ea.bits_ok = (dl->nsym <= 32 && !(getenv("ANX_SCAN") && strcmp(getenv("ANX_SCAN"), "sad") == 0)) ? 1 : 0;
+  ea.bits_ok = (dl->nsym <= 32 && !switches().scan_sad) ? 1 : 0;
   ea.kth = p.max_anagram_distance; ea.dth = p.max_edit_distance;
   ea.codes = d_codes; ea.meta = d_meta; ea.bits = d_bits; ea.sig = d_sig; ea.kind = d_kind; ea.cv = d_cv; ea.slen = d_slen; ea.ctr = d_ctr;
   const dim3 gn((n32 + 255) / 256);
@@ -512,7 +515,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   lap("k_enc_gather");
   // ---- tiles --------------------------------------------------------------------------------------------------------------
   TileArgs ta;
-  { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; ta.tq = v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }
+  ta.tq = switches().scan_tq ? (uint32_t)switches().scan_tq : SCAN_TQ;
   ta.nq = nq; ta.q_meta = b->q_meta; ta.s_kind = s_kind; ta.s_sig = s_sig; ta.siglen_begin = dl->alpha.siglen_begin; ta.ctr = d_ctr;
   ta.ball_tab = dl->ball_tab; ta.probe = probe_enabled() ? 1 : 0;
   uint32_t *d_head = nullptr, *d_tcount = nullptr;

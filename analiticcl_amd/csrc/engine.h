@@ -16,6 +16,9 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
 void lexicon_free(DeviceLexicon*);
 void device_pool_trim(int device);  // hands the cached scratch blocks of the device (and the pinned result buffers) back to the driver
 // result rows of batch_fetch live in cached pinned host buffers: release them with host_result_free (falls back to free())
+// a non-blocking stream on `device` for a replica of a multi-device model (hipStream_t behind void*)
+void* stream_create(int device, std::string& err);
+void stream_destroy(int device, void* stream);
 void* host_result_alloc(size_t bytes);
 void host_result_free(void* p);
 
@@ -32,6 +35,10 @@ int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void*
 int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::string& err);
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err);
+// the same into caller-provided storage: rows[0 .. batch_n_results) and offs[0 .. batch_n_input] = base + CSR offsets
+size_t batch_n_results(const Batch* b);
+size_t batch_n_input(const Batch* b);
+int batch_fetch_into(const Batch* b, anx_result* rows, size_t* offs, size_t base, std::string& err);
 int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_pair** out, size_t* n,
                       std::string& err);
 int batch_pair_counts(const HostModel& m, const DeviceLexicon* dl, Batch* b, uint32_t** out, std::string& err);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <chrono>
 #include <cmath>
@@ -67,6 +68,7 @@ struct DevPool {
   std::unordered_map<void*, size_t> size_of;       // every live or cached block of this pool
   size_t cached = 0;
   int lexicons = 0;
+  std::vector<hipStream_t> idle_streams;           // non-blocking streams of the device-side encoder, handed out per call
 };
 // bytes of freed blocks kept per device (MI355X: 288 GB HBM; a 1 M-query batch holds 3-6 GB of scratch).  ANX_POOL_CACHE_MB
 // overrides the default; anx_device_pool_trim() hands the cache back to the driver at any time.
@@ -83,6 +85,39 @@ DevPool& pool_of(int device) {
   return pools[device >= 0 && device < 64 ? device : 0];
 }
 }  // namespace
+// A private non-blocking stream for one encoder call (encode.hip): on the legacy NULL stream every encode would serialise with
+// the in-flight batches of other host threads that run on blocking streams.  Streams are kept per device and reused.
+hipStream_t encoder_stream_acquire(int device) {
+  DevPool& pl = pool_of(device);
+  {
+    std::lock_guard<std::mutex> g(pl.mu);
+    if (!pl.idle_streams.empty()) { hipStream_t s = pl.idle_streams.back(); pl.idle_streams.pop_back(); return s; }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }  // NULL stream: still correct
+  return s;
+}
+void encoder_stream_release(int device, hipStream_t s) {
+  if (!s) return;
+  DevPool& pl = pool_of(device);
+  std::lock_guard<std::mutex> g(pl.mu);
+  pl.idle_streams.push_back(s);
+}
+// streams of the replicas of a multi-device model (capi.cpp owns them; HIP stays behind this file)
+void* stream_create(int device, std::string& err) {
+  hipStream_t s = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    err = std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(hipGetLastError());
+    return nullptr;
+  }
+  return s;
+}
+void stream_destroy(int device, void* s) {
+  if (!s) return;
+  (void)hipSetDevice(device);
+  (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(s));
+}
+
 hipError_t pool_malloc(void** p, size_t bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -175,7 +210,7 @@ void* host_result_alloc(size_t bytes) {
     }
   }
   void* p = nullptr;
-  bool pinned = hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p;
+  bool pinned = hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p;  // portable: the replicas of a multi-device model download into one buffer
   if (!pinned) {
     (void)hipGetLastError();
     p = malloc(bytes);
@@ -220,7 +255,11 @@ static void host_cache_trim() {
   for (void* p : drop) (void)hipHostFree(p);
 }
 void device_pool_trim(int device) {
+  int cur = -1;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
   if (hipSetDevice(device) == hipSuccess) pool_trim(device);
+  else (void)hipGetLastError();
+  if (have_cur && cur != device) (void)hipSetDevice(cur);  // the caller's current device is not ours to change
   host_cache_trim();
 }
 
@@ -406,15 +445,12 @@ void lexicon_free(DeviceLexicon* d) {
   delete d;
 }
 
-static int scan_mode() {  // ANX_SCAN=sad forces the general count-vector kernel (A/B testing)
-  const char* e = getenv("ANX_SCAN");
-  return (e && strcmp(e, "sad") == 0) ? 1 : 0;
-}
+static int scan_mode() { return switches().scan_sad; }  // ANX_SCAN=sad forces the general count-vector kernel (A/B testing)
 
 // The threaded HOST encoder (ANX_ENCODE=host): the A/B reference of the device-side encoder in encode.hip, same arrays.
 static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* const* utf8, size_t n, const anx_params& p,
                        std::string& err) {
-  static const bool timing = getenv("ANX_ENCODE_TIMING") != nullptr;
+  const bool timing = switches().encode_timing != 0;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();
   auto lap = [&](const char* what) { if (timing) { const double t = tnow(); fprintf(stderr, "[anx encode] %-28s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
@@ -632,7 +668,7 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     // aligned to whole 64-signature blocks (the neighbours inside the edge blocks belong to charcounts outside the window)
     const uint32_t s0 = m.lex.siglen_begin[lo] & ~63u, s1 = (m.lex.siglen_begin[hi + 1] + 63u) & ~63u;
-    static const uint32_t tq = []() { const char* e = getenv("ANX_SCAN_TQ"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= (int)SCAN_TQ ? (uint32_t)v : SCAN_TQ; }();
+    const uint32_t tq = switches().scan_tq ? (uint32_t)switches().scan_tq : SCAN_TQ;
     // The count-vector (SAD) tiles are rare (queries with a symbol more than NBITPLANES times) and run as a launch of
     // their own: a handful of waves whose time is the latency of ONE wave walking the whole signature window.  Their
     // windows are therefore split over several waves (disjoint signature ranges = disjoint classes: same pairs).
@@ -733,9 +769,8 @@ Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const cha
   b->device = dl->device;
   b->params = p;
   b->n_input = n;
-  const char* mode = getenv("ANX_ENCODE");  // "host": the threaded host encoder (A/B reference); read per call
   int rc;
-  if (mode && strcmp(mode, "host") == 0) {
+  if (switches().encode_host) {  // ANX_ENCODE=host: the threaded host encoder (A/B reference)
     std::vector<uint32_t> hoff;
     if (!off) {
       if (!packed_offsets(blob, blob_bytes, n, hoff)) { err = "packed inputs hold fewer strings than announced"; *code = ANX_EINVAL; batch_free(b); return nullptr; }
@@ -769,20 +804,21 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     for (auto& x : th) x.join();
   };
   std::vector<uint32_t> lens(n);
-  bool too_big = false;
+  std::atomic<bool> too_big{false};
   run_threads([&](unsigned t, size_t lo, size_t hi) {
     size_t sum = 0;
     for (size_t i = lo; i < hi; ++i) {
       const size_t l = utf8[i] ? strlen(utf8[i]) : 0;  // a NULL input encodes like an empty one: no results
-      if (l >= (1u << 28)) too_big = true;
+      if (l >= (1u << 28)) too_big.store(true, std::memory_order_relaxed);
       lens[i] = (uint32_t)l;
       sum += l + 1;
     }
     part[t + 1] = sum;
   });
   for (unsigned t = 0; t < nthreads; ++t) part[t + 1] += part[t];
-  if (too_big || part[nthreads] >= ((size_t)1 << 32)) { err = "inputs exceed 4 GB per batch: split the batch"; *code = ANX_ELIMIT; return nullptr; }
+  if (too_big.load() || part[nthreads] >= ((size_t)1 << 32)) { err = "inputs exceed 4 GB per batch: split the batch"; *code = ANX_ELIMIT; return nullptr; }
   HostBuf<char> blob(part[nthreads] + 1);
+  if (!blob.data()) { err = "out of memory"; *code = ANX_ELIMIT; return nullptr; }
   run_threads([&](unsigned t, size_t lo, size_t hi) {
     size_t pos = part[t];
     for (size_t i = lo; i < hi; ++i) {
@@ -863,9 +899,10 @@ static int ensure_surv(Batch* b, size_t cap, std::string& err) {
 // read-back at the end, and a run whose assumptions did not hold is repeated with the measured sizes.
 enum { HR_RCTR = 0, HR_SCTR = SCAN_REGIONS * RC_STRIDE, HR_LCTR = 2 * SCAN_REGIONS * RC_STRIDE, HR_CTR = 5 * SCAN_REGIONS * RC_STRIDE,
        HR_TOTAL_SURV = HR_CTR + CTR_N, HR_TOTAL_RESULTS = HR_TOTAL_SURV + 1, HR_N = HR_TOTAL_RESULTS + 1 };
+constexpr size_t HR_COLD_OFF = (HR_N * sizeof(uint32_t) + 63) & ~(size_t)63;  // byte offset of the FsCold staging copy in Batch::h_read
 
 // ANX_CAP_DIV=n (tests): the first-run capacity ESTIMATES are divided by n, so that the overflow -> regrow -> repeat path runs
-static size_t cap_div() { const char* e = getenv("ANX_CAP_DIV"); const long v = e ? atol(e) : 0; return v > 1 ? (size_t)v : 1; }
+static size_t cap_div() { return (size_t)switches().cap_div; }
 
 static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
   if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
@@ -887,7 +924,9 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   int rc;
   if (b->raw_cap == 0 && (rc = ensure_raw(b, (nq * (size_t)140 + (size_t)b->ntiles * SCAN_CHUNK) / SCAN_REGIONS / cap_div() + 4096, err)))
     return rc;
-  if (!b->h_read) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_read), HR_N * sizeof(uint32_t), hipHostMallocDefault));
+  // pinned: the counters the run reads back, and behind them the staging copy of FsCold (a pageable source would make the host
+  // wait, in stream order behind the scan just enqueued, until the copy has been staged)
+  if (!b->h_read) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_read), HR_COLD_OFF + sizeof(FsCold), hipHostMallocDefault));
   const uint32_t region_cap = 1u << b->region_shift;
   // slots per region the scoring grid covers: the previous fill + 1/8 (first run: the whole region; blocks beyond a region's
   // fill return at once)
@@ -903,7 +942,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
     A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
     A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.sighash_e = dl->sighash_e; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
-    { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; A.chunk = v >= 32 && v <= 1024 ? (uint32_t)v : SCAN_CHUNK; }
+    A.chunk = SCAN_CHUNK;
+#ifdef ANX_DEBUG_SWITCHES
+    { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; if (v >= 32 && v <= 1024) A.chunk = (uint32_t)v; }
+#endif
     A.raw = b->raw; A.region_cap = region_cap; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
     A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
     A.qpairs = nullptr;
@@ -912,7 +954,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
       HIP_TRY(hipMemsetAsync(b->qpairs, 0, nq * sizeof(uint32_t), st));
       A.qpairs = b->qpairs;
     }
+    A.dbg = 0;
+#ifdef ANX_DEBUG_SWITCHES
     { const char* e = getenv("ANX_SCAN_DBG"); A.dbg = e ? atoi(e) : 0; }  // read per run: tools/scan_probe.py switches it between runs
+#endif
     const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
     switch (dl->nplanes) {
       case 8: launch_scan<8>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
@@ -930,7 +975,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   HIP_TRY(hipMemsetAsync(b->qmaxfreq, 0, nq * sizeof(uint32_t), st));
   if (dl->any_variants) HIP_TRY(hipMemsetAsync(b->qexpand, 0, nq * sizeof(uint32_t), st));
   ScoreArgs sa;
+  sa.dbg = 0;
+#ifdef ANX_DEBUG_SWITCHES
   { const char* e = getenv("ANX_SCORE_DBG"); sa.dbg = e ? atoi(e) : 0; }
+#endif
   sa.quot = b->quot;
   sa.store_pairs = b->keep_all_pairs ? 1 : 0;
   if (sa.store_pairs && (rc = ensure_pair_outputs(b, err))) return rc;
@@ -955,8 +1003,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   SurvOut so{nullptr, b->sctr, 0};
   const bool have_long_q = b->qw > 1;
   {
-    static const int enable_filter = []() { const char* e = getenv("ANX_PREFILTER"); return (e && e[0] == '0') ? 0 : 1; }();
-    static const int enable_fast = []() { const char* e = getenv("ANX_SCORE_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int enable_filter = switches().prefilter, enable_fast = switches().score_fast;
     const int fastD = (enable_fast && d >= 1 && d <= 3) ? (int)d : 0;
     // survivor records: region r of the survivor list takes the survivors of region r of the pair list.  Sized from the
     // previous run (first run: half the slots the grid covers -- ~10 % of the slots survive on config 2); an overflow is
@@ -1001,17 +1048,18 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap;
     const dim3 fgrid(((fill_cap + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
     {
-      const FsCold cold{sa, so, l8, lg, lw};
+      FsCold* cold = reinterpret_cast<FsCold*>(reinterpret_cast<char*>(b->h_read) + HR_COLD_OFF);  // pinned: a truly asynchronous copy
+      *cold = FsCold{sa, so, l8, lg, lw};
       if (!b->d_cold && (rc = dalloc(reinterpret_cast<char**>(&b->d_cold), sizeof(FsCold), err))) return rc;
-      HIP_TRY(hipMemcpyAsync(b->d_cold, &cold, sizeof cold, hipMemcpyHostToDevice, st));  // pageable source: staged before the call returns
+      HIP_TRY(hipMemcpyAsync(b->d_cold, cold, sizeof(FsCold), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
     // batches without long queries defer the 8-word prefilter of their few wide pairs (a 17..19-symbol candidate) to
     // k_filter_wide: without that state the fused kernel fits 8 waves per SIMD
-    static const int enable_split = []() { const char* e = getenv("ANX_FS_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int enable_split = switches().fs_split;
     const bool split_wide = !have_long_q && enable_split;
     // the one-add zero test of the prefilter needs every symbol code (classes, unknown = A + 1) below the masked paddings 0x7E / 0x7F
-    static const int enable_b7 = []() { const char* e = getenv("ANX_FS_B7"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int enable_b7 = switches().fs_b7;
     const bool b7 = enable_b7 && m.alphabet.size() + 1 < 0x7E;
 #define ANX_FS_LAUNCH(DD, WW, BB) hipLaunchKernelGGL((k_filter_score<DD, WW, BB>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold))
 #define ANX_FS_PICK(WW, BB)                      \
@@ -1194,16 +1242,15 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   return rc ? rc : batch_wait(m, dl, b, err);
 }
 
-int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
-                std::string& err) {
-  (void)m;
-  (void)dl;
+size_t batch_n_results(const Batch* b) { return b->ran ? (size_t)b->n_results : 0; }
+size_t batch_n_input(const Batch* b) { return b->n_input; }
+
+// Downloads the ranked rows of the batch into caller-provided storage: out[0 .. n_results) and off[0 .. n_input] = base + the
+// CSR offsets (a shard of a multi-device batch writes its slice of the whole call's arrays).
+int batch_fetch_into(const Batch* b, anx_result* out, size_t* off, size_t base, std::string& err) {
   if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
   HIP_TRY(hipSetDevice(b->device));
   const size_t n = b->n_input;
-  size_t* off = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
-  anx_result* out = static_cast<anx_result*>(host_result_alloc(std::max<size_t>(1, b->n_results) * sizeof(anx_result)));
-  if (!off || !out) { free(off); host_result_free(out); err = "out of memory"; return ANX_EINVAL; }
   int rc = ANX_OK;
   if (b->nq && b->n_results) {
     // the device lays the rows out in the caller's input order (counts scattered to the original indices, exclusive
@@ -1227,13 +1274,28 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
       HIP_TRY(hipMemcpyAsync(h_off.data(), d_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(out, d_out, b->n_results * sizeof(anx_result), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      for (size_t i = 0; i <= n; ++i) off[i] = h_off[i];
+      for (size_t i = 0; i <= n; ++i) off[i] = base + h_off[i];
       return ANX_OK;
     };
     rc = body();
     if (rc) (void)hipStreamSynchronize(st);  // nothing of this call may still be in flight when its blocks return to the pool
     for (void* p : {(void*)d_cnt, (void*)d_off, (void*)d_tmp, (void*)d_out}) pool_free(p);
+  } else {
+    for (size_t i = 0; i <= n; ++i) off[i] = base;
   }
+  return rc;
+}
+
+int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
+                std::string& err) {
+  (void)m;
+  (void)dl;
+  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  HIP_TRY(hipSetDevice(b->device));
+  size_t* off = static_cast<size_t*>(malloc((b->n_input + 1) * sizeof(size_t)));
+  anx_result* out = static_cast<anx_result*>(host_result_alloc(std::max<size_t>(1, b->n_results) * sizeof(anx_result)));
+  if (!off || !out) { free(off); host_result_free(out); err = "out of memory"; return ANX_EINVAL; }
+  const int rc = batch_fetch_into(b, out, off, 0, err);
   if (rc) { free(off); host_result_free(out); return rc; }
   *rows = out;
   *offs = off;

@@ -22,11 +22,14 @@ __host__ __device__ inline bool tile_probes(uint32_t balln, uint32_t window, uns
     if (((sig >> (8 * g)) & 0xFFu) > 120u) return false;
   return true;
 }
-inline bool probe_enabled() { const char* e = getenv("ANX_SCAN_WALK"); return !(e && strcmp(e, "flat") == 0); }  // read per encode
+inline bool probe_enabled() { return !switches().scan_walk_flat; }
 
 // per-device scratch pool (engine.hip): freed blocks are kept for the next batch
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p);
+// non-blocking stream for one call of the device-side encoder (kept per device, reused)
+hipStream_t encoder_stream_acquire(int device);
+void encoder_stream_release(int device, hipStream_t s);
 // device-side query encoder (encode.hip): fills the query and tile arrays of `b` from the packed inputs
 int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
                         const anx_params& p, std::string& err);

@@ -433,6 +433,45 @@ static int pick_planes(int nsym) {  // kernel variants are instantiated for thes
   return -1;
 }
 
+namespace {
+struct SwitchDef { const char* name; void (*set)(Switches&, const char*); };
+int flag01(const char* v, int dflt) { return !v ? dflt : (v[0] == '0' ? 0 : 1); }
+const SwitchDef kSwitches[] = {
+    {"ANX_ENCODE", [](Switches& s, const char* v) { s.encode_host = v && strcmp(v, "host") == 0; }},
+    {"ANX_SCAN", [](Switches& s, const char* v) { s.scan_sad = v && strcmp(v, "sad") == 0; }},
+    {"ANX_SCAN_WALK", [](Switches& s, const char* v) { s.scan_walk_flat = v && strcmp(v, "flat") == 0; }},
+    {"ANX_SCAN_TQ", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.scan_tq = x >= 1 && x <= 64 ? x : 0; }},
+    {"ANX_SIG_GROUPS", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.sig_groups = x >= 1 && x <= 8 ? x : 0; }},
+    {"ANX_PREFILTER", [](Switches& s, const char* v) { s.prefilter = flag01(v, 1); }},
+    {"ANX_SCORE_FAST", [](Switches& s, const char* v) { s.score_fast = flag01(v, 1); }},
+    {"ANX_FS_SPLIT", [](Switches& s, const char* v) { s.fs_split = flag01(v, 1); }},
+    {"ANX_FS_B7", [](Switches& s, const char* v) { s.fs_b7 = flag01(v, 1); }},
+    {"ANX_SCAN_FUSE", [](Switches& s, const char* v) { s.fuse_prefilter = flag01(v, 1); }},
+    {"ANX_CAP_DIV", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.cap_div = x > 1 ? x : 1; }},
+    {"ANX_MAX_BATCH", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.max_batch = x > 0 ? x : (4l << 20); }},
+    {"ANX_SHARD_MIN", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.shard_min = x > 0 ? x : 8192; }},
+    {"ANX_CONFUSABLES", [](Switches& s, const char* v) { s.confusables_host = v && strcmp(v, "host") == 0; }},
+    {"ANX_LATTICE", [](Switches& s, const char* v) { s.lattice_host = v && strcmp(v, "host") == 0; }},
+    {"ANX_ENCODE_TIMING", [](Switches& s, const char* v) { s.encode_timing = v != nullptr && v[0] != 0 && v[0] != '0'; }},
+    {"ANX_SEARCH_TIMING", [](Switches& s, const char* v) { s.search_timing = v != nullptr && v[0] != 0 && v[0] != '0'; }},
+};
+}  // namespace
+Switches& switches() {
+  static Switches sw = []() {
+    Switches s;
+    for (const SwitchDef& d : kSwitches)
+      if (const char* v = getenv(d.name)) d.set(s, v);
+    return s;
+  }();
+  return sw;
+}
+bool set_switch(const char* name, const char* value) {
+  if (!name) return false;
+  for (const SwitchDef& d : kSwitches)
+    if (strcmp(d.name, name) == 0) { d.set(switches(), value); return true; }
+  return false;
+}
+
 unsigned usable_hw_threads() {
   static const unsigned cached = []() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
@@ -510,7 +549,7 @@ int HostModel::build_index(std::string& err) {
     std::vector<uint32_t> slots(cvbytes);
     std::iota(slots.begin(), slots.end(), 0u);
     std::stable_sort(slots.begin(), slots.end(), [&](uint32_t a, uint32_t b) { return slot_freq[a] > slot_freq[b]; });
-    static const int ngroups = []() { const char* e = getenv("ANX_SIG_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : kSigGroups; }();
+    const int ngroups = switches().sig_groups ? switches().sig_groups : kSigGroups;
     uint64_t weight[8] = {};
     lex.sym_group.assign(cvbytes, 0);
     for (uint32_t sl : slots) {

@@ -60,6 +60,32 @@ std::string trim_whitespace(const std::string& s);  // str::trim()
 // show 256 hardware threads and grant 16 CPUs).
 unsigned usable_hw_threads();
 
+// A/B, test and tuning switches.  Read ONCE from the environment (variable names in the comments) when the library is first
+// used -- a variable set later has no effect -- and changed at run time only through anx_debug_set_switch (tests, tools).  None of
+// them changes results; the part-skipping timing switches exist only in -DANX_DEBUG_SWITCHES builds.
+struct Switches {
+  int encode_host = 0;       // ANX_ENCODE=host: the threaded host encoder instead of the device one (A/B reference)
+  int scan_sad = 0;          // ANX_SCAN=sad: count-vector scan kernel for every tile
+  int scan_walk_flat = 0;    // ANX_SCAN_WALK=flat: window walk instead of the hash-probed ball
+  int scan_tq = 0;           // ANX_SCAN_TQ=1..64: queries per scan tile (0 = default)
+  int sig_groups = 0;        // ANX_SIG_GROUPS=1..8: signature groups of a model built afterwards (0 = default)
+  int prefilter = 1;         // ANX_PREFILTER=0: no SWAR bound, every length-compatible pair goes through the DL
+  int score_fast = 1;        // ANX_SCORE_FAST=0: general k_score_pairs for every pair
+  int fs_split = 1;          // ANX_FS_SPLIT=0: inline 8-word prefilter for short-query batches too
+  int fs_b7 = 1;             // ANX_FS_B7=0: general zero test in the prefilter
+  int fuse_prefilter = 1;    // ANX_SCAN_FUSE=0: the scan's expansion does not apply the SWAR bound (k_filter_score's phase 1 does)
+  long cap_div = 1;          // ANX_CAP_DIV=n: first-run capacity estimates divided by n (regrow-and-repeat path)
+  long max_batch = 4l << 20; // ANX_MAX_BATCH: inputs per device batch of anx_find_variants_batch
+  long shard_min = 8192;     // ANX_SHARD_MIN: fewest inputs a replica of a multi-device model gets (smaller calls use fewer replicas)
+  int confusables_host = 0;  // ANX_CONFUSABLES=host: confusable weighting on the host threads (A/B reference of the device kernel)
+  int lattice_host = 0;      // ANX_LATTICE=host: lattice decoding on the host threads (A/B reference of the device kernel)
+  int encode_timing = 0;     // ANX_ENCODE_TIMING, ANX_SEARCH_TIMING: host phase times on stderr
+  int search_timing = 0;
+};
+Switches& switches();
+// name = the environment variable's name, value = what the variable would hold; false: unknown name
+bool set_switch(const char* name, const char* value);
+
 struct VariantRef {  // VariantReference, src/types.rs:315-324
   bool variant_of;  // true = VariantOf((id, score)), false = ReferenceFor((id, score))
   uint64_t id;

@@ -175,5 +175,13 @@ struct Batch {
   anx_batch_stats stats = {};
 };
 
+// Timing switches that skip parts of the kernels (ANX_SCAN_DBG / ANX_SCORE_DBG / ANX_SCAN_CHUNK: results are WRONG when set) exist
+// only in builds with -DANX_DEBUG_SWITCHES (tools/build_variant.sh); the release library compiles them to constants.
+#ifdef ANX_DEBUG_SWITCHES
+#define ANX_DBG(x) (x)
+#else
+#define ANX_DBG(x) 0
+#endif
+
 typedef const __attribute__((address_space(4))) uint32_t* cptr_u32;  // constant address space: s_load
 

@@ -225,7 +225,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   // branch-free: 2 ops per plane + ONE v_alignbit_b32 per test (it shifts the sign bit of acc = "miss" into the mask).
   auto process = [&]() {
     ++nchunks;
-    if (A.dbg & 2) return;
+    if (ANX_DBG(A.dbg) & 2) return;
     uint32_t cid[CPL], cw[CPL][W];
     int32_t thr[CPL];
 #pragma unroll
@@ -255,7 +255,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       }
     }
     for (uint32_t qb = 0; qb < t.nq; qb += 32) {
-      const uint32_t npass = (A.dbg & 1) ? 1u : (t.nq - qb < 32u ? t.nq - qb : 32u);
+      const uint32_t npass = (ANX_DBG(A.dbg) & 1) ? 1u : (t.nq - qb < 32u ? t.nq - qb : 32u);
       uint32_t hm[CPL];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) hm[j] = 0xFFFFFFFFu;  // miss bits
@@ -311,7 +311,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         hm[j] = ~hm[j] & valid;
         any |= hm[j];
       }
-      if (__ballot(any != 0) == 0ull || (A.dbg & 8)) continue;  // wave-uniform (dbg 8: timing without the expansion)
+      if (__ballot(any != 0) == 0ull || (ANX_DBG(A.dbg) & 8)) continue;  // wave-uniform (dbg 8: timing without the expansion)
       // The non-empty (class, hit mask) pairs are appended to the wave's LDS hit list; flush() expands the list one
       // entry per lane whenever it gets full (and at the end of the tile), so the expansion rounds run with full
       // waves and the loop runs max-over-entries popcount times.  Mask bit b = query qb + b of the tile.
@@ -341,7 +341,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   // stages the class / record runs (cb, n) of the lanes with ok: scalar loop over the ballot mask
   auto stage_runs = [&](bool ok, uint32_t cb, uint32_t n) {
     unsigned long long m = __ballot(ok);
-    if (!m || (A.dbg & 4)) return;
+    if (!m || (ANX_DBG(A.dbg) & 4)) return;
     if (!ok) { cb = 0u; n = 0u; }
     while (m) {
       const int i = __ffsll((long long)m) - 1;

@@ -119,7 +119,7 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
                                     const uint32_t* __restrict__ ent_var_off, uint32_t* __restrict__ qmaxfreq,
                                     uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand, uint32_t& lcs,
                                     uint32_t& pre, uint32_t& suf, uint32_t& samecase, bool& keep) {
-  if (a.w_lcs > 0.0 && !(a.dbg & 1)) {
+  if (a.w_lcs > 0.0 && !(ANX_DBG(a.dbg) & 1)) {
     // longest common substring (src/lib.rs:1352-1356, src/distance.rs:181-205) = longest run of equal symbols on
     // any diagonal.  Diagonals are visited from the main one outwards (0, +1, -1, +2, ...): the overlap of a diagonal
     // only shrinks with |delta|, so the walk stops as soon as neither side can beat the best run found so far.
@@ -382,7 +382,7 @@ __device__ inline void tail_of_pair(uint32_t p, bool has, uint32_t ld, const Pai
   uint32_t lcs = 0, pre = 0, suf = 0, samecase = 1;
   double score = __builtin_nan("");
   bool keep = false;
-  if (has && !(a.dbg & 2)) {
+  if (has && !(ANX_DBG(a.dbg) & 2)) {
     uint32_t* mine = lds + (threadIdx.x & 255) * (2 * NW + 1);
 #pragma unroll
     for (int w = 0; w < NW; ++w) { mine[w] = r.S[w]; mine[NW + w] = r.T[w]; }
@@ -716,7 +716,7 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
           cur[2 * d + 2] = (uint8_t)cap;
         }
         const uint32_t res = R[(lq % NR) * W + (lc - lq + d + 1)];
-        if (res <= (uint32_t)d && !(a.dbg & 2)) {  // src/distance.rs:173-178
+        if (res <= (uint32_t)d && !(ANX_DBG(a.dbg) & 2)) {  // src/distance.rs:173-178
           ld = res;
           score = score_tail(S, T, lq, lc, ld, qm, em, q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, lcs, pre, suf, samecase, keep);
           kq = q; ke = e; kscore = score;

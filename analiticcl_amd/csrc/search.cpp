@@ -32,7 +32,7 @@ namespace {
 
 using anx::HostModel;
 std::atomic<uint64_t> g_lat_ns[6];  // ANX_SEARCH_TIMING: time inside most_likely_sequence by part, all threads
-static const bool g_lat_timing = getenv("ANX_SEARCH_TIMING") != nullptr;
+#define g_lat_timing (anx::switches().search_timing != 0)
 inline uint64_t lat_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct LatLap { uint64_t t; LatLap() : t(g_lat_timing ? lat_now() : 0) {} void lap(int i) { if (g_lat_timing) { const uint64_t n = lat_now(); g_lat_ns[i] += n - t; t = n; } } };
 
@@ -432,7 +432,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   if (out_tags) *out_tags = nullptr;
   if (!model || (!texts && n) || !sp || !out_matches || !out_offsets || !out_rows || !out_n_rows)
     return anx_fail(ANX_EINVAL, "NULL argument");
-  static const bool timing = getenv("ANX_SEARCH_TIMING") != nullptr;
+  const bool timing = anx::switches().search_timing != 0;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();
   auto lap = [&](const char* what) { if (timing) { const double t = tnow(); fprintf(stderr, "[anx search] %-28s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };

@@ -206,6 +206,15 @@ class Batch:
     def wait(self):
         L.check(L.lib().anx_batch_wait(self.model.h, self.h))
 
+    def shards(self) -> List[tuple]:
+        """[(device, first_input, n_inputs)]: the replicas of a multi-device model this batch is spread over."""
+        out = []
+        for g in range(L.lib().anx_batch_num_shards(self.h)):
+            dev, lo, cnt = C.c_int(), C.c_size_t(), C.c_size_t()
+            L.check(L.lib().anx_batch_shard_info(self.h, g, C.byref(dev), C.byref(lo), C.byref(cnt)))
+            out.append((dev.value, lo.value, cnt.value))
+        return out
+
     def stats(self) -> dict:
         s = L.BatchStats()
         L.check(L.lib().anx_batch_get_stats(self.h, C.byref(s)))
@@ -291,10 +300,11 @@ class Batch:
 
 class VariantModel:
     """VariantModel (src/lib.rs:50-100) for the query path; `device` = HIP device ordinal
-    (default: $LOCAL_RANK or 0; -1 = host index only)."""
+    (default: $LOCAL_RANK or 0; -1 = host index only).  `devices` = a list of ordinals: one process drives a replica of the
+    lexicon on each of them (anx_model_to_devices) and every batch call shards its inputs over the replicas."""
 
     def __init__(self, alphabet_file: str, weights: Optional[Weights] = None, debug: int = 0,
-                 device: Optional[int] = None, alphabet_text: Optional[str] = None):
+                 device: Optional[int] = None, alphabet_text: Optional[str] = None, devices: Optional[List[int]] = None):
         w = (weights or Weights())._c()
         lib = L.lib()
         if alphabet_text is not None:
@@ -303,7 +313,8 @@ class VariantModel:
             self.h = lib.anx_model_new(_b(alphabet_file), C.byref(w), debug)
         if not self.h:
             raise L.AnxError(L.ANX_EIO, L.last_error())
-        self.device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+        self.devices = list(devices) if devices else None
+        self.device = self.devices[0] if self.devices else (int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
         self.lexicons: List[str] = []
 
     def __del__(self):
@@ -352,7 +363,11 @@ class VariantModel:
 
     def build(self):
         self.__dict__.pop("_vocab_cache", None)
-        L.check(L.lib().anx_model_build(self.h, self.device))
+        if self.devices and len(self.devices) > 1:
+            L.check(L.lib().anx_model_build(self.h, -1))
+            self.to_devices(self.devices)
+        else:
+            L.check(L.lib().anx_model_build(self.h, self.device))
 
     def set_index_tag(self, tag: str):
         """Stored in the image save_index writes: what the model was built from (see index_tag_of)."""
@@ -376,13 +391,29 @@ class VariantModel:
     def load_index(self, filename: str):
         """Instead of read_lexicon / read_variants / build: load an image written by save_index for the same alphabet."""
         self.__dict__.pop("_vocab_cache", None)
-        L.check(L.lib().anx_model_load_index(self.h, _b(filename), self.device))
+        multi = bool(self.devices and len(self.devices) > 1)
+        L.check(L.lib().anx_model_load_index(self.h, _b(filename), -1 if multi else self.device))
+        if multi:
+            self.to_devices(self.devices)
         n = L.lib().anx_model_num_lexicons(self.h) if hasattr(L.lib(), "anx_model_num_lexicons") else 0
         self.lexicons = [L.lib().anx_model_lexicon_name(self.h, i).decode("utf-8") for i in range(n)]
 
     def to_device(self, device: int):
         self.device = device
+        self.devices = None
         L.check(L.lib().anx_model_to_device(self.h, device))
+
+    def to_devices(self, devices: List[int]):
+        """One replica of the built lexicon per listed HIP device (an ordinal may repeat); batch calls then shard their inputs
+        over the replicas inside this one process (anx_model_to_devices)."""
+        arr = (C.c_int * len(devices))(*devices)
+        L.check(L.lib().anx_model_to_devices(self.h, arr, len(devices)))
+        self.devices = list(devices)
+        self.device = self.devices[0]
+
+    @property
+    def num_replicas(self) -> int:
+        return L.lib().anx_model_num_replicas(self.h)
 
     # -- introspection ------------------------------------------------------------------------------
     def __contains__(self, text: str) -> bool:

@@ -12,6 +12,19 @@ copies alternate on one stream so that the next step is enqueued while the curre
 With N>1 every rank processes its own 1 M-query shard (weak scaling, no data-path collective) and the ranked
 compact top-k records (offsets + the rows in use) are gathered to rank 0 over RCCL once per step.
 
+Other launch forms of the same measurement:
+  --single-process          ONE process drives --gpus N replicas of the lexicon through the C ABI's own split
+                            (anx_model_to_devices: one host thread + stream per device, rows concatenated in input order; no
+                            torch.distributed, no collective -- what a Rust / C caller of libanx gets); --replicas-on-one-gpu puts
+                            all N replicas on device 0 (one-GPU boxes).
+  --ranks-on-one-gpu N      dry run of the N-rank job on ONE GPU: N processes under torch.distributed.run, every rank on
+                            device 0, --backend gloo (records staged through pinned host memory) or nccl (if RCCL accepts
+                            ranks that share a device); with --check-gather rank 0 compares every rank's gathered export with
+                            that rank's own fetch().
+After the timed region (N = 1): "configs" -- the literal metric configuration (nld.aspell, ~200 k entries, len <= 16, d = 2) and
+BASELINE.json configs[2], [3] (one GPU's share), [4] (one GPU's share), each behind a spot check against the oracle (--no-extras
+skips them).
+
 Prints ONE JSON line (rank 0).  value = scored (query,candidate) pairs per second, whole job.
 """
 import argparse
@@ -56,6 +69,484 @@ def usable_cores() -> int:
     return n
 
 
+def roofline_of(args, model, queries, st, scan_ms, fs_ms, total_ms):
+    """The roofline object of the JSON line: the slowest kernel of the run against the HBM roof, both kernels with their
+    algorithmic bytes and VALU-issue floors."""
+    # ---- roofline of the dominant kernel (per launch, rank 0) --------------------------------------
+    # The dominant kernel = the slowest kernel of THIS run (k_scan_bits or k_filter_score, HIP events around each launch on
+    # the launch stream: anx_batch_stats.ms_scan_kernel / ms_filter_score_kernel); "per_kernel" carries both.
+    # Algorithmic bytes per launch (DESIGN.md section 5):
+    #  k_scan_bits: query planes 16 B/query + tile descriptors 44 B/tile + class record, signature 44 B/class
+    #               (each once per launch) + pair list out 8 B/slot;
+    #  k_filter_score: what the kernel has to touch per materialised pair-list slot: pair record 8 B + query / entry
+    #               symbols and lengths 16 + 8 B, plus 16 B of survivor record per pair that passes the score threshold.
+    #               SURVEY.md section 8(d)'s literal figure (Lpad + 32 B for EVERY scored pair, i.e. 16 B of result per pair
+    #               although only survivors are written) is reported next to it as "survey_model".
+    # SURVEY.md section 8(d)'s whole-path figure, pairs*(Lpad+32) + queries*208, is reported as "pipeline".
+    lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
+    n_classes = model.num_classes()
+    scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 44 + n_classes * 44 + st["n_pair_slots"] * 8
+    fs_bytes = st["n_pair_slots"] * (8 + lpad + 8) + st["n_survivors"] * 16
+    fs_bytes_survey = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
+    if fs_ms > scan_ms:
+        kname, kbytes, kms = "k_filter_score", fs_bytes, fs_ms
+    else:
+        kname, kbytes, kms = "k_scan_bits", scan_bytes, scan_ms
+    achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    pipeline_bytes = st["n_pairs"] * (lpad + 32) + st["n_queries"] * 208
+    pipeline_gbs = pipeline_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    # The bound that actually binds both kernels is VALU issue (89 % / 77 % VALU-active, profiles/): the floor below counts
+    # only the instructions the algorithm cannot do without, at the measured issue cost per wave-instruction per SIMD
+    # (tools/ubench_valu.hip: 2-operand ops 2.2 cycles, VOP3 ops such as v_bcnt / v_alignbit / v_sad_u8 4.3), over the
+    # 1024 SIMDs at 2.4 GHz.
+    #  scan: per 256 class tests of T planes T*4 v_and_b32 + T*4 v_bcnt_u32_b32 + 4 v_alignbit_b32.
+    SIMD_HZ = 1024 * 2.4e9
+    kinds = st["n_tests_kind"]
+    issue_cycles = (kinds[0] * (8 * 4.3 + 4.3) * 4 + sum(kinds[t] * (t * 4 * 6.5 + 4 * 4.3) for t in range(1, 5))) / 256.0
+    valu_floor_ms = issue_cycles / SIMD_HZ * 1e3
+    #  filter_score, per wave of 64 (DESIGN.md section 5 K2+K3): SWAR band filter of every slot over as many 4-symbol words as
+    #  the pair needs (the kernel picks 2 / 3 / 4 per wave; estimated here from the query lengths as ceil((len + 1) / 4)):
+    #  per word the unshifted comparison + 2d shifted ones + 2 x (and, bcnt) popcounts.  Alphabets of <= 124 classes (7-bit
+    #  symbol codes, the kernel's B7 instances): 2 mask ands, unshifted (xor, add, and, and) = 8.8 cycles, shifted
+    #  (alignbyte, xor, add, and | alignbyte, and) = 17.4; otherwise unshifted (xor, and, add, or, and, and) = 15.4, shifted
+    #  (alignbyte, xor, and, add, or3, and | alignbyte, and) = 24.0.
+    #  band DL of every selected pair: rows x (2d+1) cells x (2 min, 2 add, cmp, cndmask = 16 cycles), rows ~ mean query length;
+    #  tail of every DL survivor (LCS diagonal walk, prefix, suffix, f64 score) ~ 300 instructions = 900 cycles.
+    dd = args.edit_distance
+    nw = 4 if args.max_len <= 16 else 8
+    sample_q = queries[:20000]
+    mean_len = sum(len(q) for q in sample_q) / max(len(sample_q), 1)
+    words = sum(min(nw, (len(q) + 1 + 3) // 4) for q in sample_q) / max(len(sample_q), 1)
+    from analiticcl_amd import _lib as _L
+    b7 = _L.lib().anx_model_alphabet_size(model.h) < 0x7E  # = classes + 1 = the largest symbol code (unknown): engine.hip's condition
+    c_mask, c_unshifted, c_shifted = (4.4, 8.8, 17.4) if b7 else (0.0, 15.4, 24.0)
+    fs_cycles = (st["n_pair_slots"] / 64.0) * ((c_mask + c_unshifted + 2 * dd * c_shifted + 2 * 6.5) * words) \
+        + (st["n_selected"] / 64.0) * (mean_len * (2 * dd + 1) * 16.0) + (st["n_survivors"] / 64.0) * 900.0
+    fs_valu_floor_ms = fs_cycles / SIMD_HZ * 1e3
+    # HBM bytes per launch of that kernel from the committed PMC passes: only for the same workload AND the same kernel
+    # sources (the profile is tagged with a hash of csrc/*.hip, *.hpp; stale numbers are dropped)
+    traffic, traffic_src = None, None
+    try:
+        if (args.lexicon, args.max_len, args.anagram_distance, args.edit_distance, args.queries) == ("eng", 16, 3, 2, 1_000_000):
+            import glob
+            import hashlib
+            h = hashlib.sha256()
+            for f in sorted(glob.glob(os.path.join(REPO, "analiticcl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "analiticcl_amd", "csrc", "*.hpp"))):
+                with open(f, "rb") as fh:
+                    h.update(fh.read())
+            for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                with open(cand) as f:
+                    pj = json.load(f)
+                if pj.get("kernel_src_sha256") == h.hexdigest():
+                    traffic, traffic_src = pj["kernels"][kname]["traffic_bytes"], os.path.basename(cand)
+                    break
+    except Exception:
+        traffic = None
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": kms,
+                "algorithmic_bytes_per_launch": kbytes,
+                "note": "integer scan / DL path: both kernels are VALU-issue bound, far below the HBM roof (DESIGN.md section 5); "
+                        "valu_issue_frac = algorithmic instruction floor / measured kernel time",
+                "kernels_ms": {"k_scan_bits": scan_ms, "k_filter_score": fs_ms},
+                "per_kernel": {name: {"avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+                                      "achieved": (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
+                                      "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0),
+                                      "valu_issue_floor_ms": fl, "valu_issue_frac": (fl / ms if ms > 0 else 0.0)}
+                               for name, nbytes, ms, fl in (("k_scan_bits", scan_bytes, scan_ms, valu_floor_ms),
+                                                            ("k_filter_score", fs_bytes, fs_ms, fs_valu_floor_ms))},
+                "k_filter_score_survey_model": {"algorithmic_bytes_per_launch": fs_bytes_survey,
+                                                "frac": (fs_bytes_survey / (fs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fs_ms > 0 else 0.0)},
+                "pipeline_algorithmic_bytes": pipeline_bytes, "pipeline_gbs": pipeline_gbs,
+                "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
+                "scan_valu_issue_floor_ms": valu_floor_ms,
+                "scan_valu_issue_frac": valu_floor_ms / scan_ms if scan_ms > 0 else 0.0,
+                "scan_class_tests_per_s": st["n_class_tests"] / (scan_ms * 1e-3) if scan_ms > 0 else 0.0,
+                "scan_tests_by_planes": kinds, "scan_tiles": st["n_scan_blocks"]}
+    return roofline
+
+
+def e2e_of(args, model, queries, params, stream_handle, torch):
+    """End to end from ONE host buffer of NUL-terminated strings to the ranked rows in host memory (never `value`)."""
+    e2e = None
+    if True:
+        reps = []
+        # the queries as ONE host buffer, every string followed by a NUL byte: what a caller that reads its input from a
+        # file or a socket holds (the reference's CLI reads lines the same way, src/bin/analiticcl.rs:416-448); building it
+        # from a Python list of str costs more than the whole pipeline and is not part of the boundary
+        packed = ("\0".join(queries) + "\0").encode("utf-8")
+        for _ in range(3):
+            t = time.perf_counter()
+            b2 = model.encode_packed(packed, len(queries), params)
+            t1 = time.perf_counter()
+            b2.run(stream_handle)
+            t2 = time.perf_counter()
+            arrs = b2.fetch_arrays()
+            t3 = time.perf_counter()
+            b2.free()
+            reps.append((t3 - t, t1 - t, t2 - t1, t3 - t2, int(arrs[0][-1])))
+            del arrs  # the rows live in a pinned buffer of the library's cache: released here, reused by the next fetch
+        best = min(reps)
+        # the same with two host threads, each running encode -> run -> fetch on its own batches and its own stream (the
+        # library is thread-safe on one model): uploads, kernels and downloads of different batches overlap
+        import threading
+        nthr, per = 2, 8
+        streams2 = [torch.cuda.Stream() for _ in range(nthr)]
+        def worker(st2):
+            for _ in range(per):
+                bb = model.encode_packed(packed, len(queries), params)
+                bb.run(st2.cuda_stream)
+                res = bb.fetch_arrays()
+                del res
+                bb.free()
+        th = [threading.Thread(target=worker, args=(x,)) for x in streams2]  # warm the pools of a second set of buffers
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        t = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(x,)) for x in streams2]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        piped = nthr * per * args.queries / (time.perf_counter() - t)
+        e2e = {"queries_per_s": args.queries / best[0], "two_threads_queries_per_s": piped, "s_per_batch": best[0], "encode_upload_s": best[1], "run_s": best[2],
+               "download_s": best[3], "rows": best[4],
+               "what": "host buffer of NUL-terminated UTF-8 strings -> anx_batch_encode_packed (H2D + device-side encoder) -> anx_batch_run -> "
+                       "anx_batch_fetch (ranked rows in input order, host memory), best of 3, one batch at a time, no overlap between batches"}
+    return e2e
+
+
+def cpu_baseline_of(args, paths, queries, ncores, seconds=15.0):
+    """The C oracle ("port" of the reference algorithm, oracle/anx_oracle.c) on this box's host cores: a bounded sample of the
+    same queries.  Test infrastructure used as the reported baseline only."""
+    cpu = None
+    if True:
+        from oracle import cwrap as O
+        om = O.OracleModel(alphabet_path=paths["alphabet"])
+        om.read_lexicon(paths[args.lexicon])
+        om.build()
+        op = O.make_params(("abs", args.anagram_distance), ("abs", args.edit_distance), 10, 0.25, 2.0)
+        if args.cpu_sample > 0:
+            sample = min(args.cpu_sample, args.queries)
+        else:  # calibrate on a short run, then size the sample for ~15 s of wall time
+            ncal = min(args.queries, 16 * ncores)
+            t = time.perf_counter()
+            om.find_variants_batch(queries[:ncal], op, nthreads=ncores, stride=16)
+            rate = ncal / max(time.perf_counter() - t, 1e-3)
+            sample = int(max(ncal, min(args.queries, rate * seconds)))
+        t = time.perf_counter()
+        rc, _res, _counts, cpairs, _ccls = om.find_variants_batch(queries[:sample], op, nthreads=ncores, stride=16)
+        dt = time.perf_counter() - t
+        # one thread as well (SURVEY.md section 8(d)): a short prefix of the same sample, ~5 s
+        n1 = int(max(64, min(sample, (sample / dt) / ncores * 5.0)))
+        t = time.perf_counter()
+        _rc, _r, _c, cpairs1, _cc = om.find_variants_batch(queries[:n1], op, nthreads=1, stride=16)
+        dt1 = time.perf_counter() - t
+        cpu = {"value": cpairs / dt, "unit": "pairs/s", "cores": ncores, "kind": "port",
+               "single_thread": {"value": cpairs1 / dt1, "queries_per_s": n1 / dt1, "sample": f"first {n1} queries, {dt1:.1f} s"},
+               "queries_per_s": sample / dt,
+               "sample": f"first {sample} of the same {args.queries} queries, C oracle (oracle/anx_oracle.c), "
+                         f"OpenMP dynamic schedule, {ncores} threads (= usable cores: cgroup quota of {os.cpu_count()} hardware threads), {dt:.1f} s"}
+    return cpu
+
+
+
+# ---- per-config numbers measured after the timed region (never `value`) ---------------------------------------------------------
+def _spot_check(model, om, queries, arrays, op, n, rescore=None):
+    """n sampled queries of a finished batch against the oracle (test infrastructure used as the checker): ranked ids and f64
+    scores.  Returns 'ok (n queries)' or raises."""
+    import random
+    off, vid, dist, freq = arrays
+    idx = random.Random(5).sample(range(len(queries)), n)
+    for i in idx:
+        exp = om.find_variants(queries[i], op)
+        if rescore:
+            exp = rescore(exp, queries[i])
+        got = [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
+        if [v for v, _d, _f in got] != [v for v, _d, _f in exp] or any(abs(a[1] - b[1]) > 1e-6 or abs(a[2] - b[2]) > 1e-6 for a, b in zip(got, exp)):
+            raise RuntimeError(f"parity spot check failed on {queries[i]!r}: {got[:3]} vs {exp[:3]}")
+    return f"ok ({n} queries vs the oracle)"
+
+
+def _time_runs(b, reps=5):
+    b.run()
+    b.run()
+    t = time.perf_counter()
+    for _ in range(reps):
+        b.run()
+    return (time.perf_counter() - t) / reps
+
+
+def _e2e_packed(model, queries, params, reps=3):
+    packed = ("\0".join(queries) + "\0").encode("utf-8")
+    best = None
+    for _ in range(reps):
+        t = time.perf_counter()
+        b = model.encode_packed(packed, len(queries), params)
+        b.run()
+        arrs = b.fetch_arrays()
+        dt = time.perf_counter() - t
+        b.free()
+        del arrs
+        best = dt if best is None else min(best, dt)
+    return len(queries) / best
+
+
+def extra_configs(args, paths, device, ncores):
+    """BASELINE.json's other configurations and the literal metric configuration on this one GPU, each behind a parity spot check.
+    Every entry carries its own wall time ("took_s"); an entry that fails says why instead of stopping the bench."""
+    import analiticcl_amd as A
+    from analiticcl_amd import synth
+    from oracle import confusable_oracle as CO
+    from oracle import cwrap as O
+    out = {}
+
+    def guarded(name, fn):
+        t = time.perf_counter()
+        try:
+            r = fn()
+        except Exception as e:  # noqa: BLE001
+            r = {"error": repr(e)[:300]}
+        r["took_s"] = round(time.perf_counter() - t, 1)
+        out[name] = r
+
+    nld_words = synth.load_lexicon_words(paths["nld"])
+    std = dict(max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+
+    def nld_len16_d2():  # the metric string's "200k-lexicon, len<=16": nld.aspell has 222 908 entries
+        m = A.VariantModel(paths["alphabet"], A.Weights(), device=device)
+        m.read_lexicon(paths["nld"])
+        m.build()
+        qs = synth.make_queries(nld_words, 1_000_000, max_len=16, seed=synth.SEED + 1)
+        p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, **std)
+        b = m.encode_batch(qs, p)
+        dt = _time_runs(b)
+        st = b.stats()
+        om = O.OracleModel(alphabet_path=paths["alphabet"])
+        om.read_lexicon(paths["nld"])
+        om.build()
+        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), 48)
+        b.free()
+        return {"workload": "nld.aspell (222 908 entries) + simple.alphabet, 1 M queries len<=16, k=3 d=2 n=10", "ms_per_step": dt * 1e3,
+                "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt, "pairs_per_query": st["n_pairs"] / max(st["n_queries"], 1),
+                "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "parity": chk}
+
+    def configs2():  # nld, len <= 24, d = 3, confusable weighting
+        conf = os.path.join(synth.GOLDEN_DATA, "confusables10.tsv")
+        m = A.VariantModel(paths["alphabet"], A.Weights(), device=device)
+        m.read_lexicon(paths["nld"])
+        m.read_confusablelist(conf)
+        m.build()
+        qs = synth.make_queries(nld_words, 1_000_000, max_len=24, seed=synth.SEED + 2)
+        p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=3, **std)
+        b = m.encode_batch(qs, p)
+        dt = _time_runs(b)
+        st = b.stats()
+        om = O.OracleModel(alphabet_path=paths["alphabet"])
+        om.read_lexicon(paths["nld"])
+        om.build()
+        confs = CO.read_confusables(conf)
+        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 3), 10, 0.25, 0.0), 48,
+                          rescore=lambda exp, q: CO.late_rescore(exp, q, confs, om.text, 0.0, 2.0))
+        b.free()
+        e2e = _e2e_packed(m, qs, p)
+        return {"workload": "BASELINE.json configs[2]: nld.aspell, 1 M queries len<=24, k=3 d=3 n=10, 10 confusable patterns", "device_ms": dt * 1e3,
+                "pairs_per_s": st["n_pairs"] / dt, "e2e_queries_per_s": e2e, "parity": chk,
+                "what": "device_ms = one pass of the device pipeline over the resident batch; e2e = packed host buffer -> encode -> run -> fetch incl. the confusable rescoring"}
+
+    def configs3_share():  # merged 1 M-entry lexicon, one GPU's 1.25 M of the 10 M length-bucketed queries
+        words = list(dict.fromkeys(synth.load_lexicon_words(paths["eng"]) + nld_words))
+        lex = synth.make_lexicon(words, 1_000_000, seed=11)
+        path = os.path.join(tempfile.gettempdir(), f"anx_bench_big_{os.getuid()}.lexicon")
+        with open(path, "w", encoding="utf-8") as f:
+            f.write("\n".join(lex) + "\n")
+        m = A.VariantModel(paths["alphabet"], A.Weights(), device=device)
+        m.read_lexicon(path)
+        m.build()
+        qs = synth.make_queries(lex, 1_250_000, max_len=32, min_len=4, seed=5)
+        qs.sort(key=len)
+        p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, **std)
+        b = m.encode_batch(qs, p)
+        dt = _time_runs(b, reps=3)
+        st = b.stats()
+        om = O.OracleModel(alphabet_path=paths["alphabet"])
+        om.read_lexicon(path)
+        om.build()
+        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), 32)
+        b.free()
+        os.unlink(path)
+        return {"workload": "BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon, 1.25 M of the 10 M length-bucketed queries len 4-32, k=3 d=2 n=10",
+                "ms_per_batch": dt * 1e3, "ms_per_1M_queries": dt * 1e3 / 1.25, "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt,
+                "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "scan_tiles": st["n_scan_blocks"], "parity": chk}
+
+    def configs4_share():  # search mode: one GPU's 12.5 MB of the 100 MB running text, n-gram windows + bigram LM
+        import random
+        from oracle import twin as T
+        if os.path.join(REPO, "tests") not in sys.path:
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+        from search_common import TwinOverOracle   # the checker of tests/test_gpu_config4.py
+        eng_words = synth.load_lexicon_words(paths["eng"])
+        m = A.VariantModel(paths["alphabet"], A.Weights(), device=device)
+        m.read_lexicon(paths["eng"])
+        rng = random.Random(7)
+        common = [w for w in eng_words if w.isalpha()][::23][:5000]
+        lm = [(f"{rng.choice(common)} {rng.choice(common)}", rng.randrange(1, 20)) for _ in range(20000)]
+        lm += [(f"<bos> {w}", 5) for w in common[:500]]
+        LM = A.VocabParams(vocabtype="LM")
+        for t_, f_ in lm:
+            m.add_to_vocabulary(t_, f_, LM)
+        m.build()
+        texts = synth.make_running_text(common, 12.5, seed=7)
+        nbytes = sum(len(t_.encode("utf-8")) for t_ in texts)
+        sp = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, max_ngram=3, **{k: v for k, v in std.items() if k != "max_matches"})
+        m.find_all_matches_arrays(texts[:2000], sp)  # warm-up (device pool, pinned buffers)
+        best = None
+        for _ in range(2):
+            t = time.perf_counter()
+            off, ma, ra = m.find_all_matches_arrays(texts, sp)
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        # parity: sampled texts through the oracle twin's segmentation / lattice / LM code, per-segment find_variants by the C oracle
+        tw = TwinOverOracle(T.read_alphabet(paths["alphabet"]))
+        tw.read_vocabulary(paths["eng"])
+        for t_, f_ in lm:
+            tw.add_lm(t_, f_)
+        tw.build()
+        om = O.OracleModel(alphabet_path=paths["alphabet"])
+        om.read_lexicon(paths["eng"])
+        om.build()
+        tw.attach(om)
+        tp = T.SearchParams(("abs", 3), ("abs", 2), 10, 0.25, 2.0, False, 0.0, max_ngram=3)
+        nchk = 6
+        for i in random.Random(5).sample(range(len(texts)), nchk):
+            exp = tw.find_all_matches(texts[i], tp)
+            got = ma[off[i]:off[i + 1]]
+            if [(int(g_["begin"]), int(g_["end"])) for g_ in got] != [(e.begin, e.end) for e in exp]:
+                raise RuntimeError(f"parity spot check failed: segmentation of text {i}")
+            for g_, e in zip(got, exp):
+                ev = e.variants or []
+                rows = ra[int(g_["vb"]):int(g_["ve"])]
+                if [int(v) for v in rows["vocab_id"]] != [v.vocab_id for v in ev] or (ev and int(g_["selected"]) != e.selected) \
+                        or any(abs(float(r["dist"]) - w.dist_score) > 1e-6 for r, w in zip(rows, ev)):
+                    raise RuntimeError(f"parity spot check failed: text {i}, match {e.text!r}")
+        return {"workload": "BASELINE.json configs[4], one GPU's share: 12.5 MB of synthetic running text (sentences of 5-25 perturbed words), max_ngram 3, bigram LM, anx_find_all_matches_batch",
+                "MB_per_s": nbytes / 1e6 / best, "seconds": best, "matches": int(off[-1]), "variant_rows": int(ra.shape[0]),
+                "parity": f"ok ({nchk} texts = {8 * nchk} sentences vs the oracle twin)"}
+
+    guarded("nld_len16_d2", nld_len16_d2)
+    guarded("configs2_nld_d3_confusables", configs2)
+    guarded("configs3_share", configs3_share)
+    guarded("configs4_share_search", configs4_share)
+    return out
+
+
+def single_process(args):
+    """--single-process: ONE process, --gpus N replicas of the lexicon behind the C ABI (anx_model_to_devices: one host thread and
+    one stream per device, contiguous input ranges, rows concatenated in input order).  Weak scaling like the rank form: every
+    replica gets --queries inputs.  No torch.distributed and no collective: the rows are host-consumed."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the variant-query path has no CPU fallback")
+    import analiticcl_amd as A
+    from analiticcl_amd import synth
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    devices = [0] * n if args.replicas_on_one_gpu else list(range(n))
+    if max(devices) >= ndev:
+        raise SystemExit(f"bench.py --single-process --gpus {n}: only {ndev} device(s) visible (use --replicas-on-one-gpu for a dry run)")
+    paths = synth.materialize_golden(os.path.join(tempfile.gettempdir(), f"anx_bench_data_{os.getuid()}_sp"))
+    model = A.VariantModel(paths["alphabet"], A.Weights(), devices=devices)
+    model.read_lexicon(paths[args.lexicon])
+    model.build()
+    words = synth.load_lexicon_words(paths[args.lexicon])
+    per = [synth.make_queries(words, args.queries, max_len=args.max_len, seed=synth.SEED + r) for r in range(n)]  # the rank form's shards
+    queries = [q for part in per for q in part]
+    params = A.SearchParameters(max_anagram_distance=args.anagram_distance, max_edit_distance=args.edit_distance, max_matches=10,
+                                score_threshold=0.25, cutoff_threshold=2.0)
+    A.set_switch("ANX_SHARD_MIN", 1024)
+    batches = [model.encode_batch(queries, params) for _ in range(2)]
+    shards = batches[0].shards()
+    assert len(shards) == n, shards
+    inflight = []
+    kernel_ms = {"ms_scan_kernel": 0.0, "ms_filter_score_kernel": 0.0, "ms_total": 0.0}
+    done = [0]
+
+    def finish(collect):
+        b = batches[inflight.pop(0)]
+        b.wait()
+        if collect:
+            st_ = b.stats()
+            for k in kernel_ms:
+                kernel_ms[k] += st_[k]
+            done[0] += 1
+
+    def step(k, collect):
+        i = k & 1
+        if i in inflight:
+            finish(collect)
+        batches[i].run_async(0)
+        inflight.append(i)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    for k in range(args.warmup):
+        step(k, False)
+    while inflight:
+        finish(False)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, True)
+    while inflight:
+        finish(True)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    st = batches[0].stats()
+    # shard == whole: replica 0's rows equal those of the same queries run on a one-replica batch
+    check = None
+    if not args.timed_only:
+        off, vid, dist_, _f = batches[0].fetch_arrays()
+        A.set_switch("ANX_SHARD_MIN", 1 << 30)
+        b1 = model.encode_batch(per[-1], params)   # the LAST replica's inputs, on one replica
+        A.set_switch("ANX_SHARD_MIN", 1024)
+        b1.run()
+        o1, v1, d1, _f1 = b1.fetch_arrays()
+        b1.free()
+        lo = (n - 1) * args.queries
+        import numpy as np
+        same = np.array_equal(o1, off[lo:] - off[lo]) and np.array_equal(v1, vid[off[lo]:]) and np.array_equal(d1, dist_[off[lo]:])
+        check = "ok" if same else "rows of the last shard differ from a one-replica run of the same inputs"
+    steps = max(args.steps, 1)
+    scan_ms, fs_ms = kernel_ms["ms_scan_kernel"] / steps, kernel_ms["ms_filter_score_kernel"] / steps
+    # per-launch figures of ONE replica (the slowest): the roofline is a per-kernel quantity
+    st1 = dict(st)
+    for k in ("n_queries", "n_pairs", "n_class_tests", "n_results", "n_scan_blocks", "n_pair_slots", "n_survivors", "n_selected"):
+        st1[k] = st[k] / n
+    st1["n_tests_kind"] = [x / n for x in st["n_tests_kind"]]
+    roofline = roofline_of(args, model, per[0], st1, scan_ms, fs_ms, kernel_ms["ms_total"] / steps)
+    ncores = usable_cores()
+    cpu = cpu_baseline_of(args, paths, per[0], ncores, 15.0 if n == 1 else 6.0) if (args.cpu_sample != 0 and not args.timed_only) else None
+    out = {
+        "metric": baseline_metric(), "value": st["n_pairs"] * args.steps / elapsed, "unit": "pairs/s",
+        "queries_per_s": st["n_queries"] * args.steps / elapsed, "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": f"{args.lexicon}.aspell lexicon + simple.alphabet, {args.queries} synthetic queries len<={args.max_len} per GPU, "
+                               f"k={args.anagram_distance} d={args.edit_distance} n=10 score-threshold 0.25 cutoff 2.0",
+                   "queries_per_gpu": args.queries, "lexicon_entries": model.num_instances(), "anagram_classes": model.num_classes(),
+                   "pairs_per_query": st["n_pairs"] / max(st["n_queries"], 1),
+                   "parallelism": f"query-sharded x{n}, ONE process: anx_model_to_devices({devices}), one host thread + stream per replica, rows concatenated on the host (no collective)"},
+        "pipelining": "2 resident copies of the sharded batch, anx_batch_run_async on every replica's own stream, waited for a step later",
+        "shards": shards, "shard_check": check, "process_group": None, "roofline": roofline, "cpu_baseline": cpu,
+    }
+    for b in batches:
+        b.free()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,10 +561,19 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the export + gather code at N=1 too (testing)")
     ap.add_argument("--timed-only", action="store_true", help="skip the passes after the timed region (two-stream overlap, end to end, CPU baseline): for rocprofv3 runs")
-    ap.add_argument("--check-gather", action="store_true", help="rank 0: decode its own gathered export of the last step and compare it with fetch()")
+    ap.add_argument("--check-gather", action="store_true", help="rank 0: compare every rank's gathered export of the last step with that rank's fetch()")
+    ap.add_argument("--single-process", action="store_true", help="one process, --gpus N replicas behind the C ABI (anx_model_to_devices)")
+    ap.add_argument("--replicas-on-one-gpu", action="store_true", help="with --single-process: all replicas on device 0")
+    ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="N", help="N ranks, all on device 0 (dry run of the N-rank control flow)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the result gather")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-config numbers measured after the timed region")
     args = ap.parse_args()
+    if args.ranks_on_one_gpu:
+        args.gpus = args.ranks_on_one_gpu
+    if args.single_process:
+        return single_process(args)
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # (also --ranks-on-one-gpu N)
         # `python bench.py --gpus N` without a launcher: start the N ranks as a fresh child (nothing here has touched the
         # GPU yet -- a process that has initialised HIP must not be replaced) and relay its output and exit code
         import subprocess
@@ -92,19 +592,39 @@ def main():
                          f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or run `python bench.py --gpus {args.gpus}` alone")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the variant-query path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = 0 if args.ranks_on_one_gpu else local_rank
+    torch.cuda.set_device(device)
     use_dist = world > 1 or "WORLD_SIZE" in os.environ  # under a launcher the process group is set up at N=1 too (RCCL init + the
     if use_dist:                                          # collectives below run with one rank: what a one-GPU box can exercise)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
+    stage_host = use_dist and args.backend == "gloo"  # gloo moves host memory: the exported records are staged through pinned buffers
 
     import analiticcl_amd as A
     from analiticcl_amd import synth
 
-    paths = synth.materialize_golden(os.path.join(tempfile.gettempdir(), f"anx_bench_data_{os.getuid()}_{local_rank}"))
-    model = A.VariantModel(paths["alphabet"], A.Weights(), device=local_rank)
-    model.read_lexicon(paths[args.lexicon])
-    model.build()
+    paths = synth.materialize_golden(os.path.join(tempfile.gettempdir(), f"anx_bench_data_{os.getuid()}_{rank}"))
+    model = A.VariantModel(paths["alphabet"], A.Weights(), device=device)
+    if world > 1:
+        # N concurrent index builds would oversubscribe the host (the GPU boxes grant 16 CPUs): rank 0 builds and saves the image
+        # (anx_model_save_index), the others load it
+        image = os.path.join(tempfile.gettempdir(), f"anx_bench_index_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{args.lexicon}.idx")
+        if rank == 0:
+            model.read_lexicon(paths[args.lexicon])
+            model.build()
+            model.save_index(image)
+        dist.barrier()
+        if rank != 0:
+            model.load_index(image)
+        dist.barrier()
+        if rank == 0:
+            os.unlink(image)
+    else:
+        model.read_lexicon(paths[args.lexicon])
+        model.build()
     words = synth.load_lexicon_words(paths[args.lexicon])
     queries = synth.make_queries(words, args.queries, max_len=args.max_len, seed=synth.SEED + rank)
     params = A.SearchParameters(max_anagram_distance=args.anagram_distance, max_edit_distance=args.edit_distance, max_matches=10,
@@ -124,7 +644,11 @@ def main():
     # Compact records (offsets + the rows in use: 74 MB per million queries of this workload instead of 176 MB at a
     # fixed stride), sizes exchanged one step ahead of the payloads: analiticcl_amd/shard.py CompactGather.
     from analiticcl_amd import shard
-    gather = shard.CompactGather(shard.compact_capacity(args.queries, stride + 5), "cuda", rank, world) if do_gather else None
+    cap = shard.compact_capacity(args.queries, stride + 5)
+    gather = shard.CompactGather(cap, "cpu" if stage_host else "cuda", rank, world) if do_gather else None
+    dev_stage = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(2)] if (do_gather and stage_host) else None
+    if do_gather and stage_host:
+        gather.send = [t.pin_memory() for t in gather.send]
     step_no = [0]
     gather_bytes = [0]
     gather_error = [None]
@@ -148,7 +672,13 @@ def main():
             try:
                 j = step_no[0] & 1
                 buf = gather.acquire(j)        # the stream waits for the transfer that last used this buffer
-                used = b.export_compact(buf.data_ptr(), buf.numel(), hs)
+                if stage_host:                 # gloo: device export -> pinned host buffer, then the exchange
+                    used = b.export_compact(dev_stage[j].data_ptr(), dev_stage[j].numel(), hs)
+                    with torch.cuda.stream(stream):
+                        buf[:used].copy_(dev_stage[j][:used], non_blocking=True)
+                    stream.synchronize()
+                else:
+                    used = b.export_compact(buf.data_ptr(), buf.numel(), hs)
                 gather.submit(j, used)
                 gather_bytes[0] = used
                 step_no[0] += 1
@@ -219,188 +749,64 @@ def main():
     pairs, nq, tests = (float(x) for x in tot.tolist())
 
     gather_check = None
-    if rank == 0 and do_gather and args.check_gather and gather_error[0] is None:
-        last = (step_no[0] - 1) & 1
-        mine = gather.result(last)[0]           # rank 0's own export as it sits in the gather buffers
-        dec = shard.decode_compact(mine, args.queries)
-        ref = batches[0].fetch()
-        bad = sum(1 for a_, b_ in zip(dec, ref) if [(v, d) for v, d, _f in a_] != [(v, d) for v, d, _f in b_])
-        gather_check = "ok" if bad == 0 and len(dec) == len(ref) else f"{bad} of {len(ref)} inputs differ"
+    if do_gather and args.check_gather and gather_error[0] is None:
+        # every rank: a digest of its own fetch() (offsets, vocab ids, dist scores: the fields of a compact record); rank 0: the same
+        # digest of every rank's export as it sits in the gather buffers of the last step.  (Both resident copies hold the same
+        # queries, so the last step's export equals batches[0]'s rows.)
+        import hashlib
+
+        import numpy as np
+
+        def digest(off, vid, dscore):
+            h = hashlib.sha256()
+            for a_ in (np.ascontiguousarray(off, dtype="<u4"), np.ascontiguousarray(vid, dtype="<u4"), np.ascontiguousarray(dscore, dtype="<f8")):
+                h.update(a_.tobytes())
+            return h.hexdigest()
+        off_, vid_, dist_, _freq = batches[0].fetch_arrays()
+        mine = digest(off_, vid_, dist_)
+        digests = [mine]
+        if use_dist:
+            digests = [None] * world
+            dist.all_gather_object(digests, mine)
+        if rank == 0:
+            last = (step_no[0] - 1) & 1
+            bad = []
+            for r, part in enumerate(gather.result(last)):
+                raw = part.cpu().numpy().tobytes()
+                o_ = np.frombuffer(raw, dtype="<u4", count=args.queries + 1)
+                rows_ = np.frombuffer(raw, dtype=shard.TOPK_DTYPE, count=int(o_[args.queries]), offset=shard.compact_offsets_bytes(args.queries))
+                if digest(o_, rows_["vocab_id"], rows_["dist_score"]) != digests[r]:
+                    bad.append(r)
+            gather_check = "ok" if not bad else f"ranks {bad} differ"
     if rank == 0:
         for k in stage_ms:
             stage_ms[k] /= max(args.steps, 1)
-        # ---- roofline of the dominant kernel (per launch, rank 0) --------------------------------------
-        # The dominant kernel = the slowest kernel of THIS run (k_scan_bits or k_filter_score, HIP events around each launch on
-        # the launch stream: anx_batch_stats.ms_scan_kernel / ms_filter_score_kernel); "per_kernel" carries both.
-        # Algorithmic bytes per launch:
-        #  k_scan_bits: query planes 16 B/query + tile descriptors 44 B/tile + class record, signature 44 B/class
-        #               (each once per launch) + pair list out 8 B/slot;
-        #  k_filter_score: what the kernel has to touch per materialised pair-list slot: pair record 8 B + query / entry
-        #               symbols and lengths 16 + 8 B, plus 16 B of survivor record per pair that passes the score threshold.
-        #               SURVEY.md section 8(d)'s literal figure (Lpad + 32 B for EVERY scored pair, i.e. 16 B of result per pair
-        #               although only survivors are written) is reported next to it as "survey_model".
-        # SURVEY.md section 8(d)'s whole-path figure, pairs*(Lpad+32) + queries*208, is reported as "pipeline".
-        lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
-        n_classes = model.num_classes()
-        scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 44 + n_classes * 44 + st["n_pair_slots"] * 8
-        fs_bytes = st["n_pair_slots"] * (8 + lpad + 8) + st["n_survivors"] * 16
-        fs_bytes_survey = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
         scan_ms, fs_ms = sum_scan_kernel_ms / max(args.steps, 1), sum_fs_kernel_ms / max(args.steps, 1)
-        if fs_ms > scan_ms:
-            kname, kbytes, kms = "k_filter_score", fs_bytes, fs_ms
-        else:
-            kname, kbytes, kms = "k_scan_bits", scan_bytes, scan_ms
-        achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        pipeline_bytes = st["n_pairs"] * (lpad + 32) + st["n_queries"] * 208
-        pipeline_gbs = pipeline_bytes / (stage_ms["ms_total"] * 1e-3) / 1e9 if stage_ms["ms_total"] > 0 else 0.0
-        # The bound that actually binds both kernels is VALU issue (89 % / 77 % VALU-active, profiles/): the floor below counts
-        # only the instructions the algorithm cannot do without, at the measured issue cost per wave-instruction per SIMD
-        # (tools/ubench_valu.hip: 2-operand ops 2.2 cycles, VOP3 ops such as v_bcnt / v_alignbit / v_sad_u8 4.3), over the
-        # 1024 SIMDs at 2.4 GHz.
-        #  scan: per 256 class tests of T planes T*4 v_and_b32 + T*4 v_bcnt_u32_b32 + 4 v_alignbit_b32.
-        SIMD_HZ = 1024 * 2.4e9
-        kinds = st["n_tests_kind"]
-        issue_cycles = (kinds[0] * (8 * 4.3 + 4.3) * 4 + sum(kinds[t] * (t * 4 * 6.5 + 4 * 4.3) for t in range(1, 5))) / 256.0
-        valu_floor_ms = issue_cycles / SIMD_HZ * 1e3
-        #  filter_score, per wave of 64 (DESIGN.md section 5 K2+K3): SWAR band filter of every slot over as many 4-symbol words as
-        #  the pair needs (the kernel picks 2 / 3 / 4 per wave; estimated here from the query lengths as ceil((len + 1) / 4)):
-        #  per word the unshifted comparison + 2d shifted ones + 2 x (and, bcnt) popcounts.  Alphabets of <= 124 classes (7-bit
-        #  symbol codes, the kernel's B7 instances): 2 mask ands, unshifted (xor, add, and, and) = 8.8 cycles, shifted
-        #  (alignbyte, xor, add, and | alignbyte, and) = 17.4; otherwise unshifted (xor, and, add, or, and, and) = 15.4, shifted
-        #  (alignbyte, xor, and, add, or3, and | alignbyte, and) = 24.0.
-        #  band DL of every selected pair: rows x (2d+1) cells x (2 min, 2 add, cmp, cndmask = 16 cycles), rows ~ mean query length;
-        #  tail of every DL survivor (LCS diagonal walk, prefix, suffix, f64 score) ~ 300 instructions = 900 cycles.
-        dd = args.edit_distance
-        nw = 4 if args.max_len <= 16 else 8
-        sample_q = queries[:20000]
-        mean_len = sum(len(q) for q in sample_q) / max(len(sample_q), 1)
-        words = sum(min(nw, (len(q) + 1 + 3) // 4) for q in sample_q) / max(len(sample_q), 1)
-        from analiticcl_amd import _lib as _L
-        b7 = _L.lib().anx_model_alphabet_size(model.h) < 0x7E  # = classes + 1 = the largest symbol code (unknown): engine.hip's condition
-        c_mask, c_unshifted, c_shifted = (4.4, 8.8, 17.4) if b7 else (0.0, 15.4, 24.0)
-        fs_cycles = (st["n_pair_slots"] / 64.0) * ((c_mask + c_unshifted + 2 * dd * c_shifted + 2 * 6.5) * words) \
-            + (st["n_selected"] / 64.0) * (mean_len * (2 * dd + 1) * 16.0) + (st["n_survivors"] / 64.0) * 900.0
-        fs_valu_floor_ms = fs_cycles / SIMD_HZ * 1e3
-        # HBM bytes per launch of that kernel from the committed PMC passes: only for the same workload AND the same kernel
-        # sources (the profile is tagged with a hash of csrc/*.hip, *.hpp; stale numbers are dropped)
-        traffic, traffic_src = None, None
-        try:
-            if (args.lexicon, args.max_len, args.anagram_distance, args.edit_distance, args.queries) == ("eng", 16, 3, 2, 1_000_000):
-                import glob
-                import hashlib
-                h = hashlib.sha256()
-                for f in sorted(glob.glob(os.path.join(REPO, "analiticcl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "analiticcl_amd", "csrc", "*.hpp"))):
-                    with open(f, "rb") as fh:
-                        h.update(fh.read())
-                for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
-                    with open(cand) as f:
-                        pj = json.load(f)
-                    if pj.get("kernel_src_sha256") == h.hexdigest():
-                        traffic, traffic_src = pj["kernels"][kname]["traffic_bytes"], os.path.basename(cand)
-                        break
-        except Exception:
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": kms,
-                    "algorithmic_bytes_per_launch": kbytes,
-                    "note": "integer scan / DL path: both kernels are VALU-issue bound, far below the HBM roof (DESIGN.md section 5); "
-                            "valu_issue_frac = algorithmic instruction floor / measured kernel time",
-                    "kernels_ms": {"k_scan_bits": scan_ms, "k_filter_score": fs_ms},
-                    "per_kernel": {name: {"avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
-                                          "achieved": (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
-                                          "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0),
-                                          "valu_issue_floor_ms": fl, "valu_issue_frac": (fl / ms if ms > 0 else 0.0)}
-                                   for name, nbytes, ms, fl in (("k_scan_bits", scan_bytes, scan_ms, valu_floor_ms),
-                                                                ("k_filter_score", fs_bytes, fs_ms, fs_valu_floor_ms))},
-                    "k_filter_score_survey_model": {"algorithmic_bytes_per_launch": fs_bytes_survey,
-                                                    "frac": (fs_bytes_survey / (fs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fs_ms > 0 else 0.0)},
-                    "pipeline_algorithmic_bytes": pipeline_bytes, "pipeline_gbs": pipeline_gbs,
-                    "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
-                    "scan_valu_issue_floor_ms": valu_floor_ms,
-                    "scan_valu_issue_frac": valu_floor_ms / scan_ms if scan_ms > 0 else 0.0,
-                    "scan_class_tests_per_s": st["n_class_tests"] / (scan_ms * 1e-3) if scan_ms > 0 else 0.0,
-                    "scan_tests_by_planes": kinds, "scan_tiles": st["n_scan_blocks"]}
-        # ---- end to end from host strings (never `value`): encode + upload, device run, download of the ranked rows ------
-        e2e = None
-        if world == 1 and not args.timed_only:
-            reps = []
-            # the queries as ONE host buffer, every string followed by a NUL byte: what a caller that reads its input from a
-            # file or a socket holds (the reference's CLI reads lines the same way, src/bin/analiticcl.rs:416-448); building it
-            # from a Python list of str costs more than the whole pipeline and is not part of the boundary
-            packed = ("\0".join(queries) + "\0").encode("utf-8")
-            for _ in range(3):
-                t = time.perf_counter()
-                b2 = model.encode_packed(packed, len(queries), params)
-                t1 = time.perf_counter()
-                b2.run(stream.cuda_stream)
-                t2 = time.perf_counter()
-                arrs = b2.fetch_arrays()
-                t3 = time.perf_counter()
-                b2.free()
-                reps.append((t3 - t, t1 - t, t2 - t1, t3 - t2, int(arrs[0][-1])))
-                del arrs  # the rows live in a pinned buffer of the library's cache: released here, reused by the next fetch
-            best = min(reps)
-            # the same with two host threads, each running encode -> run -> fetch on its own batches and its own stream (the
-            # library is thread-safe on one model): uploads, kernels and downloads of different batches overlap
-            import threading
-            nthr, per = 2, 8
-            streams2 = [torch.cuda.Stream() for _ in range(nthr)]
-            def worker(st2):
-                for _ in range(per):
-                    bb = model.encode_packed(packed, len(queries), params)
-                    bb.run(st2.cuda_stream)
-                    res = bb.fetch_arrays()
-                    del res
-                    bb.free()
-            th = [threading.Thread(target=worker, args=(x,)) for x in streams2]  # warm the pools of a second set of buffers
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            t = time.perf_counter()
-            th = [threading.Thread(target=worker, args=(x,)) for x in streams2]
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            piped = nthr * per * args.queries / (time.perf_counter() - t)
-            e2e = {"queries_per_s": args.queries / best[0], "two_threads_queries_per_s": piped, "s_per_batch": best[0], "encode_upload_s": best[1], "run_s": best[2],
-                   "download_s": best[3], "rows": best[4],
-                   "what": "host buffer of NUL-terminated UTF-8 strings -> anx_batch_encode_packed (H2D + device-side encoder) -> anx_batch_run -> "
-                           "anx_batch_fetch (ranked rows in input order, host memory), best of 3, one batch at a time, no overlap between batches"}
-        # ---- CPU baseline: the C oracle ("port" of the reference algorithm) on this box's host cores -----
-        cpu = None
+        n_classes = model.num_classes()
+        roofline = roofline_of(args, model, queries, st, scan_ms, fs_ms, stage_ms["ms_total"])
+        e2e = e2e_of(args, model, queries, params, stream.cuda_stream, torch) if (world == 1 and not args.timed_only) else None
         ncores = usable_cores()
-        if args.cpu_sample != 0 and world == 1 and not args.timed_only:  # reported at N=1 only
-            from oracle import cwrap as O
-            om = O.OracleModel(alphabet_path=paths["alphabet"])
-            om.read_lexicon(paths[args.lexicon])
-            om.build()
-            op = O.make_params(("abs", args.anagram_distance), ("abs", args.edit_distance), 10, 0.25, 2.0)
-            if args.cpu_sample > 0:
-                sample = min(args.cpu_sample, args.queries)
-            else:  # calibrate on a short run, then size the sample for ~15 s of wall time
-                ncal = min(args.queries, 16 * ncores)
-                t = time.perf_counter()
-                om.find_variants_batch(queries[:ncal], op, nthreads=ncores, stride=16)
-                rate = ncal / max(time.perf_counter() - t, 1e-3)
-                sample = int(max(ncal, min(args.queries, rate * 15.0)))
+        # the CPU baseline is reported from rank 0; at N > 1 on a shorter sample (the other ranks wait at the final barrier)
+        cpu = cpu_baseline_of(args, paths, queries, ncores, 15.0 if world == 1 else 6.0) if (args.cpu_sample != 0 and not args.timed_only) else None
+        # one resident copy, one run at a time (anx_batch_run: launch, wait, launch ...): the like-for-like figure of round 1's records
+        sync_ms = None
+        extras = None
+        if world == 1 and not args.timed_only:
             t = time.perf_counter()
-            rc, _res, _counts, cpairs, _ccls = om.find_variants_batch(queries[:sample], op, nthreads=ncores, stride=16)
-            dt = time.perf_counter() - t
-            # one thread as well: a short prefix of the same sample, ~5 s
-            n1 = int(max(64, min(sample, (sample / dt) / ncores * 5.0)))
-            t = time.perf_counter()
-            _rc, _r, _c, cpairs1, _cc = om.find_variants_batch(queries[:n1], op, nthreads=1, stride=16)
-            dt1 = time.perf_counter() - t
-            cpu = {"value": cpairs / dt, "unit": "pairs/s", "cores": ncores, "kind": "port",
-                   "single_thread": {"value": cpairs1 / dt1, "queries_per_s": n1 / dt1, "sample": f"first {n1} queries, {dt1:.1f} s"},
-                   "queries_per_s": sample / dt,
-                   "sample": f"first {sample} of the same {args.queries} queries, C oracle (oracle/anx_oracle.c), "
-                             f"OpenMP dynamic schedule, {ncores} threads (= usable cores: cgroup quota of {os.cpu_count()} hardware threads), {dt:.1f} s"}
+            for _ in range(max(3, args.steps // 2)):
+                batches[0].run(stream.cuda_stream)
+            sync_ms = (time.perf_counter() - t) / max(3, args.steps // 2) * 1e3
+            is_default = (args.lexicon, args.max_len, args.anagram_distance, args.edit_distance, args.queries) == ("eng", 16, 3, 2, 1_000_000)
+            if is_default and not args.no_extras and not do_gather:
+                for b_ in batches:
+                    b_.free()
+                extras = extra_configs(args, paths, device, ncores)
         out = {
             "metric": baseline_metric(),
             "value": pairs * args.steps / elapsed, "unit": "pairs/s",
+            "pipelining": "2 resident copies of the batch alternate, anx_batch_run_async on ONE stream, each waited for a step later (steady-state throughput)",
+            "sync_single_copy_ms_per_step": sync_ms,
+            "configs": extras,
             "queries_per_s": nq * args.steps / elapsed,
             # `value` counts the reference's scored pairs (every damerau_levenshtein call of gather_instances, src/lib.rs:1343);
             # 16 % of them fail its length test and are only counted, 2/3 of the rest are rejected by the exact prefilter:
@@ -423,7 +829,7 @@ def main():
                        + (f", result gather FAILED on rank 0: {gather_error[0]}" if gather_error[0] else "")},
             "stage_ms": {"scan": stage_ms["ms_scan"], "score": stage_ms["ms_score"], "compact": stage_ms["ms_group"], "rank": stage_ms["ms_rank"], "total": stage_ms["ms_total"]},
             "pair_slots": st["n_pair_slots"], "dl_pairs": st["n_selected"], "survivors": st["n_survivors"], "results": st["n_results"], "encode_upload_s": t_enc,
-            "gather_error": gather_error[0], "gather_check": gather_check, "process_group": ("nccl" if use_dist else None),
+            "gather_error": gather_error[0], "gather_check": gather_check, "process_group": (args.backend if use_dist else None), "ranks_on_one_gpu": bool(args.ranks_on_one_gpu),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -141,6 +141,16 @@ char *anx_index_read_tag(const char *path);
 uint64_t anx_model_num_lexicons(const anx_model *);
 const char *anx_model_lexicon_name(const anx_model *, uint64_t i);
 int anx_model_to_device(anx_model *, int device);
+/* Multi-GPU, one host process (the reference's fan-out over inputs inside one process: rayon par_iter,
+ * src/bin/analiticcl.rs:445-448, src/lib.rs:1883): replicate the built lexicon on the n listed HIP devices (normally every GPU of
+ * the node once; an ordinal may be listed more than once = several replicas on one GPU).  Every batch call below then splits its
+ * inputs into consecutive ranges, one per replica, each driven by the replica's own host thread on the replica's own stream, and
+ * returns the rows concatenated in input order -- there is no collective on this path, the rows are consumed on the host.  Calls
+ * with fewer than ANX_SHARD_MIN (8192) inputs per replica use fewer replicas.  Replaces the model's previous replicas.
+ * anx_model_to_device(m, d) == anx_model_to_devices(m, &d, 1). */
+int anx_model_to_devices(anx_model *, const int *devices, int n);
+int anx_model_num_replicas(const anx_model *);
+int anx_model_replica_device(const anx_model *, int replica); /* -1 when out of range */
 /* has(text), src/lib.rs:331; get_vocab(id), src/lib.rs:341 */
 int anx_model_has(const anx_model *, const char *utf8);
 uint64_t anx_model_vocab_size(const anx_model *);
@@ -178,7 +188,8 @@ anx_batch *anx_batch_encode(const anx_model *, const char *const *utf8, size_t n
  * is and the strings are found there (the first n NUL-terminated spans; anything behind them is ignored; fewer than n spans or
  * a buffer that does not end with a NUL byte: ANX_EINVAL).  An input may not contain a NUL byte itself (as in the char** form). */
 anx_batch *anx_batch_encode_packed(const anx_model *, const char *blob, size_t blob_len, size_t n, const anx_params *);
-/* `stream` is a hipStream_t (NULL = the default stream). Asynchronous except for one count read-back. */
+/* `stream` is a hipStream_t (NULL = the default stream).  A model with several replicas runs every shard of the batch on its
+ * replica's own stream: `stream` must then be NULL. */
 int anx_batch_run(const anx_model *, anx_batch *, void *stream);
 /* The same in two halves.  run_async enqueues the whole pipeline on `stream` and returns (no host round trip inside a run: grids
  * and buffers are sized from the batch's previous run or from estimates, every kernel bounds-checks, one read-back at the end);
@@ -222,7 +233,12 @@ typedef struct anx_batch_stats {
   uint64_t n_selected;       /* pairs that passed the prefilter and went through the DL kernels */
   float ms_filter_score_kernel; /* HIP events directly around the k_filter_score launch */
 } anx_batch_stats;
+/* counts summed over the shards of the batch, times of the slowest replica */
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
+/* the replicas a batch is spread over: shard i holds the inputs [first_input, first_input + n_inputs) on HIP device *device
+ * (any out pointer may be NULL).  anx_batch_export_topk / _compact need a batch with exactly one shard. */
+int anx_batch_num_shards(const anx_batch *);
+int anx_batch_shard_info(const anx_batch *, int shard, int *device, size_t *first_input, size_t *n_inputs);
 /* Waits for asynchronous exports of the batch (anx_batch_export_topk / _compact on the caller's stream), then releases it. */
 void anx_batch_free(anx_batch *);
 /* Device scratch (pair lists, survivor rows: several GB per million queries) comes from a per-device pool that keeps freed
@@ -230,6 +246,11 @@ void anx_batch_free(anx_batch *);
  * Vec storage inside find_variants, src/lib.rs:1311-1402).  This hands the cached blocks back to the driver, e.g. before
  * another library needs the memory. */
 void anx_device_pool_trim(int device);
+
+/* A/B, test and tuning switches (DESIGN.md section 8 "Switches").  The library reads them ONCE from the environment when it is first
+ * used; a variable set later has no effect.  This sets one at run time: name = the variable's name ("ANX_ENCODE", "ANX_SHARD_MIN",
+ * ...), value = what the variable would hold (NULL = unset).  None of them changes results.  ANX_EINVAL: unknown name. */
+int anx_debug_set_switch(const char *name, const char *value);
 
 /* ---- output of `analiticcl query` --------------------------------------------------
  * The TSV lines / JSON items of output_matches_as_tsv / output_matches_as_json (src/bin/analiticcl.rs:21-187) for n

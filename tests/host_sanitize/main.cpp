@@ -11,9 +11,118 @@
 static int checks = 0;
 #define CHECK(c) do { ++checks; if (!(c)) { fprintf(stderr, "CHECK failed line %d: %s (%s)\n", __LINE__, #c, anx_last_error()); return 1; } } while (0)
 
+// Multi-replica sharding of the batch calls against the fake devices of stub_engine.cpp (ANX_STUB_FAKE=1): the results of a call
+// must not depend on the number of replicas or on the form the inputs are passed in.
+static int shards_mode(const std::string& alphabet, const std::string& lexicon) {
+  anx_weights w; anx_default_weights(&w);
+  anx_vocab_params vp; anx_default_vocab_params(&vp);
+  anx_params p; anx_default_params(&p);
+  std::vector<std::string> in;
+  uint64_t x = 88172645463325252ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (int i = 0; i < 5000; ++i) {
+    std::string s;
+    const size_t len = i % 97 == 0 ? 0 : (i > 4000 ? 1 + rnd() % 3 : rnd() % 40);  // empty strings, a short-string tail: uneven byte split
+    for (size_t j = 0; j < len; ++j) s.push_back((char)('a' + rnd() % 26));
+    in.push_back(s);
+  }
+  std::vector<const char*> ptrs;
+  std::string packed;
+  for (const std::string& s : in) { ptrs.push_back(s.c_str()); packed += s; packed.push_back('\0'); }
+  std::vector<anx_result> ref_rows, conf_rows;
+  std::vector<size_t> ref_off, conf_off;
+  std::vector<uint32_t> ref_counts;
+  size_t ref_pairs = 0;
+  for (int nrep : {1, 2, 3, 4}) {
+    anx_model* m = anx_model_new(alphabet.c_str(), &w, 0);
+    CHECK(m != nullptr);
+    CHECK(anx_model_read_vocabulary(m, lexicon.c_str(), &vp) == ANX_OK);
+    if (nrep == 3) CHECK(anx_model_add_to_confusables(m, "-[a]+[e]", 1.05) == ANX_OK);  // the rescoring path keeps the inputs on the host
+    CHECK(anx_model_build(m, -1) == ANX_OK);
+    const int devs[4] = {0, 1, 1, 3};
+    CHECK(anx_model_to_devices(m, devs, nrep) == ANX_OK);
+    CHECK(anx_model_num_replicas(m) == nrep && anx_model_replica_device(m, nrep - 1) == devs[nrep - 1] && anx_model_replica_device(m, nrep) == -1);
+    CHECK(anx_debug_set_switch("ANX_SHARD_MIN", nrep == 4 ? "2000" : "1") == ANX_OK);  // 2000: 5000 inputs use 2 of the 4 replicas
+    CHECK(anx_debug_set_switch("ANX_NO_SUCH_SWITCH", "1") == ANX_EINVAL);
+    for (int form = 0; form < 3; ++form) {
+      anx_result* rows = nullptr; size_t* off = nullptr;
+      anx_batch* b = nullptr;
+      if (form == 0) {
+        CHECK(anx_find_variants_batch(m, ptrs.data(), ptrs.size(), &p, &rows, &off) == ANX_OK);
+      } else {
+        b = form == 1 ? anx_batch_encode(m, ptrs.data(), ptrs.size(), &p) : anx_batch_encode_packed(m, packed.data(), packed.size(), in.size(), &p);
+        CHECK(b != nullptr);
+        CHECK(anx_batch_num_shards(b) == (nrep == 4 ? 2 : nrep));
+        int dev = -1; size_t lo = 99, cnt = 0, total = 0;
+        for (int g = 0; g < anx_batch_num_shards(b); ++g) { CHECK(anx_batch_shard_info(b, g, &dev, &lo, &cnt) == ANX_OK && lo == total && dev == devs[g]); total += cnt; }
+        CHECK(total == in.size());
+        CHECK(anx_batch_run_async(m, b, nullptr) == ANX_OK && anx_batch_wait(m, b) == ANX_OK);
+        if (nrep > 1) CHECK(anx_batch_run(m, b, (void*)0x10) == ANX_EINVAL);  // a caller stream with several replicas
+        CHECK(anx_batch_fetch(b, &rows, &off) == ANX_OK);
+        anx_batch_stats st;
+        CHECK(anx_batch_get_stats(b, &st) == ANX_OK && st.n_queries == in.size() && (nrep == 3 || st.n_results == off[in.size()]));
+        uint32_t* counts = nullptr;
+        CHECK(anx_batch_pair_counts(b, &counts) == ANX_OK);
+        anx_pair* pairs = nullptr; size_t npairs = 0;
+        CHECK(anx_batch_fetch_pairs(b, &pairs, &npairs) == ANX_OK);
+        if (ref_counts.empty()) { ref_counts.assign(counts, counts + in.size()); ref_pairs = npairs; }
+        CHECK(memcmp(ref_counts.data(), counts, in.size() * sizeof(uint32_t)) == 0 && npairs == ref_pairs);
+        size_t w0 = 0;  // pairs come shard by shard, each shard's in input order, with call-wide query indices
+        for (size_t i = 0; i < in.size(); ++i)
+          for (size_t j = 0; j < in[i].size(); ++j, ++w0) CHECK(pairs[w0].query == i && pairs[w0].vocab_id == (uint32_t)(unsigned char)in[i][j]);
+        anx_counts_free(counts);
+        anx_pairs_free(pairs);
+        size_t used = 0;
+        if (anx_batch_num_shards(b) > 1) CHECK(anx_batch_export_compact(b, &used, 8, nullptr, &used) == ANX_EINVAL);
+      }
+      // confusables loaded (nrep == 3): the host rescoring applies the cutoff -- compared across the three input forms only
+      std::vector<size_t>& roff = nrep == 3 ? conf_off : ref_off;
+      std::vector<anx_result>& rrows = nrep == 3 ? conf_rows : ref_rows;
+      if (roff.empty()) { roff.assign(off, off + in.size() + 1); rrows.assign(rows, rows + off[in.size()]); }
+      CHECK(memcmp(roff.data(), off, (in.size() + 1) * sizeof(size_t)) == 0);
+      CHECK(off[in.size()] == rrows.size() && memcmp(rrows.data(), rows, rrows.size() * sizeof(anx_result)) == 0);
+      anx_results_free(rows, off);
+      anx_batch_free(b);
+    }
+    // packed form: more strings announced than present / trailing strings beyond n are ignored
+    CHECK(anx_batch_encode_packed(m, packed.data(), packed.size(), in.size() + 1, &p) == nullptr && strstr(anx_last_error(), "fewer strings") != nullptr);
+    {
+      anx_batch* b = anx_batch_encode_packed(m, packed.data(), packed.size(), in.size() - 1234, &p);
+      CHECK(b != nullptr);
+      anx_result* rows = nullptr; size_t* off = nullptr;
+      CHECK(anx_batch_run(m, b, nullptr) == ANX_OK && anx_batch_fetch(b, &rows, &off) == ANX_OK);
+      if (nrep != 3) CHECK(memcmp(ref_off.data(), off, (in.size() - 1234 + 1) * sizeof(size_t)) == 0);
+      anx_results_free(rows, off);
+      anx_batch_free(b);
+    }
+    {  // a call below the shard minimum uses one replica; an empty call works
+      CHECK(anx_debug_set_switch("ANX_SHARD_MIN", nullptr) == ANX_OK);
+      anx_batch* b = anx_batch_encode(m, ptrs.data(), 100, &p);
+      CHECK(b != nullptr && anx_batch_num_shards(b) == 1);
+      anx_batch_free(b);
+      anx_result* rows = nullptr; size_t* off = nullptr;
+      CHECK(anx_find_variants_batch(m, ptrs.data(), 0, &p, &rows, &off) == ANX_OK && off[0] == 0);
+      anx_results_free(rows, off);
+    }
+    // search mode drives the same staged calls: texts over several replicas
+    if (nrep == 2) {
+      CHECK(anx_debug_set_switch("ANX_SHARD_MIN", "1") == ANX_OK);
+      anx_search_params sp; anx_default_search_params(&sp);
+      const char* texts[2] = {"I tink you are rihgt", "so it is"};
+      anx_match* ms = nullptr; size_t* mo = nullptr; anx_result* rr = nullptr; size_t nr = 0; anx_match_tag* tg = nullptr;
+      CHECK(anx_find_all_matches_batch(m, texts, 2, &sp, &ms, &mo, &rr, &nr, &tg) == ANX_OK);
+      anx_matches_free(ms, mo, rr, tg);
+    }
+    anx_model_free(m);
+  }
+  printf("OK %d\n", checks);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 4) return 2;
   const std::string alphabet = argv[1], lexicon = argv[2], tmp = argv[3];
+  if (argc > 4 && strcmp(argv[4], "shards") == 0) return shards_mode(alphabet, lexicon);
   anx_weights w; anx_default_weights(&w);
   anx_vocab_params vp; anx_default_vocab_params(&vp);
   anx_model* m = anx_model_new(alphabet.c_str(), &w, 0);
@@ -74,7 +183,7 @@ int main(int argc, char** argv) {
   // packed buffers: the host-side offset scan (confusables are loaded, so the host needs the strings for rescoring)
   {
     const char packed[] = "seperate\0\0\x01x\0acommodate\0longer than eight bytes\0";  // sizeof counts the terminator too
-    CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 1, 5, &p) == nullptr && strstr(anx_last_error(), "stub") != nullptr);
+    CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 1, 5, &p) == nullptr && strstr(anx_last_error(), "not resident") != nullptr);
     CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 1, 6, &p) == nullptr && strstr(anx_last_error(), "fewer strings") != nullptr);
     CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 2, 2, &p) == nullptr && strstr(anx_last_error(), "must end with a NUL") != nullptr);
     CHECK(anx_batch_encode_packed(m, packed, 0, 0, &p) == nullptr);

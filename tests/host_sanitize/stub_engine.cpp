@@ -1,29 +1,106 @@
-// Device side replaced by "no device" stubs so that the HOST code of libanx (model, index, confusables, context rules,
-// index image, formatters, C ABI) can run under AddressSanitizer / UBSan on a box without a GPU.  Test infrastructure.
+// Device side replaced by stubs so that the HOST code of libanx (model, index, confusables, context rules, index image,
+// formatters, C ABI, and the multi-replica sharding of the batch calls) can run under AddressSanitizer / UBSan on a box without
+// a GPU.  Test infrastructure.  Default: "no device" (every device call fails).  With ANX_STUB_FAKE=1 in the environment the stub
+// pretends to be 4 devices whose "engine" derives a deterministic result list from the bytes of every input alone, so that
+// shard == whole can be checked for the host-side split / concatenation logic.
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
 #include "../../analiticcl_amd/csrc/engine.h"
 
 namespace anx {
-int device_count(std::string& err) { err = "stub: no device"; return 0; }
-DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, int, std::string& err) { err = "stub: no device"; return nullptr; }
-void lexicon_free(DeviceLexicon*) {}
+struct DeviceLexicon { int device; };
+struct Batch {
+  std::vector<std::string> in;
+  bool ran = false;
+  std::vector<anx_result> rows;
+  std::vector<size_t> off;
+};
+static bool fake() { const char* e = getenv("ANX_STUB_FAKE"); return e && e[0] == '1'; }
+static uint64_t fnv(const std::string& s) { uint64_t h = 1469598103934665603ull; for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; } return h; }
+
+int device_count(std::string& err) { if (fake()) return 4; err = "stub: no device"; return 0; }
+DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, int device, std::string& err) {
+  if (!fake()) { err = "stub: no device"; return nullptr; }
+  if (device < 0 || device >= 4) { err = "stub: invalid device ordinal"; return nullptr; }
+  return new DeviceLexicon{device};
+}
+void lexicon_free(DeviceLexicon* d) { delete d; }
 void device_pool_trim(int) {}
+void* stream_create(int, std::string&) { return malloc(1); }
+void stream_destroy(int, void* s) { free(s); }
 void* host_result_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void host_result_free(void* p) { free(p); }
-Batch* batch_encode(const HostModel&, const DeviceLexicon*, const char* const*, size_t, const anx_params&, std::string& err, int* code) {
-  err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
+Batch* batch_encode(const HostModel&, const DeviceLexicon* dl, const char* const* utf8, size_t n, const anx_params&, std::string& err, int* code) {
+  if (!dl) { err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr; }
+  Batch* b = new Batch();
+  for (size_t i = 0; i < n; ++i) b->in.emplace_back(utf8[i] ? utf8[i] : "");
+  return b;
 }
-Batch* batch_encode_spans(const HostModel&, const DeviceLexicon*, const char*, size_t, const uint32_t*, size_t, const anx_params&, std::string& err, int* code) {
-  err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr;
+Batch* batch_encode_spans(const HostModel&, const DeviceLexicon* dl, const char* blob, size_t bytes, const uint32_t* off, size_t n, const anx_params&, std::string& err, int* code) {
+  if (!dl) { err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr; }
+  Batch* b = new Batch();
+  if (off) {
+    for (size_t i = 0; i < n; ++i) b->in.emplace_back(blob + off[i], blob + off[i + 1] - 1);
+  } else {
+    size_t p = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const void* z = p < bytes ? memchr(blob + p, 0, bytes - p) : nullptr;
+      if (!z) { err = "packed inputs hold fewer strings than announced"; if (code) *code = ANX_EINVAL; delete b; return nullptr; }
+      const size_t e = (size_t)(static_cast<const char*>(z) - blob);
+      b->in.emplace_back(blob + p, blob + e);
+      p = e + 1;
+    }
+  }
+  return b;
 }
-int batch_run(const HostModel&, const DeviceLexicon*, Batch*, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
-int batch_run_async(const HostModel&, const DeviceLexicon*, Batch*, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
-int batch_wait(const HostModel&, const DeviceLexicon*, Batch*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
-int batch_fetch(const HostModel&, const DeviceLexicon*, const Batch*, anx_result**, size_t**, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
-int batch_fetch_pairs(const HostModel&, const DeviceLexicon*, const Batch*, anx_pair**, size_t*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
-int batch_pair_counts(const HostModel&, const DeviceLexicon*, Batch*, uint32_t**, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
+int batch_run(const HostModel&, const DeviceLexicon* dl, Batch* b, void*, std::string& err) {
+  if (!dl || !b) { err = "stub"; return ANX_ENODEVICE; }
+  b->rows.clear();
+  b->off.assign(1, 0);
+  for (const std::string& s : b->in) {
+    const uint64_t h = fnv(s);
+    for (size_t j = 0; j < s.size() % 4; ++j) b->rows.push_back(anx_result{h % 1000 + j, 1.0 / (1.0 + (double)j), 1.0, ANX_NO_VIA});
+    b->off.push_back(b->rows.size());
+  }
+  b->ran = true;
+  return ANX_OK;
+}
+int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* st, std::string& err) { return batch_run(m, dl, b, st, err); }
+int batch_wait(const HostModel&, const DeviceLexicon* dl, Batch* b, std::string& err) { if (!dl || !b || !b->ran) { err = "stub"; return ANX_ENODEVICE; } return ANX_OK; }
+size_t batch_n_results(const Batch* b) { return b->ran ? b->rows.size() : 0; }
+size_t batch_n_input(const Batch* b) { return b->in.size(); }
+int batch_fetch_into(const Batch* b, anx_result* rows, size_t* offs, size_t base, std::string& err) {
+  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  if (!b->rows.empty()) memcpy(rows, b->rows.data(), b->rows.size() * sizeof(anx_result));
+  for (size_t i = 0; i < b->off.size(); ++i) offs[i] = base + b->off[i];
+  return ANX_OK;
+}
+int batch_fetch(const HostModel&, const DeviceLexicon*, const Batch* b, anx_result** rows, size_t** offs, std::string& err) {
+  if (!b) { err = "stub"; return ANX_ENODEVICE; }
+  *rows = static_cast<anx_result*>(malloc((b->rows.size() + 1) * sizeof(anx_result)));
+  *offs = static_cast<size_t*>(malloc(b->off.size() * sizeof(size_t)));
+  return batch_fetch_into(b, *rows, *offs, 0, err);
+}
+int batch_fetch_pairs(const HostModel&, const DeviceLexicon*, const Batch* b, anx_pair** out, size_t* n, std::string& err) {
+  if (!b || !b->ran) { err = "stub"; return ANX_ENODEVICE; }
+  std::vector<anx_pair> v;
+  for (size_t i = 0; i < b->in.size(); ++i)
+    for (size_t j = 0; j < b->in[i].size(); ++j) v.push_back(anx_pair{(uint32_t)i, (uint32_t)(unsigned char)b->in[i][j], 0, 0, 0, 0, 1, 0, 0.0});
+  *out = static_cast<anx_pair*>(malloc((v.size() + 1) * sizeof(anx_pair)));
+  if (!v.empty()) memcpy(*out, v.data(), v.size() * sizeof(anx_pair));
+  *n = v.size();
+  return ANX_OK;
+}
+int batch_pair_counts(const HostModel&, const DeviceLexicon*, Batch* b, uint32_t** out, std::string& err) {
+  if (!b || !b->ran) { err = "stub"; return ANX_ENODEVICE; }
+  *out = static_cast<uint32_t*>(calloc(b->in.size() + 1, sizeof(uint32_t)));
+  for (size_t i = 0; i < b->in.size(); ++i) (*out)[i] = (uint32_t)b->in[i].size();
+  return ANX_OK;
+}
 int batch_export_topk(const DeviceLexicon*, const Batch*, void*, uint32_t, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_export_compact(const DeviceLexicon*, const Batch*, void*, size_t, void*, size_t*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
-void batch_stats(const Batch*, anx_batch_stats*) {}
-void batch_free(Batch*) {}
+void batch_stats(const Batch* b, anx_batch_stats* s) { memset(s, 0, sizeof *s); if (b) { s->n_queries = b->in.size(); s->n_results = b->rows.size(); s->ms_total = 1.0f; } }
+void batch_free(Batch* b) { delete b; }
 }  // namespace anx

@@ -26,3 +26,40 @@ def test_tsv_and_json_shapes():
 
 def test_threshold_parsing():
     assert cli._threshold("3") == 3 and cli._threshold("0.3") == 0.3 and cli._threshold("0.25;3") == (0.25, 3)
+
+
+def test_reference_flags_are_accepted():
+    """Every option of the reference's query / search subcommands parses (src/bin/analiticcl.rs:656-895, 944-949), including
+    the command line performance.md used (`query --progress`) and the flags whose consumers are dead in the reference."""
+    from analiticcl_amd import cli
+    p = cli.build_parser()
+    a = p.parse_intermixed_args(["--debug", "1", "query", "--alphabet", "a.tsv", "--lexicon", "l.tsv", "--progress", "--allow-overlap",
+                                 "--lm-order", "2", "--weight-context", "0.5", "-k", "2", "-d", "0.3;2", "--devices", "0,1"])
+    assert a.progress and a.debug == 1 and a.allow_overlap and a.lm_order == 2 and a.weight_context == 0.5 and a.devices == "0,1"
+    a = p.parse_intermixed_args(["search", "-a", "a.tsv", "-l", "l.tsv", "-D", "2", "-L", "3", "--per-line"])
+    assert a.debug == 2 and a.lm_order == 3 and not a.progress
+
+
+def test_progress_lines(capsys):
+    from analiticcl_amd import cli
+    pr = cli.Progress(True)
+    pr.show(1, 1)
+    t = [100.0]
+    pr.clock = lambda: t[0]
+    pr.last = 99.0
+    pr.show(2001, 2000)     # 2000 items in 1000 ms
+    err = capsys.readouterr().err.splitlines()
+    assert err[0] == "@ 1" and err[1] == "@ 2001 - processing speed was 2000 items per second"
+    cli.Progress(False).show(5, 5)
+    assert capsys.readouterr().err == ""
+
+
+def test_index_tag_sees_equals_spelling(tmp_path, monkeypatch):
+    import json
+    import sys
+    from analiticcl_amd import cli
+    f = tmp_path / "l.tsv"
+    f.write_text("a\n")
+    a = cli.build_parser().parse_intermixed_args(["query", "-a", "x", f"--lexicon={f}"])
+    monkeypatch.setattr(sys, "argv", ["prog", "query", "-a", "x", f"--lexicon={f}"])
+    assert json.loads(cli._index_tag(a))["argv_order"] == ["--lexicon"]

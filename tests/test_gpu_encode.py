@@ -24,17 +24,14 @@ RAW = [b"\xff\xfe", b"abc\xc3", b"\xe2\x82", b"ok\x80ok", b"\xf0\x9f\x98"]  # in
 def run_both(model, queries, params):
     out = {}
     for mode in ("device", "host"):
-        if mode == "host":
-            os.environ["ANX_ENCODE"] = "host"
-        else:
-            os.environ.pop("ANX_ENCODE", None)
+        A.set_switch("ANX_ENCODE", "host" if mode == "host" else None)
         try:
             b = model.encode_batch(queries, params)
             b.run()
             out[mode] = (b.fetch_arrays(), b.stats(), b.pair_counts())
             b.free()
         finally:
-            os.environ.pop("ANX_ENCODE", None)
+            A.set_switch("ANX_ENCODE", None)
     (da, ds, dc), (ha, hs, hc) = out["device"], out["host"]
     for x, y in zip(da, ha):
         assert np.array_equal(x, y)
@@ -113,13 +110,14 @@ def test_hash_probe_walk_equals_flat_walk(eng, data_dir, monkeypatch, kw):
     p = A.SearchParameters(**kw)
     out = {}
     for mode in ("probe", "flat"):
-        if mode == "flat":
-            monkeypatch.setenv("ANX_SCAN_WALK", "flat")
-        b = eng.encode_batch(qs, p)
-        b.run()
-        out[mode] = (b.fetch_arrays(), b.stats(), b.pair_counts())
-        b.free()
-        monkeypatch.delenv("ANX_SCAN_WALK", raising=False)
+        A.set_switch("ANX_SCAN_WALK", "flat" if mode == "flat" else None)
+        try:
+            b = eng.encode_batch(qs, p)
+            b.run()
+            out[mode] = (b.fetch_arrays(), b.stats(), b.pair_counts())
+            b.free()
+        finally:
+            A.set_switch("ANX_SCAN_WALK", None)
     (pa, ps, pc), (fa, fs, fc) = out["probe"], out["flat"]
     for x, y in zip(pa, fa):
         assert np.array_equal(x, y)
@@ -164,7 +162,7 @@ def test_packed_buffer_offsets_found_on_the_device(eng):
     with pytest.raises(A.AnxError, match="must end with a NUL"):
         eng.encode_packed(packed[:-1], 3, p)
     # the host encoder (A/B) takes the same buffer through the host-side offset scan
-    os.environ["ANX_ENCODE"] = "host"
+    A.set_switch("ANX_ENCODE", "host")
     try:
         b = eng.encode_packed(packed, len(words), p)
         b.run()
@@ -173,4 +171,4 @@ def test_packed_buffer_offsets_found_on_the_device(eng):
         with pytest.raises(A.AnxError, match="fewer strings than announced"):
             eng.encode_packed(packed, len(words) + 1, p)
     finally:
-        os.environ.pop("ANX_ENCODE", None)
+        A.set_switch("ANX_ENCODE", None)

@@ -1,0 +1,172 @@
+"""The multi-GPU split behind the C ABI (the reference's one-process fan-out over inputs,
+src/bin/analiticcl.rs:445-448, src/lib.rs:1883): anx_model_to_devices replicates the lexicon, every batch call shards its
+inputs over the replicas (one host thread + stream per replica) and returns the rows concatenated in input order.  The GPU boxes
+have ONE device, so the replicas here are {0, 0} / {0, 0, 0}: two or three copies of the lexicon on the one GPU, driven
+concurrently -- the code path of N GPUs except for the device ordinal.  shard == whole (rows, scores, pair counts, statistics)
+on the shapes of BASELINE configs[1], [2] (confusables) and [3] (long queries, StopAtExactMatch), the staged and the one-shot
+forms, variant lists, and search mode."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import analiticcl_amd as A
+from analiticcl_amd import synth
+
+CONF = os.path.join(synth.GOLDEN_DATA, "confusables10.tsv")
+
+
+@pytest.fixture(autouse=True)
+def _small_shards():
+    A.set_switch("ANX_SHARD_MIN", 64)   # the default (8192 inputs per replica) would keep the small cases on one replica
+    yield
+    A.set_switch("ANX_SHARD_MIN", None)
+
+
+def _model(data_dir, lex, devices, confusables=False, variants=None):
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), devices=devices)
+    g.read_lexicon(os.path.join(data_dir, f"{lex}.aspell.lexicon"))
+    if confusables:
+        g.read_confusablelist(CONF)
+    if variants:
+        g.read_variants(variants)
+    g.build()
+    return g
+
+
+def _run(g, qs, p, packed=False, counts=True):
+    if packed:
+        blob = b"".join(q.encode("utf-8") + b"\0" for q in qs)
+        b = g.encode_packed(blob, len(qs), p)
+    else:
+        b = g.encode_batch(qs, p)
+    b.run_async()
+    b.wait()
+    out = dict(arrays=b.fetch_arrays(), stats=b.stats(), shards=b.shards())
+    if counts:
+        out["counts"] = b.pair_counts()
+    b.run()  # a second run of a sharded batch (buffers sized from the first)
+    again = b.fetch_arrays()
+    for x, y in zip(out["arrays"], again):
+        assert np.array_equal(x, y)
+    b.free()
+    return out
+
+
+def _same(a, b, counts=True):
+    for x, y in zip(a["arrays"], b["arrays"]):
+        assert np.array_equal(x, y)
+    if counts:
+        assert np.array_equal(a["counts"], b["counts"])
+    for k in ("n_queries", "n_pairs", "n_results", "n_survivors"):
+        assert a["stats"][k] == b["stats"][k], k
+
+
+@pytest.mark.parametrize("lex,n,max_len,kw,conf", [
+    ("eng", 200_000, 16, dict(max_anagram_distance=3, max_edit_distance=2, max_matches=10), False),          # configs[1] shape
+    ("nld", 120_000, 24, dict(max_anagram_distance=3, max_edit_distance=3, max_matches=10), True),           # configs[2]: confusables
+    ("nld", 60_000, 32, dict(max_anagram_distance=3, max_edit_distance=2, max_matches=5, stop_criterion=True, freq_weight=0.5), False),
+])
+def test_two_and_three_replicas_equal_one(data_dir, lex, n, max_len, kw, conf):
+    words = synth.load_lexicon_words(os.path.join(data_dir, f"{lex}.aspell.lexicon"))
+    qs = synth.make_queries(words, n, max_len=max_len, seed=synth.SEED + 7)
+    qs[5] = ""            # inputs without results in the middle of a shard and at the shard edges
+    qs[n // 2 - 1] = ""
+    qs[n // 2] = "x" * 300
+    p = A.SearchParameters(**kw)
+    one = _run(_model(data_dir, lex, [0], conf), qs, p)
+    assert len(one["shards"]) == 1
+    for devices in ([0, 0], [0, 0, 0]):
+        g = _model(data_dir, lex, devices, conf)
+        assert g.num_replicas == len(devices)
+        for packed in (False, True):
+            got = _run(g, qs, p, packed=packed)
+            assert [s[0] for s in got["shards"]] == devices and sum(s[2] for s in got["shards"]) == n
+            assert all(got["shards"][i][1] + got["shards"][i][2] == got["shards"][i + 1][1] for i in range(len(devices) - 1))
+            _same(one, got)
+        # the one-shot call (anx_find_variants_batch) over the replicas
+        ids = g.find_variants_ids(qs[:30_000], p)
+        off, vid, dist, freq = one["arrays"]
+        for i in (0, 5, 77, 14_999, 15_000, 29_999):
+            assert ids[i] == [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
+        del g
+
+
+def test_uneven_byte_split_and_tail(data_dir):
+    """The packed form splits by BYTES: a buffer whose second half holds much shorter strings gives the replicas different
+    input counts; strings behind the announced n are ignored; more announced than present is an error."""
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    qs = synth.make_queries(words, 20_000, max_len=30, min_len=12, seed=5) + synth.make_queries(words, 60_000, max_len=4, seed=6)
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    one = _run(_model(data_dir, "eng", [0]), qs, p)
+    g = _model(data_dir, "eng", [0, 0])
+    got = _run(g, qs, p, packed=True)
+    assert got["shards"][0][2] != got["shards"][1][2]
+    _same(one, got)
+    blob = b"".join(q.encode("utf-8") + b"\0" for q in qs)
+    b = g.encode_packed(blob, 50_001, p)   # the announced n cuts inside the second shard
+    b.run()
+    off, vid, _d, _f = b.fetch_arrays()
+    assert sum(s[2] for s in b.shards()) == 50_001
+    b.free()
+    assert np.array_equal(off, one["arrays"][0][:50_002]) and np.array_equal(vid, one["arrays"][1][:off[-1]])
+    with pytest.raises(A.AnxError, match="fewer strings than announced"):
+        g.encode_packed(blob, len(qs) + 1, p)
+    with pytest.raises(A.AnxError, match="own stream"):
+        b = g.encode_batch(qs, p)
+        try:
+            b.run(stream=0x1234)
+        finally:
+            b.free()
+
+
+def test_small_calls_use_one_replica_and_exports_need_one_shard(data_dir):
+    import torch
+    A.set_switch("ANX_SHARD_MIN", None)
+    g = _model(data_dir, "eng", [0, 0])
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    qs = synth.make_queries(words, 20_000, max_len=16, seed=9)
+    b = g.encode_batch(qs[:5000], p)     # below 2 x 8192: one shard, exports work
+    assert len(b.shards()) == 1
+    b.run()
+    buf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda:0")
+    assert b.export_compact(buf.data_ptr(), buf.numel()) > 0
+    torch.cuda.synchronize()
+    b.free()
+    b = g.encode_batch(qs, p)
+    assert len(b.shards()) == 2
+    b.run()
+    with pytest.raises(A.AnxError, match="several replicas"):
+        b.export_compact(buf.data_ptr(), buf.numel())
+    b.free()
+
+
+def test_variant_lists_over_replicas(data_dir, tmp_path):
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    vl = tmp_path / "variants.tsv"
+    rng = np.random.default_rng(3)
+    refs = [w for w in words[::97] if w.isalpha() and len(w) > 4][:400]
+    with open(vl, "w", encoding="utf-8") as f:
+        for w in refs:
+            i = int(rng.integers(1, len(w) - 1))
+            f.write(f"{w}\t{w[:i] + w[i + 1:]}\t0.9\t{w[:i] + w[i] + w[i:]}\t0.8\n")
+    qs = synth.make_queries(refs, 40_000, max_len=20, seed=11)
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    one = _run(_model(data_dir, "eng", [0], variants=str(vl)), qs, p, counts=False)
+    got = _run(_model(data_dir, "eng", [0, 0], variants=str(vl)), qs, p, counts=False)
+    _same(one, got, counts=False)
+
+
+def test_search_mode_over_replicas(data_dir):
+    """find_all_matches drives the same staged calls: every n-gram order's segment batch is sharded over the replicas."""
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    texts = synth.make_running_text(words, 0.4, seed=21)
+    sp = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, max_ngram=3)
+    one = _model(data_dir, "eng", [0]).find_all_matches_arrays(texts, sp)
+    two = _model(data_dir, "eng", [0, 0]).find_all_matches_arrays(texts, sp)
+    for x, y in zip(one, two):
+        assert np.array_equal(x, y)
+    assert one[1].size > 10_000

@@ -401,8 +401,11 @@ def test_oversized_call_is_split_into_device_batches(eng, data_dir, monkeypatch)
         L.lib().anx_results_free(rows, offs)
         return out
     whole = via_char_pp()
-    monkeypatch.setenv("ANX_MAX_BATCH", "100")
-    assert via_char_pp() == whole
+    A.set_switch("ANX_MAX_BATCH", 100)
+    try:
+        assert via_char_pp() == whole
+    finally:
+        A.set_switch("ANX_MAX_BATCH", None)
 
 
 @pytest.mark.parametrize("nclasses", [40, 70, 110, 150])
@@ -489,14 +492,16 @@ def test_capacity_overflow_regrow_repeats_the_run(eng, monkeypatch):
         b.run()
         ref, st = b.fetch_arrays(), b.stats()
         b.free()
-        monkeypatch.setenv("ANX_CAP_DIV", "64")
-        b = g.encode_batch(qs, p)
-        b.run()
-        got, st2 = b.fetch_arrays(), b.stats()
-        b.run()   # second run of the same batch: sized from the first
-        got3 = b.fetch_arrays()
-        b.free()
-        monkeypatch.delenv("ANX_CAP_DIV")
+        A.set_switch("ANX_CAP_DIV", 64)
+        try:
+            b = g.encode_batch(qs, p)
+            b.run()
+            got, st2 = b.fetch_arrays(), b.stats()
+            b.run()   # second run of the same batch: sized from the first
+            got3 = b.fetch_arrays()
+            b.free()
+        finally:
+            A.set_switch("ANX_CAP_DIV", None)
         for x, y, z in zip(ref, got, got3):
             assert np.array_equal(x, y) and np.array_equal(x, z)
         for k in ("n_pairs", "n_results", "n_survivors", "n_selected", "n_class_tests"):

@@ -24,3 +24,9 @@ def test_host_code_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe), data["alphabet"], data["eng"], str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert r.stdout.strip().startswith("OK ")
+    # the multi-replica sharding of the batch calls (contiguous input ranges, one host thread per replica, rows concatenated in
+    # input order) against the stub's fake devices: shard == whole for 1..4 replicas, every input form, confusables, search mode
+    env["ANX_STUB_FAKE"] = "1"
+    r = subprocess.run([str(exe), data["alphabet"], data["eng"], str(tmp_path), "shards"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.stdout.strip().startswith("OK ")
