@@ -39,6 +39,7 @@ namespace anx {
   } while (0)
 
 #include "kernels_common.hpp"
+#include "kernels_swar.hpp"
 #include "kernels_scan.hpp"
 #include "kernels_prefix.hpp"
 #include "kernels_score.hpp"
@@ -906,7 +907,7 @@ static size_t cap_div() { return (size_t)switches().cap_div; }
 
 static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
   if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
-  if (b->nq >= (1u << 27) || dl->nentries >= (1u << 27)) { err = "more than 2^27 queries per batch or lexicon entries (32-bit record offsets)"; return ANX_ELIMIT; }
+  if (b->nq >= (1u << 27) || dl->nentries >= (1u << 26)) { err = "more than 2^27 queries per batch or 2^26 lexicon entries (32-bit record offsets, packed pair records)"; return ANX_ELIMIT; }
   HIP_TRY(hipSetDevice(dl->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint32_t nq = (uint32_t)b->nq;
@@ -943,11 +944,16 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
     A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.sighash_e = dl->sighash_e; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
     A.chunk = SCAN_CHUNK;
+    A.chunk_fused = SCAN_CHUNK_FUSED;
 #ifdef ANX_DEBUG_SWITCHES
     { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; if (v >= 32 && v <= 1024) A.chunk = (uint32_t)v; }
 #endif
     A.raw = b->raw; A.region_cap = region_cap; A.rctr = b->rctr; A.qexact = b->qexact; A.want_exact = stop;
     A.drop_len = (!stop && !b->keep_all_pairs) ? 1 : 0;
+    A.q_rec = b->q_rec; A.e_rec = dl->e_rec;
+    // the band-match bound where the pair is born (not in the run that materialises every pair for the debug view, and not with
+    // StopAtExactMatch, whose dropped pairs are counted by the scoring kernel from the materialised list)
+    A.fuse = (switches().fuse_prefilter && switches().prefilter && A.drop_len) ? 1 : 0;
     A.qpairs = nullptr;
     if (b->count_pairs) {
       if (!b->qpairs && (rc = dalloc(&b->qpairs, nq, err))) return rc;
@@ -1342,7 +1348,7 @@ int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* 
       if (pm[i] == META_SKIPPED || w >= b->n_pairs) continue;
       anx_pair& r = res[w++];
       r.query = b->order[pr[i].x];
-      r.vocab_id = ev[pr[i].y & 0x7FFFFFFFu];
+      r.vocab_id = ev[pr[i].y & RAW_ENTRY_MASK];
       const uint32_t ld = pm[i] & 0x7F;
       r.ld = ld == PAIR_NONE ? (int16_t)-1 : (int16_t)ld;
       r.samecase = (pm[i] >> 7) & 1;

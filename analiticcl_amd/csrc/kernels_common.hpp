@@ -22,10 +22,14 @@ constexpr uint32_t SIG_BYTE_MAX = 120;  // group sums above this take the walk (
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
 constexpr uint32_t SCAN_TQ = 64;         // queries per tile (= per wave), compared in passes of 32 (one hit-mask bit each)
 constexpr uint32_t SCAN_HITS = 512;      // per-wave LDS hit list of the scan (entries); expanded when fewer than 256 are free
+constexpr uint32_t SCAN_PBUF = 128;      // per-wave LDS ring of dense pairs awaiting the fused filter (< 64 waiting + <= 64 new)
 constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
+constexpr uint32_t SCAN_CHUNK_FUSED = 128;  // ... in tiles whose pairs pass the fused prefilter first (a third survives)
 constexpr uint32_t SCAN_REGIONS = 64;     // pair-list regions with one reservation counter each
 constexpr uint32_t RC_STRIDE = 32;        // uint32 words per region counter block (128 B)
 constexpr uint32_t RAW_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t RAW_ENTRY_MASK = 0x3FFFFFFFu;   // entry id of a pair (bit 31: exact anagram class, StopAtExactMatch)
+constexpr uint32_t RAW_PREFILTERED = 0x40000000u;  // bit 30 of a pair's entry word: the scan applied the band-match bound already (entries < 2^26 then)
 constexpr uint32_t META_SKIPPED = 0xFFFFFFFFu;
 
 struct EntRec {   // per-entry attributes k_compact needs, one 16-B gather

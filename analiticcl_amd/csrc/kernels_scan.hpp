@@ -63,6 +63,17 @@ __device__ inline uint32_t wave_reserve(WaveOut& w, uint32_t ntot, uint32_t lane
   }
   return incl - ntot;
 }
+// the same for a run whose total is known (<= 64 pairs, lane ranks by ballot): sets split / nbase for wave_slot
+__device__ inline void wave_reserve_total(WaveOut& w, uint32_t total, uint32_t lane) {
+  w.split = w.left;
+  if (total > w.left) {
+    const uint32_t rest = total - w.left;
+    const uint32_t need = rest > w.chunk ? rest : w.chunk;
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(&w.ctr[RC_RAW], need);
+    w.nbase = w.rbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+  }
+}
 __device__ inline uint32_t wave_slot(const WaveOut& w, uint32_t g) {
   return g < w.split ? w.base + g : w.nbase + (g - w.split);
 }
@@ -107,11 +118,16 @@ struct ScanArgs {
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
   uint32_t chunk;       // pair-list slots a wave reserves per global atomic (SCAN_CHUNK; ANX_SCAN_CHUNK)
+  uint32_t chunk_fused; // ... in tiles that run the fused prefilter
   uint32_t* rctr;       // [SCAN_REGIONS][RC_STRIDE]
   const uint32_t* qexact;  // per query: class id of its exact anagram class (0xFFFFFFFF = none); stop mode only
   int want_exact;
   int drop_len;             // do not materialise pairs with |len_q - len_c| > d: damerau_levenshtein returns None for them at its
                             // first test (src/distance.rs:109-130); they are only counted as scored pairs
+  const uint4* q_rec;       // [Q][2] {first 16 symbols of the query} {meta, ...}   (fused prefilter)
+  const uint4* e_rec;       // [E][2] {first 16 symbols of the entry} {meta, row offset, freq, -}
+  int fuse;                 // apply the SWAR band-match bound (kernels_swar.hpp) where the pair is born: pairs it rejects are
+                            // counted as scored pairs and never written; survivors carry RAW_PREFILTERED
   uint32_t* qpairs;         // per query: scored pairs of THIS run, counted where they are produced (materialised or only counted);
                             // nullptr in normal runs (anx_batch_pair_counts: the per-query check of the production pair list)
   int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
@@ -131,7 +147,7 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
 //   hit <=> L1 <= k and L1 < len_q + len_c.
 template <bool BITS, int NP>
 __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage, uint32_t* __restrict__ hits,
-                                 uint32_t* __restrict__ qlds) {
+                                 uint32_t* __restrict__ qlds, uint4* __restrict__ qsym, uint32_t* __restrict__ pbuf) {
   constexpr int CPL = BITS ? 4 : (NP <= 8 ? 4 : NP <= 16 ? 2 : 1);  // classes per lane
   constexpr int W = BITS ? NBITPLANES : NP;                          // dwords held per class
   constexpr int QSTRIDE = BITS ? NBITPLANES : NP;
@@ -150,27 +166,88 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     const uint32_t* __restrict__ src = (BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE;
     for (uint32_t i = lane; i < t.nq * QSTRIDE; i += 64) qlds[i] = src[i];
   }
+  // Fused prefilter (bit-plane tiles of queries <= 16 symbols with d <= 3): the first 16 symbols of the tile's queries sit in LDS,
+  // the expansion below makes the pairs DENSE in an LDS buffer and tests 64 of them at a time against the band-match bound.
+  const bool fuse = BITS && A.fuse && t.lq <= 16u && t.d <= 3u;  // wave-uniform
+  if (fuse) wo.chunk = A.chunk_fused;  // a third of the pairs survive the filter: smaller reservations waste fewer slots
+  if (BITS && fuse && lane < t.nq) qsym[lane] = rec32(A.q_rec, t.q0 + lane)[0];
+  constexpr uint32_t PBUF = SCAN_PBUF;
+  uint32_t npb = 0, phead = 0;  // pairs waiting in the ring pbuf (wave-uniform count and read position), each (entry | query-in-tile << 26)
 
   uint32_t nhits = 0;  // entries in the hit list (wave-uniform)
   uint32_t counted_only = 0;  // per lane: pairs dropped by the length test (they still count as scored pairs)
+  // Writes pairs of the dense buffer to the pair list, 64 at a time (fin: also the remainder).  With `fuse` each lane first
+  // gathers its entry's symbols and runs the band-match bound against its query's symbols from LDS: 2/3 of the pairs of the
+  // bench workload end here (counted as scored pairs, like the ones the DL's length test drops) and never reach HBM.
+  auto emit_dense = [&](bool fin) {
+    while (npb >= 64u || (fin && npb)) {
+      const uint32_t cnt = npb < 64u ? npb : 64u;
+      const bool act = lane < cnt;
+      const uint32_t pr = pbuf[(phead + lane) & (PBUF - 1u)];
+      const uint32_t e = act ? (pr & 0x3FFFFFFu) : 0u, ql = act ? (pr >> 26) : 0u;
+      bool keep = act;
+      uint32_t flag = 0u;
+      if (BITS && fuse) {
+        const uint4 C = rec32(A.e_rec, e)[0];
+        const int lc = (int)(rec32(A.e_rec, e)[1].x & 0xFFu), lq = (int)t.lq, d = (int)t.d;
+        const uint4 Q = qsym[ql];
+        const bool filt = act && lc <= 16;      // |lq - lc| <= d holds: length-incompatible records were only counted
+        const int ml = lq > lc ? lq : lc;
+        constexpr uint32_t M = 0x7F7F7F7Fu;     // alphabets of the bit-plane kernel have <= 32 symbols: every code < 0x7E (B7 form)
+        bool rej;
+        if (__any(filt && ml > 12)) {
+          const uint32_t q4[4] = {Q.x & M, Q.y & M, Q.z & M, Q.w & M}, c6[6] = {M, C.x & M, C.y & M, C.z & M, C.w & M, M};
+          rej = band_bound_rejects<4, true, true>(q4, c6, filt, d, lq, lc);
+        } else if (__any(filt && ml > 8)) {
+          const uint32_t q3[3] = {Q.x & M, Q.y & M, Q.z & M}, c5[5] = {M, C.x & M, C.y & M, C.z & M, M};
+          rej = band_bound_rejects<3, true, true>(q3, c5, filt, d, lq, lc);
+        } else {
+          const uint32_t q2[2] = {Q.x & M, Q.y & M}, c4[4] = {M, C.x & M, C.y & M, M};
+          rej = band_bound_rejects<2, true, true>(q2, c4, filt, d, lq, lc);
+        }
+        if (rej) { keep = false; ++counted_only; }
+        if (filt) flag = RAW_PREFILTERED;
+      }
+      const unsigned long long km = __ballot(keep);
+      const uint32_t total = (uint32_t)__popcll(km);
+      if (total) {  // wave-uniform
+        wave_reserve_total(wo, total, lane);
+        if (keep) {
+          const uint32_t q = t.q0 + ql;
+          uint32_t exact = 0u;
+          if (A.want_exact) exact = A.qexact[q] == A.scan_rec[2 * (size_t)e + 1].y ? 0x80000000u : 0u;  // StopAtExactMatch, src/lib.rs:1164-1173
+          const uint32_t g = __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+          const uint32_t pos = wave_slot(wo, g);
+          if (pos < wo.rend) raw[pos] = make_uint2(q, e | exact | flag);
+        }
+        wave_commit(wo, total);
+      }
+      phead = (phead + cnt) & (PBUF - 1u);  // a ring: nothing moves
+      npb -= cnt;
+    }
+  };
   // expands the hit list into (query, entry) pairs, one list entry per lane and round
   auto flush = [&]() {
     for (uint32_t r0 = 0; r0 < nhits; r0 += 64) {
       const uint32_t idx = r0 + lane;
       uint32_t c = 0, m = 0, e0 = 0, ne = 0, qb = 0;   // c: class id (stop mode / SAD path); pairs = queries of m x entries [e0, e0 + ne)
       if (idx < nhits) {
-        c = hits[2 * idx];
-        m = hits[2 * idx + 1];
-        qb = ((c >> 27) & 1u) << 5;
         bool count_only;
         if (BITS) {
           // one scan record per lexicon ENTRY (the planes of its class): a hit is a (query, entry) pair already, there is no
-          // entries-per-class loop and no class gather here; bit 28 = "fails the DL's length test" was set by the test lane
-          count_only = (c >> 28) & 1u;
-          e0 = c & ((1u << 27) - 1u);
+          // entries-per-class loop and no class gather here.  The list holds the record's position in the staged chunk (the
+          // stage keeps the chunk's ids until process() returns), bit 8 = pass, bit 9 = "fails the DL's length test"
+          const uint32_t hx = reinterpret_cast<const uint16_t*>(hits + SCAN_HITS)[idx];
+          m = hits[idx];
+          qb = ((hx >> 8) & 1u) << 5;
+          count_only = (hx >> 9) & 1u;
+          e0 = stage[hx & 0xFFu];
           ne = 1;
-          c = (A.want_exact || A.qpairs) ? A.scan_rec[2 * (size_t)e0 + 1].y : 0u;  // class of the entry (rare modes only)
+          c = A.qpairs ? A.scan_rec[2 * (size_t)e0 + 1].y : 0u;  // class of the entry (pair-count runs only)
         } else {
+          c = hits[2 * idx];
+          m = hits[2 * idx + 1];
+          qb = ((c >> 27) & 1u) << 5;
           c &= (1u << 27) - 1u;
           const uint32_t lc = cls_len[c];
           e0 = cls_off[c];
@@ -188,6 +265,23 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
           counted_only += (uint32_t)__popc(m) * ne;
           m = 0;
         }
+      }
+      if (BITS) {
+        // bit-plane tiles: one pair per lane and trip into the dense LDS buffer (ballot ranks); whenever 64 pairs wait they are
+        // filtered and written -- the trips run as long as the fullest mask of the round, the filter rounds are always dense
+        while (true) {
+          const bool has = m != 0u;
+          const unsigned long long bm = __ballot(has);
+          if (!bm) break;  // wave-uniform
+          if (has) {
+            const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            pbuf[(phead + npb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))) & (PBUF - 1u)] = e0 | ((qb + bit) << 26);
+          }
+          npb += (uint32_t)__popcll(bm);
+          if (npb >= 64u) emit_dense(false);
+        }
+        continue;
       }
       uint32_t total;
       uint32_t g = wave_reserve(wo, (uint32_t)__popc(m) * ne, lane, &total);
@@ -323,14 +417,23 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         if (cnt) {  // wave-uniform
           if (nz) {
             const uint32_t pos = nhits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-            hits[2 * pos] = cid[j] | ((qb >> 5) << 27);  // entry (bit-plane path) or class id, pass, count-only flag
-            hits[2 * pos + 1] = __brev(hm[j]) >> (32u - npass);  // shift-in order -> bit b = query b of the pass
+            const uint32_t hmask = __brev(hm[j]) >> (32u - npass);  // shift-in order -> bit b = query b of the pass
+            if (BITS) {
+              hits[pos] = hmask;
+              reinterpret_cast<uint16_t*>(hits + SCAN_HITS)[pos] = (uint16_t)(((uint32_t)j * 64u + lane) | ((qb >> 5) << 8) | (((cid[j] >> 28) & 1u) << 9));
+            } else {
+              hits[2 * pos] = cid[j] | ((qb >> 5) << 27);  // class id, pass
+              hits[2 * pos + 1] = hmask;
+            }
           }
           nhits += cnt;
         }
       }
-      if (nhits > SCAN_HITS - CHUNK) flush();  // a pass adds at most CHUNK entries
+      if (!BITS && nhits > SCAN_HITS - CHUNK) flush();  // a pass adds at most CHUNK entries
     }
+    // bit-plane tiles expand after the passes, when the records' planes and thresholds are dead (the fused filter needs the
+    // registers): the two passes of a chunk add at most 2 * CHUNK = SCAN_HITS entries
+    if (BITS) flush();
   };
 
   // The tile's signature window [s0, s1) is aligned to whole 64-signature blocks (no bounds test is needed: the other
@@ -348,7 +451,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       m &= m - 1;
       uint32_t cbi = (uint32_t)__builtin_amdgcn_readlane((int)cb, i), ni = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
       while (ni) {
-        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 128 ids
+        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 64 ids
         stage[ns + lane] = cbi + lane;              // all 64 lanes write; only the first `take` ids count
         ns += take;
         cbi += take;
@@ -410,6 +513,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   }
   if (ns) process();
   flush();
+  if (BITS) emit_dense(true);
   if (A.drop_len) {  // wave sum of the counted-only pairs -> RC_VALID (n_pairs = every DL invocation of the reference)
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(counted_only), 63);
     wo.emitted += tot;
@@ -430,20 +534,24 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 // Every wave takes one tile; tiles are ordered by decreasing cost.  The bit-plane tiles (wave-uniform switch over
 // T) and the count-vector tiles run as two launches so that the rarely used wide SAD body does not set the register
 // budget (= occupancy) of the common one.
-constexpr uint32_t SCAN_STAGE = 64 * 4 + 128;
+constexpr uint32_t SCAN_STAGE = 64 * 4 + 64;  // a staging step writes 64 ids behind ns < CHUNK
 template <int NP, bool BITS>
 __device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
   __shared__ uint32_t s_stage[4][SCAN_STAGE];
-  __shared__ uint32_t s_hits[4][2 * SCAN_HITS];  // per wave: (class | pass << 27, hit mask) entries awaiting expansion
+  // per wave, entries awaiting expansion: bit-plane tiles hit mask u32[SCAN_HITS] + (position in the chunk | pass | flag) u16[SCAN_HITS];
+  // count-vector tiles (class | pass << 27, hit mask) pairs
+  __shared__ uint32_t s_hits[4][BITS ? SCAN_HITS + SCAN_HITS / 2 : 2 * SCAN_HITS];
+  __shared__ uint4 s_qsym[BITS ? 4 : 1][BITS ? SCAN_TQ : 1];     // first 16 symbols of the tile's queries (fused prefilter)
+  __shared__ uint32_t s_pbuf[BITS ? 4 : 1][BITS ? SCAN_PBUF : 1];      // dense (entry | query << 26) pairs awaiting the filter / the write
   const uint32_t wid = threadIdx.x >> 6;
   const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wid));
   if (item >= A.ntiles) return;
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
   t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12];
-  scan_tile<BITS, NP>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid]);
+  scan_tile<BITS, NP>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[BITS ? wid : 0], s_pbuf[BITS ? wid : 0]);
 }
 // <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
 // 64 with spills -> 2.60 ms)

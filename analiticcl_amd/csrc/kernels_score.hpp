@@ -11,77 +11,6 @@
 //   longest_common_substring_length / common_prefix_length / common_suffix_length: src/distance.rs:181-231.
 //   Score: src/lib.rs:1433-1452 (f64, same association, no FMA contraction).
 // ------------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------------
-// K2: prefilter + selection.  A necessary condition for damerau_levenshtein(q, c) <= d (src/distance.rs:101-179):
-// every optimal edit script matches all but <= d symbols of q (and of c) to an EQUAL symbol of the other string
-// at an offset within +-d (each unmatched symbol costs one deletion/insertion/substitution; transposed symbols
-// are equal symbols within the offset bound).  So count the positions of q that have no equal symbol of c in
-// [i-d, i+d] (and vice versa); more than d of them => the reference returns None.  Pure register SWAR over the
-// two 16-byte rows (7 byte-shifts with v_alignbyte_b32, zero-byte detection), no LDS, no DP.  On config 2 it
-// rejects ~2/3 of the pairs; the banded DP then runs only on the selected third.  Strings longer than 16
-// symbols or d > 3 are passed through unfiltered.
-// ------------------------------------------------------------------------------------------------
-#define PAIR_NONE 0x7Fu
-
-__device__ inline uint32_t nonzero_bytes(uint32_t x) {  // bit 7 of every byte that is non-zero
-  return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
-}
-__device__ inline uint32_t len_mask(int len, int k) {  // 0x80 in every byte position (4k..4k+3) below len
-  const int n = len - 4 * k;
-  return n >= 4 ? 0x80808080u : n <= 0 ? 0u : (0x80808080u & ((1u << (8 * n)) - 1u));
-}
-
-// B7: every byte of q and c is below 0x80 (alphabets of <= 124 classes, rows masked with 0x7F7F7F7F by the caller: the paddings
-// become 0x7E / 0x7F and still equal nothing).  Then x = q ^ c has no bit 7 and x + 0x7F7F7F7F sets bit 7 of exactly the
-// non-zero bytes without a carry between bytes: one v_add instead of v_and + v_add + v_or3 (13 of the 24 issue cycles a
-// word-shift costs are the zero test; only bit 7 of every byte of nz / nmA / nmB is ever looked at).
-template <int DELTA, int NW, bool B7>
-__device__ inline void filter_shift(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], uint32_t off, uint32_t (&nmA)[NW],
-                                    uint32_t (&nmB)[NW]) {
-  // off: 0 for lanes that use this shift (d >= |DELTA|), all ones for the others (nothing matches at this shift)
-  uint32_t nz[NW + 2];
-  nz[0] = 0xFFFFFFFFu;
-  nz[NW + 1] = 0xFFFFFFFFu;
-#pragma unroll
-  for (int k = 0; k < NW; ++k) {
-    uint32_t cs;  // bytes C[4k + DELTA ..]
-    if (DELTA == 0) cs = c[k + 1];
-    else if (DELTA > 0) cs = __builtin_amdgcn_alignbyte(c[k + 2], c[k + 1], DELTA);
-    else cs = __builtin_amdgcn_alignbyte(c[k + 1], c[k], 4 + DELTA);
-    const uint32_t x = q[k] ^ cs;
-    nz[k + 1] = B7 ? ((x + 0x7F7F7F7Fu) | off) : (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | off);  // bit7 set where q[i] != c[i + DELTA]
-    nmA[k] &= nz[k + 1];
-  }
-#pragma unroll
-  for (int k = 0; k < NW; ++k) {  // the same comparisons seen from c: position j pairs with i = j - DELTA
-    uint32_t b;
-    if (DELTA == 0) b = nz[k + 1];
-    else if (DELTA > 0) b = __builtin_amdgcn_alignbyte(nz[k + 1], nz[k], 4 - DELTA);
-    else b = __builtin_amdgcn_alignbyte(nz[k + 2], nz[k + 1], -DELTA);
-    nmB[k] &= b;
-  }
-}
-// band-match bound: a symbol with no equal symbol of the other string within +-d positions costs at least one edit.
-// Rows are padded beyond their length with bytes that equal nothing (query 0xFE, candidate 0xFF), so the 4*NW - len
-// padding positions always count as unmatched and are subtracted instead of masked.
-template <int NW, bool B7 = false>
-__device__ inline bool band_bound_rejects(const uint32_t (&q)[NW], const uint32_t (&c)[NW + 2], bool filt, int d, int lq, int lc) {
-  uint32_t nmA[NW], nmB[NW];
-#pragma unroll
-  for (int k = 0; k < NW; ++k) { nmA[k] = 0xFFFFFFFFu; nmB[k] = 0xFFFFFFFFu; }
-  filter_shift<0, NW, B7>(q, c, 0u, nmA, nmB);
-  if (__any(filt && d >= 1)) { const uint32_t off = d >= 1 ? 0u : 0xFFFFFFFFu; filter_shift<1, NW, B7>(q, c, off, nmA, nmB); filter_shift<-1, NW, B7>(q, c, off, nmA, nmB); }
-  if (__any(filt && d >= 2)) { const uint32_t off = d >= 2 ? 0u : 0xFFFFFFFFu; filter_shift<2, NW, B7>(q, c, off, nmA, nmB); filter_shift<-2, NW, B7>(q, c, off, nmA, nmB); }
-  if (__any(filt && d >= 3)) { const uint32_t off = d >= 3 ? 0u : 0xFFFFFFFFu; filter_shift<3, NW, B7>(q, c, off, nmA, nmB); filter_shift<-3, NW, B7>(q, c, off, nmA, nmB); }
-  int unA = lq - 4 * NW, unB = lc - 4 * NW;
-#pragma unroll
-  for (int k = 0; k < NW; ++k) {
-    unA += __popc(nmA[k] & 0x80808080u);
-    unB += __popc(nmB[k] & 0x80808080u);
-  }
-  return filt && (unA > d || unB > d);
-}
-
 struct ScoreArgs {
   const double* quot;  // [33][33] quot[x*33+L] = (double)x / (double)L computed on the host, or nullptr
   int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL
@@ -330,10 +259,6 @@ struct PairArgs {  // what every scoring kernel reads / writes
   uint32_t* qexpand;
 };
 
-// 32-byte record i of a record array (i < 2^27): a 32-bit byte offset lets the load use the SGPR base + VGPR offset form
-__device__ inline const uint4* rec32(const uint4* base, uint32_t i) {
-  return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (i << 5));
-}
 // Loads the pair of slot p into registers (NW words per string); returns false for !active.
 template <int NW>
 struct PairRegs {
@@ -348,7 +273,7 @@ __device__ inline void load_pair(uint32_t p, bool active, const PairArgs& A, con
   if (!active) return;
   const uint2 rp = A.raw[p];
   r.q = rp.x;
-  r.e = rp.y & 0x7FFFFFFFu;
+  r.e = rp.y & RAW_ENTRY_MASK;
   const uint4 Q0 = rec32(A.q_rec, r.q)[0], QM = rec32(A.q_rec, r.q)[1];
   const uint4 C0 = rec32(A.e_rec, r.e)[0], CM = rec32(A.e_rec, r.e)[1];
   r.qm = QM.x;
@@ -466,11 +391,19 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     // nested branches around the loads cost more than the few wasted gathers; its verdict is masked by `selected`.
     const uint2 rp = A.raw[live ? p : (region << f.region_shift)];
     const bool invalid = !live || rp.x == RAW_INVALID;  // unused chunk tail
-    bool skip = invalid;
+    // RAW_PREFILTERED: the scan's fused expansion applied the length test and the band-match bound already, and the pair has
+    // both strings <= 16 symbols and d <= 3 -- it goes straight to the inline queue, nothing is gathered for it here.  A chunk
+    // comes from one tile, so whole waves take this path (wave-uniform test).
+    const bool pre = !invalid && (rp.y & RAW_PREFILTERED);
+    bool selected = pre, wide = false;
+    int lq = 0, lc = 0, d = 0;
+    bool stop_skipped = false;
+    if (__any(!invalid && !pre)) {
+    bool skip = invalid || pre;
     if (f.stop)  // StopAtExactMatch: a non-exact class of a query that has an exact one (wave-uniform branch)
-      skip = invalid || (!(rp.y & 0x80000000u) && f.qexact[invalid ? 0u : rp.x] != 0xFFFFFFFFu);
-    const bool stop_skipped = skip && !invalid;
-    const uint32_t q = skip ? 0u : rp.x, e = skip ? 0u : (rp.y & 0x7FFFFFFFu);
+      skip = skip || (!(rp.y & 0x80000000u) && f.qexact[skip ? 0u : rp.x] != 0xFFFFFFFFu);
+    stop_skipped = skip && !invalid && !pre;
+    const uint32_t q = skip ? 0u : rp.x, e = skip ? 0u : (rp.y & RAW_ENTRY_MASK);
     // the first 16 symbols of both strings come with the records (rows are padded with bytes that equal nothing:
     // query 0xFE, candidate 0xFF)
     const uint4 Q = rec32(A.q_rec, q)[0];  // 32-B records: one line each
@@ -478,11 +411,11 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     const uint4 C = rec32(A.e_rec, e)[0];
     const uint4 CM = rec32(A.e_rec, e)[1];
     const uint32_t crow = CM.y;
-    const int lq = QM.x & 0xFF, d = (QM.x >> 16) & 0xFF, lc = CM.x & 0xFF;
+    lq = QM.x & 0xFF; d = (QM.x >> 16) & 0xFF; lc = CM.x & 0xFF;
     const int diff = lq > lc ? lq - lc : lc - lq;
-    bool selected = !skip && diff <= d;
-    const bool filt = selected && f.enable && d <= 3 && lq <= 32 && lc <= 32;
-    const bool wide = filt && (lq > 16 || lc > 16);
+    selected = pre || (!skip && diff <= d);
+    const bool filt = selected && !pre && f.enable && d <= 3 && lq <= 32 && lc <= 32;
+    wide = filt && (lq > 16 || lc > 16);
     if (WIDE && __any(wide)) {  // wave-uniform, rare: some pair of the wave has a string of 17..32 symbols
       uint32_t q8[8] = {Q.x, Q.y, Q.z, Q.w, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
       uint32_t c10[10] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -507,10 +440,11 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
         if (band_bound_rejects<2, B7>(q2, c4, f4, d, lq, lc)) selected = false;
       }
     }
+    }
     const bool tow = !WIDE && wide;  // prefiltered later by k_filter_wide (which also counts it as selected if it passes)
     if (a.store_pairs && live && !selected && !tow)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
       A.p_meta[p] = (invalid || stop_skipped) ? META_SKIPPED : (PAIR_NONE | (1u << 7));
-    const bool inl = selected && D > 0 && lq <= 16 && lc <= 16 && d <= D;
+    const bool inl = selected && D > 0 && (pre || (lq <= 16 && lc <= 16 && d <= D));   // (pre: d <= the batch's largest d = D)
     const bool to8 = selected && !inl && !tow && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
     const bool tog = selected && !inl && !tow && !to8;
     const unsigned long long mi = __ballot(inl);
@@ -590,7 +524,7 @@ __global__ __launch_bounds__(256) void k_filter_wide(SlotList in, FilterArgs f, 
     int d = 0, lq = 0, lc = 0;
     if (active) {
       const uint2 rp = A.raw[p];
-      const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+      const uint32_t q = rp.x, e = rp.y & RAW_ENTRY_MASK;
       const uint4 Q = rec32(A.q_rec, q)[0], QM = rec32(A.q_rec, q)[1], C = rec32(A.e_rec, e)[0], CM = rec32(A.e_rec, e)[1];
       lq = QM.x & 0xFF; d = (QM.x >> 16) & 0xFF; lc = CM.x & 0xFF;
       q8[0] = Q.x; q8[1] = Q.y; q8[2] = Q.z; q8[3] = Q.w;
@@ -644,7 +578,7 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
   if (i_sel < nsel) {
     const uint32_t p = in.list[(size_t)region * in.region_cap + i_sel];
     const uint2 rp = raw[p];
-    const uint32_t q = rp.x, e = rp.y & 0x7FFFFFFFu;
+    const uint32_t q = rp.x, e = rp.y & RAW_ENTRY_MASK;
     uint32_t ld = PAIR_NONE, lcs = 0, pre = 0, suf = 0, samecase = 1;
     double score = __builtin_nan("");
     {

@@ -101,3 +101,34 @@ def test_bench_rccl_path_world1():
     js = json.loads(line)
     assert js["process_group"] == "nccl" and js["gather_error"] is None and js["gather_check"] == "ok"
     assert "RCCL gather" in js["config"]["parallelism"] and js["n_gpus"] == 1 and js["value"] > 0
+
+
+def _bench(args, timeout=900):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=repo, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_single_process_replicas():
+    """bench.py --single-process: ONE process, the C ABI's own split over replicas (here 3 on the one GPU): same JSON contract,
+    the rows of the last shard equal a one-replica run of its inputs."""
+    js = _bench(["--gpus", "3", "--single-process", "--replicas-on-one-gpu", "--queries", "150000", "--steps", "3", "--warmup", "1", "--cpu-sample", "2000"])
+    assert js["n_gpus"] == 3 and js["shard_check"] == "ok" and js["value"] > 0 and js["scaling"] == "weak"
+    # the packed form splits by bytes: ~150 000 inputs per replica
+    assert [s[0] for s in js["shards"]] == [0, 0, 0] and sum(s[2] for s in js["shards"]) == 450000 and all(abs(s[2] - 150000) < 3000 for s in js["shards"])
+    assert js["roofline"]["frac"] > 0 and js["cpu_baseline"]["value"] > 0 and "anx_model_to_devices" in js["config"]["parallelism"]
+
+
+def test_bench_n_ranks_on_one_gpu_gloo():
+    """Dry run of the N-rank job on one GPU: 3 processes under torch.distributed.run, all on device 0, the index built once and
+    loaded by the other ranks, compact records gathered over gloo; rank 0's view of EVERY rank's export equals that rank's fetch();
+    roofline and cpu_baseline are reported at N > 1 too."""
+    js = _bench(["--ranks-on-one-gpu", "3", "--backend", "gloo", "--check-gather", "--queries", "120000", "--steps", "3", "--warmup", "1", "--cpu-sample", "2000"])
+    assert js["n_gpus"] == 3 and js["process_group"] == "gloo" and js["ranks_on_one_gpu"] is True
+    assert js["gather_error"] is None and js["gather_check"] == "ok"
+    assert js["queries_per_s"] > 0 and js["roofline"]["frac"] > 0 and js["cpu_baseline"]["value"] > 0
