@@ -161,6 +161,9 @@ def lib():
         "anx_batch_run_async": (C.c_int, [vp, vp, vp]),
         "anx_batch_wait": (C.c_int, [vp, vp]),
         "anx_batch_fetch": (C.c_int, [vp, C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(sz))]),
+        "anx_batch_fetch_compact": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_uint32))]),
+        "anx_compact_free": (None, [C.c_void_p, C.POINTER(C.c_uint32)]),
+        "anx_compact_to_results": (None, [C.c_void_p, sz, C.POINTER(Result)]),
         "anx_batch_fetch_pairs": (C.c_int, [vp, C.POINTER(C.POINTER(Pair)), C.POINTER(sz)]),
         "anx_pairs_free": (None, [C.POINTER(Pair)]),
         "anx_batch_pair_counts": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint32))]),

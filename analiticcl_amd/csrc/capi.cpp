@@ -819,6 +819,50 @@ int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   *offs = off;
   return ANX_OK;
 }
+int anx_batch_fetch_compact(const anx_batch* b, anx_topk_record** rows, uint32_t** offs) {
+  if (!b || !rows || !offs) return fail(ANX_EINVAL, "NULL argument");
+  if (b->rescore) return fail(ANX_EINVAL, "confusables are loaded: results are rescored on the host, use anx_batch_fetch");
+  if (b->model->host.lex.any_variants) return fail(ANX_EINVAL, "variant lists are loaded: compact records carry no `via`, use anx_batch_fetch");
+  const size_t n = b->n_input, S = b->shards.size();
+  std::vector<size_t> base(S + 1, 0);
+  for (size_t g = 0; g < S; ++g) base[g + 1] = base[g] + anx::batch_n_results(b->shards[g].b);
+  if (base[S] >= ((size_t)1 << 32)) return fail(ANX_ELIMIT, "more than 2^32 result rows: use anx_batch_fetch");
+  // offsets (pinned as well: they are a D2H target) and rows in ONE pinned block of the result cache: [rows | offsets]
+  const size_t row_bytes = (std::max<size_t>(1, base[S]) * sizeof(anx_topk_record) + 63) & ~(size_t)63;
+  char* blk = static_cast<char*>(anx::host_result_alloc(row_bytes + (n + 2) * sizeof(uint32_t)));
+  if (!blk) return fail(ANX_EINVAL, "out of memory");
+  anx_topk_record* out = reinterpret_cast<anx_topk_record*>(blk);
+  uint32_t* off = reinterpret_cast<uint32_t*>(blk + row_bytes);
+  const int rc = on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    std::vector<uint32_t> tmp;  // the last offset of a shard is the first of the next: keep the slices disjoint
+    uint32_t* dst = off + s.lo;
+    if (g + 1 < S) { tmp.resize(s.n + 1); dst = tmp.data(); }
+    const int r = anx::batch_fetch_compact_into(s.b, out + base[g], dst, (uint32_t)base[g], err);
+    if (r == ANX_OK && g + 1 < S && s.n) memcpy(off + s.lo, tmp.data(), s.n * sizeof(uint32_t));
+    return r;
+  });
+  if (rc) { anx::host_result_free(blk); return rc; }
+  off[n] = (uint32_t)base[S];
+  *rows = out;
+  *offs = off;
+  return ANX_OK;
+}
+void anx_compact_free(anx_topk_record* rows, uint32_t* offsets) {
+  (void)offsets;  // one block: the offsets live behind the rows
+  anx::host_result_free(rows);
+}
+void anx_compact_to_results(const anx_topk_record* rows, size_t n_rows, anx_result* out) {
+  if (!rows || !out) return;
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) out[i] = anx_result{rows[i].vocab_id, rows[i].dist_score, (double)rows[i].freq_score, ANX_NO_VIA};
+  };
+  unsigned nthreads = n_rows < (1u << 16) ? 1u : std::max(1u, std::min(16u, anx::usable_hw_threads()));
+  if (nthreads == 1) { work(0, n_rows); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nthreads; ++t) th.emplace_back(work, n_rows * t / nthreads, n_rows * (t + 1) / nthreads);
+  for (auto& x : th) x.join();
+}
 int anx_batch_fetch_pairs(const anx_batch* b, anx_pair** out, size_t* n) {
   if (!b || !out || !n) return fail(ANX_EINVAL, "NULL argument");
   const size_t S = b->shards.size();

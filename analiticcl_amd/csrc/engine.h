@@ -39,6 +39,7 @@ int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx
 size_t batch_n_results(const Batch* b);
 size_t batch_n_input(const Batch* b);
 int batch_fetch_into(const Batch* b, anx_result* rows, size_t* offs, size_t base, std::string& err);
+int batch_fetch_compact_into(const Batch* b, anx_topk_record* rows, uint32_t* offs, uint32_t base, std::string& err);
 int batch_fetch_pairs(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_pair** out, size_t* n,
                       std::string& err);
 int batch_pair_counts(const HostModel& m, const DeviceLexicon* dl, Batch* b, uint32_t** out, std::string& err);

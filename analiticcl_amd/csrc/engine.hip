@@ -1292,6 +1292,44 @@ int batch_fetch_into(const Batch* b, anx_result* out, size_t* off, size_t base, 
   return rc;
 }
 
+// The same rows as 16-byte anx_topk_record {vocab u32, freq f32, dist f64} with u32 offsets: half the bytes over PCIe (config 2:
+// 70 MB instead of 141 MB per million queries).  out[0 .. n_results), off[0 .. n_input] = base + CSR offsets.
+int batch_fetch_compact_into(const Batch* b, anx_topk_record* out, uint32_t* off, uint32_t base, std::string& err) {
+  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t n = b->n_input;
+  int rc = ANX_OK;
+  if (b->nq && b->n_results) {
+    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_tmp = nullptr;
+    anx_topk_record* d_out = nullptr;
+    hipStream_t st = reinterpret_cast<hipStream_t>(b->last_stream);
+    auto body = [&]() -> int {
+      const uint32_t n32 = (uint32_t)n, nq32 = (uint32_t)b->nq;
+      const size_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE + 2;
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_cnt), n * sizeof(uint32_t)));
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_off), (n + 1) * sizeof(uint32_t)));
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_tmp), nblk * sizeof(uint32_t)));
+      HIP_TRY(pool_malloc(reinterpret_cast<void**>(&d_out), b->n_results * sizeof(anx_topk_record)));
+      HIP_TRY(hipMemsetAsync(d_cnt, 0, n * sizeof(uint32_t), st));
+      hipLaunchKernelGGL(k_fetch_counts, dim3((nq32 + 255) / 256), dim3(256), 0, st, nq32, b->r_count, b->q_orig, d_cnt);
+      exclusive_scan(d_cnt, n32, d_off, d_tmp, st);
+      hipLaunchKernelGGL(k_export_rows, dim3((nq32 + 255) / 256), dim3(256), 0, st, nq32, b->soff, b->r_count, b->r_rows, b->q_orig, d_off, d_out);
+      HIP_TRY(hipMemcpyAsync(off, d_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(out, d_out, b->n_results * sizeof(anx_topk_record), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (base)
+        for (size_t i = 0; i <= n; ++i) off[i] += base;
+      return ANX_OK;
+    };
+    rc = body();
+    if (rc) (void)hipStreamSynchronize(st);
+    for (void* p : {(void*)d_cnt, (void*)d_off, (void*)d_tmp, (void*)d_out}) pool_free(p);
+  } else {
+    for (size_t i = 0; i <= n; ++i) off[i] = base;
+  }
+  return rc;
+}
+
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err) {
   (void)m;

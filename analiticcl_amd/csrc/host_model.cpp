@@ -65,6 +65,7 @@ bool first_char_is_lowercase(const char* s) {
   return in_table(anx_uc_lower, anx_uc_lower_n, u8decode(s, strlen(s), &l));
 }
 bool is_alphabetic_cp(uint32_t cp) { return in_table(anx_uc_alpha, anx_uc_alpha_n, cp); }
+const uint32_t (*alphabetic_ranges(uint32_t* n))[2] { *n = (uint32_t)anx_uc_alpha_n; return anx_uc_alpha; }
 uint32_t utf8_decode_at(const char* s, size_t avail, int* len) { return u8decode(s, avail, len); }
 static std::string trim_ws(const std::string& f);
 std::string trim_whitespace(const std::string& s) { return trim_ws(s); }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/anx.h"
+#include "confusables_core.hpp"
 
 namespace anx {
 
@@ -54,6 +55,7 @@ struct EncodeTables {
 void build_encode_tables(const Alphabet& a, EncodeTables& out);
 bool first_char_is_lowercase(const char* utf8);  // char::is_lowercase on text.chars().next()
 bool is_alphabetic_cp(uint32_t cp);              // char::is_alphabetic (L* + Nl; see oracle/gen_unicode.py)
+const uint32_t (*alphabetic_ranges(uint32_t* n))[2];  // the table behind it: sorted inclusive code point ranges
 uint32_t utf8_decode_at(const char* s, size_t avail, int* len);
 std::string trim_whitespace(const std::string& s);  // str::trim()
 // Host threads worth starting: hardware threads, limited by the affinity mask and the cgroup CPU quota (the GPU boxes
@@ -215,7 +217,19 @@ class HostModel {
   // decoded copy built on first use
   void confusable_weights(const char* input, size_t len, const uint64_t* ids, size_t n, double* out) const;
   void confusable_weights(const std::string& input, const uint64_t* ids, size_t n, double* out) const { confusable_weights(input.data(), input.size(), ids, n, out); }
+  // flattened pattern tables (confusables_core.hpp Patterns): what the host matcher and the device kernel read
+  struct ConfTables {
+    std::vector<cdiff::FlatConf> conf;
+    std::vector<cdiff::FlatOp> ops;
+    std::vector<cdiff::FlatOpt> opts;
+    std::vector<uint32_t> pool;
+  } conf_tables;
+  void rebuild_conf_tables();
+  cdiff::Patterns conf_patterns() const;
   struct ConfCache;                                   // UTF-32 texts + character sets of the vocabulary (confusables.cpp)
+  const ConfCache& conf_vocab() const;                // built on first use, rebuilt when the vocabulary grew
+  // its arrays for the device upload: code point pool, offsets [V + 1], cdiff::CharSet [V]
+  void conf_vocab_arrays(const uint32_t** pool, size_t* npool, const uint32_t** off, const void** cs, size_t* n) const;
   mutable std::atomic<const ConfCache*> conf_cache{nullptr};      // current copy (readers take no lock and no reference count)
   mutable std::vector<std::shared_ptr<ConfCache>> conf_cache_owned;  // every copy ever published, released with the model
   mutable std::mutex conf_cache_mu;

@@ -556,7 +556,7 @@ __device__ inline void scan_wave(const ScanArgs& A) {
 // <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
 // 64 with spills -> 2.60 ms)
 template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scan_bits(ScanArgs A) { scan_wave<NP, true>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_bits(ScanArgs A) { scan_wave<NP, true>(A); }
 template <int NP>
 __global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false>(A); }
 

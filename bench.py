@@ -180,7 +180,7 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
             t1 = time.perf_counter()
             b2.run(stream_handle)
             t2 = time.perf_counter()
-            arrs = b2.fetch_arrays()
+            arrs = b2.fetch_compact()   # 16-byte records + u32 offsets (anx_batch_fetch_compact)
             t3 = time.perf_counter()
             b2.free()
             reps.append((t3 - t, t1 - t, t2 - t1, t3 - t2, int(arrs[0][-1])))
@@ -195,7 +195,7 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
             for _ in range(per):
                 bb = model.encode_packed(packed, len(queries), params)
                 bb.run(st2.cuda_stream)
-                res = bb.fetch_arrays()
+                res = bb.fetch_compact()
                 del res
                 bb.free()
         th = [threading.Thread(target=worker, args=(x,)) for x in streams2]  # warm the pools of a second set of buffers
@@ -213,7 +213,7 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
         e2e = {"queries_per_s": args.queries / best[0], "two_threads_queries_per_s": piped, "s_per_batch": best[0], "encode_upload_s": best[1], "run_s": best[2],
                "download_s": best[3], "rows": best[4],
                "what": "host buffer of NUL-terminated UTF-8 strings -> anx_batch_encode_packed (H2D + device-side encoder) -> anx_batch_run -> "
-                       "anx_batch_fetch (ranked rows in input order, host memory), best of 3, one batch at a time, no overlap between batches"}
+                       "anx_batch_fetch_compact (ranked rows in input order as 16-byte records + u32 offsets, pinned host memory), best of 3, one batch at a time, no overlap between batches"}
     return e2e
 
 

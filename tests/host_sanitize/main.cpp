@@ -72,6 +72,18 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
           for (size_t j = 0; j < in[i].size(); ++j, ++w0) CHECK(pairs[w0].query == i && pairs[w0].vocab_id == (uint32_t)(unsigned char)in[i][j]);
         anx_counts_free(counts);
         anx_pairs_free(pairs);
+        if (nrep != 3) {  // compact records over the shards == the anx_result rows
+          anx_topk_record* cr = nullptr; uint32_t* co = nullptr;
+          CHECK(anx_batch_fetch_compact(b, &cr, &co) == ANX_OK);
+          std::vector<anx_result> view(off[in.size()] + 1);
+          anx_compact_to_results(cr, off[in.size()], view.data());
+          for (size_t i = 0; i <= in.size(); ++i) CHECK(co[i] == off[i]);
+          CHECK(memcmp(view.data(), rows, off[in.size()] * sizeof(anx_result)) == 0);
+          anx_compact_free(cr, co);
+        } else {
+          anx_topk_record* cr = nullptr; uint32_t* co = nullptr;
+          CHECK(anx_batch_fetch_compact(b, &cr, &co) == ANX_EINVAL);
+        }
         size_t used = 0;
         if (anx_batch_num_shards(b) > 1) CHECK(anx_batch_export_compact(b, &used, 8, nullptr, &used) == ANX_EINVAL);
       }

@@ -77,6 +77,12 @@ int batch_fetch_into(const Batch* b, anx_result* rows, size_t* offs, size_t base
   for (size_t i = 0; i < b->off.size(); ++i) offs[i] = base + b->off[i];
   return ANX_OK;
 }
+int batch_fetch_compact_into(const Batch* b, anx_topk_record* rows, uint32_t* offs, uint32_t base, std::string& err) {
+  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  for (size_t i = 0; i < b->rows.size(); ++i) rows[i] = anx_topk_record{(uint32_t)b->rows[i].vocab_id, (float)b->rows[i].freq_score, b->rows[i].dist_score};
+  for (size_t i = 0; i < b->off.size(); ++i) offs[i] = base + (uint32_t)b->off[i];
+  return ANX_OK;
+}
 int batch_fetch(const HostModel&, const DeviceLexicon*, const Batch* b, anx_result** rows, size_t** offs, std::string& err) {
   if (!b) { err = "stub"; return ANX_ENODEVICE; }
   *rows = static_cast<anx_result*>(malloc((b->rows.size() + 1) * sizeof(anx_result)));

@@ -36,7 +36,7 @@ def _model(data_dir, lex, devices, confusables=False, variants=None):
     return g
 
 
-def _run(g, qs, p, packed=False, counts=True):
+def _run(g, qs, p, packed=False, counts=True, compact=False):
     if packed:
         blob = b"".join(q.encode("utf-8") + b"\0" for q in qs)
         b = g.encode_packed(blob, len(qs), p)
@@ -45,6 +45,11 @@ def _run(g, qs, p, packed=False, counts=True):
     b.run_async()
     b.wait()
     out = dict(arrays=b.fetch_arrays(), stats=b.stats(), shards=b.shards())
+    if compact:   # the 16-byte records over the shards == the anx_result rows
+        off, vid, dist, freq = out["arrays"]
+        coff, crows = b.fetch_compact()
+        assert np.array_equal(coff, off) and np.array_equal(crows["vocab_id"], vid) and np.array_equal(crows["dist_score"], dist)
+        assert np.array_equal(crows["freq_score"], freq.astype(np.float32))
     if counts:
         out["counts"] = b.pair_counts()
     b.run()  # a second run of a sharded batch (buffers sized from the first)
@@ -82,7 +87,7 @@ def test_two_and_three_replicas_equal_one(data_dir, lex, n, max_len, kw, conf):
         g = _model(data_dir, lex, devices, conf)
         assert g.num_replicas == len(devices)
         for packed in (False, True):
-            got = _run(g, qs, p, packed=packed)
+            got = _run(g, qs, p, packed=packed, compact=not conf)
             assert [s[0] for s in got["shards"]] == devices and sum(s[2] for s in got["shards"]) == n
             assert all(got["shards"][i][1] + got["shards"][i][2] == got["shards"][i + 1][1] for i in range(len(devices) - 1))
             _same(one, got)

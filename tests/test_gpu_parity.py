@@ -582,3 +582,37 @@ def test_host_threads_share_one_model(eng):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_fetch_compact_equals_fetch(eng, data_dir, tmp_path):
+    """anx_batch_fetch_compact: the ranked rows as 16-byte records + u32 offsets (half the PCIe bytes) carry the same ids, the
+    same f64 dist scores and the f32 rounding of the freq scores; refused where a record cannot hold the row (variant lists:
+    `via`; confusables: host rescoring)."""
+    import numpy as np
+    g, _o = eng
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    qs = ["", "seperate"] + synth.make_queries(words, 50000, max_len=20, seed=91) + ["x" * 300, ""]
+    for kw in (dict(max_anagram_distance=3, max_edit_distance=2, max_matches=10), dict(max_anagram_distance=3, max_edit_distance=3, max_matches=0, freq_weight=0.3)):
+        b = g.encode_batch(qs, A.SearchParameters(**kw))
+        b.run()
+        off, vid, dist, freq = b.fetch_arrays()
+        coff, rows = b.fetch_compact()
+        assert coff.dtype == np.uint32 and np.array_equal(coff, off)
+        assert np.array_equal(rows["vocab_id"], vid) and np.array_equal(rows["dist_score"], dist)
+        assert np.array_equal(rows["freq_score"], freq.astype(np.float32))
+        b.free()
+        del rows, coff
+    b = g.encode_batch([], A.SearchParameters())
+    b.run()
+    coff, rows = b.fetch_compact()
+    assert list(coff) == [0] and rows.size == 0
+    b.free()
+    m = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    m.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+    m.add_to_confusables("-[y]+[i]", 1.1)
+    m.build()
+    b = m.encode_batch(qs[:100], A.SearchParameters())
+    b.run()
+    with pytest.raises(A.AnxError, match="confusables"):
+        b.fetch_compact()
+    b.free()
