@@ -78,6 +78,9 @@ struct anx_batch {
   // confusables loaded: the device ranks without the cutoff (late) or without crop and cutoff (early); the host
   // rescoring in anx_batch_fetch needs the caller's parameters and the input texts
   bool rescore = false;
+  // ... unless the weighting runs on the device (conf.hip; default): the rows come back final.  A run that met a row the device
+  // could not weight (string beyond its fixed working memory) falls back to the host path for the whole batch.
+  bool dev_conf = false;
   anx_params params;
   std::string in_text;            // the inputs, each followed by a NUL byte (one copy of the caller's buffer, not a string each)
   std::vector<uint32_t> in_off;   // n + 1 offsets into in_text
@@ -107,11 +110,19 @@ static void rescore_with_confusables(const anx::HostModel& m, const std::string&
   const bool early = m.confusables_before_pruning;
   const size_t n = in_off.empty() ? 0 : in_off.size() - 1;
   std::vector<size_t> newlen(n, 0);
+  // early: the reference weights its candidates in gather order and sorts once (src/lib.rs:1505-1535), so rows that tie after
+  // the weighting keep that order.  The device handed the rows over ranked by the unweighted score: put them back first.
+  const std::vector<uint32_t>* gorder = early ? &m.vocab_gather_order() : nullptr;
   // every input is independent: edit scripts, re-ranking and cut-off on host threads, in place inside the input's row range
   auto work = [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) {
       anx_result* v = rows + offs[i];
       const size_t cnt = offs[i + 1] - offs[i];
+      if (gorder)
+        std::stable_sort(v, v + cnt, [&](const anx_result& a, const anx_result& b) {
+          const uint64_t ia = a.via != ANX_NO_VIA ? a.via : a.vocab_id, ib = b.via != ANX_NO_VIA ? b.via : b.vocab_id;
+          return (ia < gorder->size() ? (*gorder)[ia] : 0xFFFFFFFFu) < (ib < gorder->size() ? (*gorder)[ib] : 0xFFFFFFFFu);
+        });
       // the weight belongs to the matched item: the variant itself for rows reached through a variant list
       uint64_t ids[64];
       double wts[64];
@@ -676,11 +687,14 @@ static int check_resident(const anx_model* m) {  // there is no CPU fallback
 anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p) {
   if (check_encode_args(m, utf8, n, p) || check_resident(m)) return nullptr;
   bool rescore;
-  const anx_params dp = device_params(m, p, &rescore);
+  anx_params dp = device_params(m, p, &rescore);
+  const bool dev_conf = rescore && !anx::switches().confusables_host;
+  if (dev_conf) { dp = *p; rescore = false; }
   anx_batch* h = new anx_batch();
   h->model = m;
   h->n_input = n;
   h->rescore = rescore;
+  h->dev_conf = dev_conf;
   h->params = *p;
   const size_t S = shards_for(m, n);
   h->shards.resize(S);
@@ -688,7 +702,8 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
   const int rc = on_shards(h, [&](size_t g, std::string& err) {
     Shard& s = h->shards[g];
     int code = ANX_OK;
-    s.b = anx::batch_encode(m->host, m->replicas[(size_t)s.replica].dev, utf8 + s.lo, s.n, dp, err, &code);
+    s.b = anx::batch_encode(m->host, m->replicas[(size_t)s.replica].dev, utf8 + s.lo, s.n, dp, err, &code, dev_conf);
+    if (s.b && dev_conf) anx::batch_set_run_mode(s.b, dp, m->host.confusables_before_pruning ? 2 : 1);
     return s.b ? ANX_OK : (code ? code : ANX_ENODEVICE);
   });
   if (rc) { free_shards(h); delete h; return nullptr; }
@@ -710,7 +725,9 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
   // the buffer goes to the device as it is; the device-side encoder finds the strings' offsets there (the host only needs
   // them when confusables are loaded: rescoring reads the input strings)
   bool rescore;
-  const anx_params dp = device_params(m, p, &rescore);
+  anx_params dp = device_params(m, p, &rescore);
+  const bool dev_conf = rescore && !anx::switches().confusables_host;
+  if (dev_conf) { dp = *p; rescore = false; }  // weighted on the device: the host needs neither the offsets nor a copy of the inputs
   std::vector<uint32_t> off;
   if (rescore && !anx::packed_offsets(blob, blob_len, n, off)) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); return nullptr; }
   if (check_resident(m)) return nullptr;
@@ -718,6 +735,7 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
   h->model = m;
   h->n_input = n;
   h->rescore = rescore;
+  h->dev_conf = dev_conf;
   h->params = *p;
   const size_t S = shards_for(m, n);
   h->shards.resize(S);
@@ -763,7 +781,8 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
       bytes = rel[s.n];
       o = rel.data();
     }
-    s.b = anx::batch_encode_spans(m->host, m->replicas[(size_t)s.replica].dev, base, bytes, o, s.n, dp, err, &code);
+    s.b = anx::batch_encode_spans(m->host, m->replicas[(size_t)s.replica].dev, base, bytes, o, s.n, dp, err, &code, dev_conf);
+    if (s.b && dev_conf) anx::batch_set_run_mode(s.b, dp, m->host.confusables_before_pruning ? 2 : 1);
     return s.b ? ANX_OK : (code ? code : ANX_ENODEVICE);
   });
   if (rc) { free_shards(h); delete h; return nullptr; }
@@ -780,19 +799,50 @@ int anx_batch_run_async(const anx_model* m, anx_batch* b, void* stream) {
     return anx::batch_run_async(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
   });
 }
+// A device-weighted run met a row the device could not weight (a string beyond the fixed working memory of conf.hip): the whole
+// batch takes the host path instead -- the inputs come back from the device, every shard is re-run with the host-mode parameters
+// (no cutoff; early mode: no crop) and anx_batch_fetch rescoring takes over.  Rare by construction (strings of > 64 code points).
+static int conf_fallback_to_host(const anx_model* m, anx_batch* b, void* stream) {
+  bool any = false;
+  for (const Shard& s : b->shards) any = any || anx::batch_conf_fallback(s.b);
+  if (!b->dev_conf || !any) return ANX_OK;
+  bool rescore;
+  const anx_params dp = device_params(m, &b->params, &rescore);
+  std::vector<std::string> text(b->shards.size());
+  std::vector<std::vector<uint32_t>> off(b->shards.size());
+  const int rc = on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    if (int r = anx::batch_download_text(s.b, text[g], off[g], err)) return r;
+    anx::batch_set_run_mode(s.b, dp, 0);
+    return anx::batch_run(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
+  });
+  if (rc) return rc;
+  b->in_text.clear();
+  b->in_off.assign(1, 0u);
+  for (size_t g = 0; g < b->shards.size(); ++g) {
+    const uint32_t base = (uint32_t)b->in_text.size();
+    b->in_text += text[g];
+    for (size_t i = 1; i < off[g].size(); ++i) b->in_off.push_back(base + off[g][i]);
+  }
+  b->dev_conf = false;
+  b->rescore = true;
+  return ANX_OK;
+}
 int anx_batch_wait(const anx_model* m, anx_batch* b) {
   if (int rc = check_batch(m, b, nullptr)) return rc;
-  return on_shards(b, [&](size_t g, std::string& err) {
+  const int rc = on_shards(b, [&](size_t g, std::string& err) {
     const Shard& s = b->shards[g];
     return anx::batch_wait(m->host, m->replicas[(size_t)s.replica].dev, s.b, err);
   });
+  return rc ? rc : conf_fallback_to_host(m, b, nullptr);
 }
 int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
   if (int rc = check_batch(m, b, stream)) return rc;
-  return on_shards(b, [&](size_t g, std::string& err) {
+  const int rc = on_shards(b, [&](size_t g, std::string& err) {
     const Shard& s = b->shards[g];
     return anx::batch_run(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
   });
+  return rc ? rc : conf_fallback_to_host(m, b, stream);
 }
 int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   if (!b || !rows || !offs) return fail(ANX_EINVAL, "NULL argument");

@@ -246,6 +246,21 @@ void HostModel::confusable_weights(const char* input, size_t len, const uint64_t
   }
 }
 
+const std::vector<uint32_t>& HostModel::vocab_gather_order() const {
+  // keyed on the entry count of the image it was built from (a rebuilt index replaces the image's arrays)
+  if (vocab_order_for.load(std::memory_order_acquire) != &lex || vocab_order_cache.size() != decoder.size()) {
+    std::lock_guard<std::mutex> g(conf_cache_mu);
+    if (vocab_order_for.load(std::memory_order_acquire) != &lex || vocab_order_cache.size() != decoder.size()) {
+      std::vector<uint32_t> o(decoder.size(), 0xFFFFFFFFu);
+      for (size_t e = 0; e < lex.ent_vocab.size() && e < lex.ent_order.size(); ++e)
+        if (lex.ent_vocab[e] < o.size()) o[lex.ent_vocab[e]] = lex.ent_order[e];
+      vocab_order_cache.swap(o);
+      vocab_order_for.store(&lex, std::memory_order_release);
+    }
+  }
+  return vocab_order_cache;
+}
+
 double HostModel::confusable_weight(const std::string& input, uint64_t candidate) const {
   double w = 1.0;
   confusable_weights(input, &candidate, 1, &w);

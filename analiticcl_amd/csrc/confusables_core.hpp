@@ -317,6 +317,7 @@ ANX_HD void diff_main(Ctx& c, const View& a0, const View& b0) {
 
 // ---- cleanup_semantic ---------------------------------------------------------------------------------------------------
 ANX_HD bool is_alphabetic(const Ctx& c, cp_t cp) {
+  if (cp < 128) return ((cp | 32u) - 'a') < 26u;  // the ASCII part of the table: the letters
   int32_t lo = 0, hi = (int32_t)c.nalpha - 1;
   while (lo <= hi) {
     const int32_t mid = (lo + hi) >> 1;
@@ -565,13 +566,22 @@ ANX_HD bool may_match(const Patterns& P, const FlatConf& cf, const View& in, con
 // the edit script, 1.0 when no pattern can match (the script is then not computed).  false = the context overflowed.
 ANX_HD bool confusable_weight(Ctx& c, const Patterns& P, const View& in, const CharSet& ins, const View& cand, const CharSet& cs, double* weight) {
   *weight = 1.0;
+  // the patterns that can match at all (bit j of `live`; with more than 64 patterns the later ones always count as live): only
+  // those are looked for in the script -- may_match is a necessary condition of found_in
+  uint64_t live = 0;
   bool any = false;
-  for (uint32_t j = 0; j < P.nconf && !any; ++j) any = may_match(P, P.conf[j], in, ins, cand, cs);
+  for (uint32_t j = 0; j < P.nconf; ++j) {
+    if (may_match(P, P.conf[j], in, ins, cand, cs)) {
+      any = true;
+      if (j < 64) live |= 1ull << j;
+      else break;  // the rest is tested in the script
+    }
+  }
   if (!any) return true;
   if (!edit_script(c, in, cand)) return false;
   double w = 1.0;
   for (uint32_t j = 0; j < P.nconf; ++j)
-    if (found_in(P, P.conf[j], c.d, c.nd)) w *= P.conf[j].weight;
+    if ((j >= 64 || ((live >> j) & 1ull)) && found_in(P, P.conf[j], c.d, c.nd)) w *= P.conf[j].weight;
   *weight = w;
   return true;
 }

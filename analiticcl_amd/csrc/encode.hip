@@ -434,7 +434,13 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   uint8_t *d_blob = nullptr, *d_codes = nullptr;
   uint32_t *d_off = nullptr, *d_meta = nullptr, *d_bits = nullptr, *d_kind = nullptr, *d_cv = nullptr, *d_slen = nullptr, *d_ctr = nullptr;
   unsigned long long* d_sig = nullptr;
-  if ((rc = sc.get(&d_blob, blob_len + 16, err)) || (rc = sc.get(&d_codes, blob_len + 16, err)) || (rc = sc.get(&d_off, n + 1, err)) ||
+  if (b->keep_text) {  // the inputs stay with the batch: the confusable weighting on the device reads them (conf.hip)
+    if ((rc = balloc(&b->d_text, blob_len + 16, err)) || (rc = balloc(&b->d_textoff, n + 1, err))) return rc;
+    d_blob = b->d_text;
+    d_off = b->d_textoff;
+    b->text_bytes = blob_len;
+  } else if ((rc = sc.get(&d_blob, blob_len + 16, err)) || (rc = sc.get(&d_off, n + 1, err))) return rc;
+  if ((rc = sc.get(&d_codes, blob_len + 16, err)) ||
       (rc = sc.get(&d_meta, n, err)) || (rc = sc.get(&d_bits, n * NBITPLANES, err)) || (rc = sc.get(&d_kind, n, err)) ||
       (rc = sc.get(&d_cv, n * (size_t)NP, err)) || (rc = sc.get(&d_slen, n, err)) || (rc = sc.get(&d_sig, n, err)) || (rc = sc.get(&d_ctr, 8, err)))
     return rc;

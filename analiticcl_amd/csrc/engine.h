@@ -22,12 +22,19 @@ void stream_destroy(int device, void* stream);
 void* host_result_alloc(size_t bytes);
 void host_result_free(void* p);
 
+// keep_text: the inputs' bytes stay on the device with the batch (confusable weighting on the device reads them)
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n,
-                    const anx_params& p, std::string& err, int* code);
+                    const anx_params& p, std::string& err, int* code, bool keep_text = false);
 // the same with the inputs in one buffer: input i = blob[off[i] .. off[i+1] - 1), followed by one NUL byte.  off == nullptr: the
 // inputs are the first n NUL-terminated spans of blob[0, blob_bytes) and the device finds their offsets itself
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
-                          const anx_params& p, std::string& err, int* code);
+                          const anx_params& p, std::string& err, int* code, bool keep_text = false);
+// how the following runs treat confusables: conf_mode 0 = not on the device (the caller rescored / has none), 1 = late, 2 = early
+// (src/lib.rs:1591-1595 / :1505-1508); `p` = the parameters those runs use
+void batch_set_run_mode(Batch* b, const anx_params& p, int conf_mode);
+bool batch_conf_fallback(const Batch* b);  // the last run met a row the device could not weight: repeat it with host-side weighting
+// the inputs as the batch holds them on the device (keep_text): bytes and n + 1 offsets
+int batch_download_text(const Batch* b, std::string& text, std::vector<uint32_t>& off, std::string& err);
 
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
 // the same in two halves: enqueue on `stream` and return / wait for it (statistics, results usable afterwards)

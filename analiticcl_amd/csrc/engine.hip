@@ -440,6 +440,7 @@ void lexicon_free(DeviceLexicon* d) {
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
     if (p) pool_free(p);
+  conf_free(d->dconf);
   bool last;
   { DevPool& pl = pool_of(d->device); std::lock_guard<std::mutex> g(pl.mu); last = --pl.lexicons <= 0; }
   if (last) pool_trim(d->device);  // the last model of this device: hand the cached blocks back to the driver
@@ -761,7 +762,7 @@ static int encode_tail(Batch* b, std::string& err) {
 }
 
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
-                          const anx_params& p, std::string& err, int* code) {
+                          const anx_params& p, std::string& err, int* code, bool keep_text) {
   *code = ANX_OK;
   if (!dl) { err = "model is not resident on a device (no HIP device / anx_model_to_device not called)"; *code = ANX_ENODEVICE; return nullptr; }
   if (hipSetDevice(dl->device) != hipSuccess) { err = "hipSetDevice failed"; *code = ANX_ENODEVICE; return nullptr; }
@@ -770,6 +771,7 @@ Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const cha
   b->device = dl->device;
   b->params = p;
   b->n_input = n;
+  b->keep_text = keep_text;
   int rc;
   if (switches().encode_host) {  // ANX_ENCODE=host: the threaded host encoder (A/B reference)
     std::vector<uint32_t> hoff;
@@ -780,6 +782,13 @@ Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const cha
     std::vector<const char*> ptrs(n);
     for (size_t i = 0; i < n; ++i) ptrs[i] = blob + off[i];  // every span is followed by a NUL byte
     rc = encode_host(m, dl, b, ptrs.data(), n, p, err);
+    if (!rc && keep_text) {  // the host encoder does not upload the inputs: the device-side confusable weighting reads them
+      const size_t bytes = n ? (size_t)off[n] : 0;
+      std::vector<uint32_t> o(off, off + n + 1);
+      if (!n) o.assign(1, 0u);
+      if ((rc = upload(&b->d_text, blob, bytes, err, nullptr)) == 0) rc = upload(&b->d_textoff, o.data(), o.size(), err, nullptr);
+      b->text_bytes = bytes;
+    }
   } else {
     rc = batch_encode_device(m, dl, b, blob, blob_bytes, off, n, p, err);
   }
@@ -790,7 +799,7 @@ Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const cha
 
 // n NUL-terminated strings -> one buffer + offsets (threaded), then batch_encode_spans
 Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n, const anx_params& p,
-                    std::string& err, int* code) {
+                    std::string& err, int* code, bool keep_text) {
   std::vector<uint32_t> off(n + 1, 0);
   unsigned nthreads = std::max(1u, std::min(16u, usable_hw_threads()));
   if (n < 16384) nthreads = 1;
@@ -830,7 +839,7 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
     }
   });
   off[n] = (uint32_t)part[nthreads];
-  return batch_encode_spans(m, dl, blob.data(), blob.size(), off.data(), n, p, err, code);
+  return batch_encode_spans(m, dl, blob.data(), blob.size(), off.data(), n, p, err, code, keep_text);
 }
 
 static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, hipStream_t st, uint32_t* maxout = nullptr) {
@@ -899,7 +908,7 @@ static int ensure_surv(Batch* b, size_t cap, std::string& err) {
 // previous run of the batch (first run: estimates); every kernel bounds-checks its appends, the fills come back with the one
 // read-back at the end, and a run whose assumptions did not hold is repeated with the measured sizes.
 enum { HR_RCTR = 0, HR_SCTR = SCAN_REGIONS * RC_STRIDE, HR_LCTR = 2 * SCAN_REGIONS * RC_STRIDE, HR_CTR = 5 * SCAN_REGIONS * RC_STRIDE,
-       HR_TOTAL_SURV = HR_CTR + CTR_N, HR_TOTAL_RESULTS = HR_TOTAL_SURV + 1, HR_N = HR_TOTAL_RESULTS + 1 };
+       HR_TOTAL_SURV = HR_CTR + CTR_N, HR_TOTAL_RESULTS = HR_TOTAL_SURV + 1, HR_CONF = HR_TOTAL_RESULTS + 1 /* 2 words */, HR_N = HR_CONF + 2 };
 constexpr size_t HR_COLD_OFF = (HR_N * sizeof(uint32_t) + 63) & ~(size_t)63;  // byte offset of the FsCold staging copy in Batch::h_read
 
 // ANX_CAP_DIV=n (tests): the first-run capacity ESTIMATES are divided by n, so that the overflow -> regrow -> repeat path runs
@@ -1095,7 +1104,8 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // ---- compact survivors + rank -----------------------------------------------------------------------
   RankArgs ra;
-  ra.cutoff_threshold = b->params.cutoff_threshold;
+  // confusables weighted on the device, late mode: k_rank crops without the cutoff, conf.hip re-ranks and cuts off afterwards
+  ra.cutoff_threshold = b->conf_mode == 1 ? 0.0 : b->params.cutoff_threshold;
   ra.max_matches = b->params.max_matches;
   ra.freq_weight = b->params.freq_weight;
   ra.have_freq = m.have_freq ? 1 : 0;
@@ -1123,8 +1133,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
                          dl->var_target_freq, dl->var_score, b->c_rows);
     }
     HIP_TRY(hipEventRecord(b->ev[3], st));
+    if (b->conf_mode == 2 && (rc = conf_launch(m, dl, b, st, true, (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu), err))) return rc;
     hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
                        b->qexpand, ra, b->t_key, b->r_rows, b->r_count, 0xFFFFFFFFu, b->counters + CTR_OVERFLOW);
+    if (b->conf_mode == 1 && (rc = conf_launch(m, dl, b, st, false, (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu), err))) return rc;
   } else {
     // No host round trip between scoring and ranking: the row buffers keep the size of the previous run (first run:
     // an estimate), the kernels check the total on the device, and batch_finish repeats the run if it did not fit.
@@ -1134,8 +1146,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
                        (uint32_t)b->surv_region_cap, m.have_freq ? 1 : 0, b->qcur, dl->ent_rec, b->c_rows, b->soff + nq, row_cap,
                        b->counters + CTR_OVERFLOW);
     HIP_TRY(hipEventRecord(b->ev[3], st));
+    if (b->conf_mode == 2 && (rc = conf_launch(m, dl, b, st, true, row_cap, err))) return rc;
     hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
                        b->qexpand, ra, b->t_key, b->r_rows, b->r_count, row_cap, b->counters + CTR_OVERFLOW);
+    if (b->conf_mode == 1 && (rc = conf_launch(m, dl, b, st, false, row_cap, err))) return rc;
   }
   exclusive_scan(b->r_count, nq, b->r_off, b->scan_tmp, st, b->counters + CTR_MAXROWS);
   HIP_TRY(hipEventRecord(b->ev[4], st));
@@ -1145,6 +1159,8 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   HIP_TRY(hipMemcpyAsync(b->h_read + HR_CTR, b->counters, CTR_N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(b->h_read + HR_TOTAL_SURV, b->soff + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(b->h_read + HR_TOTAL_RESULTS, b->r_off + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  b->h_read[HR_CONF] = b->h_read[HR_CONF + 1] = 0;
+  if (b->conf_mode && b->cf_ctr) HIP_TRY(hipMemcpyAsync(b->h_read + HR_CONF, b->cf_ctr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(b->ev_done, st));
   HIP_TRY(hipGetLastError());
   b->launched = true;
@@ -1183,6 +1199,7 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
     for (int l = 0; l < 3; ++l) list_fill = std::max(list_fill, h[HR_LCTR + (l * SCAN_REGIONS + r) * RC_STRIDE]);
   }
   const uint32_t total_surv = h[HR_TOTAL_SURV], total_results = h[HR_TOTAL_RESULTS];
+  b->conf_fallback = b->conf_mode != 0 && h[HR_CONF + 1] != 0;
   // ---- did the run fit what the launch assumed? ------------------------------------------------------------
   int rc;
   bool again = false;
@@ -1479,6 +1496,21 @@ int batch_pair_counts(const HostModel& m, const DeviceLexicon* dl, Batch* b, uin
   return ANX_OK;
 }
 
+void batch_set_run_mode(Batch* b, const anx_params& p, int conf_mode) {
+  b->params = p;
+  b->conf_mode = conf_mode;
+}
+bool batch_conf_fallback(const Batch* b) { return b->conf_fallback; }
+int batch_download_text(const Batch* b, std::string& text, std::vector<uint32_t>& off, std::string& err) {
+  if (!b->d_text || !b->d_textoff) { err = "the batch does not hold its inputs"; return ANX_EINVAL; }
+  HIP_TRY(hipSetDevice(b->device));
+  off.assign(b->n_input + 1, 0u);
+  HIP_TRY(hipMemcpy(off.data(), b->d_textoff, (b->n_input + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  text.assign(b->n_input ? (size_t)off[b->n_input] : 0, '\0');
+  if (!text.empty()) HIP_TRY(hipMemcpy(&text[0], b->d_text, text.size(), hipMemcpyDeviceToHost));
+  return ANX_OK;
+}
+
 void batch_stats(const Batch* b, anx_batch_stats* s) { *s = b->stats; }
 
 void batch_free(Batch* b) {
@@ -1491,7 +1523,8 @@ void batch_free(Batch* b) {
   for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->d_cold, (void*)b->qpairs, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
-                  (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off})
+                  (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off,
+                  (void*)b->d_text, (void*)b->d_textoff, (void*)b->cf_weight, (void*)b->cf_need, (void*)b->cf_ctr, b->cf_work})
     if (p) pool_free(p);
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);

@@ -233,6 +233,12 @@ class HostModel {
   mutable std::atomic<const ConfCache*> conf_cache{nullptr};      // current copy (readers take no lock and no reference count)
   mutable std::vector<std::shared_ptr<ConfCache>> conf_cache_owned;  // every copy ever published, released with the model
   mutable std::mutex conf_cache_mu;
+  // position of every vocabulary item in the reference's gather order (classes by ascending anagram value, then vocab id:
+  // LexiconImage::ent_order), UINT32_MAX for items that are not indexed: what the host-side EARLY confusable rescoring sorts by
+  // before it weights, because the reference weights its candidates in that order (src/lib.rs:1505-1535)
+  const std::vector<uint32_t>& vocab_gather_order() const;
+  mutable std::vector<uint32_t> vocab_order_cache;
+  mutable std::atomic<const LexiconImage*> vocab_order_for{nullptr};
   bool have_lm = false;
   std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
   std::unordered_map<uint64_t, uint32_t> unigrams, bigrams;  // the two orders lm_score_tokens looks up (id, id1 << 32 | id2)

@@ -81,6 +81,7 @@ struct DeviceLexicon {
   uint4* rows = nullptr;
   DevAlphabet alpha;
   size_t bytes = 0;
+  mutable struct DeviceConf* dconf = nullptr;  // confusable patterns + vocabulary texts of this replica (conf.hip), built on first use
 };
 
 enum { CTR_SKIPPED = 2, CTR_MAXROWS = 3 /* longest ranked list of the run */, CTR_OVERFLOW = 4 /* survivor records dropped */, CTR_N = 8 };
@@ -136,6 +137,18 @@ struct Batch {
   void* d_cold = nullptr;          // FsCold of the last launch (k_filter_score's rarely used arguments)
   uint32_t* qpairs = nullptr;      // per query: scored pairs of the last run (only when count_pairs is set)
   bool count_pairs = false;
+  // confusable weighting on the device (conf.hip): 0 none, 1 late (after the crop, then re-rank + cutoff), 2 early (before the crop)
+  int conf_mode = 0;
+  bool keep_text = false;          // keep the inputs' bytes + offsets on the device (conf_mode != 0)
+  uint8_t* d_text = nullptr;       // the inputs as uploaded: input i = d_text[d_textoff[i] .. d_textoff[i + 1] - 1)
+  uint32_t* d_textoff = nullptr;   // [n_input + 1]
+  size_t text_bytes = 0;
+  double* cf_weight = nullptr;     // per row slot
+  uint32_t* cf_need = nullptr;     // row slots that need an edit script
+  uint32_t* cf_ctr = nullptr;      // [0] their number, [1] rows the device could not weight (host fallback)
+  void* cf_work = nullptr;         // per-lane working memory of k_conf_script
+  size_t cf_cap = 0;
+  bool conf_fallback = false;      // the last run raised cf_ctr[1]
   uint32_t* scan_tmp = nullptr;
   uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
   double* p_score = nullptr;       // per pair-list slot: score of the pairs that went through a DL kernel

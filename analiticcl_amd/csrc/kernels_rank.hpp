@@ -249,7 +249,7 @@ __device__ inline void rank_query_all(uint32_t q, bool valid, int gl, int gshift
 
 // Same result, but rows that the cutoff rule (src/lib.rs:1598-1622) is certain to drop are discarded BEFORE the
 // O(n^2) rank-by-counting.  The list is sorted by the very key the cutoff tests, so every row with
-// key <= best / cutoff_threshold (and key < best) lies behind the first such row and is cut; the crop rule
+// key <= best / cutoff_threshold (and key < best) lies behind the first such row and is cut; with freq_weight == 0 the crop rule
 // (:1536-1589) only ever looks at rows before that point or yields a length beyond it (then the cutoff wins).
 // On config 2 the survivors per query are heavy-tailed (mean 10, 2 % above 64 carry half of sum n^2) and most of a
 // long list is below half the best score.  nloop: wave-uniform upper bound of n (ballot count must match).
@@ -266,7 +266,10 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
   const bool sort_weighted = a.freq_weight > 0.0f;    // rank_cmp's branch
   const bool score_weighted = a.freq_weight != 0.0f;  // score()'s branch
   const bool expanded = n && a.any_variants && qex != 0;  // has_expandable_variants
-  const bool prune = a.cutoff_threshold >= 1.0 && !expanded && (!score_weighted || sort_weighted) && n <= 0xFFFFu;
+  // Only with freq_weight == 0: then the crop rule compares like with like and can never cut before the cutoff point.  With a
+  // frequency weight its tie branch compares dist_score with the (weighted) score of row max_matches (src/lib.rs:1558-1566),
+  // which may well be a row the cutoff would drop, and cuts EARLIER than the cutoff point -- the crop has to see the whole list.
+  const bool prune = a.cutoff_threshold >= 1.0 && !expanded && !score_weighted && n <= 0xFFFFu;
   auto key_of = [&](const SurvRow& r) {
     if (!sort_weighted) return r.score;
     const double fs = max_freq > 0.0 ? (double)r.freq / max_freq : (double)r.freq;

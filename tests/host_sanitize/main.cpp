@@ -37,7 +37,9 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
     anx_model* m = anx_model_new(alphabet.c_str(), &w, 0);
     CHECK(m != nullptr);
     CHECK(anx_model_read_vocabulary(m, lexicon.c_str(), &vp) == ANX_OK);
-    if (nrep == 3) CHECK(anx_model_add_to_confusables(m, "-[a]+[e]", 1.05) == ANX_OK);  // the rescoring path keeps the inputs on the host
+    // the host rescoring path keeps the inputs on the host (ANX_CONFUSABLES=host: the device-side weighting is the default)
+    CHECK(anx_debug_set_switch("ANX_CONFUSABLES", nrep == 3 ? "host" : nullptr) == ANX_OK);
+    if (nrep == 3) CHECK(anx_model_add_to_confusables(m, "-[a]+[e]", 1.05) == ANX_OK);
     CHECK(anx_model_build(m, -1) == ANX_OK);
     const int devs[4] = {0, 1, 1, 3};
     CHECK(anx_model_to_devices(m, devs, nrep) == ANX_OK);
@@ -194,6 +196,7 @@ int main(int argc, char** argv) {
   CHECK(anx_find_variants_batch(m, q, 2, &p, &rows, &ro) == ANX_ENODEVICE);
   // packed buffers: the host-side offset scan (confusables are loaded, so the host needs the strings for rescoring)
   {
+    CHECK(anx_debug_set_switch("ANX_CONFUSABLES", "host") == ANX_OK);  // (the default weights on the device and needs no host-side scan)
     const char packed[] = "seperate\0\0\x01x\0acommodate\0longer than eight bytes\0";  // sizeof counts the terminator too
     CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 1, 5, &p) == nullptr && strstr(anx_last_error(), "not resident") != nullptr);
     CHECK(anx_batch_encode_packed(m, packed, sizeof packed - 1, 6, &p) == nullptr && strstr(anx_last_error(), "fewer strings") != nullptr);

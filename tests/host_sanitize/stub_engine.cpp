@@ -32,13 +32,16 @@ void* stream_create(int, std::string&) { return malloc(1); }
 void stream_destroy(int, void* s) { free(s); }
 void* host_result_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void host_result_free(void* p) { free(p); }
-Batch* batch_encode(const HostModel&, const DeviceLexicon* dl, const char* const* utf8, size_t n, const anx_params&, std::string& err, int* code) {
+void batch_set_run_mode(Batch*, const anx_params&, int) {}
+bool batch_conf_fallback(const Batch*) { return false; }
+int batch_download_text(const Batch*, std::string&, std::vector<uint32_t>&, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
+Batch* batch_encode(const HostModel&, const DeviceLexicon* dl, const char* const* utf8, size_t n, const anx_params&, std::string& err, int* code, bool) {
   if (!dl) { err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr; }
   Batch* b = new Batch();
   for (size_t i = 0; i < n; ++i) b->in.emplace_back(utf8[i] ? utf8[i] : "");
   return b;
 }
-Batch* batch_encode_spans(const HostModel&, const DeviceLexicon* dl, const char* blob, size_t bytes, const uint32_t* off, size_t n, const anx_params&, std::string& err, int* code) {
+Batch* batch_encode_spans(const HostModel&, const DeviceLexicon* dl, const char* blob, size_t bytes, const uint32_t* off, size_t n, const anx_params&, std::string& err, int* code, bool) {
   if (!dl) { err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr; }
   Batch* b = new Batch();
   if (off) {

@@ -127,12 +127,16 @@ def test_random_queries_vs_oracle_cli_defaults(eng, data_dir):
     dict(k=("abs", 3), d=("abs", 3), n=1),
     dict(k=("abs", 4), d=("abs", 4), n=7, thr=0.3, cutoff=1.5),
     dict(k=("abs", 3), d=("abs", 2), n=10, fw=0.5),               # weighted ranking (all freqs 1 here)
+    # weighted ranking with a tie at the crop boundary: the crop's tie branch compares dist_score with the weighted score of row
+    # max_matches and cuts far before the cutoff point (found by tools/fuzz_confusables_device.py in round 3)
+    dict(k=("abs", 2), d=("abs", 2), n=20, thr=0.5, cutoff=1.5, fw=0.5),
+    dict(k=("abs", 3), d=("abs", 3), n=5, thr=0.3, cutoff=1.2, fw=0.25),
 ])
 def test_parameter_sets_vs_oracle(eng, data_dir, kw):
     g, o = eng
     words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
     qs = synth.make_queries(words, 250, max_len=20, seed=5)
-    qs += ["a", "I", "Fo", "K", "xyzzyq", "it's", "O'Neil", "étude", "naïve", "b2b", "``", "  ", "e.g.", "AAAA",
+    qs += ["Bono", "Carly", "rocket", "a", "I", "Fo", "K", "xyzzyq", "it's", "O'Neil", "étude", "naïve", "b2b", "``", "  ", "e.g.", "AAAA",
            "antidisestablishmentarianism", "pneumonoultramicroscopicsilicovolcanoconiosis", "ZZZZZZZZZZ"]
     gp, op = params_pair(**kw)
     compare_batch(g, o, qs, gp, op)
@@ -587,7 +591,7 @@ def test_host_threads_share_one_model(eng):
 def test_fetch_compact_equals_fetch(eng, data_dir, tmp_path):
     """anx_batch_fetch_compact: the ranked rows as 16-byte records + u32 offsets (half the PCIe bytes) carry the same ids, the
     same f64 dist scores and the f32 rounding of the freq scores; refused where a record cannot hold the row (variant lists:
-    `via`; confusables: host rescoring)."""
+    `via`; confusables weighted on the host)."""
     import numpy as np
     g, _o = eng
     words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
@@ -611,8 +615,18 @@ def test_fetch_compact_equals_fetch(eng, data_dir, tmp_path):
     m.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
     m.add_to_confusables("-[y]+[i]", 1.1)
     m.build()
-    b = m.encode_batch(qs[:100], A.SearchParameters())
+    A.set_switch("ANX_CONFUSABLES", "host")   # weighted on the host threads: the rows are not final on the device
+    try:
+        b = m.encode_batch(qs[:100], A.SearchParameters())
+        b.run()
+        with pytest.raises(A.AnxError, match="confusables"):
+            b.fetch_compact()
+        b.free()
+    finally:
+        A.set_switch("ANX_CONFUSABLES", None)
+    b = m.encode_batch(qs[:100], A.SearchParameters())   # default: weighted on the device (conf.hip), compact rows are final
     b.run()
-    with pytest.raises(A.AnxError, match="confusables"):
-        b.fetch_compact()
+    off, vid, dist, _freq = b.fetch_arrays()
+    coff, rows = b.fetch_compact()
+    assert np.array_equal(coff, off) and np.array_equal(rows["vocab_id"], vid) and np.array_equal(rows["dist_score"], dist)
     b.free()
