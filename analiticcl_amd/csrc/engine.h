@@ -55,6 +55,45 @@ int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32
 int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, size_t capacity, void* stream,
                          size_t* used, std::string& err);
 void batch_stats(const Batch* b, anx_batch_stats* s);
+
+// ---- search mode's lattice decoding on the device (lattice.hip) ------------------------------------------------------------------
+// One lattice per stretch of text between hard boundaries (src/lib.rs:2088-2276): states = boundaries + start, arcs = the variants
+// of the segments (+ out-of-vocabulary and fail-safe epsilon arcs), listed per DESTINATION state in (source state, arc number)
+// order; state nstates is a virtual end state behind the final states (zero-cost epsilon arcs).  Indices inside a stretch are local.
+struct LatStretch {
+  uint32_t nstates;          // without the virtual end state
+  uint32_t in_off0;          // first of its nstates + 2 entries of LatInput::in_off
+  uint32_t arc0, sym0;       // first arc / symbol
+  uint32_t btok_off0, btok0; // first of its nb + 1 entries of btok_off / first boundary token
+  uint32_t out0;             // first slot of its chosen symbols in the output
+  float best_cost_init;      // (nb - 1) * 2 (src/lib.rs:2319)
+  uint32_t ring;             // 1 + the most states an arc of the stretch spans (virtual end arcs included): the cost lists a merge reads
+  uint64_t node0;            // set by the driver: first node of the stretch in the launch's node pool
+};
+struct LatArc { float cost; uint32_t src; uint32_t sym; };   // sym: local symbol id, 0xFFFFFFFF = epsilon
+struct LatSym { uint32_t vocab_id; uint32_t boundary; };     // OutputSymbol (src/search.rs:133-150): vocab id 0 = out of vocabulary
+struct LatInput {
+  std::vector<LatStretch> st;
+  std::vector<uint32_t> in_off;
+  std::vector<LatArc> arcs;
+  std::vector<LatSym> syms;
+  std::vector<uint32_t> btok_off;
+  std::vector<int32_t> btok;   // LM tokens of the boundary texts (-1 = not in the vocabulary)
+  size_t out_total = 0;
+};
+// the whole call's lattices as plain arrays (search.cpp lays them out in pinned host memory: host_result_alloc)
+struct LatView {
+  const LatStretch* st; size_t nst;
+  const uint32_t* in_off; size_t nin;
+  const LatArc* arcs; size_t narcs;
+  const LatSym* syms; size_t nsyms;
+  const uint32_t* btok_off; size_t nboff;
+  const int32_t* btok; size_t nbtok;
+  size_t out_total;
+};
+// out_n[i] = symbols on the chosen path of stretch i (0xFFFFFFFF: not decoded here -> the host decoder), out_syms[st[i].out0 ..]
+int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& in, const anx_search_params& p, uint32_t* out_n,
+                   uint32_t* out_syms, std::string& err);
 void batch_free(Batch*);
 
 }  // namespace anx

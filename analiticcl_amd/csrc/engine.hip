@@ -441,6 +441,7 @@ void lexicon_free(DeviceLexicon* d) {
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
     if (p) pool_free(p);
   conf_free(d->dconf);
+  lm_free(d->dlm);
   bool last;
   { DevPool& pl = pool_of(d->device); std::lock_guard<std::mutex> g(pl.mu); last = --pl.lexicons <= 0; }
   if (last) pool_trim(d->device);  // the last model of this device: hand the cached blocks back to the driver

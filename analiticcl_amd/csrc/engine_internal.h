@@ -34,6 +34,9 @@ void encoder_stream_release(int device, hipStream_t s);
 struct DeviceConf;
 void conf_free(DeviceConf*);
 int conf_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, hipStream_t st, bool early, uint32_t row_cap, std::string& err);
+// search mode's LM tables of a replica (lattice.hip)
+struct DeviceLm;
+void lm_free(DeviceLm*);
 // device-side query encoder (encode.hip): fills the query and tile arrays of `b` from the packed inputs
 int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
                         const anx_params& p, std::string& err);

@@ -81,6 +81,7 @@ struct DeviceLexicon {
   uint4* rows = nullptr;
   DevAlphabet alpha;
   size_t bytes = 0;
+  mutable struct DeviceLm* dlm = nullptr;      // bigram terms + token lists of the vocabulary (lattice.hip), built on first use
   mutable struct DeviceConf* dconf = nullptr;  // confusable patterns + vocabulary texts of this replica (conf.hip), built on first use
 };
 

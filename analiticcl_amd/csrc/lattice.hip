@@ -1,0 +1,425 @@
+// lattice.hip -- search mode's lattice decoding ON THE DEVICE (gfx950 / CDNA4): k best paths + bigram-LM rerank.
+//
+// Replaces, for all stretches of a find_all_matches batch at once, most_likely_sequence
+// (/root/reference/src/lib.rs:2088-2495: lattice with one state per boundary, rustfst shortest_path(nshortest = max_seq), rerank
+// :2318-2425) and lm_score_tokens (:2580-2674) -- the host decoder in search.cpp is the same algorithm and stays as the A/B
+// reference (ANX_LATTICE=host) and for what the device leaves to it (context rules; lattices beyond the limits below).
+// One WAVE decodes one stretch:
+//   k-best  : states in topological order; the K best paths into a state are the K smallest of {best[src][r] + arc} under
+//             (cost, arc, r): every lane holds the head of one incoming arc's (sorted) candidate list, a wave-wide minimum over
+//             (f32 cost bits << 32 | arc) pops the next path -- the K-way merge search.cpp runs with a binary heap, same order.
+//             A virtual end state behind the final states merges their lists (the host's "ends").
+//   LM      : the final paths mark the lattice nodes they run through; states in order, the marked nodes of a state side by side:
+//             a node's (f32 log-probability sum, token count, last token) = its parent's, extended by the tokens of its symbol --
+//             the same additions in the same order as the host's per-path sum.  Bigram terms come from a device hash table whose
+//             VALUES are the host's logf results (no device logf: bit-identical terms).
+//   select  : perplexity / cost normalisation with portable_log (same bits as the host), weighted mean, first maximum wins;
+//             the winner's symbols are walked back and written out.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "engine_internal.h"
+#include "portable_log.hpp"
+
+namespace anx {
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      err = std::string(#expr) + ": " + hipGetErrorString(_e);                                 \
+      return ANX_ENODEVICE;                                                                    \
+    }                                                                                          \
+  } while (0)
+
+#include "kernels_common.hpp"
+
+struct DeviceLm {  // per replica: the bigram terms and the token lists of the vocabulary
+  int device = 0;
+  unsigned long long* bg_key = nullptr;  // open addressing: (a << 32 | b) + 1, 0 = empty
+  float* bg_val = nullptr;               // the term lm_score_tokens adds for that bigram (host logf)
+  uint32_t bg_mask = 0;
+  uint32_t* ngram_off = nullptr;         // [V + 1]
+  uint32_t* ngram_ids = nullptr;
+  uint32_t nvocab = 0;
+  size_t built_vocab = 0, built_bigrams = 0;
+};
+
+struct LNode {   // one of the K best paths into a state: 24 B
+  float cost;
+  uint32_t par;  // source state << 16 | rank there; 0xFFFFFFFF = the start node
+  uint32_t sym;  // local symbol id, 0xFFFFFFFF = epsilon
+  float lp;      // LM: f32 sum of the bigram terms of the path prefix
+  uint32_t n;    // LM: tokens summed | 0x80000000 = the node lies on a final path
+  int32_t prev;  // LM: last token (-1 = out of vocabulary)
+};
+
+struct LatArgs {
+  const LatStretch* st;
+  uint32_t first, count;     // stretches [first, first + count) of the batch run in this launch
+  const uint32_t* in_off;    // per (stretch, state) CSR into arcs; a stretch owns nstates + 2 entries (virtual end state included)
+  const LatArc* arcs;
+  const LatSym* syms;
+  const uint32_t* btok_off;  // per (stretch, boundary) CSR into btok; a stretch owns nb + 1 entries
+  const int32_t* btok;
+  LNode* nodes;              // node pool of this launch
+  uint32_t K;
+  uint32_t ring_max;         // cost lists the LDS ring of this launch holds (LatStretch::ring above it: host fallback)
+  int use_lm;
+  float lm_weight, variantmodel_weight, contextrules_weight;
+  const unsigned long long* bg_key; const float* bg_val; uint32_t bg_mask;
+  const uint32_t* ngram_off; const uint32_t* ngram_ids; uint32_t nvocab;
+  uint32_t* out_n;           // per stretch: symbols of the chosen path, 0xFFFFFFFF = not decoded here (host fallback)
+  uint32_t* out_syms;        // [LatStretch::out0 ..]
+};
+
+constexpr uint32_t LAT_MAX_STATES = 1024;   // per stretch, virtual end state included
+constexpr uint32_t LAT_MAX_INDEG = 128;     // incoming arcs per state (two candidate heads per lane)
+constexpr float LAT_SMOOTH = -13.815510557964274f;  // src/search.rs:4
+
+__device__ inline unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o);
+    v = other < v ? other : v;
+  }
+  return v;
+}
+__device__ inline float lat_term(const LatArgs& a, int32_t x, int32_t y) {  // one bigram term of lm_score_tokens (src/lib.rs:2632-2674)
+  if (x < 0 || y < 0) return LAT_SMOOTH;
+  const unsigned long long key = (((unsigned long long)(uint32_t)x << 32) | (uint32_t)y) + 1ull;
+  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & a.bg_mask;
+  for (;;) {
+    const unsigned long long k = a.bg_key[h];
+    if (k == key) return a.bg_val[h];
+    if (k == 0ull) return LAT_SMOOTH;
+    h = (h + 1u) & a.bg_mask;
+  }
+}
+
+// wave-wide minimum of non-negative floats (as their bit patterns) with DPP row operations: result in every lane
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8 -> lane 15 of a row = row minimum
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
+  __shared__ uint16_t s_cnt[LAT_MAX_STATES];
+  extern __shared__ float s_ring[];  // [ring][K]: the costs of the K best paths of the last `ring` states (what a merge reads)
+  const uint32_t si = a.first + blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const LatStretch S = a.st[si];
+  const uint32_t ns = S.nstates + 1u;  // with the virtual end state
+  const uint32_t K = a.K;
+  if (ns > LAT_MAX_STATES || K > 0xFFFFu || S.ring == 0u || S.ring > a.ring_max) { if (lane == 0) a.out_n[si] = 0xFFFFFFFFu; return; }
+  const uint32_t* __restrict__ ioff = a.in_off + S.in_off0;
+  for (uint32_t d = 1; d < ns; ++d)
+    if (ioff[d + 1] - ioff[d] > LAT_MAX_INDEG) { if (lane == 0) a.out_n[si] = 0xFFFFFFFFu; return; }  // wave-uniform
+  LNode* __restrict__ nodes = a.nodes + (size_t)(S.node0);
+  const uint32_t ring = S.ring;
+  // ---- k best paths into every state ----------------------------------------------------------------------------------------
+  if (lane == 0) {
+    nodes[0] = LNode{0.0f, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0f, 0u, 0};  // the start node: <bos> (token 0), nothing summed yet
+    s_cnt[0] = 1;
+    s_ring[0] = 0.0f;
+  }
+  __syncthreads();
+  for (uint32_t d = 1; d < ns; ++d) {
+    const uint32_t a0 = ioff[d], indeg = ioff[d + 1] - a0;
+    float* __restrict__ mine = s_ring + (size_t)(d % ring) * K;  // this state's costs (sources are at most ring - 1 states back)
+    // two candidate heads per lane: arcs lane and lane + 64 of the state's incoming list (ordered by source state, arc number)
+    float hc[2] = {0.0f, 0.0f}, ac[2] = {0.0f, 0.0f};
+    uint32_t hsrc[2] = {0u, 0u}, hsym[2] = {0u, 0u}, hr[2] = {0u, 0u}, hn[2] = {0u, 0u};
+    const float* hl[2] = {s_ring, s_ring};
+    bool hv[2] = {false, false};
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t ai = lane + 64u * (uint32_t)w;
+      if (ai < indeg) {
+        const LatArc arc = a.arcs[S.arc0 + a0 + ai];
+        hsrc[w] = arc.src; hsym[w] = arc.sym; ac[w] = arc.cost;
+        hn[w] = s_cnt[arc.src];
+        hl[w] = s_ring + (size_t)(arc.src % ring) * K;
+        if (hn[w]) { hv[w] = true; hc[w] = hl[w][0] + arc.cost; }
+      }
+    }
+    uint32_t count = 0;
+    const bool two = indeg > 64u;  // wave-uniform
+    while (count < K) {
+      // smallest cost (bit pattern of a non-negative float), then the smallest arc among the heads that have it: arcs 0..63 (first
+      // heads, by lane) precede arcs 64..127 (second heads)
+      const uint32_t c0 = hv[0] ? __float_as_uint(hc[0]) : 0xFFFFFFFFu, c1 = (two && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
+      const uint32_t best = wave_min_u32(min(c0, c1));
+      if (best == 0xFFFFFFFFu) break;  // every list is exhausted (wave-uniform)
+      const unsigned long long m0 = __ballot(c0 == best);
+      int w = 0;
+      unsigned long long mw = m0;
+      if (!m0) { w = 1; mw = __ballot(c1 == best); }
+      const uint32_t wl = (uint32_t)__ffsll((long long)mw) - 1u;
+      if (lane == wl) {
+        const float cst = __uint_as_float(best);
+        if (w == 0) {
+          nodes[(size_t)d * K + count] = LNode{cst, (hsrc[0] << 16) | hr[0], hsym[0], 0.0f, 0u, 0};
+          if (++hr[0] < hn[0]) hc[0] = hl[0][hr[0]] + ac[0];
+          else hv[0] = false;
+        } else {
+          nodes[(size_t)d * K + count] = LNode{cst, (hsrc[1] << 16) | hr[1], hsym[1], 0.0f, 0u, 0};
+          if (++hr[1] < hn[1]) hc[1] = hl[1][hr[1]] + ac[1];
+          else hv[1] = false;
+        }
+        mine[count] = cst;
+      }
+      ++count;
+    }
+    if (lane == 0) s_cnt[d] = (uint16_t)count;
+    __syncthreads();  // the state's costs (and its count) are read by the states behind it
+  }
+  const uint32_t end = ns - 1u, npaths = s_cnt[end];
+  if (npaths == 0) { if (lane == 0) a.out_n[si] = 0xFFFFFFFFu; return; }  // no complete path (cannot happen: the epsilon chain): host
+  // ---- LM: (log-probability sum, tokens, last token) of every node on a final path -------------------------------------------
+  if (a.use_lm) {
+    for (uint32_t i = lane; i < npaths; i += 64) {  // mark: a node's prefix is needed once, whoever asks for it
+      uint32_t st_ = end, r = i;
+      for (;;) {
+        LNode& nd = nodes[(size_t)st_ * K + r];
+        if (nd.n & 0x80000000u) break;  // (a racing lane marks the same chain: harmless)
+        nd.n = 0x80000000u;
+        if (nd.par == 0xFFFFFFFFu) break;
+        st_ = nd.par >> 16;
+        r = nd.par & 0xFFFFu;
+      }
+    }
+    __syncthreads();
+    const uint32_t* __restrict__ boff = a.btok_off + S.btok_off0;
+    for (uint32_t d = 1; d < ns; ++d) {
+      const uint32_t cnt = s_cnt[d];
+      for (uint32_t r = lane; r < cnt; r += 64) {
+        LNode& nd = nodes[(size_t)d * K + r];
+        if (!(nd.n & 0x80000000u)) continue;
+        const LNode& pa = nodes[(size_t)(nd.par >> 16) * K + (nd.par & 0xFFFFu)];
+        float lp = pa.lp;
+        uint32_t n = pa.n & 0x7FFFFFFFu;
+        int32_t prev = pa.prev;
+        if (nd.sym != 0xFFFFFFFFu) {  // the tokens of the symbol: its n-gram parts, then the boundary text behind it (src/lib.rs:2580-2629)
+          const LatSym sy = a.syms[S.sym0 + nd.sym];
+          if (sy.vocab_id == 0u) { lp += lat_term(a, prev, -1); ++n; prev = -1; }
+          else if (sy.vocab_id < a.nvocab)
+            for (uint32_t k = a.ngram_off[sy.vocab_id]; k < a.ngram_off[sy.vocab_id + 1]; ++k) {
+              const int32_t t = (int32_t)a.ngram_ids[k];
+              lp += lat_term(a, prev, t); ++n; prev = t;
+            }
+          for (uint32_t k = boff[sy.boundary]; k < boff[sy.boundary + 1]; ++k) {
+            const int32_t t = a.btok[S.btok0 + k];
+            lp += lat_term(a, prev, t); ++n; prev = t;
+          }
+        }
+        nd.lp = lp; nd.n = n | 0x80000000u; nd.prev = prev;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- rerank (src/lib.rs:2318-2425): no context rules here (the host decodes models that have them) -----------------------------
+  double best_ppl = 999999.0;
+  float best_cost = S.best_cost_init;
+  for (uint32_t i = lane; i < npaths; i += 64) {
+    const LNode& nd = nodes[(size_t)end * K + i];
+    if (a.use_lm) {
+      const float logprob = nd.lp + lat_term(a, nd.prev, 1);  // <eos>
+      const double ppl = -1.0 / (double)((nd.n & 0x7FFFFFFFu) + 1u) * (double)logprob;
+      if (ppl < best_ppl) best_ppl = ppl;
+    }
+    if (nd.cost < best_cost) best_cost = nd.cost;
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const double op = __shfl_xor(best_ppl, o);
+    const float oc = __shfl_xor(best_cost, o);
+    best_ppl = op < best_ppl ? op : best_ppl;
+    best_cost = oc < best_cost ? oc : best_cost;
+  }
+  const bool shortcut = !a.use_lm;  // (!have_lm || lm_weight == 0) && no rules
+  double my_score = 0.0;
+  uint32_t my_i = 0xFFFFFFFFu;
+  for (uint32_t i = lane; i < npaths; i += 64) {
+    const LNode& nd = nodes[(size_t)end * K + i];
+    double norm_lm = 0.0;
+    if (a.use_lm) {
+      const float logprob = nd.lp + lat_term(a, nd.prev, 1);
+      const double ppl = -1.0 / (double)((nd.n & 0x7FFFFFFFu) + 1u) * (double)logprob;
+      norm_lm = portable_log(best_ppl / ppl);
+    }
+    const double norm_var = portable_log((double)best_cost / (double)nd.cost);
+    const double norm_ctx = portable_log(1.0 / 1.0);
+    double score;
+    if (shortcut) score = norm_var;
+    else
+      score = ((double)a.lm_weight * norm_lm + (double)a.variantmodel_weight * norm_var + (double)a.contextrules_weight * norm_ctx) /
+              ((double)a.lm_weight + (double)a.variantmodel_weight + (double)a.contextrules_weight);
+    if (my_i == 0xFFFFFFFFu || score > my_score) { my_score = score; my_i = i; }  // first maximum of this lane's paths (ascending i)
+  }
+  // first maximum over the wave: larger score wins, equal scores: the smaller path index.  (A NaN score never wins a comparison,
+  // on the host neither: path 0 stands unless a later score is greater.)
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const double os = __shfl_xor(my_score, o);
+    const uint32_t oi = (uint32_t)__shfl_xor((int)my_i, o);
+    const bool take = oi != 0xFFFFFFFFu && (my_i == 0xFFFFFFFFu || os > my_score || (os == my_score && oi < my_i) || (my_score != my_score && oi < my_i && !(os != os)));
+    if (take) { my_score = os; my_i = oi; }
+  }
+  if (lane == 0) {  // the winner's symbols, walked back over the back-pointers, written in path order
+    uint32_t st_ = end, r = my_i, cnt = 0;
+    for (;;) {
+      const LNode& nd = nodes[(size_t)st_ * K + r];
+      if (nd.par == 0xFFFFFFFFu) break;
+      if (nd.sym != 0xFFFFFFFFu) ++cnt;
+      st_ = nd.par >> 16; r = nd.par & 0xFFFFu;
+    }
+    a.out_n[si] = cnt;
+    uint32_t w = cnt;
+    st_ = end; r = my_i;
+    for (;;) {
+      const LNode& nd = nodes[(size_t)st_ * K + r];
+      if (nd.par == 0xFFFFFFFFu) break;
+      if (nd.sym != 0xFFFFFFFFu) a.out_syms[S.out0 + --w] = nd.sym;
+      st_ = nd.par >> 16; r = nd.par & 0xFFFFu;
+    }
+  }
+}
+
+// ---- host driver -----------------------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_lm_mu;
+template <typename T>
+int lt_upload(T** dst, const void* src, size_t count, std::string& err) {
+  if (*dst) { pool_free(*dst); *dst = nullptr; }
+  HIP_TRY(pool_malloc(reinterpret_cast<void**>(dst), std::max<size_t>(count * sizeof(T), 16)));
+  if (count) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return ANX_OK;
+}
+}  // namespace
+
+void lm_free(DeviceLm* d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  for (void* p : {(void*)d->bg_key, (void*)d->bg_val, (void*)d->ngram_off, (void*)d->ngram_ids})
+    if (p) pool_free(p);
+  delete d;
+}
+
+static int lm_ensure(const HostModel& m, const DeviceLexicon* dl, std::string& err) {
+  std::lock_guard<std::mutex> g(g_lm_mu);
+  DeviceLm*& d = dl->dlm;
+  if (!d) { d = new DeviceLm(); d->device = dl->device; }
+  if (d->bg_key && d->built_vocab == m.decoder.size() && d->built_bigrams == m.bigrams.size()) return ANX_OK;
+  // the bigram terms exactly as search.cpp's term() computes them (src/lib.rs:2632-2674), on the host
+  uint32_t cap = 64;
+  while (cap < 2 * m.bigrams.size() + 16) cap <<= 1;
+  std::vector<unsigned long long> keys(cap, 0ull);
+  std::vector<float> vals(cap, 0.0f);
+  for (const auto& kv : m.bigrams) {
+    const uint64_t aa = kv.first >> 32;
+    auto pit = m.unigrams.find(aa);
+    const uint32_t prior = pit == m.unigrams.end() ? 1u : pit->second;
+    const float v = prior < kv.second ? logf((float)kv.second) : logf((float)kv.second / (float)prior);
+    const unsigned long long key = kv.first + 1ull;
+    uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & (cap - 1);
+    while (keys[h]) h = (h + 1) & (cap - 1);
+    keys[h] = key;
+    vals[h] = v;
+  }
+  int rc;
+  std::vector<uint32_t> off = m.ngram_off, ids = m.ngram_ids;
+  if (off.empty()) off.assign(1, 0u);
+  if ((rc = lt_upload(&d->bg_key, keys.data(), keys.size(), err)) || (rc = lt_upload(&d->bg_val, vals.data(), vals.size(), err)) ||
+      (rc = lt_upload(&d->ngram_off, off.data(), off.size(), err)) || (rc = lt_upload(&d->ngram_ids, ids.data(), ids.size(), err)))
+    return rc;
+  d->bg_mask = cap - 1;
+  d->nvocab = (uint32_t)(off.size() - 1);
+  d->built_vocab = m.decoder.size();
+  d->built_bigrams = m.bigrams.size();
+  return ANX_OK;
+}
+
+// Decodes the stretches of `in` on the replica `dl`.  out_n[i] = symbols of the chosen path of stretch i (0xFFFFFFFF: not decoded,
+// the caller's host decoder takes it), out_syms[st[i].out0 ..] = their local symbol ids in path order.
+int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& in, const anx_search_params& p, uint32_t* out_n,
+                   uint32_t* out_syms, std::string& err) {
+  if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
+  HIP_TRY(hipSetDevice(dl->device));
+  const size_t n = in.nst;
+  if (!n) return ANX_OK;
+  int rc = lm_ensure(m, dl, err);
+  if (rc) return rc;
+  const DeviceLm* lm = dl->dlm;
+  const uint32_t K = std::max<uint32_t>(1u, p.max_seq);
+  hipStream_t st = encoder_stream_acquire(dl->device);
+  struct Rel { hipStream_t s; int dev; ~Rel() { (void)hipStreamSynchronize(s); encoder_stream_release(dev, s); } } rel{st, dl->device};
+  LatStretch* d_st = nullptr; uint32_t* d_inoff = nullptr; LatArc* d_arcs = nullptr; LatSym* d_syms = nullptr; uint32_t* d_boff = nullptr;
+  int32_t* d_btok = nullptr; uint32_t *d_outn = nullptr, *d_outs = nullptr; LNode* d_nodes = nullptr;
+  std::vector<void*> owned;
+  auto dalloc_ = [&](void** p_, size_t bytes) -> int { HIP_TRY(pool_malloc(p_, std::max<size_t>(bytes, 16))); owned.push_back(*p_); return ANX_OK; };
+  struct Free { std::vector<void*>& v; hipStream_t s; ~Free() { (void)hipStreamSynchronize(s); for (void* q : v) pool_free(q); } } fr{owned, st};
+  const size_t nout = in.out_total;
+  if ((rc = dalloc_((void**)&d_st, n * sizeof(LatStretch))) || (rc = dalloc_((void**)&d_inoff, in.nin * 4)) ||
+      (rc = dalloc_((void**)&d_arcs, in.narcs * sizeof(LatArc))) || (rc = dalloc_((void**)&d_syms, in.nsyms * sizeof(LatSym))) ||
+      (rc = dalloc_((void**)&d_boff, in.nboff * 4)) || (rc = dalloc_((void**)&d_btok, in.nbtok * 4)) ||
+      (rc = dalloc_((void**)&d_outn, n * 4)) || (rc = dalloc_((void**)&d_outs, nout * 4)))
+    return rc;
+  // node pool: (nstates + 1) * K nodes per stretch; launches of as many stretches as fit the budget
+  const size_t budget_nodes = ((size_t)6 << 30) / sizeof(LNode);
+  std::vector<LatStretch> hst(in.st, in.st + n);
+  std::vector<std::pair<uint32_t, uint32_t>> launches;  // (first, count)
+  size_t max_pool = 0;
+  for (size_t i = 0; i < n;) {
+    size_t used = 0, j = i;
+    while (j < n) {
+      const size_t need = (size_t)(hst[j].nstates + 1) * K;
+      if (j > i && used + need > budget_nodes) break;
+      hst[j].node0 = used;
+      used += need;
+      ++j;
+    }
+    launches.emplace_back((uint32_t)i, (uint32_t)(j - i));
+    max_pool = std::max(max_pool, used);
+    i = j;
+  }
+  if ((rc = dalloc_((void**)&d_nodes, max_pool * sizeof(LNode)))) return rc;
+  HIP_TRY(hipMemcpyAsync(d_st, hst.data(), n * sizeof(LatStretch), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_inoff, in.in_off, in.nin * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_arcs, in.arcs, in.narcs * sizeof(LatArc), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_syms, in.syms, in.nsyms * sizeof(LatSym), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_boff, in.btok_off, in.nboff * 4, hipMemcpyHostToDevice, st));
+  if (in.nbtok) HIP_TRY(hipMemcpyAsync(d_btok, in.btok, in.nbtok * 4, hipMemcpyHostToDevice, st));
+  LatArgs a;
+  a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.K = K;
+  a.use_lm = (m.have_lm && p.lm_weight > 0.0f) ? 1 : 0;
+  a.lm_weight = p.lm_weight; a.variantmodel_weight = p.variantmodel_weight; a.contextrules_weight = p.contextrules_weight;
+  a.bg_key = lm->bg_key; a.bg_val = lm->bg_val; a.bg_mask = lm->bg_mask; a.ngram_off = lm->ngram_off; a.ngram_ids = lm->ngram_ids; a.nvocab = lm->nvocab;
+  a.out_n = d_outn; a.out_syms = d_outs;
+  // LDS ring of cost lists: as many states as the widest arc of the call spans (+ 1), capped by 48 KB per wave
+  uint32_t ring_need = 2;
+  for (size_t i = 0; i < n; ++i) ring_need = std::max(ring_need, hst[i].ring);
+  const uint32_t ring_cap = (uint32_t)std::max<size_t>(1, ((size_t)48 << 10) / ((size_t)K * sizeof(float)));
+  a.ring_max = std::min(ring_need, ring_cap);
+  const size_t lds = (size_t)a.ring_max * K * sizeof(float);
+  for (const auto& l : launches) {
+    a.first = l.first; a.count = l.second;
+    hipLaunchKernelGGL(k_lattice, dim3(l.second), dim3(64), lds, st, a);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_n, d_outn, n * 4, hipMemcpyDeviceToHost, st));
+  if (nout) HIP_TRY(hipMemcpyAsync(out_syms, d_outs, nout * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return ANX_OK;
+}
+
+}  // namespace anx

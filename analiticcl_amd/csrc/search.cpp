@@ -19,13 +19,16 @@
 #include <limits>
 #include <vector>
 
+#include "engine.h"
 #include "host_model.h"
+#include "portable_log.hpp"
 
 extern "C" {
 int anx_find_variants_batch(const anx_model*, const char* const*, size_t, const anx_params*, anx_result**, size_t**);
 void anx_results_free(anx_result*, size_t*);
 }
 const anx::HostModel& anx_host_of(const anx_model* m);  // capi.cpp
+const anx::DeviceLexicon* anx_replica_of(const anx_model* m, size_t i);  // capi.cpp
 int anx_fail(int code, const std::string& msg);         // capi.cpp
 
 namespace {
@@ -383,9 +386,9 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   double best_score = -99999999.0;
   long best_i = -1;
   for (size_t i = 0; i < npaths; ++i) {
-    const double norm_lm = use_lm ? std::log(best_ppl / ppls[i]) : 0.0;
-    const double norm_var = std::log((double)best_cost / (double)ends[i].cost);
-    const double norm_ctx = std::log(ctx[i] / best_ctx);
+    const double norm_lm = use_lm ? anx::portable_log(best_ppl / ppls[i]) : 0.0;  // (portable_log: the device decoder returns the same bits)
+    const double norm_var = anx::portable_log((double)best_cost / (double)ends[i].cost);
+    const double norm_ctx = anx::portable_log(ctx[i] / best_ctx);
     double score;
     if (shortcut) score = norm_var;
     else
@@ -405,6 +408,102 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     out.push_back(std::move(r));
   }
   lat.lap(4);
+}
+
+// The lattice of one stretch in the flat form lattice.hip decodes (same arcs, same order as most_likely_sequence builds them):
+// appended to `L` (a chunk-local LatInput), symbols' (match, variant) kept for the output in `osym`.  Returns false when the
+// stretch needs no decoding (no symbols / no final state: the matches pass through, src/lib.rs:2277-2290).
+struct SymRef { uint32_t match_index; int32_t variant_index; };
+bool build_lattice(const HostModel& m, const char* text, const std::vector<Span>& matches, const Span* bs, size_t nb, size_t end_offset,
+                   const anx_search_params& p, bool use_lm, anx::LatInput& L, std::vector<SymRef>& osym) {
+  const size_t nstates = nb + 1;
+  struct Arc { float cost; uint32_t dst; uint32_t sym; };
+  static thread_local std::vector<std::vector<Arc>> arcs;
+  if (arcs.size() < nstates) arcs.resize(nstates);
+  for (size_t i = 0; i < nstates; ++i) arcs[i].clear();
+  static thread_local std::vector<anx::LatSym> syms;
+  static thread_local std::vector<SymRef> refs;
+  static thread_local std::vector<uint32_t> finals;
+  syms.clear(); refs.clear(); finals.clear();
+  for (size_t i = 0; i < nb; ++i)
+    if (bs[i].begin == end_offset || bs[i].end == end_offset) finals.push_back((uint32_t)i + 1);
+  for (size_t mi = 0; mi < matches.size(); ++mi) {
+    const Span& mt = matches[mi];
+    long prevb = -1, nextb = -1;
+    for (size_t i = 0; i < nb; ++i) {
+      if (mt.begin == bs[i].end) prevb = (long)i;
+      else if (mt.end == bs[i].begin) nextb = (long)i;
+    }
+    if (nextb < 0) continue;
+    const long n = prevb >= 0 ? nextb - prevb : nextb + 1;
+    const size_t src = prevb >= 0 ? (size_t)prevb + 1 : 0;
+    const uint32_t dst = (uint32_t)nextb + 1;
+    if (mt.has_variants && !mt.variants.empty()) {
+      for (size_t vi = 0; vi < mt.variants.size(); ++vi) {
+        const float cost = (float)n + (1.0f - (float)vr_score(mt.variants[vi], p.base.freq_weight));
+        arcs[src].push_back(Arc{cost, dst, (uint32_t)syms.size()});
+        syms.push_back(anx::LatSym{(uint32_t)mt.variants[vi].vocab_id, (uint32_t)nextb});
+        refs.push_back(SymRef{(uint32_t)mi, (int32_t)vi});
+      }
+    } else if (n == 1) {
+      arcs[src].push_back(Arc{(float)n + 1.0f, dst, (uint32_t)syms.size()});
+      syms.push_back(anx::LatSym{0u, (uint32_t)nextb});
+      refs.push_back(SymRef{(uint32_t)mi, -1});
+    }
+  }
+  if (syms.empty() || finals.empty()) return false;
+  for (size_t i = 0; i < nb; ++i) arcs[i].push_back(Arc{100.0f, (uint32_t)i + 1, 0xFFFFFFFFu});  // failsafe epsilon transitions
+  anx::LatStretch S;
+  S.nstates = (uint32_t)nstates;
+  S.in_off0 = (uint32_t)L.in_off.size();
+  S.arc0 = (uint32_t)L.arcs.size();
+  S.sym0 = (uint32_t)L.syms.size();
+  S.btok_off0 = (uint32_t)L.btok_off.size();
+  S.btok0 = (uint32_t)L.btok.size();
+  S.out0 = (uint32_t)L.out_total;
+  S.best_cost_init = (float)(nb - 1) * 2.0f;
+  S.node0 = 0;
+  // incoming arcs per state in (source state, arc number) order, then the virtual end state behind the finals
+  static thread_local std::vector<uint32_t> indeg;
+  indeg.assign(nstates + 2, 0u);
+  for (size_t sidx = 0; sidx < nstates; ++sidx)
+    for (const Arc& a : arcs[sidx]) ++indeg[a.dst + 1];
+  indeg[nstates + 1] = (uint32_t)finals.size();
+  for (size_t d = 1; d <= nstates + 1; ++d) indeg[d] += indeg[d - 1];
+  const size_t narcs = indeg[nstates + 1];
+  const size_t a0 = L.arcs.size();
+  L.arcs.resize(a0 + narcs);
+  for (size_t d = 0; d <= nstates + 1; ++d) L.in_off.push_back(indeg[d]);  // [d] = first incoming arc of state d; nstates + 2 entries
+  static thread_local std::vector<uint32_t> cur;
+  cur.assign(indeg.begin(), indeg.end());
+  for (size_t sidx = 0; sidx < nstates; ++sidx)
+    for (const Arc& a : arcs[sidx]) L.arcs[a0 + cur[a.dst]++] = anx::LatArc{a.cost, (uint32_t)sidx, a.sym};
+  for (uint32_t f : finals) L.arcs[a0 + cur[nstates]++] = anx::LatArc{0.0f, f, 0xFFFFFFFFu};
+  uint32_t span = 1;
+  for (size_t sidx = 0; sidx < nstates; ++sidx)
+    for (const Arc& a : arcs[sidx]) span = std::max(span, a.dst - (uint32_t)sidx);
+  for (uint32_t f : finals) span = std::max(span, (uint32_t)nstates - f);
+  S.ring = span + 1;
+  L.syms.insert(L.syms.end(), syms.begin(), syms.end());
+  osym.insert(osym.end(), refs.begin(), refs.end());
+  // LM tokens of the boundary text behind a symbol (src/lib.rs:2606-2629): once per boundary
+  for (size_t bi = 0; bi < nb; ++bi) {
+    L.btok_off.push_back((uint32_t)(L.btok.size() - S.btok0));
+    if (!use_lm) continue;
+    const Span& nbs = bs[bi];
+    if (!(nbs.end - nbs.begin == 1 && text[nbs.begin] == ' ') && nbs.end > nbs.begin) {
+      const std::string bt = anx::trim_whitespace(std::string(text + nbs.begin, nbs.end - nbs.begin));
+      if (!bt.empty()) {
+        auto it = m.encoder.find(bt);
+        if (it != m.encoder.end()) for (uint32_t k = m.ngram_off[it->second]; k < m.ngram_off[it->second + 1]; ++k) L.btok.push_back((int32_t)m.ngram_ids[k]);
+        else L.btok.push_back(-1);
+      }
+    }
+  }
+  L.btok_off.push_back((uint32_t)(L.btok.size() - S.btok0));
+  L.out_total += nstates;  // a path has at most one symbol per state it enters
+  L.st.push_back(S);
+  return true;
 }
 
 struct Stretch {  // one hard-boundary "batch" of the reference (src/lib.rs:1821-1940)
@@ -579,14 +678,110 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     static const char* names[5] = {"n-grams", "arena", "device batch", "row views", "append"};
     for (int i = 0; i < 5; ++i) fprintf(stderr, "[anx search]   segments part %-15s %8.2f ms\n", names[i], seg_part[i] * 1e3);
   }
-  // consolidate per stretch: the lattices are independent -> host threads (the reference: rayon over the segments and a
-  // sequential loop over the stretches, src/lib.rs:1821-1940)
+  // consolidate per stretch: the lattices are independent.  Default: all of them in one go on the device (lattice.hip: one wave per
+  // stretch); models with context rules, ANX_LATTICE=host, and the lattices the device hands back are decoded by the host threads
+  // (the reference: rayon over the segments and a sequential loop over the stretches, src/lib.rs:1821-1940).
   std::vector<std::vector<Span>> decoded(stretches.size());
+  const bool need_lattice = sp->max_ngram > 1 || m.have_lm || !m.context_rules.empty();  // src/lib.rs:1912
+  const anx::DeviceLexicon* lat_dev = anx_replica_of(model, 0);
+  const bool on_device = need_lattice && m.context_rules.empty() && !anx::switches().lattice_host && lat_dev && !stretches.empty();
+  std::vector<uint8_t> done(stretches.size(), 0);
+  if (on_device) {
+    const bool use_lm = m.have_lm && sp->lm_weight > 0.0f;
+    // chunks of stretches build their part of the flat lattice input side by side; the parts are then laid end to end
+    const size_t CH = 256, nch = (stretches.size() + CH - 1) / CH;
+    std::vector<anx::LatInput> part(nch);
+    std::vector<std::vector<SymRef>> part_sym(nch);
+    std::vector<std::vector<uint32_t>> part_idx(nch);  // the stretches of the chunk that have a lattice
+    parallel_for(nch, 1, 2, [&](size_t lo, size_t hi) {
+      for (size_t c = lo; c < hi; ++c)
+        for (size_t si = c * CH; si < std::min(stretches.size(), (c + 1) * CH); ++si) {
+          Stretch& st = stretches[si];
+          if (build_lattice(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end, *sp, use_lm,
+                            part[c], part_sym[c]))
+            part_idx[c].push_back((uint32_t)si);
+          else { decoded[si].insert(decoded[si].end(), st.matches.begin(), st.matches.end()); done[si] = 1; }  // src/lib.rs:2277-2290
+        }
+    });
+    // The whole call's lattices in ONE pinned block (the result cache of engine.hip): [stretches | in_off | arcs | syms | btok_off |
+    // btok | out_n | out_syms]; the chunk parts are copied into place side by side, the uploads run at PCIe speed.
+    struct Base { size_t st, in, arc, sym, boff, btok, out; };
+    std::vector<Base> base(nch + 1, Base{0, 0, 0, 0, 0, 0, 0});
+    for (size_t c = 0; c < nch; ++c) {
+      const anx::LatInput& P = part[c];
+      base[c + 1] = Base{base[c].st + P.st.size(), base[c].in + P.in_off.size(), base[c].arc + P.arcs.size(), base[c].sym + P.syms.size(),
+                         base[c].boff + P.btok_off.size(), base[c].btok + P.btok.size(), base[c].out + P.out_total};
+    }
+    const Base T = base[nch];
+    if (T.arc >= ((size_t)1 << 32) || T.sym >= ((size_t)1 << 32) || T.in >= ((size_t)1 << 32) || T.out >= ((size_t)1 << 32)) {
+      free_kept();
+      return anx_fail(ANX_ELIMIT, "more than 2^32 lattice arcs in one call: split the texts");
+    }
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_st = 0, o_in = o_st + al(T.st * sizeof(anx::LatStretch)), o_arc = o_in + al(T.in * 4), o_sym = o_arc + al(T.arc * sizeof(anx::LatArc)),
+                 o_boff = o_sym + al(T.sym * sizeof(anx::LatSym)), o_btok = o_boff + al(T.boff * 4), o_outn = o_btok + al(T.btok * 4),
+                 o_outs = o_outn + al(T.st * 4), o_end = o_outs + al(std::max<size_t>(1, T.out) * 4);
+    char* blk = static_cast<char*>(anx::host_result_alloc(o_end));
+    if (!blk) { free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
+    struct BlkFree { char* p; ~BlkFree() { anx::host_result_free(p); } } blk_free{blk};
+    anx::LatStretch* g_st = reinterpret_cast<anx::LatStretch*>(blk + o_st);
+    uint32_t* g_in = reinterpret_cast<uint32_t*>(blk + o_in);
+    anx::LatArc* g_arc = reinterpret_cast<anx::LatArc*>(blk + o_arc);
+    anx::LatSym* g_sym = reinterpret_cast<anx::LatSym*>(blk + o_sym);
+    uint32_t* g_boff = reinterpret_cast<uint32_t*>(blk + o_boff);
+    int32_t* g_btok = reinterpret_cast<int32_t*>(blk + o_btok);
+    uint32_t* out_n = reinterpret_cast<uint32_t*>(blk + o_outn);
+    uint32_t* out_syms = reinterpret_cast<uint32_t*>(blk + o_outs);
+    std::vector<SymRef> osym(T.sym);
+    std::vector<uint32_t> lat_of(T.st);  // lattice -> stretch
+    parallel_for(nch, 1, 2, [&](size_t lo, size_t hi) {
+      for (size_t c = lo; c < hi; ++c) {
+        const anx::LatInput& P = part[c];
+        const Base& B = base[c];
+        for (size_t i = 0; i < P.st.size(); ++i) {
+          anx::LatStretch S = P.st[i];
+          S.in_off0 += (uint32_t)B.in; S.arc0 += (uint32_t)B.arc; S.sym0 += (uint32_t)B.sym; S.btok_off0 += (uint32_t)B.boff; S.btok0 += (uint32_t)B.btok; S.out0 += (uint32_t)B.out;
+          g_st[B.st + i] = S;
+          lat_of[B.st + i] = part_idx[c][i];
+        }
+        if (!P.in_off.empty()) memcpy(g_in + B.in, P.in_off.data(), P.in_off.size() * sizeof(uint32_t));
+        if (!P.arcs.empty()) memcpy(g_arc + B.arc, P.arcs.data(), P.arcs.size() * sizeof(anx::LatArc));
+        if (!P.syms.empty()) { memcpy(g_sym + B.sym, P.syms.data(), P.syms.size() * sizeof(anx::LatSym)); memcpy(&osym[B.sym], part_sym[c].data(), P.syms.size() * sizeof(SymRef)); }
+        if (!P.btok_off.empty()) memcpy(g_boff + B.boff, P.btok_off.data(), P.btok_off.size() * sizeof(uint32_t));
+        if (!P.btok.empty()) memcpy(g_btok + B.btok, P.btok.data(), P.btok.size() * sizeof(int32_t));
+        part[c] = anx::LatInput();
+        std::vector<SymRef>().swap(part_sym[c]);
+      }
+    });
+    lap("lattice input");
+    const anx::LatView L{g_st, T.st, g_in, T.in, g_arc, T.arc, g_sym, T.sym, g_boff, T.boff, g_btok, T.btok, T.out};
+    std::string err;
+    const int rc = anx::lattice_decode(m, lat_dev, L, *sp, out_n, out_syms, err);
+    if (rc != ANX_OK) { free_kept(); return anx_fail(rc, err); }
+    lap("lattice on the device");
+    parallel_for(T.st, 256, 512, [&](size_t lo, size_t hi) {
+      for (size_t li = lo; li < hi; ++li) {
+        if (out_n[li] == 0xFFFFFFFFu) continue;  // handed back: the host decoder below
+        const size_t si = lat_of[li];
+        const anx::LatStretch& S = g_st[li];
+        std::vector<Span>& out = decoded[si];
+        out.reserve(out_n[li]);
+        for (uint32_t j = 0; j < out_n[li]; ++j) {
+          const SymRef& o = osym[S.sym0 + out_syms[S.out0 + j]];
+          Span r = stretches[si].matches[o.match_index];
+          r.selected = o.variant_index;
+          out.push_back(std::move(r));
+        }
+        done[si] = 1;
+      }
+    });
+  }
   {
     auto work = [&](size_t lo, size_t hi) {
       for (size_t si = lo; si < hi; ++si) {
+        if (done[si]) continue;
         Stretch& st = stretches[si];
-        if (sp->max_ngram > 1 || m.have_lm || !m.context_rules.empty())  // src/lib.rs:1912
+        if (need_lattice)
           most_likely_sequence(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end,
                                *sp, decoded[si]);
         else
@@ -613,9 +808,20 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     }
   }
   std::vector<std::vector<Span>> per_text(n);
-  for (size_t si = 0; si < stretches.size(); ++si) {
-    std::vector<Span>& dst = per_text[stretches[si].text_index];
-    for (Span& s : decoded[si]) dst.push_back(std::move(s));
+  {  // the stretches of a text are consecutive: every text gathers its own
+    std::vector<size_t> first(n + 1, stretches.size());
+    for (size_t si = stretches.size(); si-- > 0;) first[stretches[si].text_index] = si;
+    for (size_t t = n; t-- > 0;) if (first[t] == stretches.size()) first[t] = first[t + 1];
+    parallel_for(n, 8, 64, [&](size_t lo, size_t hi) {
+      for (size_t t = lo; t < hi; ++t) {
+        size_t total_t = 0;
+        for (size_t si = first[t]; si < first[t + 1] && stretches[si].text_index == t; ++si) total_t += decoded[si].size();
+        std::vector<Span>& dst = per_text[t];
+        dst.reserve(total_t);
+        for (size_t si = first[t]; si < first[t + 1] && stretches[si].text_index == t; ++si)
+          for (Span& s_ : decoded[si]) dst.push_back(std::move(s_));
+      }
+    });
   }
   lap("lattice + LM");
   if (timing) {

@@ -465,3 +465,41 @@ def test_python_binding_multiple_lexicons(data_dir, tmp_path):
         best_match = result["variants"][0]
         assert best_match["text"] == lex_term
         assert best_match["lexicons"] == [str(lexicon)]
+
+
+def test_device_lattice_equals_host_lattice(data_dir):
+    """Search mode's lattice decoding on the device (lattice.hip: k best paths per state by a wave-wide merge, LM sums per lattice
+    node, portable_log normalisation) against the host decoder (ANX_LATTICE=host): every match field of every text identical, with
+    and without a language model, for several max_seq / max_ngram / weight settings."""
+    import random
+    import numpy as np
+    lex = os.path.join(data_dir, "eng.aspell.lexicon")
+    words = synth.load_lexicon_words(lex)
+    rng = random.Random(7)
+    common = [w for w in words if w.isalpha()][::23][:5000]
+    LM = A.VocabParams(vocabtype="LM")
+    for with_lm in (True, False):
+        g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+        g.read_lexicon(lex)
+        if with_lm:
+            for _ in range(20000):
+                g.add_to_vocabulary(f"{rng.choice(common)} {rng.choice(common)}", rng.randrange(1, 20), LM)
+            for w in common[:500]:
+                g.add_to_vocabulary(f"<bos> {w}", 5, LM)
+            for w in common[:300]:
+                g.add_to_vocabulary(w, rng.randrange(1, 50), LM)
+        g.build()
+        texts = synth.make_running_text(common, 1.2, seed=31) + ["", "one", "it's a well-known co-op, isn't it?", "a " * 300, "zzqx " * 40 + "end."]
+        for kw in (dict(max_ngram=3), dict(max_ngram=2, max_seq=7), dict(max_ngram=3, max_seq=1), dict(max_ngram=3, lm_weight=0.0),
+                   dict(max_ngram=1), dict(max_ngram=3, max_matches=20, variantmodel_weight=1.0, lm_weight=2.0)):
+            p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, **({"max_matches": 10} | kw))
+            out = {}
+            for mode in ("device", "host"):
+                A.set_switch("ANX_LATTICE", "host" if mode == "host" else None)
+                try:
+                    out[mode] = g.find_all_matches_arrays(texts, p)
+                finally:
+                    A.set_switch("ANX_LATTICE", None)
+            for x, y in zip(out["device"], out["host"]):
+                assert np.array_equal(x, y), (with_lm, kw)
+            assert out["device"][1].size > 50_000
