@@ -57,7 +57,9 @@ struct Span {  // Match without variants (boundaries, segments); byte offsets in
   RowView variants;
   bool has_variants = false;  // Some(vec) vs None
   int selected = -1;
-  std::vector<std::pair<uint16_t, uint8_t>> tags;  // Match.tag / Match.seqnr (src/search.rs:60-66), set by context rules
+  // Match.tag / Match.seqnr (src/search.rs:60-66), set by context rules: entries [tag0, tag0 + ntags) of the tag pool of stretch
+  // tag_stretch (a Span stays trivially copyable: four million of them are moved around per 12 MB of text)
+  uint32_t tag0 = 0, ntags = 0, tag_stretch = 0;
 };
 
 // find_boundaries (src/search.rs:190-233)
@@ -144,8 +146,9 @@ struct OutSym {  // OutputSymbol, src/search.rs:133-150
 // most_likely_sequence (src/lib.rs:2088-2495).  The reference decodes with rustfst's
 // shortest_path(nshortest = max_seq) over a lattice whose states are the boundaries; this is the exact k-best over the
 // same DAG.  The order among equal-cost paths is rustfst-internal in the reference and is not pinned.
+typedef std::vector<std::pair<uint16_t, uint8_t>> TagPool;
 void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span>& matches, const Span* bs, size_t nb,
-                          size_t end_offset, const anx_search_params& p, std::vector<Span>& out) {
+                          size_t end_offset, const anx_search_params& p, std::vector<Span>& out, TagPool& tagpool, uint32_t stretch_index) {
   LatLap lat;
   struct Arc { float cost; size_t dst; long sym; };
   const size_t nstates = nb + 1;
@@ -402,10 +405,14 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
     const OutSym& o = symbols[(size_t)best_syms[j]];
     Span r = matches[o.match_index];
     r.selected = o.variant_index;
-    if (use_rules)
+    if (use_rules) {
+      r.tag0 = (uint32_t)tagpool.size();
+      r.tag_stretch = stretch_index;
       for (const anx::PatternMatchResult& pm : ctx_results[(size_t)best_i][j])
-        if (pm.tag >= 0) r.tags.emplace_back((uint16_t)pm.tag, pm.seqnr);
-    out.push_back(std::move(r));
+        if (pm.tag >= 0) tagpool.emplace_back((uint16_t)pm.tag, pm.seqnr);
+      r.ntags = (uint32_t)tagpool.size() - r.tag0;
+    }
+    out.push_back(r);
   }
   lat.lap(4);
 }
@@ -584,25 +591,42 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   struct OrderRows { anx_result* rows; size_t* offs; };
   std::vector<OrderRows> kept;
   auto free_kept = [&]() { for (OrderRows& o : kept) anx_results_free(o.rows, o.offs); kept.clear(); };
-  auto parallel_stretches = [&](const std::function<void(size_t, size_t)>& work) { parallel_for(stretches.size(), 64, 256, work); };
   double seg_part[5] = {0, 0, 0, 0, 0};  // timing: n-grams, arena, device batch, row views, append
   double seg_t = tnow();
   auto seg_lap = [&](int i) { if (timing) { const double t = tnow(); seg_part[i] += t - seg_t; seg_t = t; } };
   for (uint32_t order = 1; order <= sp->max_ngram; ++order) {
     seg_lap(4);
-    std::vector<std::vector<Span>> cur(stretches.size());
-    std::vector<std::vector<uint8_t>> lookup(stretches.size());  // per segment: goes to the device (not redundant)
+    // The segments of this order, chunk by chunk: 64 consecutive stretches share one segment vector (a vector per stretch and
+    // order meant a quarter of a million small blocks allocated by one thread and freed by another: the allocator's arenas
+    // became the bottleneck of this phase).
+    const size_t SC = 64, nsc = (stretches.size() + SC - 1) / SC;
+    struct ChunkSegs { std::vector<Span> segs; std::vector<uint8_t> look; std::vector<uint32_t> first; };  // first[j]: first segment of the chunk's j-th stretch
+    std::vector<ChunkSegs> cs(nsc);
+    auto parallel_chunks = [&](const std::function<void(size_t)>& work) {
+      parallel_for(nsc, 4, 8, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) work(c); });
+    };
     // per stretch: first segment / first arena byte of its looked-up segments (counts first, prefix sums below)
     std::vector<size_t> seg0(stretches.size() + 1, 0), byte0(stretches.size() + 1, 0);
-    parallel_stretches([&](size_t lo, size_t hi) {
-      for (size_t si = lo; si < hi; ++si) {
+    parallel_chunks([&](size_t c) {
+      ChunkSegs& C = cs[c];
+      const size_t s_lo = c * SC, s_hi = std::min(stretches.size(), s_lo + SC);
+      size_t nbound = 0;
+      for (size_t si = s_lo; si < s_hi; ++si) nbound += stretches[si].b1 - stretches[si].b0 + 1;
+      C.segs.reserve(nbound);  // at most one segment per boundary
+      C.first.reserve(s_hi - s_lo + 1);
+      for (size_t si = s_lo; si < s_hi; ++si) {
         Stretch& st = stretches[si];
-        find_match_ngrams(texts[st.text_index], bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, cur[si]);
-        lookup[si].resize(cur[si].size());
+        C.first.push_back((uint32_t)C.segs.size());
+        find_match_ngrams(texts[st.text_index], bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, C.segs);
+      }
+      C.first.push_back((uint32_t)C.segs.size());
+      C.look.resize(C.segs.size());
+      for (size_t si = s_lo; si < s_hi; ++si) {
+        const Stretch& st = stretches[si];
         size_t ns = 0, nb = 0;
-        for (size_t k = 0; k < cur[si].size(); ++k) {
-          lookup[si][k] = (order == 1 || !redundant_match(cur[si][k], st.matches)) ? 1 : 0;
-          if (lookup[si][k]) { ++ns; nb += cur[si][k].end - cur[si][k].begin + 1; }
+        for (uint32_t k = C.first[si - s_lo]; k < C.first[si - s_lo + 1]; ++k) {
+          C.look[k] = (order == 1 || !redundant_match(C.segs[k], st.matches)) ? 1 : 0;
+          if (C.look[k]) { ++ns; nb += C.segs[k].end - C.segs[k].begin + 1; }
         }
         seg0[si + 1] = ns;
         byte0[si + 1] = nb;
@@ -612,16 +636,18 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     const size_t nseg = seg0[stretches.size()], bytes = byte0[stretches.size()];
     seg_lap(0);
     if (nseg) {
-      // all segments of this order in one NUL-separated arena, every stretch writing its own part
+      // all segments of this order in one NUL-separated arena, every chunk writing its own part
       std::vector<char> arena(bytes);
-      parallel_stretches([&](size_t lo, size_t hi) {
-        for (size_t si = lo; si < hi; ++si) {
+      parallel_chunks([&](size_t c) {
+        const ChunkSegs& C = cs[c];
+        const size_t s_lo = c * SC, s_hi = std::min(stretches.size(), s_lo + SC);
+        for (size_t si = s_lo; si < s_hi; ++si) {
           const char* text = texts[stretches[si].text_index];
           char* w = arena.data() + byte0[si];
-          for (size_t k = 0; k < cur[si].size(); ++k)
-            if (lookup[si][k]) {
-              const size_t l = cur[si][k].end - cur[si][k].begin;
-              memcpy(w, text + cur[si][k].begin, l);
+          for (uint32_t k = C.first[si - s_lo]; k < C.first[si - s_lo + 1]; ++k)
+            if (C.look[k]) {
+              const size_t l = C.segs[k].end - C.segs[k].begin;
+              memcpy(w, text + C.segs[k].begin, l);
               w[l] = '\0';
               w += l + 1;
             }
@@ -642,9 +668,10 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         std::vector<const char*> ptrs(nseg);
         size_t i = 0;
         for (size_t si = 0; si < stretches.size(); ++si) {
+          const ChunkSegs& C = cs[si / SC];
           const char* w = arena.data() + byte0[si];
-          for (size_t k = 0; k < cur[si].size(); ++k)
-            if (lookup[si][k]) { ptrs[i++] = w; w += cur[si][k].end - cur[si][k].begin + 1; }
+          for (uint32_t k = C.first[si % SC]; k < C.first[si % SC + 1]; ++k)
+            if (C.look[k]) { ptrs[i++] = w; w += C.segs[k].end - C.segs[k].begin + 1; }
         }
         rc = anx_find_variants_batch(model, ptrs.data(), nseg, &sp->base, &rows, &offs);
       }
@@ -652,22 +679,24 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
       kept.push_back(OrderRows{rows, offs});
       seg_lap(2);
     }
-    // row views + the order's segments behind the stretch's matches (moved, not copied)
+    // row views + the order's segments behind the stretch's matches
     const OrderRows* orows_cur = nseg ? &kept.back() : nullptr;
-    parallel_stretches([&](size_t lo, size_t hi) {
-      for (size_t si = lo; si < hi; ++si) {
+    parallel_chunks([&](size_t c) {
+      ChunkSegs& C = cs[c];
+      const size_t s_lo = c * SC, s_hi = std::min(stretches.size(), s_lo + SC);
+      for (size_t si = s_lo; si < s_hi; ++si) {
         size_t i = seg0[si];
-        for (size_t k = 0; k < cur[si].size(); ++k)
-          if (lookup[si][k]) {
-            Span& sg = cur[si][k];
+        const uint32_t k0 = C.first[si - s_lo], k1 = C.first[si - s_lo + 1];
+        for (uint32_t k = k0; k < k1; ++k)
+          if (C.look[k]) {
+            Span& sg = C.segs[k];
             sg.has_variants = true;
             sg.variants = RowView{orows_cur->rows + orows_cur->offs[i], orows_cur->offs[i + 1] - orows_cur->offs[i]};
             ++i;
           }
-        std::vector<Span>& mv = stretches[si].matches;
-        mv.insert(mv.end(), std::make_move_iterator(cur[si].begin()), std::make_move_iterator(cur[si].end()));
-        std::vector<Span>().swap(cur[si]);
-        std::vector<uint8_t>().swap(lookup[si]);
+        std::vector<Span>& mv = stretches[si].matches;  // one allocation per stretch for all orders
+        if (order == 1) mv.reserve((size_t)(k1 - k0) * sp->max_ngram + 1);
+        mv.insert(mv.end(), C.segs.begin() + k0, C.segs.begin() + k1);
       }
     });
     seg_lap(3);
@@ -682,6 +711,8 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   // stretch); models with context rules, ANX_LATTICE=host, and the lattices the device hands back are decoded by the host threads
   // (the reference: rayon over the segments and a sequential loop over the stretches, src/lib.rs:1821-1940).
   std::vector<std::vector<Span>> decoded(stretches.size());
+  std::vector<TagPool> tagpools(m.context_rules.empty() ? 0 : stretches.size());
+  TagPool no_tags;
   const bool need_lattice = sp->max_ngram > 1 || m.have_lm || !m.context_rules.empty();  // src/lib.rs:1912
   const anx::DeviceLexicon* lat_dev = anx_replica_of(model, 0);
   const bool on_device = need_lattice && m.context_rules.empty() && !anx::switches().lattice_host && lat_dev && !stretches.empty();
@@ -783,7 +814,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         Stretch& st = stretches[si];
         if (need_lattice)
           most_likely_sequence(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end,
-                               *sp, decoded[si]);
+                               *sp, decoded[si], tagpools.empty() ? no_tags : tagpools[si], (uint32_t)si);
         else
           for (Span& s : st.matches) { s.selected = 0; decoded[si].push_back(std::move(s)); }
       }
@@ -829,7 +860,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     for (int i = 0; i < 5; ++i) fprintf(stderr, "[anx search]   lattice part %-16s %8.2f ms (summed over threads)\n", names[i], (double)g_lat_ns[i].exchange(0) * 1e-6);
   }
   size_t total = 0, total_rows = 0, total_tags = 0;
-  for (auto& v : per_text) { total += v.size(); for (auto& s : v) { total_rows += s.variants.size(); total_tags += s.tags.size(); } }
+  for (auto& v : per_text) { total += v.size(); for (auto& s : v) { total_rows += s.variants.size(); total_tags += s.ntags; } }
   anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, total_tags) * sizeof(anx_match_tag))) : nullptr;
   if (out_tags && !otags) { free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
   anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, total) * sizeof(anx_match)));
@@ -840,7 +871,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   std::vector<size_t> row0(n + 1, 0), tag0(n + 1, 0);
   for (size_t t = 0; t < n; ++t) {
     size_t nr = 0, nt = 0;
-    for (const Span& sp_ : per_text[t]) { nr += sp_.variants.size(); nt += sp_.tags.size(); }
+    for (const Span& sp_ : per_text[t]) { nr += sp_.variants.size(); nt += sp_.ntags; }
     oo[t + 1] = oo[t] + per_text[t].size();
     row0[t + 1] = row0[t] + nr;
     tag0[t + 1] = tag0[t] + nt;
@@ -873,7 +904,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         o.var_end = rw;
         o.tag_begin = (uint32_t)tw;
         if (otags)
-          for (const auto& tg : s.tags) otags[tw++] = anx_match_tag{tg.first, tg.second, 0};
+          for (uint32_t k = 0; k < s.ntags; ++k) { const auto& tg = tagpools[s.tag_stretch][s.tag0 + k]; otags[tw++] = anx_match_tag{tg.first, tg.second, 0}; }
         o.tag_end = (uint32_t)tw;
       }
     }
