@@ -12,81 +12,7 @@ from oracle import cwrap as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-d = synth.materialize_golden("/tmp/anxdata")
-ALPHA = d["alphabet"]
-allwords = [w for w in synth.load_lexicon_words(d["eng"])] + [w for w in synth.load_lexicon_words(d["nld"])][::3]
-
-
-def sp(th):
-    return th[1] if th[0] == "abs" else (float(th[1]) if th[0] == "ratio" else (float(th[1]), int(th[2])))
-
-
-def one(seed):
-    rng = random.Random(seed)
-    nwords = rng.choice((300, 2000, 8000, 30000))
-    words = rng.sample(allwords, nwords)
-    with_freq = rng.random() < 0.6
-    w = [rng.choice((1.0, 0.5, 0.0)), rng.choice((1.0, 0.5, 0.0)), rng.choice((1.0, 0.0)), rng.choice((1.0, 0.0)), rng.choice((1.0, 0.2, 0.0))]
-    if w[0] + w[1] + w[2] + w[3] + w[4] == 0:
-        w[0] = 1.0
-    g = A.VariantModel(ALPHA, A.Weights(ld=w[0], lcs=w[1], prefix=w[2], suffix=w[3], case=w[4]), device=0)
-    o = O.OracleModel(alphabet_path=ALPHA)
-    o.set_weights(*w)
-    for x in words:
-        f = rng.choice((1, 1, 2, 5, 40, 1000, 250000)) if with_freq else None
-        if f is None:
-            g.add_to_vocabulary(x)
-            o.add(x)
-        else:
-            g.add_to_vocabulary(x, f)
-            o.add(x, f)
-    nvar = 0
-    if rng.random() < 0.3:  # variant lists: weighted variants of some items (src/lib.rs:1677-1727)
-        for x in rng.sample(words, min(200, nwords // 4)):
-            ref = g.add_to_vocabulary(x, 3) if with_freq else g.add_to_vocabulary(x)
-            oref = o.add(x, 3) if with_freq else o.add(x)
-            assert ref == oref
-            v = synth.make_queries([x], 1, max_len=40, seed=rng.randrange(1 << 30))[0]
-            sc = rng.choice((1.0, 0.9, 0.5))
-            tr = rng.random() < 0.3
-            a = g.add_variant(ref, v, sc, None, A.VocabParams(vocabtype="INDEXED|TRANSPARENT") if tr else None)
-            b = o.add_variant(oref, v, sc, None, tr)
-            assert bool(a) == bool(b), (x, v)
-            nvar += 1
-    g.build()
-    o.build()
-    k = rng.choice((("abs", rng.randrange(1, 6)), ("ratio", rng.choice((0.2, 0.34, 0.5))), ("ratiolimit", 0.4, rng.randrange(1, 5))))
-    dd = rng.choice((("abs", rng.randrange(1, 6)), ("ratio", rng.choice((0.2, 0.34, 0.5))), ("ratiolimit", 0.4, rng.randrange(1, 4))))
-    n = rng.choice((0, 1, 2, 3, 10, 20))
-    thr = rng.choice((0.0, 0.25, 0.5, 0.7))
-    cutoff = rng.choice((0.0, 1.0, 1.5, 2.0, 3.0))
-    stop = rng.random() < 0.25
-    fw = rng.choice((0.0, 0.0, 0.5, 1.0))
-    gp = A.SearchParameters(max_anagram_distance=sp(k), max_edit_distance=sp(dd), max_matches=n, score_threshold=thr,
-                            cutoff_threshold=cutoff, stop_criterion=stop, freq_weight=fw)
-    op = O.make_params(k, dd, n, thr, cutoff, stop, fw)
-    nq = rng.choice((200, 600, 1500))
-    qs = synth.make_queries(words, nq, max_len=rng.choice((12, 16, 24, 40)), seed=seed)
-    qs += rng.sample(words, min(50, nwords))
-    qs += ["".join(rng.choice("etaoins'. -éßAZ") for _ in range(rng.randrange(0, 30))) for _ in range(40)]
-    qs += ["", "a", "e" * 70, "x" * 255, "y" * 256]
-    b = g.encode_batch(qs, gp)
-    b.run()
-    res = b.fetch()
-    counts = b.pair_counts()
-    st = b.stats()
-    b.free()
-    total = 0
-    for i, text in enumerate(qs):
-        if text == "" or len(text) > 255:
-            assert res[i] == [], (seed, text)
-            continue
-        ores, _opairs, npairs, _ = o.find_variants(text, op, want_pairs=True, cap=1 << 17)
-        total += npairs
-        assert int(counts[i]) == npairs, (seed, text, int(counts[i]), npairs)
-        assert [(v, ds, fs) for v, ds, fs in res[i]] == [tuple(x) for x in ores], (seed, text, res[i][:4], ores[:4])
-    assert st["n_pairs"] == total, (seed, st["n_pairs"], total)
-    return nwords, with_freq, nvar, len(qs), total, (k, dd, n, thr, cutoff, stop, fw)
+from soak_common import parity_round as one   # one round: shared with tests/test_gpu_soak.py
 
 
 t0 = time.time()
