@@ -441,63 +441,29 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   // least the length difference > k, and the table is padded with never-matching entries).
   // One 16-byte record per signature: the run (first class, count) comes with the signature, so a matching step does not
   // wait for a second, dependent load.
-  // Stages the class / record runs (cb, n) of the lanes with ok.  A run is a range of consecutive ids, so id = position + delta
-  // with one delta per run: the lanes drop their run's delta at the stage position where the run starts (a marker), and a
-  // segmented copy-scan over the window fills every position from the last marker before it -- ~50 wave instructions per window
-  // instead of a scalar loop over the runs (round 2: ~15 instructions for each of the ~260 runs of a tile, the largest fixed
-  // cost of a tile).  The window is the free part of the current chunk; a step's records beyond it wait for the next round.
+  // stages the class / record runs (cb, n) of the lanes with ok: scalar loop over the ballot mask
   auto stage_runs = [&](bool ok, uint32_t cb, uint32_t n) {
-    if (!__ballot(ok) || (ANX_DBG(A.dbg) & 4)) return;
+    unsigned long long m = __ballot(ok);
+    if (!m || (ANX_DBG(A.dbg) & 4)) return;
     if (!ok) { cb = 0u; n = 0u; }
-    const uint32_t incl = wave_inclusive_scan(n), excl = incl - n;          // this lane's run = step records [excl, excl + n)
-    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    constexpr uint32_t BIAS = 1024u;  // marker = delta + BIAS > 0 (delta = id - position > -CHUNK); 0 = no marker
-    uint32_t consumed = 0;            // step records already staged (wave-uniform)
-    while (consumed < T) {
-      const uint32_t take = min(CHUNK - ns, T - consumed);  // window: stage positions [ns, ns + take) <- step records [consumed, consumed + take)
-#pragma unroll
-      for (int j = 0; j < (int)(CHUNK / 64u); ++j) {
-        const uint32_t pz = (uint32_t)j * 64u + lane;
-        if (pz >= ns && pz < ns + take) stage[pz] = 0u;
-      }
-      const uint32_t lo = excl > consumed ? excl : consumed, hi = min(excl + n, consumed + take);
-      if (lo < hi) {  // the run intersects the window: marker where its part starts (LDS operations of a wave complete in order)
-        const uint32_t pos = ns + (lo - consumed);
-        stage[pos] = (cb + (lo - excl)) - pos + BIAS;
-      }
-      // every lane owns CHUNK / 64 consecutive positions: fill from the last marker at or before each (the window starts with one)
-      constexpr int PP = (int)(CHUNK / 64u);
-      uint32_t v[PP];
-      uint32_t last = 0u;
-#pragma unroll
-      for (int j = 0; j < PP; ++j) {
-        const uint32_t pq = lane * (uint32_t)PP + (uint32_t)j;
-        v[j] = stage[pq];
-        if (pq >= ns && pq < ns + take && v[j]) last = v[j];
-      }
-      // inclusive "last non-zero" over the lanes (DPP: rows of 16, then across rows), then the carry from the lanes below
-      uint32_t x = last, y;
-      y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x = x ? x : y;   // row_shr:1
-      y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x = x ? x : y;   // row_shr:2
-      y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x = x ? x : y;   // row_shr:4
-      y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true); x = x ? x : y;   // row_shr:8
-      y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true); x = x ? x : y;   // row_bcast:15 -> rows 1, 3
-      y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true); x = x ? x : y;   // row_bcast:31 -> rows 2, 3
-      uint32_t carry = (uint32_t)__shfl_up((int)x, 1);
-      if (lane == 0) carry = 0u;
-#pragma unroll
-      for (int j = 0; j < PP; ++j) {
-        const uint32_t pq = lane * (uint32_t)PP + (uint32_t)j;
-        if (pq >= ns && pq < ns + take) {
-          if (v[j]) carry = v[j];
-          stage[pq] = pq + carry - BIAS;
+    while (m) {
+      const int i = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      uint32_t cbi = (uint32_t)__builtin_amdgcn_readlane((int)cb, i), ni = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
+      while (ni) {
+        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 64 ids
+        stage[ns + lane] = cbi + lane;              // all 64 lanes write; only the first `take` ids count
+        ns += take;
+        cbi += take;
+        ni -= take;
+        if (ns >= CHUNK) {
+          process();
+          const uint32_t rem = ns - CHUNK;
+          uint32_t v = 0;
+          if (lane < rem) v = stage[CHUNK + lane];
+          if (lane < rem) stage[lane] = v;
+          ns = rem;
         }
-      }
-      ns += take;
-      consumed += take;
-      if (ns >= CHUNK) {
-        process();
-        ns = 0;
       }
     }
   };
