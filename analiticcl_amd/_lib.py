@@ -73,7 +73,8 @@ class BatchStats(C.Structure):
                 ("n_results", C.c_uint64), ("n_scan_blocks", C.c_uint64), ("n_tests_kind", C.c_uint64 * 5),
                 ("n_pair_slots", C.c_uint64), ("n_survivors", C.c_uint64), ("ms_scan", C.c_float),
                 ("ms_group", C.c_float), ("ms_score", C.c_float), ("ms_rank", C.c_float), ("ms_total", C.c_float),
-                ("ms_scan_kernel", C.c_float), ("n_selected", C.c_uint64), ("ms_filter_score_kernel", C.c_float)]
+                ("ms_scan_kernel", C.c_float), ("n_selected", C.c_uint64), ("ms_filter_score_kernel", C.c_float),
+                ("n_prefiltered_in_scan", C.c_uint64)]
 
 
 _lib = None

@@ -994,7 +994,7 @@ int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* s) {
     anx_batch_stats t;
     anx::batch_stats(b->shards[g].b, &t);
     s->n_queries += t.n_queries; s->n_pairs += t.n_pairs; s->n_class_tests += t.n_class_tests; s->n_results += t.n_results;
-    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected;
+    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected; s->n_prefiltered_in_scan += t.n_prefiltered_in_scan;
     for (int i = 0; i < 5; ++i) s->n_tests_kind[i] += t.n_tests_kind[i];
     s->ms_scan = std::max(s->ms_scan, t.ms_scan); s->ms_group = std::max(s->ms_group, t.ms_group); s->ms_score = std::max(s->ms_score, t.ms_score);
     s->ms_rank = std::max(s->ms_rank, t.ms_rank); s->ms_total = std::max(s->ms_total, t.ms_total);

@@ -92,8 +92,9 @@ struct LatView {
   size_t out_total;
 };
 // out_n[i] = symbols on the chosen path of stretch i (0xFFFFFFFF: not decoded here -> the host decoder), out_syms[st[i].out0 ..]
-int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& in, const anx_search_params& p, uint32_t* out_n,
-                   uint32_t* out_syms, std::string& err);
+// decodes the lattices [first, first + count) of the view on the replica `dl` (a multi-device model gives every replica a share)
+int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& in, size_t first, size_t count, const anx_search_params& p,
+                   uint32_t* out_n, uint32_t* out_syms, std::string& err);
 void batch_free(Batch*);
 
 }  // namespace anx

@@ -1180,7 +1180,7 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
   const uint32_t nq = (uint32_t)b->nq;
   const uint32_t* h = b->h_read;
   uint32_t maxfill = 0, surv_fill = 0, list_fill = 0;
-  uint64_t n_valid = 0, n_slots = 0, nsel = 0;
+  uint64_t n_valid = 0, n_slots = 0, nsel = 0, n_fused = 0;
   b->n_class_tests = 0;
   for (int i = 0; i <= NBITPLANES; ++i) b->n_tests_kind[i] = 0;
   for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
@@ -1189,6 +1189,7 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
     b->region_fill[r] = c[RC_RAW];
     n_slots += c[RC_RAW];
     n_valid += c[RC_VALID];
+    n_fused += c[RC_FUSED];
     for (int i = 0; i <= NBITPLANES; ++i) {
       uint64_t v;
       memcpy(&v, c + RC_TESTS + 2 * i, sizeof v);
@@ -1236,6 +1237,7 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
   s.n_pair_slots = n_slots;
   s.n_survivors = total_surv;
   s.n_selected = b->n_sel;
+  s.n_prefiltered_in_scan = n_fused;
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.ms_score, b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&s.ms_group, b->ev[2], b->ev[3]);

@@ -22,7 +22,7 @@
 //   reservation counter each (128 B apart): a single contended counter word sustains only ~88 M atomics/s, which
 //   at ~1.5 ms per million queries would be the bottleneck.
 // ------------------------------------------------------------------------------------------------
-enum { RC_RAW = 0, RC_VALID = 1, RC_TESTS = 4 /* u64 per scan kind at 4 + 2*kind */ };
+enum { RC_RAW = 0, RC_VALID = 1, RC_FUSED = 2 /* pairs the fused band-match filter tested */, RC_TESTS = 4 /* u64 per scan kind at 4 + 2*kind */ };
 
 struct WaveOut {
   uint32_t base, left;  // unused part of the current chunk of the pair list (wave-uniform)
@@ -172,6 +172,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   if (fuse) wo.chunk = A.chunk_fused;  // a third of the pairs survive the filter: smaller reservations waste fewer slots
   if (BITS && fuse && lane < t.nq) qsym[lane] = rec32(A.q_rec, t.q0 + lane)[0];
   constexpr uint32_t PBUF = SCAN_PBUF;
+  uint32_t nfused = 0;          // pairs the fused filter tested (wave-uniform; statistics)
   uint32_t npb = 0, phead = 0;  // pairs waiting in the ring pbuf (wave-uniform count and read position), each (entry | query-in-tile << 26)
 
   uint32_t nhits = 0;  // entries in the hit list (wave-uniform)
@@ -188,6 +189,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
       bool keep = act;
       uint32_t flag = 0u;
       if (BITS && fuse) {
+        nfused += cnt;
         const uint4 C = rec32(A.e_rec, e)[0];
         const int lc = (int)(rec32(A.e_rec, e)[1].x & 0xFFu), lq = (int)t.lq, d = (int)t.d;
         const uint4 Q = qsym[ql];
@@ -519,6 +521,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     wo.emitted += tot;
   }
   wave_close(wo, lane, raw);
+  if (BITS && lane == 0 && nfused) atomicAdd(&wo.ctr[RC_FUSED], nfused);
   if (lane == 0 && nchunks) {  // class tests by planes compared (statistics)
     if (BITS) {
       const uint32_t e[5] = {0u, t.kend & 0xFFu, (t.kend >> 8) & 0xFFu, (t.kend >> 16) & 0xFFu, t.nq};

@@ -351,12 +351,27 @@ static int lm_ensure(const HostModel& m, const DeviceLexicon* dl, std::string& e
 
 // Decodes the stretches of `in` on the replica `dl`.  out_n[i] = symbols of the chosen path of stretch i (0xFFFFFFFF: not decoded,
 // the caller's host decoder takes it), out_syms[st[i].out0 ..] = their local symbol ids in path order.
-int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& in, const anx_search_params& p, uint32_t* out_n,
-                   uint32_t* out_syms, std::string& err) {
+int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& whole, size_t first, size_t count, const anx_search_params& p,
+                   uint32_t* out_n, uint32_t* out_syms, std::string& err) {
   if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
   HIP_TRY(hipSetDevice(dl->device));
-  const size_t n = in.nst;
-  if (!n) return ANX_OK;
+  if (!count) return ANX_OK;
+  // the sub-range [first, first + count) of the call's lattices as a view of its own: the arrays of consecutive stretches are
+  // consecutive, so only their part is uploaded (a replica of a multi-device model decodes its share)
+  const LatStretch& s0 = whole.st[first];
+  const bool last = first + count == whole.nst;
+  const LatStretch* s1 = last ? nullptr : &whole.st[first + count];
+  LatView in;
+  in.st = whole.st + first; in.nst = count;
+  in.in_off = whole.in_off + s0.in_off0; in.nin = (last ? whole.nin : s1->in_off0) - s0.in_off0;
+  in.arcs = whole.arcs + s0.arc0; in.narcs = (last ? whole.narcs : s1->arc0) - s0.arc0;
+  in.syms = whole.syms + s0.sym0; in.nsyms = (last ? whole.nsyms : s1->sym0) - s0.sym0;
+  in.btok_off = whole.btok_off + s0.btok_off0; in.nboff = (last ? whole.nboff : s1->btok_off0) - s0.btok_off0;
+  in.btok = whole.btok + s0.btok0; in.nbtok = (last ? whole.nbtok : s1->btok0) - s0.btok0;
+  in.out_total = (last ? whole.out_total : s1->out0) - s0.out0;
+  out_n += first;
+  out_syms += s0.out0;
+  const size_t n = count;
   int rc = lm_ensure(m, dl, err);
   if (rc) return rc;
   const DeviceLm* lm = dl->dlm;
@@ -377,6 +392,9 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& i
   // node pool: (nstates + 1) * K nodes per stretch; launches of as many stretches as fit the budget
   const size_t budget_nodes = ((size_t)6 << 30) / sizeof(LNode);
   std::vector<LatStretch> hst(in.st, in.st + n);
+  for (LatStretch& S : hst) {  // indices relative to the uploaded parts
+    S.in_off0 -= s0.in_off0; S.arc0 -= s0.arc0; S.sym0 -= s0.sym0; S.btok_off0 -= s0.btok_off0; S.btok0 -= s0.btok0; S.out0 -= s0.out0;
+  }
   std::vector<std::pair<uint32_t, uint32_t>> launches;  // (first, count)
   size_t max_pool = 0;
   for (size_t i = 0; i < n;) {

@@ -786,9 +786,32 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     });
     lap("lattice input");
     const anx::LatView L{g_st, T.st, g_in, T.in, g_arc, T.arc, g_sym, T.sym, g_boff, T.boff, g_btok, T.btok, T.out};
-    std::string err;
-    const int rc = anx::lattice_decode(m, lat_dev, L, *sp, out_n, out_syms, err);
-    if (rc != ANX_OK) { free_kept(); return anx_fail(rc, err); }
+    {  // every replica of the model decodes a contiguous share of the lattices (balanced by lattice nodes), each from a thread of its own
+      size_t nrep = 0;
+      while (anx_replica_of(model, nrep)) ++nrep;
+      if (T.st < (size_t)std::max<long>(1, anx::switches().shard_min / 2) * nrep) nrep = 1;  // (ANX_SHARD_MIN: 4096 lattices per replica by default)
+      std::vector<size_t> cut(nrep + 1, T.st);
+      cut[0] = 0;
+      if (nrep > 1) {
+        size_t total_nodes = 0, run = 0, r = 1;
+        for (size_t i = 0; i < T.st; ++i) total_nodes += g_st[i].nstates + 1;
+        for (size_t i = 0; i < T.st && r < nrep; ++i) {
+          run += g_st[i].nstates + 1;
+          if (run * nrep >= total_nodes * r) cut[r++] = i + 1;
+        }
+      }
+      std::vector<std::string> errs(nrep);
+      std::vector<int> rcs(nrep, ANX_OK);
+      auto job = [&](size_t r) { rcs[r] = anx::lattice_decode(m, anx_replica_of(model, r), L, cut[r], cut[r + 1] - cut[r], *sp, out_n, out_syms, errs[r]); };
+      if (nrep == 1) job(0);
+      else {
+        std::vector<std::thread> th;
+        for (size_t r = 0; r < nrep; ++r) th.emplace_back(job, r);
+        for (auto& x : th) x.join();
+      }
+      for (size_t r = 0; r < nrep; ++r)
+        if (rcs[r] != ANX_OK) { free_kept(); return anx_fail(rcs[r], errs[r]); }
+    }
     lap("lattice on the device");
     parallel_for(T.st, 256, 512, [&](size_t lo, size_t hi) {
       for (size_t li = lo; li < hi; ++li) {

@@ -85,7 +85,11 @@ def roofline_of(args, model, queries, st, scan_ms, fs_ms, total_ms):
     # SURVEY.md section 8(d)'s whole-path figure, pairs*(Lpad+32) + queries*208, is reported as "pipeline".
     lpad = 16 if args.max_len <= 16 else (24 if args.max_len <= 24 else 32)
     n_classes = model.num_classes()
-    scan_bytes = st["n_queries"] * 16 + st["n_scan_blocks"] * 44 + n_classes * 44 + st["n_pair_slots"] * 8
+    # round 3: the scan's fused expansion applies the band-match bound itself, so per pair it tests it touches what the scoring
+    # kernel's prefilter touched before (candidate symbols 16 B + entry meta 8 B = the `Lpad + 8` of SURVEY.md section 8(d)'s
+    # per-pair figure; the query's symbols come from LDS, staged once per tile: 16 B per query) and writes a pair record only
+    # for the survivors
+    scan_bytes = st["n_queries"] * (16 + 16) + st["n_scan_blocks"] * 44 + n_classes * 44 + st.get("n_prefiltered_in_scan", 0) * (lpad + 8) + st["n_pair_slots"] * 8
     fs_bytes = st["n_pair_slots"] * (8 + lpad + 8) + st["n_survivors"] * 16
     fs_bytes_survey = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
     if fs_ms > scan_ms:
@@ -120,9 +124,15 @@ def roofline_of(args, model, queries, st, scan_ms, fs_ms, total_ms):
     from analiticcl_amd import _lib as _L
     b7 = _L.lib().anx_model_alphabet_size(model.h) < 0x7E  # = classes + 1 = the largest symbol code (unknown): engine.hip's condition
     c_mask, c_unshifted, c_shifted = (4.4, 8.8, 17.4) if b7 else (0.0, 15.4, 24.0)
-    fs_cycles = (st["n_pair_slots"] / 64.0) * ((c_mask + c_unshifted + 2 * dd * c_shifted + 2 * 6.5) * words) \
+    band_cycles_per_wave = (c_mask + c_unshifted + 2 * dd * c_shifted + 2 * 6.5) * words
+    fused = st.get("n_prefiltered_in_scan", 0)
+    # round 3: with the filter fused into the scan's expansion the band bound of those pairs is the SCAN's work (uniform d per
+    # tile: one OR per shifted word less); k_filter_score only filters the few pairs the scan left unflagged (wide candidates)
+    fs_filter_waves = 0.0 if fused else st["n_pair_slots"] / 64.0
+    fs_cycles = fs_filter_waves * band_cycles_per_wave \
         + (st["n_selected"] / 64.0) * (mean_len * (2 * dd + 1) * 16.0) + (st["n_survivors"] / 64.0) * 900.0
     fs_valu_floor_ms = fs_cycles / SIMD_HZ * 1e3
+    valu_floor_ms += (fused / 64.0) * ((c_mask + c_unshifted + 2 * dd * (c_shifted - 2.2) + 2 * 6.5) * words) / SIMD_HZ * 1e3
     # HBM bytes per launch of that kernel from the committed PMC passes: only for the same workload AND the same kernel
     # sources (the profile is tagged with a hash of csrc/*.hip, *.hpp; stale numbers are dropped)
     traffic, traffic_src = None, None
@@ -531,7 +541,7 @@ def single_process(args):
     scan_ms, fs_ms = kernel_ms["ms_scan_kernel"] / steps, kernel_ms["ms_filter_score_kernel"] / steps
     # per-launch figures of ONE replica (the slowest): the roofline is a per-kernel quantity
     st1 = dict(st)
-    for k in ("n_queries", "n_pairs", "n_class_tests", "n_results", "n_scan_blocks", "n_pair_slots", "n_survivors", "n_selected"):
+    for k in ("n_queries", "n_pairs", "n_class_tests", "n_results", "n_scan_blocks", "n_pair_slots", "n_survivors", "n_selected", "n_prefiltered_in_scan"):
         st1[k] = st[k] / n
     st1["n_tests_kind"] = [x / n for x in st["n_tests_kind"]]
     roofline = roofline_of(args, model, per[0], st1, scan_ms, fs_ms, kernel_ms["ms_total"] / steps)

@@ -240,6 +240,9 @@ typedef struct anx_batch_stats {
   float ms_scan_kernel;      /* HIP events directly around the k_scan_bits launch (the dominant kernel) */
   uint64_t n_selected;       /* pairs that passed the prefilter and went through the DL kernels */
   float ms_filter_score_kernel; /* HIP events directly around the k_filter_score launch */
+  uint64_t n_prefiltered_in_scan; /* scored pairs the scan's fused expansion tested against the band-match bound itself (their
+                                   * survivors are the pair-list slots; the others of n_pairs failed the DL's length test or were
+                                   * left to k_filter_score) */
 } anx_batch_stats;
 /* counts summed over the shards of the batch, times of the slowest replica */
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);

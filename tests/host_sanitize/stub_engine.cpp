@@ -111,9 +111,9 @@ int batch_pair_counts(const HostModel&, const DeviceLexicon*, Batch* b, uint32_t
 int batch_export_topk(const DeviceLexicon*, const Batch*, void*, uint32_t, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_export_compact(const DeviceLexicon*, const Batch*, void*, size_t, void*, size_t*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 // the fake device hands every lattice back (out_n = 0xFFFFFFFF): search.cpp's host decoder takes them -- the fallback path
-int lattice_decode(const HostModel&, const DeviceLexicon* dl, const LatView& in, const anx_search_params&, uint32_t* out_n, uint32_t*, std::string& err) {
+int lattice_decode(const HostModel&, const DeviceLexicon* dl, const LatView&, size_t first, size_t count, const anx_search_params&, uint32_t* out_n, uint32_t*, std::string& err) {
   if (!dl) { err = "stub"; return ANX_ENODEVICE; }
-  for (size_t i = 0; i < in.nst; ++i) out_n[i] = 0xFFFFFFFFu;
+  for (size_t i = first; i < first + count; ++i) out_n[i] = 0xFFFFFFFFu;
   return ANX_OK;
 }
 void batch_stats(const Batch* b, anx_batch_stats* s) { memset(s, 0, sizeof *s); if (b) { s->n_queries = b->in.size(); s->n_results = b->rows.size(); s->ms_total = 1.0f; } }
