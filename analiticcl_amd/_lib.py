@@ -97,6 +97,7 @@ def lib():
     sig = {
         "anx_last_error": (cp, []),
         "anx_abi_version": (C.c_int, []),
+        "anx_last_error_code": (C.c_int, []),
         "anx_default_weights": (None, [C.POINTER(Weights)]),
         "anx_default_params": (None, [C.POINTER(Params)]),
         "anx_default_vocab_params": (None, [C.POINTER(VocabParams)]),

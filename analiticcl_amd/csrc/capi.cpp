@@ -198,6 +198,7 @@ extern "C" {
 void anx_results_free(anx_result* rows, size_t* offsets);
 
 const char* anx_last_error(void) { return g_err.c_str(); }
+int anx_last_error_code(void) { return g_code; }
 int anx_abi_version(void) { return ANX_ABI_VERSION; }
 
 void anx_default_weights(anx_weights* w) {  // src/types.rs:57-67

@@ -26,6 +26,7 @@
 extern "C" {
 int anx_find_variants_batch(const anx_model*, const char* const*, size_t, const anx_params*, anx_result**, size_t**);
 void anx_results_free(anx_result*, size_t*);
+int anx_last_error_code(void);
 }
 const anx::HostModel& anx_host_of(const anx_model* m);  // capi.cpp
 const anx::DeviceLexicon* anx_replica_of(const anx_model* m, size_t i);  // capi.cpp
@@ -663,7 +664,11 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         rc = bt ? anx_batch_run(model, bt, nullptr) : ANX_EINVAL;
         if (bt && rc == ANX_OK) rc = anx_batch_fetch(bt, &rows, &offs);
         if (bt) anx_batch_free(bt);
-        if (!bt) { free_kept(); return ANX_ENODEVICE; }  // the message of the failed encode stays in anx_last_error()
+        if (!bt) {  // code and message of the failed encode stay in anx_last_error_code() / anx_last_error()
+          free_kept();
+          const int code = anx_last_error_code();
+          return code ? code : ANX_ENODEVICE;
+        }
       } else {  // more segments than one device batch holds: the pointer form splits them
         std::vector<const char*> ptrs(nseg);
         size_t i = 0;

@@ -102,6 +102,7 @@ void anx_default_weights(anx_weights *);           /* Weights::default() */
 void anx_default_params(anx_params *);             /* SearchParameters::default() */
 void anx_default_vocab_params(anx_vocab_params *); /* VocabParams::default() */
 const char *anx_last_error(void);
+int anx_last_error_code(void); /* the ANX_E* code that goes with anx_last_error() (entry points that return a pointer set it too) */
 int anx_abi_version(void);
 
 /* ---- model construction (host) ------------------------------------------------------------------ */
