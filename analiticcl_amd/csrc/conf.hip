@@ -63,7 +63,7 @@ struct alignas(16) ConfWork {
   int32_t v[CF_V];
   cdiff::Frame frames[CF_FRAMES];
 };
-constexpr uint32_t CF_BLOCKS = 8192, CF_THREADS = 64;  // lanes in flight = working sets of a batch (262 k x 5.3 KB = 1.4 GB of HBM)
+constexpr uint32_t CF_BLOCKS = 4096, CF_THREADS = 64;  // lanes in flight = working sets of a batch (262 k x 5.3 KB = 1.4 GB of HBM; 8192 blocks measured no faster)
 
 struct ConfArgs {
   uint32_t nq, row_cap;            // row_cap: slots the row buffers hold (a run that needs more is repeated by the host)

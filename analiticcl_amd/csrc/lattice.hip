@@ -376,6 +376,10 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   if (rc) return rc;
   const DeviceLm* lm = dl->dlm;
   const uint32_t K = std::max<uint32_t>(1u, p.max_seq);
+  if (K > 4096u) {  // node pools of (states x K) and the LDS cost ring are sized for the reference's default of 250: the host decoder takes these
+    for (size_t i = 0; i < count; ++i) out_n[i] = 0xFFFFFFFFu;
+    return ANX_OK;
+  }
   hipStream_t st = encoder_stream_acquire(dl->device);
   struct Rel { hipStream_t s; int dev; ~Rel() { (void)hipStreamSynchronize(s); encoder_stream_release(dev, s); } } rel{st, dl->device};
   LatStretch* d_st = nullptr; uint32_t* d_inoff = nullptr; LatArc* d_arcs = nullptr; LatSym* d_syms = nullptr; uint32_t* d_boff = nullptr;

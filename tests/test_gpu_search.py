@@ -491,15 +491,17 @@ def test_device_lattice_equals_host_lattice(data_dir):
         g.build()
         texts = synth.make_running_text(common, 1.2, seed=31) + ["", "one", "it's a well-known co-op, isn't it?", "a " * 300, "zzqx " * 40 + "end."]
         for kw in (dict(max_ngram=3), dict(max_ngram=2, max_seq=7), dict(max_ngram=3, max_seq=1), dict(max_ngram=3, lm_weight=0.0),
-                   dict(max_ngram=1), dict(max_ngram=3, max_matches=20, variantmodel_weight=1.0, lm_weight=2.0)):
+                   dict(max_ngram=1), dict(max_ngram=3, max_matches=20, variantmodel_weight=1.0, lm_weight=2.0),
+                   dict(max_ngram=3, max_seq=5000)):   # beyond the device's node pools: handed back to the host decoder
             p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, **({"max_matches": 10} | kw))
+            tx = texts if kw.get("max_seq", 250) <= 4096 else texts[:300] + texts[-5:]
             out = {}
             for mode in ("device", "host"):
                 A.set_switch("ANX_LATTICE", "host" if mode == "host" else None)
                 try:
-                    out[mode] = g.find_all_matches_arrays(texts, p)
+                    out[mode] = g.find_all_matches_arrays(tx, p)
                 finally:
                     A.set_switch("ANX_LATTICE", None)
             for x, y in zip(out["device"], out["host"]):
                 assert np.array_equal(x, y), (with_lm, kw)
-            assert out["device"][1].size > 50_000
+            assert out["device"][1].size > (50_000 if tx is texts else 5_000)
