@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libanx.so")
+LIB_PATH = os.environ.get("ANX_LIB") or os.path.join(HERE, "libanx.so")  # ANX_LIB: an experiment build (tools/build_variant.sh)
 
 ANX_OK, ANX_EINVAL, ANX_EIO, ANX_ENOTBUILT, ANX_ENODEVICE, ANX_ELIMIT, ANX_EEMPTY = 0, -1, -2, -3, -4, -5, -6
 ANX_NO_VIA = 0xFFFFFFFFFFFFFFFF

@@ -326,14 +326,14 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
   // scan records of the bit-plane kernel: one per ENTRY (class-major, the order of the entry ids) carrying the planes of its
   // class, so that a scan hit is a (query, entry) pair -- classes with several entries (8 % of eng.aspell) are tested once per
   // entry, and the hit expansion has no entries-per-class loop (it ran as long as the largest class among 64 hits)
-  std::vector<uint4> srec(2 * ((size_t)img.nentries + 1), make_uint4(0u, 0u, 0u, 0u));
+  std::vector<uint4> srec((size_t)img.nentries + 1, make_uint4(0u, 0u, 0u, 0u));   // {plane 1, plane 2, len, class}
+  std::vector<uint2> srec34((size_t)img.nentries + 1, make_uint2(0u, 0u));         // {plane 3, plane 4}
   for (uint32_t c = 0; c < img.nclasses; ++c)
     for (uint32_t e = img.cls_off[c]; e < img.cls_off[c + 1]; ++e) {
-      srec[2 * (size_t)e] = make_uint4(img.cls_bits[c], img.cls_bits[(size_t)img.cstride + c], img.cls_bits[2 * (size_t)img.cstride + c],
-                                       img.cls_bits[3 * (size_t)img.cstride + c]);
-      srec[2 * (size_t)e + 1] = make_uint4(img.cls_len[c], c, 0u, 0u);
+      srec[e] = make_uint4(img.cls_bits[c], img.cls_bits[(size_t)img.cstride + c], img.cls_len[c], c);
+      srec34[e] = make_uint2(img.cls_bits[2 * (size_t)img.cstride + c], img.cls_bits[3 * (size_t)img.cstride + c]);
     }
-  srec[2 * (size_t)img.nentries + 1] = make_uint4(255u, 0xFFFFFFFFu, 0u, 0u);  // the padding record
+  srec[img.nentries] = make_uint4(0u, 0u, 255u, 0xFFFFFFFFu);  // the padding record
   std::vector<uint4> sig2(img.sig_lo.size());  // {signature, first class of the run, classes in the run}
   for (size_t i = 0; i < sig2.size(); ++i)
     sig2[i] = make_uint4(img.sig_lo[i], img.sig_hi[i], img.sig_cbeg[i], i + 1 < img.sig_cbeg.size() ? img.sig_cbeg[i + 1] - img.sig_cbeg[i] : 0u);
@@ -399,6 +399,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
       (rc = upload(&d->cls_len, img.cls_len.data(), img.cls_len.size(), err, &d->bytes)) ||
       (rc = upload(&d->cls_off, off.data(), off.size(), err, &d->bytes)) ||
       (rc = upload(&d->scan_rec, srec.data(), srec.size(), err, &d->bytes)) ||
+      (rc = upload(&d->scan_rec34, srec34.data(), srec34.size(), err, &d->bytes)) ||
       (rc = upload(&d->sig_e, sig2e.data(), sig2e.size(), err, &d->bytes)) ||
       (rc = upload(&d->sighash, shash.data(), shash.size(), err, &d->bytes)) ||
       (rc = upload(&d->sighash_e, shash_e.data(), shash_e.size(), err, &d->bytes)) ||
@@ -435,7 +436,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->sig_e, (void*)d->sighash, (void*)d->sighash_e, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
+  for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->scan_rec34, (void*)d->sig_e, (void*)d->sighash, (void*)d->sighash_e, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
@@ -951,7 +952,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   if (b->ntiles) {
     ScanArgs A;
     A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
-    A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
+    A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.scan_rec34 = dl->scan_rec34; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
     A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.sighash_e = dl->sighash_e; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
     A.chunk = SCAN_CHUNK;
     A.chunk_fused = SCAN_CHUNK_FUSED;

@@ -56,7 +56,8 @@ struct DeviceLexicon {
   uint32_t* cls_bits = nullptr;    // [NBITPLANES][cstride] thermometer planes (bit s of plane t: count_s > t), nsym <= 32
   uint8_t* cls_len = nullptr;      // [cstride]
   uint32_t* cls_off = nullptr;
-  uint4* scan_rec = nullptr;       // [E + 1][2] per entry {4 planes of its class} {len, class, 0, 0}: ScanArgs::scan_rec
+  uint4* scan_rec = nullptr;       // [E + 1] per entry {plane 1, plane 2 of its class, len, class}: ScanArgs::scan_rec
+  uint2* scan_rec34 = nullptr;     // [E + 1] {plane 3, plane 4}
   uint4* sig_e = nullptr;          // [nsig_pad] signature table with entry runs (ScanArgs::sig_e)
   uint4* sighash = nullptr;        // open-addressing table {sig lo, sig hi, first class of the run, classes}; empty slots are 0
   uint4* sighash_e = nullptr;      // the same slots with the run as scan records {.., .., first entry, entries} (bit-plane scan)

@@ -102,7 +102,8 @@ struct ScanArgs {
   const uint32_t* q_cv;
   const uint32_t* cls_bits;
   const uint32_t* cls_planes;
-  const uint4* scan_rec;    // [E + 1][2] per ENTRY {4 thermometer planes of its class} {len, class, 0, 0} (bit-plane kernel)
+  const uint4* scan_rec;    // [E + 1] per ENTRY {planes 1 and 2 of its class, len, class}: ONE 16-byte gather per record (bit-plane kernel)
+  const uint2* scan_rec34;  // [E + 1] planes 3 and 4: gathered only by tiles that hold a query with a symbol three or four times
   uint32_t pad_rec;         // = E: a never-matching padding record (planes 0, len 255)
   uint32_t cstride;
   uint32_t pad_class;   // a never-matching padding class (counts 0xFF, len 255; count-vector kernel)
@@ -217,7 +218,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
         if (keep) {
           const uint32_t q = t.q0 + ql;
           uint32_t exact = 0u;
-          if (A.want_exact) exact = A.qexact[q] == A.scan_rec[2 * (size_t)e + 1].y ? 0x80000000u : 0u;  // StopAtExactMatch, src/lib.rs:1164-1173
+          if (A.want_exact) exact = A.qexact[q] == A.scan_rec[e].w ? 0x80000000u : 0u;  // StopAtExactMatch, src/lib.rs:1164-1173
           const uint32_t g = __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
           const uint32_t pos = wave_slot(wo, g);
           if (pos < wo.rend) raw[pos] = make_uint2(q, e | exact | flag);
@@ -245,7 +246,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
           count_only = (hx >> 9) & 1u;
           e0 = stage[hx & 0xFFu];
           ne = 1;
-          c = A.qpairs ? A.scan_rec[2 * (size_t)e0 + 1].y : 0u;  // class of the entry (pair-count runs only)
+          c = A.qpairs ? A.scan_rec[e0].w : 0u;  // class of the entry (pair-count runs only)
         } else {
           c = hits[2 * idx];
           m = hits[2 * idx + 1];
@@ -324,17 +325,23 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
     if (ANX_DBG(A.dbg) & 2) return;
     uint32_t cid[CPL], cw[CPL][W];
     int32_t thr[CPL];
+    const bool need34 = BITS && ((t.kend >> 8) & 0xFFu) < t.nq;  // some query of the tile is of kind 3 or 4
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const uint32_t idx = (uint32_t)j * 64u + lane;
       cid[j] = idx < ns ? stage[idx] : (BITS ? A.pad_rec : A.pad_class);
       int32_t lc;
       if (BITS) {  // one 32-B scan record per entry {4 planes of its class} {len, class, -, -} instead of T + 3 gathers
-        const uint4 pl = A.scan_rec[2 * (size_t)cid[j]], mt = A.scan_rec[2 * (size_t)cid[j] + 1];
-        const uint32_t plw[4] = {pl.x, pl.y, pl.z, pl.w};
+        // 16 B per record {plane 1, plane 2, len, class}: the chunk set-up is bound by the texture addresser (8 -> 4 gathers per lane
+        // and chunk); planes 3 / 4 only matter to queries with a symbol three / four times (5 % of the tests), so only tiles that
+        // hold such a query fetch them (wave-uniform: the tile's kind boundaries)
+        const uint4 mt = A.scan_rec[cid[j]];
+        uint2 hi = make_uint2(0u, 0u);
+        if (need34) hi = A.scan_rec34[cid[j]];
+        const uint32_t plw[4] = {mt.x, mt.y, hi.x, hi.y};
 #pragma unroll
         for (int p = 0; p < W; ++p) cw[j][p] = plw[p];
-        lc = (int32_t)mt.x;
+        lc = (int32_t)mt.z;
         const int32_t diff = lc > (int32_t)t.lq ? lc - (int32_t)t.lq : (int32_t)t.lq - lc;
         if (A.drop_len && diff > (int32_t)t.d) cid[j] |= 1u << 28;  // its pairs fail the DL's length test: counted, not emitted
       } else {
