@@ -203,8 +203,9 @@ int anx_batch_wait(const anx_model *, anx_batch *);
 int anx_batch_fetch(const anx_batch *, anx_result **out_rows, size_t **out_offsets);
 /* The same ranked rows as 16-byte anx_topk_record {vocab_id u32, freq_score f32, dist_score f64} with uint32 offsets[n + 1]: half
  * the bytes of anx_batch_fetch over PCIe (BASELINE configs[1]: 70 MB instead of 141 MB per million queries).  A record has no
- * `via`, so models with variant lists -- and models with confusables, whose lists are rescored on the host -- are refused
- * (ANX_EINVAL): use anx_batch_fetch.  Rows and offsets live in one cached pinned block: release both with anx_compact_free.
+ * `via`, so models with variant lists are refused (ANX_EINVAL; so are models with confusables when their lists are rescored on the
+ * host -- the ANX_CONFUSABLES=host A/B path, or after a batch fell back to it --: the device-side weighting is served): use
+ * anx_batch_fetch.  Rows and offsets live in one cached pinned block: release both with anx_compact_free.
  * anx_compact_to_results writes the anx_result view (via = ANX_NO_VIA) of n_rows records into caller storage. */
 int anx_batch_fetch_compact(const anx_batch *, anx_topk_record **out_rows, uint32_t **out_offsets);
 void anx_compact_free(anx_topk_record *rows, uint32_t *offsets);
