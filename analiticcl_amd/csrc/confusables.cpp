@@ -25,47 +25,53 @@ U to_u32(const char* s, size_t n) {
   return out;
 }
 U to_u32(const std::string& s) { return to_u32(s.data(), s.size()); }
-cdiff::View view_of(const U& s) { return cdiff::mk(reinterpret_cast<const cdiff::cp_t*>(s.data()), (uint32_t)s.size()); }
+typedef cdiff::Core<1> HC;  // the shared core over a contiguous lane memory (stride 1)
 
-// The working memory of one edit script on the host: per thread, grown (doubled) and the script recomputed when the core reports
-// an overflow, so a host call always succeeds.  The result lives in the buffers until the thread's next call.
+// The working memory of one edit script on the host: per thread, ONE array of words [input | candidate | arena | diffs | diagonal
+// arrays | frames] (confusables_core.hpp), grown (doubled) and the script recomputed when the core reports an overflow, so a host
+// call always succeeds.  The result lives in the buffer until the thread's next call.
 struct HostCtx {
-  std::vector<cdiff::cp_t> arena;
-  std::vector<cdiff::Diff> d;
-  std::vector<int32_t> v;
-  std::vector<cdiff::Frame> frames;
+  std::vector<uint32_t> mem;
   cdiff::Ctx c;
+  cdiff::View in, cand;
   void size_for(size_t la, size_t lb, unsigned scale) {
     const size_t n = la + lb + 8;
-    arena.resize(n * 16 * scale);
-    d.resize(n * 2 * scale + 16);
-    v.resize((n + 4) * 4 * scale);
-    frames.resize(n * scale + 8);
-    c.arena = arena.data(); c.arena_cap = (uint32_t)arena.size(); c.arena_used = 0;
-    c.d = d.data(); c.d_cap = (uint32_t)d.size(); c.nd = 0;
-    c.v = v.data(); c.v_cap = (uint32_t)v.size();
-    c.frames = frames.data(); c.frame_cap = (uint32_t)frames.size();
+    const size_t arena = n * 16 * scale, nd = n * 2 * scale + 16, nv = (n + 4) * 4 * scale, nf = n * scale + 8;
+    mem.resize(la + lb + arena + nd * cdiff::DIFF_WORDS + nv + nf * cdiff::FRAME_WORDS);
+    c.mem = mem.data();
+    in = cdiff::mk(0, (uint32_t)la);
+    cand = cdiff::mk((uint32_t)la, (uint32_t)lb);
+    c.arena_off = (uint32_t)(la + lb); c.arena_cap = (uint32_t)arena; c.arena_used = 0;
+    c.d_off = c.arena_off + c.arena_cap; c.d_cap = (uint32_t)nd; c.nd = 0;
+    c.v_off = c.d_off + c.d_cap * cdiff::DIFF_WORDS; c.v_cap = (uint32_t)nv;
+    c.f_off = c.v_off + c.v_cap; c.frame_cap = (uint32_t)nf;
     uint32_t na = 0;
     c.alpha = alphabetic_ranges(&na);
     c.nalpha = na;
     c.overflow = false;
   }
+  // the two strings into the lane memory (after size_for)
+  void load(const cdiff::cp_t* a, const cdiff::cp_t* b) {
+    for (uint32_t i = 0; i < in.n; ++i) mem[in.p + i] = a[i];
+    for (uint32_t i = 0; i < cand.n; ++i) mem[cand.p + i] = b[i];
+  }
 };
 HostCtx& host_ctx() { static thread_local HostCtx h; return h; }
 
 // edit script of (a -> b) in the calling thread's context
-cdiff::Ctx& edit_script(const U& a, const U& b) {
+HostCtx& edit_script(const U& a, const U& b) {
   HostCtx& h = host_ctx();
   for (unsigned scale = 1;; scale *= 2) {
     h.size_for(a.size(), b.size(), scale);
-    if (cdiff::edit_script(h.c, view_of(a), view_of(b))) return h.c;
+    h.load(reinterpret_cast<const cdiff::cp_t*>(a.data()), reinterpret_cast<const cdiff::cp_t*>(b.data()));
+    if (HC::edit_script(h.c, h.in, h.cand)) return h;
   }
 }
 
-std::string to_utf8(const cdiff::View& s) {
+std::string to_utf8(const cdiff::Ctx& cx, const cdiff::View& s) {
   std::string out;
   for (uint32_t i = 0; i < s.n; ++i) {
-    const uint32_t c = s.p[i];
+    const uint32_t c = HC::at(cx, s, i);
     if (c < 0x80) out.push_back((char)c);
     else if (c < 0x800) { out.push_back((char)(0xC0 | (c >> 6))); out.push_back((char)(0x80 | (c & 0x3F))); }
     else if (c < 0x10000) { out.push_back((char)(0xE0 | (c >> 12))); out.push_back((char)(0x80 | ((c >> 6) & 0x3F))); out.push_back((char)(0x80 | (c & 0x3F))); }
@@ -78,12 +84,13 @@ std::string to_utf8(const cdiff::View& s) {
 
 std::string edit_script_string(const std::string& source, const std::string& target) {
   std::string out;
-  const U a = to_u32(source), b = to_u32(target);  // the script holds views of them
-  const cdiff::Ctx& c = edit_script(a, b);
-  for (uint32_t i = 0; i < c.nd; ++i) {
-    out.push_back((char)c.d[i].op);
+  const U a = to_u32(source), b = to_u32(target);
+  const HostCtx& h = edit_script(a, b);
+  for (uint32_t i = 0; i < h.c.nd; ++i) {
+    const cdiff::Diff d = HC::diff_at(h.c, i);
+    out.push_back((char)d.op);
     out.push_back('[');
-    out += to_utf8(c.d[i].text);
+    out += to_utf8(h.c, d.text);
     out.push_back(']');
   }
   return out;
@@ -211,7 +218,7 @@ const HostModel::ConfCache& HostModel::conf_vocab() const {
         const U t = to_u32(decoder[i].text);
         for (char32_t ch : t) cc->pool.push_back((uint32_t)ch);
         cc->off.push_back((uint32_t)cc->pool.size());
-        cc->cs[i] = cdiff::charset_of(view_of(t));
+        cc->cs[i] = cdiff::charset_of_array(reinterpret_cast<const cdiff::cp_t*>(t.data()), (uint32_t)t.size());
       }
       if (cc->pool.empty()) cc->pool.push_back(0);
       conf_cache_owned.push_back(cc);
@@ -229,17 +236,19 @@ void HostModel::conf_vocab_arrays(const uint32_t** pool, size_t* npool, const ui
 void HostModel::confusable_weights(const char* input, size_t len, const uint64_t* ids, size_t n, double* out) const {  // src/lib.rs:1733-1756
   const ConfCache& cc = conf_vocab();
   const U in = to_u32(input, len);
-  const cdiff::View inv = view_of(in);
-  const cdiff::CharSet ins = cdiff::charset_of(inv);
+  const cdiff::cp_t* inp = reinterpret_cast<const cdiff::cp_t*>(in.data());
+  const cdiff::CharSet ins = cdiff::charset_of_array(inp, (uint32_t)in.size());
   const cdiff::Patterns P = conf_patterns();
   HostCtx& h = host_ctx();
   for (size_t k = 0; k < n; ++k) {
     double weight = 1.0;
     if (ids[k] < cc.cs.size()) {
-      const cdiff::View cand = cdiff::mk(cc.pool.data() + cc.off[ids[k]], cc.off[ids[k] + 1] - cc.off[ids[k]]);
+      const cdiff::cp_t* cand = cc.pool.data() + cc.off[ids[k]];
+      const uint32_t ncand = cc.off[ids[k] + 1] - cc.off[ids[k]];
       for (unsigned scale = 1;; scale *= 2) {  // (the screen inside confusable_weight decides whether a script is computed at all)
-        h.size_for(inv.n, cand.n, scale);
-        if (cdiff::confusable_weight(h.c, P, inv, ins, cand, cc.cs[ids[k]], &weight)) break;
+        h.size_for(in.size(), ncand, scale);
+        h.load(inp, cand);
+        if (HC::confusable_weight(h.c, P, h.in, ins, h.cand, cc.cs[ids[k]], &weight)) break;
       }
     }
     out[k] = weight;

@@ -1528,7 +1528,7 @@ void batch_free(Batch* b) {
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->d_cold, (void*)b->qpairs, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off,
-                  (void*)b->d_text, (void*)b->d_textoff, (void*)b->cf_weight, (void*)b->cf_need, (void*)b->cf_ctr, b->cf_work})
+                  (void*)b->d_text, (void*)b->d_textoff, (void*)b->cf_weight, (void*)b->cf_need, (void*)b->cf_ctr, b->cf_work, (void*)b->cf_sort, b->cf_sort_tmp})
     if (p) pool_free(p);
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);

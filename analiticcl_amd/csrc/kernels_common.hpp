@@ -149,6 +149,9 @@ struct Batch {
   uint32_t* cf_need = nullptr;     // row slots that need an edit script
   uint32_t* cf_ctr = nullptr;      // [0] their number, [1] rows the device could not weight (host fallback)
   void* cf_work = nullptr;         // per-lane working memory of k_conf_script
+  uint32_t* cf_sort = nullptr;     // [4][cf_cap] shape keys / list positions before and after the sort; cf_sort_tmp: the sort's scratch
+  void* cf_sort_tmp = nullptr;
+  size_t cf_sort_tmp_bytes = 0;
   size_t cf_cap = 0;
   bool conf_fallback = false;      // the last run raised cf_ctr[1]
   uint32_t* scan_tmp = nullptr;
