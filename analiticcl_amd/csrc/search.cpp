@@ -533,12 +533,127 @@ void anx_default_search_params(anx_search_params* p) {  // src/types.rs:170-192
   p->unicodeoffsets = 0;
 }
 
+const char* anx_last_error(void);
+void anx_matches_free(anx_match* matches, size_t* offsets, anx_result* rows, anx_match_tag* tags);
+static int find_all_part(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp, anx_match** out_matches,
+                         size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows, anx_match_tag** out_tags);
+
+// Texts are independent of each other (src/lib.rs:1790-1957 works text by text); a call only batches them for the device.  A large
+// call is cut into contiguous parts of ~4 MB of text (ANX_SEARCH_PART_BYTES) and ANX_SEARCH_PARTS (3) of them are in flight at a
+// time, each the whole pipeline in a thread of its own: the phases of the pipeline alternate between the host threads and the
+// device, so one part's device batches and lattices run under the others' host phases (a single pass leaves the device idle
+// for two thirds of the call and the host threads for the rest).
+// The parts' arrays are then written side by side into the arrays the caller gets, indices rebased.
 int anx_find_all_matches_batch(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp,
                                anx_match** out_matches, size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows,
                                anx_match_tag** out_tags) {
   if (out_tags) *out_tags = nullptr;
   if (!model || (!texts && n) || !sp || !out_matches || !out_offsets || !out_rows || !out_n_rows)
     return anx_fail(ANX_EINVAL, "NULL argument");
+  const size_t workers = std::min((size_t)std::max(1, anx::switches().search_parts), n);
+  std::vector<size_t> len_upto;
+  size_t parts = 1;
+  if (workers > 1) {  // worth it from a few megabytes on (ANX_SEARCH_PARTS_MIN)
+    len_upto.assign(n + 1, 0);
+    for (size_t t = 0; t < n; ++t) len_upto[t + 1] = len_upto[t] + (texts[t] ? strlen(texts[t]) : 0);
+    if (len_upto[n] >= (size_t)anx::switches().search_parts_min) {
+      // parts of ~ANX_SEARCH_PART_BYTES (a single pass over tens of megabytes is slower per byte: its arrays outgrow the caches and
+      // the allocator), a whole number of rounds of the workers
+      const size_t per_round = workers * (size_t)std::max(1l, anx::switches().search_part_bytes);
+      parts = std::min(n, workers * ((len_upto[n] + per_round - 1) / per_round));
+    }
+  }
+  if (parts <= 1) return find_all_part(model, texts, n, sp, out_matches, out_offsets, out_rows, out_n_rows, out_tags);
+  std::vector<size_t> cut(parts + 1, n);
+  cut[0] = 0;
+  for (size_t r = 1, t = 0; r < parts; ++r) {
+    while (t < n && len_upto[t] * parts < len_upto[n] * r) ++t;
+    cut[r] = t;
+  }
+  struct Part { anx_match* m = nullptr; size_t* o = nullptr; anx_result* rows = nullptr; size_t nrows = 0; anx_match_tag* tags = nullptr; int rc = ANX_OK; std::string err; };
+  std::vector<Part> P(parts);
+  {
+    std::atomic<size_t> next_part{0};
+    std::atomic<bool> failed{false};
+    std::vector<std::thread> th;
+    for (size_t w = 0; w < workers; ++w)
+      th.emplace_back([&]() {
+        for (;;) {
+          const size_t r = next_part.fetch_add(1);
+          if (r >= parts) break;
+          Part& p = P[r];
+          if (failed.load()) { p.rc = ANX_EINVAL; p.err = "another part of the call failed"; continue; }
+          p.rc = find_all_part(model, texts + cut[r], cut[r + 1] - cut[r], sp, &p.m, &p.o, &p.rows, &p.nrows, out_tags ? &p.tags : nullptr);
+          if (p.rc != ANX_OK) { p.err = anx_last_error(); failed.store(true); }  // (the message is the worker thread's)
+        }
+      });
+    for (auto& x : th) x.join();
+  }
+  auto free_parts = [&]() { for (Part& p : P) if (p.rc == ANX_OK) anx_matches_free(p.m, p.o, p.rows, p.tags); };
+  for (Part& p : P)
+    if (p.rc != ANX_OK && p.err != "another part of the call failed") { const int rc = p.rc; const std::string e = p.err; free_parts(); return anx_fail(rc, e); }
+  std::vector<size_t> m0(parts + 1, 0), r0(parts + 1, 0), t0(parts + 1, 0);
+  for (size_t r = 0; r < parts; ++r) {
+    const size_t nt = cut[r + 1] - cut[r], nm = P[r].o[nt];
+    m0[r + 1] = m0[r] + nm;
+    r0[r + 1] = r0[r] + P[r].nrows;
+    t0[r + 1] = t0[r] + ((nm && out_tags) ? P[r].m[nm - 1].tag_end : 0);  // tags are numbered in match order
+  }
+  anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, m0[parts]) * sizeof(anx_match)));
+  size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
+  anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, r0[parts]) * sizeof(anx_result)));
+  anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, t0[parts]) * sizeof(anx_match_tag))) : nullptr;
+  if (!om || !oo || !orows || (out_tags && !otags)) { free(om); free(oo); free(orows); free(otags); free_parts(); return anx_fail(ANX_EINVAL, "out of memory"); }
+  {
+    // slices of every part's arrays, copied by the host threads
+    const unsigned hw = std::max(1u, std::min(64u, anx::usable_hw_threads()));
+    struct Job { size_t part, lo, hi; int what; };  // what: 0 matches, 1 rows
+    std::vector<Job> jobs;
+    for (size_t r = 0; r < parts; ++r) {
+      const size_t nm = m0[r + 1] - m0[r], nr = P[r].nrows;
+      for (size_t lo = 0; lo < nm; lo += 65536) jobs.push_back(Job{r, lo, std::min(nm, lo + 65536), 0});
+      for (size_t lo = 0; lo < nr; lo += 262144) jobs.push_back(Job{r, lo, std::min(nr, lo + 262144), 1});
+    }
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const size_t j = next.fetch_add(1);
+        if (j >= jobs.size()) break;
+        const Job& jb = jobs[j];
+        const Part& p = P[jb.part];
+        if (jb.what == 1) { memcpy(orows + r0[jb.part] + jb.lo, p.rows + jb.lo, (jb.hi - jb.lo) * sizeof(anx_result)); continue; }
+        for (size_t k = jb.lo; k < jb.hi; ++k) {
+          anx_match mt = p.m[k];
+          mt.var_begin += r0[jb.part];
+          mt.var_end += r0[jb.part];
+          mt.tag_begin += (uint32_t)t0[jb.part];
+          mt.tag_end += (uint32_t)t0[jb.part];
+          om[m0[jb.part] + k] = mt;
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < hw && t < jobs.size(); ++t) th.emplace_back(worker);
+    worker();
+    for (auto& x : th) x.join();
+    for (size_t r = 0; r < parts; ++r) {
+      const size_t nt = cut[r + 1] - cut[r];
+      for (size_t t = 0; t < nt; ++t) oo[cut[r] + t + 1] = m0[r] + P[r].o[t + 1];
+      if (otags && t0[r + 1] > t0[r]) memcpy(otags + t0[r], P[r].tags, (t0[r + 1] - t0[r]) * sizeof(anx_match_tag));
+    }
+  }
+  free_parts();
+  *out_matches = om;
+  *out_offsets = oo;
+  *out_rows = orows;
+  *out_n_rows = r0[parts];
+  if (out_tags) *out_tags = otags;
+  return ANX_OK;
+}
+
+static int find_all_part(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp, anx_match** out_matches,
+                         size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows, anx_match_tag** out_tags) {
+  if (out_tags) *out_tags = nullptr;
   const bool timing = anx::switches().search_timing != 0;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();
@@ -930,10 +1045,10 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         o.var_begin = rw;
         for (const anx_result& r : s.variants) orows[rw++] = r;
         o.var_end = rw;
-        o.tag_begin = (uint32_t)tw;
+        o.tag_begin = otags ? (uint32_t)tw : 0u;  // (no tag array asked for: empty ranges)
         if (otags)
           for (uint32_t k = 0; k < s.ntags; ++k) { const auto& tg = tagpools[s.tag_stretch][s.tag0 + k]; otags[tw++] = anx_match_tag{tg.first, tg.second, 0}; }
-        o.tag_end = (uint32_t)tw;
+        o.tag_end = otags ? (uint32_t)tw : 0u;
       }
     }
   });

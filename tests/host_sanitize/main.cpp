@@ -126,6 +126,32 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
       anx_match* ms = nullptr; size_t* mo = nullptr; anx_result* rr = nullptr; size_t nr = 0; anx_match_tag* tg = nullptr;
       CHECK(anx_find_all_matches_batch(m, texts, 2, &sp, &ms, &mo, &rr, &nr, &tg) == ANX_OK);
       anx_matches_free(ms, mo, rr, tg);
+      // a large call runs as concurrent parts whose arrays are merged: the same matches, offsets, rows and tags as one pass
+      std::vector<std::string> many;
+      for (int i = 0; i < 41; ++i) many.push_back(i % 7 == 3 ? std::string() : std::string(texts[i % 2]) + (i % 3 ? " and teh " : "\n") + in[(size_t)i * 37 % in.size()]);
+      std::vector<const char*> mp;
+      for (auto& x : many) mp.push_back(x.c_str());
+      CHECK(anx_debug_set_switch("ANX_SEARCH_PARTS_MIN", "1") == ANX_OK);
+      anx_match* ref_m = nullptr; size_t* ref_o = nullptr; anx_result* ref_r = nullptr; size_t ref_nr = 0; anx_match_tag* ref_t = nullptr;
+      CHECK(anx_debug_set_switch("ANX_SEARCH_PARTS", "1") == ANX_OK);
+      CHECK(anx_find_all_matches_batch(m, mp.data(), mp.size(), &sp, &ref_m, &ref_o, &ref_r, &ref_nr, &ref_t) == ANX_OK);
+      for (const char* np : {"2", "3", "8"}) {
+        CHECK(anx_debug_set_switch("ANX_SEARCH_PARTS", np) == ANX_OK);
+        CHECK(anx_find_all_matches_batch(m, mp.data(), mp.size(), &sp, &ms, &mo, &rr, &nr, &tg) == ANX_OK);
+        CHECK(nr == ref_nr && memcmp(mo, ref_o, (mp.size() + 1) * sizeof(size_t)) == 0);
+        const size_t nm = ref_o[mp.size()];
+        bool same = true;
+        for (size_t k = 0; k < nm && same; ++k)
+          same = ms[k].begin == ref_m[k].begin && ms[k].end == ref_m[k].end && ms[k].n == ref_m[k].n && ms[k].selected == ref_m[k].selected &&
+                 ms[k].var_begin == ref_m[k].var_begin && ms[k].var_end == ref_m[k].var_end && ms[k].tag_begin == ref_m[k].tag_begin && ms[k].tag_end == ref_m[k].tag_end;
+        CHECK(same);
+        for (size_t k = 0; k < nr && same; ++k)
+          same = rr[k].vocab_id == ref_r[k].vocab_id && rr[k].dist_score == ref_r[k].dist_score && rr[k].freq_score == ref_r[k].freq_score && rr[k].via == ref_r[k].via;
+        CHECK(same);
+        anx_matches_free(ms, mo, rr, tg);
+      }
+      anx_matches_free(ref_m, ref_o, ref_r, ref_t);
+      CHECK(anx_debug_set_switch("ANX_SEARCH_PARTS", nullptr) == ANX_OK && anx_debug_set_switch("ANX_SEARCH_PARTS_MIN", nullptr) == ANX_OK);
     }
     anx_model_free(m);
   }

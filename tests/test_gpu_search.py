@@ -505,3 +505,40 @@ def test_device_lattice_equals_host_lattice(data_dir):
             for x, y in zip(out["device"], out["host"]):
                 assert np.array_equal(x, y), (with_lm, kw)
             assert out["device"][1].size > (50_000 if tx is texts else 5_000)
+
+
+@pytest.mark.gpu
+def test_search_parts_equal_one_pass(data_dir):
+    """A large find_all_matches call runs as concurrent parts (ANX_SEARCH_PARTS, default 2: one part's device work under the other's
+    host phases) whose arrays are merged: offsets, every match field, every variant row and the tags identical to one pass."""
+    import random
+    import numpy as np
+    lex = os.path.join(data_dir, "eng.aspell.lexicon")
+    words = synth.load_lexicon_words(lex)
+    rng = random.Random(11)
+    common = [w for w in words if w.isalpha()][::23][:5000]
+    LM = A.VocabParams(vocabtype="LM")
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(lex)
+    for _ in range(5000):
+        g.add_to_vocabulary(f"{rng.choice(common)} {rng.choice(common)}", rng.randrange(1, 20), LM)
+    g.add_contextrule("the; ?", 1.5, ["det", "noun"])
+    g.build()
+    texts = synth.make_running_text(common, 0.8, seed=5) + ["", "one", "the cat and the dgo", ""]
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, max_ngram=3)
+    A.set_switch("ANX_SEARCH_PARTS_MIN", "1")
+    try:
+        ref = None
+        for parts in ("1", "2", "3", "7"):
+            A.set_switch("ANX_SEARCH_PARTS", parts)
+            off, ma, ra = g.find_all_matches_arrays(texts, p)
+            ids = g.find_all_matches_ids(texts[:200] + texts[-4:], p)   # the form with tags
+            if ref is None:
+                ref = (off, ma, ra, ids)
+                assert off[-1] > 1000
+                continue
+            assert np.array_equal(off, ref[0]) and np.array_equal(ma, ref[1]) and np.array_equal(ra, ref[2]), parts
+            assert ids == ref[3], parts
+    finally:
+        A.set_switch("ANX_SEARCH_PARTS", None)
+        A.set_switch("ANX_SEARCH_PARTS_MIN", None)

@@ -1,5 +1,5 @@
 """Search-mode throughput (BASELINE config 5 shape, scaled): sentences of 5-25 sampled + perturbed lexicon words,
-max_ngram 3, bigram LM counts from the same sampler.  usage: search_bench.py [MB of text]"""
+max_ngram 3, bigram LM counts from the same sampler.  usage: search_bench.py [MB of text] [parts,parts,...]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import analiticcl_amd as A
@@ -40,6 +40,22 @@ for rep in range(2):  # the C entry point alone (what a Rust / C caller sees)
     dt = time.time() - t
     print(f"C ABI: {size/1e6:.1f} MB in {dt:.2f} s = {size/1e6/dt:.2f} MB/s, {offs[len(texts)]} matches, {nrows.value} variant rows")
     L.lib().anx_matches_free(ms, offs, rows, None)
+if len(sys.argv) > 2:  # search_bench.py MB parts[:MB per part],...: ANX_SEARCH_PARTS / _PART_BYTES settings side by side, alternating, 4 calls each
+    settings = sys.argv[2].split(",")
+    times = {k: [] for k in settings}
+    for rep in range(4):
+        for k in settings:
+            A.set_switch("ANX_SEARCH_PARTS", k.split(":")[0])
+            A.set_switch("ANX_SEARCH_PART_BYTES", str(int(float(k.split(":")[1]) * (1 << 20))) if ":" in k else None)
+            ms, offs, rows, nrows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)(), C.c_size_t(0)
+            t = time.time()
+            L.check(L.lib().anx_find_all_matches_batch(m.h, arr, len(texts), C.byref(spc), C.byref(ms), C.byref(offs), C.byref(rows), C.byref(nrows), None))
+            times[k].append(time.time() - t)
+            L.lib().anx_matches_free(ms, offs, rows, None)
+    for k in settings:
+        ts = sorted(times[k])
+        print(f"parts {k}: best {size/1e6/ts[0]:.1f} MB/s, median {size/1e6/ts[len(ts)//2]:.1f} MB/s")
+    sys.exit(0)
 for rep in range(1):
     t = time.time()
     res = m.find_all_matches_ids(texts, p)
