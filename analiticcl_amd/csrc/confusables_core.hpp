@@ -197,6 +197,11 @@ ANX_HDS int64_t find(const Ctx& c, const View& hay, const PView& needle) {
 
 // ---- arena and diff array ----------------------------------------------------------------------------------------------
 ANX_HDS View concat(Ctx& c, const View& a, const View& b) {
+  // no copy when there is nothing to join, or when the two pieces already sit side by side (pieces of one string that the
+  // clean-ups put back together: the common case)
+  if (a.n == 0) return b;
+  if (b.n == 0) return a;
+  if (a.p + a.n == b.p) return mk(a.p, a.n + b.n);
   const uint32_t n = a.n + b.n;
   if (c.overflow || c.arena_used + n > c.arena_cap) { c.overflow = true; return empty(c); }
   const uint32_t q = c.arena_off + c.arena_used;
