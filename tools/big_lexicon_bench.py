@@ -1,6 +1,7 @@
 """BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon (eng.aspell + nld.aspell + Markov-chain
 words, len 4-32), 1.25 M length-bucketed queries len 4-32, k=3 d=2 n=10.  Prints build / encode / run times, the batch
-statistics and a 150-query spot check against the C oracle.  usage: big_lexicon_bench.py [entries] [queries]"""
+statistics and a 150-query spot check against the C oracle (skipped with a third argument "nocheck": timing of the whole
+10 M-query job on one GPU).  usage: big_lexicon_bench.py [entries] [queries] [nocheck]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import analiticcl_amd as A
@@ -29,6 +30,8 @@ st = b.stats()
 print("encode %.2f s; run %.2f ms per batch of %d queries = %.2f ms per 1M; %.1f G pairs/s; pairs/query %.1f, class tests/query %.0f, slots %d, survivors %d, results %d"
       % (te, tr * 1e3, NQ, tr * 1e3 * 1e6 / NQ, st["n_pairs"] / tr / 1e9, st["n_pairs"] / NQ, st["n_class_tests"] / NQ, st["n_pair_slots"], st["n_survivors"], st["n_results"]))
 print({k: round(st[k], 3) for k in ("ms_scan", "ms_score", "ms_group", "ms_rank", "ms_total", "ms_scan_kernel", "ms_filter_score_kernel")})
+if len(sys.argv) > 3 and sys.argv[3] == "nocheck":
+    sys.exit(0)
 res = b.fetch()
 t = time.time()
 o = O.OracleModel(alphabet_path=d["alphabet"]); o.read_lexicon(path); o.build()
