@@ -51,9 +51,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t* __r
     for (int i = 0; i < SCAN_ITEMS; ++i) mx = max(mx, v[i]);
 #pragma unroll
     for (int o = 32; o; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-    // only when it would raise the word (a stale read costs an atomic that changes nothing): ~2 k waves meeting on one word were
-    // most of this kernel's time
-    if ((threadIdx.x & 63) == 0 && mx > *const_cast<volatile uint32_t*>(maxout)) atomicMax(maxout, mx);
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxout, mx);
   }
 }
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(uint32_t* __restrict__ blocksum, uint32_t nb) {
