@@ -7,7 +7,11 @@
 // orders are processed one after another.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <functional>
+#include <memory>
+#include <mutex>
 #include <iterator>
 #include <thread>
 #include <chrono>
@@ -39,6 +43,70 @@ std::atomic<uint64_t> g_lat_ns[6];  // ANX_SEARCH_TIMING: time inside most_likel
 #define g_lat_timing (anx::switches().search_timing != 0)
 inline uint64_t lat_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct LatLap { uint64_t t; LatLap() : t(g_lat_timing ? lat_now() : 0) {} void lap(int i) { if (g_lat_timing) { const uint64_t n = lat_now(); g_lat_ns[i] += n - t; t = n; } } };
+
+// The host threads of search mode: one pool for the process (usable cores - 1 threads; the caller of a loop works too).  A call
+// runs a dozen parallel loops per part, several parts at a time: starting and joining 16 threads per loop cost ~0.5 ms each,
+// a sixth of a part's time.  Threads are created on first use and never joined (the pool object is leaked on purpose: no
+// destructor runs at exit while a thread may still sit in wait()).
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool* p = new HostPool(std::max(1u, std::min(64u, anx::usable_hw_threads())));
+    return *p;
+  }
+  unsigned width() const { return nthreads_ + 1; }
+  // body() on up to `helpers` pool threads and on the caller; returns when every started body has returned.  A caller that waits
+  // takes queued tasks itself, so loops started from inside a pool thread cannot starve each other.
+  void run(unsigned helpers, const std::function<void()>& body) {
+    helpers = std::min(helpers, nthreads_);
+    struct State { std::atomic<unsigned> remaining; std::mutex m; std::condition_variable cv; };
+    auto st = std::make_shared<State>();
+    st->remaining.store(helpers);
+    if (helpers) {
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        for (unsigned i = 0; i < helpers; ++i)
+          q_.push_back([st, &body]() {
+            body();
+            if (st->remaining.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g2(st->m); st->cv.notify_all(); }
+          });
+      }
+      cv_.notify_all();
+    }
+    body();
+    while (st->remaining.load() != 0) {
+      std::function<void()> f;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!q_.empty()) { f = std::move(q_.front()); q_.pop_front(); }
+      }
+      if (f) { f(); continue; }
+      std::unique_lock<std::mutex> l(st->m);
+      st->cv.wait_for(l, std::chrono::microseconds(200), [&]() { return st->remaining.load() == 0; });
+    }
+  }
+
+ private:
+  explicit HostPool(unsigned hw) : nthreads_(hw > 1 ? hw - 1 : 0) {
+    for (unsigned i = 0; i < nthreads_; ++i)
+      std::thread([this]() {
+        for (;;) {
+          std::function<void()> f;
+          {
+            std::unique_lock<std::mutex> l(mu_);
+            cv_.wait(l, [&]() { return !q_.empty(); });
+            f = std::move(q_.front());
+            q_.pop_front();
+          }
+          f();
+        }
+      }).detach();
+  }
+  unsigned nthreads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+};
 
 struct RowView {  // the ranked variants of a segment: a range of one n-gram order's result array (kept until the end)
   const anx_result* p = nullptr;
@@ -606,7 +674,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   if (!om || !oo || !orows || (out_tags && !otags)) { free(om); free(oo); free(orows); free(otags); free_parts(); return anx_fail(ANX_EINVAL, "out of memory"); }
   {
     // slices of every part's arrays, copied by the host threads
-    const unsigned hw = std::max(1u, std::min(64u, anx::usable_hw_threads()));
+    const unsigned hw = HostPool::get().width();
     struct Job { size_t part, lo, hi; int what; };  // what: 0 matches, 1 rows
     std::vector<Job> jobs;
     for (size_t r = 0; r < parts; ++r) {
@@ -632,10 +700,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         }
       }
     };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < hw && t < jobs.size(); ++t) th.emplace_back(worker);
-    worker();
-    for (auto& x : th) x.join();
+    HostPool::get().run((unsigned)std::min<size_t>(hw - 1, jobs.empty() ? 0 : jobs.size() - 1), worker);
     for (size_t r = 0; r < parts; ++r) {
       const size_t nt = cut[r + 1] - cut[r];
       for (size_t t = 0; t < nt; ++t) oo[cut[r] + t + 1] = m0[r] + P[r].o[t + 1];
@@ -663,21 +728,20 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     return anx_fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_all_matches()");
   std::vector<std::vector<Span>> bounds(n);
   std::vector<Stretch> stretches;
-  const unsigned hw = std::max(1u, std::min(64u, anx::usable_hw_threads()));
+  HostPool& pool = HostPool::get();
+  const unsigned hw = pool.width();
   // work(lo, hi) over [0, count) in chunks handed to the host threads
   auto parallel_for = [&](size_t count, size_t chunk, size_t serial_below, const std::function<void(size_t, size_t)>& work) {
     if (count < serial_below || hw == 1) { work(0, count); return; }
-    std::vector<std::thread> th;
     std::atomic<size_t> next{0};
-    for (unsigned t = 0; t < hw; ++t)
-      th.emplace_back([&]() {
-        for (;;) {
-          const size_t lo = next.fetch_add(chunk);
-          if (lo >= count) break;
-          work(lo, std::min(count, lo + chunk));
-        }
-      });
-    for (auto& x : th) x.join();
+    const size_t nchunks = (count + chunk - 1) / chunk;
+    pool.run((unsigned)std::min<size_t>(hw - 1, nchunks - 1), [&]() {
+      for (;;) {
+        const size_t lo = next.fetch_add(chunk);
+        if (lo >= count) break;
+        work(lo, std::min(count, lo + chunk));
+      }
+    });
   };
   {
     std::vector<std::vector<Stretch>> per_text_stretches(n);
