@@ -1026,24 +1026,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
           for (Span& s : st.matches) { s.selected = 0; decoded[si].push_back(std::move(s)); }
       }
     };
-    unsigned nthreads = std::max(1u, std::min(64u, anx::usable_hw_threads()));
-    if (stretches.size() < 64) nthreads = 1;
-    if (nthreads == 1) work(0, stretches.size());
-    else {
-      // interleaved chunks: neighbouring stretches have similar cost
-      std::vector<std::thread> th;
-      const size_t chunk = 16;
-      std::atomic<size_t> next{0};
-      for (unsigned t = 0; t < nthreads; ++t)
-        th.emplace_back([&]() {
-          for (;;) {
-            const size_t lo = next.fetch_add(chunk);
-            if (lo >= stretches.size()) break;
-            work(lo, std::min(stretches.size(), lo + chunk));
-          }
-        });
-      for (auto& x : th) x.join();
-    }
+    parallel_for(stretches.size(), 16, 64, work);  // interleaved chunks: neighbouring stretches have similar cost
   }
   std::vector<std::vector<Span>> per_text(n);
   {  // the stretches of a text are consecutive: every text gathers its own
