@@ -660,6 +660,8 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   auto free_parts = [&]() { for (Part& p : P) if (p.rc == ANX_OK) anx_matches_free(p.m, p.o, p.rows, p.tags); };
   for (Part& p : P)
     if (p.rc != ANX_OK && p.err != "another part of the call failed") { const int rc = p.rc; const std::string e = p.err; free_parts(); return anx_fail(rc, e); }
+  const bool timing = anx::switches().search_timing != 0;
+  const auto t_merge = std::chrono::steady_clock::now();
   std::vector<size_t> m0(parts + 1, 0), r0(parts + 1, 0), t0(parts + 1, 0);
   for (size_t r = 0; r < parts; ++r) {
     const size_t nt = cut[r + 1] - cut[r], nm = P[r].o[nt];
@@ -708,6 +710,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     }
   }
   free_parts();
+  if (timing) fprintf(stderr, "[anx search] merge of %zu parts          %8.2f ms\n", parts, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_merge).count() * 1e3);
   *out_matches = om;
   *out_offsets = oo;
   *out_rows = orows;
