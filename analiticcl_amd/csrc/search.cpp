@@ -603,8 +603,84 @@ void anx_default_search_params(anx_search_params* p) {  // src/types.rs:170-192
 
 const char* anx_last_error(void);
 void anx_matches_free(anx_match* matches, size_t* offsets, anx_result* rows, anx_match_tag* tags);
-static int find_all_part(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp, anx_match** out_matches,
-                         size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows, anx_match_tag** out_tags);
+// work(lo, hi) over [0, count) in chunks handed to the host threads
+static void pool_for(size_t count, size_t chunk, size_t serial_below, const std::function<void(size_t, size_t)>& work) {
+  HostPool& pool = HostPool::get();
+  const unsigned hw = pool.width();
+  if (count < serial_below || hw == 1) { work(0, count); return; }
+  std::atomic<size_t> next{0};
+  const size_t nchunks = (count + chunk - 1) / chunk;
+  pool.run((unsigned)std::min<size_t>(hw - 1, nchunks - 1), [&]() {
+    for (;;) {
+      const size_t lo = next.fetch_add(chunk);
+      if (lo >= count) break;
+      work(lo, std::min(count, lo + chunk));
+    }
+  });
+}
+// What the pipeline leaves for a part of a call: the matches of every text (their variants are views of the kept result arrays of
+// the n-gram orders), the tags, and the sizes of the part's share of the output arrays.
+struct OrderRows { anx_result* rows; size_t* offs; };
+struct PartOut {
+  std::vector<std::vector<Span>> per_text;
+  std::vector<TagPool> tagpools;
+  std::vector<OrderRows> kept;
+  size_t total = 0, total_rows = 0, total_tags = 0;
+  int rc = ANX_OK;
+  std::string err;
+  void free_kept() { for (OrderRows& o : kept) anx_results_free(o.rows, o.offs); kept.clear(); }
+  ~PartOut() { free_kept(); }
+};
+static int find_all_part(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp, PartOut& po);
+// The part's matches, rows and tags into the call's arrays: om / orows / otags at the part's bases, oo[t + 1] for its texts (oo points
+// at the part's first text; oo[0] is the previous part's business).
+static void write_part(const PartOut& po, const char* const* texts, size_t n, const anx_search_params* sp, anx_match* om, size_t* oo,
+                       anx_result* orows, anx_match_tag* otags, size_t m_base, size_t r_base, size_t t_base) {
+  const std::vector<std::vector<Span>>& per_text = po.per_text;
+  // first match / row / tag of every text, then the texts are written side by side
+  std::vector<size_t> m0(n + 1, m_base), row0(n + 1, r_base), tag0(n + 1, t_base);
+  for (size_t t = 0; t < n; ++t) {
+    size_t nr = 0, nt = 0;
+    for (const Span& sp_ : per_text[t]) { nr += sp_.variants.size(); nt += sp_.ntags; }
+    m0[t + 1] = m0[t] + per_text[t].size();
+    row0[t + 1] = row0[t] + nr;
+    tag0[t + 1] = tag0[t] + nt;
+    oo[t + 1] = m0[t + 1];
+  }
+  pool_for(n, 8, 64, [&](size_t lo, size_t hi) {
+    for (size_t t = lo; t < hi; ++t) {
+      size_t w = m0[t], rw = row0[t], tw = tag0[t];
+      std::vector<size_t> cpmap;  // byte offset -> code point index (remap_offsets_to_unicodepoints, src/search.rs:527-546)
+      if (sp->unicodeoffsets && texts[t]) {
+        const size_t len = strlen(texts[t]);
+        cpmap.assign(len + 1, 0);
+        size_t cp = 0;
+        for (size_t i = 0; i < len;) {
+          int l;
+          anx::utf8_decode_at(texts[t] + i, len - i, &l);
+          for (int k = 0; k < l && i + (size_t)k < len; ++k) cpmap[i + (size_t)k] = cp;
+          i += (size_t)l;
+          ++cp;
+        }
+        cpmap[len] = cp;
+      }
+      for (const Span& s : per_text[t]) {
+        anx_match& o = om[w++];
+        o.begin = cpmap.empty() ? s.begin : cpmap[s.begin];
+        o.end = cpmap.empty() ? s.end : cpmap[s.end];
+        o.n = s.n;
+        o.selected = (s.has_variants && !s.variants.empty()) ? s.selected : -1;
+        o.var_begin = rw;
+        for (const anx_result& r : s.variants) orows[rw++] = r;
+        o.var_end = rw;
+        o.tag_begin = otags ? (uint32_t)tw : 0u;  // (no tag array asked for: empty ranges)
+        if (otags)
+          for (uint32_t k = 0; k < s.ntags; ++k) { const auto& tg = po.tagpools[s.tag_stretch][s.tag0 + k]; otags[tw++] = anx_match_tag{tg.first, tg.second, 0}; }
+        o.tag_end = otags ? (uint32_t)tw : 0u;
+      }
+    }
+  });
+}
 
 // Texts are independent of each other (src/lib.rs:1790-1957 works text by text); a call only batches them for the device.  A large
 // call is cut into contiguous parts of ~4 MB of text (ANX_SEARCH_PART_BYTES) and ANX_SEARCH_PARTS (3) of them are in flight at a
@@ -631,16 +707,19 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
       parts = std::min(n, workers * ((len_upto[n] + per_round - 1) / per_round));
     }
   }
-  if (parts <= 1) return find_all_part(model, texts, n, sp, out_matches, out_offsets, out_rows, out_n_rows, out_tags);
+  parts = std::max<size_t>(parts, 1);
   std::vector<size_t> cut(parts + 1, n);
   cut[0] = 0;
   for (size_t r = 1, t = 0; r < parts; ++r) {
     while (t < n && len_upto[t] * parts < len_upto[n] * r) ++t;
     cut[r] = t;
   }
-  struct Part { anx_match* m = nullptr; size_t* o = nullptr; anx_result* rows = nullptr; size_t nrows = 0; anx_match_tag* tags = nullptr; int rc = ANX_OK; std::string err; };
-  std::vector<Part> P(parts);
-  {
+  std::vector<std::unique_ptr<PartOut>> P(parts);
+  for (auto& p : P) p.reset(new PartOut());
+  if (parts == 1) {
+    P[0]->rc = find_all_part(model, texts, n, sp, *P[0]);
+    if (P[0]->rc != ANX_OK) return P[0]->rc;  // (the message is this thread's)
+  } else {
     std::atomic<size_t> next_part{0};
     std::atomic<bool> failed{false};
     std::vector<std::thread> th;
@@ -649,68 +728,38 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
         for (;;) {
           const size_t r = next_part.fetch_add(1);
           if (r >= parts) break;
-          Part& p = P[r];
-          if (failed.load()) { p.rc = ANX_EINVAL; p.err = "another part of the call failed"; continue; }
-          p.rc = find_all_part(model, texts + cut[r], cut[r + 1] - cut[r], sp, &p.m, &p.o, &p.rows, &p.nrows, out_tags ? &p.tags : nullptr);
+          PartOut& p = *P[r];
+          if (failed.load()) { p.rc = ANX_EINVAL; continue; }
+          p.rc = find_all_part(model, texts + cut[r], cut[r + 1] - cut[r], sp, p);
           if (p.rc != ANX_OK) { p.err = anx_last_error(); failed.store(true); }  // (the message is the worker thread's)
         }
       });
     for (auto& x : th) x.join();
+    for (auto& p : P)
+      if (p->rc != ANX_OK && !p->err.empty()) return anx_fail(p->rc, p->err);
+    for (auto& p : P)
+      if (p->rc != ANX_OK) return anx_fail(p->rc, "a part of the call failed");
   }
-  auto free_parts = [&]() { for (Part& p : P) if (p.rc == ANX_OK) anx_matches_free(p.m, p.o, p.rows, p.tags); };
-  for (Part& p : P)
-    if (p.rc != ANX_OK && p.err != "another part of the call failed") { const int rc = p.rc; const std::string e = p.err; free_parts(); return anx_fail(rc, e); }
+  // ONE set of arrays for the call, written by every part at its base (the parts used to build arrays of their own that were
+  // copied here: twice the fresh pages, and 38 ms of copying per 12.5 MB of text)
   const bool timing = anx::switches().search_timing != 0;
-  const auto t_merge = std::chrono::steady_clock::now();
+  const auto t_out = std::chrono::steady_clock::now();
   std::vector<size_t> m0(parts + 1, 0), r0(parts + 1, 0), t0(parts + 1, 0);
   for (size_t r = 0; r < parts; ++r) {
-    const size_t nt = cut[r + 1] - cut[r], nm = P[r].o[nt];
-    m0[r + 1] = m0[r] + nm;
-    r0[r + 1] = r0[r] + P[r].nrows;
-    t0[r + 1] = t0[r] + ((nm && out_tags) ? P[r].m[nm - 1].tag_end : 0);  // tags are numbered in match order
+    m0[r + 1] = m0[r] + P[r]->total;
+    r0[r + 1] = r0[r] + P[r]->total_rows;
+    t0[r + 1] = t0[r] + P[r]->total_tags;
   }
   anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, m0[parts]) * sizeof(anx_match)));
   size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
   anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, r0[parts]) * sizeof(anx_result)));
   anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, t0[parts]) * sizeof(anx_match_tag))) : nullptr;
-  if (!om || !oo || !orows || (out_tags && !otags)) { free(om); free(oo); free(orows); free(otags); free_parts(); return anx_fail(ANX_EINVAL, "out of memory"); }
-  {
-    // slices of every part's arrays, copied by the host threads
-    const unsigned hw = HostPool::get().width();
-    struct Job { size_t part, lo, hi; int what; };  // what: 0 matches, 1 rows
-    std::vector<Job> jobs;
-    for (size_t r = 0; r < parts; ++r) {
-      const size_t nm = m0[r + 1] - m0[r], nr = P[r].nrows;
-      for (size_t lo = 0; lo < nm; lo += 65536) jobs.push_back(Job{r, lo, std::min(nm, lo + 65536), 0});
-      for (size_t lo = 0; lo < nr; lo += 262144) jobs.push_back(Job{r, lo, std::min(nr, lo + 262144), 1});
-    }
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-      for (;;) {
-        const size_t j = next.fetch_add(1);
-        if (j >= jobs.size()) break;
-        const Job& jb = jobs[j];
-        const Part& p = P[jb.part];
-        if (jb.what == 1) { memcpy(orows + r0[jb.part] + jb.lo, p.rows + jb.lo, (jb.hi - jb.lo) * sizeof(anx_result)); continue; }
-        for (size_t k = jb.lo; k < jb.hi; ++k) {
-          anx_match mt = p.m[k];
-          mt.var_begin += r0[jb.part];
-          mt.var_end += r0[jb.part];
-          mt.tag_begin += (uint32_t)t0[jb.part];
-          mt.tag_end += (uint32_t)t0[jb.part];
-          om[m0[jb.part] + k] = mt;
-        }
-      }
-    };
-    HostPool::get().run((unsigned)std::min<size_t>(hw - 1, jobs.empty() ? 0 : jobs.size() - 1), worker);
-    for (size_t r = 0; r < parts; ++r) {
-      const size_t nt = cut[r + 1] - cut[r];
-      for (size_t t = 0; t < nt; ++t) oo[cut[r] + t + 1] = m0[r] + P[r].o[t + 1];
-      if (otags && t0[r + 1] > t0[r]) memcpy(otags + t0[r], P[r].tags, (t0[r + 1] - t0[r]) * sizeof(anx_match_tag));
-    }
+  if (!om || !oo || !orows || (out_tags && !otags)) { free(om); free(oo); free(orows); free(otags); return anx_fail(ANX_EINVAL, "out of memory"); }
+  for (size_t r = 0; r < parts; ++r) {
+    write_part(*P[r], texts + cut[r], cut[r + 1] - cut[r], sp, om, oo + cut[r], orows, otags, m0[r], r0[r], t0[r]);
+    P[r].reset();  // its result arrays go back to the pinned cache
   }
-  free_parts();
-  if (timing) fprintf(stderr, "[anx search] merge of %zu parts          %8.2f ms\n", parts, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_merge).count() * 1e3);
+  if (timing) fprintf(stderr, "[anx search] output (%zu parts)            %8.2f ms\n", parts, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count() * 1e3);
   *out_matches = om;
   *out_offsets = oo;
   *out_rows = orows;
@@ -719,9 +768,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   return ANX_OK;
 }
 
-static int find_all_part(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp, anx_match** out_matches,
-                         size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows, anx_match_tag** out_tags) {
-  if (out_tags) *out_tags = nullptr;
+static int find_all_part(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp, PartOut& po) {
   const bool timing = anx::switches().search_timing != 0;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();
@@ -731,21 +778,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     return anx_fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_all_matches()");
   std::vector<std::vector<Span>> bounds(n);
   std::vector<Stretch> stretches;
-  HostPool& pool = HostPool::get();
-  const unsigned hw = pool.width();
-  // work(lo, hi) over [0, count) in chunks handed to the host threads
-  auto parallel_for = [&](size_t count, size_t chunk, size_t serial_below, const std::function<void(size_t, size_t)>& work) {
-    if (count < serial_below || hw == 1) { work(0, count); return; }
-    std::atomic<size_t> next{0};
-    const size_t nchunks = (count + chunk - 1) / chunk;
-    pool.run((unsigned)std::min<size_t>(hw - 1, nchunks - 1), [&]() {
-      for (;;) {
-        const size_t lo = next.fetch_add(chunk);
-        if (lo >= count) break;
-        work(lo, std::min(count, lo + chunk));
-      }
-    });
-  };
+  auto parallel_for = [&](size_t count, size_t chunk, size_t serial_below, const std::function<void(size_t, size_t)>& work) { pool_for(count, chunk, serial_below, work); };
   {
     std::vector<std::vector<Stretch>> per_text_stretches(n);
     parallel_for(n, 8, 64, [&](size_t lo, size_t hi) {
@@ -771,9 +804,8 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   }
   lap("boundaries");
   // one device batch per n-gram order; the result arrays stay alive until the output has been written
-  struct OrderRows { anx_result* rows; size_t* offs; };
-  std::vector<OrderRows> kept;
-  auto free_kept = [&]() { for (OrderRows& o : kept) anx_results_free(o.rows, o.offs); kept.clear(); };
+  std::vector<OrderRows>& kept = po.kept;
+  auto free_kept = [&]() { po.free_kept(); };
   double seg_part[5] = {0, 0, 0, 0, 0};  // timing: n-grams, arena, device batch, row views, append
   double seg_t = tnow();
   auto seg_lap = [&](int i) { if (timing) { const double t = tnow(); seg_part[i] += t - seg_t; seg_t = t; } };
@@ -898,7 +930,8 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   // stretch); models with context rules, ANX_LATTICE=host, and the lattices the device hands back are decoded by the host threads
   // (the reference: rayon over the segments and a sequential loop over the stretches, src/lib.rs:1821-1940).
   std::vector<std::vector<Span>> decoded(stretches.size());
-  std::vector<TagPool> tagpools(m.context_rules.empty() ? 0 : stretches.size());
+  std::vector<TagPool>& tagpools = po.tagpools;
+  tagpools.assign(m.context_rules.empty() ? 0 : stretches.size(), TagPool());
   TagPool no_tags;
   const bool need_lattice = sp->max_ngram > 1 || m.have_lm || !m.context_rules.empty();  // src/lib.rs:1912
   const anx::DeviceLexicon* lat_dev = anx_replica_of(model, 0);
@@ -1031,7 +1064,8 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     };
     parallel_for(stretches.size(), 16, 64, work);  // interleaved chunks: neighbouring stretches have similar cost
   }
-  std::vector<std::vector<Span>> per_text(n);
+  std::vector<std::vector<Span>>& per_text = po.per_text;
+  per_text.assign(n, std::vector<Span>());
   {  // the stretches of a text are consecutive: every text gathers its own
     std::vector<size_t> first(n + 1, stretches.size());
     for (size_t si = stretches.size(); si-- > 0;) first[stretches[si].text_index] = si;
@@ -1052,63 +1086,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     static const char* names[5] = {"arcs", "k-best", "paths", "LM + rules", "select + output"};
     for (int i = 0; i < 5; ++i) fprintf(stderr, "[anx search]   lattice part %-16s %8.2f ms (summed over threads)\n", names[i], (double)g_lat_ns[i].exchange(0) * 1e-6);
   }
-  size_t total = 0, total_rows = 0, total_tags = 0;
-  for (auto& v : per_text) { total += v.size(); for (auto& s : v) { total_rows += s.variants.size(); total_tags += s.ntags; } }
-  anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, total_tags) * sizeof(anx_match_tag))) : nullptr;
-  if (out_tags && !otags) { free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
-  anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, total) * sizeof(anx_match)));
-  size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
-  anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, total_rows) * sizeof(anx_result)));
-  if (!om || !oo || !orows) { free(om); free(oo); free(orows); free(otags); free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
-  // first match / row / tag of every text, then the texts are written side by side
-  std::vector<size_t> row0(n + 1, 0), tag0(n + 1, 0);
-  for (size_t t = 0; t < n; ++t) {
-    size_t nr = 0, nt = 0;
-    for (const Span& sp_ : per_text[t]) { nr += sp_.variants.size(); nt += sp_.ntags; }
-    oo[t + 1] = oo[t] + per_text[t].size();
-    row0[t + 1] = row0[t] + nr;
-    tag0[t + 1] = tag0[t] + nt;
-  }
-  parallel_for(n, 8, 64, [&](size_t lo, size_t hi) {
-    for (size_t t = lo; t < hi; ++t) {
-      size_t w = oo[t], rw = row0[t], tw = tag0[t];
-      std::vector<size_t> cpmap;  // byte offset -> code point index (remap_offsets_to_unicodepoints, src/search.rs:527-546)
-      if (sp->unicodeoffsets && texts[t]) {
-        const size_t len = strlen(texts[t]);
-        cpmap.assign(len + 1, 0);
-        size_t cp = 0;
-        for (size_t i = 0; i < len;) {
-          int l;
-          anx::utf8_decode_at(texts[t] + i, len - i, &l);
-          for (int k = 0; k < l && i + (size_t)k < len; ++k) cpmap[i + (size_t)k] = cp;
-          i += (size_t)l;
-          ++cp;
-        }
-        cpmap[len] = cp;
-      }
-      for (const Span& s : per_text[t]) {
-        anx_match& o = om[w++];
-        o.begin = cpmap.empty() ? s.begin : cpmap[s.begin];
-        o.end = cpmap.empty() ? s.end : cpmap[s.end];
-        o.n = s.n;
-        o.selected = (s.has_variants && !s.variants.empty()) ? s.selected : -1;
-        o.var_begin = rw;
-        for (const anx_result& r : s.variants) orows[rw++] = r;
-        o.var_end = rw;
-        o.tag_begin = otags ? (uint32_t)tw : 0u;  // (no tag array asked for: empty ranges)
-        if (otags)
-          for (uint32_t k = 0; k < s.ntags; ++k) { const auto& tg = tagpools[s.tag_stretch][s.tag0 + k]; otags[tw++] = anx_match_tag{tg.first, tg.second, 0}; }
-        o.tag_end = otags ? (uint32_t)tw : 0u;
-      }
-    }
-  });
-  free_kept();
-  lap("output");
-  *out_matches = om;
-  *out_offsets = oo;
-  *out_rows = orows;
-  *out_n_rows = row0[n];
-  if (out_tags) *out_tags = otags;
+  for (auto& v : per_text) { po.total += v.size(); for (auto& s : v) { po.total_rows += s.variants.size(); po.total_tags += s.ntags; } }
   return ANX_OK;
 }
 
