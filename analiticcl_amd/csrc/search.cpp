@@ -687,7 +687,8 @@ static void write_part(const PartOut& po, const char* const* texts, size_t n, co
 // time, each the whole pipeline in a thread of its own: the phases of the pipeline alternate between the host threads and the
 // device, so one part's device batches and lattices run under the others' host phases (a single pass leaves the device idle
 // for two thirds of the call and the host threads for the rest).
-// The parts' arrays are then written side by side into the arrays the caller gets, indices rebased.
+// When all parts are done their sizes are known: the call's arrays are allocated once and every part writes its matches, rows
+// and tags at its base (write_part).
 int anx_find_all_matches_batch(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp,
                                anx_match** out_matches, size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows,
                                anx_match_tag** out_tags) {
