@@ -83,7 +83,7 @@ struct Switches {
   int lattice_host = 0;      // ANX_LATTICE=host: lattice decoding on the host threads (A/B reference of the device kernel)
   int encode_timing = 0;     // ANX_ENCODE_TIMING, ANX_SEARCH_TIMING: host phase times on stderr
   int search_timing = 0;
-  int search_parts = 3;      // ANX_SEARCH_PARTS: parts of a large find_all_matches call in flight at a time (search.cpp)
+  int search_parts = 4;      // ANX_SEARCH_PARTS: parts of a large find_all_matches call in flight at a time (search.cpp)
   long search_parts_min = 2l << 20;  // ANX_SEARCH_PARTS_MIN: bytes of text from which a call is split
   long search_part_bytes = 4l << 20;  // ANX_SEARCH_PART_BYTES: text per part
 };

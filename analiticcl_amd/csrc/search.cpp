@@ -683,7 +683,7 @@ static void write_part(const PartOut& po, const char* const* texts, size_t n, co
 }
 
 // Texts are independent of each other (src/lib.rs:1790-1957 works text by text); a call only batches them for the device.  A large
-// call is cut into contiguous parts of ~4 MB of text (ANX_SEARCH_PART_BYTES) and ANX_SEARCH_PARTS (3) of them are in flight at a
+// call is cut into contiguous parts of ~4 MB of text (ANX_SEARCH_PART_BYTES) and ANX_SEARCH_PARTS (4) of them are in flight at a
 // time, each the whole pipeline in a thread of its own: the phases of the pipeline alternate between the host threads and the
 // device, so one part's device batches and lattices run under the others' host phases (a single pass leaves the device idle
 // for two thirds of the call and the host threads for the rest).
