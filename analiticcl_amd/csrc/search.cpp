@@ -5,6 +5,8 @@
 // go to the device as ONE anx_find_variants_batch call (the reference calls find_variants once per segment from a
 // rayon par_iter, src/lib.rs:1883-1899).  Order n depends on the unigram results through redundant_match, so the
 // orders are processed one after another.
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -618,6 +620,18 @@ static void pool_for(size_t count, size_t chunk, size_t serial_below, const std:
     }
   });
 }
+// The call's big output arrays are fresh memory every time (the caller frees them): with 4 KB pages writing 250 MB of them means
+// 60 k page faults inside the output loops.  Where transparent huge pages are available on request (the usual `madvise` setting)
+// the 2 MB-aligned inside of such an array asks for them.
+static void advise_huge(void* p, size_t bytes) {
+#ifdef MADV_HUGEPAGE
+  const uintptr_t H = (uintptr_t)2 << 20;
+  const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + bytes) & ~(H - 1);
+  if (bytes >= 4 * H && e > a) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);
+#else
+  (void)p; (void)bytes;
+#endif
+}
 // What the pipeline leaves for a part of a call: the matches of every text (their variants are views of the kept result arrays of
 // the n-gram orders), the tags, and the sizes of the part's share of the output arrays.
 struct OrderRows { anx_result* rows; size_t* offs; };
@@ -756,6 +770,8 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, r0[parts]) * sizeof(anx_result)));
   anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, t0[parts]) * sizeof(anx_match_tag))) : nullptr;
   if (!om || !oo || !orows || (out_tags && !otags)) { free(om); free(oo); free(orows); free(otags); return anx_fail(ANX_EINVAL, "out of memory"); }
+  advise_huge(om, m0[parts] * sizeof(anx_match));
+  advise_huge(orows, r0[parts] * sizeof(anx_result));
   for (size_t r = 0; r < parts; ++r) {
     write_part(*P[r], texts + cut[r], cut[r + 1] - cut[r], sp, om, oo + cut[r], orows, otags, m0[r], r0[r], t0[r]);
     P[r].reset();  // its result arrays go back to the pinned cache
