@@ -962,7 +962,22 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     std::vector<std::vector<SymRef>> part_sym(nch);
     std::vector<std::vector<uint32_t>> part_idx(nch);  // the stretches of the chunk that have a lattice
     parallel_for(nch, 1, 2, [&](size_t lo, size_t hi) {
-      for (size_t c = lo; c < hi; ++c)
+      for (size_t c = lo; c < hi; ++c) {
+        {  // room for the chunk's lattices up front: its vectors grow by hundreds of thousands of arcs otherwise, copying as they go
+          size_t nsym = 0, nstate = 0;
+          const size_t s0 = c * CH, s1 = std::min(stretches.size(), (c + 1) * CH);
+          for (size_t si = s0; si < s1; ++si) {
+            for (const Span& mt : stretches[si].matches) nsym += mt.variants.empty() ? 1 : mt.variants.size();
+            nstate += stretches[si].b1 - stretches[si].b0 + 1;
+          }
+          part[c].st.reserve(s1 - s0);
+          part[c].syms.reserve(nsym);
+          part_sym[c].reserve(nsym);
+          part[c].arcs.reserve(nsym + 2 * nstate + 4 * (s1 - s0));
+          part[c].in_off.reserve(nstate + 2 * (s1 - s0));
+          part[c].btok_off.reserve(nstate + (s1 - s0));
+          part_idx[c].reserve(s1 - s0);
+        }
         for (size_t si = c * CH; si < std::min(stretches.size(), (c + 1) * CH); ++si) {
           Stretch& st = stretches[si];
           if (build_lattice(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end, *sp, use_lm,
@@ -970,6 +985,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
             part_idx[c].push_back((uint32_t)si);
           else { decoded[si].insert(decoded[si].end(), st.matches.begin(), st.matches.end()); done[si] = 1; }  // src/lib.rs:2277-2290
         }
+      }
     });
     // The whole call's lattices in ONE pinned block (the result cache of engine.hip): [stretches | in_off | arcs | syms | btok_off |
     // btok | out_n | out_syms]; the chunk parts are copied into place side by side, the uploads run at PCIe speed.
