@@ -109,5 +109,15 @@ def search_round(seed, worlds):
     pool = synth.make_queries(words[:400], 400, max_len=14, seed=seed + 7)
     texts += [" ".join(pool[i:i + rng.randrange(10, 80)]) for i in range(0, 300, 80)]  # stretches without a hard boundary
     max_seq = rng.choice((1, 2, 5, 20, 40, 250))
-    n_multi, n_tagged = T.compare_with_twin(g, tw, texts, max_seq)
+    # every second round as concurrent parts of the call (search.cpp: large calls only, so the threshold comes down for the soak)
+    parts = rng.choice((None, None, "2", "3", "5"))
+    if parts:
+        A.set_switch("ANX_SEARCH_PARTS_MIN", "1")
+        A.set_switch("ANX_SEARCH_PARTS", parts)
+    try:
+        n_multi, n_tagged = T.compare_with_twin(g, tw, texts, max_seq)
+    finally:
+        if parts:
+            A.set_switch("ANX_SEARCH_PARTS_MIN", None)
+            A.set_switch("ANX_SEARCH_PARTS", None)
     return with_lm, with_rules, max_seq, len(texts), n_multi, n_tagged
