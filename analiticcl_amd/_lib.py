@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ANX_LIB") or os.path.join(HERE, "libanx.so")  # ANX_L
 
 ANX_OK, ANX_EINVAL, ANX_EIO, ANX_ENOTBUILT, ANX_ENODEVICE, ANX_ELIMIT, ANX_EEMPTY = 0, -1, -2, -3, -4, -5, -6
 ANX_NO_VIA = 0xFFFFFFFFFFFFFFFF
+ABI_VERSION = 2  # include/anx.h ANX_ABI_VERSION these ctypes signatures were written against (checked when the library is loaded)
 
 
 class AnxError(RuntimeError):
@@ -93,6 +94,10 @@ def lib():
     except Exception:
         pass
     L = C.CDLL(LIB_PATH)
+    L.anx_abi_version.restype = C.c_int
+    if L.anx_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.anx_abi_version()}, these bindings need {ABI_VERSION}: rebuild it "
+                          "(`python -m analiticcl_amd.build`)")
     vp, cp, u64, sz = C.c_void_p, C.c_char_p, C.c_uint64, C.c_size_t
     sig = {
         "anx_last_error": (cp, []),
@@ -172,7 +177,7 @@ def lib():
         "anx_counts_free": (None, [C.POINTER(C.c_uint32)]),
         "anx_batch_export_topk": (C.c_int, [vp, vp, C.c_uint32, vp]),
         "anx_batch_export_compact": (C.c_int, [vp, vp, sz, vp, C.POINTER(sz)]),
-        "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats)]),
+        "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats), C.c_size_t]),
         "anx_batch_free": (None, [vp]),
         "anx_device_pool_trim": (None, [C.c_int]),
     }

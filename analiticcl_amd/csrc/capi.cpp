@@ -988,8 +988,10 @@ int anx_batch_shard_info(const anx_batch* b, int shard, int* device, size_t* fir
   if (n_inputs) *n_inputs = s.n;
   return ANX_OK;
 }
-int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* s) {
-  if (!b || !s) return fail(ANX_EINVAL, "NULL argument");
+int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* out, size_t struct_size) {
+  if (!b || !out) return fail(ANX_EINVAL, "NULL argument");
+  anx_batch_stats full;
+  anx_batch_stats* s = &full;
   anx::batch_stats(b->shards[0].b, s);
   for (size_t g = 1; g < b->shards.size(); ++g) {  // counts add up, times are those of the slowest replica
     anx_batch_stats t;
@@ -1001,6 +1003,7 @@ int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* s) {
     s->ms_rank = std::max(s->ms_rank, t.ms_rank); s->ms_total = std::max(s->ms_total, t.ms_total);
     s->ms_scan_kernel = std::max(s->ms_scan_kernel, t.ms_scan_kernel); s->ms_filter_score_kernel = std::max(s->ms_filter_score_kernel, t.ms_filter_score_kernel);
   }
+  memcpy(out, s, std::min(struct_size, sizeof full));  // a caller compiled against an older (shorter) struct stays in bounds
   return ANX_OK;
 }
 void anx_device_pool_trim(int device) { anx::device_pool_trim(device); }

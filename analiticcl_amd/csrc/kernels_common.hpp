@@ -22,6 +22,7 @@ constexpr uint32_t SIG_BYTE_MAX = 120;  // group sums above this take the walk (
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
 constexpr uint32_t SCAN_TQ = 64;         // queries per tile (= per wave), compared in passes of 32 (one hit-mask bit each)
 constexpr uint32_t SCAN_HITS = 512;      // per-wave LDS hit list of the scan (entries); expanded when fewer than 256 are free
+constexpr uint32_t SCAN_MASKW = 2048;    // stream positions per window of run-end bits in the scan's run staging (stage_runs)
 constexpr uint32_t SCAN_PBUF = 128;      // per-wave LDS ring of dense pairs awaiting the fused filter (< 64 waiting + <= 64 new)
 constexpr uint32_t SCAN_CHUNK = 256;     // pair slots a wave reserves per global atomic
 constexpr uint32_t SCAN_CHUNK_FUSED = 128;  // ... in tiles whose pairs pass the fused prefilter first (a third survives)

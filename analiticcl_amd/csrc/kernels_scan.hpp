@@ -450,28 +450,50 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
   // least the length difference > k, and the table is padded with never-matching entries).
   // One 16-byte record per signature: the run (first class, count) comes with the signature, so a matching step does not
   // wait for a second, dependent load.
-  // stages the class / record runs (cb, n) of the lanes with ok: scalar loop over the ballot mask
+  // Stages the class / record runs (cb, n) of the lanes with ok -- all runs of a probe / walk step at once, 64 ids per trip.
+  // The ids of the step form a stream (runs back to back in lane order) that continues the stage at position ns; the stream is
+  // cut into blocks of 64 positions aligned with the stage, so every trip fills whole 64-id rows (only the first and the last
+  // block of a step are partial).  Lane -> run: a bit per run END in an LDS mask (ds_or, one instruction for all runs), and
+  // r = runs that ended before my position = mbcnt of the block's 64-bit mask; id = sdelta[r] + position with
+  // sdelta[r] = first id of run r - its first position.  ~14 wave instructions per 64 ids whatever the run lengths; the scalar
+  // loop this replaces took ~15 per RUN (16 ids on average: ~260 runs per tile on BASELINE configs[1], 0.28 of the kernel's
+  // 1.63 ms and most of its 0.55 SALU instructions per VALU instruction).
+  uint32_t* __restrict__ sdelta = stage + CHUNK;                                  // [64] per run of the step, in lane order
+  unsigned long long* __restrict__ smask = reinterpret_cast<unsigned long long*>(stage + CHUNK + 64);  // [SCAN_MASKW / 64] run ends of the window
   auto stage_runs = [&](bool ok, uint32_t cb, uint32_t n) {
-    unsigned long long m = __ballot(ok);
-    if (!m || (ANX_DBG(A.dbg) & 4)) return;
-    if (!ok) { cb = 0u; n = 0u; }
-    while (m) {
-      const int i = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      uint32_t cbi = (uint32_t)__builtin_amdgcn_readlane((int)cb, i), ni = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
-      while (ni) {
-        const uint32_t take = ni < 64u ? ni : 64u;  // ns < CHUNK here, the stage holds CHUNK + 64 ids
-        stage[ns + lane] = cbi + lane;              // all 64 lanes write; only the first `take` ids count
-        ns += take;
-        cbi += take;
-        ni -= take;
-        if (ns >= CHUNK) {
-          process();
-          const uint32_t rem = ns - CHUNK;
-          uint32_t v = 0;
-          if (lane < rem) v = stage[CHUNK + lane];
-          if (lane < rem) stage[lane] = v;
-          ns = rem;
+    ok = ok && n != 0u;  // an empty run has no end of its own
+    const unsigned long long okm = __ballot(ok);
+    if (!okm || (ANX_DBG(A.dbg) & 4)) return;
+    const uint32_t cnt = ok ? n : 0u;
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t carry = ns & 63u;                 // ids of the stage's last, partial row
+    const uint32_t total = carry + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);  // stream positions [carry, total)
+    uint32_t wbase = ns - carry;                     // stage row the next block goes to (multiple of 64, < CHUNK)
+    const uint32_t endp = carry + incl - 1u;         // stream position of the run's last id (ok lanes, n >= 1)
+    if (ok) sdelta[__builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = cb + cnt - 1u - endp;
+    uint32_t rbase = 0;                              // runs that ended before the current block
+    for (uint32_t w0 = 0; w0 < total; w0 += SCAN_MASKW) {  // windows of SCAN_MASKW stream positions (one, as a rule)
+      if (lane < SCAN_MASKW / 64u) smask[lane] = 0ull;
+      if (ok && endp - w0 < SCAN_MASKW) atomicOr(reinterpret_cast<uint32_t*>(smask) + ((endp - w0) >> 5), 1u << (endp & 31u));
+      const uint32_t wend = total < w0 + SCAN_MASKW ? total : w0 + SCAN_MASKW;
+      for (uint32_t p0 = w0; p0 < wend; p0 += 64) {
+        const unsigned long long m = smask[(p0 - w0) >> 6];  // wave-uniform address: a broadcast
+        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m), mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+        const uint32_t r = rbase + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        rbase += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+        const uint32_t p = p0 + lane;
+        const uint32_t id = sdelta[r & 63u] + p;
+        if (p >= carry && p < total) stage[wbase + lane] = id;
+        if (p0 + 64u <= total) {  // a whole row
+          wbase += 64u;
+          ns = wbase;
+          if (wbase == CHUNK) {
+            process();
+            ns = 0;
+            wbase = 0;
+          }
+        } else {
+          ns = wbase + (total - p0);
         }
       }
     }
@@ -544,12 +566,12 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 // Every wave takes one tile; tiles are ordered by decreasing cost.  The bit-plane tiles (wave-uniform switch over
 // T) and the count-vector tiles run as two launches so that the rarely used wide SAD body does not set the register
 // budget (= occupancy) of the common one.
-constexpr uint32_t SCAN_STAGE = 64 * 4 + 64;  // a staging step writes 64 ids behind ns < CHUNK
+constexpr uint32_t SCAN_STAGE = 64 * 4 + 64 + SCAN_MASKW / 32;  // the chunk's ids, the step's run deltas, the window's run-end masks
 template <int NP, bool BITS>
 __device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
-  __shared__ uint32_t s_stage[4][SCAN_STAGE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][SCAN_STAGE];
   // per wave, entries awaiting expansion: bit-plane tiles hit mask u32[SCAN_HITS] + (position in the chunk | pass | flag) u16[SCAN_HITS];
   // count-vector tiles (class | pass << 27, hit mask) pairs
   __shared__ uint32_t s_hits[4][BITS ? SCAN_HITS + SCAN_HITS / 2 : 2 * SCAN_HITS];

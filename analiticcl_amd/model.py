@@ -217,7 +217,7 @@ class Batch:
 
     def stats(self) -> dict:
         s = L.BatchStats()
-        L.check(L.lib().anx_batch_get_stats(self.h, C.byref(s)))
+        L.check(L.lib().anx_batch_get_stats(self.h, C.byref(s), C.sizeof(s)))
         return {k: (list(getattr(s, k)) if k == "n_tests_kind" else getattr(s, k)) for k, _ in L.BatchStats._fields_}
 
     def fetch(self) -> List[List[tuple]]:

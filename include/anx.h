@@ -20,7 +20,11 @@
 extern "C" {
 #endif
 
-#define ANX_ABI_VERSION 1
+/* 1: rounds 1-3.
+ * 2: anx_batch_stats grew (n_prefiltered_in_scan, ...), anx_batch_get_stats takes the caller's struct size through
+ *    anx_batch_get_stats_sized, anx_shutdown, asynchronous fetch, length-partitioned sharding.  A binding compares
+ *    anx_abi_version() with the ANX_ABI_VERSION it was compiled against before it calls anything else. */
+#define ANX_ABI_VERSION 2
 
 enum {
   ANX_OK = 0,
@@ -180,8 +184,9 @@ int anx_find_variants_batch(const anx_model *, const char *const *utf8, size_t n
 void anx_results_free(anx_result *rows, size_t *offsets);
 
 /* ---- staged form of the same call (inputs/results resident in HBM between stages) --------------------
- * encode : host normalisation (src/anahash.rs:16-80), threshold clamps (src/lib.rs:982-1012), length
- *          bucketing, upload.  run: the device pipeline (candidate scan -> pair list -> scoring -> rank).
+ * encode : upload of the input bytes, then ON THE DEVICE: normalisation to the alphabet (src/anahash.rs:16-80), count
+ *          vectors / signatures, threshold clamps (src/lib.rs:982-1012), sort by (length, signature), tiles.
+ * run    : the device pipeline (candidate scan -> pair list -> scoring -> rank [-> confusable weighting]).
  * fetch  : download + convert.  anx_find_variants_batch == encode + run + fetch + free. */
 anx_batch *anx_batch_encode(const anx_model *, const char *const *utf8, size_t n, const anx_params *);
 /* the same with the n inputs packed into one buffer, each terminated by a NUL byte (saves building a pointer array
@@ -246,8 +251,10 @@ typedef struct anx_batch_stats {
                                    * survivors are the pair-list slots; the others of n_pairs failed the DL's length test or were
                                    * left to k_filter_score) */
 } anx_batch_stats;
-/* counts summed over the shards of the batch, times of the slowest replica */
-int anx_batch_get_stats(const anx_batch *, anx_batch_stats *);
+/* counts summed over the shards of the batch, times of the slowest replica.  struct_size = sizeof(anx_batch_stats) as the CALLER
+ * was compiled: the library writes at most that many bytes, so a caller built against an older, shorter struct stays in bounds
+ * (the struct only ever grows at its end). */
+int anx_batch_get_stats(const anx_batch *, anx_batch_stats *, size_t struct_size);
 /* the replicas a batch is spread over: shard i holds the inputs [first_input, first_input + n_inputs) on HIP device *device
  * (any out pointer may be NULL).  anx_batch_export_topk / _compact need a batch with exactly one shard. */
 int anx_batch_num_shards(const anx_batch *);
@@ -278,8 +285,10 @@ void anx_string_free(char *);
 /* ---- confusables --------------------------------------------------------------
  * add_to_confusables / read_confusablelist / set_confusables_before_pruning: src/lib.rs:446-458, :409-443, :157-159.
  * Patterns are sesdiff edit scripts ("-[y]+[i]", "=[c|k]-[y]+[i]", "^...", "...$"; src/confusables.rs:13-44).  With
- * confusables loaded the ranked lists are rescored on the host after the device run (late, src/lib.rs:1591-1595, or
- * before the crop when set_confusables_before_pruning was called, :1505-1508); anx_batch_export_topk is then refused.
+ * confusables loaded the ranked rows are weighted ON THE DEVICE as part of anx_batch_run (late: after the crop, then re-rank and
+ * cutoff, src/lib.rs:1591-1622; or before the crop when set_confusables_before_pruning was called, :1505-1508), so the exports
+ * and anx_batch_fetch_compact work as without confusables.  A batch with an input or candidate beyond the device kernel's fixed
+ * working memory (64 code points) is redone with the host-side weighting (same results); the exports are refused for such a batch.
  * The edit script restates sesdiff 0.3.1 / dissimilar (diff-match-patch): parity unpinned beyond tests/main.rs:914-1020. */
 int anx_model_add_to_confusables(anx_model *, const char *editscript, double weight);
 int anx_model_read_confusablelist(anx_model *, const char *path);

@@ -62,7 +62,7 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
         if (nrep > 1) CHECK(anx_batch_run(m, b, (void*)0x10) == ANX_EINVAL);  // a caller stream with several replicas
         CHECK(anx_batch_fetch(b, &rows, &off) == ANX_OK);
         anx_batch_stats st;
-        CHECK(anx_batch_get_stats(b, &st) == ANX_OK && st.n_queries == in.size() && (nrep == 3 || st.n_results == off[in.size()]));
+        CHECK(anx_batch_get_stats(b, &st, sizeof st) == ANX_OK && st.n_queries == in.size() && (nrep == 3 || st.n_results == off[in.size()]));
         uint32_t* counts = nullptr;
         CHECK(anx_batch_pair_counts(b, &counts) == ANX_OK);
         anx_pair* pairs = nullptr; size_t npairs = 0;
