@@ -858,7 +858,9 @@ static void launch_scan(ScanArgs A, uint32_t nbits, uint32_t nsad, hipStream_t s
   (void)hipEventRecord(e0, st);  // e0 .. e1 = k_scan_bits alone (anx_batch_stats.ms_scan_kernel)
   if (nbits) {
     A.ntiles = nbits;
-    hipLaunchKernelGGL((k_scan_bits<NP>), dim3((nbits + 3) / 4), dim3(256), 0, st, A);
+    // the general instance for StopAtExactMatch, per-query pair counts and runs that keep every pair; production runs take the lean one
+    if (A.want_exact || A.qpairs || !A.drop_len) hipLaunchKernelGGL((k_scan_bits<true>), dim3((nbits + 3) / 4), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_scan_bits<false>), dim3((nbits + 3) / 4), dim3(256), 0, st, A);
   }
   (void)hipEventRecord(e1, st);
   if (nsad) {

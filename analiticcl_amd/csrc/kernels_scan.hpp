@@ -146,9 +146,13 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
 //   classes share a symbol, src/iterators.rs:177).  2 ops per plane: v_and_b32 + accumulating v_bcnt_u32_b32.
 // T == 0: general path (any alphabet size / multiplicity): packed u8 count vectors, NP x v_sad_u8;
 //   hit <=> L1 <= k and L1 < len_q + len_c.
-template <bool BITS, int NP>
-__device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item, uint32_t* __restrict__ stage, uint32_t* __restrict__ hits,
+template <bool BITS, int NP, bool GEN>
+__device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t item, uint32_t* __restrict__ stage, uint32_t* __restrict__ hits,
                                  uint32_t* __restrict__ qlds, uint4* __restrict__ qsym, uint32_t* __restrict__ pbuf) {
+  // GEN = false: the production instance (no StopAtExactMatch, no per-query pair counts, pairs that fail the DL's length test are
+  // only counted): those branches and their arguments stay out of the kernel
+  ScanArgs A = AA;
+  if (!GEN) { A.want_exact = 0; A.qpairs = nullptr; A.drop_len = 1; A.qexact = nullptr; }
   constexpr int CPL = BITS ? 4 : (NP <= 8 ? 4 : NP <= 16 ? 2 : 1);  // classes per lane
   constexpr int W = BITS ? NBITPLANES : NP;                          // dwords held per class
   constexpr int QSTRIDE = BITS ? NBITPLANES : NP;
@@ -567,7 +571,7 @@ __device__ inline void scan_tile(const ScanArgs& A, const Tile& t, uint32_t item
 // T) and the count-vector tiles run as two launches so that the rarely used wide SAD body does not set the register
 // budget (= occupancy) of the common one.
 constexpr uint32_t SCAN_STAGE = 64 * 4 + 64 + SCAN_MASKW / 32;  // the chunk's ids, the step's run deltas, the window's run-end masks
-template <int NP, bool BITS>
+template <int NP, bool BITS, bool GEN>
 __device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
@@ -583,12 +587,13 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
   t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12];
-  scan_tile<BITS, NP>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[BITS ? wid : 0], s_pbuf[BITS ? wid : 0]);
+  scan_tile<BITS, NP, GEN>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[BITS ? wid : 0], s_pbuf[BITS ? wid : 0]);
 }
 // <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
 // 64 with spills -> 2.60 ms)
+// one instance for every alphabet (the bit-plane body does not depend on the count-vector width); GEN: see scan_tile
+template <bool GEN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_bits(ScanArgs A) { scan_wave<8, true, GEN>(A); }
 template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_bits(ScanArgs A) { scan_wave<NP, true>(A); }
-template <int NP>
-__global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false>(A); }
+__global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false, true>(A); }
 
