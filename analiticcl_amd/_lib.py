@@ -178,6 +178,7 @@ def lib():
         "anx_batch_export_topk": (C.c_int, [vp, vp, C.c_uint32, vp]),
         "anx_batch_export_compact": (C.c_int, [vp, vp, sz, vp, C.POINTER(sz)]),
         "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats), C.c_size_t]),
+        "anx_debug_band_bound": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
         "anx_batch_free": (None, [vp]),
         "anx_device_pool_trim": (None, [C.c_int]),
     }

@@ -317,6 +317,13 @@ int anx_model_replica_device(const anx_model* m, int i) { return (m && i >= 0 &&
 int anx_debug_set_switch(const char* name, const char* value) {
   return anx::set_switch(name, value) ? ANX_OK : fail(ANX_EINVAL, "unknown switch");
 }
+int anx_debug_band_bound(int device, const uint8_t* q_rows, const uint8_t* c_rows, const uint8_t* lq, const uint8_t* lc, size_t n, int d, int form,
+                         uint8_t* out_reject) {
+  if ((!q_rows || !c_rows || !lq || !lc || !out_reject) && n) return fail(ANX_EINVAL, "NULL argument");
+  std::string err;
+  const int rc = anx::debug_band_bound(device, q_rows, c_rows, lq, lc, n, d, form, out_reject, err);
+  return rc ? fail(rc, err) : ANX_OK;
+}
 int anx_model_build(anx_model* m, int device) {
   if (!m) return fail(ANX_EINVAL, "NULL model");
   std::string err;

@@ -14,6 +14,9 @@ struct Batch;          // encoded queries + pipeline buffers + results, HBM-resi
 int device_count(std::string& err);
 DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, int device, std::string& err);
 void lexicon_free(DeviceLexicon*);
+// test hook: the band-match bound of the scan / scoring kernels on n (query row, candidate row) pairs (engine.hip k_debug_band_bound)
+int debug_band_bound(int device, const uint8_t* q_rows, const uint8_t* c_rows, const uint8_t* lq, const uint8_t* lc, size_t n, int d, int form,
+                     uint8_t* out, std::string& err);
 void device_pool_trim(int device);  // hands the cached scratch blocks of the device (and the pinned result buffers) back to the driver
 // result rows of batch_fetch live in cached pinned host buffers: release them with host_result_free (falls back to free())
 // a non-blocking stream on `device` for a replica of a multi-device model (hipStream_t behind void*)

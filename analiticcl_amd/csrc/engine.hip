@@ -1542,4 +1542,63 @@ void batch_free(Batch* b) {
   delete b;
 }
 
+// ---- test hook: the band-match bound alone (anx_debug_band_bound; tests/test_gpu_switches.py) ------------------------------------
+// One lane per pair, rows as the kernels see them (first 16 symbols, query padded with 0xFE, candidate with 0xFF); the three forms
+// in use: 0 the scan's fused filter (B7 masks, wave-uniform d, words by the wave's longest string), 1 k_filter_score's (B7, per-lane
+// d), 2 the general zero test (alphabets above 124 classes).  out[i] = 1: the bound says damerau_levenshtein(q, c) > d.
+__global__ __launch_bounds__(64) void k_debug_band_bound(const uint4* __restrict__ q, const uint4* __restrict__ c, const uint8_t* __restrict__ lqs,
+                                                         const uint8_t* __restrict__ lcs, uint32_t n, int d, int form, uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  const bool act = i < n;
+  const uint4 Q = act ? q[i] : make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+  const uint4 C = act ? c[i] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  const int lq = act ? lqs[i] : 1, lc = act ? lcs[i] : 1;
+  const int ml = lq > lc ? lq : lc;
+  bool rej;
+  if (form == 2) {
+    constexpr uint32_t M = 0xFFFFFFFFu;
+    if (__any(act && ml > 12)) { const uint32_t q4[4] = {Q.x, Q.y, Q.z, Q.w}, c6[6] = {M, C.x, C.y, C.z, C.w, M}; rej = band_bound_rejects<4, false>(q4, c6, act, d, lq, lc); }
+    else if (__any(act && ml > 8)) { const uint32_t q3[3] = {Q.x, Q.y, Q.z}, c5[5] = {M, C.x, C.y, C.z, M}; rej = band_bound_rejects<3, false>(q3, c5, act, d, lq, lc); }
+    else { const uint32_t q2[2] = {Q.x, Q.y}, c4[4] = {M, C.x, C.y, M}; rej = band_bound_rejects<2, false>(q2, c4, act, d, lq, lc); }
+  } else {
+    constexpr uint32_t M = 0x7F7F7F7Fu;
+    const uint32_t q4[4] = {Q.x & M, Q.y & M, Q.z & M, Q.w & M}, c6[6] = {M, C.x & M, C.y & M, C.z & M, C.w & M, M};
+    const uint32_t q3[3] = {q4[0], q4[1], q4[2]}, c5[5] = {M, c6[1], c6[2], c6[3], M};
+    const uint32_t q2[2] = {q4[0], q4[1]}, c4[4] = {M, c6[1], c6[2], M};
+    if (form == 0) {
+      if (__any(act && ml > 12)) rej = band_bound_rejects<4, true, true>(q4, c6, act, d, lq, lc);
+      else if (__any(act && ml > 8)) rej = band_bound_rejects<3, true, true>(q3, c5, act, d, lq, lc);
+      else rej = band_bound_rejects<2, true, true>(q2, c4, act, d, lq, lc);
+    } else {
+      if (__any(act && ml > 12)) rej = band_bound_rejects<4, true>(q4, c6, act, d, lq, lc);
+      else if (__any(act && ml > 8)) rej = band_bound_rejects<3, true>(q3, c5, act, d, lq, lc);
+      else rej = band_bound_rejects<2, true>(q2, c4, act, d, lq, lc);
+    }
+  }
+  if (act) out[i] = rej ? 1 : 0;
+}
+int debug_band_bound(int device, const uint8_t* q_rows, const uint8_t* c_rows, const uint8_t* lq, const uint8_t* lc, size_t n, int d, int form,
+                     uint8_t* out, std::string& err) {
+  if (n == 0) return ANX_OK;
+  if (n > (1u << 30) || d < 0 || d > 3 || form < 0 || form > 2) { err = "band bound: bad arguments"; return ANX_EINVAL; }
+  HIP_TRY(hipSetDevice(device));
+  uint4 *dq = nullptr, *dc = nullptr;
+  uint8_t *dlq = nullptr, *dlc = nullptr, *dout = nullptr;
+  int rc = ANX_OK;
+  auto cleanup = [&]() { for (void* p : {(void*)dq, (void*)dc, (void*)dlq, (void*)dlc, (void*)dout}) if (p) (void)hipFree(p); };
+  auto fail_hip = [&](hipError_t e) { err = std::string("HIP: ") + hipGetErrorString(e); cleanup(); return ANX_ENODEVICE; };
+  hipError_t e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&dq), n * 16)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void**>(&dc), n * 16)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&dlq), n)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void**>(&dlc), n)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&dout), n)) != hipSuccess)
+    return fail_hip(e);
+  if ((e = hipMemcpy(dq, q_rows, n * 16, hipMemcpyHostToDevice)) != hipSuccess || (e = hipMemcpy(dc, c_rows, n * 16, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(dlq, lq, n, hipMemcpyHostToDevice)) != hipSuccess || (e = hipMemcpy(dlc, lc, n, hipMemcpyHostToDevice)) != hipSuccess)
+    return fail_hip(e);
+  hipLaunchKernelGGL(k_debug_band_bound, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, 0, dq, dc, dlq, dlc, (uint32_t)n, d, form, dout);
+  if ((e = hipDeviceSynchronize()) != hipSuccess || (e = hipMemcpy(out, dout, n, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e);
+  cleanup();
+  return rc;
+}
+
 }  // namespace anx

@@ -271,6 +271,13 @@ void anx_device_pool_trim(int device);
  * used; a variable set later has no effect.  This sets one at run time: name = the variable's name ("ANX_ENCODE", "ANX_SHARD_MIN",
  * ...), value = what the variable would hold (NULL = unset).  None of them changes results.  ANX_EINVAL: unknown name. */
 int anx_debug_set_switch(const char *name, const char *value);
+/* Test hook: the band-match bound the scan's fused filter and k_filter_score apply before damerau_levenshtein (src/distance.rs:101-179)
+ * on n (query, candidate) pairs of <= 16 symbols: rows of 16 bytes (alphabet-indexed symbols, the query padded with 0xFE, the
+ * candidate with 0xFF), lengths, d <= 3.  form: 0 the scan's (7-bit symbols, wave-uniform d), 1 k_filter_score's (7-bit symbols),
+ * 2 the general one.  out_reject[i] = 1: the bound claims damerau_levenshtein(q, c) > d -- tests/test_gpu_switches.py checks that claim
+ * against the oracle's DL.  Runs on HIP device `device`. */
+int anx_debug_band_bound(int device, const uint8_t *q_rows, const uint8_t *c_rows, const uint8_t *lq, const uint8_t *lc, size_t n,
+                         int d, int form, uint8_t *out_reject);
 
 /* ---- output of `analiticcl query` --------------------------------------------------
  * The TSV lines / JSON items of output_matches_as_tsv / output_matches_as_json (src/bin/analiticcl.rs:21-187) for n
