@@ -75,7 +75,7 @@ class BatchStats(C.Structure):
                 ("n_pair_slots", C.c_uint64), ("n_survivors", C.c_uint64), ("ms_scan", C.c_float),
                 ("ms_group", C.c_float), ("ms_score", C.c_float), ("ms_rank", C.c_float), ("ms_total", C.c_float),
                 ("ms_scan_kernel", C.c_float), ("n_selected", C.c_uint64), ("ms_filter_score_kernel", C.c_float),
-                ("n_prefiltered_in_scan", C.c_uint64)]
+                ("n_prefiltered_in_scan", C.c_uint64), ("n_conf_scripts", C.c_uint64)]
 
 
 _lib = None
@@ -178,6 +178,9 @@ def lib():
         "anx_batch_export_topk": (C.c_int, [vp, vp, C.c_uint32, vp]),
         "anx_batch_export_compact": (C.c_int, [vp, vp, sz, vp, C.POINTER(sz)]),
         "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats), C.c_size_t]),
+        "anx_shutdown": (None, []),
+        "anx_debug_kernel_timer": (None, [C.c_int]),
+        "anx_debug_kernel_time": (C.c_int, [cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "anx_debug_band_bound": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
         "anx_batch_free": (None, [vp]),
         "anx_device_pool_trim": (None, [C.c_int]),
@@ -197,6 +200,18 @@ def set_switch(name: str, value) -> None:
     """anx_debug_set_switch: the A/B and test switches are read from the environment once, when the library is first used;
     this changes one afterwards (value None = unset).  Tests use it instead of os.environ."""
     check(lib().anx_debug_set_switch(name.encode(), None if value is None else str(value).encode()))
+
+
+def kernel_timer(enable: bool) -> None:
+    """HIP-event timing of k_conf_script / k_lattice launches (anx_debug_kernel_timer): clears the totals."""
+    lib().anx_debug_kernel_timer(1 if enable else 0)
+
+
+def kernel_time(name: str):
+    """(total ms, launches) of the timed launches of a kernel since kernel_timer(True); (0.0, 0) when none."""
+    ms, n = C.c_double(0.0), C.c_uint64(0)
+    lib().anx_debug_kernel_time(name.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value
 
 
 def check(rc: int):

@@ -317,6 +317,10 @@ int anx_model_replica_device(const anx_model* m, int i) { return (m && i >= 0 &&
 int anx_debug_set_switch(const char* name, const char* value) {
   return anx::set_switch(name, value) ? ANX_OK : fail(ANX_EINVAL, "unknown switch");
 }
+void anx_debug_kernel_timer(int enable) { anx::kernel_timer_enable(enable != 0); }
+int anx_debug_kernel_time(const char* name, double* total_ms, uint64_t* launches) {
+  return anx::kernel_timer_read(name, total_ms, launches) ? ANX_OK : fail(ANX_EINVAL, "no launch of that kernel was timed");
+}
 int anx_debug_band_bound(int device, const uint8_t* q_rows, const uint8_t* c_rows, const uint8_t* lq, const uint8_t* lc, size_t n, int d, int form,
                          uint8_t* out_reject) {
   if ((!q_rows || !c_rows || !lq || !lc || !out_reject) && n) return fail(ANX_EINVAL, "NULL argument");
@@ -1004,7 +1008,7 @@ int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* out, size_t struct_
     anx_batch_stats t;
     anx::batch_stats(b->shards[g].b, &t);
     s->n_queries += t.n_queries; s->n_pairs += t.n_pairs; s->n_class_tests += t.n_class_tests; s->n_results += t.n_results;
-    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected; s->n_prefiltered_in_scan += t.n_prefiltered_in_scan;
+    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected; s->n_prefiltered_in_scan += t.n_prefiltered_in_scan; s->n_conf_scripts += t.n_conf_scripts;
     for (int i = 0; i < 5; ++i) s->n_tests_kind[i] += t.n_tests_kind[i];
     s->ms_scan = std::max(s->ms_scan, t.ms_scan); s->ms_group = std::max(s->ms_group, t.ms_group); s->ms_score = std::max(s->ms_score, t.ms_score);
     s->ms_rank = std::max(s->ms_rank, t.ms_rank); s->ms_total = std::max(s->ms_total, t.ms_total);

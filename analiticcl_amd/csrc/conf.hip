@@ -261,7 +261,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_conf_script(ConfArgs a) {
   c.f_off = CF_F_OFF; c.frame_cap = CF_FRAMES;
   c.alpha = a.alpha; c.nalpha = a.nalpha;
   c.overflow = false;
-  for (uint32_t k = blockIdx.x * CF_THREADS + threadIdx.x; k < n; k += CF_BLOCKS * CF_THREADS) {
+  for (uint32_t k = blockIdx.x * CF_THREADS + threadIdx.x; k < n; k += gridDim.x * CF_THREADS) {
     const uint2 nd = a.need[a.order[k]];
     const uint32_t slot = nd.x, s = nd.y, id = row_item(a, slot);
     const uint32_t i = a.q_orig[s], t0 = a.textoff[i], t1 = a.textoff[i + 1] - 1u;
@@ -402,6 +402,7 @@ static int conf_ensure(const HostModel& m, const DeviceLexicon* dl, std::string&
 int conf_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, hipStream_t st, bool early, uint32_t row_cap, std::string& err) {
   int rc = conf_ensure(m, dl, err);
   if (rc) return rc;
+  b->conf_skipped = false;
   const DeviceConf* dc = dl->dconf;
   const uint32_t nq = (uint32_t)b->nq;
   if (!b->cf_weight || b->cf_cap < row_cap) {
@@ -421,7 +422,19 @@ int conf_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, hipStream
   }
   uint32_t* sort_buf = b->cf_sort;
   if (!b->cf_ctr) HIP_TRY(pool_malloc(reinterpret_cast<void**>(&b->cf_ctr), 16));
-  if (!b->cf_work) HIP_TRY(pool_malloc(&b->cf_work, (size_t)CF_BLOCKS * CF_WORDS * 64u * sizeof(uint32_t)));
+  // one wave per 64 rows that may need a script, at most CF_BLOCKS of them in flight: the working set (5.8 KB per lane) follows the
+  // batch's rows, so a one-line query or a small n-gram order of a search call does not claim the 1.5 GB a million queries use
+  const uint32_t cf_blocks = std::min<uint32_t>(CF_BLOCKS, std::max<uint32_t>(1u, (row_cap + 63u) / 64u));
+  if (b->cf_work && b->cf_work_blocks < cf_blocks) { pool_free(b->cf_work); b->cf_work = nullptr; }
+  if (!b->cf_work) {
+    if (pool_malloc(&b->cf_work, (size_t)cf_blocks * CF_WORDS * 64u * sizeof(uint32_t)) != hipSuccess) {
+      b->cf_work = nullptr;
+      (void)hipGetLastError();
+      b->conf_skipped = true;  // no room for the working set: the batch is redone with the host-side weighting (same results)
+      return ANX_OK;
+    }
+    b->cf_work_blocks = cf_blocks;
+  }
   HIP_TRY(hipMemsetAsync(b->cf_ctr, 0, 16, st));
   ConfArgs a;
   a.nq = nq; a.row_cap = row_cap; a.early = early ? 1 : 0; a.soff = b->soff; a.r_count = b->r_count; a.c_rows = b->c_rows; a.r_rows = b->r_rows;
@@ -442,7 +455,9 @@ int conf_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, hipStream
     HIP_TRY(rocprim::radix_sort_pairs(b->cf_sort_tmp, b->cf_sort_tmp_bytes, sort_buf, sort_buf + 2 * (size_t)row_cap, sort_buf + (size_t)row_cap,
                                       sort_buf + 3 * (size_t)row_cap, (size_t)row_cap, 0u, 13u, st));
   }
-  hipLaunchKernelGGL(k_conf_script, dim3(CF_BLOCKS), dim3(CF_THREADS), 0, st, a);
+  const int kt = ktimer_begin("k_conf_script", st);
+  hipLaunchKernelGGL(k_conf_script, dim3(b->cf_work_blocks), dim3(CF_THREADS), 0, st, a);
+  ktimer_end(kt, st);
   if (early) { if (nblk) hipLaunchKernelGGL(k_conf_apply_early, dim3(nblk), dim3(256), 0, st, a); }
   else hipLaunchKernelGGL(k_conf_apply_late, dim3((nq + 255u) / 256u), dim3(256), 0, st, a, b->r_count);
   HIP_TRY(hipGetLastError());

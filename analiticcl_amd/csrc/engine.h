@@ -17,6 +17,8 @@ void lexicon_free(DeviceLexicon*);
 // test hook: the band-match bound of the scan / scoring kernels on n (query row, candidate row) pairs (engine.hip k_debug_band_bound)
 int debug_band_bound(int device, const uint8_t* q_rows, const uint8_t* c_rows, const uint8_t* lq, const uint8_t* lc, size_t n, int d, int form,
                      uint8_t* out, std::string& err);
+void kernel_timer_enable(bool on);  // also clears the totals
+bool kernel_timer_read(const char* name, double* total_ms, uint64_t* launches);  // waits for the recorded launches
 void device_pool_trim(int device);  // hands the cached scratch blocks of the device (and the pinned result buffers) back to the driver
 // result rows of batch_fetch live in cached pinned host buffers: release them with host_result_free (falls back to free())
 // a non-blocking stream on `device` for a replica of a multi-device model (hipStream_t behind void*)

@@ -853,6 +853,68 @@ static int exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_
   return 0;
 }
 
+// ---- kernel timer (engine_internal.h) ---------------------------------------------------------------------------------
+namespace {
+struct KTimerRec { std::string name; hipEvent_t e0 = nullptr, e1 = nullptr; int device = 0; bool closed = false; };
+struct KTimer {
+  std::mutex mu;
+  std::atomic<bool> on{false};
+  std::vector<KTimerRec> pending;
+  std::map<std::string, std::pair<double, uint64_t>> acc;
+};
+KTimer& ktimer() { static KTimer* t = new KTimer; return *t; }
+void ktimer_resolve_locked(KTimer& t) {
+  for (KTimerRec& r : t.pending) {
+    if (r.closed && hipEventSynchronize(r.e1) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = t.acc[r.name]; a.first += ms; a.second += 1; }
+    }
+    if (r.e0) (void)hipEventDestroy(r.e0);
+    if (r.e1) (void)hipEventDestroy(r.e1);
+  }
+  t.pending.clear();
+}
+}  // namespace
+int ktimer_begin(const char* name, hipStream_t st) {
+  KTimer& t = ktimer();
+  if (!t.on.load(std::memory_order_relaxed)) return -1;
+  KTimerRec r;
+  r.name = name;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess || hipEventRecord(r.e0, st) != hipSuccess) {
+    if (r.e0) (void)hipEventDestroy(r.e0);
+    if (r.e1) (void)hipEventDestroy(r.e1);
+    return -1;
+  }
+  std::lock_guard<std::mutex> lk(t.mu);
+  t.pending.push_back(r);
+  return (int)t.pending.size() - 1;
+}
+void ktimer_end(int handle, hipStream_t st) {
+  if (handle < 0) return;
+  KTimer& t = ktimer();
+  std::lock_guard<std::mutex> lk(t.mu);
+  if ((size_t)handle >= t.pending.size()) return;  // the totals were read in between: the record is gone
+  KTimerRec& r = t.pending[(size_t)handle];
+  if (hipEventRecord(r.e1, st) == hipSuccess) r.closed = true;
+}
+void kernel_timer_enable(bool on) {
+  KTimer& t = ktimer();
+  std::lock_guard<std::mutex> lk(t.mu);
+  ktimer_resolve_locked(t);
+  t.acc.clear();
+  t.on.store(on);
+}
+bool kernel_timer_read(const char* name, double* total_ms, uint64_t* launches) {
+  KTimer& t = ktimer();
+  std::lock_guard<std::mutex> lk(t.mu);
+  ktimer_resolve_locked(t);
+  auto it = t.acc.find(name ? name : "");
+  if (it == t.acc.end()) { if (total_ms) *total_ms = 0.0; if (launches) *launches = 0; return false; }
+  if (total_ms) *total_ms = it->second.first;
+  if (launches) *launches = it->second.second;
+  return true;
+}
+
 template <int NP>
 static void launch_scan(ScanArgs A, uint32_t nbits, uint32_t nsad, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {  // tiles: [bit-plane kinds | SAD kind]
   (void)hipEventRecord(e0, st);  // e0 .. e1 = k_scan_bits alone (anx_batch_stats.ms_scan_kernel)
@@ -1204,7 +1266,8 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
     for (int l = 0; l < 3; ++l) list_fill = std::max(list_fill, h[HR_LCTR + (l * SCAN_REGIONS + r) * RC_STRIDE]);
   }
   const uint32_t total_surv = h[HR_TOTAL_SURV], total_results = h[HR_TOTAL_RESULTS];
-  b->conf_fallback = b->conf_mode != 0 && h[HR_CONF + 1] != 0;
+  b->conf_fallback = b->conf_mode != 0 && (h[HR_CONF + 1] != 0 || b->conf_skipped);
+  b->stats.n_conf_scripts = b->conf_mode ? h[HR_CONF] : 0;
   // ---- did the run fit what the launch assumed? ------------------------------------------------------------
   int rc;
   bool again = false;
@@ -1508,6 +1571,11 @@ void batch_set_run_mode(Batch* b, const anx_params& p, int conf_mode) {
 }
 bool batch_conf_fallback(const Batch* b) { return b->conf_fallback; }
 int batch_download_text(const Batch* b, std::string& text, std::vector<uint32_t>& off, std::string& err) {
+  if (b->n_input == 0) {  // a shard that received no inputs never allocated its text: it contributes nothing
+    text.clear();
+    off.assign(1, 0u);
+    return ANX_OK;
+  }
   if (!b->d_text || !b->d_textoff) { err = "the batch does not hold its inputs"; return ANX_EINVAL; }
   HIP_TRY(hipSetDevice(b->device));
   off.assign(b->n_input + 1, 0u);

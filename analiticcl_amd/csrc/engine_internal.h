@@ -24,6 +24,11 @@ __host__ __device__ inline bool tile_probes(uint32_t balln, uint32_t window, uns
 }
 inline bool probe_enabled() { return !switches().scan_walk_flat; }
 
+// Kernel timer (engine.hip; off unless anx_debug_kernel_timer(1)): HIP events around the launches of the kernels that dominate the
+// configurations bench.py reports (k_scan_bits, k_filter_score, k_conf_script, k_lattice), on the launch stream; resolved lazily
+// when the totals are read.  ktimer_begin returns a handle (or -1 when off) for ktimer_end.
+int ktimer_begin(const char* name, hipStream_t st);
+void ktimer_end(int handle, hipStream_t st);
 // per-device scratch pool (engine.hip): freed blocks are kept for the next batch
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p);

@@ -150,11 +150,13 @@ struct Batch {
   uint32_t* cf_need = nullptr;     // row slots that need an edit script
   uint32_t* cf_ctr = nullptr;      // [0] their number, [1] rows the device could not weight (host fallback)
   void* cf_work = nullptr;         // per-lane working memory of k_conf_script
+  uint32_t cf_work_blocks = 0;     // ... for this many one-wave blocks in flight
   uint32_t* cf_sort = nullptr;     // [4][cf_cap] shape keys / list positions before and after the sort; cf_sort_tmp: the sort's scratch
   void* cf_sort_tmp = nullptr;
   size_t cf_sort_tmp_bytes = 0;
   size_t cf_cap = 0;
-  bool conf_fallback = false;      // the last run raised cf_ctr[1]
+  bool conf_fallback = false;      // the last run raised cf_ctr[1] (or could not allocate the device working set: conf_skipped)
+  bool conf_skipped = false;
   uint32_t* scan_tmp = nullptr;
   uint2* raw = nullptr;            // flat pair list (query, entry | exact<<31), in wave chunks
   double* p_score = nullptr;       // per pair-list slot: score of the pairs that went through a DL kernel

@@ -435,7 +435,9 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   const size_t lds = (size_t)a.ring_max * K * sizeof(float);
   for (const auto& l : launches) {
     a.first = l.first; a.count = l.second;
+    const int kt = ktimer_begin("k_lattice", st);
     hipLaunchKernelGGL(k_lattice, dim3(l.second), dim3(64), lds, st, a);
+    ktimer_end(kt, st);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out_n, d_outn, n * 4, hipMemcpyDeviceToHost, st));

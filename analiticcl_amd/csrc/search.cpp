@@ -5,6 +5,7 @@
 // go to the device as ONE anx_find_variants_batch call (the reference calls find_variants once per segment from a
 // rayon par_iter, src/lib.rs:1883-1899).  Order n depends on the unigram results through redundant_match, so the
 // orders are processed one after another.
+#include <pthread.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -14,6 +15,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <iterator>
 #include <thread>
 #include <chrono>
@@ -48,13 +50,40 @@ struct LatLap { uint64_t t; LatLap() : t(g_lat_timing ? lat_now() : 0) {} void l
 
 // The host threads of search mode: one pool for the process (usable cores - 1 threads; the caller of a loop works too).  A call
 // runs a dozen parallel loops per part, several parts at a time: starting and joining 16 threads per loop cost ~0.5 ms each,
-// a sixth of a part's time.  Threads are created on first use and never joined (the pool object is leaked on purpose: no
-// destructor runs at exit while a thread may still sit in wait()).
+// a sixth of a part's time.  The threads start on first use and are JOINED by anx_shutdown() and when the library is unloaded
+// (a destructor function: dlclose / exit with no call in flight); the next call starts a fresh pool.  A fork()ed child does not
+// inherit threads: its atfork handler forgets the parent's pool object (leaked: its mutex may be held by a thread that does not
+// exist in the child), so the child's first call builds its own.
+class HostPool;
+std::atomic<HostPool*> g_pool{nullptr};
+std::mutex g_pool_mu;
 class HostPool {
  public:
   static HostPool& get() {
-    static HostPool* p = new HostPool(std::max(1u, std::min(64u, anx::usable_hw_threads())));
+    HostPool* p = g_pool.load(std::memory_order_acquire);
+    if (p) return *p;
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    p = g_pool.load(std::memory_order_relaxed);
+    if (!p) {
+      static std::once_flag fork_once;
+      std::call_once(fork_once, []() { pthread_atfork(nullptr, nullptr, []() { g_pool.store(nullptr); new (&g_pool_mu) std::mutex; }); });
+      p = new HostPool(std::max(1u, std::min(64u, anx::usable_hw_threads())));
+      g_pool.store(p, std::memory_order_release);
+    }
     return *p;
+  }
+  // joins the pool's threads and deletes it (no loop may be running); the next get() starts a new one
+  static void shutdown() {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    HostPool* p = g_pool.exchange(nullptr);
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> g2(p->mu_);
+      p->stop_ = true;
+    }
+    p->cv_.notify_all();
+    for (std::thread& t : p->threads_) t.join();
+    delete p;
   }
   unsigned width() const { return nthreads_ + 1; }
   // body() on up to `helpers` pool threads and on the caller; returns when every started body has returned.  A caller that waits
@@ -91,20 +120,23 @@ class HostPool {
  private:
   explicit HostPool(unsigned hw) : nthreads_(hw > 1 ? hw - 1 : 0) {
     for (unsigned i = 0; i < nthreads_; ++i)
-      std::thread([this]() {
+      threads_.emplace_back([this]() {
         for (;;) {
           std::function<void()> f;
           {
             std::unique_lock<std::mutex> l(mu_);
-            cv_.wait(l, [&]() { return !q_.empty(); });
+            cv_.wait(l, [&]() { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;  // stop_ and nothing left to do
             f = std::move(q_.front());
             q_.pop_front();
           }
           f();
         }
-      }).detach();
+      });
   }
   unsigned nthreads_;
+  bool stop_ = false;
+  std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<std::function<void()>> q_;
@@ -590,6 +622,13 @@ struct Stretch {  // one hard-boundary "batch" of the reference (src/lib.rs:1821
 };
 
 }  // namespace
+
+extern "C" {
+// joins the library's host threads (the pool of search mode); see include/anx.h
+void anx_shutdown(void) { HostPool::shutdown(); }
+}
+// the library is unloaded (dlclose) or the process exits through exit(): no thread of ours may be left running code that is about to be unmapped
+__attribute__((destructor)) static void anx_on_unload() { HostPool::shutdown(); }
 
 extern "C" {
 

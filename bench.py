@@ -279,6 +279,26 @@ def _spot_check(model, om, queries, arrays, op, n, rescore=None):
     return f"ok ({n} queries vs the oracle)"
 
 
+def _config_roofline(model, queries, st, total_ms, lexicon, max_len, dd, nq, extra=None):
+    """The roofline entry of an extra configuration: the slowest kernel of its device pass against the 8 TB/s HBM roof, from the
+    same byte / instruction models as the headline line (roofline_of) and the live HIP-event kernel times of anx_batch_stats;
+    `extra` = (name, ms, algorithmic bytes, note) of a kernel outside that pair (k_conf_script, k_lattice: timed by the library's
+    kernel timer, anx_debug_kernel_time)."""
+    r = roofline_of(argparse.Namespace(max_len=max_len, edit_distance=dd, anagram_distance=3, lexicon=lexicon, queries=nq), model, queries, st,
+                    st["ms_scan_kernel"], st["ms_filter_score_kernel"], total_ms)
+    pk = r["per_kernel"]
+    cands = [(k, v["avg_kernel_ms"], v["algorithmic_bytes_per_launch"], v["valu_issue_frac"], None) for k, v in pk.items()]
+    if extra:
+        cands.append((extra[0], extra[1], extra[2], None, extra[3]))
+    k, ms, nbytes, vf, note = max(cands, key=lambda c: c[1])
+    out = {"bound": "hbm", "kernel": k, "avg_kernel_ms": ms, "algorithmic_bytes": nbytes, "achieved": (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0), "valu_issue_frac": vf,
+           "kernels_ms": {c[0]: c[1] for c in cands}, "traffic": None}
+    if note:
+        out["note"] = note
+    return out
+
+
 def _time_runs(b, reps=5):
     b.run()
     b.run()
@@ -308,6 +328,7 @@ def extra_configs(args, paths, device, ncores):
     Every entry carries its own wall time ("took_s"); an entry that fails says why instead of stopping the bench."""
     import analiticcl_amd as A
     from analiticcl_amd import synth
+    from analiticcl_amd import _lib as L_
     from oracle import confusable_oracle as CO
     from oracle import cwrap as O
     out = {}
@@ -323,6 +344,7 @@ def extra_configs(args, paths, device, ncores):
 
     nld_words = synth.load_lexicon_words(paths["nld"])
     std = dict(max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+    nspot = max(1, args.spot_check)
 
     def nld_len16_d2():  # the metric string's "200k-lexicon, len<=16": nld.aspell has 222 908 entries
         m = A.VariantModel(paths["alphabet"], A.Weights(), device=device)
@@ -336,11 +358,12 @@ def extra_configs(args, paths, device, ncores):
         om = O.OracleModel(alphabet_path=paths["alphabet"])
         om.read_lexicon(paths["nld"])
         om.build()
-        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), 48)
+        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
         b.free()
         return {"workload": "nld.aspell (222 908 entries) + simple.alphabet, 1 M queries len<=16, k=3 d=2 n=10", "ms_per_step": dt * 1e3,
                 "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt, "pairs_per_query": st["n_pairs"] / max(st["n_queries"], 1),
-                "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "parity": chk}
+                "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "parity": chk,
+                "roofline": _config_roofline(m, qs, st, dt * 1e3, "nld", 16, 2, 1_000_000)}
 
     def configs2():  # nld, len <= 24, d = 3, confusable weighting
         conf = os.path.join(synth.GOLDEN_DATA, "confusables10.tsv")
@@ -352,17 +375,28 @@ def extra_configs(args, paths, device, ncores):
         p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=3, **std)
         b = m.encode_batch(qs, p)
         dt = _time_runs(b)
+        L_.kernel_timer(True)
+        b.run()
+        conf_ms, conf_n = L_.kernel_time("k_conf_script")
+        L_.kernel_timer(False)
         st = b.stats()
+        # k_conf_script, algorithmic bytes per scripted row: the input's bytes (<= 24) + the candidate's code points (4 B each) + its
+        # character-set record (16 B) + the ranked row read (24 B) + the weight written (8 B)
+        mean_len = sum(len(q) for q in qs[:20000]) / 20000.0
+        conf_bytes = st["n_conf_scripts"] * (mean_len + 4 * mean_len + 16 + 24 + 8)
         om = O.OracleModel(alphabet_path=paths["alphabet"])
         om.read_lexicon(paths["nld"])
         om.build()
         confs = CO.read_confusables(conf)
-        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 3), 10, 0.25, 0.0), 48,
+        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 3), 10, 0.25, 0.0), nspot,
                           rescore=lambda exp, q: CO.late_rescore(exp, q, confs, om.text, 0.0, 2.0))
         b.free()
         e2e = _e2e_packed(m, qs, p)
         return {"workload": "BASELINE.json configs[2]: nld.aspell, 1 M queries len<=24, k=3 d=3 n=10, 10 confusable patterns", "device_ms": dt * 1e3,
-                "pairs_per_s": st["n_pairs"] / dt, "e2e_queries_per_s": e2e, "parity": chk,
+                "pairs_per_s": st["n_pairs"] / dt, "e2e_queries_per_s": e2e, "parity": chk, "conf_scripts": st["n_conf_scripts"],
+                "roofline": _config_roofline(m, qs, st, dt * 1e3, "nld", 24, 3, 1_000_000,
+                                             extra=("k_conf_script", conf_ms / max(conf_n, 1), conf_bytes,
+                                                    "one lane group per ranked row through a branchy edit-script algorithm: bound by lane divergence, not by bytes (profiles/)")),
                 "what": "device_ms = one pass of the device pipeline over the resident batch; e2e = packed host buffer -> encode -> run -> fetch incl. the confusable rescoring"}
 
     def configs3_share():  # merged 1 M-entry lexicon, one GPU's 1.25 M of the 10 M length-bucketed queries
@@ -383,12 +417,13 @@ def extra_configs(args, paths, device, ncores):
         om = O.OracleModel(alphabet_path=paths["alphabet"])
         om.read_lexicon(path)
         om.build()
-        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), 32)
+        chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
         b.free()
         os.unlink(path)
         return {"workload": "BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon, 1.25 M of the 10 M length-bucketed queries len 4-32, k=3 d=2 n=10",
                 "ms_per_batch": dt * 1e3, "ms_per_1M_queries": dt * 1e3 / 1.25, "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt,
-                "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "scan_tiles": st["n_scan_blocks"], "parity": chk}
+                "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "scan_tiles": st["n_scan_blocks"], "parity": chk,
+                "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000)}
 
     def configs4_share():  # search mode: one GPU's 12.5 MB of the 100 MB running text, n-gram windows + bigram LM
         import random
@@ -417,6 +452,7 @@ def extra_configs(args, paths, device, ncores):
         arr = (C.c_char_p * len(texts))(*[t_.encode("utf-8") for t_ in texts])
         spc = sp._c_search()
         best = None
+        L_.kernel_timer(True)
         for _ in range(5):  # host-bound: the best of a few calls is what the box's 16 usable cores allow
             ms, offs, rows, nrows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)(), C.c_size_t(0)
             t = time.perf_counter()
@@ -424,6 +460,8 @@ def extra_configs(args, paths, device, ncores):
             dt = time.perf_counter() - t
             L.lib().anx_matches_free(ms, offs, rows, None)
             best = dt if best is None else min(best, dt)
+        lat_ms, lat_n = L_.kernel_time("k_lattice")
+        L_.kernel_timer(False)
         off, ma, ra = m.find_all_matches_arrays(texts, sp)
         # parity: sampled texts through the oracle twin's segmentation / lattice / LM code, per-segment find_variants by the C oracle
         tw = TwinOverOracle(T.read_alphabet(paths["alphabet"]))
@@ -436,7 +474,7 @@ def extra_configs(args, paths, device, ncores):
         om.build()
         tw.attach(om)
         tp = T.SearchParams(("abs", 3), ("abs", 2), 10, 0.25, 2.0, False, 0.0, max_ngram=3)
-        nchk = 6
+        nchk = 16
         for i in random.Random(5).sample(range(len(texts)), nchk):
             exp = tw.find_all_matches(texts[i], tp)
             got = ma[off[i]:off[i + 1]]
@@ -450,6 +488,15 @@ def extra_configs(args, paths, device, ncores):
                     raise RuntimeError(f"parity spot check failed: text {i}, match {e.text!r}")
         return {"workload": "BASELINE.json configs[4], one GPU's share: 12.5 MB of synthetic running text (sentences of 5-25 perturbed words), max_ngram 3, bigram LM, anx_find_all_matches_batch",
                 "MB_per_s": nbytes / 1e6 / best, "seconds": best, "matches": int(off[-1]), "variant_rows": int(ra.shape[0]),
+                # k_lattice per call (all its launches): algorithmic bytes = the lattice input (16 B per arc: one arc per variant row, plus
+                # one out-of-vocabulary / epsilon arc per match) + the chosen symbols out (8 B per match)
+                "roofline": (lambda ms, nb: {"bound": "hbm", "kernel": "k_lattice", "avg_kernel_ms": ms, "algorithmic_bytes": nb,
+                                             "achieved": (nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": (nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0), "valu_issue_frac": None, "traffic": None,
+                                             "launches_per_call": lat_n / 5.0,
+                                             "note": "ms = all k_lattice launches of one call; one wave per stretch, K <= 250 serial pops of a wave-wide minimum: "
+                                                     "latency-bound, and the call as a whole is bound by its host phases (MB_per_s)"})(
+                    lat_ms / 5.0, int(ra.shape[0]) * 16 + int(off[-1]) * (16 + 8)),
                 "parity": f"ok ({nchk} texts = {8 * nchk} sentences vs the oracle twin)"}
 
     guarded("nld_len16_d2", nld_len16_d2)
@@ -585,6 +632,9 @@ def main():
     ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="N", help="N ranks, all on device 0 (dry run of the N-rank control flow)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the result gather")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config numbers measured after the timed region")
+    ap.add_argument("--preroll-s", type=float, default=2.5, help="seconds of untimed steady-state steps before the timed region (lets an external "
+                    "GPU-utilisation sampler see the device busy; 0 with --timed-only)")
+    ap.add_argument("--spot-check", type=int, default=256, help="queries of the timed batch (and of every extra configuration) checked against the oracle after the timed region")
     args = ap.parse_args()
     if args.ranks_on_one_gpu:
         args.gpus = args.ranks_on_one_gpu
@@ -735,6 +785,16 @@ def main():
     for k in range(args.warmup):
         step(k, stream.cuda_stream, False)
     barrier()
+    # untimed pre-roll: the same steps for a couple of seconds, so that the device is visibly busy before the (sub-second) timed
+    # region starts and runs at its steady-state clocks
+    preroll_steps = 0
+    if args.preroll_s > 0 and not args.timed_only:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.preroll_s:
+            for k in range(8):
+                step(k, stream.cuda_stream, False)
+            preroll_steps += 8
+        barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, stream.cuda_stream, True)
@@ -814,6 +874,17 @@ def main():
         roofline = roofline_of(args, model, queries, st, scan_ms, fs_ms, stage_ms["ms_total"])
         e2e = e2e_of(args, model, queries, params, stream.cuda_stream, torch) if (world == 1 and not args.timed_only) else None
         ncores = usable_cores()
+        # parity of the TIMED batch itself: sampled queries of the rows the last timed step left on the device against the oracle
+        # (ranked ids, f64 scores) -- after the timed region, never inside it
+        parity = None
+        if args.spot_check > 0 and not args.timed_only:
+            from oracle import cwrap as O
+            om_ = O.OracleModel(alphabet_path=paths["alphabet"])
+            om_.read_lexicon(paths[args.lexicon])
+            om_.build()
+            parity = _spot_check(model, om_, queries, batches[(args.steps - 1) & 1].fetch_arrays(),
+                                 O.make_params(("abs", args.anagram_distance), ("abs", args.edit_distance), 10, 0.25, 2.0), min(args.spot_check, len(queries)))
+            del om_
         # the CPU baseline is reported from rank 0; at N > 1 on a shorter sample (the other ranks wait at the final barrier)
         cpu = cpu_baseline_of(args, paths, queries, ncores, 15.0 if world == 1 else 6.0) if (args.cpu_sample != 0 and not args.timed_only) else None
         # one resident copy, one run at a time (anx_batch_run: launch, wait, launch ...): the like-for-like figure of round 1's records
@@ -829,6 +900,7 @@ def main():
             "value": pairs * args.steps / elapsed, "unit": "pairs/s",
             "pipelining": "2 resident copies of the batch alternate, anx_batch_run_async on ONE stream, each waited for a step later (steady-state throughput)",
             "sync_single_copy_ms_per_step": sync_ms,
+            "parity": parity, "preroll_steps": preroll_steps,
             "configs": extras,
             "queries_per_s": nq * args.steps / elapsed,
             # `value` counts the reference's scored pairs (every damerau_levenshtein call of gather_instances, src/lib.rs:1343);

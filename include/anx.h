@@ -250,6 +250,8 @@ typedef struct anx_batch_stats {
   uint64_t n_prefiltered_in_scan; /* scored pairs the scan's fused expansion tested against the band-match bound itself (their
                                    * survivors are the pair-list slots; the others of n_pairs failed the DL's length test or were
                                    * left to k_filter_score) */
+  uint64_t n_conf_scripts;   /* ABI 2: ranked rows whose edit script the device-side confusable weighting computed (the other rows
+                              * were screened out: no pattern can match them) */
 } anx_batch_stats;
 /* counts summed over the shards of the batch, times of the slowest replica.  struct_size = sizeof(anx_batch_stats) as the CALLER
  * was compiled: the library writes at most that many bytes, so a caller built against an older, shorter struct stays in bounds
@@ -266,11 +268,23 @@ void anx_batch_free(anx_batch *);
  * Vec storage inside find_variants, src/lib.rs:1311-1402).  This hands the cached blocks back to the driver, e.g. before
  * another library needs the memory. */
 void anx_device_pool_trim(int device);
+/* Joins the host threads the library keeps between calls (the pool search mode's parallel loops run on; a model's replica threads
+ * end with anx_model_free).  Call it with no library call in flight -- before dlclose() or at the end of main(); the library also
+ * does it from a destructor function when it is unloaded.  The next call that needs the pool starts a fresh one.  After fork() the
+ * child starts with no pool (a pthread_atfork handler forgets the parent's), so forked workers may use the library independently;
+ * device state (models, batches) is NOT usable across fork(): create models in the child. */
+void anx_shutdown(void);
 
 /* A/B, test and tuning switches (DESIGN.md section 8 "Switches").  The library reads them ONCE from the environment when it is first
  * used; a variable set later has no effect.  This sets one at run time: name = the variable's name ("ANX_ENCODE", "ANX_SHARD_MIN",
  * ...), value = what the variable would hold (NULL = unset).  None of them changes results.  ANX_EINVAL: unknown name. */
 int anx_debug_set_switch(const char *name, const char *value);
+/* Measurement hook (bench.py: live kernel times of the configurations that are not the headline one): while enabled, the launches of
+ * "k_conf_script" (confusable weighting) and "k_lattice" (search mode's lattice decoding) are bracketed by HIP events on their launch
+ * stream.  anx_debug_kernel_timer(1) clears the totals and starts, (0) stops; anx_debug_kernel_time waits for the recorded launches
+ * and returns their summed duration and count (ANX_EINVAL: none recorded).  k_scan_bits / k_filter_score are always timed: anx_batch_stats. */
+void anx_debug_kernel_timer(int enable);
+int anx_debug_kernel_time(const char *name, double *total_ms, uint64_t *launches);
 /* Test hook: the band-match bound the scan's fused filter and k_filter_score apply before damerau_levenshtein (src/distance.rs:101-179)
  * on n (query, candidate) pairs of <= 16 symbols: rows of 16 bytes (alphabet-indexed symbols, the query padded with 0xFE, the
  * candidate with 0xFF), lengths, d <= 3.  form: 0 the scan's (7-bit symbols, wave-uniform d), 1 k_filter_score's (7-bit symbols),

@@ -1,6 +1,8 @@
 // Drives the host side of libanx through its C ABI under ASan / UBSan (no device): usage: host_sanitize <alphabet.tsv>
 // <lexicon.tsv> <tmpdir>.  Prints "OK <checks>" and exits 0; any sanitizer report aborts with a non-zero status.
 #include <cstdio>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -149,6 +151,26 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
           same = rr[k].vocab_id == ref_r[k].vocab_id && rr[k].dist_score == ref_r[k].dist_score && rr[k].freq_score == ref_r[k].freq_score && rr[k].via == ref_r[k].via;
         CHECK(same);
         anx_matches_free(ms, mo, rr, tg);
+      }
+      // anx_shutdown joins the pool's threads; the next call starts a fresh pool and gives the same answer
+      anx_shutdown();
+      anx_shutdown();  // idempotent
+      CHECK(anx_find_all_matches_batch(m, mp.data(), mp.size(), &sp, &ms, &mo, &rr, &nr, &tg) == ANX_OK);
+      CHECK(nr == ref_nr && memcmp(mo, ref_o, (mp.size() + 1) * sizeof(size_t)) == 0);
+      anx_matches_free(ms, mo, rr, tg);
+      // a fork()ed child has none of the parent's threads: its atfork handler forgets the parent's pool, so host-only calls work
+      // there (models are not usable across fork: the child only touches the pool through a model-free entry point)
+      {
+        fflush(stdout);
+        const pid_t pid = fork();
+        CHECK(pid >= 0);
+        if (pid == 0) {
+          anx_shutdown();           // nothing to join in the child
+          char buf[64];
+          _exit(anx_edit_script("huys", "huis", buf, sizeof buf) > 0 ? 0 : 3);
+        }
+        int status = 0;
+        CHECK(waitpid(pid, &status, 0) == pid && WIFEXITED(status) && WEXITSTATUS(status) == 0);
       }
       anx_matches_free(ref_m, ref_o, ref_r, ref_t);
       CHECK(anx_debug_set_switch("ANX_SEARCH_PARTS", nullptr) == ANX_OK && anx_debug_set_switch("ANX_SEARCH_PARTS_MIN", nullptr) == ANX_OK);

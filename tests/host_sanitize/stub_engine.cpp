@@ -28,6 +28,8 @@ DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, int devi
 }
 void lexicon_free(DeviceLexicon* d) { delete d; }
 void device_pool_trim(int) {}
+void kernel_timer_enable(bool) {}
+bool kernel_timer_read(const char*, double* ms, uint64_t* n) { if (ms) *ms = 0.0; if (n) *n = 0; return false; }
 int debug_band_bound(int, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, int, int, uint8_t*, std::string& err) { err = "stub: no device"; return ANX_ENODEVICE; }
 void* stream_create(int, std::string&) { return malloc(1); }
 void stream_destroy(int, void* s) { free(s); }
