@@ -132,6 +132,7 @@ def lib():
         "anx_debug_set_switch": (C.c_int, [cp, cp]),
         "anx_batch_num_shards": (C.c_int, [vp]),
         "anx_batch_shard_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(sz), C.POINTER(sz)]),
+        "anx_batch_shard_inputs": (C.c_int, [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint32))]),
         "anx_model_has": (C.c_int, [vp, cp]),
         "anx_model_vocab_size": (u64, [vp]),
         "anx_model_vocab_text": (cp, [vp, u64]),
@@ -181,6 +182,7 @@ def lib():
         "anx_shutdown": (None, []),
         "anx_debug_kernel_timer": (None, [C.c_int]),
         "anx_debug_kernel_time": (C.c_int, [cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "anx_debug_length_split": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(Params), C.c_int, vp]),
         "anx_debug_band_bound": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
         "anx_batch_free": (None, [vp]),
         "anx_device_pool_trim": (None, [C.c_int]),

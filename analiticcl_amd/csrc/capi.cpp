@@ -59,10 +59,12 @@ struct Replica {
   void* stream = nullptr;              // non-blocking stream of the replica (multi-replica batches run on it)
   std::unique_ptr<Worker> worker;      // only with more than one replica
 };
-struct Shard {  // the part of a batch one replica holds: inputs [lo, lo + n) of the call
+struct Shard {  // the part of a batch one replica holds: inputs [lo, lo + n) of the call, or -- length-partitioned split -- the inputs idx[0 .. n)
   int replica = 0;
   anx::Batch* b = nullptr;
   size_t lo = 0, n = 0;
+  std::vector<uint32_t> idx;  // ascending original indices of the shard's inputs; empty = the consecutive range
+  size_t input(size_t i) const { return idx.empty() ? lo + i : idx[i]; }
 };
 }  // namespace
 
@@ -73,7 +75,8 @@ struct anx_model {
 };
 struct anx_batch {
   const anx_model* model = nullptr;
-  std::vector<Shard> shards;      // one per replica that got inputs, consecutive input ranges in input order (never empty)
+  std::vector<Shard> shards;      // one per replica that got inputs (never empty): consecutive input ranges in input order, or the
+                                  // length-partitioned split (Shard::idx; split_by_length below)
   size_t n_input = 0;
   // confusables loaded: the device ranks without the cutoff (late) or without crop and cutoff (early); the host
   // rescoring in anx_batch_fetch needs the caller's parameters and the input texts
@@ -676,6 +679,126 @@ size_t count_nul(const char* p, size_t len) {
   for (; i < len; ++i) c += p[i] == 0;
   return c;
 }
+
+// body(lo, hi, t) over [0, n) on up to 16 host threads (one for small n)
+void parallel_ranges(size_t n, const std::function<void(size_t, size_t, unsigned)>& body, unsigned* used = nullptr) {
+  unsigned T = n < (1u << 16) ? 1u : std::max(1u, std::min(16u, anx::usable_hw_threads()));
+  if (used) *used = T;
+  if (T == 1) { body(0, n, 0); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; ++t) th.emplace_back(body, n * t / T, n * (t + 1) / T, t);
+  for (auto& x : th) x.join();
+}
+// offsets of the first n NUL-terminated spans of blob (n + 1 values), found by several threads: every thread takes a byte range that
+// starts at a string start, counts its strings, then writes their offsets behind the strings of the ranges before it
+bool packed_offsets_mt(const char* blob, size_t len, size_t n, std::vector<uint32_t>& off) {
+  const unsigned T = len < (1u << 20) ? 1u : std::max(1u, std::min(16u, anx::usable_hw_threads()));
+  if (T == 1) return anx::packed_offsets(blob, len, n, off);
+  std::vector<size_t> pos(T + 1, len), cnt(T, 0);
+  pos[0] = 0;
+  for (unsigned t = 1; t < T; ++t) {
+    size_t p = len * t / T;
+    if (p > 0 && blob[p - 1] != '\0') {
+      const void* z = memchr(blob + p, 0, len - p);
+      p = z ? (size_t)(static_cast<const char*>(z) - blob) + 1 : len;
+    }
+    pos[t] = std::max(p, pos[t - 1]);
+  }
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t]() { cnt[t] = count_nul(blob + pos[t], pos[t + 1] - pos[t]); });
+    for (auto& x : th) x.join();
+  }
+  std::vector<size_t> first(T + 1, 0);
+  for (unsigned t = 0; t < T; ++t) first[t + 1] = first[t] + cnt[t];
+  if (first[T] < n) return false;
+  off.assign(n + 1, 0u);
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        size_t k = first[t];
+        const char* p = blob + pos[t];
+        const char* end = blob + pos[t + 1];
+        while (p < end && k < n) {
+          off[k++] = (uint32_t)(p - blob);
+          p = static_cast<const char*>(memchr(p, 0, (size_t)(end - p))) + 1;
+        }
+        if (k == n && first[t] < n && first[t + 1] >= n) off[n] = (uint32_t)(p - blob);  // the thread that holds the n-th string closes the list
+      });
+    for (auto& x : th) x.join();
+  }
+  return true;
+}
+// Length-partitioned split (BASELINE configs[3]: "10M queries len 4-32 length-bucketed, query-sharded over 8 GPUs").  The device
+// groups a batch's queries by (length, signature) into scan tiles of <= 64; consecutive input ranges give every replica 1 / S of
+// EVERY group -- 4.9 queries per tile at 1.25 M queries per GPU against the 1 M-entry lexicon, where the whole job on one device
+// has 13 -- and a third of each GPU's time goes into per-tile overheads the split itself creates.  The reference fans out over
+// independent inputs in arbitrary order (src/bin/analiticcl.rs:416-448), so any partition is legal: here the inputs are ordered
+// by byte length (= symbol count for ASCII; other strings only land in a less fitting share) and cut into S cost-balanced
+// consecutive pieces of that order, so that a replica owns whole lengths and with them whole (length, signature) groups; only the
+// lengths a cut runs through are split (by input order).  Cost of an input = a constant + the lexicon's classes within its
+// anagram-distance window (what its scan walks through).  Results go back to input order when they are fetched (Shard::idx).
+void split_by_length(const anx_model* m, const uint32_t* lens, size_t n, const anx_params& p, std::vector<Shard>& shards) {
+  const size_t S = shards.size();
+  constexpr uint32_t LMAX = 256;  // byte lengths >= 255 share the last class
+  unsigned T = 1;
+  std::vector<std::vector<uint32_t>> hist;
+  parallel_ranges(n, [&](size_t, size_t, unsigned) {}, &T);
+  hist.assign(T, std::vector<uint32_t>(LMAX, 0));
+  parallel_ranges(n, [&](size_t lo, size_t hi, unsigned t) {
+    std::vector<uint32_t>& h = hist[t];
+    for (size_t i = lo; i < hi; ++i) ++h[std::min<uint32_t>(lens[i], LMAX - 1)];
+  });
+  // cost per input of every length, cumulative cost at the first input of every length
+  const anx::LexiconImage& lex = m->host.lex;
+  double w[LMAX], base[LMAX + 1];
+  base[0] = 0.0;
+  for (uint32_t L = 0; L < LMAX; ++L) {
+    const int k = anx::clamp_threshold(p.max_anagram_distance, (int)L, anx::kMaxAnagramDistance);
+    double window = 0.0;
+    for (int c = std::max(1, (int)L - k); c <= std::min(anx::kMaxSymbols, (int)L + k); ++c) window += (double)(lex.bucket_begin[c + 1] - lex.bucket_begin[c]);
+    w[L] = 1024.0 + window / 16.0;
+    uint64_t cnt = 0;
+    for (unsigned t = 0; t < T; ++t) cnt += hist[t][L];
+    base[L + 1] = base[L] + w[L] * (double)cnt;
+  }
+  const double total = base[LMAX] > 0.0 ? base[LMAX] : 1.0;
+  // rank of every thread's first input inside its length class
+  std::vector<std::vector<uint32_t>> start(T, std::vector<uint32_t>(LMAX, 0));
+  for (uint32_t L = 0; L < LMAX; ++L) {
+    uint32_t run = 0;
+    for (unsigned t = 0; t < T; ++t) { start[t][L] = run; run += hist[t][L]; }
+  }
+  std::vector<uint8_t> gid(n);
+  std::vector<std::vector<uint32_t>> per(T, std::vector<uint32_t>(S, 0));
+  parallel_ranges(n, [&](size_t lo, size_t hi, unsigned t) {
+    std::vector<uint32_t>& st = start[t];
+    for (size_t i = lo; i < hi; ++i) {
+      const uint32_t L = std::min<uint32_t>(lens[i], LMAX - 1);
+      const double cum = base[L] + w[L] * (double)st[L]++;
+      const size_t g = std::min(S - 1, (size_t)(cum * (double)S / total));
+      gid[i] = (uint8_t)g;
+      ++per[t][g];
+    }
+  });
+  std::vector<std::vector<size_t>> at(T, std::vector<size_t>(S, 0));
+  for (size_t g = 0; g < S; ++g) {
+    size_t run = 0;
+    for (unsigned t = 0; t < T; ++t) { at[t][g] = run; run += per[t][g]; }
+    shards[g].idx.assign(run, 0u);
+    shards[g].n = run;
+    shards[g].lo = 0;
+  }
+  parallel_ranges(n, [&](size_t lo, size_t hi, unsigned t) {
+    std::vector<size_t>& a = at[t];
+    for (size_t i = lo; i < hi; ++i) shards[gid[i]].idx[a[gid[i]]++] = (uint32_t)i;  // a thread's inputs are consecutive: ascending per shard
+  });
+  shards.erase(std::remove_if(shards.begin(), shards.end(), [](const Shard& s) { return s.n == 0; }), shards.end());
+}
+bool use_length_split(const anx_model* m, size_t S, bool rescore) {
+  return S > 1 && S <= 255 && !rescore && anx::switches().shard_by_length && m->host.built;
+}
 }  // namespace
 
 // device parameters of a batch: with confusables the cutoff (and in early mode the crop) follows the host-side rescoring
@@ -697,6 +820,16 @@ static int check_resident(const anx_model* m) {  // there is no CPU fallback
   if (m->replicas.empty()) return fail(ANX_ENODEVICE, "model is not resident on a device (no HIP device / anx_model_to_device not called)");
   return ANX_OK;
 }
+int anx_debug_length_split(const anx_model* m, const uint32_t* byte_lengths, size_t n, const anx_params* p, int n_shards, uint8_t* out_shard) {
+  if (!m || (!byte_lengths && n) || !p || (!out_shard && n) || n_shards < 1 || n_shards > 255) return fail(ANX_EINVAL, "bad argument");
+  if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet!");
+  std::vector<Shard> shards((size_t)n_shards);
+  for (int g = 0; g < n_shards; ++g) shards[(size_t)g].replica = g;
+  split_by_length(m, byte_lengths, n, *p, shards);
+  for (const Shard& s : shards)
+    for (uint32_t i : s.idx) out_shard[i] = (uint8_t)s.replica;
+  return ANX_OK;
+}
 anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p) {
   if (check_encode_args(m, utf8, n, p) || check_resident(m)) return nullptr;
   bool rescore;
@@ -712,10 +845,23 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
   const size_t S = shards_for(m, n);
   h->shards.resize(S);
   for (size_t g = 0; g < S; ++g) { h->shards[g].replica = (int)g; h->shards[g].lo = n * g / S; h->shards[g].n = n * (g + 1) / S - n * g / S; }
+  if (use_length_split(m, S, rescore)) {
+    std::vector<uint32_t> lens(n);
+    parallel_ranges(n, [&](size_t lo, size_t hi, unsigned) {
+      for (size_t i = lo; i < hi; ++i) lens[i] = utf8[i] ? (uint32_t)std::min<size_t>(strlen(utf8[i]), 0xFFFFu) : 0u;
+    });
+    split_by_length(m, lens.data(), n, *p, h->shards);
+  }
   const int rc = on_shards(h, [&](size_t g, std::string& err) {
     Shard& s = h->shards[g];
     int code = ANX_OK;
-    s.b = anx::batch_encode(m->host, m->replicas[(size_t)s.replica].dev, utf8 + s.lo, s.n, dp, err, &code, dev_conf);
+    if (s.idx.empty()) {
+      s.b = anx::batch_encode(m->host, m->replicas[(size_t)s.replica].dev, utf8 + s.lo, s.n, dp, err, &code, dev_conf);
+    } else {
+      std::vector<const char*> ptrs(s.n);
+      for (size_t i = 0; i < s.n; ++i) ptrs[i] = utf8[s.idx[i]];
+      s.b = anx::batch_encode(m->host, m->replicas[(size_t)s.replica].dev, ptrs.data(), s.n, dp, err, &code, dev_conf);
+    }
     if (s.b && dev_conf) anx::batch_set_run_mode(s.b, dp, m->host.confusables_before_pruning ? 2 : 1);
     return s.b ? ANX_OK : (code ? code : ANX_ENODEVICE);
   });
@@ -753,6 +899,29 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
   const size_t S = shards_for(m, n);
   h->shards.resize(S);
   for (size_t g = 0; g < S; ++g) h->shards[g].replica = (int)g;
+  if (use_length_split(m, S, rescore)) {
+    // length-partitioned split: the host finds the strings (threaded), orders them by length and hands every replica its own
+    // list; each replica's thread packs and uploads its strings (the char** path).  Costs the host one pass over the buffer that
+    // the byte-balanced split below does not need -- and buys full scan tiles on every device.
+    std::vector<uint32_t> poff;
+    if (!packed_offsets_mt(blob, blob_len, n, poff)) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); delete h; return nullptr; }
+    std::vector<uint32_t> lens(n);
+    parallel_ranges(n, [&](size_t lo, size_t hi, unsigned) {
+      for (size_t i = lo; i < hi; ++i) lens[i] = poff[i + 1] - poff[i] - 1u;
+    });
+    split_by_length(m, lens.data(), n, *p, h->shards);
+    const int rcl = on_shards(h, [&](size_t g, std::string& err) {
+      Shard& s = h->shards[g];
+      int code = ANX_OK;
+      std::vector<const char*> ptrs(s.n);
+      for (size_t i = 0; i < s.n; ++i) ptrs[i] = blob + poff[s.idx[i]];
+      s.b = anx::batch_encode(m->host, m->replicas[(size_t)s.replica].dev, ptrs.data(), s.n, dp, err, &code, dev_conf);
+      if (s.b && dev_conf) anx::batch_set_run_mode(s.b, dp, m->host.confusables_before_pruning ? 2 : 1);
+      return s.b ? ANX_OK : (code ? code : ANX_ENODEVICE);
+    });
+    if (rcl) { free_shards(h); delete h; return nullptr; }
+    return h;
+  }
   // Byte-balanced split: shard g takes the strings that START in bytes [pos[g], pos[g + 1]), where pos[g] is the first string
   // start at or behind blob_len * g / S.  Each replica's thread counts the strings of its own slice (phase 1); the prefix sums give
   // every shard its first input index, and the call's n cuts the tail ("the first n NUL-terminated spans").
@@ -830,12 +999,18 @@ static int conf_fallback_to_host(const anx_model* m, anx_batch* b, void* stream)
     return anx::batch_run(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
   });
   if (rc) return rc;
-  b->in_text.clear();
-  b->in_off.assign(1, 0u);
+  // the inputs in the call's order (a length-partitioned shard holds a scattered subset)
+  b->in_off.assign(b->n_input + 1, 0u);
   for (size_t g = 0; g < b->shards.size(); ++g) {
-    const uint32_t base = (uint32_t)b->in_text.size();
-    b->in_text += text[g];
-    for (size_t i = 1; i < off[g].size(); ++i) b->in_off.push_back(base + off[g][i]);
+    const Shard& s = b->shards[g];
+    for (size_t i = 0; i + 1 < off[g].size(); ++i) b->in_off[s.input(i) + 1] = off[g][i + 1] - off[g][i];
+  }
+  for (size_t i = 0; i < b->n_input; ++i) b->in_off[i + 1] += b->in_off[i];
+  b->in_text.assign(b->in_off[b->n_input], '\0');
+  for (size_t g = 0; g < b->shards.size(); ++g) {
+    const Shard& s = b->shards[g];
+    for (size_t i = 0; i + 1 < off[g].size(); ++i)
+      memcpy(&b->in_text[b->in_off[s.input(i)]], text[g].data() + off[g][i], off[g][i + 1] - off[g][i]);
   }
   b->dev_conf = false;
   b->rescore = true;
@@ -857,6 +1032,47 @@ int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
   });
   return rc ? rc : conf_fallback_to_host(m, b, stream);
 }
+}  // extern "C"
+// Rows of a batch whose shards hold scattered inputs (length-partitioned split), back in the call's input order: every shard
+// downloads into a buffer of its own (pinned cache), the per-input counts give the global offsets, and the shards' threads copy
+// their rows to where they belong.  Row = anx_result / anx_topk_record, Off = size_t / uint32_t.
+template <typename Row, typename Off, typename FetchFn>
+static int scatter_fetch(const anx_batch* b, Row* out, Off* off, const FetchFn& fetch_into) {
+  const size_t n = b->n_input, S = b->shards.size();
+  std::vector<Row*> rows(S, nullptr);
+  std::vector<std::vector<Off>> loff(S);
+  auto release = [&]() { for (Row* r : rows) anx::host_result_free(r); };
+  int rc = on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    rows[g] = static_cast<Row*>(anx::host_result_alloc(std::max<size_t>(1, anx::batch_n_results(s.b)) * sizeof(Row)));
+    if (!rows[g]) { err = "out of memory"; return (int)ANX_EINVAL; }
+    loff[g].assign(s.n + 1, 0);
+    return fetch_into(s.b, rows[g], loff[g].data(), err);
+  });
+  if (rc) { release(); return rc; }
+  for (size_t i = 0; i <= n; ++i) off[i] = 0;
+  (void)on_shards(b, [&](size_t g, std::string&) {
+    const Shard& s = b->shards[g];
+    for (size_t i = 0; i < s.n; ++i) off[s.input(i) + 1] = loff[g][i + 1] - loff[g][i];
+    return (int)ANX_OK;
+  });
+  for (size_t i = 0; i < n; ++i) off[i + 1] += off[i];
+  (void)on_shards(b, [&](size_t g, std::string&) {
+    const Shard& s = b->shards[g];
+    for (size_t i = 0; i < s.n; ++i) {
+      const size_t c = (size_t)(loff[g][i + 1] - loff[g][i]);
+      if (c) memcpy(out + off[s.input(i)], rows[g] + loff[g][i], c * sizeof(Row));
+    }
+    return (int)ANX_OK;
+  });
+  release();
+  return ANX_OK;
+}
+static bool scattered(const anx_batch* b) {
+  for (const Shard& s : b->shards) if (!s.idx.empty()) return true;
+  return false;
+}
+extern "C" {
 int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   if (!b || !rows || !offs) return fail(ANX_EINVAL, "NULL argument");
   // one row array for the whole call; every shard downloads straight into its slice (the sizes are known since the run)
@@ -866,6 +1082,16 @@ int anx_batch_fetch(const anx_batch* b, anx_result** rows, size_t** offs) {
   size_t* off = static_cast<size_t*>(malloc((n + 1) * sizeof(size_t)));
   anx_result* out = static_cast<anx_result*>(anx::host_result_alloc(std::max<size_t>(1, base[S]) * sizeof(anx_result)));
   if (!off || !out) { free(off); anx::host_result_free(out); return fail(ANX_EINVAL, "out of memory"); }
+  if (scattered(b)) {
+    const int rcs = scatter_fetch<anx_result, size_t>(b, out, off, [](const anx::Batch* sb, anx_result* r, size_t* o, std::string& err) {
+      return anx::batch_fetch_into(sb, r, o, 0, err);
+    });
+    if (rcs) { free(off); anx::host_result_free(out); return rcs; }
+    if (b->rescore) rescore_with_confusables(b->model->host, b->in_text, b->in_off, b->params, out, off);
+    *rows = out;
+    *offs = off;
+    return ANX_OK;
+  }
   const int rc = on_shards(b, [&](size_t g, std::string& err) {
     const Shard& s = b->shards[g];
     std::vector<size_t> tmp;  // a shard writes n + 1 offsets; its last one is the next shard's first (same value): keep the slices disjoint
@@ -896,6 +1122,15 @@ int anx_batch_fetch_compact(const anx_batch* b, anx_topk_record** rows, uint32_t
   if (!blk) return fail(ANX_EINVAL, "out of memory");
   anx_topk_record* out = reinterpret_cast<anx_topk_record*>(blk);
   uint32_t* off = reinterpret_cast<uint32_t*>(blk + row_bytes);
+  if (scattered(b)) {
+    const int rcs = scatter_fetch<anx_topk_record, uint32_t>(b, out, off, [](const anx::Batch* sb, anx_topk_record* r, uint32_t* o, std::string& err) {
+      return anx::batch_fetch_compact_into(sb, r, o, 0u, err);
+    });
+    if (rcs) { anx::host_result_free(blk); return rcs; }
+    *rows = out;
+    *offs = off;
+    return ANX_OK;
+  }
   const int rc = on_shards(b, [&](size_t g, std::string& err) {
     const Shard& s = b->shards[g];
     std::vector<uint32_t> tmp;  // the last offset of a shard is the first of the next: keep the slices disjoint
@@ -936,14 +1171,14 @@ int anx_batch_fetch_pairs(const anx_batch* b, anx_pair** out, size_t* n) {
     return anx::batch_fetch_pairs(b->model->host, b->model->replicas[(size_t)s.replica].dev, s.b, &part[g], &cnt[g], err);
   });
   if (rc) { for (anx_pair* p : part) free(p); return rc; }
-  if (S == 1) { *out = part[0]; *n = cnt[0]; return ANX_OK; }
+  if (S == 1 && !scattered(b)) { *out = part[0]; *n = cnt[0]; return ANX_OK; }
   size_t total = 0;
   for (size_t c : cnt) total += c;
   anx_pair* all = static_cast<anx_pair*>(malloc(std::max<size_t>(1, total) * sizeof(anx_pair)));
   if (!all) { for (anx_pair* p : part) free(p); return fail(ANX_EINVAL, "out of memory"); }
   size_t w = 0;
   for (size_t g = 0; g < S; ++g) {
-    for (size_t i = 0; i < cnt[g]; ++i) { all[w] = part[g][i]; all[w].query += (uint32_t)b->shards[g].lo; ++w; }
+    for (size_t i = 0; i < cnt[g]; ++i) { all[w] = part[g][i]; all[w].query = (uint32_t)b->shards[g].input(part[g][i].query); ++w; }
     free(part[g]);
   }
   *out = all;
@@ -960,11 +1195,13 @@ int anx_batch_pair_counts(anx_batch* b, uint32_t** out) {
     return anx::batch_pair_counts(b->model->host, b->model->replicas[(size_t)s.replica].dev, s.b, &part[g], err);
   });
   if (rc) { for (uint32_t* p : part) free(p); return rc; }
-  if (S == 1) { *out = part[0]; return ANX_OK; }
+  if (S == 1 && !scattered(b)) { *out = part[0]; return ANX_OK; }
   uint32_t* all = static_cast<uint32_t*>(calloc(std::max<size_t>(1, b->n_input), sizeof(uint32_t)));
   if (!all) { for (uint32_t* p : part) free(p); return fail(ANX_EINVAL, "out of memory"); }
   for (size_t g = 0; g < S; ++g) {
-    if (b->shards[g].n) memcpy(all + b->shards[g].lo, part[g], b->shards[g].n * sizeof(uint32_t));
+    const Shard& sh = b->shards[g];
+    if (sh.idx.empty()) { if (sh.n) memcpy(all + sh.lo, part[g], sh.n * sizeof(uint32_t)); }
+    else for (size_t i = 0; i < sh.n; ++i) all[sh.idx[i]] = part[g][i];
     free(part[g]);
   }
   *out = all;
@@ -995,8 +1232,14 @@ int anx_batch_shard_info(const anx_batch* b, int shard, int* device, size_t* fir
   if (!b || shard < 0 || (size_t)shard >= b->shards.size()) return fail(ANX_EINVAL, "no such shard");
   const Shard& s = b->shards[(size_t)shard];
   if (device) *device = b->model->replicas[(size_t)s.replica].device;
-  if (first_input) *first_input = s.lo;
+  if (first_input) *first_input = s.idx.empty() ? s.lo : s.idx[0];
   if (n_inputs) *n_inputs = s.n;
+  return ANX_OK;
+}
+int anx_batch_shard_inputs(const anx_batch* b, int shard, const uint32_t** indices) {
+  if (!b || !indices || shard < 0 || (size_t)shard >= b->shards.size()) return fail(ANX_EINVAL, "no such shard");
+  const Shard& s = b->shards[(size_t)shard];
+  *indices = s.idx.empty() ? nullptr : s.idx.data();
   return ANX_OK;
 }
 int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* out, size_t struct_size) {

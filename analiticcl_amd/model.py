@@ -215,6 +215,15 @@ class Batch:
             out.append((dev.value, lo.value, cnt.value))
         return out
 
+    def shard_inputs(self, shard: int):
+        """Indices (ascending) of the inputs shard `shard` holds under the length-partitioned split, None for a consecutive range."""
+        import numpy as np
+        dev, lo, cnt = C.c_int(), C.c_size_t(), C.c_size_t()
+        L.check(L.lib().anx_batch_shard_info(self.h, shard, C.byref(dev), C.byref(lo), C.byref(cnt)))
+        ix = C.POINTER(C.c_uint32)()
+        L.check(L.lib().anx_batch_shard_inputs(self.h, shard, C.byref(ix)))
+        return np.ctypeslib.as_array(ix, shape=(cnt.value,)).copy() if ix else None
+
     def stats(self) -> dict:
         s = L.BatchStats()
         L.check(L.lib().anx_batch_get_stats(self.h, C.byref(s), C.sizeof(s)))
@@ -462,6 +471,15 @@ class VariantModel:
         if n < 0:
             L.check(n)
         return int(buf.value)
+
+    def length_split(self, byte_lengths, params: "SearchParameters", n_shards: int):
+        """Which of n_shards replicas each input of the given byte length would go to under the length-partitioned split of a
+        multi-device model (anx_debug_length_split; needs no device): a numpy uint8 array."""
+        import numpy as np
+        lens = np.ascontiguousarray(byte_lengths, dtype=np.uint32)
+        out = np.zeros(lens.size, dtype=np.uint8)
+        L.check(L.lib().anx_debug_length_split(self.h, lens.ctypes.data, lens.size, C.byref(params._c()), n_shards, out.ctypes.data))
+        return out
 
     # -- the hot path ---------------------------------------------------------------------------------
     def encode_packed(self, packed: bytes, n: int, params: SearchParameters) -> Batch:

@@ -62,6 +62,42 @@ def make_queries(words: Sequence[str], n: int, max_len: int = 16, min_len: int =
     return out
 
 
+def make_queries_with_quota(words: Sequence[str], quota: dict, max_len: int = 16, min_len: int = 1, seed: int = SEED) -> List[str]:
+    """Queries from the law of make_queries(words, ., max_len, min_len) CONDITIONED on their length: quota[L] queries of every length
+    L in quota (one GPU's share of a length-partitioned job, BASELINE configs[3]).  Rejection sampling from the entries that can
+    reach those lengths (an edit changes the length by at most one, <= 2 edits), same edit process: exactly the conditional law."""
+    rng = random.Random(seed)
+    lo, hi = min(quota), max(quota)
+    pool = [w for w in words if max(min_len, lo - 2) <= len(w) <= min(max_len, hi + 2)]
+    left = dict(quota)
+    need = sum(left.values())
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    out: List[str] = []
+    choice, rnd, randrange = rng.choice, rng.random, rng.randrange
+    while need > 0:
+        cs = list(choice(pool))
+        r = rnd()
+        e = 0 if r < 0.2 else (1 if r < 0.7 else 2)
+        for _ in range(e):
+            op = randrange(4)
+            if op == 0:
+                if len(cs) > 1:
+                    del cs[randrange(len(cs))]
+            elif op == 1:
+                cs.insert(randrange(len(cs) + 1), letters[randrange(26)])
+            elif op == 2:
+                cs[randrange(len(cs))] = letters[randrange(26)]
+            elif len(cs) > 1:
+                p = randrange(len(cs) - 1)
+                cs[p], cs[p + 1] = cs[p + 1], cs[p]
+        n = len(cs)
+        if left.get(n, 0) > 0 and n <= max_len:
+            left[n] -= 1
+            need -= 1
+            out.append("".join(cs))
+    return out
+
+
 def make_lexicon(words: Sequence[str], n: int, min_len: int = 4, max_len: int = 32, seed: int = SEED) -> List[str]:
     """BASELINE.json configs[3]: the given words plus seeded order-2 Markov-chain words (trained on them) up to n
     distinct entries; lengths min_len..max_len."""

@@ -419,11 +419,39 @@ def extra_configs(args, paths, device, ncores):
         om.build()
         chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
         b.free()
+        # The same job cut the way a multi-device model cuts it (anx_model_to_devices: length-partitioned split, cost-balanced): ONE of
+        # the 8 shares of the 10 M-query job -- every query of the lengths that share owns -- run on this GPU.  The lengths come from
+        # the library's own split of a 1 M sample of the job (anx_debug_length_split, 8 shards), scaled by 10; the queries from the
+        # job's generator conditioned on their length (synth.make_queries_with_quota).
+        import numpy as np
+        sample = synth.make_queries(lex, 1_000_000, max_len=32, min_len=4, seed=6)
+        gid = m.length_split([len(q.encode("utf-8")) for q in sample], p, 8)
+        share = 4
+        quota = {}
+        for q, g_ in zip(sample, gid):
+            if g_ == share:
+                quota[len(q)] = quota.get(len(q), 0) + 10
+        qs2 = synth.make_queries_with_quota(lex, quota, max_len=32, min_len=4, seed=7)
+        qs2.sort(key=len)
+        b2 = m.encode_batch(qs2, p)
+        dt2 = _time_runs(b2, reps=3)
+        st2 = b2.stats()
+        chk2 = _spot_check(m, om, qs2, b2.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
+        b2.free()
         os.unlink(path)
+        shares = [int((gid == g_).sum()) for g_ in range(8)]
         return {"workload": "BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon, 1.25 M of the 10 M length-bucketed queries len 4-32, k=3 d=2 n=10",
                 "ms_per_batch": dt * 1e3, "ms_per_1M_queries": dt * 1e3 / 1.25, "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt,
                 "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "scan_tiles": st["n_scan_blocks"], "parity": chk,
-                "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000)}
+                "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000),
+                "what": "ms_per_1M_queries = a RANDOM eighth of the job (what consecutive input ranges give a GPU: an eighth of every (length, signature) group); "
+                        "by_length = one share of the length-partitioned split the library uses for multi-device models",
+                "by_length": {"workload": f"share {share} of 8 of the 10 M-query job under the length-partitioned split: every query of lengths {min(quota)}-{max(quota)} it owns",
+                              "queries": len(qs2), "ms_per_batch": dt2 * 1e3, "ms_per_1M_queries": dt2 * 1e3 / (len(qs2) / 1e6), "pairs_per_s": st2["n_pairs"] / dt2,
+                              "scan_kernel_ms": st2["ms_scan_kernel"], "filter_score_kernel_ms": st2["ms_filter_score_kernel"], "scan_tiles": st2["n_scan_blocks"],
+                              "queries_per_tile": len(qs2) / max(st2["n_scan_blocks"], 1), "parity": chk2,
+                              "shares_of_1M_sample": shares,
+                              "roofline": _config_roofline(m, qs2, st2, dt2 * 1e3, "big", 32, 2, len(qs2))}}
 
     def configs4_share():  # search mode: one GPU's 12.5 MB of the 100 MB running text, n-gram windows + bigram LM
         import random
@@ -499,10 +527,10 @@ def extra_configs(args, paths, device, ncores):
                     lat_ms / 5.0, int(ra.shape[0]) * 16 + int(off[-1]) * (16 + 8)),
                 "parity": f"ok ({nchk} texts = {8 * nchk} sentences vs the oracle twin)"}
 
-    guarded("nld_len16_d2", nld_len16_d2)
-    guarded("configs2_nld_d3_confusables", configs2)
-    guarded("configs3_share", configs3_share)
-    guarded("configs4_share_search", configs4_share)
+    for name, fn in (("nld_len16_d2", nld_len16_d2), ("configs2_nld_d3_confusables", configs2), ("configs3_share", configs3_share),
+                     ("configs4_share_search", configs4_share)):
+        if not args.extras or name in args.extras.split(","):
+            guarded(name, fn)
     return out
 
 
@@ -632,6 +660,7 @@ def main():
     ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="N", help="N ranks, all on device 0 (dry run of the N-rank control flow)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the result gather")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config numbers measured after the timed region")
+    ap.add_argument("--extras", default="", help="comma-separated names of the extra configurations to run (default: all)")
     ap.add_argument("--preroll-s", type=float, default=2.5, help="seconds of untimed steady-state steps before the timed region (lets an external "
                     "GPU-utilisation sampler see the device busy; 0 with --timed-only)")
     ap.add_argument("--spot-check", type=int, default=256, help="queries of the timed batch (and of every extra configuration) checked against the oracle after the timed region")

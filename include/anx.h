@@ -149,8 +149,8 @@ int anx_model_to_device(anx_model *, int device);
 /* Multi-GPU, one host process (the reference's fan-out over inputs inside one process: rayon par_iter,
  * src/bin/analiticcl.rs:445-448, src/lib.rs:1883): replicate the built lexicon on the n listed HIP devices (normally every GPU of
  * the node once; an ordinal may be listed more than once = several replicas on one GPU).  Every batch call below then splits its
- * inputs into consecutive ranges, one per replica, each driven by the replica's own host thread on the replica's own stream, and
- * returns the rows concatenated in input order -- there is no collective on this path, the rows are consumed on the host.  Calls
+ * inputs over the replicas (by length, see anx_batch_shard_info), each part driven by the replica's own host thread on the replica's
+ * own stream, and returns the rows in input order -- there is no collective on this path, the rows are consumed on the host.  Calls
  * with fewer than ANX_SHARD_MIN (8192) inputs per replica use fewer replicas.  Replaces the model's previous replicas.
  * anx_model_to_device(m, d) == anx_model_to_devices(m, &d, 1). */
 int anx_model_to_devices(anx_model *, const int *devices, int n);
@@ -257,10 +257,16 @@ typedef struct anx_batch_stats {
  * was compiled: the library writes at most that many bytes, so a caller built against an older, shorter struct stays in bounds
  * (the struct only ever grows at its end). */
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *, size_t struct_size);
-/* the replicas a batch is spread over: shard i holds the inputs [first_input, first_input + n_inputs) on HIP device *device
- * (any out pointer may be NULL).  anx_batch_export_topk / _compact need a batch with exactly one shard. */
+/* The replicas a batch is spread over.  Default split of a multi-replica call (ANX_SHARD_POLICY=length): the inputs are ordered by
+ * byte length and cut into cost-balanced pieces, one per replica, so that a replica owns whole lengths -- and with them whole
+ * (length, signature) groups: full scan tiles on every device (BASELINE configs[3]); a shard then holds n_inputs scattered inputs,
+ * *first_input is its smallest index and anx_batch_shard_inputs returns all of them (ascending; valid until the batch is freed).
+ * ANX_SHARD_POLICY=range (and calls whose rows are rescored on the host): shard i holds the consecutive inputs [first_input,
+ * first_input + n_inputs) and anx_batch_shard_inputs returns NULL.  Either way every fetch returns rows in the call's input order.
+ * Any out pointer may be NULL.  anx_batch_export_topk / _compact need a batch with exactly one shard. */
 int anx_batch_num_shards(const anx_batch *);
 int anx_batch_shard_info(const anx_batch *, int shard, int *device, size_t *first_input, size_t *n_inputs);
+int anx_batch_shard_inputs(const anx_batch *, int shard, const uint32_t **indices);
 /* Waits for asynchronous exports of the batch (anx_batch_export_topk / _compact on the caller's stream), then releases it. */
 void anx_batch_free(anx_batch *);
 /* Device scratch (pair lists, survivor rows: several GB per million queries) comes from a per-device pool that keeps freed
@@ -285,6 +291,10 @@ int anx_debug_set_switch(const char *name, const char *value);
  * and returns their summed duration and count (ANX_EINVAL: none recorded).  k_scan_bits / k_filter_score are always timed: anx_batch_stats. */
 void anx_debug_kernel_timer(int enable);
 int anx_debug_kernel_time(const char *name, double *total_ms, uint64_t *launches);
+/* The length-partitioned split by itself (no device needed): which of n_shards replicas each of n inputs with the given byte lengths
+ * would go to (out_shard[i] in 0 .. n_shards - 1; see anx_batch_shard_info).  bench.py and the tests use it to build one GPU's share of
+ * a larger job (BASELINE configs[3]) on a one-GPU box. */
+int anx_debug_length_split(const anx_model *, const uint32_t *byte_lengths, size_t n, const anx_params *, int n_shards, uint8_t *out_shard);
 /* Test hook: the band-match bound the scan's fused filter and k_filter_score apply before damerau_levenshtein (src/distance.rs:101-179)
  * on n (query, candidate) pairs of <= 16 symbols: rows of 16 bytes (alphabet-indexed symbols, the query padded with 0xFE, the
  * candidate with 0xFF), lengths, d <= 3.  form: 0 the scan's (7-bit symbols, wave-uniform d), 1 k_filter_score's (7-bit symbols),

@@ -35,7 +35,12 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
   std::vector<size_t> ref_off, conf_off;
   std::vector<uint32_t> ref_counts;
   size_t ref_pairs = 0;
+  // both split policies of a multi-replica call: consecutive input ranges, and the length-partitioned split (the default: a replica
+  // holds scattered inputs, the rows come back in input order all the same) -- against the same reference rows
+  for (const char* policy : {"range", "length"})
   for (int nrep : {1, 2, 3, 4}) {
+    const bool by_length = strcmp(policy, "length") == 0;
+    CHECK(anx_debug_set_switch("ANX_SHARD_POLICY", policy) == ANX_OK);
     anx_model* m = anx_model_new(alphabet.c_str(), &w, 0);
     CHECK(m != nullptr);
     CHECK(anx_model_read_vocabulary(m, lexicon.c_str(), &vp) == ANX_OK);
@@ -58,7 +63,21 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
         CHECK(b != nullptr);
         CHECK(anx_batch_num_shards(b) == (nrep == 4 ? 2 : nrep));
         int dev = -1; size_t lo = 99, cnt = 0, total = 0;
-        for (int g = 0; g < anx_batch_num_shards(b); ++g) { CHECK(anx_batch_shard_info(b, g, &dev, &lo, &cnt) == ANX_OK && lo == total && dev == devs[g]); total += cnt; }
+        std::vector<char> seen(in.size(), 0);
+        for (int g = 0; g < anx_batch_num_shards(b); ++g) {
+          CHECK(anx_batch_shard_info(b, g, &dev, &lo, &cnt) == ANX_OK && dev == devs[g]);
+          const uint32_t* ix = nullptr;
+          CHECK(anx_batch_shard_inputs(b, g, &ix) == ANX_OK);
+          // the host-rescoring model (nrep == 3) and one-shard calls keep consecutive ranges under either policy
+          if (by_length && nrep != 3 && anx_batch_num_shards(b) > 1) {
+            CHECK(ix != nullptr && cnt > 0 && ix[0] == lo);
+            for (size_t i = 0; i < cnt; ++i) { CHECK(ix[i] < in.size() && !seen[ix[i]] && (i == 0 || ix[i] > ix[i - 1])); seen[ix[i]] = 1; }
+            // whole lengths stay together: apart from the lengths a cut runs through, a shard's lengths are a range of their own
+          } else {
+            CHECK(ix == nullptr && lo == total);
+          }
+          total += cnt;
+        }
         CHECK(total == in.size());
         CHECK(anx_batch_run_async(m, b, nullptr) == ANX_OK && anx_batch_wait(m, b) == ANX_OK);
         if (nrep > 1) CHECK(anx_batch_run(m, b, (void*)0x10) == ANX_EINVAL);  // a caller stream with several replicas
@@ -71,9 +90,23 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
         CHECK(anx_batch_fetch_pairs(b, &pairs, &npairs) == ANX_OK);
         if (ref_counts.empty()) { ref_counts.assign(counts, counts + in.size()); ref_pairs = npairs; }
         CHECK(memcmp(ref_counts.data(), counts, in.size() * sizeof(uint32_t)) == 0 && npairs == ref_pairs);
-        size_t w0 = 0;  // pairs come shard by shard, each shard's in input order, with call-wide query indices
-        for (size_t i = 0; i < in.size(); ++i)
-          for (size_t j = 0; j < in[i].size(); ++j, ++w0) CHECK(pairs[w0].query == i && pairs[w0].vocab_id == (uint32_t)(unsigned char)in[i][j]);
+        // pairs come shard by shard, each shard's in its own input order, with call-wide query indices
+        if (!by_length || nrep == 3) {
+          size_t w0 = 0;
+          for (size_t i = 0; i < in.size(); ++i)
+            for (size_t j = 0; j < in[i].size(); ++j, ++w0) CHECK(pairs[w0].query == i && pairs[w0].vocab_id == (uint32_t)(unsigned char)in[i][j]);
+        } else {
+          std::vector<uint32_t> at(in.size(), 0);
+          bool okp = true;
+          for (size_t k = 0; k < npairs && okp; ++k) {
+            const uint32_t q = pairs[k].query;
+            okp = q < in.size() && at[q] < in[q].size() && pairs[k].vocab_id == (uint32_t)(unsigned char)in[q][at[q]];
+            if (okp) ++at[q];
+          }
+          CHECK(okp);
+          for (size_t i = 0; i < in.size() && okp; ++i) okp = at[i] == in[i].size();
+          CHECK(okp);
+        }
         anx_counts_free(counts);
         anx_pairs_free(pairs);
         if (nrep != 3) {  // compact records over the shards == the anx_result rows
@@ -177,6 +210,7 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
     }
     anx_model_free(m);
   }
+  CHECK(anx_debug_set_switch("ANX_SHARD_POLICY", nullptr) == ANX_OK);
   printf("OK %d\n", checks);
   return 0;
 }

@@ -63,6 +63,44 @@ def test_shards_equal_whole(setup):
     check_shards_equal_whole(g, qs, p, arrays, ((0, 30_000), (600_000, 640_000), (NQ - 25_000, NQ)))
 
 
+def test_length_partitioned_share_has_fuller_tiles(setup, data_dir):
+    """What a multi-device model gives ONE of 8 GPUs of the 10 M-query job (anx_model_to_devices: inputs ordered by length, cut into
+    cost-balanced pieces): every query of the lengths the share owns.  Built here from the library's own split of a sample of the
+    job (anx_debug_length_split) and the job's generator conditioned on length; its scan tiles hold more than twice the queries of
+    the random eighth above (consecutive input ranges: an eighth of every (length, signature) group), rows checked against the oracle."""
+    g, path, qs, p, _b, _arrays, st = setup
+    lex = synth.load_lexicon_words(path)
+    sample = synth.make_queries(lex, 400_000, max_len=32, min_len=4, seed=6)
+    gid = g.length_split([len(q.encode("utf-8")) for q in sample], p, 8)
+    counts = np.bincount(gid, minlength=8)
+    assert counts.min() > 0 and counts.max() < 3 * counts.min()        # cost-balanced: short queries are cheap, so their share is larger
+    lens = np.array([len(q) for q in sample])
+    for a, b2 in zip(range(7), range(1, 8)):                            # ascending lengths, neighbours share at most the boundary length
+        assert lens[gid == a].max() <= lens[gid == b2].min()
+    quota = {}
+    for q, s in zip(sample, gid):
+        if s == 4:
+            quota[len(q)] = quota.get(len(q), 0) + 8                    # 3.2 M-query job: a 400 k share
+    qs2 = synth.make_queries_with_quota(lex, quota, max_len=32, min_len=4, seed=7)
+    b = g.encode_batch(qs2, p)
+    b.run()
+    st2 = b.stats()
+    off, vid, dist, freq = b.fetch_arrays()
+    b.free()
+    fill_random = st["n_queries"] / st["n_scan_blocks"]
+    fill_share = st2["n_queries"] / st2["n_scan_blocks"]
+    assert fill_share > 1.5 * fill_random * (len(qs2) / NQ) ** 0.5, (fill_random, fill_share)
+    o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+    o.read_lexicon(path)
+    o.build()
+    op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0)
+    idx = [int(i) for i in np.random.default_rng(4).choice(len(qs2), 200, replace=False)]
+    _rc, res, cnts, _tp, _tc = o.find_variants_batch([qs2[i] for i in idx], op, nthreads=16, stride=16)
+    for n, i in enumerate(idx):
+        exp = [(res[n * 16 + j].vocab_id, res[n * 16 + j].dist_score, res[n * 16 + j].freq_score) for j in range(cnts[n])]
+        assert [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])] == exp, qs2[i]
+
+
 def test_oracle_spot_check(setup, data_dir):
     g, path, qs, _p, _b, (off, vid, dist, freq), _st = setup
     o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))

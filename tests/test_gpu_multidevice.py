@@ -23,6 +23,28 @@ def _small_shards():
     A.set_switch("ANX_SHARD_MIN", 64)   # the default (8192 inputs per replica) would keep the small cases on one replica
     yield
     A.set_switch("ANX_SHARD_MIN", None)
+    A.set_switch("ANX_SHARD_POLICY", None)
+
+
+def _check_shards(b_shards, b_inputs, qs, devices, policy):
+    """range: consecutive input ranges in input order.  length (the default): every replica holds whole byte lengths -- only a length
+    a cut runs through is shared by two neighbouring replicas -- and the shards partition the inputs."""
+    n = len(qs)
+    assert [s[0] for s in b_shards] == devices[:len(b_shards)] and sum(s[2] for s in b_shards) == n
+    if policy == "range":
+        assert all(ix is None for ix in b_inputs)
+        assert all(b_shards[i][1] + b_shards[i][2] == b_shards[i + 1][1] for i in range(len(b_shards) - 1))
+        return
+    lens = np.array([len(q.encode("utf-8")) for q in qs])
+    seen = np.zeros(n, dtype=bool)
+    ranges = []
+    for (dev, lo, cnt), ix in zip(b_shards, b_inputs):
+        assert ix is not None and ix.size == cnt and ix[0] == lo and np.all(np.diff(ix.astype(np.int64)) > 0) and not seen[ix].any()
+        seen[ix] = True
+        ranges.append((int(np.minimum(lens[ix], 255).min()), int(np.minimum(lens[ix], 255).max())))
+    assert seen.all()
+    for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+        assert a1 <= b0 and a0 <= b0 and a1 <= b1, ranges   # ascending length ranges that overlap in at most the boundary length
 
 
 def _model(data_dir, lex, devices, confusables=False, variants=None):
@@ -44,7 +66,7 @@ def _run(g, qs, p, packed=False, counts=True, compact=False):
         b = g.encode_batch(qs, p)
     b.run_async()
     b.wait()
-    out = dict(arrays=b.fetch_arrays(), stats=b.stats(), shards=b.shards())
+    out = dict(arrays=b.fetch_arrays(), stats=b.stats(), shards=b.shards(), inputs=[b.shard_inputs(g_) for g_ in range(len(b.shards()))])
     if compact:   # the 16-byte records over the shards == the anx_result rows
         off, vid, dist, freq = out["arrays"]
         coff, crows = b.fetch_compact()
@@ -86,11 +108,13 @@ def test_two_and_three_replicas_equal_one(data_dir, lex, n, max_len, kw, conf):
     for devices in ([0, 0], [0, 0, 0]):
         g = _model(data_dir, lex, devices, conf)
         assert g.num_replicas == len(devices)
-        for packed in (False, True):
-            got = _run(g, qs, p, packed=packed, compact=not conf)
-            assert [s[0] for s in got["shards"]] == devices and sum(s[2] for s in got["shards"]) == n
-            assert all(got["shards"][i][1] + got["shards"][i][2] == got["shards"][i + 1][1] for i in range(len(devices) - 1))
-            _same(one, got)
+        for policy in ("length", "range"):
+            A.set_switch("ANX_SHARD_POLICY", policy)
+            for packed in (False, True):
+                got = _run(g, qs, p, packed=packed, compact=not conf)
+                _check_shards(got["shards"], got["inputs"], qs, devices, policy)
+                _same(one, got)
+        A.set_switch("ANX_SHARD_POLICY", None)
         # the one-shot call (anx_find_variants_batch) over the replicas
         ids = g.find_variants_ids(qs[:30_000], p)
         off, vid, dist, freq = one["arrays"]
@@ -107,16 +131,19 @@ def test_uneven_byte_split_and_tail(data_dir):
     p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
     one = _run(_model(data_dir, "eng", [0]), qs, p)
     g = _model(data_dir, "eng", [0, 0])
-    got = _run(g, qs, p, packed=True)
-    assert got["shards"][0][2] != got["shards"][1][2]
-    _same(one, got)
     blob = b"".join(q.encode("utf-8") + b"\0" for q in qs)
-    b = g.encode_packed(blob, 50_001, p)   # the announced n cuts inside the second shard
-    b.run()
-    off, vid, _d, _f = b.fetch_arrays()
-    assert sum(s[2] for s in b.shards()) == 50_001
-    b.free()
-    assert np.array_equal(off, one["arrays"][0][:50_002]) and np.array_equal(vid, one["arrays"][1][:off[-1]])
+    for policy in ("range", "length"):
+        A.set_switch("ANX_SHARD_POLICY", policy)
+        got = _run(g, qs, p, packed=True)
+        assert got["shards"][0][2] != got["shards"][1][2]
+        _same(one, got)
+        b = g.encode_packed(blob, 50_001, p)   # the announced n cuts inside the second shard (range) / drops the tail (length)
+        b.run()
+        off, vid, _d, _f = b.fetch_arrays()
+        assert sum(s[2] for s in b.shards()) == 50_001
+        b.free()
+        assert np.array_equal(off, one["arrays"][0][:50_002]) and np.array_equal(vid, one["arrays"][1][:off[-1]])
+    A.set_switch("ANX_SHARD_POLICY", None)
     with pytest.raises(A.AnxError, match="fewer strings than announced"):
         g.encode_packed(blob, len(qs) + 1, p)
     with pytest.raises(A.AnxError, match="own stream"):
