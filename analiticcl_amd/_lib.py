@@ -182,7 +182,7 @@ def lib():
         "anx_shutdown": (None, []),
         "anx_debug_kernel_timer": (None, [C.c_int]),
         "anx_debug_kernel_time": (C.c_int, [cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
-        "anx_debug_length_split": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(Params), C.c_int, vp]),
+        "anx_debug_length_split": (C.c_int, [vp, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(Params), C.c_int, vp, vp]),
         "anx_debug_band_bound": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
         "anx_batch_free": (None, [vp]),
         "anx_device_pool_trim": (None, [C.c_int]),

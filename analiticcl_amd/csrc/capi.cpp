@@ -1,4 +1,5 @@
 // capi.cpp -- the extern "C" boundary declared in include/anx.h.
+#include <cmath>
 #include <cstdlib>
 #include <charconv>
 #include <cstring>
@@ -64,14 +65,28 @@ struct Shard {  // the part of a batch one replica holds: inputs [lo, lo + n) of
   anx::Batch* b = nullptr;
   size_t lo = 0, n = 0;
   std::vector<uint32_t> idx;  // ascending original indices of the shard's inputs; empty = the consecutive range
+  std::vector<uint32_t> lhist;  // length-partitioned split: inputs per byte-length class, and what the split predicted they cost
+  double predicted = 0.0;
   size_t input(size_t i) const { return idx.empty() ? lo + i : idx[i]; }
 };
 }  // namespace
 
+// What one input of a byte length costs the device, relative to the other lengths: the weights of the length-partitioned split.
+// prior x learned correction: after every run of a length-partitioned batch the correction of the lengths a shard held moves
+// towards (its measured device time / its predicted cost), so the shares of the following calls even out whatever the lexicon,
+// the alphabet and the parameters are (LengthCost::learn; the corrections start over when the distance parameters change).
+struct LengthCost {
+  static constexpr uint32_t LMAX = 256;  // byte lengths >= 255 share the last class
+  std::mutex mu;
+  double scale[LMAX];
+  anx_threshold k_of, d_of;
+  bool init = false;
+};
 struct anx_model {
   anx::HostModel host;
   anx::DeviceLexicon* dev = nullptr;   // == replicas[0].dev
   std::vector<Replica> replicas;
+  mutable LengthCost len_cost;
 };
 struct anx_batch {
   const anx_model* model = nullptr;
@@ -735,48 +750,95 @@ bool packed_offsets_mt(const char* blob, size_t len, size_t n, std::vector<uint3
 // EVERY group -- 4.9 queries per tile at 1.25 M queries per GPU against the 1 M-entry lexicon, where the whole job on one device
 // has 13 -- and a third of each GPU's time goes into per-tile overheads the split itself creates.  The reference fans out over
 // independent inputs in arbitrary order (src/bin/analiticcl.rs:416-448), so any partition is legal: here the inputs are ordered
-// by byte length (= symbol count for ASCII; other strings only land in a less fitting share) and cut into S cost-balanced
-// consecutive pieces of that order, so that a replica owns whole lengths and with them whole (length, signature) groups; only the
-// lengths a cut runs through are split (by input order).  Cost of an input = a constant + the lexicon's classes within its
-// anagram-distance window (what its scan walks through).  Results go back to input order when they are fetched (Shard::idx).
-void split_by_length(const anx_model* m, const uint32_t* lens, size_t n, const anx_params& p, std::vector<Shard>& shards) {
+// by CLASS = (byte length, how many of the bytes belong to signature groups 0 and 1) -- a function of (length, signature) for
+// strings of one-byte alphabet members, so every (length, signature) group lies inside one class; other strings only land in a
+// less fitting share -- and cut into S cost-balanced consecutive pieces of that order: a replica owns whole classes, only a class a
+// cut runs through is split (by input order).  A few hundred classes instead of ~30 lengths: the heavy lengths (one length can be
+// more than a share) are cut between signature ranges, not through their groups.  Cost of an input = LengthCost of its length.
+// Results go back to input order when they are fetched (Shard::idx).
+constexpr uint32_t SPLIT_SUBLEN = 64;                      // lengths below this are subdivided by the two group counts (5 bits each)
+constexpr uint32_t SPLIT_NCLS = SPLIT_SUBLEN * 1024 + 256;  // ... the others are one class per length (255 = that and longer)
+inline uint32_t split_class(uint32_t len, uint32_t g0, uint32_t g1) {
+  return len < SPLIT_SUBLEN ? len * 1024u + std::min(g0, 31u) * 32u + std::min(g1, 31u) : SPLIT_SUBLEN * 1024u + std::min(len, 255u);
+}
+inline uint32_t split_class_len(uint32_t cls) { return cls < SPLIT_SUBLEN * 1024u ? cls >> 10 : cls - SPLIT_SUBLEN * 1024u; }
+// byte -> signature group of the alphabet class whose one-byte member it is (0xFF: none)
+void split_byte_groups(const anx_model* m, uint8_t (&tab)[256]) {
+  memset(tab, 0xFF, sizeof tab);
+  const anx::Alphabet& a = m->host.alphabet;
+  const std::vector<uint8_t>& sg = m->host.lex.sym_group;
+  for (size_t c = 0; c < a.classes.size() && c < sg.size(); ++c)
+    for (const anx::AlphabetMember& mem : a.classes[c])
+      if (mem.bytes.size() == 1 && tab[(uint8_t)mem.bytes[0]] == 0xFF) tab[(uint8_t)mem.bytes[0]] = sg[c];
+}
+// the class of every input; get(i) = (pointer, byte length)
+void split_classes(const anx_model* m, size_t n, const std::function<void(size_t, const char**, size_t*)>& get, std::vector<uint32_t>& cls) {
+  uint8_t tab[256];
+  split_byte_groups(m, tab);
+  cls.resize(n);
+  parallel_ranges(n, [&](size_t lo, size_t hi, unsigned) {
+    for (size_t i = lo; i < hi; ++i) {
+      const char* s;
+      size_t len;
+      get(i, &s, &len);
+      uint32_t g0 = 0, g1 = 0;
+      if (len < SPLIT_SUBLEN)
+        for (size_t j = 0; j < len; ++j) { const uint8_t g = tab[(uint8_t)s[j]]; g0 += g == 0; g1 += g == 1; }
+      cls[i] = split_class((uint32_t)std::min<size_t>(len, 0xFFFFu), g0, g1);
+    }
+  });
+}
+void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const anx_params& p, std::vector<Shard>& shards) {
   const size_t S = shards.size();
-  constexpr uint32_t LMAX = 256;  // byte lengths >= 255 share the last class
+  constexpr uint32_t LMAX = LengthCost::LMAX;
   unsigned T = 1;
   std::vector<std::vector<uint32_t>> hist;
   parallel_ranges(n, [&](size_t, size_t, unsigned) {}, &T);
-  hist.assign(T, std::vector<uint32_t>(LMAX, 0));
+  hist.assign(T, std::vector<uint32_t>(SPLIT_NCLS, 0));
   parallel_ranges(n, [&](size_t lo, size_t hi, unsigned t) {
     std::vector<uint32_t>& h = hist[t];
-    for (size_t i = lo; i < hi; ++i) ++h[std::min<uint32_t>(lens[i], LMAX - 1)];
+    for (size_t i = lo; i < hi; ++i) ++h[cls[i]];
   });
-  // cost per input of every length, cumulative cost at the first input of every length
+  // cost per input of every length.  Prior: a constant + the lexicon's classes within the anagram-distance window (what the scan
+  // walks through), times a factor that grows with k / length -- a short string has far more lexicon entries within its distance
+  // bounds than a long one (measured on the 1 M-entry lexicon of configs[3]: 31 ns per query of 4 symbols, 15 at 8, 6 at 12-16).
+  // The learned correction (LengthCost) takes it from there.
   const anx::LexiconImage& lex = m->host.lex;
-  double w[LMAX], base[LMAX + 1];
-  base[0] = 0.0;
-  for (uint32_t L = 0; L < LMAX; ++L) {
-    const int k = anx::clamp_threshold(p.max_anagram_distance, (int)L, anx::kMaxAnagramDistance);
-    double window = 0.0;
-    for (int c = std::max(1, (int)L - k); c <= std::min(anx::kMaxSymbols, (int)L + k); ++c) window += (double)(lex.bucket_begin[c + 1] - lex.bucket_begin[c]);
-    w[L] = 1024.0 + window / 16.0;
-    uint64_t cnt = 0;
-    for (unsigned t = 0; t < T; ++t) cnt += hist[t][L];
-    base[L + 1] = base[L] + w[L] * (double)cnt;
+  double w[LMAX];
+  {
+    LengthCost& lc = m->len_cost;
+    std::lock_guard<std::mutex> lk(lc.mu);
+    auto same = [](const anx_threshold& a, const anx_threshold& b) { return a.kind == b.kind && a.value == b.value && a.ratio == b.ratio; };
+    if (!lc.init || !same(lc.k_of, p.max_anagram_distance) || !same(lc.d_of, p.max_edit_distance)) {
+      for (double& x : lc.scale) x = 1.0;
+      lc.k_of = p.max_anagram_distance;
+      lc.d_of = p.max_edit_distance;
+      lc.init = true;
+    }
+    for (uint32_t L = 0; L < LMAX; ++L) {
+      const int k = anx::clamp_threshold(p.max_anagram_distance, (int)L, anx::kMaxAnagramDistance);
+      double window = 0.0;
+      for (int c = std::max(1, (int)L - k); c <= std::min(anx::kMaxSymbols, (int)L + k); ++c) window += (double)(lex.bucket_begin[c + 1] - lex.bucket_begin[c]);
+      const double rel = L ? (double)k / (double)L : 0.0;
+      w[L] = (1024.0 + window / 16.0) * (1.0 + 30.0 * rel * rel * rel) * lc.scale[L];
+    }
   }
-  const double total = base[LMAX] > 0.0 ? base[LMAX] : 1.0;
-  // rank of every thread's first input inside its length class
-  std::vector<std::vector<uint32_t>> start(T, std::vector<uint32_t>(LMAX, 0));
-  for (uint32_t L = 0; L < LMAX; ++L) {
+  // cumulative cost at the first input of every class; rank of every thread's first input inside its class
+  std::vector<double> base(SPLIT_NCLS + 1, 0.0);
+  std::vector<std::vector<uint32_t>>& start = hist;  // turned into the running ranks in place
+  for (uint32_t c = 0; c < SPLIT_NCLS; ++c) {
     uint32_t run = 0;
-    for (unsigned t = 0; t < T; ++t) { start[t][L] = run; run += hist[t][L]; }
+    for (unsigned t = 0; t < T; ++t) { const uint32_t h = hist[t][c]; start[t][c] = run; run += h; }
+    base[c + 1] = base[c] + w[split_class_len(c)] * (double)run;
   }
+  const double total = base[SPLIT_NCLS] > 0.0 ? base[SPLIT_NCLS] : 1.0;
   std::vector<uint8_t> gid(n);
   std::vector<std::vector<uint32_t>> per(T, std::vector<uint32_t>(S, 0));
   parallel_ranges(n, [&](size_t lo, size_t hi, unsigned t) {
     std::vector<uint32_t>& st = start[t];
     for (size_t i = lo; i < hi; ++i) {
-      const uint32_t L = std::min<uint32_t>(lens[i], LMAX - 1);
-      const double cum = base[L] + w[L] * (double)st[L]++;
+      const uint32_t c = cls[i];
+      const double cum = base[c] + w[split_class_len(c)] * (double)st[c]++;
       const size_t g = std::min(S - 1, (size_t)(cum * (double)S / total));
       gid[i] = (uint8_t)g;
       ++per[t][g];
@@ -794,7 +856,44 @@ void split_by_length(const anx_model* m, const uint32_t* lens, size_t n, const a
     std::vector<size_t>& a = at[t];
     for (size_t i = lo; i < hi; ++i) shards[gid[i]].idx[a[gid[i]]++] = (uint32_t)i;  // a thread's inputs are consecutive: ascending per shard
   });
+  for (Shard& sh : shards) {
+    sh.lhist.assign(LMAX, 0u);
+    for (uint32_t i : sh.idx) ++sh.lhist[std::min<uint32_t>(split_class_len(cls[i]), LMAX - 1)];
+    sh.predicted = 0.0;
+    for (uint32_t L = 0; L < LMAX; ++L) sh.predicted += w[L] * (double)sh.lhist[L];
+  }
   shards.erase(std::remove_if(shards.begin(), shards.end(), [](const Shard& s) { return s.n == 0; }), shards.end());
+}
+// after a run: the shards' device times against what the split predicted -> the per-length corrections of the next split
+void learn_length_costs(const anx_model* m, const std::vector<Shard>& shards, const std::vector<double>& t) {
+  const size_t S = shards.size();
+  if (S < 2) return;
+  double tsum = 0.0, psum = 0.0;
+  for (size_t g = 0; g < S; ++g) {
+    if (shards[g].lhist.empty() || shards[g].predicted <= 0.0 || !(t[g] > 0.02)) return;  // not a length split / too short to say anything
+    tsum += t[g];
+    psum += shards[g].predicted;
+  }
+  LengthCost& lc = m->len_cost;
+  std::lock_guard<std::mutex> lk(lc.mu);
+  for (uint32_t L = 0; L < LengthCost::LMAX; ++L) {
+    double num = 0.0, den = 0.0;
+    for (size_t g = 0; g < S; ++g) {
+      const double c = (double)shards[g].lhist[L];
+      num += c * (t[g] / shards[g].predicted) / (tsum / psum);
+      den += c;
+    }
+    if (den > 0.0) lc.scale[L] = std::min(64.0, std::max(1.0 / 64.0, lc.scale[L] * (num / den)));
+  }
+}
+void learn_from_batch(const anx_batch* b) {
+  std::vector<double> t(b->shards.size(), 0.0);
+  for (size_t g = 0; g < b->shards.size(); ++g) {
+    anx_batch_stats st;
+    anx::batch_stats(b->shards[g].b, &st);
+    t[g] = (double)st.ms_total;
+  }
+  learn_length_costs(b->model, b->shards, t);
 }
 bool use_length_split(const anx_model* m, size_t S, bool rescore) {
   return S > 1 && S <= 255 && !rescore && anx::switches().shard_by_length && m->host.built;
@@ -820,14 +919,18 @@ static int check_resident(const anx_model* m) {  // there is no CPU fallback
   if (m->replicas.empty()) return fail(ANX_ENODEVICE, "model is not resident on a device (no HIP device / anx_model_to_device not called)");
   return ANX_OK;
 }
-int anx_debug_length_split(const anx_model* m, const uint32_t* byte_lengths, size_t n, const anx_params* p, int n_shards, uint8_t* out_shard) {
-  if (!m || (!byte_lengths && n) || !p || (!out_shard && n) || n_shards < 1 || n_shards > 255) return fail(ANX_EINVAL, "bad argument");
+int anx_debug_length_split(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p, int n_shards, uint8_t* out_shard,
+                           const double* learn_ms) {
+  if (!m || (!utf8 && n) || !p || (!out_shard && n) || n_shards < 1 || n_shards > 255) return fail(ANX_EINVAL, "bad argument");
   if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet!");
   std::vector<Shard> shards((size_t)n_shards);
   for (int g = 0; g < n_shards; ++g) shards[(size_t)g].replica = g;
-  split_by_length(m, byte_lengths, n, *p, shards);
+  std::vector<uint32_t> cls;
+  split_classes(m, n, [&](size_t i, const char** sp, size_t* len) { *sp = utf8[i] ? utf8[i] : ""; *len = strlen(*sp); }, cls);
+  split_by_length(m, cls.data(), n, *p, shards);
   for (const Shard& s : shards)
     for (uint32_t i : s.idx) out_shard[i] = (uint8_t)s.replica;
+  if (learn_ms && shards.size() == (size_t)n_shards) learn_length_costs(m, shards, std::vector<double>(learn_ms, learn_ms + n_shards));
   return ANX_OK;
 }
 anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t n, const anx_params* p) {
@@ -846,11 +949,9 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
   h->shards.resize(S);
   for (size_t g = 0; g < S; ++g) { h->shards[g].replica = (int)g; h->shards[g].lo = n * g / S; h->shards[g].n = n * (g + 1) / S - n * g / S; }
   if (use_length_split(m, S, rescore)) {
-    std::vector<uint32_t> lens(n);
-    parallel_ranges(n, [&](size_t lo, size_t hi, unsigned) {
-      for (size_t i = lo; i < hi; ++i) lens[i] = utf8[i] ? (uint32_t)std::min<size_t>(strlen(utf8[i]), 0xFFFFu) : 0u;
-    });
-    split_by_length(m, lens.data(), n, *p, h->shards);
+    std::vector<uint32_t> cls;
+    split_classes(m, n, [&](size_t i, const char** sp, size_t* len) { *sp = utf8[i] ? utf8[i] : ""; *len = strlen(*sp); }, cls);
+    split_by_length(m, cls.data(), n, *p, h->shards);
   }
   const int rc = on_shards(h, [&](size_t g, std::string& err) {
     Shard& s = h->shards[g];
@@ -905,11 +1006,9 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
     // the byte-balanced split below does not need -- and buys full scan tiles on every device.
     std::vector<uint32_t> poff;
     if (!packed_offsets_mt(blob, blob_len, n, poff)) { fail(ANX_EINVAL, "packed inputs hold fewer strings than announced"); delete h; return nullptr; }
-    std::vector<uint32_t> lens(n);
-    parallel_ranges(n, [&](size_t lo, size_t hi, unsigned) {
-      for (size_t i = lo; i < hi; ++i) lens[i] = poff[i + 1] - poff[i] - 1u;
-    });
-    split_by_length(m, lens.data(), n, *p, h->shards);
+    std::vector<uint32_t> cls;
+    split_classes(m, n, [&](size_t i, const char** sp, size_t* len) { *sp = blob + poff[i]; *len = poff[i + 1] - poff[i] - 1u; }, cls);
+    split_by_length(m, cls.data(), n, *p, h->shards);
     const int rcl = on_shards(h, [&](size_t g, std::string& err) {
       Shard& s = h->shards[g];
       int code = ANX_OK;
@@ -1022,6 +1121,7 @@ int anx_batch_wait(const anx_model* m, anx_batch* b) {
     const Shard& s = b->shards[g];
     return anx::batch_wait(m->host, m->replicas[(size_t)s.replica].dev, s.b, err);
   });
+  if (!rc) learn_from_batch(b);
   return rc ? rc : conf_fallback_to_host(m, b, nullptr);
 }
 int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
@@ -1030,6 +1130,7 @@ int anx_batch_run(const anx_model* m, anx_batch* b, void* stream) {
     const Shard& s = b->shards[g];
     return anx::batch_run(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
   });
+  if (!rc) learn_from_batch(b);
   return rc ? rc : conf_fallback_to_host(m, b, stream);
 }
 }  // extern "C"

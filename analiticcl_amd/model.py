@@ -472,13 +472,16 @@ class VariantModel:
             L.check(n)
         return int(buf.value)
 
-    def length_split(self, byte_lengths, params: "SearchParameters", n_shards: int):
-        """Which of n_shards replicas each input of the given byte length would go to under the length-partitioned split of a
-        multi-device model (anx_debug_length_split; needs no device): a numpy uint8 array."""
+    def length_split(self, inputs: Sequence[str], params: "SearchParameters", n_shards: int, learn_ms=None):
+        """Which of n_shards replicas each input would go to under the length-partitioned split of a multi-device model
+        (anx_debug_length_split; needs no device): a numpy uint8 array.  learn_ms: measured device times of those shares, fed to
+        the split's cost corrections (the next call then returns the corrected split)."""
         import numpy as np
-        lens = np.ascontiguousarray(byte_lengths, dtype=np.uint32)
-        out = np.zeros(lens.size, dtype=np.uint8)
-        L.check(L.lib().anx_debug_length_split(self.h, lens.ctypes.data, lens.size, C.byref(params._c()), n_shards, out.ctypes.data))
+        arr = (C.c_char_p * len(inputs))(*[_b(t) for t in inputs])
+        out = np.zeros(len(inputs), dtype=np.uint8)
+        ms = np.ascontiguousarray(learn_ms, dtype=np.float64) if learn_ms is not None else None
+        L.check(L.lib().anx_debug_length_split(self.h, arr, len(inputs), C.byref(params._c()), n_shards, out.ctypes.data,
+                                               ms.ctypes.data if ms is not None else None))
         return out
 
     # -- the hot path ---------------------------------------------------------------------------------

@@ -425,8 +425,19 @@ def extra_configs(args, paths, device, ncores):
         # job's generator conditioned on their length (synth.make_queries_with_quota).
         import numpy as np
         sample = synth.make_queries(lex, 1_000_000, max_len=32, min_len=4, seed=6)
-        gid = m.length_split([len(q.encode("utf-8")) for q in sample], p, 8)
-        share = 4
+        # the split learns what a query of every length costs from the device times of its shards (capi.cpp LengthCost): three
+        # rounds on the sample's own 8 shares, run one after the other on this GPU, stand in for the first calls of an 8-GPU job
+        share_ms = []
+        for _round in range(4):
+            gid = m.length_split(sample, p, 8)
+            share_ms = []
+            for g_ in range(8):
+                bs = m.encode_batch([q for q, s_ in zip(sample, gid) if s_ == g_], p)
+                share_ms.append(_time_runs(bs, reps=2) * 1e3)
+                bs.free()
+            if _round < 3:
+                m.length_split(sample, p, 8, learn_ms=share_ms)
+        share = int(np.argmax(share_ms))   # the share that takes longest decides the job's time
         quota = {}
         for q, g_ in zip(sample, gid):
             if g_ == share:
@@ -446,7 +457,10 @@ def extra_configs(args, paths, device, ncores):
                 "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000),
                 "what": "ms_per_1M_queries = a RANDOM eighth of the job (what consecutive input ranges give a GPU: an eighth of every (length, signature) group); "
                         "by_length = one share of the length-partitioned split the library uses for multi-device models",
-                "by_length": {"workload": f"share {share} of 8 of the 10 M-query job under the length-partitioned split: every query of lengths {min(quota)}-{max(quota)} it owns",
+                "by_length": {"workload": f"the longest of the 8 shares of the 10 M-query job under the length-partitioned split (share {share}: the queries of lengths {min(quota)}-{max(quota)} it owns), "
+                                          "after three learning rounds of the split's cost model on a 1 M-query sample of the job",
+                              "sample_share_ms": share_ms, "sample_balance": sum(share_ms) / 8 / max(share_ms),
+                              "job_speedup_vs_consecutive_ranges": dt / dt2,
                               "queries": len(qs2), "ms_per_batch": dt2 * 1e3, "ms_per_1M_queries": dt2 * 1e3 / (len(qs2) / 1e6), "pairs_per_s": st2["n_pairs"] / dt2,
                               "scan_kernel_ms": st2["ms_scan_kernel"], "filter_score_kernel_ms": st2["ms_filter_score_kernel"], "scan_tiles": st2["n_scan_blocks"],
                               "queries_per_tile": len(qs2) / max(st2["n_scan_blocks"], 1), "parity": chk2,

@@ -258,7 +258,7 @@ typedef struct anx_batch_stats {
  * (the struct only ever grows at its end). */
 int anx_batch_get_stats(const anx_batch *, anx_batch_stats *, size_t struct_size);
 /* The replicas a batch is spread over.  Default split of a multi-replica call (ANX_SHARD_POLICY=length): the inputs are ordered by
- * byte length and cut into cost-balanced pieces, one per replica, so that a replica owns whole lengths -- and with them whole
+ * (byte length, a cheap function of the signature) and cut into cost-balanced pieces, one per replica, so that a replica owns whole
  * (length, signature) groups: full scan tiles on every device (BASELINE configs[3]); a shard then holds n_inputs scattered inputs,
  * *first_input is its smallest index and anx_batch_shard_inputs returns all of them (ascending; valid until the batch is freed).
  * ANX_SHARD_POLICY=range (and calls whose rows are rescored on the host): shard i holds the consecutive inputs [first_input,
@@ -291,10 +291,13 @@ int anx_debug_set_switch(const char *name, const char *value);
  * and returns their summed duration and count (ANX_EINVAL: none recorded).  k_scan_bits / k_filter_score are always timed: anx_batch_stats. */
 void anx_debug_kernel_timer(int enable);
 int anx_debug_kernel_time(const char *name, double *total_ms, uint64_t *launches);
-/* The length-partitioned split by itself (no device needed): which of n_shards replicas each of n inputs with the given byte lengths
+/* The length-partitioned split by itself (no device needed): which of n_shards replicas each of the n inputs
  * would go to (out_shard[i] in 0 .. n_shards - 1; see anx_batch_shard_info).  bench.py and the tests use it to build one GPU's share of
- * a larger job (BASELINE configs[3]) on a one-GPU box. */
-int anx_debug_length_split(const anx_model *, const uint32_t *byte_lengths, size_t n, const anx_params *, int n_shards, uint8_t *out_shard);
+ * a larger job (BASELINE configs[3]) on a one-GPU box.  learn_ms (may be NULL): the device times of THOSE shares, measured by the caller
+ * one after the other -- fed to the split's per-length cost corrections exactly as a multi-replica run feeds its own shard times, so
+ * that the next split is the one a real N-GPU job would see after this call. */
+int anx_debug_length_split(const anx_model *, const char *const *utf8, size_t n, const anx_params *, int n_shards, uint8_t *out_shard,
+                           const double *learn_ms);
 /* Test hook: the band-match bound the scan's fused filter and k_filter_score apply before damerau_levenshtein (src/distance.rs:101-179)
  * on n (query, candidate) pairs of <= 16 symbols: rows of 16 bytes (alphabet-indexed symbols, the query padded with 0xFE, the
  * candidate with 0xFF), lengths, d <= 3.  form: 0 the scan's (7-bit symbols, wave-uniform d), 1 k_filter_score's (7-bit symbols),
