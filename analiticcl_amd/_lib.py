@@ -180,6 +180,11 @@ def lib():
         "anx_batch_export_compact": (C.c_int, [vp, vp, sz, vp, C.POINTER(sz)]),
         "anx_batch_get_stats": (C.c_int, [vp, C.POINTER(BatchStats), C.c_size_t]),
         "anx_shutdown": (None, []),
+        "anx_pipeline_new": (vp, [vp, C.c_int]),
+        "anx_pipeline_submit_packed": (C.c_int, [vp, cp, C.c_size_t, C.c_size_t, C.POINTER(Params)]),
+        "anx_pipeline_pending": (C.c_int, [vp]),
+        "anx_pipeline_next": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]),
+        "anx_pipeline_free": (None, [vp]),
         "anx_debug_kernel_timer": (None, [C.c_int]),
         "anx_debug_kernel_time": (C.c_int, [cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "anx_debug_length_split": (C.c_int, [vp, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(Params), C.c_int, vp, vp]),

@@ -1,4 +1,5 @@
 // capi.cpp -- the extern "C" boundary declared in include/anx.h.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <charconv>
@@ -1412,6 +1413,149 @@ int anx_find_variants_batch(const anx_model* m, const char* const* utf8, size_t 
   *out_offsets = offs;
   return ANX_OK;
 }
+// ---- pipeline: encode(i + 2) / run(i + 1) / fetch(i) in flight for ONE caller thread -------------------------------------------------
+// Three library threads, one per stage, and two alternating run streams (single-replica models): while batch i is downloaded
+// (copy engine), batch i + 1 runs and batch i + 2 is uploaded and encoded.  The stages are the public entry points
+// (anx_batch_encode_packed -> anx_batch_run -> anx_batch_fetch_compact); results come back in submission order.
+struct PipeJob {
+  const char* blob = nullptr;
+  size_t blob_len = 0, n = 0;
+  anx_params p;
+  anx_batch* b = nullptr;
+  int rc = ANX_OK;
+  std::string err;
+  anx_topk_record* rows = nullptr;
+  uint32_t* offs = nullptr;
+  int stage = 0;  // 0 submitted, 1 encoded, 2 run, 3 fetched (done)
+  uint64_t seq = 0;
+};
+struct anx_pipeline {
+  const anx_model* m = nullptr;
+  size_t depth = 4;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<PipeJob>> jobs;  // in submission order; the front is what anx_pipeline_next returns
+  bool stop = false;
+  uint64_t next_seq = 0;
+  void* streams[2] = {nullptr, nullptr};
+  std::thread th[3];
+};
+static void pipeline_stage(anx_pipeline* pl, int stage) {
+  for (;;) {
+    std::shared_ptr<PipeJob> job;
+    {
+      std::unique_lock<std::mutex> lk(pl->mu);
+      pl->cv.wait(lk, [&]() {
+        if (pl->stop) return true;
+        for (auto& j : pl->jobs) if (j->stage == stage) { job = j; return true; }  // the oldest job waiting for this stage
+        return false;
+      });
+      if (!job) return;  // stop
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (job->rc == ANX_OK) {
+      if (stage == 0) {
+        job->b = anx_batch_encode_packed(pl->m, job->blob, job->blob_len, job->n, &job->p);
+        if (!job->b) { job->rc = g_code ? g_code : ANX_EINVAL; job->err = g_err; }
+      } else if (stage == 1) {
+        job->rc = anx_batch_run(pl->m, job->b, pl->streams[job->seq & 1]);
+        if (job->rc) job->err = g_err;
+      } else {
+        job->rc = anx_batch_fetch_compact(job->b, &job->rows, &job->offs);
+        if (job->rc) job->err = g_err;
+      }
+    }
+    if (anx::switches().encode_timing)
+      fprintf(stderr, "[anx pipeline] job %llu stage %d: %.2f ms\n", (unsigned long long)job->seq, stage,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (stage == 2 || job->rc != ANX_OK) {  // the batch's device buffers go back to the pool as soon as its rows are on the host
+      if (job->b) anx_batch_free(job->b);
+      job->b = nullptr;
+    }
+    {
+      std::lock_guard<std::mutex> lk(pl->mu);
+      job->stage = job->rc == ANX_OK ? stage + 1 : 3;
+    }
+    pl->cv.notify_all();
+  }
+}
+anx_pipeline* anx_pipeline_new(const anx_model* m, int depth) {
+  if (!m) { fail(ANX_EINVAL, "NULL model"); return nullptr; }
+  if (check_resident(m)) return nullptr;
+  anx_pipeline* pl = new anx_pipeline();
+  pl->m = m;
+  pl->depth = depth > 0 ? (size_t)depth : 4;
+  if (m->replicas.size() == 1) {  // a multi-replica model runs every shard on its replica's own stream
+    std::string err;
+    for (void*& st : pl->streams)
+      if (!(st = anx::stream_create(m->replicas[0].device, err))) {
+        for (void* x : pl->streams) if (x) anx::stream_destroy(m->replicas[0].device, x);
+        delete pl;
+        fail(ANX_ENODEVICE, err);
+        return nullptr;
+      }
+  }
+  for (int s = 0; s < 3; ++s) pl->th[s] = std::thread(pipeline_stage, pl, s);
+  return pl;
+}
+int anx_pipeline_submit_packed(anx_pipeline* pl, const char* blob, size_t blob_len, size_t n, const anx_params* p) {
+  if (!pl || (!blob && n) || !p) return fail(ANX_EINVAL, "NULL argument");
+  auto job = std::make_shared<PipeJob>();
+  job->blob = blob; job->blob_len = blob_len; job->n = n; job->p = *p;
+  {
+    std::unique_lock<std::mutex> lk(pl->mu);
+    pl->cv.wait(lk, [&]() { return pl->jobs.size() < pl->depth; });
+    job->seq = pl->next_seq++;
+    pl->jobs.push_back(job);
+  }
+  pl->cv.notify_all();
+  return ANX_OK;
+}
+int anx_pipeline_pending(const anx_pipeline* pl) {
+  if (!pl) return 0;
+  std::lock_guard<std::mutex> lk(const_cast<anx_pipeline*>(pl)->mu);
+  return (int)pl->jobs.size();
+}
+int anx_pipeline_next(anx_pipeline* pl, anx_topk_record** rows, uint32_t** offs, size_t* n) {
+  if (!pl || !rows || !offs) return fail(ANX_EINVAL, "NULL argument");
+  std::shared_ptr<PipeJob> job;
+  {
+    std::unique_lock<std::mutex> lk(pl->mu);
+    if (pl->jobs.empty()) return fail(ANX_EINVAL, "no job in flight");
+    job = pl->jobs.front();
+    pl->cv.wait(lk, [&]() { return job->stage == 3; });
+    pl->jobs.pop_front();
+  }
+  pl->cv.notify_all();
+  if (job->rc != ANX_OK) return fail(job->rc, job->err);
+  *rows = job->rows;
+  *offs = job->offs;
+  if (n) *n = job->n;
+  return ANX_OK;
+}
+void anx_pipeline_free(anx_pipeline* pl) {
+  if (!pl) return;
+  for (;;) {  // the jobs in flight finish; their results are dropped
+    std::shared_ptr<PipeJob> job;
+    {
+      std::unique_lock<std::mutex> lk(pl->mu);
+      if (pl->jobs.empty()) break;
+      job = pl->jobs.front();
+      pl->cv.wait(lk, [&]() { return job->stage == 3; });
+      pl->jobs.pop_front();
+    }
+    if (job->rc == ANX_OK) anx_compact_free(job->rows, job->offs);
+  }
+  {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    pl->stop = true;
+  }
+  pl->cv.notify_all();
+  for (std::thread& t : pl->th) t.join();
+  for (void* st : pl->streams) if (st) anx::stream_destroy(pl->m->replicas[0].device, st);
+  delete pl;
+}
+
 void anx_results_free(anx_result* rows, size_t* offsets) {
   anx::host_result_free(rows);  // a cached pinned buffer of batch_fetch, or a malloc block
   free(offsets);

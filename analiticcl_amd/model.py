@@ -325,6 +325,50 @@ class Batch:
         self.free()
 
 
+class Pipeline:
+    """anx_pipeline: encode / run / fetch of consecutive packed batches overlapped for one caller thread.  submit() hands over a
+    bytes object (every input followed by a NUL byte) and returns at once (or blocks while `depth` jobs are in flight); next()
+    returns the oldest job's (offsets, rows) as Batch.fetch_compact does."""
+
+    def __init__(self, model: "VariantModel", depth: int = 4):
+        self.model = model
+        self.h = L.lib().anx_pipeline_new(model.h, depth)
+        if not self.h:
+            raise L.AnxError(L.lib().anx_last_error_code(), L.lib().anx_last_error().decode("utf-8", "replace"))
+        self._keep = []  # the submitted buffers stay alive until their results were returned
+
+    def submit(self, packed: bytes, n: int, params: "SearchParameters"):
+        self._keep.append(packed)
+        L.check(L.lib().anx_pipeline_submit_packed(self.h, packed, len(packed), n, C.byref(params._c())))
+
+    def pending(self) -> int:
+        return L.lib().anx_pipeline_pending(self.h)
+
+    def next(self):
+        import weakref
+
+        import numpy as np
+        rows = C.c_void_p()
+        offs = C.POINTER(C.c_uint32)()
+        n = C.c_size_t()
+        L.check(L.lib().anx_pipeline_next(self.h, C.byref(rows), C.byref(offs), C.byref(n)))
+        self._keep.pop(0)
+        dt = np.dtype([("vocab_id", "<u4"), ("freq_score", "<f4"), ("dist_score", "<f8")])
+        off_addr = C.addressof(offs.contents)
+        owner = (C.c_char * (off_addr - rows.value + (n.value + 1) * 4)).from_address(rows.value)
+        weakref.finalize(owner, L.lib().anx_compact_free, rows, offs)
+        off = np.frombuffer(owner, dtype="<u4", count=n.value + 1, offset=off_addr - rows.value)
+        return off, np.frombuffer(owner, dtype=dt, count=int(off[-1]))
+
+    def close(self):
+        if self.h:
+            L.lib().anx_pipeline_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class VariantModel:
     """VariantModel (src/lib.rs:50-100) for the query path; `device` = HIP device ordinal
     (default: $LOCAL_RANK or 0; -1 = host index only).  `devices` = a list of ordinals: one process drives a replica of the

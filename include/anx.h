@@ -215,6 +215,20 @@ int anx_batch_fetch(const anx_batch *, anx_result **out_rows, size_t **out_offse
 int anx_batch_fetch_compact(const anx_batch *, anx_topk_record **out_rows, uint32_t **out_offsets);
 void anx_compact_free(anx_topk_record *rows, uint32_t *offsets);
 void anx_compact_to_results(const anx_topk_record *rows, size_t n_rows, anx_result *out);
+/* The staged calls as an asynchronous pipeline for ONE caller thread (the reference's counterpart: independent find_variants calls in
+ * flight on rayon's pool, src/bin/analiticcl.rs:445-448): submit hands over a packed buffer (as anx_batch_encode_packed; it must stay
+ * valid until that job's results were returned) and returns at once -- or blocks while `depth` jobs are in flight; three library
+ * threads encode, run and download the jobs on separate HIP streams, so the upload + encoding of batch i + 2, the device pipeline of
+ * batch i + 1 and the download of batch i overlap; anx_pipeline_next returns the oldest job's ranked rows (compact records, as
+ * anx_batch_fetch_compact; release with anx_compact_free) in submission order, or that job's error.  Models with variant lists or
+ * host-side confusable rescoring are refused by the fetch stage (use the staged calls).  anx_pipeline_free waits for the jobs in
+ * flight and drops their results. */
+typedef struct anx_pipeline anx_pipeline;
+anx_pipeline *anx_pipeline_new(const anx_model *, int depth /* jobs in flight; <= 0: 4 */);
+int anx_pipeline_submit_packed(anx_pipeline *, const char *blob, size_t blob_len, size_t n, const anx_params *);
+int anx_pipeline_pending(const anx_pipeline *); /* jobs submitted and not yet returned */
+int anx_pipeline_next(anx_pipeline *, anx_topk_record **out_rows, uint32_t **out_offsets, size_t *out_n);
+void anx_pipeline_free(anx_pipeline *);
 /* every scored pair of the batch (order unspecified within a query) */
 int anx_batch_fetch_pairs(const anx_batch *, anx_pair **out_pairs, size_t *out_n);
 void anx_pairs_free(anx_pair *);

@@ -123,6 +123,29 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
         }
         size_t used = 0;
         if (anx_batch_num_shards(b) > 1) CHECK(anx_batch_export_compact(b, &used, 8, nullptr, &used) == ANX_EINVAL);
+        if (form == 2 && nrep != 3) {  // the asynchronous pipeline over the same packed buffer: three jobs in flight, rows as the staged calls'
+          anx_pipeline* pl = anx_pipeline_new(m, 2);
+          CHECK(pl != nullptr);
+          for (int j = 0; j < 3; ++j) {
+            if (j == 2) { anx_topk_record* cr = nullptr; uint32_t* co = nullptr; size_t cn = 0; CHECK(anx_pipeline_next(pl, &cr, &co, &cn) == ANX_OK && cn == in.size()); anx_compact_free(cr, co); }
+            CHECK(anx_pipeline_submit_packed(pl, packed.data(), packed.size(), in.size(), &p) == ANX_OK);
+          }
+          CHECK(anx_pipeline_pending(pl) == 2);
+          anx_topk_record* cr = nullptr; uint32_t* co = nullptr; size_t cn = 0;
+          CHECK(anx_pipeline_next(pl, &cr, &co, &cn) == ANX_OK && cn == in.size());
+          bool samep = true;
+          for (size_t i = 0; i <= in.size() && samep; ++i) samep = co[i] == off[i];
+          for (size_t i = 0; i < off[in.size()] && samep; ++i) samep = cr[i].vocab_id == rows[i].vocab_id && cr[i].dist_score == rows[i].dist_score;
+          CHECK(samep);
+          anx_compact_free(cr, co);
+          CHECK(anx_pipeline_submit_packed(pl, packed.data(), packed.size(), in.size() + 9, &p) == ANX_OK);  // fails in its encode stage
+          CHECK(anx_pipeline_next(pl, &cr, &co, &cn) == ANX_OK);
+          anx_compact_free(cr, co);
+          CHECK(anx_pipeline_next(pl, &cr, &co, &cn) == ANX_EINVAL);
+          CHECK(anx_pipeline_next(pl, &cr, &co, &cn) == ANX_EINVAL && anx_pipeline_pending(pl) == 0);  // nothing in flight
+          CHECK(anx_pipeline_submit_packed(pl, packed.data(), packed.size(), in.size(), &p) == ANX_OK);  // left in flight: freed with the pipeline
+          anx_pipeline_free(pl);
+        }
       }
       // confusables loaded (nrep == 3): the host rescoring applies the cutoff -- compared across the three input forms only
       std::vector<size_t>& roff = nrep == 3 ? conf_off : ref_off;

@@ -630,3 +630,40 @@ def test_fetch_compact_equals_fetch(eng, data_dir, tmp_path):
     coff, rows = b.fetch_compact()
     assert np.array_equal(coff, off) and np.array_equal(rows["vocab_id"], vid) and np.array_equal(rows["dist_score"], dist)
     b.free()
+
+
+def test_pipeline_equals_staged_calls(eng, data_dir):
+    """anx_pipeline: several packed batches in flight (encode / run / fetch on three library threads) return, in submission order, the
+    rows of the synchronous staged calls; a job that fails reports its own error and the following jobs are unaffected."""
+    eng = eng[0]
+    words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    sets = [synth.make_queries(words, n, max_len=16, seed=100 + i) for i, n in enumerate((30_000, 1, 70_000, 500, 120_000, 30_000))]
+    blobs = [b"".join(q.encode("utf-8") + b"\0" for q in qs) for qs in sets]
+    want = []
+    for qs, blob in zip(sets, blobs):
+        b = eng.encode_packed(blob, len(qs), p)
+        b.run()
+        off, rows = b.fetch_compact()
+        want.append((off.copy(), rows.copy()))
+        b.free()
+    pl = A.Pipeline(eng, depth=3)
+    for rep in range(2):
+        got = []
+        for i, (qs, blob) in enumerate(zip(sets, blobs)):
+            pl.submit(blob, len(qs), p)
+            if pl.pending() == 3:
+                got.append(pl.next())
+        while pl.pending():
+            got.append(pl.next())
+        assert len(got) == len(sets)
+        for (o, r), (wo, wr) in zip(got, want):
+            assert np.array_equal(o, wo) and np.array_equal(r, wr)
+    pl.submit(blobs[0], len(sets[0]) + 5, p)     # more strings announced than present: that job fails ...
+    pl.submit(blobs[1], len(sets[1]), p)
+    with pytest.raises(A.AnxError, match="fewer strings than announced"):
+        pl.next()
+    o, r = pl.next()                             # ... the next one does not
+    assert np.array_equal(o, want[1][0]) and np.array_equal(r, want[1][1])
+    pl.submit(blobs[2], len(sets[2]), p)         # a job still in flight when the pipeline is freed
+    pl.close()
