@@ -1078,7 +1078,7 @@ int anx_batch_run_async(const anx_model* m, anx_batch* b, void* stream) {
   if (int rc = check_batch(m, b, stream)) return rc;
   return on_shards(b, [&](size_t g, std::string& err) {
     const Shard& s = b->shards[g];
-    return anx::batch_run_async(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), err);
+    return anx::batch_run_async(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), m->replicas.size() == 1, err);
   });
 }
 // A device-weighted run met a row the device could not weight (a string beyond the fixed working memory of conf.hip): the whole
@@ -1431,7 +1431,7 @@ struct PipeJob {
 };
 struct anx_pipeline {
   const anx_model* m = nullptr;
-  size_t depth = 4;
+  size_t depth = 6;
   std::mutex mu;
   std::condition_variable cv;
   std::deque<std::shared_ptr<PipeJob>> jobs;  // in submission order; the front is what anx_pipeline_next returns
@@ -1484,7 +1484,7 @@ anx_pipeline* anx_pipeline_new(const anx_model* m, int depth) {
   if (check_resident(m)) return nullptr;
   anx_pipeline* pl = new anx_pipeline();
   pl->m = m;
-  pl->depth = depth > 0 ? (size_t)depth : 4;
+  pl->depth = depth > 0 ? (size_t)depth : 6;
   if (m->replicas.size() == 1) {  // a multi-replica model runs every shard on its replica's own stream
     std::string err;
     for (void*& st : pl->streams)

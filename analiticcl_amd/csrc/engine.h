@@ -43,7 +43,7 @@ int batch_download_text(const Batch* b, std::string& text, std::vector<uint32_t>
 
 int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
 // the same in two halves: enqueue on `stream` and return / wait for it (statistics, results usable afterwards)
-int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err);
+int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, bool own_streams, std::string& err);
 int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::string& err);
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err);

@@ -70,6 +70,8 @@ struct DevPool {
   size_t cached = 0;
   int lexicons = 0;
   std::vector<hipStream_t> idle_streams;           // non-blocking streams of the device-side encoder, handed out per call
+  hipStream_t run_streams[2] = {nullptr, nullptr}; // the library's own streams for asynchronous runs (batch_run_async)
+  unsigned run_counter = 0;
 };
 // bytes of freed blocks kept per device (MI355X: 288 GB HBM; a 1 M-query batch holds 3-6 GB of scratch).  ANX_POOL_CACHE_MB
 // overrides the default; anx_device_pool_trim() hands the cache back to the driver at any time.
@@ -1317,8 +1319,31 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
 // asynchronous form: enqueue the run on `stream` and return; batch_wait completes it (repeating it synchronously in the rare
 // case a capacity estimate did not hold).  Several batches in flight on different streams overlap the latency-bound tail of
 // one run (compaction, ranking) with the scan of the next.
-int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
-  return batch_launch(m, dl, b, stream, err);
+// own_streams (single-replica models, ANX_RUN_OVERLAP != 0): the run goes to one of two streams of the library's own, alternately,
+// ordered behind what the caller's stream holds at this point (an event) -- so that consecutive asynchronous runs of DIFFERENT
+// batches overlap (the scan of one under the scoring tail, compaction and ranking of the other) although the caller uses one
+// stream: 3.11 -> 2.7-2.8 ms per step on BASELINE configs[1], what two caller streams gave before.  Everything that reads a batch's
+// results requires a finished run (batch_wait has synchronised with it), so the caller's stream needs no event back.
+int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, bool own_streams, std::string& err) {
+  void* use = stream;
+  if (own_streams && dl && switches().run_overlap) {
+    HIP_TRY(hipSetDevice(dl->device));
+    DevPool& pl = pool_of(dl->device);
+    hipStream_t s = nullptr;
+    {
+      std::lock_guard<std::mutex> g(pl.mu);
+      hipStream_t& slot = pl.run_streams[pl.run_counter++ & 1u];
+      if (!slot && hipStreamCreateWithFlags(&slot, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); slot = nullptr; }
+      s = slot;
+    }
+    if (s) {
+      if (!b->ev_in) HIP_TRY(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(b->ev_in, reinterpret_cast<hipStream_t>(stream)));
+      HIP_TRY(hipStreamWaitEvent(s, b->ev_in, 0));
+      use = s;
+    }
+  }
+  return batch_launch(m, dl, b, use, err);
 }
 int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::string& err) {
   for (int attempt = 0;; ++attempt) {
@@ -1604,6 +1629,7 @@ void batch_free(Batch* b) {
     if (e) (void)hipEventDestroy(e);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
   if (b->ev_done) (void)hipEventDestroy(b->ev_done);
+  if (b->ev_in) (void)hipEventDestroy(b->ev_in);
   if (b->h_read) (void)hipHostFree(b->h_read);
   if (b->ev_fs0) (void)hipEventDestroy(b->ev_fs0);
   if (b->ev_fs1) (void)hipEventDestroy(b->ev_fs1);

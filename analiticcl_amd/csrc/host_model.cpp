@@ -450,6 +450,7 @@ const SwitchDef kSwitches[] = {
     {"ANX_SCAN_FUSE", [](Switches& s, const char* v) { s.fuse_prefilter = flag01(v, 1); }},
     {"ANX_CAP_DIV", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.cap_div = x > 1 ? x : 1; }},
     {"ANX_MAX_BATCH", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.max_batch = x > 0 ? x : (4l << 20); }},
+    {"ANX_RUN_OVERLAP", [](Switches& s, const char* v) { s.run_overlap = (v && atoi(v) == 0 && v[0] == '0') ? 0 : 1; }},
     {"ANX_SHARD_POLICY", [](Switches& s, const char* v) { s.shard_by_length = (v && strcmp(v, "range") == 0) ? 0 : 1; }},
     {"ANX_SHARD_MIN", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.shard_min = x > 0 ? x : 8192; }},
     {"ANX_CONFUSABLES", [](Switches& s, const char* v) { s.confusables_host = v && strcmp(v, "host") == 0; }},

@@ -78,6 +78,7 @@ struct Switches {
   int fuse_prefilter = 1;    // ANX_SCAN_FUSE=0: the scan's expansion does not apply the SWAR bound (k_filter_score's phase 1 does)
   long cap_div = 1;          // ANX_CAP_DIV=n: first-run capacity estimates divided by n (regrow-and-repeat path)
   long max_batch = 4l << 20; // ANX_MAX_BATCH: inputs per device batch of anx_find_variants_batch
+  int run_overlap = 1;       // ANX_RUN_OVERLAP=0: anx_batch_run_async enqueues on the caller's stream (no library streams: clean per-kernel times for profiling)
   int shard_by_length = 1;   // ANX_SHARD_POLICY=range: consecutive input ranges per replica instead of the length-partitioned split (A/B reference)
   long shard_min = 8192;     // ANX_SHARD_MIN: fewest inputs a replica of a multi-device model gets (smaller calls use fewer replicas)
   int confusables_host = 0;  // ANX_CONFUSABLES=host: confusable weighting on the host threads (A/B reference of the device kernel)

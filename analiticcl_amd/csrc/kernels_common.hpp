@@ -193,6 +193,7 @@ struct Batch {
   hipEvent_t ev_scan0 = nullptr;   // just before the scan kernels (after the counter memsets)
   hipEvent_t ev_fs0 = nullptr, ev_fs1 = nullptr;  // around k_filter_score
   hipEvent_t ev_done = nullptr;    // after the read-back of a launched run
+  hipEvent_t ev_in = nullptr;      // the caller's stream at the time of an asynchronous run on one of the library's streams
   uint32_t* h_read = nullptr;      // pinned: counters of the launched run (engine.hip HR_*)
   bool launched = false;           // a run is enqueued and not yet finished
   uint32_t fill_cap_launched = 0;  // slots per region the scoring grid of the launched run covers

@@ -330,7 +330,7 @@ class Pipeline:
     bytes object (every input followed by a NUL byte) and returns at once (or blocks while `depth` jobs are in flight); next()
     returns the oldest job's (offsets, rows) as Batch.fetch_compact does."""
 
-    def __init__(self, model: "VariantModel", depth: int = 4):
+    def __init__(self, model: "VariantModel", depth: int = 6):
         self.model = model
         self.h = L.lib().anx_pipeline_new(model.h, depth)
         if not self.h:

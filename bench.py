@@ -235,7 +235,7 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
         bref.run(stream_handle)
         want = digest(bref.fetch_compact())
         bref.free()
-        pl = A_.Pipeline(model, depth=4)
+        pl = A_.Pipeline(model, depth=6)
         got_ok = True
 
         def pipe_pass(njobs, check):
@@ -245,7 +245,7 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
             for _k in range(njobs):
                 pl.submit(packed, len(queries), params)
                 sub += 1
-                if sub >= 4:
+                if sub >= 6:
                     last = pl.next()
                     sub -= 1
                     if check:
@@ -716,6 +716,7 @@ def main():
     ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="N", help="N ranks, all on device 0 (dry run of the N-rank control flow)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the result gather")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config numbers measured after the timed region")
+    ap.add_argument("--no-overlap", action="store_true", help="ANX_RUN_OVERLAP=0 for the whole run: every kernel alone on the GPU (rocprofv3 passes: clean per-kernel durations)")
     ap.add_argument("--extras", default="", help="comma-separated names of the extra configurations to run (default: all)")
     ap.add_argument("--preroll-s", type=float, default=2.5, help="seconds of untimed steady-state steps before the timed region (lets an external "
                     "GPU-utilisation sampler see the device busy; 0 with --timed-only)")
@@ -782,6 +783,8 @@ def main():
     queries = synth.make_queries(words, args.queries, max_len=args.max_len, seed=synth.SEED + rank)
     params = A.SearchParameters(max_anagram_distance=args.anagram_distance, max_edit_distance=args.edit_distance, max_matches=10,
                                 score_threshold=0.25, cutoff_threshold=2.0)
+    if args.no_overlap:
+        A.set_switch("ANX_RUN_OVERLAP", "0")
     t_enc = time.time()
     batch = model.encode_batch(queries, params)  # encode + H2D, outside the timed region
     t_enc = time.time() - t_enc
@@ -887,20 +890,32 @@ def main():
     elapsed = time.perf_counter() - t0
     assert finished[0] == args.steps
     sum_scan_kernel_ms, sum_fs_kernel_ms = kernel_ms["ms_scan_kernel"], kernel_ms["ms_filter_score_kernel"]
-    # ---- after the timed region: the same steps with the two copies on TWO streams, so that the latency-bound tail of one run
-    # (compaction, ranking) overlaps the scan of the next (reported as "overlapped"; never `value`) ------------------------
-    overlapped = None
-    if world == 1 and not do_gather and not args.timed_only:
-        s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+    # The timed steps overlap (anx_batch_run_async alternates between two streams of the library: the scan of one step runs under
+    # the tail of the previous one), so the HIP-event times of their kernels include the time they share the GPU.  The roofline
+    # uses the kernels' OWN durations: the same steps once more with ANX_RUN_OVERLAP=0 (one stream, no kernel overlaps another) --
+    # which is also how the rocprofv3 passes of profiles/ are taken.
+    overlapped_kernel_ms = {"k_scan_bits": sum_scan_kernel_ms / max(args.steps, 1), "k_filter_score": sum_fs_kernel_ms / max(args.steps, 1)}
+    serial_ms = None
+    if args.no_overlap:
+        serial_ms = elapsed / max(args.steps, 1) * 1e3
+    elif A.lib().anx_debug_set_switch(b"ANX_RUN_OVERLAP", b"0") == 0:
         for k in range(2):
-            step(k, s2[k & 1].cuda_stream, False)
+            step(k, stream.cuda_stream, False)
         barrier()
+        for k_ in kernel_ms:
+            kernel_ms[k_] = 0.0
+        for k_ in stage_ms:
+            stage_ms[k_] = 0.0
+        finished[0] = 0
         t1 = time.perf_counter()
-        nov = max(4, args.steps)
-        for k in range(nov):
-            step(k, s2[k & 1].cuda_stream, False)
-        barrier()
-        overlapped = (time.perf_counter() - t1) / nov
+        for k in range(args.steps):
+            step(k, stream.cuda_stream, True)
+        barrier(True)
+        serial_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
+        assert finished[0] == args.steps
+        sum_scan_kernel_ms, sum_fs_kernel_ms = kernel_ms["ms_scan_kernel"], kernel_ms["ms_filter_score_kernel"]
+        A.lib().anx_debug_set_switch(b"ANX_RUN_OVERLAP", None)
+    overlapped = None  # (until round 3: the same steps on two caller streams; the library overlaps consecutive runs itself now)
     # one resident copy, one run at a time (anx_batch_run: launch, wait, launch ...): the like-for-like figure of round 1's records.
     # Measured here, while the GPU is still busy (after the CPU baseline its clocks have dropped).
     sync_ms = None
@@ -983,7 +998,10 @@ def main():
         out = {
             "metric": baseline_metric(),
             "value": pairs * args.steps / elapsed, "unit": "pairs/s",
-            "pipelining": "2 resident copies of the batch alternate, anx_batch_run_async on ONE stream, each waited for a step later (steady-state throughput)",
+            "pipelining": "2 resident copies of the batch alternate: anx_batch_run_async from ONE caller stream, each waited for a step later; the library runs "
+                          "consecutive asynchronous runs on two streams of its own (the scan of one under the scoring tail / compaction / ranking of the other)",
+            "serial_ms_per_step": serial_ms,
+            "kernels_ms_in_timed_region": overlapped_kernel_ms,
             "sync_single_copy_ms_per_step": sync_ms,
             "parity": parity, "preroll_steps": preroll_steps,
             "configs": extras,

@@ -200,8 +200,10 @@ int anx_batch_run(const anx_model *, anx_batch *, void *stream);
 /* The same in two halves.  run_async enqueues the whole pipeline on `stream` and returns (no host round trip inside a run: grids
  * and buffers are sized from the batch's previous run or from estimates, every kernel bounds-checks, one read-back at the end);
  * wait completes it -- in the rare case an estimate did not hold it regrows the buffers and repeats the run synchronously.
- * Batches in flight on different streams overlap: the latency-bound tail of one run (compaction, ranking) runs under the scan
- * of the next.  anx_batch_run == run_async + wait.  (The reference's counterpart is the rayon fan-out over inputs,
+ * Batches in flight overlap: the latency-bound tail of one run (compaction, ranking) runs under the scan of the next.  For a
+ * single-replica model run_async therefore enqueues on one of two streams of the library's own, alternately, ordered behind what
+ * `stream` holds at the time of the call (so one caller stream is enough to get the overlap; ANX_RUN_OVERLAP=0: on `stream` itself);
+ * results are read through the calls below after anx_batch_wait.  anx_batch_run == launch on `stream` + wait.  (The reference's counterpart is the rayon fan-out over inputs,
  * src/bin/analiticcl.rs:445-448: independent calls in flight at once.) */
 int anx_batch_run_async(const anx_model *, anx_batch *, void *stream);
 int anx_batch_wait(const anx_model *, anx_batch *);
@@ -224,7 +226,7 @@ void anx_compact_to_results(const anx_topk_record *rows, size_t n_rows, anx_resu
  * host-side confusable rescoring are refused by the fetch stage (use the staged calls).  anx_pipeline_free waits for the jobs in
  * flight and drops their results. */
 typedef struct anx_pipeline anx_pipeline;
-anx_pipeline *anx_pipeline_new(const anx_model *, int depth /* jobs in flight; <= 0: 4 */);
+anx_pipeline *anx_pipeline_new(const anx_model *, int depth /* jobs in flight; <= 0: 6 (three stages, each working on one job with one queued) */);
 int anx_pipeline_submit_packed(anx_pipeline *, const char *blob, size_t blob_len, size_t n, const anx_params *);
 int anx_pipeline_pending(const anx_pipeline *); /* jobs submitted and not yet returned */
 int anx_pipeline_next(anx_pipeline *, anx_topk_record **out_rows, uint32_t **out_offsets, size_t *out_n);

@@ -73,7 +73,7 @@ int batch_run(const HostModel&, const DeviceLexicon* dl, Batch* b, void*, std::s
   b->ran = true;
   return ANX_OK;
 }
-int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* st, std::string& err) { return batch_run(m, dl, b, st, err); }
+int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* st, bool, std::string& err) { return batch_run(m, dl, b, st, err); }
 int batch_wait(const HostModel&, const DeviceLexicon* dl, Batch* b, std::string& err) { if (!dl || !b || !b->ran) { err = "stub"; return ANX_ENODEVICE; } return ANX_OK; }
 size_t batch_n_results(const Batch* b) { return b->ran ? b->rows.size() : 0; }
 size_t batch_n_input(const Batch* b) { return b->in.size(); }

@@ -635,6 +635,7 @@ def test_fetch_compact_equals_fetch(eng, data_dir, tmp_path):
 def test_pipeline_equals_staged_calls(eng, data_dir):
     """anx_pipeline: several packed batches in flight (encode / run / fetch on three library threads) return, in submission order, the
     rows of the synchronous staged calls; a job that fails reports its own error and the following jobs are unaffected."""
+    import numpy as np
     eng = eng[0]
     words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
     p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
