@@ -687,7 +687,7 @@ def single_process(args):
                                f"k={args.anagram_distance} d={args.edit_distance} n=10 score-threshold 0.25 cutoff 2.0",
                    "queries_per_gpu": args.queries, "lexicon_entries": model.num_instances(), "anagram_classes": model.num_classes(),
                    "pairs_per_query": st["n_pairs"] / max(st["n_queries"], 1),
-                   "parallelism": f"query-sharded x{n}, ONE process: anx_model_to_devices({devices}), one host thread + stream per replica, rows concatenated on the host (no collective)"},
+                   "parallelism": f"query-sharded x{n}, ONE process: anx_model_to_devices({devices}), one host thread + stream per replica, length-partitioned split of every call, rows back in input order on the host (no collective)"},
         "pipelining": "2 resident copies of the sharded batch, anx_batch_run_async on every replica's own stream, waited for a step later",
         "shards": shards, "shard_check": check, "process_group": None, "roofline": roofline, "cpu_baseline": cpu,
     }
