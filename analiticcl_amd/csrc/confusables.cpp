@@ -256,18 +256,21 @@ void HostModel::confusable_weights(const char* input, size_t len, const uint64_t
 }
 
 const std::vector<uint32_t>& HostModel::vocab_gather_order() const {
-  // keyed on the entry count of the image it was built from (a rebuilt index replaces the image's arrays)
-  if (vocab_order_for.load(std::memory_order_acquire) != &lex || vocab_order_cache.size() != decoder.size()) {
+  const uint64_t gen = index_generation.load(std::memory_order_acquire);
+  const VocabOrder* cur = vocab_order.load(std::memory_order_acquire);
+  if (!cur || cur->generation != gen || cur->order.size() != decoder.size()) {
     std::lock_guard<std::mutex> g(conf_cache_mu);
-    if (vocab_order_for.load(std::memory_order_acquire) != &lex || vocab_order_cache.size() != decoder.size()) {
-      std::vector<uint32_t> o(decoder.size(), 0xFFFFFFFFu);
+    cur = vocab_order.load(std::memory_order_acquire);
+    if (!cur || cur->generation != gen || cur->order.size() != decoder.size()) {
+      std::unique_ptr<VocabOrder> o(new VocabOrder{gen, std::vector<uint32_t>(decoder.size(), 0xFFFFFFFFu)});
       for (size_t e = 0; e < lex.ent_vocab.size() && e < lex.ent_order.size(); ++e)
-        if (lex.ent_vocab[e] < o.size()) o[lex.ent_vocab[e]] = lex.ent_order[e];
-      vocab_order_cache.swap(o);
-      vocab_order_for.store(&lex, std::memory_order_release);
+        if (lex.ent_vocab[e] < o->order.size()) o->order[lex.ent_vocab[e]] = lex.ent_order[e];
+      cur = o.get();
+      vocab_order_owned.push_back(std::move(o));
+      vocab_order.store(cur, std::memory_order_release);
     }
   }
-  return vocab_order_cache;
+  return cur->order;
 }
 
 double HostModel::confusable_weight(const std::string& input, uint64_t candidate) const {

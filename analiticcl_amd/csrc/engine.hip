@@ -106,8 +106,16 @@ void encoder_stream_release(int device, hipStream_t s) {
   std::lock_guard<std::mutex> g(pl.mu);
   pl.idle_streams.push_back(s);
 }
+// The calling thread's current HIP device is not ours to change: entry points that run on a CALLER's thread (model upload / free,
+// stream create / destroy, pool trim) switch to the replica's device and put the caller's back when they return.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 // streams of the replicas of a multi-device model (capi.cpp owns them; HIP stays behind this file)
 void* stream_create(int device, std::string& err) {
+  DeviceGuard guard;
   hipStream_t s = nullptr;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
     err = std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(hipGetLastError());
@@ -116,6 +124,7 @@ void* stream_create(int device, std::string& err) {
   return s;
 }
 void stream_destroy(int device, void* s) {
+  DeviceGuard guard;
   if (!s) return;
   (void)hipSetDevice(device);
   (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(s));
@@ -298,6 +307,7 @@ static int dalloc(T** dst, size_t count, std::string& err) {
 }
 
 DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, int device, std::string& err) {
+  DeviceGuard guard;
   int n = device_count(err);
   if (n <= 0) {
     if (err.empty()) err = "no HIP device available";
@@ -437,6 +447,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
 
 void lexicon_free(DeviceLexicon* d) {
   if (!d) return;
+  DeviceGuard guard;
   (void)hipSetDevice(d->device);
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->scan_rec34, (void*)d->sig_e, (void*)d->sighash, (void*)d->sighash_e, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,

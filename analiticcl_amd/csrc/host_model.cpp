@@ -648,6 +648,7 @@ int HostModel::build_index(std::string& err) {
   lex.sig_hi.resize(nsig_pad, 0xFFFFFFFFu);
   lex.sig_cbeg.resize(nsig_pad + 1, lex.nclasses);
   build_lm();
+  index_generation.fetch_add(1, std::memory_order_release);  // caches derived from the image (vocab_gather_order) start over
   built = true;
   return ANX_OK;
 }

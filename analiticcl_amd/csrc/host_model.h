@@ -242,8 +242,12 @@ class HostModel {
   // LexiconImage::ent_order), UINT32_MAX for items that are not indexed: what the host-side EARLY confusable rescoring sorts by
   // before it weights, because the reference weights its candidates in that order (src/lib.rs:1505-1535)
   const std::vector<uint32_t>& vocab_gather_order() const;
-  mutable std::vector<uint32_t> vocab_order_cache;
-  mutable std::atomic<const LexiconImage*> vocab_order_for{nullptr};
+  // published copies: readers take the current one without a lock; a copy is built for one index generation (build_index /
+  // load_index bump it) and one vocabulary size, and every copy ever published lives as long as the model
+  struct VocabOrder { uint64_t generation; std::vector<uint32_t> order; };
+  mutable std::atomic<const VocabOrder*> vocab_order{nullptr};
+  mutable std::vector<std::unique_ptr<VocabOrder>> vocab_order_owned;
+  std::atomic<uint64_t> index_generation{0};
   bool have_lm = false;
   std::unordered_map<std::string, uint32_t> ngrams;  // LM n-gram counts keyed by the packed vocab ids (src/lib.rs:68-70)
   std::unordered_map<uint64_t, uint32_t> unigrams, bigrams;  // the two orders lm_score_tokens looks up (id, id1 << 32 | id2)

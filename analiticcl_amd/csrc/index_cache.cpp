@@ -201,6 +201,7 @@ int HostModel::load_index(const std::string& path, std::string& err) {
     class_of_cv.emplace(cv, c);
   }
   build_lm();
+  index_generation.fetch_add(1, std::memory_order_release);
   built = true;
   return ANX_OK;
 }

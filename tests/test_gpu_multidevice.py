@@ -202,3 +202,22 @@ def test_search_mode_over_replicas(data_dir):
     for x, y in zip(one, two):
         assert np.array_equal(x, y)
     assert one[1].size > 10_000
+
+
+def test_conf_fallback_with_an_empty_shard(data_dir):
+    """Confusables weighted on the device, a string beyond the device kernel's working memory (> 64 code points) -> the whole batch is
+    redone with the host weighting, which downloads the inputs from every shard -- also from a shard that received NO input (range
+    policy, packed form: the byte-balanced cut falls inside the long last string)."""
+    words = synth.load_lexicon_words(os.path.join(data_dir, "nld.aspell.lexicon"))
+    qs = synth.make_queries(words, 6, max_len=12, seed=3) + ["x" * 40 + "y" * 700]
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+    A.set_switch("ANX_SHARD_MIN", 1)
+    one = _run(_model(data_dir, "nld", [0], True), qs, p, counts=False)
+    g = _model(data_dir, "nld", [0, 0], True)
+    for policy in ("range", "length"):
+        A.set_switch("ANX_SHARD_POLICY", policy)
+        for packed in (True, False):
+            got = _run(g, qs, p, packed=packed, counts=False)
+            for x, y in zip(one["arrays"], got["arrays"]):
+                assert np.array_equal(x, y)
+    A.set_switch("ANX_SHARD_POLICY", None)
