@@ -60,7 +60,8 @@ struct LNode {   // one of the K best paths into a state: 24 B
 
 struct LatArgs {
   const LatStretch* st;
-  uint32_t first, count;     // stretches [first, first + count) of the batch run in this launch
+  uint32_t first, count;     // stretches index[first .. first + count) of the batch run in this launch
+  const uint32_t* index;     // stretch ids in launch order (narrow ones paired by size for the two-per-wave kernel, then the wide ones)
   const uint32_t* in_off;    // per (stretch, state) CSR into arcs; a stretch owns nstates + 2 entries (virtual end state included)
   const LatArc* arcs;
   const LatSym* syms;
@@ -78,7 +79,6 @@ struct LatArgs {
 };
 
 constexpr uint32_t LAT_MAX_STATES = 1024;   // per stretch, virtual end state included
-constexpr uint32_t LAT_MAX_INDEG = 128;     // incoming arcs per state (two candidate heads per lane)
 constexpr float LAT_SMOOTH = -13.815510557964274f;  // src/search.rs:4
 
 __device__ inline unsigned long long wave_min_u64(unsigned long long v) {
@@ -101,49 +101,75 @@ __device__ inline float lat_term(const LatArgs& a, int32_t x, int32_t y) {  // o
   }
 }
 
-// wave-wide minimum of non-negative floats (as their bit patterns) with DPP row operations: result in every lane
-__device__ inline uint32_t wave_min_u32(uint32_t v) {
+// minimum of non-negative floats (as their bit patterns) over a GROUP of G lanes (G = 64: the wave; G = 32: each half on its own)
+// with DPP row operations: result in every lane of the group
+template <uint32_t G>
+__device__ inline uint32_t group_min_u32(uint32_t v, uint32_t lane) {
   v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
   v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
   v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
   v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8 -> lane 15 of a row = row minimum
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold their half's minimum
+  if (G == 64) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  }
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  return lane < 32u ? lo : hi;
 }
 
+// G lanes per stretch: G = 64 one stretch per wave (states with up to 128 incoming arcs, two candidate heads per lane); G = 32 two
+// stretches per wave, side by side in its halves (up to 64 incoming arcs per state: the common case -- ~30 on the bench's text): the
+// wave-wide minimum, the ballot and the bookkeeping of a pop then serve two lattices.  The host pairs stretches of similar size.
+template <uint32_t G>
 __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
-  __shared__ uint16_t s_cnt[LAT_MAX_STATES];
-  extern __shared__ float s_ring[];  // [ring][K]: the costs of the K best paths of the last `ring` states (what a merge reads)
-  const uint32_t si = a.first + blockIdx.x;
-  const uint32_t lane = threadIdx.x;
+  constexpr uint32_t NG = 64u / G;
+  __shared__ uint16_t s_cnt_all[NG][LAT_MAX_STATES];
+  extern __shared__ float s_ring_all[];  // [NG][ring_max][K]: the costs of the K best paths of the last `ring` states (what a merge reads)
+  const uint32_t lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const uint32_t slot = blockIdx.x * NG + grp;
+  const bool have = slot < a.count;
+  const uint32_t si = a.index[a.first + (have ? slot : 0u)];
   const LatStretch S = a.st[si];
-  const uint32_t ns = S.nstates + 1u;  // with the virtual end state
   const uint32_t K = a.K;
-  if (ns > LAT_MAX_STATES || K > 0xFFFFu || S.ring == 0u || S.ring > a.ring_max) { if (lane == 0) a.out_n[si] = 0xFFFFFFFFu; return; }
+  uint16_t* __restrict__ s_cnt = s_cnt_all[grp];
+  float* __restrict__ s_ring = s_ring_all + (size_t)grp * a.ring_max * K;
+  // the (parent, symbol) of the state being merged: its K nodes leave for HBM together, every lane writing whole nodes, instead of one
+  // 24-byte store by ONE lane per pop (two memory instructions per path: ~0.7 G single-lane requests per 12.5 MB of text, which --
+  // not the merge's instructions -- bounded the kernel)
+  uint32_t* __restrict__ s_par = reinterpret_cast<uint32_t*>(s_ring_all + (size_t)NG * a.ring_max * K) + (size_t)grp * 2u * K;
+  uint32_t* __restrict__ s_sym = s_par + K;
+  const uint32_t ns = S.nstates + 1u;  // with the virtual end state
   const uint32_t* __restrict__ ioff = a.in_off + S.in_off0;
-  for (uint32_t d = 1; d < ns; ++d)
-    if (ioff[d + 1] - ioff[d] > LAT_MAX_INDEG) { if (lane == 0) a.out_n[si] = 0xFFFFFFFFu; return; }  // wave-uniform
+  bool alive = have && !(ns > LAT_MAX_STATES || K > 0xFFFFu || S.ring == 0u || S.ring > a.ring_max);
+  if (alive)
+    for (uint32_t d = 1; d < ns; ++d)
+      if (ioff[d + 1] - ioff[d] > 2u * G) { alive = false; break; }  // group-uniform
+  if (have && !alive && gl == 0) a.out_n[si] = 0xFFFFFFFFu;  // not decoded here: the host decoder takes it
   LNode* __restrict__ nodes = a.nodes + (size_t)(S.node0);
-  const uint32_t ring = S.ring;
+  const uint32_t ring = S.ring ? S.ring : 1u;
+  uint32_t nsmax = alive ? ns : 0u;  // the wave's states loop runs as long as its longest stretch
+#pragma unroll
+  for (int o = 32; o >= (int)G && o < 64; o >>= 1) nsmax = max(nsmax, (uint32_t)__shfl_xor((int)nsmax, o));
   // ---- k best paths into every state ----------------------------------------------------------------------------------------
-  if (lane == 0) {
+  if (alive && gl == 0) {
     nodes[0] = LNode{0.0f, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0f, 0u, 0};  // the start node: <bos> (token 0), nothing summed yet
     s_cnt[0] = 1;
     s_ring[0] = 0.0f;
   }
   __syncthreads();
-  for (uint32_t d = 1; d < ns; ++d) {
-    const uint32_t a0 = ioff[d], indeg = ioff[d + 1] - a0;
+  for (uint32_t d = 1; d < nsmax; ++d) {
+    const bool act = alive && d < ns;
+    const uint32_t a0 = act ? ioff[d] : 0u, indeg = act ? ioff[d + 1] - a0 : 0u;
     float* __restrict__ mine = s_ring + (size_t)(d % ring) * K;  // this state's costs (sources are at most ring - 1 states back)
-    // two candidate heads per lane: arcs lane and lane + 64 of the state's incoming list (ordered by source state, arc number)
+    // two candidate heads per lane: arcs gl and gl + G of the state's incoming list (ordered by source state, arc number)
     float hc[2] = {0.0f, 0.0f}, ac[2] = {0.0f, 0.0f};
     uint32_t hsrc[2] = {0u, 0u}, hsym[2] = {0u, 0u}, hr[2] = {0u, 0u}, hn[2] = {0u, 0u};
     const float* hl[2] = {s_ring, s_ring};
     bool hv[2] = {false, false};
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-      const uint32_t ai = lane + 64u * (uint32_t)w;
+      const uint32_t ai = gl + G * (uint32_t)w;
       if (ai < indeg) {
         const LatArc arc = a.arcs[S.arc0 + a0 + ai];
         hsrc[w] = arc.src; hsym[w] = arc.sym; ac[w] = arc.cost;
@@ -152,42 +178,50 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         if (hn[w]) { hv[w] = true; hc[w] = hl[w][0] + arc.cost; }
       }
     }
-    uint32_t count = 0;
-    const bool two = indeg > 64u;  // wave-uniform
-    while (count < K) {
-      // smallest cost (bit pattern of a non-negative float), then the smallest arc among the heads that have it: arcs 0..63 (first
-      // heads, by lane) precede arcs 64..127 (second heads)
-      const uint32_t c0 = hv[0] ? __float_as_uint(hc[0]) : 0xFFFFFFFFu, c1 = (two && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
-      const uint32_t best = wave_min_u32(min(c0, c1));
-      if (best == 0xFFFFFFFFu) break;  // every list is exhausted (wave-uniform)
-      const unsigned long long m0 = __ballot(c0 == best);
-      int w = 0;
-      unsigned long long mw = m0;
-      if (!m0) { w = 1; mw = __ballot(c1 == best); }
-      const uint32_t wl = (uint32_t)__ffsll((long long)mw) - 1u;
-      if (lane == wl) {
+    uint32_t count = 0;       // group-uniform
+    bool gdone = !act;        // group-uniform
+    const bool two = __any(indeg > G);  // wave-uniform: some group of the wave uses its second heads
+    for (;;) {
+      // smallest cost (bit pattern of a non-negative float), then the smallest arc among the heads that have it: arcs 0 .. G-1 (first
+      // heads, by lane) precede arcs G .. 2G-1 (second heads)
+      const uint32_t c0 = (!gdone && hv[0]) ? __float_as_uint(hc[0]) : 0xFFFFFFFFu, c1 = (!gdone && two && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
+      const uint32_t best = group_min_u32<G>(min(c0, c1), lane);
+      gdone = gdone || best == 0xFFFFFFFFu || count >= K;  // every list of the group is exhausted, or K paths are out
+      if (!__any(!gdone)) break;  // wave-uniform
+      const unsigned long long m0 = __ballot(!gdone && c0 == best);
+      const unsigned long long m1 = two ? __ballot(!gdone && c1 == best) : 0ull;
+      const unsigned long long g0 = G == 64 ? m0 : ((m0 >> (grp * 32u)) & 0xFFFFFFFFull), g1 = G == 64 ? m1 : ((m1 >> (grp * 32u)) & 0xFFFFFFFFull);
+      const int w = g0 ? 0 : 1;
+      const unsigned long long gm = g0 ? g0 : g1;
+      const uint32_t wl = (uint32_t)__ffsll((long long)gm) - 1u;  // within the group (gm != 0 unless the group is done)
+      if (!gdone && gl == wl) {
         const float cst = __uint_as_float(best);
         if (w == 0) {
-          nodes[(size_t)d * K + count] = LNode{cst, (hsrc[0] << 16) | hr[0], hsym[0], 0.0f, 0u, 0};
+          s_par[count] = (hsrc[0] << 16) | hr[0];
+          s_sym[count] = hsym[0];
           if (++hr[0] < hn[0]) hc[0] = hl[0][hr[0]] + ac[0];
           else hv[0] = false;
         } else {
-          nodes[(size_t)d * K + count] = LNode{cst, (hsrc[1] << 16) | hr[1], hsym[1], 0.0f, 0u, 0};
+          s_par[count] = (hsrc[1] << 16) | hr[1];
+          s_sym[count] = hsym[1];
           if (++hr[1] < hn[1]) hc[1] = hl[1][hr[1]] + ac[1];
           else hv[1] = false;
         }
         mine[count] = cst;
       }
-      ++count;
+      if (!gdone) ++count;
     }
-    if (lane == 0) s_cnt[d] = (uint16_t)count;
+    if (act && gl == 0) s_cnt[d] = (uint16_t)count;
     __syncthreads();  // the state's costs (and its count) are read by the states behind it
+    if (act)
+      for (uint32_t r = gl; r < count; r += G) nodes[(size_t)d * K + r] = LNode{mine[r], s_par[r], s_sym[r], 0.0f, 0u, 0};
   }
-  const uint32_t end = ns - 1u, npaths = s_cnt[end];
-  if (npaths == 0) { if (lane == 0) a.out_n[si] = 0xFFFFFFFFu; return; }  // no complete path (cannot happen: the epsilon chain): host
+  const uint32_t end = ns - 1u;
+  uint32_t npaths = alive ? s_cnt[end] : 0u;
+  if (alive && npaths == 0) { if (gl == 0) a.out_n[si] = 0xFFFFFFFFu; alive = false; }  // no complete path (cannot happen: the epsilon chain): host
   // ---- LM: (log-probability sum, tokens, last token) of every node on a final path -------------------------------------------
   if (a.use_lm) {
-    for (uint32_t i = lane; i < npaths; i += 64) {  // mark: a node's prefix is needed once, whoever asks for it
+    for (uint32_t i = gl; i < npaths; i += G) {  // mark: a node's prefix is needed once, whoever asks for it
       uint32_t st_ = end, r = i;
       for (;;) {
         LNode& nd = nodes[(size_t)st_ * K + r];
@@ -200,9 +234,9 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     }
     __syncthreads();
     const uint32_t* __restrict__ boff = a.btok_off + S.btok_off0;
-    for (uint32_t d = 1; d < ns; ++d) {
-      const uint32_t cnt = s_cnt[d];
-      for (uint32_t r = lane; r < cnt; r += 64) {
+    for (uint32_t d = 1; d < nsmax; ++d) {
+      const uint32_t cnt = (alive && d < ns) ? s_cnt[d] : 0u;
+      for (uint32_t r = gl; r < cnt; r += G) {
         LNode& nd = nodes[(size_t)d * K + r];
         if (!(nd.n & 0x80000000u)) continue;
         const LNode& pa = nodes[(size_t)(nd.par >> 16) * K + (nd.par & 0xFFFFu)];
@@ -230,7 +264,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   // ---- rerank (src/lib.rs:2318-2425): no context rules here (the host decodes models that have them) -----------------------------
   double best_ppl = 999999.0;
   float best_cost = S.best_cost_init;
-  for (uint32_t i = lane; i < npaths; i += 64) {
+  for (uint32_t i = gl; i < npaths; i += G) {
     const LNode& nd = nodes[(size_t)end * K + i];
     if (a.use_lm) {
       const float logprob = nd.lp + lat_term(a, nd.prev, 1);  // <eos>
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     if (nd.cost < best_cost) best_cost = nd.cost;
   }
 #pragma unroll
-  for (int o = 32; o; o >>= 1) {
+  for (int o = (int)G / 2; o; o >>= 1) {  // within the group
     const double op = __shfl_xor(best_ppl, o);
     const float oc = __shfl_xor(best_cost, o);
     best_ppl = op < best_ppl ? op : best_ppl;
@@ -249,7 +283,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   const bool shortcut = !a.use_lm;  // (!have_lm || lm_weight == 0) && no rules
   double my_score = 0.0;
   uint32_t my_i = 0xFFFFFFFFu;
-  for (uint32_t i = lane; i < npaths; i += 64) {
+  for (uint32_t i = gl; i < npaths; i += G) {
     const LNode& nd = nodes[(size_t)end * K + i];
     double norm_lm = 0.0;
     if (a.use_lm) {
@@ -266,16 +300,16 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
               ((double)a.lm_weight + (double)a.variantmodel_weight + (double)a.contextrules_weight);
     if (my_i == 0xFFFFFFFFu || score > my_score) { my_score = score; my_i = i; }  // first maximum of this lane's paths (ascending i)
   }
-  // first maximum over the wave: larger score wins, equal scores: the smaller path index.  (A NaN score never wins a comparison,
+  // first maximum over the group: larger score wins, equal scores: the smaller path index.  (A NaN score never wins a comparison,
   // on the host neither: path 0 stands unless a later score is greater.)
 #pragma unroll
-  for (int o = 32; o; o >>= 1) {
+  for (int o = (int)G / 2; o; o >>= 1) {
     const double os = __shfl_xor(my_score, o);
     const uint32_t oi = (uint32_t)__shfl_xor((int)my_i, o);
     const bool take = oi != 0xFFFFFFFFu && (my_i == 0xFFFFFFFFu || os > my_score || (os == my_score && oi < my_i) || (my_score != my_score && oi < my_i && !(os != os)));
     if (take) { my_score = os; my_i = oi; }
   }
-  if (lane == 0) {  // the winner's symbols, walked back over the back-pointers, written in path order
+  if (alive && gl == 0) {  // the winner's symbols, walked back over the back-pointers, written in path order
     uint32_t st_ = end, r = my_i, cnt = 0;
     for (;;) {
       const LNode& nd = nodes[(size_t)st_ * K + r];
@@ -399,21 +433,44 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   for (LatStretch& S : hst) {  // indices relative to the uploaded parts
     S.in_off0 -= s0.in_off0; S.arc0 -= s0.arc0; S.sym0 -= s0.sym0; S.btok_off0 -= s0.btok_off0; S.btok0 -= s0.btok0; S.out0 -= s0.out0;
   }
-  std::vector<std::pair<uint32_t, uint32_t>> launches;  // (first, count)
+  // Launch order: the stretches none of whose states has more than 64 incoming arcs (and whose cost ring fits half the LDS budget)
+  // first, by decreasing number of states -- k_lattice<32> decodes them two per wave, neighbours of this order side by side --,
+  // then the others (k_lattice<64>: one per wave, up to 128 incoming arcs).
+  const uint32_t ring_cap64 = (uint32_t)std::max<size_t>(3, ((size_t)48 << 10) / ((size_t)K * sizeof(float))) - 2u;  // two lists of K words beside the rings
+  const uint32_t ring_cap32 = (uint32_t)std::max<size_t>(3, ((size_t)24 << 10) / ((size_t)K * sizeof(float))) - 2u;
+  std::vector<uint32_t> order;
+  order.reserve(n);
+  std::vector<uint32_t> wide;
+  for (size_t j = 0; j < n; ++j) {
+    const uint32_t* io = in.in_off + hst[j].in_off0;
+    uint32_t maxdeg = 0;
+    for (uint32_t d = 1; d <= hst[j].nstates; ++d) maxdeg = std::max(maxdeg, io[d + 1] - io[d]);
+    if (maxdeg <= 64u && hst[j].ring <= ring_cap32) order.push_back((uint32_t)j);
+    else wide.push_back((uint32_t)j);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return hst[x].nstates > hst[y].nstates; });
+  const size_t n_narrow = order.size();
+  order.insert(order.end(), wide.begin(), wide.end());
+  struct Launch { uint32_t first, count, lanes; };
+  std::vector<Launch> launches;
   size_t max_pool = 0;
   for (size_t i = 0; i < n;) {
+    const size_t stop = i < n_narrow ? n_narrow : n;  // a launch holds stretches of one kind
     size_t used = 0, j = i;
-    while (j < n) {
-      const size_t need = (size_t)(hst[j].nstates + 1) * K;
+    while (j < stop) {
+      const size_t need = (size_t)(hst[order[j]].nstates + 1) * K;
       if (j > i && used + need > budget_nodes) break;
-      hst[j].node0 = used;
+      hst[order[j]].node0 = used;
       used += need;
       ++j;
     }
-    launches.emplace_back((uint32_t)i, (uint32_t)(j - i));
+    launches.push_back(Launch{(uint32_t)i, (uint32_t)(j - i), i < n_narrow ? 32u : 64u});
     max_pool = std::max(max_pool, used);
     i = j;
   }
+  uint32_t* d_index = nullptr;
+  if ((rc = dalloc_((void**)&d_index, n * 4))) return rc;
+  HIP_TRY(hipMemcpyAsync(d_index, order.data(), n * 4, hipMemcpyHostToDevice, st));
   if ((rc = dalloc_((void**)&d_nodes, max_pool * sizeof(LNode)))) return rc;
   HIP_TRY(hipMemcpyAsync(d_st, hst.data(), n * sizeof(LatStretch), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_inoff, in.in_off, in.nin * 4, hipMemcpyHostToDevice, st));
@@ -427,16 +484,17 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   a.lm_weight = p.lm_weight; a.variantmodel_weight = p.variantmodel_weight; a.contextrules_weight = p.contextrules_weight;
   a.bg_key = lm->bg_key; a.bg_val = lm->bg_val; a.bg_mask = lm->bg_mask; a.ngram_off = lm->ngram_off; a.ngram_ids = lm->ngram_ids; a.nvocab = lm->nvocab;
   a.out_n = d_outn; a.out_syms = d_outs;
-  // LDS ring of cost lists: as many states as the widest arc of the call spans (+ 1), capped by 48 KB per wave
-  uint32_t ring_need = 2;
-  for (size_t i = 0; i < n; ++i) ring_need = std::max(ring_need, hst[i].ring);
-  const uint32_t ring_cap = (uint32_t)std::max<size_t>(1, ((size_t)48 << 10) / ((size_t)K * sizeof(float)));
-  a.ring_max = std::min(ring_need, ring_cap);
-  const size_t lds = (size_t)a.ring_max * K * sizeof(float);
-  for (const auto& l : launches) {
-    a.first = l.first; a.count = l.second;
+  a.index = d_index;
+  // LDS ring of cost lists: as many states as the widest arc of the launch's stretches spans (+ 1), capped by 48 KB per wave
+  for (const Launch& l : launches) {
+    uint32_t ring_need = 2;
+    for (uint32_t i = 0; i < l.count; ++i) ring_need = std::max(ring_need, hst[order[l.first + i]].ring);
+    a.ring_max = std::min(ring_need, l.lanes == 32u ? ring_cap32 : ring_cap64);
+    const size_t lds = (size_t)(64u / l.lanes) * ((size_t)a.ring_max + 2u) * K * sizeof(float);  // cost rings + the merged state's (parent, symbol) lists
+    a.first = l.first; a.count = l.count;
     const int kt = ktimer_begin("k_lattice", st);
-    hipLaunchKernelGGL(k_lattice, dim3(l.second), dim3(64), lds, st, a);
+    if (l.lanes == 32u) hipLaunchKernelGGL(k_lattice<32>, dim3((l.count + 1u) / 2u), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL(k_lattice<64>, dim3(l.count), dim3(64), lds, st, a);
     ktimer_end(kt, st);
   }
   HIP_TRY(hipGetLastError());
