@@ -70,6 +70,10 @@ def test_occupancy_of_the_dominant_kernels(kernels):
     # round 3: the fused band-match filter in the scan's expansion needs 90 VGPRs -> 5 waves per SIMD (512 / 96), which the
     # kernel's LDS footprint (27.6 KB per 4-wave block) allows as well; without the filter state it was 76 (6 waves)
     assert vgprs("k_scan_bits") <= 96
+    # round 4: the production instance of the scan (no StopAtExactMatch / pair-count / keep-all branches) keeps its scalar state in
+    # registers: 28 SGPRs spilled into VGPR lanes cost the hot loops 0.05 ms of the kernel's 1.60 (v_readlane / v_writelane + hazards)
+    prod = [r for n, r in kernels.items() if "k_scan_bitsILb0" in n]
+    assert prod and all(r["sgpr_spill_count"] <= 8 for r in prod), prod
     assert vgprs("k_filter_scoreILi2ELb0") <= 64         # 8 waves per SIMD for the bench configuration (d = 2, short queries)
     assert vgprs("k_filter_scoreILi1ELb0") <= 64
     assert vgprs("k_filter_score") <= 80                 # every instance, incl. the inline 8-word prefilter variants
