@@ -114,7 +114,8 @@ ANX_HD CharSet charset_of_array(const cp_t* s, uint32_t n) {  // of a string out
   cs.w[0] = cs.w[1] = 0;
   cs.other = 0;
   for (uint32_t i = 0; i < n; ++i) {
-    if (s[i] < 128) cs.w[s[i] >> 6] |= 1ull << (s[i] & 63);
+    if (s[i] < 64) cs.w[0] |= 1ull << s[i];  // (no run-time index into the two words: on the device that became a hidden 3 KB LDS array)
+    else if (s[i] < 128) cs.w[1] |= 1ull << (s[i] & 63);
     else cs.other = 1;
   }
   return cs;
@@ -579,7 +580,8 @@ ANX_HDS CharSet charset_of(const Ctx& c, const View& s) {
   cs.other = 0;
   for (uint32_t i = 0; i < s.n; ++i) {
     const cp_t ch = at(c, s, i);
-    if (ch < 128) cs.w[ch >> 6] |= 1ull << (ch & 63);
+    if (ch < 64) cs.w[0] |= 1ull << ch;
+    else if (ch < 128) cs.w[1] |= 1ull << (ch & 63);
     else cs.other = 1;
   }
   return cs;
@@ -621,7 +623,7 @@ ANX_HDS bool found_in(const Ctx& c, const Patterns& P, const FlatConf& cf) {
 // candidate, an equality's a piece of both; with `$` the last diff is the end of the strings.  Necessary, not sufficient: it only
 // decides whether the edit script is worth computing.
 ANX_HDS bool occurs(const Ctx& c, const PView& opt, const View& s, const CharSet& cs) {
-  if (opt.n == 1 && opt.p[0] < 128) return (cs.w[opt.p[0] >> 6] >> (opt.p[0] & 63)) & 1ull;
+  if (opt.n == 1 && opt.p[0] < 128) return ((opt.p[0] < 64 ? cs.w[0] : cs.w[1]) >> (opt.p[0] & 63)) & 1ull;
   return opt.n == 0 ? true : find(c, s, opt) >= 0;
 }
 ANX_HDS bool may_match(const Ctx& c, const Patterns& P, const FlatConf& cf, const View& in, const CharSet& ins, const View& cand, const CharSet& cs) {

@@ -685,7 +685,7 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     // aligned to whole 64-signature blocks (the neighbours inside the edge blocks belong to charcounts outside the window)
     const uint32_t s0 = m.lex.siglen_begin[lo] & ~63u, s1 = (m.lex.siglen_begin[hi + 1] + 63u) & ~63u;
-    const uint32_t tq = switches().scan_tq ? (uint32_t)switches().scan_tq : SCAN_TQ;
+    const uint32_t tq = switches().scan_tq ? (uint32_t)switches().scan_tq : SCAN_TQ_DEFAULT;
     // The count-vector (SAD) tiles are rare (queries with a symbol more than NBITPLANES times) and run as a launch of
     // their own: a handful of waves whose time is the latency of ONE wave walking the whole signature window.  Their
     // windows are therefore split over several waves (disjoint signature ranges = disjoint classes: same pairs).

@@ -171,8 +171,15 @@ void find_boundaries(const char* text, size_t len, std::vector<Span>& out) {
   size_t b = 0;
   for (size_t i = 0; i < len;) {
     int l;
-    const uint32_t cp = anx::utf8_decode_at(text + i, len - i, &l);
-    const bool alpha = anx::is_alphabetic_cp(cp);
+    bool alpha;
+    const unsigned char c0 = (unsigned char)text[i];
+    if (c0 < 0x80) {  // ASCII: the letters are the alphabetic ones (the table's ASCII part), one byte each
+      l = 1;
+      alpha = (unsigned)((c0 | 32u) - 'a') < 26u;
+    } else {
+      const uint32_t cp = anx::utf8_decode_at(text + i, len - i, &l);
+      alpha = anx::is_alphabetic_cp(cp);
+    }
     if (open) {
       if (alpha) { out.push_back(Span{b, i}); open = false; }
     } else if (!alpha) { b = i; open = true; }
