@@ -993,6 +993,8 @@ constexpr size_t HR_COLD_OFF = (HR_N * sizeof(uint32_t) + 63) & ~(size_t)63;  //
 // ANX_CAP_DIV=n (tests): the first-run capacity ESTIMATES are divided by n, so that the overflow -> regrow -> repeat path runs
 static size_t cap_div() { return (size_t)switches().cap_div; }
 
+// k_rank<true> for models without variant lists at freq_weight == 0, k_rank<false> otherwise (ra = the RankArgs of the launch)
+#define ANX_RANK_LAUNCH(...) do { if (!ra.any_variants && ra.freq_weight == 0.0f) hipLaunchKernelGGL(k_rank<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_rank<false>, __VA_ARGS__); } while (0)
 static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
   if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
   if (b->nq >= (1u << 27) || dl->nentries >= (1u << 26)) { err = "more than 2^27 queries per batch or 2^26 lexicon entries (32-bit record offsets, packed pair records)"; return ANX_ELIMIT; }
@@ -1213,7 +1215,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     }
     HIP_TRY(hipEventRecord(b->ev[3], st));
     if (b->conf_mode == 2 && (rc = conf_launch(m, dl, b, st, true, (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu), err))) return rc;
-    hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
+    ANX_RANK_LAUNCH( dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
                        b->qexpand, ra, b->t_key, b->r_rows, b->r_count, 0xFFFFFFFFu, b->counters + CTR_OVERFLOW);
     if (b->conf_mode == 1 && (rc = conf_launch(m, dl, b, st, false, (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu), err))) return rc;
   } else {
@@ -1226,7 +1228,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
                        b->counters + CTR_OVERFLOW);
     HIP_TRY(hipEventRecord(b->ev[3], st));
     if (b->conf_mode == 2 && (rc = conf_launch(m, dl, b, st, true, row_cap, err))) return rc;
-    hipLaunchKernelGGL(k_rank, dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
+    ANX_RANK_LAUNCH( dim3((nq + 4 * RANK_QPW - 1) / (4 * RANK_QPW)), dim3(256), 0, st, nq, b->soff, b->c_rows, b->qmaxfreq,
                        b->qexpand, ra, b->t_key, b->r_rows, b->r_count, row_cap, b->counters + CTR_OVERFLOW);
     if (b->conf_mode == 1 && (rc = conf_launch(m, dl, b, st, false, row_cap, err))) return rc;
   }

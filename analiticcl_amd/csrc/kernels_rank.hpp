@@ -471,12 +471,16 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
 // wave (lists up to RANK_LCAP rows in LDS, longer ones through t_key).  1M one-query waves were latency-bound.
 constexpr int RANK_QPW = 4;                                    // queries per wave
 constexpr int RANK_WAVE_BYTES = RANK_LCAP * 22 + 64 * 16;      // LDS per wave: keys, order keys, freqs, source rows + ranked heads
+// SIMPLE: no variant lists and freq_weight == 0 (the common model): the expansion / dedup and the weighted-score branches fold away
+template <bool SIMPLE>
 __global__ __launch_bounds__(256) void k_rank(uint32_t nq, const uint32_t* __restrict__ soff,
                                               const SurvRow* __restrict__ c_rows,
                                               const uint32_t* __restrict__ qmaxfreq,
-                                              const uint32_t* __restrict__ qexpand, RankArgs a,
+                                              const uint32_t* __restrict__ qexpand, RankArgs aa,
                                               double* __restrict__ t_key, DevRow* __restrict__ r_rows,
                                               uint32_t* __restrict__ r_count, uint32_t row_cap, const uint32_t* __restrict__ overflow) {
+  RankArgs a = aa;
+  if (SIMPLE) { a.any_variants = 0; a.freq_weight = 0.0f; }
   __shared__ __attribute__((aligned(16))) uint8_t s_raw[4 * RANK_WAVE_BYTES];
   // more candidate rows than c_rows / r_rows hold, or survivor records dropped (k_compact_grouped): the host grows the buffers
   // and repeats the run; nothing of this one is used
