@@ -33,12 +33,21 @@ import ctypes as C
 from analiticcl_amd import _lib as L
 arr = (C.c_char_p * len(texts))(*[t.encode() for t in texts])
 spc = p._c_search()
-for rep in range(2):  # the C entry point alone (what a Rust / C caller sees)
+def _throttled():  # CFS quota: periods in which the cgroup ran out of CPU time
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for line in open(path):
+                if line.startswith("nr_throttled"): return int(line.split()[1])
+        except OSError:
+            pass
+    return 0
+for rep in range(4):  # the C entry point alone (what a Rust / C caller sees)
     ms, offs, rows, nrows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)(), C.c_size_t(0)
-    t = time.time()
+    t = time.time(); c0 = sum(os.times()[:2]); th0 = _throttled()
     L.check(L.lib().anx_find_all_matches_batch(m.h, arr, len(texts), C.byref(spc), C.byref(ms), C.byref(offs), C.byref(rows), C.byref(nrows), None))
     dt = time.time() - t
-    print(f"C ABI: {size/1e6:.1f} MB in {dt:.2f} s = {size/1e6/dt:.2f} MB/s, {offs[len(texts)]} matches, {nrows.value} variant rows")
+    print(f"C ABI: {size/1e6:.1f} MB in {dt:.2f} s = {size/1e6/dt:.2f} MB/s, {offs[len(texts)]} matches, {nrows.value} variant rows; "
+          f"process CPU {sum(os.times()[:2]) - c0:.2f} core-s, cgroup throttled periods +{_throttled() - th0}")
     L.lib().anx_matches_free(ms, offs, rows, None)
 if len(sys.argv) > 2:  # search_bench.py MB parts[:MB per part],...: ANX_SEARCH_PARTS / _PART_BYTES settings side by side, alternating, 4 calls each
     settings = sys.argv[2].split(",")
