@@ -70,6 +70,7 @@ struct LatArgs {
   LNode* nodes;              // node pool of this launch
   uint32_t K;
   uint32_t ring_max;         // cost lists the LDS ring of this launch holds (LatStretch::ring above it: host fallback)
+  uint32_t cnt_cap;          // states (virtual end state included) of the launch's longest stretch: size of the per-state counts in LDS
   int use_lm;
   float lm_weight, variantmodel_weight, contextrules_weight;
   const unsigned long long* bg_key; const float* bg_val; uint32_t bg_mask;
@@ -124,7 +125,6 @@ __device__ inline uint32_t group_min_u32(uint32_t v, uint32_t lane) {
 template <uint32_t G>
 __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   constexpr uint32_t NG = 64u / G;
-  __shared__ uint16_t s_cnt_all[NG][LAT_MAX_STATES];
   extern __shared__ float s_ring_all[];  // [NG][ring_max][K]: the costs of the K best paths of the last `ring` states (what a merge reads)
   const uint32_t lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const uint32_t slot = blockIdx.x * NG + grp;
@@ -132,16 +132,18 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   const uint32_t si = a.index[a.first + (have ? slot : 0u)];
   const LatStretch S = a.st[si];
   const uint32_t K = a.K;
-  uint16_t* __restrict__ s_cnt = s_cnt_all[grp];
   float* __restrict__ s_ring = s_ring_all + (size_t)grp * a.ring_max * K;
   // the (parent, symbol) of the state being merged: its K nodes leave for HBM together, every lane writing whole nodes, instead of one
   // 24-byte store by ONE lane per pop (two memory instructions per path: ~0.7 G single-lane requests per 12.5 MB of text, which --
   // not the merge's instructions -- bounded the kernel)
   uint32_t* __restrict__ s_par = reinterpret_cast<uint32_t*>(s_ring_all + (size_t)NG * a.ring_max * K) + (size_t)grp * 2u * K;
   uint32_t* __restrict__ s_sym = s_par + K;
+  // nodes per state (sized by the launch's longest stretch: a fixed 1024 entries per group were 4 of the kernel's 14 KB of LDS, and
+  // LDS is what bounds the waves in flight of this latency-bound kernel)
+  uint16_t* __restrict__ s_cnt = reinterpret_cast<uint16_t*>(s_ring_all + (size_t)NG * (a.ring_max + 2u) * K) + (size_t)grp * a.cnt_cap;
   const uint32_t ns = S.nstates + 1u;  // with the virtual end state
   const uint32_t* __restrict__ ioff = a.in_off + S.in_off0;
-  bool alive = have && !(ns > LAT_MAX_STATES || K > 0xFFFFu || S.ring == 0u || S.ring > a.ring_max);
+  bool alive = have && !(ns > LAT_MAX_STATES || ns > a.cnt_cap || K > 0xFFFFu || S.ring == 0u || S.ring > a.ring_max);
   if (alive)
     for (uint32_t d = 1; d < ns; ++d)
       if (ioff[d + 1] - ioff[d] > 2u * G) { alive = false; break; }  // group-uniform
@@ -163,7 +165,9 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     const uint32_t a0 = act ? ioff[d] : 0u, indeg = act ? ioff[d + 1] - a0 : 0u;
     float* __restrict__ mine = s_ring + (size_t)(d % ring) * K;  // this state's costs (sources are at most ring - 1 states back)
     // two candidate heads per lane: arcs gl and gl + G of the state's incoming list (ordered by source state, arc number)
-    float hc[2] = {0.0f, 0.0f}, ac[2] = {0.0f, 0.0f};
+    // hx: the NEXT cost of the head's list, fetched when the head moves up: the LDS read of a pop then completes under the next
+    // minimum instead of ahead of it (the winner's list[r + 1] + arc cost is the same sum either way)
+    float hc[2] = {0.0f, 0.0f}, ac[2] = {0.0f, 0.0f}, hx[2] = {0.0f, 0.0f};
     uint32_t hsrc[2] = {0u, 0u}, hsym[2] = {0u, 0u}, hr[2] = {0u, 0u}, hn[2] = {0u, 0u};
     const float* hl[2] = {s_ring, s_ring};
     bool hv[2] = {false, false};
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         hsrc[w] = arc.src; hsym[w] = arc.sym; ac[w] = arc.cost;
         hn[w] = s_cnt[arc.src];
         hl[w] = s_ring + (size_t)(arc.src % ring) * K;
-        if (hn[w]) { hv[w] = true; hc[w] = hl[w][0] + arc.cost; }
+        if (hn[w]) { hv[w] = true; hc[w] = hl[w][0] + arc.cost; if (hn[w] > 1u) hx[w] = hl[w][1]; }
       }
     }
     uint32_t count = 0;       // group-uniform
@@ -199,12 +203,12 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         if (w == 0) {
           s_par[count] = (hsrc[0] << 16) | hr[0];
           s_sym[count] = hsym[0];
-          if (++hr[0] < hn[0]) hc[0] = hl[0][hr[0]] + ac[0];
+          if (++hr[0] < hn[0]) { hc[0] = hx[0] + ac[0]; if (hr[0] + 1u < hn[0]) hx[0] = hl[0][hr[0] + 1u]; }
           else hv[0] = false;
         } else {
           s_par[count] = (hsrc[1] << 16) | hr[1];
           s_sym[count] = hsym[1];
-          if (++hr[1] < hn[1]) hc[1] = hl[1][hr[1]] + ac[1];
+          if (++hr[1] < hn[1]) { hc[1] = hx[1] + ac[1]; if (hr[1] + 1u < hn[1]) hx[1] = hl[1][hr[1] + 1u]; }
           else hv[1] = false;
         }
         mine[count] = cst;
@@ -490,7 +494,11 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
     uint32_t ring_need = 2;
     for (uint32_t i = 0; i < l.count; ++i) ring_need = std::max(ring_need, hst[order[l.first + i]].ring);
     a.ring_max = std::min(ring_need, l.lanes == 32u ? ring_cap32 : ring_cap64);
-    const size_t lds = (size_t)(64u / l.lanes) * ((size_t)a.ring_max + 2u) * K * sizeof(float);  // cost rings + the merged state's (parent, symbol) lists
+    uint32_t cnt_cap = 2;
+    for (uint32_t i = 0; i < l.count; ++i) cnt_cap = std::max(cnt_cap, std::min(hst[order[l.first + i]].nstates + 1u, LAT_MAX_STATES));
+    a.cnt_cap = (cnt_cap + 1u) & ~1u;
+    // cost rings + the merged state's (parent, symbol) lists + the per-state node counts
+    const size_t lds = (size_t)(64u / l.lanes) * (((size_t)a.ring_max + 2u) * K * sizeof(float) + (size_t)a.cnt_cap * sizeof(uint16_t));
     a.first = l.first; a.count = l.count;
     const int kt = ktimer_begin("k_lattice", st);
     if (l.lanes == 32u) hipLaunchKernelGGL(k_lattice<32>, dim3((l.count + 1u) / 2u), dim3(64), lds, st, a);
