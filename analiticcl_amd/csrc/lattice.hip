@@ -133,14 +133,14 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   const LatStretch S = a.st[si];
   const uint32_t K = a.K;
   float* __restrict__ s_ring = s_ring_all + (size_t)grp * a.ring_max * K;
-  // the (parent, symbol) of the state being merged: its K nodes leave for HBM together, every lane writing whole nodes, instead of one
-  // 24-byte store by ONE lane per pop (two memory instructions per path: ~0.7 G single-lane requests per 12.5 MB of text, which --
-  // not the merge's instructions -- bounded the kernel)
-  uint32_t* __restrict__ s_par = reinterpret_cast<uint32_t*>(s_ring_all + (size_t)NG * a.ring_max * K) + (size_t)grp * 2u * K;
-  uint32_t* __restrict__ s_sym = s_par + K;
+  // the (incoming arc, rank at its source) of the nodes of the state being merged: its K nodes leave for HBM together, every lane
+  // writing whole nodes (source state and symbol come from the arc again), instead of one 24-byte store by ONE lane per pop (two
+  // memory instructions per path: ~0.7 G single-lane requests per 12.5 MB of text, which -- not the merge's instructions -- bounded
+  // the kernel).  One word per node: LDS is what bounds the waves in flight.
+  uint32_t* __restrict__ s_par = reinterpret_cast<uint32_t*>(s_ring_all + (size_t)NG * a.ring_max * K) + (size_t)grp * K;
   // nodes per state (sized by the launch's longest stretch: a fixed 1024 entries per group were 4 of the kernel's 14 KB of LDS, and
   // LDS is what bounds the waves in flight of this latency-bound kernel)
-  uint16_t* __restrict__ s_cnt = reinterpret_cast<uint16_t*>(s_ring_all + (size_t)NG * (a.ring_max + 2u) * K) + (size_t)grp * a.cnt_cap;
+  uint16_t* __restrict__ s_cnt = reinterpret_cast<uint16_t*>(s_ring_all + (size_t)NG * (a.ring_max + 1u) * K) + (size_t)grp * a.cnt_cap;
   const uint32_t ns = S.nstates + 1u;  // with the virtual end state
   const uint32_t* __restrict__ ioff = a.in_off + S.in_off0;
   bool alive = have && !(ns > LAT_MAX_STATES || ns > a.cnt_cap || K > 0xFFFFu || S.ring == 0u || S.ring > a.ring_max);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     // hx: the NEXT cost of the head's list, fetched when the head moves up: the LDS read of a pop then completes under the next
     // minimum instead of ahead of it (the winner's list[r + 1] + arc cost is the same sum either way)
     float hc[2] = {0.0f, 0.0f}, ac[2] = {0.0f, 0.0f}, hx[2] = {0.0f, 0.0f};
-    uint32_t hsrc[2] = {0u, 0u}, hsym[2] = {0u, 0u}, hr[2] = {0u, 0u}, hn[2] = {0u, 0u};
+    uint32_t hr[2] = {0u, 0u}, hn[2] = {0u, 0u};
     const float* hl[2] = {s_ring, s_ring};
     bool hv[2] = {false, false};
 #pragma unroll
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
       const uint32_t ai = gl + G * (uint32_t)w;
       if (ai < indeg) {
         const LatArc arc = a.arcs[S.arc0 + a0 + ai];
-        hsrc[w] = arc.src; hsym[w] = arc.sym; ac[w] = arc.cost;
+        ac[w] = arc.cost;
         hn[w] = s_cnt[arc.src];
         hl[w] = s_ring + (size_t)(arc.src % ring) * K;
         if (hn[w]) { hv[w] = true; hc[w] = hl[w][0] + arc.cost; if (hn[w] > 1u) hx[w] = hl[w][1]; }
@@ -201,13 +201,11 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
       if (!gdone && gl == wl) {
         const float cst = __uint_as_float(best);
         if (w == 0) {
-          s_par[count] = (hsrc[0] << 16) | hr[0];
-          s_sym[count] = hsym[0];
+          s_par[count] = (gl << 16) | hr[0];
           if (++hr[0] < hn[0]) { hc[0] = hx[0] + ac[0]; if (hr[0] + 1u < hn[0]) hx[0] = hl[0][hr[0] + 1u]; }
           else hv[0] = false;
         } else {
-          s_par[count] = (hsrc[1] << 16) | hr[1];
-          s_sym[count] = hsym[1];
+          s_par[count] = ((gl + G) << 16) | hr[1];
           if (++hr[1] < hn[1]) { hc[1] = hx[1] + ac[1]; if (hr[1] + 1u < hn[1]) hx[1] = hl[1][hr[1] + 1u]; }
           else hv[1] = false;
         }
@@ -218,7 +216,11 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     if (act && gl == 0) s_cnt[d] = (uint16_t)count;
     __syncthreads();  // the state's costs (and its count) are read by the states behind it
     if (act)
-      for (uint32_t r = gl; r < count; r += G) nodes[(size_t)d * K + r] = LNode{mine[r], s_par[r], s_sym[r], 0.0f, 0u, 0};
+      for (uint32_t r = gl; r < count; r += G) {
+        const uint32_t pk = s_par[r];
+        const LatArc arc = a.arcs[S.arc0 + a0 + (pk >> 16)];
+        nodes[(size_t)d * K + r] = LNode{mine[r], (arc.src << 16) | (pk & 0xFFFFu), arc.sym, 0.0f, 0u, 0};
+      }
   }
   const uint32_t end = ns - 1u;
   uint32_t npaths = alive ? s_cnt[end] : 0u;
@@ -440,8 +442,8 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   // Launch order: the stretches none of whose states has more than 64 incoming arcs (and whose cost ring fits half the LDS budget)
   // first, by decreasing number of states -- k_lattice<32> decodes them two per wave, neighbours of this order side by side --,
   // then the others (k_lattice<64>: one per wave, up to 128 incoming arcs).
-  const uint32_t ring_cap64 = (uint32_t)std::max<size_t>(3, ((size_t)48 << 10) / ((size_t)K * sizeof(float))) - 2u;  // two lists of K words beside the rings
-  const uint32_t ring_cap32 = (uint32_t)std::max<size_t>(3, ((size_t)24 << 10) / ((size_t)K * sizeof(float))) - 2u;
+  const uint32_t ring_cap64 = (uint32_t)std::max<size_t>(3, ((size_t)48 << 10) / ((size_t)K * sizeof(float))) - 1u;  // one list of K words beside the rings
+  const uint32_t ring_cap32 = (uint32_t)std::max<size_t>(3, ((size_t)24 << 10) / ((size_t)K * sizeof(float))) - 1u;
   std::vector<uint32_t> order;
   order.reserve(n);
   std::vector<uint32_t> wide;
@@ -497,8 +499,8 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
     uint32_t cnt_cap = 2;
     for (uint32_t i = 0; i < l.count; ++i) cnt_cap = std::max(cnt_cap, std::min(hst[order[l.first + i]].nstates + 1u, LAT_MAX_STATES));
     a.cnt_cap = (cnt_cap + 1u) & ~1u;
-    // cost rings + the merged state's (parent, symbol) lists + the per-state node counts
-    const size_t lds = (size_t)(64u / l.lanes) * (((size_t)a.ring_max + 2u) * K * sizeof(float) + (size_t)a.cnt_cap * sizeof(uint16_t));
+    // cost rings + the merged state's (arc, rank) list + the per-state node counts
+    const size_t lds = (size_t)(64u / l.lanes) * (((size_t)a.ring_max + 1u) * K * sizeof(float) + (size_t)a.cnt_cap * sizeof(uint16_t));
     a.first = l.first; a.count = l.count;
     const int kt = ktimer_begin("k_lattice", st);
     if (l.lanes == 32u) hipLaunchKernelGGL(k_lattice<32>, dim3((l.count + 1u) / 2u), dim3(64), lds, st, a);
