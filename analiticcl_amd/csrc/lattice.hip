@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -164,12 +165,12 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     const bool act = alive && d < ns;
     const uint32_t a0 = act ? ioff[d] : 0u, indeg = act ? ioff[d + 1] - a0 : 0u;
     float* __restrict__ mine = s_ring + (size_t)(d % ring) * K;  // this state's costs (sources are at most ring - 1 states back)
-    // two candidate heads per lane: arcs gl and gl + G of the state's incoming list (ordered by source state, arc number)
+    // two candidate heads per lane: arcs gl and gl + G of the state's incoming list (ordered by source state, arc number).
     // hx: the NEXT cost of the head's list, fetched when the head moves up: the LDS read of a pop then completes under the next
-    // minimum instead of ahead of it (the winner's list[r + 1] + arc cost is the same sum either way)
+    // minimum instead of ahead of it (the winner's list[r + 1] + arc cost is the same sum either way).  ho: the list's place in the
+    // group's ring (an LDS index, not a pointer: ds_read instead of flat loads).
     float hc[2] = {0.0f, 0.0f}, ac[2] = {0.0f, 0.0f}, hx[2] = {0.0f, 0.0f};
-    uint32_t hr[2] = {0u, 0u}, hn[2] = {0u, 0u};
-    const float* hl[2] = {s_ring, s_ring};
+    uint32_t hr[2] = {0u, 0u}, hn[2] = {0u, 0u}, ho[2] = {0u, 0u};
     bool hv[2] = {false, false};
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
@@ -178,41 +179,57 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         const LatArc arc = a.arcs[S.arc0 + a0 + ai];
         ac[w] = arc.cost;
         hn[w] = s_cnt[arc.src];
-        hl[w] = s_ring + (size_t)(arc.src % ring) * K;
-        if (hn[w]) { hv[w] = true; hc[w] = hl[w][0] + arc.cost; if (hn[w] > 1u) hx[w] = hl[w][1]; }
+        ho[w] = (arc.src % ring) * K;
+        if (hn[w]) { hv[w] = true; hc[w] = s_ring[ho[w]] + arc.cost; hx[w] = s_ring[ho[w] + (hn[w] > 1u ? 1u : 0u)]; }
       }
     }
     uint32_t count = 0;       // group-uniform
-    bool gdone = !act;        // group-uniform
     const bool two = __any(indeg > G);  // wave-uniform: some group of the wave uses its second heads
-    for (;;) {
-      // smallest cost (bit pattern of a non-negative float), then the smallest arc among the heads that have it: arcs 0 .. G-1 (first
-      // heads, by lane) precede arcs G .. 2G-1 (second heads)
-      const uint32_t c0 = (!gdone && hv[0]) ? __float_as_uint(hc[0]) : 0xFFFFFFFFu, c1 = (!gdone && two && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
-      const uint32_t best = group_min_u32<G>(min(c0, c1), lane);
-      gdone = gdone || best == 0xFFFFFFFFu || count >= K;  // every list of the group is exhausted, or K paths are out
-      if (!__any(!gdone)) break;  // wave-uniform
-      const unsigned long long m0 = __ballot(!gdone && c0 == best);
-      const unsigned long long m1 = two ? __ballot(!gdone && c1 == best) : 0ull;
-      const unsigned long long g0 = G == 64 ? m0 : ((m0 >> (grp * 32u)) & 0xFFFFFFFFull), g1 = G == 64 ? m1 : ((m1 >> (grp * 32u)) & 0xFFFFFFFFull);
-      const int w = g0 ? 0 : 1;
-      const unsigned long long gm = g0 ? g0 : g1;
-      const uint32_t wl = (uint32_t)__ffsll((long long)gm) - 1u;  // within the group (gm != 0 unless the group is done)
-      if (!gdone && gl == wl) {
-        const float cst = __uint_as_float(best);
-        if (w == 0) {
-          s_par[count] = (gl << 16) | hr[0];
-          if (++hr[0] < hn[0]) { hc[0] = hx[0] + ac[0]; if (hr[0] + 1u < hn[0]) hx[0] = hl[0][hr[0] + 1u]; }
-          else hv[0] = false;
+    // K pops (or until every list of the group is exhausted).  A pop: the smallest cost (bit pattern of a non-negative float) over
+    // the group's heads, then the smallest arc among the heads that have it -- arcs 0 .. G-1 (first heads, by lane) precede arcs
+    // G .. 2G-1 (second heads); the winning lane notes (arc, rank) and the cost, and moves its head up.  TWO = false (no state of
+    // the wave has more than G incoming arcs: the common case) compiles the loop without the second heads.
+    auto pops = [&](auto two_c) {
+      constexpr bool TWO = decltype(two_c)::value;
+      // (the minimum of the NEXT pop is taken at the end of the loop body, behind the winner's LDS read: the read is waited for at
+      // the loop head, i.e. after that minimum, not before it)
+      uint32_t c0 = hv[0] ? __float_as_uint(hc[0]) : 0xFFFFFFFFu;
+      uint32_t c1 = (TWO && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
+      uint32_t best = group_min_u32<G>(TWO ? min(c0, c1) : c0, lane);
+      for (;;) {
+        const bool live = best != 0xFFFFFFFFu && count < K;  // group-uniform (groups without an active state have no heads)
+        if (!__any(live)) break;  // wave-uniform
+        const unsigned long long m0 = __ballot(live && c0 == best);
+        const unsigned long long m1 = TWO ? __ballot(live && c1 == best) : 0ull;
+        bool first;
+        uint32_t wl;  // the winning lane within the group
+        if (G == 64) {
+          first = m0 != 0ull;
+          wl = (uint32_t)__ffsll((long long)(first ? m0 : m1)) - 1u;
         } else {
-          s_par[count] = ((gl + G) << 16) | hr[1];
-          if (++hr[1] < hn[1]) { hc[1] = hx[1] + ac[1]; if (hr[1] + 1u < hn[1]) hx[1] = hl[1][hr[1] + 1u]; }
-          else hv[1] = false;
+          const uint32_t g0 = grp ? (uint32_t)(m0 >> 32) : (uint32_t)m0, g1 = grp ? (uint32_t)(m1 >> 32) : (uint32_t)m1;
+          first = g0 != 0u;
+          wl = (uint32_t)__ffs((int)(first ? g0 : g1)) - 1u;
         }
-        mine[count] = cst;
+        if (live && gl == wl) {
+          if (!TWO || first) {
+            s_par[count] = (gl << 16) | hr[0];
+            if (++hr[0] < hn[0]) { hc[0] = hx[0] + ac[0]; hx[0] = s_ring[ho[0] + (hr[0] + 1u < hn[0] ? hr[0] + 1u : hr[0])]; }
+            else hv[0] = false;
+          } else {
+            s_par[count] = ((gl + G) << 16) | hr[1];
+            if (++hr[1] < hn[1]) { hc[1] = hx[1] + ac[1]; hx[1] = s_ring[ho[1] + (hr[1] + 1u < hn[1] ? hr[1] + 1u : hr[1])]; }
+            else hv[1] = false;
+          }
+          mine[count] = __uint_as_float(best);
+        }
+        if (live) ++count;
+        c0 = hv[0] ? __float_as_uint(hc[0]) : 0xFFFFFFFFu;
+        c1 = (TWO && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
+        best = group_min_u32<G>(TWO ? min(c0, c1) : c0, lane);
       }
-      if (!gdone) ++count;
-    }
+    };
+    if (two) pops(std::true_type{}); else pops(std::false_type{});
     if (act && gl == 0) s_cnt[d] = (uint16_t)count;
     __syncthreads();  // the state's costs (and its count) are read by the states behind it
     if (act)
