@@ -103,21 +103,24 @@ __device__ inline float lat_term(const LatArgs& a, int32_t x, int32_t y) {  // o
   }
 }
 
-// minimum of non-negative floats (as their bit patterns) over a GROUP of G lanes (G = 64: the wave; G = 32: each half on its own)
-// with DPP row operations: result in every lane of the group
+// minimum of non-negative floats (as their bit patterns) over a GROUP of G lanes (G = 64: the wave; G = 32: each half on its own),
+// result in every lane of the group: a rotate-and-min butterfly inside the rows of 16 lanes (DPP row_ror: every lane of a row ends up
+// with the row's minimum), then gfx950's row swaps -- v_permlane16_swap of the value with itself leaves {row 0, row 0, row 2, row 2}
+// in one register and {row 1, row 1, row 3, row 3} in the other, v_permlane32_swap the two halves -- and a min of the two registers.
+// No trip through SGPRs (v_readlane + v_mov + select), which the pop loop's dependent chain used to wait for.
 template <uint32_t G>
-__device__ inline uint32_t group_min_u32(uint32_t v, uint32_t lane) {
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8 -> lane 15 of a row = row minimum
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold their half's minimum
+__device__ inline uint32_t group_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x121, 0xF, 0xF, false));  // row_ror:1
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x122, 0xF, 0xF, false));  // row_ror:2
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x124, 0xF, 0xF, false));  // row_ror:4
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x128, 0xF, 0xF, false));  // row_ror:8
+  const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = min((uint32_t)r16[0], (uint32_t)r16[1]);
   if (G == 64) {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = min((uint32_t)r32[0], (uint32_t)r32[1]);
   }
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-  return lane < 32u ? lo : hi;
+  return v;
 }
 
 // G lanes per stretch: G = 64 one stretch per wave (states with up to 128 incoming arcs, two candidate heads per lane); G = 32 two
@@ -161,17 +164,21 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     s_ring[0] = 0.0f;
   }
   __syncthreads();
+  // the lanes of this lane's group below it, as masks over the two halves of a wave-wide ballot
+  const uint32_t below = gl >= 32u ? 0xFFFFFFFFu : ((1u << (gl & 31u)) - 1u);
+  const uint32_t blo = G == 64 ? below : (grp ? 0u : below);
+  const uint32_t bhi = G == 64 ? (gl >= 32u ? (1u << (gl - 32u)) - 1u : 0u) : (grp ? below : 0u);
   for (uint32_t d = 1; d < nsmax; ++d) {
     const bool act = alive && d < ns;
     const uint32_t a0 = act ? ioff[d] : 0u, indeg = act ? ioff[d + 1] - a0 : 0u;
     float* __restrict__ mine = s_ring + (size_t)(d % ring) * K;  // this state's costs (sources are at most ring - 1 states back)
     // two candidate heads per lane: arcs gl and gl + G of the state's incoming list (ordered by source state, arc number).
-    // hx: the NEXT cost of the head's list, fetched when the head moves up: the LDS read of a pop then completes under the next
-    // minimum instead of ahead of it (the winner's list[r + 1] + arc cost is the same sum either way).  ho: the list's place in the
-    // group's ring (an LDS index, not a pointer: ds_read instead of flat loads).
-    float hc[2] = {0.0f, 0.0f}, ac[2] = {0.0f, 0.0f}, hx[2] = {0.0f, 0.0f};
+    // hx: the NEXT cost of the head's list, fetched when the head moves up (the winner's list[r + 1] + arc cost is the same sum
+    // either way).  ho: the list's place in the group's ring (an LDS index, not a pointer: ds_read instead of flat loads).
+    // hc: the head's cost as its bit pattern, 0xFFFFFFFF = no head (exhausted list, no arc): larger than every cost.
+    uint32_t hc[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    float ac[2] = {0.0f, 0.0f}, hx[2] = {0.0f, 0.0f};
     uint32_t hr[2] = {0u, 0u}, hn[2] = {0u, 0u}, ho[2] = {0u, 0u};
-    bool hv[2] = {false, false};
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       const uint32_t ai = gl + G * (uint32_t)w;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         ac[w] = arc.cost;
         hn[w] = s_cnt[arc.src];
         ho[w] = (arc.src % ring) * K;
-        if (hn[w]) { hv[w] = true; hc[w] = s_ring[ho[w]] + arc.cost; hx[w] = s_ring[ho[w] + (hn[w] > 1u ? 1u : 0u)]; }
+        if (hn[w]) { hc[w] = __float_as_uint(s_ring[ho[w]] + arc.cost); hx[w] = s_ring[ho[w] + (hn[w] > 1u ? 1u : 0u)]; }
       }
     }
     uint32_t count = 0;       // group-uniform
@@ -188,45 +195,43 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     // K pops (or until every list of the group is exhausted).  A pop: the smallest cost (bit pattern of a non-negative float) over
     // the group's heads, then the smallest arc among the heads that have it -- arcs 0 .. G-1 (first heads, by lane) precede arcs
     // G .. 2G-1 (second heads); the winning lane notes (arc, rank) and the cost, and moves its head up.  TWO = false (no state of
-    // the wave has more than G incoming arcs: the common case) compiles the loop without the second heads.
+    // the wave has more than G incoming arcs: the common case) compiles the loop without the second heads; its winner is the lane
+    // that has the minimum and no such lane below it in its group (blo / bhi: the lanes of the group below this one).
+    // The minimum of the NEXT pop is taken at the end of the loop body, behind the winner's LDS read: the read is waited for after
+    // that minimum, not before it.
+    auto move_up = [&](int w, uint32_t arc_index) {
+      s_par[count] = (arc_index << 16) | hr[w];
+      if (++hr[w] < hn[w]) { hc[w] = __float_as_uint(hx[w] + ac[w]); hx[w] = s_ring[ho[w] + (hr[w] + 1u < hn[w] ? hr[w] + 1u : hr[w])]; }
+      else hc[w] = 0xFFFFFFFFu;
+    };
     auto pops = [&](auto two_c) {
       constexpr bool TWO = decltype(two_c)::value;
-      // (the minimum of the NEXT pop is taken at the end of the loop body, behind the winner's LDS read: the read is waited for at
-      // the loop head, i.e. after that minimum, not before it)
-      uint32_t c0 = hv[0] ? __float_as_uint(hc[0]) : 0xFFFFFFFFu;
-      uint32_t c1 = (TWO && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
-      uint32_t best = group_min_u32<G>(TWO ? min(c0, c1) : c0, lane);
+      uint32_t best = group_min_u32<G>(TWO ? min(hc[0], hc[1]) : hc[0]);
       for (;;) {
         const bool live = best != 0xFFFFFFFFu && count < K;  // group-uniform (groups without an active state have no heads)
-        if (!__any(live)) break;  // wave-uniform
-        const unsigned long long m0 = __ballot(live && c0 == best);
-        const unsigned long long m1 = TWO ? __ballot(live && c1 == best) : 0ull;
-        bool first;
-        uint32_t wl;  // the winning lane within the group
-        if (G == 64) {
-          first = m0 != 0ull;
-          wl = (uint32_t)__ffsll((long long)(first ? m0 : m1)) - 1u;
-        } else {
-          const uint32_t g0 = grp ? (uint32_t)(m0 >> 32) : (uint32_t)m0, g1 = grp ? (uint32_t)(m1 >> 32) : (uint32_t)m1;
-          first = g0 != 0u;
-          wl = (uint32_t)__ffs((int)(first ? g0 : g1)) - 1u;
-        }
-        if (live && gl == wl) {
-          if (!TWO || first) {
-            s_par[count] = (gl << 16) | hr[0];
-            if (++hr[0] < hn[0]) { hc[0] = hx[0] + ac[0]; hx[0] = s_ring[ho[0] + (hr[0] + 1u < hn[0] ? hr[0] + 1u : hr[0])]; }
-            else hv[0] = false;
-          } else {
-            s_par[count] = ((gl + G) << 16) | hr[1];
-            if (++hr[1] < hn[1]) { hc[1] = hx[1] + ac[1]; hx[1] = s_ring[ho[1] + (hr[1] + 1u < hn[1] ? hr[1] + 1u : hr[1])]; }
-            else hv[1] = false;
+        const bool eq0 = live && hc[0] == best;
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(eq0);
+        if (!TWO) {
+          if (m0 == 0ull) break;  // wave-uniform: no group has anything left to pop
+          if (eq0 && (((uint32_t)m0 & blo) | ((uint32_t)(m0 >> 32) & bhi)) == 0u) {
+            move_up(0, gl);
+            mine[count] = __uint_as_float(best);
           }
-          mine[count] = __uint_as_float(best);
+        } else {
+          const bool eq1 = live && hc[1] == best;
+          const unsigned long long m1 = __builtin_amdgcn_ballot_w64(eq1);
+          if ((m0 | m1) == 0ull) break;
+          const bool none0 = (G == 64 ? m0 : (unsigned long long)(grp ? (uint32_t)(m0 >> 32) : (uint32_t)m0)) == 0ull;  // no first head of the group has it
+          if (eq0 && (((uint32_t)m0 & blo) | ((uint32_t)(m0 >> 32) & bhi)) == 0u) {
+            move_up(0, gl);
+            mine[count] = __uint_as_float(best);
+          } else if (none0 && eq1 && (((uint32_t)m1 & blo) | ((uint32_t)(m1 >> 32) & bhi)) == 0u) {
+            move_up(1, gl + G);
+            mine[count] = __uint_as_float(best);
+          }
         }
         if (live) ++count;
-        c0 = hv[0] ? __float_as_uint(hc[0]) : 0xFFFFFFFFu;
-        c1 = (TWO && hv[1]) ? __float_as_uint(hc[1]) : 0xFFFFFFFFu;
-        best = group_min_u32<G>(TWO ? min(c0, c1) : c0, lane);
+        best = group_min_u32<G>(TWO ? min(hc[0], hc[1]) : hc[0]);
       }
     };
     if (two) pops(std::true_type{}); else pops(std::false_type{});

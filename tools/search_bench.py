@@ -28,7 +28,8 @@ while size < mb * 1e6:
     cur.append(sent)
     if len(cur) == 8:
         texts.append("".join(cur)); size += len(texts[-1]); cur = []
-p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, max_ngram=3)
+p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, max_ngram=3,
+                       lm_weight=float(os.environ.get("ANX_BENCH_LM_WEIGHT", "1.0")), max_seq=int(os.environ.get("ANX_BENCH_MAX_SEQ", "250")))
 import ctypes as C
 from analiticcl_amd import _lib as L
 arr = (C.c_char_p * len(texts))(*[t.encode() for t in texts])
