@@ -86,6 +86,15 @@ class HostPool {
     delete p;
   }
   unsigned width() const { return nthreads_ + 1; }
+  // f() on a pool thread, not waited for (on the caller when there is no pool thread); shutdown() runs what is still queued
+  void post(std::function<void()> f) {
+    if (!nthreads_) { f(); return; }
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      q_.push_back(std::move(f));
+    }
+    cv_.notify_one();
+  }
   // body() on up to `helpers` pool threads and on the caller; returns when every started body has returned.  A caller that waits
   // takes queued tasks itself, so loops started from inside a pool thread cannot starve each other.
   void run(unsigned helpers, const std::function<void()>& body) {
@@ -685,6 +694,7 @@ struct PartOut {
   std::vector<std::vector<Span>> per_text;
   std::vector<TagPool> tagpools;
   std::vector<OrderRows> kept;
+  std::vector<size_t> text_rows, text_tags;  // per text: variant rows / tags of its matches (summed where per_text is built, by the pool)
   size_t total = 0, total_rows = 0, total_tags = 0;
   int rc = ANX_OK;
   std::string err;
@@ -699,12 +709,10 @@ static void write_part(const PartOut& po, const char* const* texts, size_t n, co
   const std::vector<std::vector<Span>>& per_text = po.per_text;
   // first match / row / tag of every text, then the texts are written side by side
   std::vector<size_t> m0(n + 1, m_base), row0(n + 1, r_base), tag0(n + 1, t_base);
-  for (size_t t = 0; t < n; ++t) {
-    size_t nr = 0, nt = 0;
-    for (const Span& sp_ : per_text[t]) { nr += sp_.variants.size(); nt += sp_.ntags; }
+  for (size_t t = 0; t < n; ++t) {  // (a pass over the 1.3 M spans of 12 MB of text here, by one thread, was a third of the output phase)
     m0[t + 1] = m0[t] + per_text[t].size();
-    row0[t + 1] = row0[t] + nr;
-    tag0[t + 1] = tag0[t] + nt;
+    row0[t + 1] = row0[t] + po.text_rows[t];
+    tag0[t + 1] = tag0[t] + po.text_tags[t];
     oo[t + 1] = m0[t + 1];
   }
   pool_for(n, 8, 64, [&](size_t lo, size_t hi) {
@@ -818,10 +826,20 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   if (!om || !oo || !orows || (out_tags && !otags)) { free(om); free(oo); free(orows); free(otags); return anx_fail(ANX_EINVAL, "out of memory"); }
   advise_huge(om, m0[parts] * sizeof(anx_match));
   advise_huge(orows, r0[parts] * sizeof(anx_result));
-  for (size_t r = 0; r < parts; ++r) {
-    write_part(*P[r], texts + cut[r], cut[r + 1] - cut[r], sp, om, oo + cut[r], orows, otags, m0[r], r0[r], t0[r]);
-    P[r].reset();  // its result arrays go back to the pinned cache
+  double t_write = 0.0, t_reset = 0.0;
+  {
+    const auto ta = std::chrono::steady_clock::now();
+    for (size_t r = 0; r < parts; ++r) write_part(*P[r], texts + cut[r], cut[r + 1] - cut[r], sp, om, oo + cut[r], orows, otags, m0[r], r0[r], t0[r]);
+    const auto tb = std::chrono::steady_clock::now();
+    // the kept result arrays go back to the pinned cache now (the next call's fetches find them there); the parts' own data (the
+    // spans of every text: 4-5 ms of frees, slower still from several threads at once) is released by a pool thread after the return
+    for (size_t r = 0; r < parts; ++r) P[r]->free_kept();
+    auto garbage = std::make_shared<std::vector<std::unique_ptr<PartOut>>>(std::move(P));
+    HostPool::get().post([garbage]() { garbage->clear(); });
+    t_write = std::chrono::duration<double>(tb - ta).count();
+    t_reset = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
   }
+  if (timing) fprintf(stderr, "[anx search]   output: writing %.2f ms, releasing the parts %.2f ms\n", t_write * 1e3, t_reset * 1e3);
   if (timing) fprintf(stderr, "[anx search] output (%zu parts)            %8.2f ms\n", parts, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count() * 1e3);
   *out_matches = om;
   *out_offsets = oo;
@@ -1145,6 +1163,8 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   }
   std::vector<std::vector<Span>>& per_text = po.per_text;
   per_text.assign(n, std::vector<Span>());
+  po.text_rows.assign(n, 0);
+  po.text_tags.assign(n, 0);
   {  // the stretches of a text are consecutive: every text gathers its own
     std::vector<size_t> first(n + 1, stretches.size());
     for (size_t si = stretches.size(); si-- > 0;) first[stretches[si].text_index] = si;
@@ -1155,8 +1175,11 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
         for (size_t si = first[t]; si < first[t + 1] && stretches[si].text_index == t; ++si) total_t += decoded[si].size();
         std::vector<Span>& dst = per_text[t];
         dst.reserve(total_t);
+        size_t nr = 0, nt = 0;
         for (size_t si = first[t]; si < first[t + 1] && stretches[si].text_index == t; ++si)
-          for (Span& s_ : decoded[si]) dst.push_back(std::move(s_));
+          for (Span& s_ : decoded[si]) { nr += s_.variants.size(); nt += s_.ntags; dst.push_back(std::move(s_)); }
+        po.text_rows[t] = nr;
+        po.text_tags[t] = nt;
       }
     });
   }
@@ -1165,7 +1188,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     static const char* names[5] = {"arcs", "k-best", "paths", "LM + rules", "select + output"};
     for (int i = 0; i < 5; ++i) fprintf(stderr, "[anx search]   lattice part %-16s %8.2f ms (summed over threads)\n", names[i], (double)g_lat_ns[i].exchange(0) * 1e-6);
   }
-  for (auto& v : per_text) { po.total += v.size(); for (auto& s : v) { po.total_rows += s.variants.size(); po.total_tags += s.ntags; } }
+  for (size_t t = 0; t < n; ++t) { po.total += per_text[t].size(); po.total_rows += po.text_rows[t]; po.total_tags += po.text_tags[t]; }
   return ANX_OK;
 }
 
