@@ -799,7 +799,9 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
           if (r >= parts) break;
           PartOut& p = *P[r];
           if (failed.load()) { p.rc = ANX_EINVAL; continue; }
+          const auto tp = std::chrono::steady_clock::now();
           p.rc = find_all_part(model, texts + cut[r], cut[r + 1] - cut[r], sp, p);
+          if (anx::switches().search_timing) fprintf(stderr, "[anx search] part %zu, all of it          %8.2f ms\n", r, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count() * 1e3);
           if (p.rc != ANX_OK) { p.err = anx_last_error(); failed.store(true); }  // (the message is the worker thread's)
         }
       });
@@ -1189,6 +1191,14 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     for (int i = 0; i < 5; ++i) fprintf(stderr, "[anx search]   lattice part %-16s %8.2f ms (summed over threads)\n", names[i], (double)g_lat_ns[i].exchange(0) * 1e-6);
   }
   for (size_t t = 0; t < n; ++t) { po.total += per_text[t].size(); po.total_rows += po.text_rows[t]; po.total_tags += po.text_tags[t]; }
+  {  // ~50 k vectors allocated by the pool's threads: freeing them here costs this part's thread 5-10 ms; a pool thread does it instead
+    struct Garbage { std::vector<std::vector<Span>> bounds, decoded; std::vector<Stretch> stretches; };
+    auto g = std::make_shared<Garbage>();
+    g->bounds = std::move(bounds);
+    g->decoded = std::move(decoded);
+    g->stretches = std::move(stretches);
+    HostPool::get().post([g]() mutable { g.reset(); });
+  }
   return ANX_OK;
 }
 
