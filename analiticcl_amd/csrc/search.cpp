@@ -889,6 +889,8 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   // one device batch per n-gram order; the result arrays stay alive until the output has been written
   std::vector<OrderRows>& kept = po.kept;
   auto free_kept = [&]() { po.free_kept(); };
+  std::unique_ptr<char[]> arena_buf;  // the segments of an order, packed (kept over the orders)
+  size_t arena_cap = 0;
   double seg_part[5] = {0, 0, 0, 0, 0};  // timing: n-grams, arena, device batch, row views, append
   double seg_t = tnow();
   auto seg_lap = [&](int i) { if (timing) { const double t = tnow(); seg_part[i] += t - seg_t; seg_t = t; } };
@@ -935,7 +937,8 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     seg_lap(0);
     if (nseg) {
       // all segments of this order in one NUL-separated arena, every chunk writing its own part
-      std::vector<char> arena(bytes);
+      if (arena_cap < bytes) { arena_buf.reset(new char[bytes]); arena_cap = bytes; }  // (not zero-filled: every byte is written below)
+      struct { char* p; size_t n; char* data() const { return p; } size_t size() const { return n; } } arena{arena_buf.get(), bytes};
       parallel_chunks([&](size_t c) {
         const ChunkSegs& C = cs[c];
         const size_t s_lo = c * SC, s_hi = std::min(stretches.size(), s_lo + SC);
@@ -1082,8 +1085,9 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     int32_t* g_btok = reinterpret_cast<int32_t*>(blk + o_btok);
     uint32_t* out_n = reinterpret_cast<uint32_t*>(blk + o_outn);
     uint32_t* out_syms = reinterpret_cast<uint32_t*>(blk + o_outs);
-    std::vector<SymRef> osym(T.sym);
-    std::vector<uint32_t> lat_of(T.st);  // lattice -> stretch
+    // (plain arrays, not zero-filled vectors: every entry is written by the copy below; 20 MB of zeroes per part otherwise)
+    std::unique_ptr<SymRef[]> osym(new SymRef[std::max<size_t>(1, T.sym)]);
+    std::unique_ptr<uint32_t[]> lat_of(new uint32_t[std::max<size_t>(1, T.st)]);  // lattice -> stretch
     parallel_for(nch, 1, 2, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
         const anx::LatInput& P = part[c];
