@@ -208,6 +208,8 @@ size_t host_cache_limit() {
   return lim;
 }
 }  // namespace
+static std::atomic<uint64_t> g_host_hits{0}, g_host_misses{0}, g_host_miss_bytes{0};
+void host_result_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* miss_bytes) { *hits = g_host_hits.load(); *misses = g_host_misses.load(); *miss_bytes = g_host_miss_bytes.load(); }
 void* host_result_alloc(size_t bytes) {
   HostCache& hc = host_cache();
   bytes = (std::max<size_t>(bytes, 64) + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);  // whole MB: a few distinct sizes
@@ -218,9 +220,12 @@ void* host_result_alloc(size_t bytes) {
       void* p = it->second;
       hc.cached -= it->first;
       hc.free_blocks.erase(it);
+      ++g_host_hits;
       return p;
     }
   }
+  ++g_host_misses;
+  g_host_miss_bytes += bytes;
   void* p = nullptr;
   bool pinned = hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p;  // portable: the replicas of a multi-device model download into one buffer
   if (!pinned) {

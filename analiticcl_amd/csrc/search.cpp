@@ -841,6 +841,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     t_write = std::chrono::duration<double>(tb - ta).count();
     t_reset = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
   }
+  if (timing) { uint64_t h, mi, mb; anx::host_result_cache_stats(&h, &mi, &mb); fprintf(stderr, "[anx search]   pinned result cache since load: %llu hits, %llu misses (%.0f MB pinned afresh)\n", (unsigned long long)h, (unsigned long long)mi, (double)mb / 1048576.0); }
   if (timing) fprintf(stderr, "[anx search]   output: writing %.2f ms, releasing the parts %.2f ms\n", t_write * 1e3, t_reset * 1e3);
   if (timing) fprintf(stderr, "[anx search] output (%zu parts)            %8.2f ms\n", parts, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count() * 1e3);
   *out_matches = om;
@@ -886,7 +887,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
       for (Stretch& x : v) stretches.push_back(std::move(x));
   }
   lap("boundaries");
-  // one device batch per n-gram order; the result arrays stay alive until the output has been written
+  // the result arrays of the device batches stay alive until the output has been written
   std::vector<OrderRows>& kept = po.kept;
   auto free_kept = [&]() { po.free_kept(); };
   std::unique_ptr<char[]> arena_buf;  // the segments of an order, packed (kept over the orders)
@@ -894,64 +895,79 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   double seg_part[5] = {0, 0, 0, 0, 0};  // timing: n-grams, arena, device batch, row views, append
   double seg_t = tnow();
   auto seg_lap = [&](int i) { if (timing) { const double t = tnow(); seg_part[i] += t - seg_t; seg_t = t; } };
-  for (uint32_t order = 1; order <= sp->max_ngram; ++order) {
+  // Two device batches per part, not one per n-gram order: the unigrams, then the segments of every higher order together -- whether
+  // a higher-order segment is looked up (redundant_match, src/search.rs:317-336) only depends on the unigrams' results.
+  // The segments of an order, chunk by chunk: 64 consecutive stretches share one segment vector (a vector per stretch and order
+  // meant a quarter of a million small blocks allocated by one thread and freed by another: the allocator's arenas became the
+  // bottleneck of this phase).
+  const size_t SC = 64, nsc = (stretches.size() + SC - 1) / SC;
+  struct ChunkSegs { std::vector<Span> segs; std::vector<uint8_t> look; std::vector<uint32_t> first; };  // first[j]: first segment of the chunk's j-th stretch
+  auto parallel_chunks = [&](const std::function<void(size_t)>& work) {
+    parallel_for(nsc, 4, 8, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) work(c); });
+  };
+  for (uint32_t o_lo = 1; o_lo <= sp->max_ngram; o_lo = (o_lo == 1 ? 2 : sp->max_ngram + 1)) {
+    const uint32_t o_hi = o_lo == 1 ? 1 : sp->max_ngram, no = o_hi - o_lo + 1;
     seg_lap(4);
-    // The segments of this order, chunk by chunk: 64 consecutive stretches share one segment vector (a vector per stretch and
-    // order meant a quarter of a million small blocks allocated by one thread and freed by another: the allocator's arenas
-    // became the bottleneck of this phase).
-    const size_t SC = 64, nsc = (stretches.size() + SC - 1) / SC;
-    struct ChunkSegs { std::vector<Span> segs; std::vector<uint8_t> look; std::vector<uint32_t> first; };  // first[j]: first segment of the chunk's j-th stretch
-    std::vector<ChunkSegs> cs(nsc);
-    auto parallel_chunks = [&](const std::function<void(size_t)>& work) {
-      parallel_for(nsc, 4, 8, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) work(c); });
-    };
-    // per stretch: first segment / first arena byte of its looked-up segments (counts first, prefix sums below)
-    std::vector<size_t> seg0(stretches.size() + 1, 0), byte0(stretches.size() + 1, 0);
+    std::vector<std::vector<ChunkSegs>> cs(no, std::vector<ChunkSegs>(nsc));
+    // per order and stretch: first segment / first arena byte of its looked-up segments within the batch (counts first, prefix sums
+    // below; the batch holds the group's orders one after the other)
+    std::vector<std::vector<size_t>> seg0(no, std::vector<size_t>(stretches.size() + 1, 0)), byte0(no, std::vector<size_t>(stretches.size() + 1, 0));
     parallel_chunks([&](size_t c) {
-      ChunkSegs& C = cs[c];
       const size_t s_lo = c * SC, s_hi = std::min(stretches.size(), s_lo + SC);
       size_t nbound = 0;
       for (size_t si = s_lo; si < s_hi; ++si) nbound += stretches[si].b1 - stretches[si].b0 + 1;
-      C.segs.reserve(nbound);  // at most one segment per boundary
-      C.first.reserve(s_hi - s_lo + 1);
-      for (size_t si = s_lo; si < s_hi; ++si) {
-        Stretch& st = stretches[si];
-        C.first.push_back((uint32_t)C.segs.size());
-        find_match_ngrams(texts[st.text_index], bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, C.segs);
-      }
-      C.first.push_back((uint32_t)C.segs.size());
-      C.look.resize(C.segs.size());
-      for (size_t si = s_lo; si < s_hi; ++si) {
-        const Stretch& st = stretches[si];
-        size_t ns = 0, nb = 0;
-        for (uint32_t k = C.first[si - s_lo]; k < C.first[si - s_lo + 1]; ++k) {
-          C.look[k] = (order == 1 || !redundant_match(C.segs[k], st.matches)) ? 1 : 0;
-          if (C.look[k]) { ++ns; nb += C.segs[k].end - C.segs[k].begin + 1; }
+      for (uint32_t oi = 0; oi < no; ++oi) {
+        const uint32_t order = o_lo + oi;
+        ChunkSegs& C = cs[oi][c];
+        C.segs.reserve(nbound);  // at most one segment per boundary
+        C.first.reserve(s_hi - s_lo + 1);
+        for (size_t si = s_lo; si < s_hi; ++si) {
+          Stretch& st = stretches[si];
+          C.first.push_back((uint32_t)C.segs.size());
+          find_match_ngrams(texts[st.text_index], bounds[st.text_index].data() + st.b0, st.b1 - st.b0, order, st.begin, st.end, C.segs);
         }
-        seg0[si + 1] = ns;
-        byte0[si + 1] = nb;
+        C.first.push_back((uint32_t)C.segs.size());
+        C.look.resize(C.segs.size());
+        for (size_t si = s_lo; si < s_hi; ++si) {
+          const Stretch& st = stretches[si];
+          size_t ns = 0, nb = 0;
+          for (uint32_t k = C.first[si - s_lo]; k < C.first[si - s_lo + 1]; ++k) {
+            C.look[k] = (order == 1 || !redundant_match(C.segs[k], st.matches)) ? 1 : 0;
+            if (C.look[k]) { ++ns; nb += C.segs[k].end - C.segs[k].begin + 1; }
+          }
+          seg0[oi][si + 1] = ns;
+          byte0[oi][si + 1] = nb;
+        }
       }
     });
-    for (size_t si = 0; si < stretches.size(); ++si) { seg0[si + 1] += seg0[si]; byte0[si + 1] += byte0[si]; }
-    const size_t nseg = seg0[stretches.size()], bytes = byte0[stretches.size()];
+    size_t nseg = 0, bytes = 0;
+    for (uint32_t oi = 0; oi < no; ++oi) {
+      seg0[oi][0] = nseg;
+      byte0[oi][0] = bytes;
+      for (size_t si = 0; si < stretches.size(); ++si) { seg0[oi][si + 1] += seg0[oi][si]; byte0[oi][si + 1] += byte0[oi][si]; }
+      nseg = seg0[oi][stretches.size()];
+      bytes = byte0[oi][stretches.size()];
+    }
     seg_lap(0);
     if (nseg) {
-      // all segments of this order in one NUL-separated arena, every chunk writing its own part
+      // all segments of the group in one NUL-separated arena, every chunk writing its own parts
       if (arena_cap < bytes) { arena_buf.reset(new char[bytes]); arena_cap = bytes; }  // (not zero-filled: every byte is written below)
       struct { char* p; size_t n; char* data() const { return p; } size_t size() const { return n; } } arena{arena_buf.get(), bytes};
       parallel_chunks([&](size_t c) {
-        const ChunkSegs& C = cs[c];
         const size_t s_lo = c * SC, s_hi = std::min(stretches.size(), s_lo + SC);
-        for (size_t si = s_lo; si < s_hi; ++si) {
-          const char* text = texts[stretches[si].text_index];
-          char* w = arena.data() + byte0[si];
-          for (uint32_t k = C.first[si - s_lo]; k < C.first[si - s_lo + 1]; ++k)
-            if (C.look[k]) {
-              const size_t l = C.segs[k].end - C.segs[k].begin;
-              memcpy(w, text + C.segs[k].begin, l);
-              w[l] = '\0';
-              w += l + 1;
-            }
+        for (uint32_t oi = 0; oi < no; ++oi) {
+          const ChunkSegs& C = cs[oi][c];
+          for (size_t si = s_lo; si < s_hi; ++si) {
+            const char* text = texts[stretches[si].text_index];
+            char* w = arena.data() + byte0[oi][si];
+            for (uint32_t k = C.first[si - s_lo]; k < C.first[si - s_lo + 1]; ++k)
+              if (C.look[k]) {
+                const size_t l = C.segs[k].end - C.segs[k].begin;
+                memcpy(w, text + C.segs[k].begin, l);
+                w[l] = '\0';
+                w += l + 1;
+              }
+          }
         }
       });
       seg_lap(1);
@@ -971,12 +987,14 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
         }
       } else {  // more segments than one device batch holds: the pointer form splits them
         std::vector<const char*> ptrs(nseg);
-        size_t i = 0;
-        for (size_t si = 0; si < stretches.size(); ++si) {
-          const ChunkSegs& C = cs[si / SC];
-          const char* w = arena.data() + byte0[si];
-          for (uint32_t k = C.first[si % SC]; k < C.first[si % SC + 1]; ++k)
-            if (C.look[k]) { ptrs[i++] = w; w += C.segs[k].end - C.segs[k].begin + 1; }
+        for (uint32_t oi = 0; oi < no; ++oi) {
+          size_t i = seg0[oi][0];
+          for (size_t si = 0; si < stretches.size(); ++si) {
+            const ChunkSegs& C = cs[oi][si / SC];
+            const char* w = arena.data() + byte0[oi][si];
+            for (uint32_t k = C.first[si % SC]; k < C.first[si % SC + 1]; ++k)
+              if (C.look[k]) { ptrs[i++] = w; w += C.segs[k].end - C.segs[k].begin + 1; }
+          }
         }
         rc = anx_find_variants_batch(model, ptrs.data(), nseg, &sp->base, &rows, &offs);
       }
@@ -984,24 +1002,26 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
       kept.push_back(OrderRows{rows, offs});
       seg_lap(2);
     }
-    // row views + the order's segments behind the stretch's matches
+    // row views + the group's segments behind the stretch's matches, order by order
     const OrderRows* orows_cur = nseg ? &kept.back() : nullptr;
     parallel_chunks([&](size_t c) {
-      ChunkSegs& C = cs[c];
       const size_t s_lo = c * SC, s_hi = std::min(stretches.size(), s_lo + SC);
       for (size_t si = s_lo; si < s_hi; ++si) {
-        size_t i = seg0[si];
-        const uint32_t k0 = C.first[si - s_lo], k1 = C.first[si - s_lo + 1];
-        for (uint32_t k = k0; k < k1; ++k)
-          if (C.look[k]) {
-            Span& sg = C.segs[k];
-            sg.has_variants = true;
-            sg.variants = RowView{orows_cur->rows + orows_cur->offs[i], orows_cur->offs[i + 1] - orows_cur->offs[i]};
-            ++i;
-          }
         std::vector<Span>& mv = stretches[si].matches;  // one allocation per stretch for all orders
-        if (order == 1) mv.reserve((size_t)(k1 - k0) * sp->max_ngram + 1);
-        mv.insert(mv.end(), C.segs.begin() + k0, C.segs.begin() + k1);
+        for (uint32_t oi = 0; oi < no; ++oi) {
+          ChunkSegs& C = cs[oi][c];
+          size_t i = seg0[oi][si];
+          const uint32_t k0 = C.first[si - s_lo], k1 = C.first[si - s_lo + 1];
+          for (uint32_t k = k0; k < k1; ++k)
+            if (C.look[k]) {
+              Span& sg = C.segs[k];
+              sg.has_variants = true;
+              sg.variants = RowView{orows_cur->rows + orows_cur->offs[i], orows_cur->offs[i + 1] - orows_cur->offs[i]};
+              ++i;
+            }
+          if (o_lo == 1) mv.reserve((size_t)(k1 - k0) * sp->max_ngram + 1);
+          mv.insert(mv.end(), C.segs.begin() + k0, C.segs.begin() + k1);
+        }
       }
     });
     seg_lap(3);
