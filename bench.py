@@ -578,7 +578,7 @@ def extra_configs(args, paths, device, ncores):
                                              "achieved": (nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": (nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0), "valu_issue_frac": None, "traffic": None,
                                              "launches_per_call": lat_n / 5.0,
-                                             "note": "ms = all k_lattice launches of one call; one wave per stretch, K <= 250 serial pops of a wave-wide minimum: "
+                                             "note": "ms = all k_lattice launches of one call; two stretches per wave, K <= 250 serial pops of a group-wide minimum each: "
                                                      "latency-bound, and the call as a whole is bound by its host phases (MB_per_s)"})(
                     lat_ms / 5.0, int(ra.shape[0]) * 16 + int(off[-1]) * (16 + 8)),
                 "parity": f"ok ({nchk} texts = {8 * nchk} sentences vs the oracle twin)"}
