@@ -1024,6 +1024,10 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
         }
       }
     });
+    {  // the group's segment vectors were allocated by the pool's threads: a pool thread frees them (see the end of this function)
+      auto g = std::make_shared<std::vector<std::vector<ChunkSegs>>>(std::move(cs));
+      HostPool::get().post([g]() mutable { g.reset(); });
+    }
     seg_lap(3);
   }
   seg_lap(4);
