@@ -50,13 +50,15 @@ struct DeviceLm {  // per replica: the bigram terms and the token lists of the v
   size_t built_vocab = 0, built_bigrams = 0;
 };
 
-struct LNode {   // one of the K best paths into a state: 24 B
+struct LNode {   // one of the K best paths into a state: 12 B, written for every node
   float cost;
   uint32_t par;  // source state << 16 | rank there; 0xFFFFFFFF = the start node
   uint32_t sym;  // local symbol id, 0xFFFFFFFF = epsilon
-  float lp;      // LM: f32 sum of the bigram terms of the path prefix
-  uint32_t n;    // LM: tokens summed | 0x80000000 = the node lies on a final path
-  int32_t prev;  // LM: last token (-1 = out of vocabulary)
+};
+struct LmNode {  // the LM side of a node, only written for the nodes that lie on a final path (the marks): 12 B
+  float lp;      // f32 sum of the bigram terms of the path prefix
+  uint32_t n;    // tokens summed
+  int32_t prev;  // last token (-1 = out of vocabulary)
 };
 
 struct LatArgs {
@@ -69,6 +71,8 @@ struct LatArgs {
   const uint32_t* btok_off;  // per (stretch, boundary) CSR into btok; a stretch owns nb + 1 entries
   const int32_t* btok;
   LNode* nodes;              // node pool of this launch
+  LmNode* lm;                // [same index]: LM sums of the marked nodes
+  uint8_t* marks;            // a byte per node ((K + 3) & ~3 per state): the node lies on one of the final paths
   uint32_t K;
   uint32_t ring_max;         // cost lists the LDS ring of this launch holds (LatStretch::ring above it: host fallback)
   uint32_t cnt_cap;          // states (virtual end state included) of the launch's longest stretch: size of the per-state counts in LDS
@@ -153,13 +157,17 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
       if (ioff[d + 1] - ioff[d] > 2u * G) { alive = false; break; }  // group-uniform
   if (have && !alive && gl == 0) a.out_n[si] = 0xFFFFFFFFu;  // not decoded here: the host decoder takes it
   LNode* __restrict__ nodes = a.nodes + (size_t)(S.node0);
+  LmNode* __restrict__ lmn = a.lm + (size_t)(S.node0);
+  const uint32_t MK = (K + 3u) & ~3u;  // mark bytes per state
+  uint8_t* __restrict__ marks = a.marks + (size_t)(S.node0 / K) * MK;
   const uint32_t ring = S.ring ? S.ring : 1u;
   uint32_t nsmax = alive ? ns : 0u;  // the wave's states loop runs as long as its longest stretch
 #pragma unroll
   for (int o = 32; o >= (int)G && o < 64; o >>= 1) nsmax = max(nsmax, (uint32_t)__shfl_xor((int)nsmax, o));
   // ---- k best paths into every state ----------------------------------------------------------------------------------------
   if (alive && gl == 0) {
-    nodes[0] = LNode{0.0f, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0f, 0u, 0};  // the start node: <bos> (token 0), nothing summed yet
+    nodes[0] = LNode{0.0f, 0xFFFFFFFFu, 0xFFFFFFFFu};  // the start node
+    if (a.use_lm) lmn[0] = LmNode{0.0f, 0u, 0};        // <bos> (token 0), nothing summed yet
     s_cnt[0] = 1;
     s_ring[0] = 0.0f;
   }
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
       for (uint32_t r = gl; r < count; r += G) {
         const uint32_t pk = s_par[r];
         const LatArc arc = a.arcs[S.arc0 + a0 + (pk >> 16)];
-        nodes[(size_t)d * K + r] = LNode{mine[r], (arc.src << 16) | (pk & 0xFFFFu), arc.sym, 0.0f, 0u, 0};
+        nodes[(size_t)d * K + r] = LNode{mine[r], (arc.src << 16) | (pk & 0xFFFFu), arc.sym};
       }
   }
   const uint32_t end = ns - 1u;
@@ -249,27 +257,39 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   if (alive && npaths == 0) { if (gl == 0) a.out_n[si] = 0xFFFFFFFFu; alive = false; }  // no complete path (cannot happen: the epsilon chain): host
   // ---- LM: (log-probability sum, tokens, last token) of every node on a final path -------------------------------------------
   if (a.use_lm) {
-    for (uint32_t i = gl; i < npaths; i += G) {  // mark: a node's prefix is needed once, whoever asks for it
-      uint32_t st_ = end, r = i;
-      for (;;) {
-        LNode& nd = nodes[(size_t)st_ * K + r];
-        if (nd.n & 0x80000000u) break;  // (a racing lane marks the same chain: harmless)
-        nd.n = 0x80000000u;
-        if (nd.par == 0xFFFFFFFFu) break;
-        st_ = nd.par >> 16;
-        r = nd.par & 0xFFFFu;
-      }
+    // The nodes on the final paths, state by state from the end: a marked node marks its parent (a byte per node in HBM, plain
+    // stores of 1 -- every writer stores the same; the parent lies in an earlier state, so a state's marks are complete when its
+    // turn comes).  One pass of ~nstates steps with every lane at work, instead of one walk per final path (250 walks of ~20
+    // dependent loads, 8 of them per lane).
+    if (alive) {
+      uint32_t* __restrict__ mw = reinterpret_cast<uint32_t*>(marks);
+      for (uint32_t w = gl; w < ns * (MK / 4u); w += G) mw[w] = 0u;
     }
     __syncthreads();
+    if (alive)
+      for (uint32_t i = gl; i < npaths; i += G) marks[(size_t)end * MK + i] = 1;
+    __syncthreads();
+    for (uint32_t dd = 1; dd < nsmax; ++dd) {  // (the wave's loop runs as long as its longest stretch)
+      if (alive && dd < ns) {
+        const uint32_t d = ns - dd;  // end .. 1
+        const uint32_t cnt = s_cnt[d];
+        for (uint32_t r = gl; r < cnt; r += G)
+          if (marks[(size_t)d * MK + r]) {
+            const uint32_t par = nodes[(size_t)d * K + r].par;
+            if (par != 0xFFFFFFFFu) marks[(size_t)(par >> 16) * MK + (par & 0xFFFFu)] = 1;
+          }
+      }
+      __syncthreads();
+    }
     const uint32_t* __restrict__ boff = a.btok_off + S.btok_off0;
     for (uint32_t d = 1; d < nsmax; ++d) {
       const uint32_t cnt = (alive && d < ns) ? s_cnt[d] : 0u;
       for (uint32_t r = gl; r < cnt; r += G) {
-        LNode& nd = nodes[(size_t)d * K + r];
-        if (!(nd.n & 0x80000000u)) continue;
-        const LNode& pa = nodes[(size_t)(nd.par >> 16) * K + (nd.par & 0xFFFFu)];
+        if (!marks[(size_t)d * MK + r]) continue;
+        const LNode nd = nodes[(size_t)d * K + r];
+        const LmNode pa = lmn[(size_t)(nd.par >> 16) * K + (nd.par & 0xFFFFu)];
         float lp = pa.lp;
-        uint32_t n = pa.n & 0x7FFFFFFFu;
+        uint32_t n = pa.n;
         int32_t prev = pa.prev;
         if (nd.sym != 0xFFFFFFFFu) {  // the tokens of the symbol: its n-gram parts, then the boundary text behind it (src/lib.rs:2580-2629)
           const LatSym sy = a.syms[S.sym0 + nd.sym];
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
             lp += lat_term(a, prev, t); ++n; prev = t;
           }
         }
-        nd.lp = lp; nd.n = n | 0x80000000u; nd.prev = prev;
+        lmn[(size_t)d * K + r] = LmNode{lp, n, prev};
       }
       __syncthreads();
     }
@@ -295,8 +315,9 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   for (uint32_t i = gl; i < npaths; i += G) {
     const LNode& nd = nodes[(size_t)end * K + i];
     if (a.use_lm) {
-      const float logprob = nd.lp + lat_term(a, nd.prev, 1);  // <eos>
-      const double ppl = -1.0 / (double)((nd.n & 0x7FFFFFFFu) + 1u) * (double)logprob;
+      const LmNode lm = lmn[(size_t)end * K + i];
+      const float logprob = lm.lp + lat_term(a, lm.prev, 1);  // <eos>
+      const double ppl = -1.0 / (double)(lm.n + 1u) * (double)logprob;
       if (ppl < best_ppl) best_ppl = ppl;
     }
     if (nd.cost < best_cost) best_cost = nd.cost;
@@ -315,8 +336,9 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     const LNode& nd = nodes[(size_t)end * K + i];
     double norm_lm = 0.0;
     if (a.use_lm) {
-      const float logprob = nd.lp + lat_term(a, nd.prev, 1);
-      const double ppl = -1.0 / (double)((nd.n & 0x7FFFFFFFu) + 1u) * (double)logprob;
+      const LmNode lm = lmn[(size_t)end * K + i];
+      const float logprob = lm.lp + lat_term(a, lm.prev, 1);
+      const double ppl = -1.0 / (double)(lm.n + 1u) * (double)logprob;
       norm_lm = portable_log(best_ppl / ppl);
     }
     const double norm_var = portable_log((double)best_cost / (double)nd.cost);
@@ -500,6 +522,10 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   if ((rc = dalloc_((void**)&d_index, n * 4))) return rc;
   HIP_TRY(hipMemcpyAsync(d_index, order.data(), n * 4, hipMemcpyHostToDevice, st));
   if ((rc = dalloc_((void**)&d_nodes, max_pool * sizeof(LNode)))) return rc;
+  LmNode* d_lm = nullptr;
+  uint8_t* d_marks = nullptr;
+  const bool lm_on = m.have_lm && p.lm_weight > 0.0f;
+  if (lm_on && ((rc = dalloc_((void**)&d_lm, max_pool * sizeof(LmNode))) || (rc = dalloc_((void**)&d_marks, max_pool / K * ((K + 3u) & ~3u))))) return rc;
   HIP_TRY(hipMemcpyAsync(d_st, hst.data(), n * sizeof(LatStretch), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_inoff, in.in_off, in.nin * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_arcs, in.arcs, in.narcs * sizeof(LatArc), hipMemcpyHostToDevice, st));
@@ -507,7 +533,7 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   HIP_TRY(hipMemcpyAsync(d_boff, in.btok_off, in.nboff * 4, hipMemcpyHostToDevice, st));
   if (in.nbtok) HIP_TRY(hipMemcpyAsync(d_btok, in.btok, in.nbtok * 4, hipMemcpyHostToDevice, st));
   LatArgs a;
-  a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.K = K;
+  a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.lm = d_lm; a.marks = d_marks; a.K = K;
   a.use_lm = (m.have_lm && p.lm_weight > 0.0f) ? 1 : 0;
   a.lm_weight = p.lm_weight; a.variantmodel_weight = p.variantmodel_weight; a.contextrules_weight = p.contextrules_weight;
   a.bg_key = lm->bg_key; a.bg_val = lm->bg_val; a.bg_mask = lm->bg_mask; a.ngram_off = lm->ngram_off; a.ngram_ids = lm->ngram_ids; a.nvocab = lm->nvocab;
