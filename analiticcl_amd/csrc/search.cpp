@@ -536,12 +536,20 @@ void most_likely_sequence(const HostModel& m, const char* text, std::vector<Span
   lat.lap(4);
 }
 
-// The lattice of one stretch in the flat form lattice.hip decodes (same arcs, same order as most_likely_sequence builds them):
-// appended to `L` (a chunk-local LatInput), symbols' (match, variant) kept for the output in `osym`.  Returns false when the
-// stretch needs no decoding (no symbols / no final state: the matches pass through, src/lib.rs:2277-2290).
+// The lattice of one stretch in the flat form lattice.hip decodes (same arcs, same order as most_likely_sequence builds them), written
+// straight into the call's arrays (pinned host memory) at the cursors of `K`: a chunk of stretches owns a region of every array, sized
+// by upper bounds, so the chunks build side by side and nothing is copied afterwards (the regions' unused tails stay as gaps: a
+// stretch addresses its own parts by absolute offsets).  The symbols' (match, variant) go to `refs` at the symbols' positions.
+// Returns false when the stretch needs no decoding (no symbols / no final state: the matches pass through, src/lib.rs:2277-2290).
 struct SymRef { uint32_t match_index; int32_t variant_index; };
+struct LatSink {
+  uint32_t* in_off; anx::LatArc* arcs; anx::LatSym* syms; SymRef* refs; uint32_t* btok_off; int32_t* btok;
+  size_t in_pos, arc_pos, sym_pos, boff_pos, btok_pos, out_pos;      // cursors (absolute indices)
+  size_t in_end, arc_end, sym_end, boff_end, btok_end;               // the region's ends
+  bool overflow = false;                                             // an upper bound did not hold (a bug: the call fails)
+};
 bool build_lattice(const HostModel& m, const char* text, const std::vector<Span>& matches, const Span* bs, size_t nb, size_t end_offset,
-                   const anx_search_params& p, bool use_lm, anx::LatInput& L, std::vector<SymRef>& osym) {
+                   const anx_search_params& p, bool use_lm, LatSink& K, anx::LatStretch& S) {
   const size_t nstates = nb + 1;
   struct Arc { float cost; uint32_t dst; uint32_t sym; };
   static thread_local std::vector<std::vector<Arc>> arcs;
@@ -579,16 +587,6 @@ bool build_lattice(const HostModel& m, const char* text, const std::vector<Span>
   }
   if (syms.empty() || finals.empty()) return false;
   for (size_t i = 0; i < nb; ++i) arcs[i].push_back(Arc{100.0f, (uint32_t)i + 1, 0xFFFFFFFFu});  // failsafe epsilon transitions
-  anx::LatStretch S;
-  S.nstates = (uint32_t)nstates;
-  S.in_off0 = (uint32_t)L.in_off.size();
-  S.arc0 = (uint32_t)L.arcs.size();
-  S.sym0 = (uint32_t)L.syms.size();
-  S.btok_off0 = (uint32_t)L.btok_off.size();
-  S.btok0 = (uint32_t)L.btok.size();
-  S.out0 = (uint32_t)L.out_total;
-  S.best_cost_init = (float)(nb - 1) * 2.0f;
-  S.node0 = 0;
   // incoming arcs per state in (source state, arc number) order, then the virtual end state behind the finals
   static thread_local std::vector<uint32_t> indeg;
   indeg.assign(nstates + 2, 0u);
@@ -597,38 +595,56 @@ bool build_lattice(const HostModel& m, const char* text, const std::vector<Span>
   indeg[nstates + 1] = (uint32_t)finals.size();
   for (size_t d = 1; d <= nstates + 1; ++d) indeg[d] += indeg[d - 1];
   const size_t narcs = indeg[nstates + 1];
-  const size_t a0 = L.arcs.size();
-  L.arcs.resize(a0 + narcs);
-  for (size_t d = 0; d <= nstates + 1; ++d) L.in_off.push_back(indeg[d]);  // [d] = first incoming arc of state d; nstates + 2 entries
+  if (K.in_pos + nstates + 2 > K.in_end || K.arc_pos + narcs > K.arc_end || K.sym_pos + syms.size() > K.sym_end ||
+      K.boff_pos + nb + 1 > K.boff_end) { K.overflow = true; return false; }
+  S.nstates = (uint32_t)nstates;
+  S.in_off0 = (uint32_t)K.in_pos;
+  S.arc0 = (uint32_t)K.arc_pos;
+  S.sym0 = (uint32_t)K.sym_pos;
+  S.btok_off0 = (uint32_t)K.boff_pos;
+  S.btok0 = (uint32_t)K.btok_pos;
+  S.out0 = (uint32_t)K.out_pos;
+  S.best_cost_init = (float)(nb - 1) * 2.0f;
+  S.node0 = 0;
+  for (size_t d = 0; d <= nstates + 1; ++d) K.in_off[K.in_pos + d] = indeg[d];  // [d] = first incoming arc of state d; nstates + 2 entries
+  K.in_pos += nstates + 2;
+  anx::LatArc* out_arcs = K.arcs + K.arc_pos;
   static thread_local std::vector<uint32_t> cur;
   cur.assign(indeg.begin(), indeg.end());
-  for (size_t sidx = 0; sidx < nstates; ++sidx)
-    for (const Arc& a : arcs[sidx]) L.arcs[a0 + cur[a.dst]++] = anx::LatArc{a.cost, (uint32_t)sidx, a.sym};
-  for (uint32_t f : finals) L.arcs[a0 + cur[nstates]++] = anx::LatArc{0.0f, f, 0xFFFFFFFFu};
   uint32_t span = 1;
   for (size_t sidx = 0; sidx < nstates; ++sidx)
-    for (const Arc& a : arcs[sidx]) span = std::max(span, a.dst - (uint32_t)sidx);
-  for (uint32_t f : finals) span = std::max(span, (uint32_t)nstates - f);
+    for (const Arc& a : arcs[sidx]) {
+      out_arcs[cur[a.dst]++] = anx::LatArc{a.cost, (uint32_t)sidx, a.sym};
+      span = std::max(span, a.dst - (uint32_t)sidx);
+    }
+  for (uint32_t f : finals) {
+    out_arcs[cur[nstates]++] = anx::LatArc{0.0f, f, 0xFFFFFFFFu};
+    span = std::max(span, (uint32_t)nstates - f);
+  }
+  K.arc_pos += narcs;
   S.ring = span + 1;
-  L.syms.insert(L.syms.end(), syms.begin(), syms.end());
-  osym.insert(osym.end(), refs.begin(), refs.end());
+  memcpy(K.syms + K.sym_pos, syms.data(), syms.size() * sizeof(anx::LatSym));
+  memcpy(K.refs + K.sym_pos, refs.data(), refs.size() * sizeof(SymRef));
+  K.sym_pos += syms.size();
   // LM tokens of the boundary text behind a symbol (src/lib.rs:2606-2629): once per boundary
+  const size_t btok0 = K.btok_pos;
   for (size_t bi = 0; bi < nb; ++bi) {
-    L.btok_off.push_back((uint32_t)(L.btok.size() - S.btok0));
+    K.btok_off[K.boff_pos++] = (uint32_t)(K.btok_pos - btok0);
     if (!use_lm) continue;
     const Span& nbs = bs[bi];
     if (!(nbs.end - nbs.begin == 1 && text[nbs.begin] == ' ') && nbs.end > nbs.begin) {
       const std::string bt = anx::trim_whitespace(std::string(text + nbs.begin, nbs.end - nbs.begin));
       if (!bt.empty()) {
         auto it = m.encoder.find(bt);
-        if (it != m.encoder.end()) for (uint32_t k = m.ngram_off[it->second]; k < m.ngram_off[it->second + 1]; ++k) L.btok.push_back((int32_t)m.ngram_ids[k]);
-        else L.btok.push_back(-1);
+        const size_t nt = it != m.encoder.end() ? m.ngram_off[it->second + 1] - m.ngram_off[it->second] : 1;
+        if (K.btok_pos + nt > K.btok_end) { K.overflow = true; return false; }
+        if (it != m.encoder.end()) for (uint32_t k = m.ngram_off[it->second]; k < m.ngram_off[it->second + 1]; ++k) K.btok[K.btok_pos++] = (int32_t)m.ngram_ids[k];
+        else K.btok[K.btok_pos++] = -1;
       }
     }
   }
-  L.btok_off.push_back((uint32_t)(L.btok.size() - S.btok0));
-  L.out_total += nstates;  // a path has at most one symbol per state it enters
-  L.st.push_back(S);
+  K.btok_off[K.boff_pos++] = (uint32_t)(K.btok_pos - btok0);
+  K.out_pos += nstates;  // a path has at most one symbol per state it enters
   return true;
 }
 
@@ -1049,55 +1065,49 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   std::vector<uint8_t> done(stretches.size(), 0);
   if (on_device) {
     const bool use_lm = m.have_lm && sp->lm_weight > 0.0f;
-    // chunks of stretches build their part of the flat lattice input side by side; the parts are then laid end to end
+    // Chunks of stretches build their lattices side by side, straight into the call's arrays: ONE pinned block (the result cache of
+    // engine.hip) [stretches | in_off | arcs | syms | btok_off | btok | out_n | out_syms], in which every chunk owns a region of each
+    // array sized by upper bounds (symbols <= one per variant or match; arcs <= symbols + an epsilon per boundary + the finals; LM
+    // tokens of a boundary <= its bytes + 1).  Until round 4 the chunks built vectors of their own that were copied into the block.
     const size_t CH = 256, nch = (stretches.size() + CH - 1) / CH;
-    std::vector<anx::LatInput> part(nch);
-    std::vector<std::vector<SymRef>> part_sym(nch);
-    std::vector<std::vector<uint32_t>> part_idx(nch);  // the stretches of the chunk that have a lattice
-    parallel_for(nch, 1, 2, [&](size_t lo, size_t hi) {
+    struct Base { size_t in, arc, sym, boff, btok, out; };
+    std::vector<Base> base(nch + 1, Base{0, 0, 0, 0, 0, 0});
+    parallel_for(nch, 4, 8, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
-        {  // room for the chunk's lattices up front: its vectors grow by hundreds of thousands of arcs otherwise, copying as they go
-          size_t nsym = 0, nstate = 0;
-          const size_t s0 = c * CH, s1 = std::min(stretches.size(), (c + 1) * CH);
-          for (size_t si = s0; si < s1; ++si) {
-            for (const Span& mt : stretches[si].matches) nsym += mt.variants.empty() ? 1 : mt.variants.size();
-            nstate += stretches[si].b1 - stretches[si].b0 + 1;
-          }
-          part[c].st.reserve(s1 - s0);
-          part[c].syms.reserve(nsym);
-          part_sym[c].reserve(nsym);
-          part[c].arcs.reserve(nsym + 2 * nstate + 4 * (s1 - s0));
-          part[c].in_off.reserve(nstate + 2 * (s1 - s0));
-          part[c].btok_off.reserve(nstate + (s1 - s0));
-          part_idx[c].reserve(s1 - s0);
-        }
+        Base B{0, 0, 0, 0, 0, 0};
         for (size_t si = c * CH; si < std::min(stretches.size(), (c + 1) * CH); ++si) {
-          Stretch& st = stretches[si];
-          if (build_lattice(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end, *sp, use_lm,
-                            part[c], part_sym[c]))
-            part_idx[c].push_back((uint32_t)si);
-          else { decoded[si].insert(decoded[si].end(), st.matches.begin(), st.matches.end()); done[si] = 1; }  // src/lib.rs:2277-2290
+          const Stretch& st = stretches[si];
+          const size_t nb = st.b1 - st.b0;
+          size_t nsym = 0;
+          for (const Span& mt : st.matches) nsym += mt.variants.empty() ? 1 : mt.variants.size();
+          B.sym += nsym;
+          B.arc += nsym + 2 * nb + 1;
+          B.in += nb + 3;
+          B.boff += nb + 1;
+          B.out += nb + 1;
+          if (use_lm) {
+            const Span* bs = bounds[st.text_index].data() + st.b0;
+            for (size_t bi = 0; bi < nb; ++bi) B.btok += bs[bi].end - bs[bi].begin + 1;
+          }
         }
+        base[c + 1] = B;  // (sizes; the prefix sums follow)
       }
     });
-    // The whole call's lattices in ONE pinned block (the result cache of engine.hip): [stretches | in_off | arcs | syms | btok_off |
-    // btok | out_n | out_syms]; the chunk parts are copied into place side by side, the uploads run at PCIe speed.
-    struct Base { size_t st, in, arc, sym, boff, btok, out; };
-    std::vector<Base> base(nch + 1, Base{0, 0, 0, 0, 0, 0, 0});
     for (size_t c = 0; c < nch; ++c) {
-      const anx::LatInput& P = part[c];
-      base[c + 1] = Base{base[c].st + P.st.size(), base[c].in + P.in_off.size(), base[c].arc + P.arcs.size(), base[c].sym + P.syms.size(),
-                         base[c].boff + P.btok_off.size(), base[c].btok + P.btok.size(), base[c].out + P.out_total};
+      const Base& A = base[c];
+      Base& B = base[c + 1];
+      B = Base{A.in + B.in, A.arc + B.arc, A.sym + B.sym, A.boff + B.boff, A.btok + B.btok, A.out + B.out};
     }
     const Base T = base[nch];
-    if (T.arc >= ((size_t)1 << 32) || T.sym >= ((size_t)1 << 32) || T.in >= ((size_t)1 << 32) || T.out >= ((size_t)1 << 32)) {
+    if (T.arc >= ((size_t)1 << 32) || T.sym >= ((size_t)1 << 32) || T.in >= ((size_t)1 << 32) || T.out >= ((size_t)1 << 32) || T.btok >= ((size_t)1 << 32)) {
       free_kept();
       return anx_fail(ANX_ELIMIT, "more than 2^32 lattice arcs in one call: split the texts");
     }
+    const size_t max_st = stretches.size();
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
-    const size_t o_st = 0, o_in = o_st + al(T.st * sizeof(anx::LatStretch)), o_arc = o_in + al(T.in * 4), o_sym = o_arc + al(T.arc * sizeof(anx::LatArc)),
-                 o_boff = o_sym + al(T.sym * sizeof(anx::LatSym)), o_btok = o_boff + al(T.boff * 4), o_outn = o_btok + al(T.btok * 4),
-                 o_outs = o_outn + al(T.st * 4), o_end = o_outs + al(std::max<size_t>(1, T.out) * 4);
+    const size_t o_st = 0, o_in = o_st + al(max_st * sizeof(anx::LatStretch)), o_arc = o_in + al(T.in * 4), o_sym = o_arc + al(T.arc * sizeof(anx::LatArc)),
+                 o_boff = o_sym + al(T.sym * sizeof(anx::LatSym)), o_btok = o_boff + al(T.boff * 4), o_outn = o_btok + al(std::max<size_t>(1, T.btok) * 4),
+                 o_outs = o_outn + al(max_st * 4), o_end = o_outs + al(std::max<size_t>(1, T.out) * 4);
     char* blk = static_cast<char*>(anx::host_result_alloc(o_end));
     if (!blk) { free_kept(); return anx_fail(ANX_EINVAL, "out of memory"); }
     struct BlkFree { char* p; ~BlkFree() { anx::host_result_free(p); } } blk_free{blk};
@@ -1109,40 +1119,50 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     int32_t* g_btok = reinterpret_cast<int32_t*>(blk + o_btok);
     uint32_t* out_n = reinterpret_cast<uint32_t*>(blk + o_outn);
     uint32_t* out_syms = reinterpret_cast<uint32_t*>(blk + o_outs);
-    // (plain arrays, not zero-filled vectors: every entry is written by the copy below; 20 MB of zeroes per part otherwise)
+    // (plain arrays, not zero-filled vectors: 20 MB of zeroes per part otherwise)
     std::unique_ptr<SymRef[]> osym(new SymRef[std::max<size_t>(1, T.sym)]);
-    std::unique_ptr<uint32_t[]> lat_of(new uint32_t[std::max<size_t>(1, T.st)]);  // lattice -> stretch
+    std::unique_ptr<uint32_t[]> lat_of(new uint32_t[std::max<size_t>(1, max_st)]);  // lattice -> stretch
+    std::vector<std::vector<anx::LatStretch>> part_st(nch);  // the chunk's lattices, in stretch order
+    std::vector<std::vector<uint32_t>> part_idx(nch);        // ... and their stretches
+    std::atomic<bool> overflow{false};
     parallel_for(nch, 1, 2, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
-        const anx::LatInput& P = part[c];
-        const Base& B = base[c];
-        for (size_t i = 0; i < P.st.size(); ++i) {
-          anx::LatStretch S = P.st[i];
-          S.in_off0 += (uint32_t)B.in; S.arc0 += (uint32_t)B.arc; S.sym0 += (uint32_t)B.sym; S.btok_off0 += (uint32_t)B.boff; S.btok0 += (uint32_t)B.btok; S.out0 += (uint32_t)B.out;
-          g_st[B.st + i] = S;
-          lat_of[B.st + i] = part_idx[c][i];
+        const size_t s0 = c * CH, s1 = std::min(stretches.size(), (c + 1) * CH);
+        const Base &B = base[c], &E = base[c + 1];
+        LatSink K{g_in, g_arc, g_sym, osym.get(), g_boff, g_btok, B.in, B.arc, B.sym, B.boff, B.btok, B.out, E.in, E.arc, E.sym, E.boff, E.btok};
+        part_st[c].reserve(s1 - s0);
+        part_idx[c].reserve(s1 - s0);
+        for (size_t si = s0; si < s1; ++si) {
+          Stretch& st = stretches[si];
+          anx::LatStretch S;
+          if (build_lattice(m, texts[st.text_index], st.matches, bounds[st.text_index].data() + st.b0, st.b1 - st.b0, st.end, *sp, use_lm, K, S)) {
+            part_st[c].push_back(S);
+            part_idx[c].push_back((uint32_t)si);
+          } else { decoded[si].insert(decoded[si].end(), st.matches.begin(), st.matches.end()); done[si] = 1; }  // src/lib.rs:2277-2290
         }
-        if (!P.in_off.empty()) memcpy(g_in + B.in, P.in_off.data(), P.in_off.size() * sizeof(uint32_t));
-        if (!P.arcs.empty()) memcpy(g_arc + B.arc, P.arcs.data(), P.arcs.size() * sizeof(anx::LatArc));
-        if (!P.syms.empty()) { memcpy(g_sym + B.sym, P.syms.data(), P.syms.size() * sizeof(anx::LatSym)); memcpy(&osym[B.sym], part_sym[c].data(), P.syms.size() * sizeof(SymRef)); }
-        if (!P.btok_off.empty()) memcpy(g_boff + B.boff, P.btok_off.data(), P.btok_off.size() * sizeof(uint32_t));
-        if (!P.btok.empty()) memcpy(g_btok + B.btok, P.btok.data(), P.btok.size() * sizeof(int32_t));
-        part[c] = anx::LatInput();
-        std::vector<SymRef>().swap(part_sym[c]);
+        if (K.overflow) overflow.store(true);
       }
     });
+    if (overflow.load()) { free_kept(); return anx_fail(ANX_ELIMIT, "internal error: a lattice outgrew the bounds of its chunk"); }
+    size_t nlat = 0;  // the lattices, dense and in stretch order (the arrays they point into keep their gaps)
+    for (size_t c = 0; c < nch; ++c) {
+      if (!part_st[c].empty()) memcpy(g_st + nlat, part_st[c].data(), part_st[c].size() * sizeof(anx::LatStretch));
+      for (size_t i = 0; i < part_idx[c].size(); ++i) lat_of[nlat + i] = part_idx[c][i];
+      nlat += part_st[c].size();
+    }
+    struct { size_t st, in, arc, sym, boff, btok, out; } const TT{nlat, T.in, T.arc, T.sym, T.boff, T.btok, T.out};
     lap("lattice input");
-    const anx::LatView L{g_st, T.st, g_in, T.in, g_arc, T.arc, g_sym, T.sym, g_boff, T.boff, g_btok, T.btok, T.out};
+    const anx::LatView L{g_st, TT.st, g_in, TT.in, g_arc, TT.arc, g_sym, TT.sym, g_boff, TT.boff, g_btok, TT.btok, TT.out};
     {  // every replica of the model decodes a contiguous share of the lattices (balanced by lattice nodes), each from a thread of its own
       size_t nrep = 0;
       while (anx_replica_of(model, nrep)) ++nrep;
-      if (T.st < (size_t)std::max<long>(1, anx::switches().shard_min / 2) * nrep) nrep = 1;  // (ANX_SHARD_MIN: 4096 lattices per replica by default)
-      std::vector<size_t> cut(nrep + 1, T.st);
+      if (TT.st < (size_t)std::max<long>(1, anx::switches().shard_min / 2) * nrep) nrep = 1;  // (ANX_SHARD_MIN: 4096 lattices per replica by default)
+      std::vector<size_t> cut(nrep + 1, TT.st);
       cut[0] = 0;
       if (nrep > 1) {
         size_t total_nodes = 0, run = 0, r = 1;
-        for (size_t i = 0; i < T.st; ++i) total_nodes += g_st[i].nstates + 1;
-        for (size_t i = 0; i < T.st && r < nrep; ++i) {
+        for (size_t i = 0; i < TT.st; ++i) total_nodes += g_st[i].nstates + 1;
+        for (size_t i = 0; i < TT.st && r < nrep; ++i) {
           run += g_st[i].nstates + 1;
           if (run * nrep >= total_nodes * r) cut[r++] = i + 1;
         }
@@ -1160,7 +1180,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
         if (rcs[r] != ANX_OK) { free_kept(); return anx_fail(rcs[r], errs[r]); }
     }
     lap("lattice on the device");
-    parallel_for(T.st, 256, 512, [&](size_t lo, size_t hi) {
+    parallel_for(TT.st, 256, 512, [&](size_t lo, size_t hi) {
       for (size_t li = lo; li < hi; ++li) {
         if (out_n[li] == 0xFFFFFFFFu) continue;  // handed back: the host decoder below
         const size_t si = lat_of[li];
