@@ -1438,9 +1438,11 @@ struct anx_pipeline {
   bool stop = false;
   uint64_t next_seq = 0;
   void* streams[2] = {nullptr, nullptr};
+  void* enc_stream = nullptr;  // the encode thread's own stream (single-replica models)
   std::thread th[3];
 };
 static void pipeline_stage(anx_pipeline* pl, int stage) {
+  if (stage == 0 && pl->enc_stream) anx::encoder_stream_set_override(pl->enc_stream);
   for (;;) {
     std::shared_ptr<PipeJob> job;
     {
@@ -1487,9 +1489,11 @@ anx_pipeline* anx_pipeline_new(const anx_model* m, int depth) {
   pl->depth = depth > 0 ? (size_t)depth : 6;
   if (m->replicas.size() == 1) {  // a multi-replica model runs every shard on its replica's own stream
     std::string err;
+    pl->enc_stream = anx::stream_create(m->replicas[0].device, err);  // (nullptr: the encoder's pooled streams)
     for (void*& st : pl->streams)
       if (!(st = anx::stream_create(m->replicas[0].device, err))) {
         for (void* x : pl->streams) if (x) anx::stream_destroy(m->replicas[0].device, x);
+        if (pl->enc_stream) anx::stream_destroy(m->replicas[0].device, pl->enc_stream);
         delete pl;
         fail(ANX_ENODEVICE, err);
         return nullptr;
@@ -1553,6 +1557,7 @@ void anx_pipeline_free(anx_pipeline* pl) {
   pl->cv.notify_all();
   for (std::thread& t : pl->th) t.join();
   for (void* st : pl->streams) if (st) anx::stream_destroy(pl->m->replicas[0].device, st);
+  if (pl->enc_stream) anx::stream_destroy(pl->m->replicas[0].device, pl->enc_stream);
   delete pl;
 }
 

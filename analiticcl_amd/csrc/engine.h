@@ -26,6 +26,7 @@ void* stream_create(int device, std::string& err);
 void stream_destroy(int device, void* stream);
 void* host_result_alloc(size_t bytes);
 void host_result_free(void* p);
+void encoder_stream_set_override(void* stream);  // this thread's encodes (and lattice decodes) use `stream` (nullptr: the pool's streams again)
 void host_result_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* miss_bytes);  // since the library was loaded (diagnosis)
 
 // keep_text: the inputs' bytes stay on the device with the batch (confusable weighting on the device reads them)

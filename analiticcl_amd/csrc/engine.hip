@@ -90,7 +90,12 @@ DevPool& pool_of(int device) {
 }  // namespace
 // A private non-blocking stream for one encoder call (encode.hip): on the legacy NULL stream every encode would serialise with
 // the in-flight batches of other host threads that run on blocking streams.  Streams are kept per device and reused.
+// A thread may bring its own encoder stream (anx_pipeline's encode thread: created together with the pipeline's run streams, so that
+// the runtime's least-used-hardware-queue rule puts the three on different queues -- see anx_pipeline_new).
+static thread_local hipStream_t t_encoder_stream = nullptr;
+void encoder_stream_set_override(void* s) { t_encoder_stream = reinterpret_cast<hipStream_t>(s); }
 hipStream_t encoder_stream_acquire(int device) {
+  if (t_encoder_stream) return t_encoder_stream;
   DevPool& pl = pool_of(device);
   {
     std::lock_guard<std::mutex> g(pl.mu);
@@ -101,7 +106,7 @@ hipStream_t encoder_stream_acquire(int device) {
   return s;
 }
 void encoder_stream_release(int device, hipStream_t s) {
-  if (!s) return;
+  if (!s || s == t_encoder_stream) return;
   DevPool& pl = pool_of(device);
   std::lock_guard<std::mutex> g(pl.mu);
   pl.idle_streams.push_back(s);

@@ -235,7 +235,8 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
         bref.run(stream_handle)
         want = digest(bref.fetch_compact())
         bref.free()
-        pl = A_.Pipeline(model, depth=6)
+        PD = int(os.environ.get("ANX_BENCH_PIPE_DEPTH", "6"))  # EXPERIMENT
+        pl = A_.Pipeline(model, depth=PD)
         got_ok = True
 
         def pipe_pass(njobs, check):
@@ -245,7 +246,7 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
             for _k in range(njobs):
                 pl.submit(packed, len(queries), params)
                 sub += 1
-                if sub >= 6:
+                if sub >= PD:
                     last = pl.next()
                     sub -= 1
                     if check:
@@ -259,8 +260,8 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
             got_ok = digest(last) == want and got_ok
             return njobs * args.queries / dt
         pipe_pass(8, True)   # every batch of this pass is checked (and the pools of the extra buffers warm up); hashing 70 MB per
-        passes = sorted(pipe_pass(16, False) for _ in range(7))  # best and median of seven passes: sporadic ~10 ms stalls of single
-        pipelined, pipelined_median = passes[-1], passes[3]     # jobs (any stage) cost a pass 15 % each
+        passes = sorted(pipe_pass(40, False) for _ in range(5))  # best and median of five passes of 40 jobs (filling and draining the
+        pipelined, pipelined_median = passes[-1], passes[2]     # pipeline is inside the timed pass: ~6 % at this length)
         # batch would dominate a timed loop: there the last batch stands for all
         pl.close()
         e2e = {"queries_per_s": args.queries / best[0], "two_threads_queries_per_s": piped,
