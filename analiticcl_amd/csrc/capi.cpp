@@ -115,6 +115,7 @@ static int fail(int code, const std::string& msg) {
 
 const anx::HostModel& anx_host_of(const anx_model* m) { return m->host; }
 const anx::DeviceLexicon* anx_replica_of(const anx_model* m, size_t i) { return i < m->replicas.size() ? m->replicas[i].dev : nullptr; }
+int anx_replica_device(const anx_model* m, size_t i) { return i < m->replicas.size() ? m->replicas[i].device : -1; }
 int anx_fail(int code, const std::string& msg) { return fail(code, msg); }
 
 

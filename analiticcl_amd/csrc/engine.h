@@ -26,6 +26,8 @@ void* stream_create(int device, std::string& err);
 void stream_destroy(int device, void* stream);
 void* host_result_alloc(size_t bytes);
 void host_result_free(void* p);
+void* thread_stream_begin(int device);            // see engine.hip; nullptr = nothing to end
+void thread_stream_end(int device, void* stream);
 void encoder_stream_set_override(void* stream);  // this thread's encodes (and lattice decodes) use `stream` (nullptr: the pool's streams again)
 void host_result_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* miss_bytes);  // since the library was loaded (diagnosis)
 

@@ -118,6 +118,21 @@ struct DeviceGuard {
   DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+// One stream for everything a host thread sends to the device during a stretch of work (a part of a search-mode call: its batches'
+// encodes and runs, its lattices): taken from the encoder's pool, installed as the thread's encoder stream, handed back at the end.
+void* thread_stream_begin(int device) {
+  if (t_encoder_stream) return nullptr;  // the thread brought its own
+  DeviceGuard guard;  // (the pool may have to create the stream: on the replica's device, not on the thread's current one)
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  hipStream_t s = encoder_stream_acquire(device);
+  t_encoder_stream = s;
+  return s;
+}
+void thread_stream_end(int device, void* s) {
+  if (!s) return;
+  t_encoder_stream = nullptr;
+  encoder_stream_release(device, reinterpret_cast<hipStream_t>(s));
+}
 // streams of the replicas of a multi-device model (capi.cpp owns them; HIP stays behind this file)
 void* stream_create(int device, std::string& err) {
   DeviceGuard guard;

@@ -37,7 +37,8 @@ void anx_results_free(anx_result*, size_t*);
 int anx_last_error_code(void);
 }
 const anx::HostModel& anx_host_of(const anx_model* m);  // capi.cpp
-const anx::DeviceLexicon* anx_replica_of(const anx_model* m, size_t i);  // capi.cpp
+const anx::DeviceLexicon* anx_replica_of(const anx_model* m, size_t i);
+int anx_replica_device(const anx_model* m, size_t i);  // capi.cpp
 int anx_fail(int code, const std::string& msg);         // capi.cpp
 
 namespace {
@@ -876,6 +877,12 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   const HostModel& m = anx_host_of(model);
   if (!m.built || m.lex.nclasses == 0)  // src/lib.rs:1801-1805 (the reference eprintln!s and returns no matches)
     return anx_fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() before find_all_matches()");
+  // One stream for everything this part sends to the device (the encodes and runs of its batches, its lattices): with four parts in
+  // flight that is four streams for the runtime's four hardware queues, instead of four encoder streams plus the NULL stream for
+  // the runs, mapped however the threads' first calls happened to fall.  (Multi-replica models: every shard runs on its replica's.)
+  struct PartStream { int dev; void* s; ~PartStream() { anx::thread_stream_end(dev, s); } };
+  const bool one_replica = anx_replica_of(model, 0) && !anx_replica_of(model, 1);
+  PartStream part_stream{anx_replica_device(model, 0), one_replica ? anx::thread_stream_begin(anx_replica_device(model, 0)) : nullptr};
   std::vector<std::vector<Span>> bounds(n);
   std::vector<Stretch> stretches;
   auto parallel_for = [&](size_t count, size_t chunk, size_t serial_below, const std::function<void(size_t, size_t)>& work) { pool_for(count, chunk, serial_below, work); };
@@ -993,7 +1000,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
       if (nseg <= ((size_t)4 << 20) && arena.size() < ((size_t)1 << 32)) {
         // the arena IS the packed form of the batch (every segment followed by a NUL byte): it goes to the device as it is
         anx_batch* bt = anx_batch_encode_packed(model, arena.data(), arena.size(), nseg, &sp->base);
-        rc = bt ? anx_batch_run(model, bt, nullptr) : ANX_EINVAL;
+        rc = bt ? anx_batch_run(model, bt, part_stream.s) : ANX_EINVAL;
         if (bt && rc == ANX_OK) rc = anx_batch_fetch(bt, &rows, &offs);
         if (bt) anx_batch_free(bt);
         if (!bt) {  // code and message of the failed encode stay in anx_last_error_code() / anx_last_error()

@@ -35,6 +35,8 @@ void* stream_create(int, std::string&) { return malloc(1); }
 void stream_destroy(int, void* s) { free(s); }
 void* host_result_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void encoder_stream_set_override(void*) {}
+void* thread_stream_begin(int) { return nullptr; }
+void thread_stream_end(int, void*) {}
 void host_result_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* miss_bytes) { *hits = *misses = *miss_bytes = 0; }
 void host_result_free(void* p) { free(p); }
 void batch_set_run_mode(Batch*, const anx_params&, int) {}
