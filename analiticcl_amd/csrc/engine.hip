@@ -214,7 +214,8 @@ static void pool_trim(int device) {
 // Pinned host buffers for the downloaded results.  A fresh malloc'd buffer of 141 MB (1 M queries of config 2) is pageable and
 // untouched: the D2H copy is staged and page-faults its way through it (~20 ms); a pinned buffer takes the rows at PCIe speed.
 // Pinning costs more than the copy, so freed buffers are kept (anx_results_free returns them here) up to ANX_PINNED_CACHE_MB
-// (default 1024); anx_device_pool_trim releases them.  Without a HIP device the buffers are plain malloc blocks.
+// (default 2048: a pipeline of 6-8 batches of a million queries in flight, 75-140 MB of rows each, outgrew 1024 and pinned afresh
+// for every batch at half the rate); anx_device_pool_trim releases them.  Without a HIP device the buffers are plain malloc blocks.
 namespace {
 struct HostCache {
   std::mutex mu;
@@ -224,7 +225,7 @@ struct HostCache {
 };
 HostCache& host_cache() { static HostCache c; return c; }
 size_t host_cache_limit() {
-  static const size_t lim = []() { const char* e = getenv("ANX_PINNED_CACHE_MB"); const long long v = e ? atoll(e) : -1; return v >= 0 ? (size_t)v << 20 : (size_t)1 << 30; }();
+  static const size_t lim = []() { const char* e = getenv("ANX_PINNED_CACHE_MB"); const long long v = e ? atoll(e) : -1; return v >= 0 ? (size_t)v << 20 : (size_t)2 << 30; }();
   return lim;
 }
 }  // namespace
