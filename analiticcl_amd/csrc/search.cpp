@@ -88,11 +88,13 @@ class HostPool {
   }
   unsigned width() const { return nthreads_ + 1; }
   // f() on a pool thread, not waited for (on the caller when there is no pool thread); shutdown() runs what is still queued
+  // (a queue of its own, served by the pool's threads when no loop has work for them: a caller waiting for its loop in run() takes
+  // loop tasks only -- it must not spend milliseconds of its critical path on somebody's frees)
   void post(std::function<void()> f) {
     if (!nthreads_) { f(); return; }
     {
       std::lock_guard<std::mutex> g(mu_);
-      q_.push_back(std::move(f));
+      bg_.push_back(std::move(f));
     }
     cv_.notify_one();
   }
@@ -135,10 +137,10 @@ class HostPool {
           std::function<void()> f;
           {
             std::unique_lock<std::mutex> l(mu_);
-            cv_.wait(l, [&]() { return stop_ || !q_.empty(); });
-            if (q_.empty()) return;  // stop_ and nothing left to do
-            f = std::move(q_.front());
-            q_.pop_front();
+            cv_.wait(l, [&]() { return stop_ || !q_.empty() || !bg_.empty(); });
+            if (!q_.empty()) { f = std::move(q_.front()); q_.pop_front(); }
+            else if (!bg_.empty()) { f = std::move(bg_.front()); bg_.pop_front(); }
+            else return;  // stop_ and nothing left to do
           }
           f();
         }
@@ -150,6 +152,7 @@ class HostPool {
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<std::function<void()>> q_;
+  std::deque<std::function<void()>> bg_;  // post(): run when no loop task waits
 };
 
 struct RowView {  // the ranked variants of a segment: a range of one n-gram order's result array (kept until the end)
