@@ -92,11 +92,14 @@ class HostPool {
   // loop tasks only -- it must not spend milliseconds of its critical path on somebody's frees)
   void post(std::function<void()> f) {
     if (!nthreads_) { f(); return; }
+    std::function<void()> overdue;  // loops that never leave the pool idle must not let posted work pile up: the poster then takes the oldest
     {
       std::lock_guard<std::mutex> g(mu_);
       bg_.push_back(std::move(f));
+      if (bg_.size() > 16) { overdue = std::move(bg_.front()); bg_.pop_front(); }
     }
     cv_.notify_one();
+    if (overdue) overdue();
   }
   // body() on up to `helpers` pool threads and on the caller; returns when every started body has returned.  A caller that waits
   // takes queued tasks itself, so loops started from inside a pool thread cannot starve each other.
