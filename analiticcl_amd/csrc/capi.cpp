@@ -319,10 +319,19 @@ int anx_model_to_devices(anx_model* m, const int* devices, int n) {
   std::string err;
   anx::EncodeTables et;
   anx::build_encode_tables(m->host.alphabet, et);
+  // the signature adjacency lists (adjacency.h): built once per call, uploaded to every replica, not kept on the host
+  std::unique_ptr<anx::AdjIndex> adj;
+  if (anx::switches().scan_adj && m->host.lex.nsym <= 32) {
+    adj.reset(new anx::AdjIndex());
+    anx::build_adjacency(m->host.lex, anx::switches().adj_closure, (size_t)anx::switches().adj_budget_mb << 20, anx::usable_hw_threads(), *adj);
+    if (getenv("ANX_ADJ_TIMING"))
+      fprintf(stderr, "[anx adjacency] %u lexicon signatures, %u in the closure, %u lists, %llu records in %llu rows (%.1f MB), %.1f ms\n", adj->nsig_lexicon,
+              adj->nsig_closure, adj->nsig_kept, (unsigned long long)adj->records, (unsigned long long)adj->rows, adj->rows * 64.0 * 12.0 / 1e6, adj->build_ms);
+  }
   for (int i = 0; i < n; ++i) {
     Replica r;
     r.device = devices[i];
-    r.dev = anx::lexicon_upload(m->host.lex, et, devices[i], err);
+    r.dev = anx::lexicon_upload(m->host.lex, et, adj.get(), devices[i], err);
     if (r.dev && n > 1 && !(r.stream = anx::stream_create(devices[i], err))) { anx::lexicon_free(r.dev); r.dev = nullptr; }
     if (!r.dev) { drop_replicas(m); return fail(ANX_ENODEVICE, err); }
     if (n > 1) r.worker.reset(new Worker());
@@ -334,6 +343,55 @@ int anx_model_to_devices(anx_model* m, const int* devices, int n) {
 int anx_model_to_device(anx_model* m, int device) { return anx_model_to_devices(m, &device, 1); }
 int anx_model_num_replicas(const anx_model* m) { return m ? (int)m->replicas.size() : 0; }
 int anx_model_replica_device(const anx_model* m, int i) { return (m && i >= 0 && (size_t)i < m->replicas.size()) ? m->replicas[(size_t)i].device : -1; }
+int anx_debug_signature(const anx_model* m, const char* utf8, uint64_t* out_sig) {
+  if (!m || !utf8 || !out_sig) return fail(ANX_EINVAL, "NULL argument");
+  if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet!");
+  std::vector<uint8_t> norm, cv;
+  if (!m->host.encode(utf8, norm, cv)) return fail(ANX_ELIMIT, "more than 255 symbols");
+  cv.resize((size_t)m->host.lex.nplanes * 4, 0);
+  *out_sig = anx::signature_of(cv.data(), cv.size(), m->host.lex.sym_group);
+  return ANX_OK;
+}
+int anx_debug_entries(const anx_model* m, uint32_t** out_vocab_ids, size_t* n) {
+  if (!m || !out_vocab_ids || !n) return fail(ANX_EINVAL, "NULL argument");
+  if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet!");
+  const std::vector<uint32_t>& v = m->host.lex.ent_vocab;
+  uint32_t* o = static_cast<uint32_t*>(malloc(std::max<size_t>(v.size(), 1) * sizeof(uint32_t)));
+  if (!o) return fail(ANX_ELIMIT, "out of memory");
+  if (!v.empty()) memcpy(o, v.data(), v.size() * sizeof(uint32_t));
+  *out_vocab_ids = o;
+  *n = v.size();
+  return ANX_OK;
+}
+int anx_debug_adjacency(const anx_model* m, int closure, uint64_t budget_bytes, const uint64_t* sigs, size_t n, uint32_t* out_cum, uint32_t** out_ids,
+                        uint64_t* out_stats) {
+  if (!m || (!sigs && n) || (!out_cum && n) || !out_ids) return fail(ANX_EINVAL, "NULL argument");
+  if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet!");
+  anx::AdjIndex adj;
+  anx::build_adjacency(m->host.lex, closure, (size_t)budget_bytes, anx::usable_hw_threads(), adj);
+  if (out_stats) { out_stats[0] = adj.nsig_lexicon; out_stats[1] = adj.nsig_closure; out_stats[2] = adj.nsig_kept; out_stats[3] = adj.records; out_stats[4] = adj.rows; out_stats[5] = (uint64_t)adj.build_ms; }
+  size_t total = 0;
+  std::vector<uint32_t> h1(n);
+  for (size_t i = 0; i < n; ++i) {
+    h1[i] = adj.find((uint32_t)sigs[i], (uint32_t)(sigs[i] >> 32));
+    if (h1[i]) total += (size_t)adj.hdr[h1[i] - 1].cum[anx::kAdjSections - 1] * anx::kAdjRow;
+  }
+  uint32_t* ids = static_cast<uint32_t*>(malloc(std::max<size_t>(total, 1) * sizeof(uint32_t)));
+  if (!ids) return fail(ANX_ELIMIT, "out of memory");
+  size_t pos = 0;
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t* c = out_cum + i * (anx::kAdjSections + 1);
+    if (!h1[i]) { for (int s = 0; s <= anx::kAdjSections; ++s) c[s] = 0xFFFFFFFFu; continue; }
+    const anx::AdjHdr& h = adj.hdr[h1[i] - 1];
+    c[0] = (uint32_t)(pos / anx::kAdjRow);  // first row of this list in *out_ids
+    for (int s = 0; s < anx::kAdjSections; ++s) c[s + 1] = h.cum[s];
+    const size_t cnt = (size_t)h.cum[anx::kAdjSections - 1] * anx::kAdjRow;
+    memcpy(ids + pos, adj.ids + (size_t)h.row0 * anx::kAdjRow, cnt * sizeof(uint32_t));
+    pos += cnt;
+  }
+  *out_ids = ids;
+  return ANX_OK;
+}
 int anx_debug_set_switch(const char* name, const char* value) {
   return anx::set_switch(name, value) ? ANX_OK : fail(ANX_EINVAL, "unknown switch");
 }

@@ -410,7 +410,21 @@ struct TileArgs {
   uint32_t* ctr;        // [3] = SAD tiles
   const uint32_t* ball_tab;  // ball_off[13] ++ ball_n[13] (DeviceLexicon::ball_tab)
   int probe;            // tiles may probe the signature hash table (ANX_SCAN_WALK=flat: never)
+  const uint4* adj_hash;  // signature adjacency lists (adjacency.h): {sig lo, sig hi, header index + 1, rows}; adj_mask 0 = none
+  uint32_t adj_mask;
 };
+// header index + 1 of the signature's adjacency list (0 = none), *rows = its length
+__device__ inline uint32_t adj_lookup(const uint4* tab, uint32_t mask, uint32_t lo, uint32_t hi, uint32_t* rows) {
+  if (!mask) return 0u;
+  uint32_t h = sig_hash(lo, hi) & mask;
+  for (int p = 0; p < 17; ++p) {  // every key within 16 slots of its home
+    const uint4 e = tab[h];
+    if (!e.z) return 0u;
+    if (e.x == lo && e.y == hi) { *rows = e.w; return e.z; }
+    h = (h + 1u) & mask;
+  }
+  return 0u;
+}
 __device__ inline bool same_segment(const TileArgs& t, uint32_t a, uint32_t b) {
   return (t.s_kind[a] == 0) == (t.s_kind[b] == 0) && (t.q_meta[a] & 0xFFu) == (t.q_meta[b] & 0xFFu) && t.s_sig[a] == t.s_sig[b];
 }
@@ -476,18 +490,28 @@ __global__ __launch_bounds__(256) void k_tile_emit(TileArgs t) {
   tile_window(t, s, s0, s1, step, nparts, ball0, balln);
   const unsigned long long sig = t.s_sig[s];
   const uint32_t base = t.tcount[s];
+  uint32_t adj_rows = 0;
+  const uint32_t adj = (!sad && k <= (uint32_t)kAdjRadius) ? adj_lookup(t.adj_hash, t.adj_mask, (uint32_t)sig, (uint32_t)(sig >> 32), &adj_rows) : 0u;
   for (uint32_t part = 0; part < nparts; ++part) {
     const uint32_t a0 = s0 + part * step, a1 = min(s1, a0 + step);
     Tile tl;
     tl.q0 = s; tl.nq = tn; tl.s0 = a0; tl.s1 = a1; tl.k = k; tl.lq = lq; tl.sig_lo = (uint32_t)sig; tl.sig_hi = (uint32_t)(sig >> 32);
     tl.kind = sad ? 0u : 1u; tl.d = d; tl.kend = sad ? 0u : (ke[0] | ke[1] << 8 | ke[2] << 16);
-    tl.ball0 = ball0; tl.balln = balln;
+    tl.ball0 = ball0; tl.balln = balln; tl.adj = adj;
     t.tiles[base + part] = tl;
     // longest-processing-time first, bit-plane tiles before the count-vector ones: ascending key, stable
-    const unsigned long long cost = (unsigned long long)tn * (a1 - a0 + 64u);
-    t.tkey[base + part] = (sad ? 0x80000000u : 0u) | (0x7FFFFFFFu - (uint32_t)(cost < 0x7FFFFFFFull ? cost : 0x7FFFFFFFull));
+    // (a tile that streams an adjacency list: rows x (set-up + a test per query); the others: the signatures of their window)
+    const unsigned long long cost = adj ? (unsigned long long)adj_rows * (8u + tn) + 16u : (unsigned long long)tn * (a1 - a0 + 64u);
+    // order: tiles with an adjacency list (k_scan_adj) | other bit-plane tiles | count-vector tiles
+    t.tkey[base + part] = (sad ? 0x80000000u : adj ? 0u : 0x40000000u) | (0x3FFFFFFFu - (uint32_t)(cost < 0x3FFFFFFFull ? cost : 0x3FFFFFFFull));
   }
   if (sad) atomicAdd(&t.ctr[3], nparts);
+}
+
+// ctr[5] = number of leading tiles with an adjacency list (the tiles are sorted: those come first)
+__global__ __launch_bounds__(256) void k_tile_adj_count(const Tile* tiles, uint32_t n, uint32_t* ctr) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && tiles[i].adj && (i + 1 == n || !tiles[i + 1].adj)) ctr[5] = i + 1u;
 }
 
 // ---- host driver --------------------------------------------------------------------------------------------------------
@@ -546,7 +570,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   int rc;
   if (blob_len + 4 * (size_t)n + 16 >= ((size_t)1 << 32)) { err = "inputs exceed 4 GB per batch (bytes + 4 per string): split the batch"; return ANX_ELIMIT; }
   if (n == 0) {  // nothing to encode: empty query arrays (the launches below do not take an empty grid)
-    b->nq = 0; b->dmax = 0; b->qw = 1; b->ntiles = 0; b->n_sad_tiles = 0;
+    b->nq = 0; b->dmax = 0; b->qw = 1; b->ntiles = 0; b->n_sad_tiles = 0; b->n_adj_tiles = 0;
     if ((rc = balloc(&b->q_rec, 0, err)) || (rc = balloc(&b->qexact, 0, err)) || (rc = balloc(&b->q_cv, 0, err)) || (rc = balloc(&b->q_bits, 0, err)) ||
         (rc = balloc(&b->q_rows, 0, err)) || (rc = balloc(&b->q_meta, 0, err)) || (rc = balloc(&b->q_orig, 0, err)) || (rc = balloc(&b->d_tiles, 0, err)))
       return rc;
@@ -631,6 +655,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
     return rc;
   b->ntiles = 0;
   b->n_sad_tiles = 0;
+  b->n_adj_tiles = 0;
   if (nq == 0) {
     if ((rc = balloc(&b->d_tiles, 0, err))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
@@ -650,6 +675,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   ta.tq = switches().scan_tq ? (uint32_t)switches().scan_tq : SCAN_TQ_DEFAULT;
   ta.nq = nq; ta.q_meta = b->q_meta; ta.s_kind = s_kind; ta.s_sig = s_sig; ta.siglen_begin = dl->alpha.siglen_begin; ta.ctr = d_ctr;
   ta.ball_tab = dl->ball_tab; ta.probe = probe_enabled() ? 1 : 0;
+  ta.adj_hash = dl->adj_hash; ta.adj_mask = switches().scan_adj ? dl->adj_mask : 0u;
   uint32_t *d_head = nullptr, *d_tcount = nullptr;
   if ((rc = sc.get(&d_head, nq, err)) || (rc = sc.get(&d_tcount, (size_t)nq + 1, err))) return rc;
   ta.head = d_head; ta.tcount = d_tcount; ta.tiles = nullptr; ta.tkey = nullptr;
@@ -684,12 +710,14 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
     hipLaunchKernelGGL(k_iota, gt, dim3(256), 0, st, tperm_a, ntiles);
     if ((rc = sort_pairs(tkey_a, tkey_b, tperm_a, tperm_b, ntiles, 0, 32, sc, st, err))) return rc;
     hipLaunchKernelGGL(k_gather<Tile>, gt, dim3(256), 0, st, t_unsorted, tperm_b, b->d_tiles, ntiles);
+    hipLaunchKernelGGL(k_tile_adj_count, gt, dim3(256), 0, st, b->d_tiles, ntiles, d_ctr);
   }
   HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   b->ntiles = ntiles;
   b->n_sad_tiles = h_ctr[3];
+  b->n_adj_tiles = h_ctr[5];
   lap("tiles");
   return ANX_OK;
 }

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "host_model.h"
+#include "adjacency.h"
 
 namespace anx {
 
@@ -12,7 +13,8 @@ struct DeviceLexicon;  // HBM-resident SoA lexicon
 struct Batch;          // encoded queries + pipeline buffers + results, HBM-resident
 
 int device_count(std::string& err);
-DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, int device, std::string& err);
+// adj: the signature adjacency lists of the image (adjacency.h; nullptr = none: every scan tile probes its ball itself)
+DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, const AdjIndex* adj, int device, std::string& err);
 void lexicon_free(DeviceLexicon*);
 // test hook: the band-match bound of the scan / scoring kernels on n (query row, candidate row) pairs (engine.hip k_debug_band_bound)
 int debug_band_bound(int device, const uint8_t* q_rows, const uint8_t* c_rows, const uint8_t* lq, const uint8_t* lc, size_t n, int d, int form,

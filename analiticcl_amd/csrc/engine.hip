@@ -332,7 +332,7 @@ static int dalloc(T** dst, size_t count, std::string& err) {
   return ANX_OK;
 }
 
-DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, int device, std::string& err) {
+DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, const AdjIndex* adj, int device, std::string& err) {
   DeviceGuard guard;
   int n = device_count(err);
   if (n <= 0) {
@@ -468,6 +468,19 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, i
     return nullptr;
   }
   d->alpha.nlower = (uint32_t)(et.lower.size() / 2);
+  if (adj && !adj->hash.empty() && img.nsym <= 32) {  // signature adjacency lists (adjacency.h): streamed by the bit-plane scan
+    static_assert(sizeof(AdjSlot) == sizeof(uint4) && sizeof(AdjHdr) == 32 && sizeof(AdjPlanes) == sizeof(uint2), "adjacency records");
+    if ((rc = upload(reinterpret_cast<AdjSlot**>(&d->adj_hash), adj->hash.data(), adj->hash.size(), err, &d->bytes)) ||
+        (rc = upload(reinterpret_cast<AdjHdr**>(&d->adj_hdr), adj->hdr.data(), adj->hdr.size(), err, &d->bytes)) ||
+        (rc = upload(reinterpret_cast<AdjPlanes**>(&d->adj_planes), adj->planes, adj->rows * kAdjRow, err, &d->bytes)) ||
+        (rc = upload(&d->adj_ids, adj->ids, adj->rows * kAdjRow, err, &d->bytes))) {
+      lexicon_free(d);
+      return nullptr;
+    }
+    d->adj_mask = adj->hash_mask;
+    d->adj_hash_host = adj->hash;
+    d->adj_hdr_host = adj->hdr;
+  }
   return d;
 }
 
@@ -478,7 +491,8 @@ void lexicon_free(DeviceLexicon* d) {
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->scan_rec34, (void*)d->sig_e, (void*)d->sighash, (void*)d->sighash_e, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
-                  (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin})
+                  (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin,
+                  (void*)d->adj_hash, (void*)d->adj_hdr, (void*)d->adj_planes, (void*)d->adj_ids})
     if (p) pool_free(p);
   conf_free(d->dconf);
   lm_free(d->dlm);
@@ -720,6 +734,16 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
     if (probe_enabled() && k <= 12 && tile_probes(dl->ball_n[k], s1 - s0, h_sig[i])) { ball0 = dl->ball_off[k]; balln = dl->ball_n[k]; }
     const uint32_t nsplit = (sad && !balln) ? 8u : 1u;
     const uint32_t step = (((s1 - s0) + nsplit - 1) / nsplit + 63u) & ~63u;
+    uint32_t adj = 0;  // the signature's adjacency list (adjacency.h), as the device encoder's adj_lookup finds it
+    if (!sad && k <= (uint32_t)kAdjRadius && switches().scan_adj && !dl->adj_hash_host.empty()) {
+      uint32_t h = sig_hash((uint32_t)h_sig[i], (uint32_t)(h_sig[i] >> 32)) & dl->adj_mask;
+      for (int pr = 0; pr < 17; ++pr) {
+        const AdjSlot& e = dl->adj_hash_host[h];
+        if (!e.hdr1) break;
+        if (e.lo == (uint32_t)h_sig[i] && e.hi == (uint32_t)(h_sig[i] >> 32)) { adj = e.hdr1; break; }
+        h = (h + 1u) & dl->adj_mask;
+      }
+    }
     for (size_t s = i; s < j; s += tq) {
       const uint32_t tn = (uint32_t)std::min<size_t>(tq, j - s);
       uint32_t ke[3] = {0, 0, 0};  // end of the kind-1 / kind-2 / kind-3 queries inside the tile
@@ -730,18 +754,23 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
         const uint32_t a0 = s0 + part * step, a1 = std::min(s1, a0 + step);
         if (a0 >= a1 && part) break;
         b->tiles.push_back(Tile{(uint32_t)s, tn, a0, a1, k, lq, (uint32_t)h_sig[i], (uint32_t)(h_sig[i] >> 32), sad ? 0u : 1u,
-                                (h_meta[i] >> 16) & 0xFFu, kend, ball0, balln});
+                                (h_meta[i] >> 16) & 0xFFu, kend, ball0, balln, adj});
       }
     }
     i = j;
   }
   // longest-processing-time-first: cost ~ queries (the compatible classes per query vary little inside a length)
   // bit-plane tiles first, the SAD tiles (kind 0) after them: two launches
-  std::stable_sort(b->tiles.begin(), b->tiles.end(), [](const Tile& x, const Tile& y) {
+  auto tile_cost = [&](const Tile& x) {
+    return x.adj ? (uint64_t)dl->adj_hdr_host[x.adj - 1].cum[kAdjSections - 1] * (8u + x.nq) + 16u : (uint64_t)x.nq * (x.s1 - x.s0 + 64);
+  };
+  std::stable_sort(b->tiles.begin(), b->tiles.end(), [&](const Tile& x, const Tile& y) {
     if ((x.kind == 0) != (y.kind == 0)) return y.kind == 0;
-    return (uint64_t)x.nq * (x.s1 - x.s0 + 64) > (uint64_t)y.nq * (y.s1 - y.s0 + 64);
+    if ((x.adj == 0) != (y.adj == 0)) return y.adj == 0;   // the tiles of k_scan_adj first
+    return tile_cost(x) > tile_cost(y);
   });
-  for (const Tile& t : b->tiles) b->n_sad_tiles += t.kind == 0;
+  b->n_adj_tiles = 0;
+  for (const Tile& t : b->tiles) { b->n_sad_tiles += t.kind == 0; b->n_adj_tiles += t.adj != 0; }
   lap("tiles + LPT order");
   std::vector<uint32_t> h_xcls(nq, 0xFFFFFFFFu);
   if (p.stop_at_exact_match) {  // the exact anagram class of every query (the index lookup of src/lib.rs:1164-1173)
@@ -955,8 +984,17 @@ bool kernel_timer_read(const char* name, double* total_ms, uint64_t* launches) {
 }
 
 template <int NP>
-static void launch_scan(ScanArgs A, uint32_t nbits, uint32_t nsad, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {  // tiles: [bit-plane kinds | SAD kind]
-  (void)hipEventRecord(e0, st);  // e0 .. e1 = k_scan_bits alone (anx_batch_stats.ms_scan_kernel)
+static void launch_scan(ScanArgs A, uint32_t nadj, uint32_t nbits, uint32_t nsad, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  // tiles: [bit-plane tiles with an adjacency list | other bit-plane tiles | SAD kind]
+  (void)hipEventRecord(e0, st);  // e0 .. e1 = k_scan_adj + k_scan_bits (anx_batch_stats.ms_scan_kernel)
+  const bool gen = A.want_exact || A.qpairs || !A.drop_len;
+  if (nadj) {
+    A.ntiles = nadj;
+    if (gen) hipLaunchKernelGGL((k_scan_adj<true>), dim3((nadj + 3) / 4), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_scan_adj<false>), dim3((nadj + 3) / 4), dim3(256), 0, st, A);
+    A.tiles += nadj;
+    nbits -= nadj;
+  }
   if (nbits) {
     A.ntiles = nbits;
     // the general instance for StopAtExactMatch, per-query pair counts and runs that keep every pair; production runs take the lean one
@@ -1059,6 +1097,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     A.tiles = b->d_tiles; A.ntiles = b->ntiles; A.q_bits = b->q_bits; A.q_cv = b->q_cv;
     A.cls_bits = dl->cls_bits; A.cls_planes = dl->cls_planes; A.scan_rec = dl->scan_rec; A.scan_rec34 = dl->scan_rec34; A.pad_rec = dl->nentries; A.cstride = dl->cstride; A.pad_class = dl->nclasses;
     A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.sighash_e = dl->sighash_e; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
+    A.adj_hdr = dl->adj_hdr; A.adj_planes = dl->adj_planes; A.adj_ids = dl->adj_ids;
     A.chunk = SCAN_CHUNK;
     A.chunk_fused = SCAN_CHUNK_FUSED;
 #ifdef ANX_DEBUG_SWITCHES
@@ -1080,13 +1119,13 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
 #ifdef ANX_DEBUG_SWITCHES
     { const char* e = getenv("ANX_SCAN_DBG"); A.dbg = e ? atoi(e) : 0; }  // read per run: tools/scan_probe.py switches it between runs
 #endif
-    const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad;
+    const uint32_t nsad = b->n_sad_tiles, nbits = A.ntiles - nsad, nadj = std::min(b->n_adj_tiles, nbits);
     switch (dl->nplanes) {
-      case 8: launch_scan<8>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-      case 16: launch_scan<16>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-      case 24: launch_scan<24>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-      case 32: launch_scan<32>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
-      default: launch_scan<42>(A, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      case 8: launch_scan<8>(A, nadj, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      case 16: launch_scan<16>(A, nadj, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      case 24: launch_scan<24>(A, nadj, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      case 32: launch_scan<32>(A, nadj, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
+      default: launch_scan<42>(A, nadj, nbits, nsad, st, b->ev_scan0, b->ev[5]); break;
     }
   }
   HIP_TRY(hipMemcpyAsync(b->h_read + HR_RCTR, b->rctr, SCAN_REGIONS * RC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -3,17 +3,10 @@
 #include <cstdlib>
 #include <cstring>
 #include "engine.h"
+#include "sig_hash.h"
 
 namespace anx {
 
-// signature hash (host table build and device probe must agree)
-__host__ __device__ inline uint32_t sig_hash(uint32_t lo, uint32_t hi) {
-  uint32_t h = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  h ^= h >> 13;
-  return h;
-}
 // a tile probes the hash table instead of walking its window when the ball is cheaper (a probe step costs ~3 walk steps) and
 // no group sum is large enough to overflow the byte-wise add of an offset
 __host__ __device__ inline bool tile_probes(uint32_t balln, uint32_t window, unsigned long long sig) {

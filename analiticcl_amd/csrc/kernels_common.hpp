@@ -15,6 +15,7 @@ struct Tile {           // <= SCAN_TQ queries of one length and one signature (b
   uint32_t d;           // clamped edit distance for this length
   uint32_t kend;        // bit-plane tiles: end (within the tile) of the queries of kind 1 | kind 2 << 8 | kind 3 << 16; the rest are kind 4
   uint32_t ball0, balln;  // balln > 0: probe the signature hash table with the balln offsets ball[ball0 ..] instead of walking [s0, s1)
+  uint32_t adj;           // > 0: header index + 1 of the signature's adjacency list (adjacency.h): the tile streams it (bit-plane tiles, k <= kAdjRadius)
 };
 constexpr uint32_t BALL_MAX = 4096;   // largest L1 ball of signature offsets enumerated (per k; larger k walk the window)
 constexpr uint32_t SIG_BYTE_MAX = 120;  // group sums above this take the walk (byte-wise SWAR add of an offset must not overflow)
@@ -69,6 +70,13 @@ struct DeviceLexicon {
   unsigned long long* ball = nullptr;  // signature offsets (8 x int8) with sum |offset| <= k, for k = 0..12 back to back
   uint32_t* ball_tab = nullptr;    // device copy of ball_off[13] ++ ball_n[13]
   uint32_t ball_off[13] = {}, ball_n[13] = {};  // per k; ball_n = 0: no ball (walk)
+  uint4* adj_hash = nullptr;       // adjacency lists (adjacency.h): table {sig lo, sig hi, header index + 1, rows}
+  uint32_t adj_mask = 0;           // 0 = no lists
+  uint32_t* adj_hdr = nullptr;     // [lists][8] {first row, cumulative rows of the 7 length sections}
+  uint2* adj_planes = nullptr;     // [rows * 64] {plane 1, plane 2}
+  uint32_t* adj_ids = nullptr;     // [rows * 64] entry ids (padding: nentries)
+  std::vector<AdjSlot> adj_hash_host;  // host copies for the host encoder (ANX_ENCODE=host)
+  std::vector<AdjHdr> adj_hdr_host;
   uint4* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage): {groups 0-3, groups 4-7, first class of the run, classes}
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint32_t* ent_vocab = nullptr;
@@ -118,6 +126,7 @@ struct Batch {
   std::vector<Tile> tiles;         // host encoder only, emptied after the upload
   uint32_t ntiles = 0;             // d_tiles, in launch order: bit-plane tiles, then the count-vector (SAD) ones; each by decreasing cost
   uint32_t n_sad_tiles = 0;
+  uint32_t n_adj_tiles = 0;        // the first n_adj_tiles bit-plane tiles stream an adjacency list (k_scan_adj)
   uint32_t qw = 1;                 // uint4 words per query row
   uint32_t dmax = 0;
   uint64_t n_class_tests = 0;

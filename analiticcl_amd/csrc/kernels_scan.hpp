@@ -115,6 +115,9 @@ struct ScanArgs {
   const uint4* sighash_e;   // the same slots with entry runs (bit-plane kernel)
   uint32_t hash_mask;
   const unsigned long long* ball;  // signature offsets (8 x int8) of the L1 balls, Tile::ball0 / balln index it
+  const uint32_t* adj_hdr;  // signature adjacency lists (adjacency.h; tiles with Tile::adj): [list][8] {first row, cumulative rows of the 7 length sections}
+  const uint2* adj_planes;  // [row][64] {plane 1, plane 2} of the records
+  const uint32_t* adj_ids;  // [row][64] their entry ids (padding: pad_rec)
   const uint32_t* sig_cbeg;
   uint2* raw;
   uint32_t region_cap;  // pair-list slots per region
@@ -139,6 +142,11 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
   asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
   return r;
 }
+__device__ inline int32_t bcnt_acc_s(uint32_t x, int32_t acc) {  // the same with a wave-uniform addend (an SGPR operand: no VGPR per threshold)
+  int32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(acc));
+  return r;
+}
 
 // T >= 1: thermometer bit planes.  common(q,c) = sum_t popc(Q_t & C_t) is exact when every symbol of the query
 //   occurs at most T times (min(a,b) only needs a's planes; class planes saturate at NBITPLANES).
@@ -146,7 +154,10 @@ __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount
 //   classes share a symbol, src/iterators.rs:177).  2 ops per plane: v_and_b32 + accumulating v_bcnt_u32_b32.
 // T == 0: general path (any alphabet size / multiplicity): packed u8 count vectors, NP x v_sad_u8;
 //   hit <=> L1 <= k and L1 < len_q + len_c.
-template <bool BITS, int NP, bool GEN>
+// ADJ: the tile's signature has an adjacency list (adjacency.h): the records of its ball are streamed, rows of 64 with one length
+//   each, instead of probed / staged / gathered -- no ball walk, no run staging, coalesced 8 + 4 bytes per record, and the
+//   thresholds are wave-uniform per row (scalar registers).
+template <bool BITS, int NP, bool GEN, bool ADJ = false>
 __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t item, uint32_t* __restrict__ stage, uint32_t* __restrict__ hits,
                                  uint32_t* __restrict__ qlds, uint4* __restrict__ qsym, uint32_t* __restrict__ pbuf) {
   // GEN = false: the production instance (no StopAtExactMatch, no per-query pair counts, pairs that fail the DL's length test are
@@ -167,6 +178,8 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
   WaveOut wo{0, 0, 0, 0, 0, region * A.region_cap, (region + 1) * A.region_cap, A.rctr + region * RC_STRIDE, A.chunk};
   uint32_t ns = 0;  // staged class ids (wave-uniform)
   uint32_t nchunks = 0;
+  uint32_t arow = 0, arend = 0;     // ADJ: the chunk's first row and the end of the tile's rows (absolute row numbers, wave-uniform)
+  int32_t alc[4] = {0, 0, 0, 0};    // ADJ: record length of each of the chunk's rows (wave-uniform)
   {  // the tile's query words -> LDS: the comparison loop reads them back as broadcasts into VGPRs
     const uint32_t* __restrict__ src = (BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE;
     for (uint32_t i = lane; i < t.nq * QSTRIDE; i += 64) qlds[i] = src[i];
@@ -328,13 +341,33 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
     ++nchunks;
     if (ANX_DBG(A.dbg) & 2) return;
     uint32_t cid[CPL], cw[CPL][W];
-    int32_t thr[CPL];
+    int32_t thr[CPL];   // ADJ: wave-uniform (scalar registers)
     const bool need34 = BITS && ((t.kend >> 8) & 0xFFu) < t.nq;  // some query of the tile is of kind 3 or 4
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const uint32_t idx = (uint32_t)j * 64u + lane;
-      cid[j] = idx < ns ? stage[idx] : (BITS ? A.pad_rec : A.pad_class);
       int32_t lc;
+      if (ADJ) {
+        // row arow + j of the list: 64 consecutive records, one per lane (coalesced 8-byte and 4-byte loads); rows beyond the tile's
+        // range read as padding (planes 0: no common symbol with anything)
+        const bool in = arow + (uint32_t)j < arend;  // wave-uniform
+        uint2 pl = make_uint2(0u, 0u);
+        uint32_t id = A.pad_rec;
+        if (in) {
+          const size_t p = (size_t)(arow + (uint32_t)j) * 64u + lane;
+          pl = A.adj_planes[p];
+          id = A.adj_ids[p];
+        }
+        stage[idx] = id;  // the hit list holds positions in the chunk (flush)
+        uint2 hi = make_uint2(0u, 0u);
+        if (need34) hi = A.scan_rec34[id];
+        cw[j][0] = pl.x; cw[j][1] = pl.y;
+        if (W > 2) { cw[j][2] = hi.x; cw[j][W - 1] = hi.y; }
+        lc = alc[j];
+        const int32_t diff = lc > (int32_t)t.lq ? lc - (int32_t)t.lq : (int32_t)t.lq - lc;
+        cid[j] = (A.drop_len && diff > (int32_t)t.d) ? id | (1u << 28) : id;
+      } else {
+      cid[j] = idx < ns ? stage[idx] : (BITS ? A.pad_rec : A.pad_class);
       if (BITS) {  // one 32-B scan record per entry {4 planes of its class} {len, class, -, -} instead of T + 3 gathers
         // 16 B per record {plane 1, plane 2, len, class}: the chunk set-up is bound by the texture addresser (8 -> 4 gathers per lane
         // and chunk); planes 3 / 4 only matter to queries with a symbol three / four times (5 % of the tests), so only tiles that
@@ -352,6 +385,7 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
 #pragma unroll
         for (int p = 0; p < W; ++p) cw[j][p] = cls_words[(size_t)p * cstride + cid[j]];
         lc = (int32_t)cls_len[cid[j]];
+      }
       }
       if (BITS) {
         const int32_t need = ((int32_t)t.lq - (int32_t)t.k + lc + 1) >> 1;  // ceil((lq + lc - k) / 2)
@@ -377,9 +411,10 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
         for (int j = 0; j < CPL; ++j) {
           int32_t acc;
           if (BITS) {
-            acc = thr[j];  // common - threshold: negative = miss
+            // common - threshold: negative = miss
+            acc = ADJ ? bcnt_acc_s(qreg[0] & cw[j][0], thr[j]) : bcnt_acc(qreg[0] & cw[j][0], thr[j]);
 #pragma unroll
-            for (int p = 0; p < TW; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
+            for (int p = 1; p < TW; ++p) acc = bcnt_acc(qreg[p] & cw[j][p], acc);
           } else {
             uint32_t sad = 0;
 #pragma unroll
@@ -503,7 +538,24 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
     }
   };
   const uint4* __restrict__ sigtab = BITS ? A.sig_e : A.sig;  // runs of scan records (entries) / of classes
-  if (t.balln) {
+  if (ADJ) {
+    // the list of the tile's signature: rows [row0 + rbeg, row0 + rend) hold the records of the lengths lq - k .. lq + k (section i of the
+    // list = length lq - 3 + i; a list holds the ball of radius 3, a tile with a smaller k tests a few records more than it has to)
+    const cptr_u32 hp = (cptr_u32)(A.adj_hdr + (size_t)(t.adj - 1u) * 8u);
+    const uint32_t row0 = hp[0], c0 = hp[1], c1 = hp[2], c2 = hp[3], c3 = hp[4], c4 = hp[5], c5 = hp[6], c6 = hp[7];
+    const uint32_t rbeg = t.k >= 3u ? 0u : t.k == 2u ? c0 : t.k == 1u ? c1 : c2;
+    const uint32_t rend = t.k >= 3u ? c6 : t.k == 2u ? c5 : t.k == 1u ? c4 : c3;
+    arend = row0 + rend;
+    for (uint32_t r = rbeg; r < rend; r += (uint32_t)CPL) {
+      arow = row0 + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t rr = r + (uint32_t)j;
+        alc[j] = (int32_t)t.lq - 3 + (int32_t)((rr >= c0) + (rr >= c1) + (rr >= c2) + (rr >= c3) + (rr >= c4) + (rr >= c5));
+      }
+      process();
+    }
+  } else if (t.balln) {
     // Signatures within L1 distance k of the tile's: enumerated, not searched.  Lane i adds offset i of the ball (sum |d_g| <= k)
     // to the tile's signature byte-wise and looks the result up in the hash table of the lexicon's signatures -- 377 probes for
     // 6 groups and k = 3 whatever the size of the lexicon, against a walk over every signature of the +-k charcount window.
@@ -546,7 +598,7 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
       stage_runs(ok, sg.z, sg.w);
     }
   }
-  if (ns) process();
+  if (!ADJ && ns) process();
   flush();
   if (BITS) emit_dense(true);
   if (A.drop_len) {  // wave sum of the counted-only pairs -> RC_VALID (n_pairs = every DL invocation of the reference)
@@ -571,7 +623,7 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
 // T) and the count-vector tiles run as two launches so that the rarely used wide SAD body does not set the register
 // budget (= occupancy) of the common one.
 constexpr uint32_t SCAN_STAGE = 64 * 4 + 64 + SCAN_MASKW / 32;  // the chunk's ids, the step's run deltas, the window's run-end masks
-template <int NP, bool BITS, bool GEN>
+template <int NP, bool BITS, bool GEN, bool ADJ = false>
 __device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
@@ -586,14 +638,18 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   if (item >= A.ntiles) return;
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
-  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12];
-  scan_tile<BITS, NP, GEN>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[BITS ? wid : 0], s_pbuf[BITS ? wid : 0]);
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12]; t.adj = tp[13];
+  // the launches are split by the encoders' tile order: [tiles that stream an adjacency list | other bit-plane tiles | count-vector tiles]
+  scan_tile<BITS, NP, GEN, ADJ>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[BITS ? wid : 0], s_pbuf[BITS ? wid : 0]);
 }
 // <= 80 VGPRs = 6 waves per SIMD for the bit-plane kernel (measured: unconstrained 85 VGPRs -> 2.33 ms, 80 -> 2.20 ms,
 // 64 with spills -> 2.60 ms)
 // one instance for every alphabet (the bit-plane body does not depend on the count-vector width); GEN: see scan_tile
 template <bool GEN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_bits(ScanArgs A) { scan_wave<8, true, GEN>(A); }
+// the tiles whose signature has an adjacency list (adjacency.h): a kernel of their own, so that neither path carries the other's registers
+template <bool GEN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_adj(ScanArgs A) { scan_wave<8, true, GEN, true>(A); }
 template <int NP>
 __global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false, true>(A); }
 

@@ -314,6 +314,17 @@ int anx_debug_kernel_time(const char *name, double *total_ms, uint64_t *launches
  * that the next split is the one a real N-GPU job would see after this call. */
 int anx_debug_length_split(const anx_model *, const char *const *utf8, size_t n, const anx_params *, int n_shards, uint8_t *out_shard,
                            const double *learn_ms);
+/* Test hooks of the signature adjacency lists (analiticcl_amd/csrc/adjacency.h; no device needed).  anx_debug_signature: the group-sum
+ * signature the scan prunes with (one byte per symbol group) of a string.  anx_debug_adjacency builds the lists of the model's lexicon
+ * (closure 0..2, budget in bytes) and returns, for each of the n signatures, out_cum[i][8] = {first row of its list in *out_ids, rows
+ * of the length sections L-3 .. L+3 cumulated} (all 0xFFFFFFFF: no list) and the lists' entry ids in rows of 64 (padding = number of
+ * entries); *out_ids is released with free().  out_stats (may be NULL): {lexicon signatures, closure, lists kept, records, rows, ms}.
+ * tests/test_adjacency_cpu.py compares them with find_nearest_anahashes' candidate set (src/lib.rs:1143-1308) by brute force. */
+int anx_debug_signature(const anx_model *, const char *utf8, uint64_t *out_sig);
+/* the index's entries (class-major order = the entry ids of the pair list and of the adjacency lists) as vocabulary ids; free() */
+int anx_debug_entries(const anx_model *, uint32_t **out_vocab_ids, size_t *n);
+int anx_debug_adjacency(const anx_model *, int closure, uint64_t budget_bytes, const uint64_t *sigs, size_t n, uint32_t *out_cum,
+                        uint32_t **out_ids, uint64_t *out_stats);
 /* Test hook: the band-match bound the scan's fused filter and k_filter_score apply before damerau_levenshtein (src/distance.rs:101-179)
  * on n (query, candidate) pairs of <= 16 symbols: rows of 16 bytes (alphabet-indexed symbols, the query padded with 0xFE, the
  * candidate with 0xFF), lengths, d <= 3.  form: 0 the scan's (7-bit symbols, wave-uniform d), 1 k_filter_score's (7-bit symbols),

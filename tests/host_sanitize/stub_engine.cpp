@@ -21,7 +21,7 @@ static bool fake() { const char* e = getenv("ANX_STUB_FAKE"); return e && e[0] =
 static uint64_t fnv(const std::string& s) { uint64_t h = 1469598103934665603ull; for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; } return h; }
 
 int device_count(std::string& err) { if (fake()) return 4; err = "stub: no device"; return 0; }
-DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, int device, std::string& err) {
+DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, const AdjIndex*, int device, std::string& err) {
   if (!fake()) { err = "stub: no device"; return nullptr; }
   if (device < 0 || device >= 4) { err = "stub: invalid device ordinal"; return nullptr; }
   return new DeviceLexicon{device};
