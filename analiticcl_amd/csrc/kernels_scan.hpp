@@ -134,7 +134,8 @@ struct ScanArgs {
                             // counted as scored pairs and never written; survivors carry RAW_PREFILTERED
   uint32_t* qpairs;         // per query: scored pairs of THIS run, counted where they are produced (materialised or only counted);
                             // nullptr in normal runs (anx_batch_pair_counts: the per-query check of the production pair list)
-  int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 skip the query loop, 2 skip process(), 4 skip the expansion
+  int dbg;  // ANX_SCAN_DBG (timing experiments only; results are wrong when set): 1 one query per pass, 2 skip process(), 4 no run staging,
+            // 8 no hit expansion, 16 pairs dropped before the band filter, 32 filtered pairs not written
 };
 
 __device__ inline int32_t bcnt_acc(uint32_t x, int32_t acc) {  // acc + popcount(x) in one v_bcnt_u32_b32
@@ -178,8 +179,24 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
   WaveOut wo{0, 0, 0, 0, 0, region * A.region_cap, (region + 1) * A.region_cap, A.rctr + region * RC_STRIDE, A.chunk};
   uint32_t ns = 0;  // staged class ids (wave-uniform)
   uint32_t nchunks = 0;
-  uint32_t arow = 0, arend = 0;     // ADJ: the chunk's first row and the end of the tile's rows (absolute row numbers, wave-uniform)
+  uint32_t arend = 0;               // ADJ: end of the tile's rows (absolute row number, wave-uniform)
   int32_t alc[4] = {0, 0, 0, 0};    // ADJ: record length of each of the chunk's rows (wave-uniform)
+  // ADJ: the records of a chunk (4 rows of 64, one record per lane and row) are requested one chunk AHEAD: the stream comes from HBM
+  // (~2 us), and a wave that waited for its own loads at the head of every chunk left the SIMD to 4 other waves doing the same
+  uint2 apl[4] = {};                // planes 1 / 2 of the lane's record in each row of the chunk being processed
+  uint32_t aid[4] = {};             // their entry ids
+  auto adj_load = [&](uint32_t row, uint2 (&pl)[4], uint32_t (&id)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pl[j] = make_uint2(0u, 0u);   // rows beyond the tile's range read as padding (planes 0: no common symbol with anything)
+      id[j] = A.pad_rec;
+      if (row + (uint32_t)j < arend) {  // wave-uniform
+        const size_t p = (size_t)(row + (uint32_t)j) * 64u + lane;
+        pl[j] = A.adj_planes[p];
+        id[j] = A.adj_ids[p];
+      }
+    }
+  };
   {  // the tile's query words -> LDS: the comparison loop reads them back as broadcasts into VGPRs
     const uint32_t* __restrict__ src = (BITS ? A.q_bits : A.q_cv) + (size_t)t.q0 * QSTRIDE;
     for (uint32_t i = lane; i < t.nq * QSTRIDE; i += 64) qlds[i] = src[i];
@@ -206,7 +223,8 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
       const uint32_t e = act ? (pr & 0x3FFFFFFu) : 0u, ql = act ? (pr >> 26) : 0u;
       bool keep = act;
       uint32_t flag = 0u;
-      if (BITS && fuse) {
+      if (ANX_DBG(A.dbg) & 16) keep = false;  // timing: the pairs are dropped unfiltered
+      if (BITS && fuse && !(ANX_DBG(A.dbg) & 16)) {
         nfused += cnt;
         const uint4 C = rec32(A.e_rec, e)[0];
         const int lc = (int)(rec32(A.e_rec, e)[1].x & 0xFFu), lq = (int)t.lq, d = (int)t.d;
@@ -228,6 +246,7 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
         if (rej) { keep = false; ++counted_only; }
         if (filt) flag = RAW_PREFILTERED;
       }
+      if (ANX_DBG(A.dbg) & 32) keep = false;  // timing: filtered, nothing written
       const unsigned long long km = __ballot(keep);
       const uint32_t total = (uint32_t)__popcll(km);
       if (total) {  // wave-uniform
@@ -348,16 +367,9 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
       const uint32_t idx = (uint32_t)j * 64u + lane;
       int32_t lc;
       if (ADJ) {
-        // row arow + j of the list: 64 consecutive records, one per lane (coalesced 8-byte and 4-byte loads); rows beyond the tile's
-        // range read as padding (planes 0: no common symbol with anything)
-        const bool in = arow + (uint32_t)j < arend;  // wave-uniform
-        uint2 pl = make_uint2(0u, 0u);
-        uint32_t id = A.pad_rec;
-        if (in) {
-          const size_t p = (size_t)(arow + (uint32_t)j) * 64u + lane;
-          pl = A.adj_planes[p];
-          id = A.adj_ids[p];
-        }
+        // row j of the chunk: 64 consecutive records of the list, one per lane (adj_load: coalesced 8-byte and 4-byte loads)
+        const uint2 pl = apl[j];
+        const uint32_t id = aid[j];
         stage[idx] = id;  // the hit list holds positions in the chunk (flush)
         uint2 hi = make_uint2(0u, 0u);
         if (need34) hi = A.scan_rec34[id];
@@ -546,13 +558,18 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
     const uint32_t rbeg = t.k >= 3u ? 0u : t.k == 2u ? c0 : t.k == 1u ? c1 : c2;
     const uint32_t rend = t.k >= 3u ? c6 : t.k == 2u ? c5 : t.k == 1u ? c4 : c3;
     arend = row0 + rend;
+    uint2 npl[4];
+    uint32_t nid[4];
+    if (rbeg < rend) adj_load(row0 + rbeg, npl, nid);
     for (uint32_t r = rbeg; r < rend; r += (uint32_t)CPL) {
-      arow = row0 + r;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t rr = r + (uint32_t)j;
         alc[j] = (int32_t)t.lq - 3 + (int32_t)((rr >= c0) + (rr >= c1) + (rr >= c2) + (rr >= c3) + (rr >= c4) + (rr >= c5));
+        apl[j] = npl[j];
+        aid[j] = nid[j];
       }
+      if (r + (uint32_t)CPL < rend) adj_load(row0 + r + (uint32_t)CPL, npl, nid);  // the next chunk: in flight under this one's tests
       process();
     }
   } else if (t.balln) {

@@ -16,7 +16,7 @@ name, path = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(path)):
     k = r["Kernel_Name"]
-    short = "k_scan_bits" if "k_scan_bits" in k else "k_filter_score" if "k_filter_score" in k else None
+    short = "k_scan_adj" if "k_scan_adj" in k else "k_scan_bits" if "k_scan_bits" in k else "k_filter_score" if "k_filter_score" in k else None
     if not short: continue
     acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES" or r["Counter_Name"] == "SQ_INSTS_LDS": cnt[short] += 1

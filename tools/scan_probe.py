@@ -24,7 +24,7 @@ def run(label, env):
         for k in ("ms_scan_kernel", "ms_filter_score_kernel", "ms_group", "ms_rank", "ms_total"): acc[k] = acc.get(k, 0.0) + st[k] / 5
     print(f"{label:28s} scan {acc['ms_scan_kernel']:.3f}  fscore {acc['ms_filter_score_kernel']:.3f}  compact {acc['ms_group']:.3f} rank {acc['ms_rank']:.3f} total {acc['ms_total']:.3f}  tiles {st['n_scan_blocks']} tests/q {st['n_class_tests']/nq:.0f} slots {st['n_pair_slots']} pairs {st['n_pairs']}", flush=True)
 run("default", {})
-for v in (8, 1, 2, 4, 16, 32, 64, 16 + 64):
+for v in (8, 1, 2, 16, 32):
     run(f"scan dbg={v}", {"ANX_SCAN_DBG": str(v)})
 for v in (1, 2):
     run(f"score dbg={v}", {"ANX_SCORE_DBG": str(v)})
