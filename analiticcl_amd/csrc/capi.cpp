@@ -1405,6 +1405,8 @@ int anx_batch_shard_inputs(const anx_batch* b, int shard, const uint32_t** indic
 }
 int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* out, size_t struct_size) {
   if (!b || !out) return fail(ANX_EINVAL, "NULL argument");
+  // the struct as ABI version 2 introduced it ended with n_conf_scripts; anything shorter (or absurdly long) is not a struct size
+  if (struct_size < offsetof(anx_batch_stats, n_conf_scripts) + sizeof(uint64_t) || struct_size > 4096) return fail(ANX_EINVAL, "struct_size is not the size of an anx_batch_stats");
   anx_batch_stats full;
   anx_batch_stats* s = &full;
   anx::batch_stats(b->shards[0].b, s);
@@ -1412,7 +1414,7 @@ int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* out, size_t struct_
     anx_batch_stats t;
     anx::batch_stats(b->shards[g].b, &t);
     s->n_queries += t.n_queries; s->n_pairs += t.n_pairs; s->n_class_tests += t.n_class_tests; s->n_results += t.n_results;
-    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected; s->n_prefiltered_in_scan += t.n_prefiltered_in_scan; s->n_conf_scripts += t.n_conf_scripts;
+    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected; s->n_prefiltered_in_scan += t.n_prefiltered_in_scan; s->n_conf_scripts += t.n_conf_scripts; s->n_adj_tiles += t.n_adj_tiles;
     for (int i = 0; i < 5; ++i) s->n_tests_kind[i] += t.n_tests_kind[i];
     s->ms_scan = std::max(s->ms_scan, t.ms_scan); s->ms_group = std::max(s->ms_group, t.ms_group); s->ms_score = std::max(s->ms_score, t.ms_score);
     s->ms_rank = std::max(s->ms_rank, t.ms_rank); s->ms_total = std::max(s->ms_total, t.ms_total);

@@ -1348,6 +1348,7 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
   const uint32_t total_surv = h[HR_TOTAL_SURV], total_results = h[HR_TOTAL_RESULTS];
   b->conf_fallback = b->conf_mode != 0 && (h[HR_CONF + 1] != 0 || b->conf_skipped);
   b->stats.n_conf_scripts = b->conf_mode ? h[HR_CONF] : 0;
+  b->stats.n_adj_tiles = std::min(b->n_adj_tiles, b->ntiles - b->n_sad_tiles);
   // ---- did the run fit what the launch assumed? ------------------------------------------------------------
   int rc;
   bool again = false;

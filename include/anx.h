@@ -21,9 +21,10 @@ extern "C" {
 #endif
 
 /* 1: rounds 1-3.
- * 2: anx_batch_stats grew (n_prefiltered_in_scan, ...), anx_batch_get_stats takes the caller's struct size through
- *    anx_batch_get_stats_sized, anx_shutdown, asynchronous fetch, length-partitioned sharding.  A binding compares
- *    anx_abi_version() with the ANX_ABI_VERSION it was compiled against before it calls anything else. */
+ * 2: anx_batch_stats grew (n_prefiltered_in_scan, ...) and anx_batch_get_stats(batch, out, struct_size) takes the caller's struct
+ *    size as its third argument (the struct only grows at its end; a size below the version-2 struct's first 152 bytes is refused
+ *    with ANX_EINVAL: a caller built against ABI 1 passes no size at all), anx_shutdown, asynchronous fetch, length-partitioned
+ *    sharding.  A binding compares anx_abi_version() with the ANX_ABI_VERSION it was compiled against before it calls anything else. */
 #define ANX_ABI_VERSION 2
 
 enum {
@@ -268,6 +269,7 @@ typedef struct anx_batch_stats {
                                    * left to k_filter_score) */
   uint64_t n_conf_scripts;   /* ABI 2: ranked rows whose edit script the device-side confusable weighting computed (the other rows
                               * were screened out: no pattern can match them) */
+  uint64_t n_adj_tiles;      /* scan tiles that streamed a signature adjacency list (k_scan_adj) instead of probing their ball themselves */
 } anx_batch_stats;
 /* counts summed over the shards of the batch, times of the slowest replica.  struct_size = sizeof(anx_batch_stats) as the CALLER
  * was compiled: the library writes at most that many bytes, so a caller built against an older, shorter struct stays in bounds

@@ -126,7 +126,7 @@ def test_filters_off_equal_default_at_full_size(data_dir, lex, maxlen, d, nq):
         b.free()
 
 
-@pytest.mark.parametrize("switch,value", [("ANX_SCAN", "sad"), ("ANX_SCORE_FAST", "0"), ("ANX_FS_SPLIT", "0"), ("ANX_FS_B7", "0")])
+@pytest.mark.parametrize("switch,value", [("ANX_SCAN_ADJ", "0"), ("ANX_SCAN", "sad"), ("ANX_SCORE_FAST", "0"), ("ANX_FS_SPLIT", "0"), ("ANX_FS_B7", "0")])
 def test_result_neutral_switches(data_dir, switch, value):
     g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
     g.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
@@ -144,3 +144,68 @@ def test_result_neutral_switches(data_dir, switch, value):
         assert got == ref
     finally:
         A.set_switch(switch, None)
+
+
+def _model(data_dir, lex):
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(os.path.join(data_dir, f"{lex}.aspell.lexicon"))
+    g.build()
+    return g
+
+
+@pytest.mark.parametrize("lex,maxlen,k,d,nq", [("eng", 16, 3, 2, 1_000_000), ("nld", 24, 3, 3, 400_000), ("eng", 16, 2, 2, 200_000), ("eng", 12, 1, 1, 200_000)])
+def test_adjacency_lists_equal_the_probe_walk_at_full_size(data_dir, lex, maxlen, k, d, nq):
+    """k_scan_adj (tiles stream the prebuilt adjacency list of their signature, analiticcl_amd/csrc/adjacency.h) against
+    ANX_SCAN_ADJ=0 (every tile enumerates its signature ball itself, as until round 4): scored pairs
+    (= find_nearest_anahashes' candidates x instances, /root/reference/src/lib.rs:1143-1402), survivors and result checksum."""
+    g = _model(data_dir, lex)
+    qs = synth.make_queries(synth.load_lexicon_words(os.path.join(data_dir, f"{lex}.aspell.lexicon")), nq, max_len=maxlen, seed=synth.SEED + k)
+    p = A.SearchParameters(max_anagram_distance=k, max_edit_distance=d, max_matches=10)
+    try:
+        b = g.encode_batch(qs, p)
+        got, st = _run(b)
+        b.free()
+        assert st["n_adj_tiles"] > 0.9 * st["n_scan_blocks"]     # nearly every tile has a list (closure 2 of the lexicon's signatures)
+        A.set_switch("ANX_SCAN_ADJ", "0")
+        b = g.encode_batch(qs, p)   # read when the tiles are built
+        ref, st0 = _run(b)
+        b.free()
+        assert st0["n_adj_tiles"] == 0
+        assert got == ref
+    finally:
+        A.set_switch("ANX_SCAN_ADJ", None)
+
+
+def test_adjacency_mixed_with_probe_tiles_stop_at_exact_and_pair_counts(data_dir):
+    """Lists for the lexicon's own signatures only (ANX_ADJ_CLOSURE=0: a third of the tiles keep the probe walk, both scan kernels run in
+    one batch), the general kernel instance (StopAtExactMatch) and the per-query pair counts of the production run -- all against the
+    oracle's find_variants on a sample and against the run without lists."""
+    qs = synth.make_queries(synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon")), 120_000, max_len=20, seed=77)
+    try:
+        A.set_switch("ANX_ADJ_CLOSURE", "0")
+        g = _model(data_dir, "eng")   # read when the model goes to the device
+        o = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+        o.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))
+        o.build()
+        for stop in (False, True):
+            p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, stop_criterion=stop)
+            op = O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0, stop_at_exact_match=stop)
+            b = g.encode_batch(qs, p)
+            got, st = _run(b)
+            assert 0.3 * st["n_scan_blocks"] < st["n_adj_tiles"] < 0.95 * st["n_scan_blocks"]
+            counts = b.pair_counts()
+            rows = b.fetch()
+            b.free()
+            for i in range(0, len(qs), 997):
+                exp = o.find_variants(qs[i], op)
+                assert [(v, dd, f) for v, dd, f in rows[i]] == exp, (stop, qs[i])
+            A.set_switch("ANX_SCAN_ADJ", "0")
+            b = g.encode_batch(qs, p)
+            ref, _ = _run(b)
+            counts0 = b.pair_counts()
+            b.free()
+            A.set_switch("ANX_SCAN_ADJ", None)
+            assert got == ref and np.array_equal(counts, counts0)
+    finally:
+        A.set_switch("ANX_SCAN_ADJ", None)
+        A.set_switch("ANX_ADJ_CLOSURE", None)
