@@ -75,7 +75,7 @@ class BatchStats(C.Structure):
                 ("n_pair_slots", C.c_uint64), ("n_survivors", C.c_uint64), ("ms_scan", C.c_float),
                 ("ms_group", C.c_float), ("ms_score", C.c_float), ("ms_rank", C.c_float), ("ms_total", C.c_float),
                 ("ms_scan_kernel", C.c_float), ("n_selected", C.c_uint64), ("ms_filter_score_kernel", C.c_float),
-                ("n_prefiltered_in_scan", C.c_uint64), ("n_conf_scripts", C.c_uint64), ("n_adj_tiles", C.c_uint64)]
+                ("n_prefiltered_in_scan", C.c_uint64), ("n_conf_scripts", C.c_uint64), ("n_adj_tiles", C.c_uint64), ("n_adj_records", C.c_uint64), ("n_adj_records_first", C.c_uint64)]
 
 
 _lib = None

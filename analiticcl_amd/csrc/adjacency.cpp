@@ -210,6 +210,20 @@ void build_adjacency(const LexiconImage& img, int closure, size_t budget_bytes, 
     }
   });
 
+  {  // expected records per query of every length (queries drawn like lexicon entries)
+    double num[256] = {}, den[256] = {};
+    for (size_t x = 0; x < nk; ++x) {
+      if (keys[x].tier != 0) continue;
+      const int i = lexsig.find(keys[x].sig);
+      if (i < 0) continue;
+      int len = 0;
+      for (int g = 0; g < 8; ++g) len += (int)((keys[x].sig >> (8 * g)) & 0xFFu);
+      const double e = (double)entries_of_run(i);
+      num[std::min(len, 255)] += e * (double)nrec[x];
+      den[std::min(len, 255)] += e;
+    }
+    for (int L = 0; L < 256; ++L) out.len_records[L] = den[L] > 0.0 ? num[L] / den[L] : 0.0;
+  }
   lap("pass 1 (rows)");
   // ---- which lists fit the budget: by (distance from the lexicon, rows) ascending ---------------------------------------------
   const uint64_t row_bytes = (uint64_t)kAdjRow * (sizeof(AdjPlanes) + sizeof(uint32_t));
@@ -217,6 +231,7 @@ void build_adjacency(const LexiconImage& img, int closure, size_t budget_bytes, 
   {
     uint64_t total = 0;
     for (size_t x = 0; x < nk; ++x) total += hdr[x].cum[kAdjSections - 1];
+    out.rows_wanted = total;
     if (total * row_bytes > budget_bytes) {
       std::vector<uint32_t> ord(nk);
       for (size_t x = 0; x < nk; ++x) ord[x] = (uint32_t)x;

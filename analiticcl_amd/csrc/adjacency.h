@@ -43,6 +43,10 @@ struct AdjIndex {
   // statistics
   uint32_t nsig_lexicon = 0, nsig_closure = 0, nsig_kept = 0;
   uint64_t records = 0;          // without padding
+  uint64_t rows_wanted = 0;      // rows of every list of the closure (what an unlimited budget would keep)
+  // per length L: records in the ball of a lexicon entry's signature, averaged over the entries of that length (0: no entry) -- what
+  // the scan tests per query of that length when the queries resemble the lexicon: the prior of the length-partitioned split (capi.cpp)
+  double len_records[256] = {};
   double build_ms = 0.0;
   AdjIndex() = default;
   AdjIndex(const AdjIndex&) = delete;

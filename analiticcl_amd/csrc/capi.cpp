@@ -80,6 +80,10 @@ struct LengthCost {
   static constexpr uint32_t LMAX = 256;  // byte lengths >= 255 share the last class
   std::mutex mu;
   double scale[LMAX];
+  // prior from the signature adjacency lists (anx_model_to_devices): records the scan tests per query of every length, averaged over
+  // the lexicon's entries of that length; have_records = false: the window-size prior below
+  double records[LMAX] = {};
+  bool have_records = false;
   anx_threshold k_of, d_of;
   bool init = false;
 };
@@ -100,6 +104,7 @@ struct anx_batch {
   // ... unless the weighting runs on the device (conf.hip; default): the rows come back final.  A run that met a row the device
   // could not weight (string beyond its fixed working memory) falls back to the host path for the whole batch.
   bool dev_conf = false;
+  mutable bool learned = false;   // the length split's cost model has taken this batch's shard times (learn_from_batch)
   anx_params params;
   std::string in_text;            // the inputs, each followed by a NUL byte (one copy of the caller's buffer, not a string each)
   std::vector<uint32_t> in_off;   // n + 1 offsets into in_text
@@ -324,6 +329,13 @@ int anx_model_to_devices(anx_model* m, const int* devices, int n) {
   if (anx::switches().scan_adj && m->host.lex.nsym <= 32) {
     adj.reset(new anx::AdjIndex());
     anx::build_adjacency(m->host.lex, anx::switches().adj_closure, (size_t)anx::switches().adj_budget_mb << 20, anx::usable_hw_threads(), *adj);
+    {
+      LengthCost& lc = m->len_cost;
+      std::lock_guard<std::mutex> lk(lc.mu);
+      for (uint32_t L = 0; L < LengthCost::LMAX; ++L) lc.records[L] = adj->len_records[L];
+      lc.have_records = !adj->hash.empty();
+      lc.init = false;  // the corrections were learned against another prior
+    }
     if (getenv("ANX_ADJ_TIMING"))
       fprintf(stderr, "[anx adjacency] %u lexicon signatures, %u in the closure, %u lists, %llu records in %llu rows (%.1f MB), %.1f ms\n", adj->nsig_lexicon,
               adj->nsig_closure, adj->nsig_kept, (unsigned long long)adj->records, (unsigned long long)adj->rows, adj->rows * 64.0 * 12.0 / 1e6, adj->build_ms);
@@ -369,7 +381,7 @@ int anx_debug_adjacency(const anx_model* m, int closure, uint64_t budget_bytes, 
   if (!m->host.built) return fail(ANX_ENOTBUILT, "Model has not been built yet!");
   anx::AdjIndex adj;
   anx::build_adjacency(m->host.lex, closure, (size_t)budget_bytes, anx::usable_hw_threads(), adj);
-  if (out_stats) { out_stats[0] = adj.nsig_lexicon; out_stats[1] = adj.nsig_closure; out_stats[2] = adj.nsig_kept; out_stats[3] = adj.records; out_stats[4] = adj.rows; out_stats[5] = (uint64_t)adj.build_ms; }
+  if (out_stats) { out_stats[0] = adj.nsig_lexicon; out_stats[1] = adj.nsig_closure; out_stats[2] = adj.nsig_kept; out_stats[3] = adj.records; out_stats[4] = adj.rows; out_stats[5] = (uint64_t)adj.build_ms; out_stats[6] = adj.rows_wanted; }
   size_t total = 0;
   std::vector<uint32_t> h1(n);
   for (size_t i = 0; i < n; ++i) {
@@ -880,7 +892,20 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
       double window = 0.0;
       for (int c = std::max(1, (int)L - k); c <= std::min(anx::kMaxSymbols, (int)L + k); ++c) window += (double)(lex.bucket_begin[c + 1] - lex.bucket_begin[c]);
       const double rel = L ? (double)k / (double)L : 0.0;
-      w[L] = (1024.0 + window / 16.0) * (1.0 + 30.0 * rel * rel * rel) * lc.scale[L];
+      if (lc.have_records && k <= anx::kAdjRadius) {
+        // round 5: the adjacency lists say how many records a query of this length meets (lengths without lexicon entries take
+        // the nearest length that has some); 3000 record tests ~ the per-query work that does not depend on them (encoder, tile
+        // set-up, ranking: ~1 ns against 0.3 ps per record test on BASELINE configs[1] / [3]).  First-call balance of the configs[3]
+        // job: 0.57 with the window prior, see DESIGN.md section 6
+        double r = lc.records[L];
+        for (uint32_t o = 1; r == 0.0 && o < LMAX; ++o) {
+          if (L >= o && lc.records[L - o] > 0.0) r = lc.records[L - o];
+          else if (L + o < LMAX && lc.records[L + o] > 0.0) r = lc.records[L + o];
+        }
+        w[L] = (3000.0 + r) * lc.scale[L];
+      } else {
+        w[L] = (1024.0 + window / 16.0) * (1.0 + 30.0 * rel * rel * rel) * lc.scale[L];
+      }
     }
   }
   // cumulative cost at the first input of every class; rank of every thread's first input inside its class
@@ -943,10 +968,15 @@ void learn_length_costs(const anx_model* m, const std::vector<Shard>& shards, co
       num += c * (t[g] / shards[g].predicted) / (tsum / psum);
       den += c;
     }
-    if (den > 0.0) lc.scale[L] = std::min(64.0, std::max(1.0 / 64.0, lc.scale[L] * (num / den)));
+    // damped (square root of the measured ratio): a noisy run moves the weights half way, and the next split is measured afresh
+    if (den > 0.0) lc.scale[L] = std::min(64.0, std::max(1.0 / 64.0, lc.scale[L] * std::sqrt(num / den)));
   }
 }
 void learn_from_batch(const anx_batch* b) {
+  // once per split: Shard::predicted is what the split assumed when it was made -- a batch that is run again and again (a resident
+  // benchmark batch) would otherwise apply the same ratio every time and drive the weights to their clamps
+  if (b->learned) return;
+  b->learned = true;
   std::vector<double> t(b->shards.size(), 0.0);
   for (size_t g = 0; g < b->shards.size(); ++g) {
     anx_batch_stats st;
@@ -1414,7 +1444,7 @@ int anx_batch_get_stats(const anx_batch* b, anx_batch_stats* out, size_t struct_
     anx_batch_stats t;
     anx::batch_stats(b->shards[g].b, &t);
     s->n_queries += t.n_queries; s->n_pairs += t.n_pairs; s->n_class_tests += t.n_class_tests; s->n_results += t.n_results;
-    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected; s->n_prefiltered_in_scan += t.n_prefiltered_in_scan; s->n_conf_scripts += t.n_conf_scripts; s->n_adj_tiles += t.n_adj_tiles;
+    s->n_scan_blocks += t.n_scan_blocks; s->n_pair_slots += t.n_pair_slots; s->n_survivors += t.n_survivors; s->n_selected += t.n_selected; s->n_prefiltered_in_scan += t.n_prefiltered_in_scan; s->n_conf_scripts += t.n_conf_scripts; s->n_adj_tiles += t.n_adj_tiles; s->n_adj_records += t.n_adj_records; s->n_adj_records_first += t.n_adj_records_first;
     for (int i = 0; i < 5; ++i) s->n_tests_kind[i] += t.n_tests_kind[i];
     s->ms_scan = std::max(s->ms_scan, t.ms_scan); s->ms_group = std::max(s->ms_group, t.ms_group); s->ms_score = std::max(s->ms_score, t.ms_score);
     s->ms_rank = std::max(s->ms_rank, t.ms_rank); s->ms_total = std::max(s->ms_total, t.ms_total);
@@ -1569,7 +1599,9 @@ int anx_pipeline_submit_packed(anx_pipeline* pl, const char* blob, size_t blob_l
   job->blob = blob; job->blob_len = blob_len; job->n = n; job->p = *p;
   {
     std::unique_lock<std::mutex> lk(pl->mu);
-    pl->cv.wait(lk, [&]() { return pl->jobs.size() < pl->depth; });
+    // a job leaves the queue in anx_pipeline_next only (finished jobs count until their results were taken): waiting here would
+    // block the one caller thread the pipeline is made for, for good
+    if (pl->jobs.size() >= pl->depth) return fail(ANX_ELIMIT, "pipeline full: take a result with anx_pipeline_next before submitting another job");
     job->seq = pl->next_seq++;
     pl->jobs.push_back(job);
   }

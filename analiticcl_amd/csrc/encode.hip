@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_tile_emit(TileArgs t) {
     Tile tl;
     tl.q0 = s; tl.nq = tn; tl.s0 = a0; tl.s1 = a1; tl.k = k; tl.lq = lq; tl.sig_lo = (uint32_t)sig; tl.sig_hi = (uint32_t)(sig >> 32);
     tl.kind = sad ? 0u : 1u; tl.d = d; tl.kend = sad ? 0u : (ke[0] | ke[1] << 8 | ke[2] << 16);
-    tl.ball0 = ball0; tl.balln = balln; tl.adj = adj;
+    tl.ball0 = ball0; tl.balln = balln; tl.adj = adj; tl.flags = (s == hs && part == 0u) ? 1u : 0u;
     t.tiles[base + part] = tl;
     // longest-processing-time first, bit-plane tiles before the count-vector ones: ascending key, stable
     // (a tile that streams an adjacency list: rows x (set-up + a test per query); the others: the signatures of their window)

@@ -754,7 +754,7 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
         const uint32_t a0 = s0 + part * step, a1 = std::min(s1, a0 + step);
         if (a0 >= a1 && part) break;
         b->tiles.push_back(Tile{(uint32_t)s, tn, a0, a1, k, lq, (uint32_t)h_sig[i], (uint32_t)(h_sig[i] >> 32), sad ? 0u : 1u,
-                                (h_meta[i] >> 16) & 0xFFu, kend, ball0, balln, adj});
+                                (h_meta[i] >> 16) & 0xFFu, kend, ball0, balln, adj, (s == i && part == 0u) ? 1u : 0u});
       }
     }
     i = j;
@@ -928,6 +928,7 @@ struct KTimer {
   std::mutex mu;
   std::atomic<bool> on{false};
   std::vector<KTimerRec> pending;
+  uint32_t generation = 0;  // of `pending`: part of the handles ktimer_begin hands out
   std::map<std::string, std::pair<double, uint64_t>> acc;
 };
 KTimer& ktimer() { static KTimer* t = new KTimer; return *t; }
@@ -941,6 +942,7 @@ void ktimer_resolve_locked(KTimer& t) {
     if (r.e1) (void)hipEventDestroy(r.e1);
   }
   t.pending.clear();
+  ++t.generation;  // handles of the records just dropped (also unclosed ones of a launch in progress on another thread) are void now
 }
 }  // namespace
 int ktimer_begin(const char* name, hipStream_t st) {
@@ -954,15 +956,17 @@ int ktimer_begin(const char* name, hipStream_t st) {
     return -1;
   }
   std::lock_guard<std::mutex> lk(t.mu);
+  if (t.pending.size() >= 0xFFFFu) return -1;
   t.pending.push_back(r);
-  return (int)t.pending.size() - 1;
+  return (int)(((t.generation & 0x7FFFu) << 16) | (uint32_t)(t.pending.size() - 1));  // generation + index: stable across kernel_timer_read
 }
 void ktimer_end(int handle, hipStream_t st) {
   if (handle < 0) return;
   KTimer& t = ktimer();
   std::lock_guard<std::mutex> lk(t.mu);
-  if ((size_t)handle >= t.pending.size()) return;  // the totals were read in between: the record is gone
-  KTimerRec& r = t.pending[(size_t)handle];
+  const uint32_t idx = (uint32_t)handle & 0xFFFFu;
+  if ((((uint32_t)handle >> 16) & 0x7FFFu) != (t.generation & 0x7FFFu) || idx >= t.pending.size()) return;  // the totals were read in between: the record is gone
+  KTimerRec& r = t.pending[idx];
   if (hipEventRecord(r.e1, st) == hipSuccess) r.closed = true;
 }
 void kernel_timer_enable(bool on) {
@@ -1325,7 +1329,7 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
   const uint32_t nq = (uint32_t)b->nq;
   const uint32_t* h = b->h_read;
   uint32_t maxfill = 0, surv_fill = 0, list_fill = 0;
-  uint64_t n_valid = 0, n_slots = 0, nsel = 0, n_fused = 0;
+  uint64_t n_valid = 0, n_slots = 0, nsel = 0, n_fused = 0, n_adj_rows = 0, n_adj_rows_first = 0;
   b->n_class_tests = 0;
   for (int i = 0; i <= NBITPLANES; ++i) b->n_tests_kind[i] = 0;
   for (uint32_t r = 0; r < SCAN_REGIONS; ++r) {
@@ -1335,6 +1339,8 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
     n_slots += c[RC_RAW];
     n_valid += c[RC_VALID];
     n_fused += c[RC_FUSED];
+    n_adj_rows += c[RC_ADJ];
+    n_adj_rows_first += c[RC_ADJ_FIRST];
     for (int i = 0; i <= NBITPLANES; ++i) {
       uint64_t v;
       memcpy(&v, c + RC_TESTS + 2 * i, sizeof v);
@@ -1385,6 +1391,8 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
   s.n_survivors = total_surv;
   s.n_selected = b->n_sel;
   s.n_prefiltered_in_scan = n_fused;
+  s.n_adj_records = n_adj_rows * kAdjRow;
+  s.n_adj_records_first = n_adj_rows_first * kAdjRow;
   (void)hipEventElapsedTime(&s.ms_scan, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.ms_score, b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&s.ms_group, b->ev[2], b->ev[3]);
@@ -1422,7 +1430,11 @@ int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void*
       use = s;
     }
   }
-  return batch_launch(m, dl, b, use, err);
+  const int rc = batch_launch(m, dl, b, use, err);
+  // what follows a finished run (fetches, exports, a repeated launch) goes to the CALLER's stream: on the library's shared run stream a
+  // fetch would queue behind the whole run of another batch in flight there
+  if (rc == ANX_OK && use != stream) b->last_stream = stream;
+  return rc;
 }
 int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::string& err) {
   for (int attempt = 0;; ++attempt) {

@@ -22,7 +22,8 @@
 //   reservation counter each (128 B apart): a single contended counter word sustains only ~88 M atomics/s, which
 //   at ~1.5 ms per million queries would be the bottleneck.
 // ------------------------------------------------------------------------------------------------
-enum { RC_RAW = 0, RC_VALID = 1, RC_FUSED = 2 /* pairs the fused band-match filter tested */, RC_TESTS = 4 /* u64 per scan kind at 4 + 2*kind */ };
+enum { RC_RAW = 0, RC_VALID = 1, RC_FUSED = 2 /* pairs the fused band-match filter tested */, RC_TESTS = 4 /* u64 per scan kind at 4 + 2*kind */,
+       RC_ADJ = 14 /* rows of adjacency lists streamed by the region's tiles */, RC_ADJ_FIRST = 15 /* ... by the first tile of every (length, signature) group */ };
 
 struct WaveOut {
   uint32_t base, left;  // unused part of the current chunk of the pair list (wave-uniform)
@@ -510,7 +511,7 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
   // loop this replaces took ~15 per RUN (16 ids on average: ~260 runs per tile on BASELINE configs[1], 0.28 of the kernel's
   // 1.63 ms and most of its 0.55 SALU instructions per VALU instruction).
   uint32_t* __restrict__ sdelta = stage + CHUNK;                                  // [64] per run of the step, in lane order
-  unsigned long long* __restrict__ smask = reinterpret_cast<unsigned long long*>(stage + CHUNK + 64);  // [SCAN_MASKW / 64] run ends of the window
+  uint32_t* __restrict__ smask = stage + CHUNK + 64;  // [SCAN_MASKW / 32] run ends of the window (one type for the store, the atomic and the load)
   auto stage_runs = [&](bool ok, uint32_t cb, uint32_t n) {
     ok = ok && n != 0u;  // an empty run has no end of its own
     const unsigned long long okm = __ballot(ok);
@@ -524,12 +525,12 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
     if (ok) sdelta[__builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = cb + cnt - 1u - endp;
     uint32_t rbase = 0;                              // runs that ended before the current block
     for (uint32_t w0 = 0; w0 < total; w0 += SCAN_MASKW) {  // windows of SCAN_MASKW stream positions (one, as a rule)
-      if (lane < SCAN_MASKW / 64u) smask[lane] = 0ull;
-      if (ok && endp - w0 < SCAN_MASKW) atomicOr(reinterpret_cast<uint32_t*>(smask) + ((endp - w0) >> 5), 1u << (endp & 31u));
+      if (lane < SCAN_MASKW / 32u) smask[lane] = 0u;
+      if (ok && endp - w0 < SCAN_MASKW) atomicOr(smask + ((endp - w0) >> 5), 1u << (endp & 31u));
       const uint32_t wend = total < w0 + SCAN_MASKW ? total : w0 + SCAN_MASKW;
       for (uint32_t p0 = w0; p0 < wend; p0 += 64) {
-        const unsigned long long m = smask[(p0 - w0) >> 6];  // wave-uniform address: a broadcast
-        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m), mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+        // wave-uniform addresses: broadcasts
+        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)smask[((p0 - w0) >> 6) * 2u]), mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)smask[((p0 - w0) >> 6) * 2u + 1u]);
         const uint32_t r = rbase + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
         rbase += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
         const uint32_t p = p0 + lane;
@@ -558,6 +559,10 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
     const uint32_t rbeg = t.k >= 3u ? 0u : t.k == 2u ? c0 : t.k == 1u ? c1 : c2;
     const uint32_t rend = t.k >= 3u ? c6 : t.k == 2u ? c5 : t.k == 1u ? c4 : c3;
     arend = row0 + rend;
+    if (lane == 0 && rend > rbeg) {  // statistics: rows streamed (bench.py: access bytes / bytes that have to be read at least once)
+      atomicAdd(&wo.ctr[RC_ADJ], rend - rbeg);
+      if (t.flags & 1u) atomicAdd(&wo.ctr[RC_ADJ_FIRST], rend - rbeg);
+    }
     uint2 npl[4];
     uint32_t nid[4];
     if (rbeg < rend) adj_load(row0 + rbeg, npl, nid);
@@ -655,7 +660,7 @@ __device__ inline void scan_wave(const ScanArgs& A) {
   if (item >= A.ntiles) return;
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
   Tile t;
-  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12]; t.adj = tp[13];
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12]; t.adj = tp[13]; t.flags = tp[14];
   // the launches are split by the encoders' tile order: [tiles that stream an adjacency list | other bit-plane tiles | count-vector tiles]
   scan_tile<BITS, NP, GEN, ADJ>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[BITS ? wid : 0], s_pbuf[BITS ? wid : 0]);
 }

@@ -338,8 +338,9 @@ class Pipeline:
         self._keep = []  # the submitted buffers stay alive until their results were returned
 
     def submit(self, packed: bytes, n: int, params: "SearchParameters"):
-        self._keep.append(packed)
+        """Raises AnxError (ANX_ELIMIT) when `depth` jobs are in flight: take a result with next() first."""
         L.check(L.lib().anx_pipeline_submit_packed(self.h, packed, len(packed), n, C.byref(params._c())))
+        self._keep.append(packed)
 
     def pending(self) -> int:
         return L.lib().anx_pipeline_pending(self.h)

@@ -220,7 +220,8 @@ void anx_compact_free(anx_topk_record *rows, uint32_t *offsets);
 void anx_compact_to_results(const anx_topk_record *rows, size_t n_rows, anx_result *out);
 /* The staged calls as an asynchronous pipeline for ONE caller thread (the reference's counterpart: independent find_variants calls in
  * flight on rayon's pool, src/bin/analiticcl.rs:445-448): submit hands over a packed buffer (as anx_batch_encode_packed; it must stay
- * valid until that job's results were returned) and returns at once -- or blocks while `depth` jobs are in flight; three library
+ * valid until that job's results were returned) and returns at once -- ANX_ELIMIT, nothing submitted, when `depth` jobs are in flight
+ * already: a job counts until anx_pipeline_next has returned its results, so the caller takes a result first; three library
  * threads encode, run and download the jobs on separate HIP streams, so the upload + encoding of batch i + 2, the device pipeline of
  * batch i + 1 and the download of batch i overlap; anx_pipeline_next returns the oldest job's ranked rows (compact records, as
  * anx_batch_fetch_compact; release with anx_compact_free) in submission order, or that job's error.  Models with variant lists or
@@ -270,6 +271,8 @@ typedef struct anx_batch_stats {
   uint64_t n_conf_scripts;   /* ABI 2: ranked rows whose edit script the device-side confusable weighting computed (the other rows
                               * were screened out: no pattern can match them) */
   uint64_t n_adj_tiles;      /* scan tiles that streamed a signature adjacency list (k_scan_adj) instead of probing their ball themselves */
+  uint64_t n_adj_records;    /* records (12 bytes each, padding included) those tiles streamed ... */
+  uint64_t n_adj_records_first; /* ... and the share of the first tile of every (length, signature) group: what the batch reads at least once */
 } anx_batch_stats;
 /* counts summed over the shards of the batch, times of the slowest replica.  struct_size = sizeof(anx_batch_stats) as the CALLER
  * was compiled: the library writes at most that many bytes, so a caller built against an older, shorter struct stays in bounds
@@ -320,7 +323,8 @@ int anx_debug_length_split(const anx_model *, const char *const *utf8, size_t n,
  * signature the scan prunes with (one byte per symbol group) of a string.  anx_debug_adjacency builds the lists of the model's lexicon
  * (closure 0..2, budget in bytes) and returns, for each of the n signatures, out_cum[i][8] = {first row of its list in *out_ids, rows
  * of the length sections L-3 .. L+3 cumulated} (all 0xFFFFFFFF: no list) and the lists' entry ids in rows of 64 (padding = number of
- * entries); *out_ids is released with free().  out_stats (may be NULL): {lexicon signatures, closure, lists kept, records, rows, ms}.
+ * entries); *out_ids is released with free().  out_stats (may be NULL): uint64[7] {lexicon signatures, closure, lists kept, records, rows, ms, rows an
+ * unlimited budget would keep}.
  * tests/test_adjacency_cpu.py compares them with find_nearest_anahashes' candidate set (src/lib.rs:1143-1308) by brute force. */
 int anx_debug_signature(const anx_model *, const char *utf8, uint64_t *out_sig);
 /* the index's entries (class-major order = the entry ids of the pair list and of the adjacency lists) as vocabulary ids; free() */

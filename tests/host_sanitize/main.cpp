@@ -40,6 +40,8 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
   for (const char* policy : {"range", "length"})
   for (int nrep : {1, 2, 3, 4}) {
     const bool by_length = strcmp(policy, "length") == 0;
+    // ANX_HARNESS_QUICK (the ThreadSanitizer run, several times slower): the two-replica and four-replica models under the default policy
+    if (getenv("ANX_HARNESS_QUICK") && !(by_length && (nrep == 2 || nrep == 4))) continue;
     CHECK(anx_debug_set_switch("ANX_SHARD_POLICY", policy) == ANX_OK);
     anx_model* m = anx_model_new(alphabet.c_str(), &w, 0);
     CHECK(m != nullptr);
@@ -49,7 +51,25 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
     if (nrep == 3) CHECK(anx_model_add_to_confusables(m, "-[a]+[e]", 1.05) == ANX_OK);
     CHECK(anx_model_build(m, -1) == ANX_OK);
     const int devs[4] = {0, 1, 1, 3};
+    // the signature adjacency lists are built (threaded) when the model goes to its devices: the lexicon's signatures only, their
+    // 1-neighbourhood too, and a budget that drops most of the lists
+    CHECK(anx_debug_set_switch("ANX_ADJ_CLOSURE", nrep == 2 ? "1" : "0") == ANX_OK);
+    CHECK(anx_debug_set_switch("ANX_ADJ_MB", (nrep == 3 || getenv("ANX_HARNESS_QUICK")) ? "16" : nullptr) == ANX_OK);
     CHECK(anx_model_to_devices(m, devs, nrep) == ANX_OK);
+    if (nrep == 1 && !by_length) {  // the lists by themselves: every list holds its own signature's entries (section 3 = the same length)
+      uint64_t sig = 0, stats[7] = {};
+      CHECK(anx_debug_signature(m, "separate", &sig) == ANX_OK);
+      uint32_t cum[8] = {}, *ids = nullptr, *ent = nullptr;
+      size_t nent = 0;
+      CHECK(anx_debug_entries(m, &ent, &nent) == ANX_OK && nent > 100000);
+      CHECK(anx_debug_adjacency(m, 1, (uint64_t)1 << 40, &sig, 1, cum, &ids, stats) == ANX_OK);
+      CHECK(cum[0] != 0xFFFFFFFFu && stats[2] == stats[1] && stats[1] > stats[0] && cum[7] > cum[1]);
+      size_t real = 0;
+      for (size_t i = (size_t)cum[0] * 64; i < (size_t)(cum[0] + cum[7]) * 64; ++i) real += ids[i] < nent;
+      CHECK(real > 100 && real <= (size_t)cum[7] * 64);
+      free(ids);
+      free(ent);
+    }
     CHECK(anx_model_num_replicas(m) == nrep && anx_model_replica_device(m, nrep - 1) == devs[nrep - 1] && anx_model_replica_device(m, nrep) == -1);
     CHECK(anx_debug_set_switch("ANX_SHARD_MIN", nrep == 4 ? "2000" : "1") == ANX_OK);  // 2000: 5000 inputs use 2 of the 4 replicas
     CHECK(anx_debug_set_switch("ANX_NO_SUCH_SWITCH", "1") == ANX_EINVAL);

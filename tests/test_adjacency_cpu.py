@@ -44,7 +44,7 @@ def _lists(m, closure, budget, sigs):
     sigs = np.asarray(sigs, dtype=np.uint64)
     cum = np.zeros((len(sigs), 8), dtype=np.uint32)
     ids = C.POINTER(C.c_uint32)()
-    stats = (C.c_uint64 * 6)()
+    stats = (C.c_uint64 * 7)()
     L.check(lib.anx_debug_adjacency(m.h, closure, budget, sigs.ctypes.data_as(C.c_void_p), len(sigs), cum.ctypes.data_as(C.c_void_p), C.byref(ids), stats))
     total = 0
     for c in cum:

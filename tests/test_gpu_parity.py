@@ -666,5 +666,12 @@ def test_pipeline_equals_staged_calls(eng, data_dir):
         pl.next()
     o, r = pl.next()                             # ... the next one does not
     assert np.array_equal(o, want[1][0]) and np.array_equal(r, want[1][1])
-    pl.submit(blobs[2], len(sets[2]), p)         # a job still in flight when the pipeline is freed
+    for i in range(3):                           # a full pipeline refuses the next job instead of blocking its one caller thread
+        pl.submit(blobs[i], len(sets[i]), p)
+    with pytest.raises(A.AnxError, match="pipeline full"):
+        pl.submit(blobs[3], len(sets[3]), p)
+    assert pl.pending() == 3
+    o, r = pl.next()
+    assert np.array_equal(o, want[0][0]) and np.array_equal(r, want[0][1])
+    pl.submit(blobs[3], len(sets[3]), p)         # jobs still in flight when the pipeline is freed
     pl.close()
