@@ -212,6 +212,7 @@ void build_adjacency(const LexiconImage& img, int closure, size_t budget_bytes, 
 
   {  // expected records per query of every length (queries drawn like lexicon entries)
     double num[256] = {}, den[256] = {};
+    std::vector<double> cnum(64 * 1024, 0.0), cden(64 * 1024, 0.0);
     for (size_t x = 0; x < nk; ++x) {
       if (keys[x].tier != 0) continue;
       const int i = lexsig.find(keys[x].sig);
@@ -221,8 +222,15 @@ void build_adjacency(const LexiconImage& img, int closure, size_t budget_bytes, 
       const double e = (double)entries_of_run(i);
       num[std::min(len, 255)] += e * (double)nrec[x];
       den[std::min(len, 255)] += e;
+      if (len < 64) {
+        const size_t c = (size_t)len * 1024 + std::min<size_t>(keys[x].sig & 0xFFu, 31) * 32 + std::min<size_t>((keys[x].sig >> 8) & 0xFFu, 31);
+        cnum[c] += e * (double)nrec[x];
+        cden[c] += e;
+      }
     }
     for (int L = 0; L < 256; ++L) out.len_records[L] = den[L] > 0.0 ? num[L] / den[L] : 0.0;
+    out.class_records.assign(64 * 1024, 0.0f);
+    for (size_t c = 0; c < cnum.size(); ++c) out.class_records[c] = cden[c] > 0.0 ? (float)(cnum[c] / cden[c]) : 0.0f;
   }
   lap("pass 1 (rows)");
   // ---- which lists fit the budget: by (distance from the lexicon, rows) ascending ---------------------------------------------

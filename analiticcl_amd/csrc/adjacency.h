@@ -47,6 +47,9 @@ struct AdjIndex {
   // per length L: records in the ball of a lexicon entry's signature, averaged over the entries of that length (0: no entry) -- what
   // the scan tests per query of that length when the queries resemble the lexicon: the prior of the length-partitioned split (capi.cpp)
   double len_records[256] = {};
+  // the same by (length, group sum 0, group sum 1) for lengths < 64, sums clipped to 31: index length * 1024 + sum0 * 32 + sum1 -- the
+  // classes the split orders the inputs by; within one length the dense signatures (common letters) meet several times the records
+  std::vector<float> class_records;
   double build_ms = 0.0;
   AdjIndex() = default;
   AdjIndex(const AdjIndex&) = delete;

@@ -83,7 +83,9 @@ struct LengthCost {
   // prior from the signature adjacency lists (anx_model_to_devices): records the scan tests per query of every length, averaged over
   // the lexicon's entries of that length; have_records = false: the window-size prior below
   double records[LMAX] = {};
+  std::vector<float> class_records;   // by split class (length < 64: length * 1024 + group sum 0 * 32 + group sum 1); 0 = no entry there
   bool have_records = false;
+  unsigned updates = 0;   // learning steps since the corrections started over
   anx_threshold k_of, d_of;
   bool init = false;
 };
@@ -333,6 +335,7 @@ int anx_model_to_devices(anx_model* m, const int* devices, int n) {
       LengthCost& lc = m->len_cost;
       std::lock_guard<std::mutex> lk(lc.mu);
       for (uint32_t L = 0; L < LengthCost::LMAX; ++L) lc.records[L] = adj->len_records[L];
+      lc.class_records = adj->class_records;
       lc.have_records = !adj->hash.empty();
       lc.init = false;  // the corrections were learned against another prior
     }
@@ -877,12 +880,14 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
   // The learned correction (LengthCost) takes it from there.
   const anx::LexiconImage& lex = m->host.lex;
   double w[LMAX];
+  std::vector<double> wc(SPLIT_NCLS, 0.0);  // per class: the length's weight, refined by the class's own records where the lexicon has entries there
   {
     LengthCost& lc = m->len_cost;
     std::lock_guard<std::mutex> lk(lc.mu);
     auto same = [](const anx_threshold& a, const anx_threshold& b) { return a.kind == b.kind && a.value == b.value && a.ratio == b.ratio; };
     if (!lc.init || !same(lc.k_of, p.max_anagram_distance) || !same(lc.d_of, p.max_edit_distance)) {
       for (double& x : lc.scale) x = 1.0;
+      lc.updates = 0;
       lc.k_of = p.max_anagram_distance;
       lc.d_of = p.max_edit_distance;
       lc.init = true;
@@ -894,7 +899,7 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
       const double rel = L ? (double)k / (double)L : 0.0;
       if (lc.have_records && k <= anx::kAdjRadius) {
         // round 5: the adjacency lists say how many records a query of this length meets (lengths without lexicon entries take
-        // the nearest length that has some); 3000 record tests ~ the per-query work that does not depend on them (encoder, tile
+        // the nearest length that has some) plus the per-query work that does not depend on them (encoder, tile
         // set-up, ranking: ~1 ns against 0.3 ps per record test on BASELINE configs[1] / [3]).  First-call balance of the configs[3]
         // job: 0.57 with the window prior, see DESIGN.md section 6
         double r = lc.records[L];
@@ -902,11 +907,32 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
           if (L >= o && lc.records[L - o] > 0.0) r = lc.records[L - o];
           else if (L + o < LMAX && lc.records[L + o] > 0.0) r = lc.records[L + o];
         }
-        w[L] = (3000.0 + r) * lc.scale[L];
+        // what a record test goes on to cost depends on the share of the records that are hits and survive the band filter and the
+        // DL: large for short strings (k / L large: most of a short string's neighbourhood is within reach), small for long ones.
+        // Fitted on the 10 M-query configs[3] job (ns per query by length: 21.7 at 6 symbols, 10.5 at 8, 5 at 10, 3 at 12, 2.3 from 16 on:
+        // 6500 record tests ~ the per-query work that does not depend on the records -- encoder, tile set-up at 5 queries per tile, ranking)
+        const double x = std::min(rel, 0.5);
+        w[L] = (6500.0 + r * (0.35 + 15.2 * x * x * x)) * lc.scale[L];
       } else {
         w[L] = (1024.0 + window / 16.0) * (1.0 + 30.0 * rel * rel * rel) * lc.scale[L];
       }
     }
+    for (uint32_t c = 0; c < SPLIT_NCLS; ++c) {
+      const uint32_t L = std::min(split_class_len(c), LMAX - 1);
+      wc[c] = w[L];
+      if (lc.have_records && c < lc.class_records.size() && lc.class_records[c] > 0.0f && lc.records[L] > 0.0) {
+        const int k = anx::clamp_threshold(p.max_anagram_distance, (int)L, anx::kMaxAnagramDistance);
+        if (k <= anx::kAdjRadius) {
+          const double x = std::min(L ? (double)k / (double)L : 0.0, 0.5), f = 0.35 + 15.2 * x * x * x;
+          wc[c] = w[L] * (6500.0 + (double)lc.class_records[c] * f) / (6500.0 + lc.records[L] * f);
+        }
+      }
+    }
+  }
+  if (getenv("ANX_SPLIT_DEBUG")) {
+    fprintf(stderr, "[anx split] have_records %d updates %u:", (int)m->len_cost.have_records, m->len_cost.updates);
+    for (uint32_t L = 1; L < 36; ++L) fprintf(stderr, " %u:%.0f", L, w[L]);
+    fprintf(stderr, "\n");
   }
   // cumulative cost at the first input of every class; rank of every thread's first input inside its class
   std::vector<double> base(SPLIT_NCLS + 1, 0.0);
@@ -914,7 +940,7 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
   for (uint32_t c = 0; c < SPLIT_NCLS; ++c) {
     uint32_t run = 0;
     for (unsigned t = 0; t < T; ++t) { const uint32_t h = hist[t][c]; start[t][c] = run; run += h; }
-    base[c + 1] = base[c] + w[split_class_len(c)] * (double)run;
+    base[c + 1] = base[c] + wc[c] * (double)run;
   }
   const double total = base[SPLIT_NCLS] > 0.0 ? base[SPLIT_NCLS] : 1.0;
   std::vector<uint8_t> gid(n);
@@ -923,7 +949,7 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
     std::vector<uint32_t>& st = start[t];
     for (size_t i = lo; i < hi; ++i) {
       const uint32_t c = cls[i];
-      const double cum = base[c] + w[split_class_len(c)] * (double)st[c]++;
+      const double cum = base[c] + wc[c] * (double)st[c]++;
       const size_t g = std::min(S - 1, (size_t)(cum * (double)S / total));
       gid[i] = (uint8_t)g;
       ++per[t][g];
@@ -945,7 +971,7 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
     sh.lhist.assign(LMAX, 0u);
     for (uint32_t i : sh.idx) ++sh.lhist[std::min<uint32_t>(split_class_len(cls[i]), LMAX - 1)];
     sh.predicted = 0.0;
-    for (uint32_t L = 0; L < LMAX; ++L) sh.predicted += w[L] * (double)sh.lhist[L];
+    for (uint32_t i : sh.idx) sh.predicted += wc[cls[i]];
   }
   shards.erase(std::remove_if(shards.begin(), shards.end(), [](const Shard& s) { return s.n == 0; }), shards.end());
 }
@@ -968,9 +994,11 @@ void learn_length_costs(const anx_model* m, const std::vector<Shard>& shards, co
       num += c * (t[g] / shards[g].predicted) / (tsum / psum);
       den += c;
     }
-    // damped (square root of the measured ratio): a noisy run moves the weights half way, and the next split is measured afresh
-    if (den > 0.0) lc.scale[L] = std::min(64.0, std::max(1.0 / 64.0, lc.scale[L] * std::sqrt(num / den)));
+    // the first two updates take the measured ratio as it is (the prior may be far off for this lexicon / these parameters); later
+    // ones are damped (square root): a noisy run moves the weights half way, and the next split is measured afresh
+    if (den > 0.0) lc.scale[L] = std::min(64.0, std::max(1.0 / 64.0, lc.scale[L] * (lc.updates < 2 ? num / den : std::sqrt(num / den))));
   }
+  ++lc.updates;
 }
 void learn_from_batch(const anx_batch* b) {
   // once per split: Shard::predicted is what the split assumed when it was made -- a batch that is run again and again (a resident
@@ -1066,6 +1094,32 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
       h->in_off.push_back((uint32_t)h->in_text.size());
     }
   }
+  return h;
+}
+anx_batch* anx_batch_encode_packed_device(const anx_model* m, const void* device_blob, size_t blob_len, size_t n, const anx_params* p) {
+  if (!m || (!device_blob && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
+  if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() first"); return nullptr; }
+  if (blob_len >= ((size_t)1 << 32)) { fail(ANX_ELIMIT, "inputs exceed 4 GB per batch: split the batch"); return nullptr; }
+  if (check_resident(m)) return nullptr;
+  if (m->replicas.size() != 1) { fail(ANX_EINVAL, "inputs in device memory: the model must be on exactly one device (the one that holds them)"); return nullptr; }
+  bool rescore;
+  anx_params dp = device_params(m, p, &rescore);
+  const bool dev_conf = rescore && !anx::switches().confusables_host;
+  if (dev_conf) { dp = *p; rescore = false; }
+  if (rescore) { fail(ANX_EINVAL, "inputs in device memory cannot be rescored on the host (ANX_CONFUSABLES=host)"); return nullptr; }
+  anx_batch* h = new anx_batch();
+  h->model = m;
+  h->n_input = n;
+  h->dev_conf = dev_conf;
+  h->params = *p;
+  h->shards.resize(1);
+  Shard& s = h->shards[0];
+  s.replica = 0; s.lo = 0; s.n = n;
+  std::string err;
+  int code = ANX_OK;
+  s.b = anx::batch_encode_spans(m->host, m->replicas[0].dev, static_cast<const char*>(device_blob), blob_len, nullptr, n, dp, err, &code, dev_conf, true);
+  if (!s.b) { fail(code ? code : ANX_ENODEVICE, err); delete h; return nullptr; }
+  if (dev_conf) anx::batch_set_run_mode(s.b, dp, m->host.confusables_before_pruning ? 2 : 1);
   return h;
 }
 anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t blob_len, size_t n, const anx_params* p) {

@@ -38,8 +38,9 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
                     const anx_params& p, std::string& err, int* code, bool keep_text = false);
 // the same with the inputs in one buffer: input i = blob[off[i] .. off[i+1] - 1), followed by one NUL byte.  off == nullptr: the
 // inputs are the first n NUL-terminated spans of blob[0, blob_bytes) and the device finds their offsets itself
+// blob_on_device: `blob` is device memory of the replica's device (off must be nullptr then): the encoder copies it device to device
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
-                          const anx_params& p, std::string& err, int* code, bool keep_text = false);
+                          const anx_params& p, std::string& err, int* code, bool keep_text = false, bool blob_on_device = false);
 // how the following runs treat confusables: conf_mode 0 = not on the device (the caller rescored / has none), 1 = late, 2 = early
 // (src/lib.rs:1591-1595 / :1505-1508); `p` = the parameters those runs use
 void batch_set_run_mode(Batch* b, const anx_params& p, int conf_mode);

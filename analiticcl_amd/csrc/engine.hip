@@ -832,8 +832,9 @@ static int encode_tail(Batch* b, std::string& err) {
 }
 
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
-                          const anx_params& p, std::string& err, int* code, bool keep_text) {
+                          const anx_params& p, std::string& err, int* code, bool keep_text, bool blob_on_device) {
   *code = ANX_OK;
+  if (blob_on_device && (off || switches().encode_host)) { err = "inputs in device memory need the device-side encoder and no host offsets"; *code = ANX_EINVAL; return nullptr; }
   if (!dl) { err = "model is not resident on a device (no HIP device / anx_model_to_device not called)"; *code = ANX_ENODEVICE; return nullptr; }
   if (hipSetDevice(dl->device) != hipSuccess) { err = "hipSetDevice failed"; *code = ANX_ENODEVICE; return nullptr; }
   if (n >= (1u << 27)) { err = "more than 2^27 inputs per batch"; *code = ANX_ELIMIT; return nullptr; }
@@ -860,7 +861,7 @@ Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const cha
       b->text_bytes = bytes;
     }
   } else {
-    rc = batch_encode_device(m, dl, b, blob, blob_bytes, off, n, p, err);
+    rc = batch_encode_device(m, dl, b, blob, blob_bytes, off, n, p, err, blob_on_device);
   }
   if (!rc) rc = encode_tail(b, err);
   if (rc) { *code = rc; batch_free(b); return nullptr; }

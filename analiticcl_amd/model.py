@@ -183,15 +183,19 @@ class Batch:
     """A batch of queries encoded and resident in HBM (anx_batch_*): encode once, run many times."""
 
     def __init__(self, model: "VariantModel", inputs: Sequence[str], params: SearchParameters, packed: Optional[bytes] = None,
-                 n: Optional[int] = None):
+                 n: Optional[int] = None, device_ptr: Optional[int] = None, nbytes: int = 0):
         """inputs: the query strings; or packed + n: the same as ONE bytes object, every input followed by a NUL byte (what a
         caller that reads its queries from a file or a socket already has: the buffer goes to the device as it is)."""
         self.model = model
         cp = params._c()
         # one NUL-terminated buffer instead of a pointer array (anx_batch_encode_packed)
-        blob = _pack(inputs) if packed is None else packed
-        self.n = len(inputs) if packed is None else int(n)
-        self.h = L.lib().anx_batch_encode_packed(model.h, blob, len(blob), self.n, C.byref(cp))
+        if device_ptr is not None:   # the packed buffer already sits in HBM (anx_batch_encode_packed_device)
+            self.n = int(n)
+            self.h = L.lib().anx_batch_encode_packed_device(model.h, C.c_void_p(device_ptr), int(nbytes), self.n, C.byref(cp))
+        else:
+            blob = _pack(inputs) if packed is None else packed
+            self.n = len(inputs) if packed is None else int(n)
+            self.h = L.lib().anx_batch_encode_packed(model.h, blob, len(blob), self.n, C.byref(cp))
         if not self.h:
             raise L.AnxError(L.ANX_ENODEVICE if "device" in L.last_error() else L.ANX_EINVAL, L.last_error())
         self.freq_weight = float(params.freq_weight)
@@ -533,6 +537,10 @@ class VariantModel:
     def encode_packed(self, packed: bytes, n: int, params: SearchParameters) -> Batch:
         """encode_batch for n inputs already packed into one bytes object, each followed by a NUL byte."""
         return Batch(self, (), params, packed=packed, n=n)
+
+    def encode_packed_device(self, device_ptr: int, nbytes: int, n: int, params: SearchParameters) -> Batch:
+        """encode_packed for a packed buffer in device memory (e.g. a torch uint8 tensor's data_ptr()): nothing crosses PCIe."""
+        return Batch(self, (), params, n=n, device_ptr=device_ptr, nbytes=nbytes)
 
     def encode_batch(self, inputs: Sequence[str], params: SearchParameters) -> Batch:
         return Batch(self, inputs, params)

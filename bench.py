@@ -89,14 +89,34 @@ def roofline_of(args, model, queries, st, scan_ms, fs_ms, total_ms):
     # kernel's prefilter touched before (candidate symbols 16 B + entry meta 8 B = the `Lpad + 8` of SURVEY.md section 8(d)'s
     # per-pair figure; the query's symbols come from LDS, staged once per tile: 16 B per query) and writes a pair record only
     # for the survivors
-    scan_bytes = st["n_queries"] * (16 + 16) + st["n_scan_blocks"] * 44 + n_classes * 44 + st.get("n_prefiltered_in_scan", 0) * (lpad + 8) + st["n_pair_slots"] * 8
+    # round 5: the scan STREAMS the adjacency list of every tile's signature (analiticcl_amd/csrc/adjacency.h: 12 B per record, padding
+    # included) instead of gathering 16-B records out of an L2-resident image: the lists are real HBM traffic.  Two figures:
+    #   access bytes     = what the kernel requests: every tile's list (n_adj_records x 12), the 32-B candidate record of every pair the
+    #                      fused band filter tests, queries, tile descriptors, pair-list slots out;
+    #   compulsory bytes = what a launch has to move at least once: the list of every DISTINCT (length, signature) group of the batch
+    #                      (n_adj_records_first: the tiles a large group is cut into re-read it, as a rule from the Infinity Cache), the
+    #                      candidate records once (the e_rec image, 32 B per lexicon entry), queries, tiles, slots out.
+    # `achieved` / `frac` of the JSON line are the compulsory bytes over the kernel's duration (SURVEY.md section 8(d)'s sense);
+    # `access_frac` is the requested-bytes figure the line carried until round 4.
+    n_entries = model.num_instances()
+    fused_pairs = st.get("n_prefiltered_in_scan", 0)
+    adj_rec, adj_first = st.get("n_adj_records", 0), st.get("n_adj_records_first", 0)
+    scan_fixed = st["n_queries"] * (16 + 16) + st["n_scan_blocks"] * 60 + st["n_pair_slots"] * 8
+    if adj_rec:
+        scan_bytes = scan_fixed + adj_rec * 12 + fused_pairs * 32
+        scan_compulsory = scan_fixed + adj_first * 12 + min(fused_pairs, n_entries) * 32
+    else:  # ANX_SCAN_ADJ=0 / alphabets beyond the bit-plane scan: the round-4 model (16-B record gathers out of the lexicon image)
+        scan_bytes = scan_fixed + n_classes * 44 + fused_pairs * (lpad + 8)
+        scan_compulsory = scan_fixed + n_entries * (16 + 32)
     fs_bytes = st["n_pair_slots"] * (8 + lpad + 8) + st["n_survivors"] * 16
+    fs_compulsory = st["n_pair_slots"] * 8 + (st["n_queries"] + n_entries) * 32 + st["n_survivors"] * 16
     fs_bytes_survey = min(st["n_pairs"], st["n_pair_slots"]) * (lpad + 32)
     if fs_ms > scan_ms:
-        kname, kbytes, kms = "k_filter_score", fs_bytes, fs_ms
+        kname, kbytes, kcomp, kms = "k_filter_score", fs_bytes, fs_compulsory, fs_ms
     else:
-        kname, kbytes, kms = "k_scan_bits", scan_bytes, scan_ms
-    achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        kname, kbytes, kcomp, kms = ("k_scan_adj" if adj_rec else "k_scan_bits"), scan_bytes, scan_compulsory, scan_ms
+    achieved = kcomp / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    access_gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     pipeline_bytes = st["n_pairs"] * (lpad + 32) + st["n_queries"] * 208
     pipeline_gbs = pipeline_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
     # The bound that actually binds both kernels is VALU issue (89 % / 77 % VALU-active, profiles/): the floor below counts
@@ -150,20 +170,34 @@ def roofline_of(args, model, queries, st, scan_ms, fs_ms, total_ms):
                 if pj.get("kernel_src_sha256") == h.hexdigest():
                     traffic, traffic_src = pj["kernels"][kname]["traffic_bytes"], os.path.basename(cand)
                     break
+        elif getattr(args, "profile_key", None):  # the other configurations: profiles/r*_pmc_traffic.json "configs" (tools/collect_profiles.py)
+            import glob
+            for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                with open(cand) as f:
+                    pj = json.load(f)
+                ent = pj.get("configs", {}).get(args.profile_key, {}).get(kname)
+                if ent:
+                    traffic, traffic_src = ent["traffic_bytes"], os.path.basename(cand) + ":" + args.profile_key
+                    break
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "valu_issue", "hbm_bound_fields": "achieved / peak / unit / frac = compulsory HBM bytes per launch of the slowest kernel over its duration "
+                                                            "(the figure the bench contract asks for); what binds the kernel is vector-instruction issue",
+                "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": kms,
-                "algorithmic_bytes_per_launch": kbytes,
-                "note": "integer scan / DL path: both kernels are VALU-issue bound, far below the HBM roof (DESIGN.md section 5); "
-                        "valu_issue_frac = algorithmic instruction floor / measured kernel time",
+                "compulsory_bytes": kcomp, "access_bytes": kbytes, "access_gbs": access_gbs, "access_frac": access_gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": kcomp,
+                "note": "integer scan / DL path: both kernels are bound by vector-instruction issue (DESIGN.md section 5); valu_issue_frac = algorithmic "
+                        "instruction floor / measured kernel time.  The scan streams its adjacency lists from HBM (12 B per record): access_bytes "
+                        "counts every tile's list, compulsory_bytes the list of every distinct (length, signature) group once",
                 "kernels_ms": {"k_scan_bits": scan_ms, "k_filter_score": fs_ms},
-                "per_kernel": {name: {"avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
-                                      "achieved": (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
-                                      "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0),
-                                      "valu_issue_floor_ms": fl, "valu_issue_frac": (fl / ms if ms > 0 else 0.0)}
-                               for name, nbytes, ms, fl in (("k_scan_bits", scan_bytes, scan_ms, valu_floor_ms),
-                                                            ("k_filter_score", fs_bytes, fs_ms, fs_valu_floor_ms))},
+                "per_kernel": {name: {"avg_kernel_ms": ms, "compulsory_bytes": comp, "access_bytes": nbytes, "algorithmic_bytes_per_launch": comp,
+                                      "achieved": (comp / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
+                                      "frac": (comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0),
+                                      "access_frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0),
+                                      "bound": "valu_issue", "valu_issue_floor_ms": fl, "valu_issue_frac": (fl / ms if ms > 0 else 0.0)}
+                               for name, nbytes, comp, ms, fl in ((("k_scan_adj (+ k_scan_bits)" if adj_rec else "k_scan_bits"), scan_bytes, scan_compulsory, scan_ms, valu_floor_ms),
+                                                                  ("k_filter_score", fs_bytes, fs_compulsory, fs_ms, fs_valu_floor_ms))},
                 "k_filter_score_survey_model": {"algorithmic_bytes_per_launch": fs_bytes_survey,
                                                 "frac": (fs_bytes_survey / (fs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fs_ms > 0 else 0.0)},
                 "pipeline_algorithmic_bytes": pipeline_bytes, "pipeline_gbs": pipeline_gbs,
@@ -324,7 +358,23 @@ def _spot_check(model, om, queries, arrays, op, n, rescore=None):
     return f"ok ({n} queries vs the oracle)"
 
 
-def _config_roofline(model, queries, st, total_ms, lexicon, max_len, dd, nq, extra=None):
+def _profile_traffic(profile_key, kernel):
+    """HBM bytes per launch of `kernel` in the tracked PMC passes of a configuration (profiles/r*_pmc_traffic.json "configs",
+    written by tools/collect_profiles.py from profiles/r*_{conf,big,search}_pmc.md) -> (bytes | None, source | None)."""
+    import glob
+    short = kernel.split(" ")[0]
+    for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(cand) as f:
+                ent = json.load(f).get("configs", {}).get(profile_key, {}).get(short)
+        except Exception:
+            ent = None
+        if ent:
+            return ent["traffic_bytes"], os.path.basename(cand) + ":" + profile_key
+    return None, None
+
+
+def _config_roofline(model, queries, st, total_ms, lexicon, max_len, dd, nq, extra=None, profile_key=None):
     """The roofline entry of an extra configuration: the slowest kernel of its device pass against the 8 TB/s HBM roof, from the
     same byte / instruction models as the headline line (roofline_of) and the live HIP-event kernel times of anx_batch_stats;
     `extra` = (name, ms, algorithmic bytes, note) of a kernel outside that pair (k_conf_script, k_lattice: timed by the library's
@@ -332,13 +382,17 @@ def _config_roofline(model, queries, st, total_ms, lexicon, max_len, dd, nq, ext
     r = roofline_of(argparse.Namespace(max_len=max_len, edit_distance=dd, anagram_distance=3, lexicon=lexicon, queries=nq), model, queries, st,
                     st["ms_scan_kernel"], st["ms_filter_score_kernel"], total_ms)
     pk = r["per_kernel"]
-    cands = [(k, v["avg_kernel_ms"], v["algorithmic_bytes_per_launch"], v["valu_issue_frac"], None) for k, v in pk.items()]
-    if extra:
-        cands.append((extra[0], extra[1], extra[2], None, extra[3]))
-    k, ms, nbytes, vf, note = max(cands, key=lambda c: c[1])
-    out = {"bound": "hbm", "kernel": k, "avg_kernel_ms": ms, "algorithmic_bytes": nbytes, "achieved": (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0),
-           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0), "valu_issue_frac": vf,
-           "kernels_ms": {c[0]: c[1] for c in cands}, "traffic": None}
+    # (name, ms, compulsory bytes, access bytes, VALU-issue fraction, what binds it, note)
+    cands = [(k, v["avg_kernel_ms"], v["compulsory_bytes"], v["access_bytes"], v["valu_issue_frac"], "valu_issue", None) for k, v in pk.items()]
+    if extra:  # (name, ms, bytes, note[, bound])
+        cands.append((extra[0], extra[1], extra[2], extra[2], None, extra[4] if len(extra) > 4 else "divergence", extra[3]))
+    k, ms, comp, acc, vf, bound, note = max(cands, key=lambda c: c[1])
+    traffic, tsrc = _profile_traffic(profile_key, k) if profile_key else (None, None)
+    gbs = lambda nb: (nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)  # noqa: E731
+    out = {"bound": bound, "kernel": k, "avg_kernel_ms": ms, "compulsory_bytes": comp, "access_bytes": acc, "algorithmic_bytes": comp,
+           "achieved": gbs(comp), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(comp) / HBM_PEAK_GBS, "access_frac": gbs(acc) / HBM_PEAK_GBS,
+           "valu_issue_frac": vf, "kernels_ms": {c[0]: c[1] for c in cands}, "traffic": traffic, "traffic_source": tsrc,
+           "hbm_bound_fields": "achieved / frac = compulsory HBM bytes of the slowest kernel over its duration; `bound` names what binds it"}
     if note:
         out["note"] = note
     return out
@@ -441,7 +495,8 @@ def extra_configs(args, paths, device, ncores):
                 "pairs_per_s": st["n_pairs"] / dt, "e2e_queries_per_s": e2e, "parity": chk, "conf_scripts": st["n_conf_scripts"],
                 "roofline": _config_roofline(m, qs, st, dt * 1e3, "nld", 24, 3, 1_000_000,
                                              extra=("k_conf_script", conf_ms / max(conf_n, 1), conf_bytes,
-                                                    "one lane group per ranked row through a branchy edit-script algorithm: bound by lane divergence, not by bytes (profiles/)")),
+                                                    "one lane group per ranked row through a branchy edit-script algorithm: bound by lane divergence, not by bytes (profiles/)", "divergence"),
+                                             profile_key="conf"),
                 "what": "device_ms = one pass of the device pipeline over the resident batch; e2e = packed host buffer -> encode -> run -> fetch incl. the confusable rescoring"}
 
     def configs3_share():  # merged 1 M-entry lexicon, one GPU's 1.25 M of the 10 M length-bucketed queries
@@ -473,6 +528,7 @@ def extra_configs(args, paths, device, ncores):
         # the split learns what a query of every length costs from the device times of its shards (capi.cpp LengthCost): three
         # rounds on the sample's own 8 shares, run one after the other on this GPU, stand in for the first calls of an 8-GPU job
         share_ms = []
+        balance_by_round, longest_by_round = [], []
         for _round in range(4):
             gid = m.length_split(sample, p, 8)
             share_ms = []
@@ -480,6 +536,8 @@ def extra_configs(args, paths, device, ncores):
                 bs = m.encode_batch([q for q, s_ in zip(sample, gid) if s_ == g_], p)
                 share_ms.append(_time_runs(bs, reps=2) * 1e3)
                 bs.free()
+            balance_by_round.append(sum(share_ms) / 8 / max(share_ms))
+            longest_by_round.append(max(share_ms))
             if _round < 3:
                 m.length_split(sample, p, 8, learn_ms=share_ms)
         share = int(np.argmax(share_ms))   # the share that takes longest decides the job's time
@@ -499,12 +557,15 @@ def extra_configs(args, paths, device, ncores):
         return {"workload": "BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon, 1.25 M of the 10 M length-bucketed queries len 4-32, k=3 d=2 n=10",
                 "ms_per_batch": dt * 1e3, "ms_per_1M_queries": dt * 1e3 / 1.25, "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt,
                 "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "scan_tiles": st["n_scan_blocks"], "parity": chk,
-                "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000),
+                "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000, profile_key="big"),
                 "what": "ms_per_1M_queries = a RANDOM eighth of the job (what consecutive input ranges give a GPU: an eighth of every (length, signature) group); "
                         "by_length = one share of the length-partitioned split the library uses for multi-device models",
                 "by_length": {"workload": f"the longest of the 8 shares of the 10 M-query job under the length-partitioned split (share {share}: the queries of lengths {min(quota)}-{max(quota)} it owns), "
                                           "after three learning rounds of the split's cost model on a 1 M-query sample of the job",
                               "sample_share_ms": share_ms, "sample_balance": sum(share_ms) / 8 / max(share_ms),
+                              # round 0 = the FIRST call of a job: the split's prior alone (records per query of every length, from the
+                              # adjacency lists), no measured correction yet; the later rounds have learned from the shards' device times
+                              "first_call_balance": balance_by_round[0], "balance_by_round": balance_by_round, "longest_share_ms_by_round": longest_by_round,
                               "job_speedup_vs_consecutive_ranges": dt / dt2,
                               "queries": len(qs2), "ms_per_batch": dt2 * 1e3, "ms_per_1M_queries": dt2 * 1e3 / (len(qs2) / 1e6), "pairs_per_s": st2["n_pairs"] / dt2,
                               "scan_kernel_ms": st2["ms_scan_kernel"], "filter_score_kernel_ms": st2["ms_filter_score_kernel"], "scan_tiles": st2["n_scan_blocks"],
@@ -577,9 +638,10 @@ def extra_configs(args, paths, device, ncores):
                 "MB_per_s": nbytes / 1e6 / best, "seconds": best, "matches": int(off[-1]), "variant_rows": int(ra.shape[0]),
                 # k_lattice per call (all its launches): algorithmic bytes = the lattice input (16 B per arc: one arc per variant row, plus
                 # one out-of-vocabulary / epsilon arc per match) + the chosen symbols out (8 B per match)
-                "roofline": (lambda ms, nb: {"bound": "hbm", "kernel": "k_lattice", "avg_kernel_ms": ms, "algorithmic_bytes": nb,
+                "roofline": (lambda ms, nb: {"bound": "latency", "kernel": "k_lattice", "avg_kernel_ms": ms, "algorithmic_bytes": nb, "compulsory_bytes": nb, "access_bytes": nb,
                                              "achieved": (nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": (nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0), "valu_issue_frac": None, "traffic": None,
+                                             "frac": (nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0), "valu_issue_frac": None,
+                                             "traffic": _profile_traffic("search", "k_lattice")[0], "traffic_source": _profile_traffic("search", "k_lattice")[1],
                                              "launches_per_call": lat_n / 5.0,
                                              "note": "ms = all k_lattice launches of one call; two stretches per wave, K <= 250 serial pops of a group-wide minimum each: "
                                                      "latency-bound, and the call as a whole is bound by its host phases (MB_per_s)"})(
@@ -929,6 +991,45 @@ def main():
         for _ in range(nsync):
             batches[0].run(stream.cuda_stream)
         sync_ms = (time.perf_counter() - t1) / nsync * 1e3
+    # The step WITH the query encoder (normalize_to_alphabet, the count vector behind anahash,
+    # the clamps): the raw input bytes are resident in HBM (one packed buffer, every string followed by a NUL byte), a step = device
+    # encoder (anx_batch_encode_packed_device: no PCIe) + anx_batch_run_async, the run waited for a step later -- the encoder of
+    # step i + 1 works while the GPU runs step i.  Never `value`: reported next to it.
+    with_encode = None
+    if world == 1 and not do_gather and not args.timed_only:
+        packed_ = ("\0".join(queries) + "\0").encode("utf-8")
+        dev_blob = torch.frombuffer(bytearray(packed_), dtype=torch.uint8).cuda()
+        live = []
+
+        def enc_step():
+            b_ = model.encode_packed_device(dev_blob.data_ptr(), dev_blob.numel(), len(queries), params)
+            b_.run_async(stream.cuda_stream)
+            live.append(b_)
+            if len(live) > 1:
+                o_ = live.pop(0)
+                o_.wait()
+                o_.free()
+
+        def enc_drain():
+            while live:
+                o_ = live.pop(0)
+                o_.wait()
+                o_.free()
+            torch.cuda.synchronize()
+        for _ in range(3):
+            enc_step()
+        enc_drain()
+        t1 = time.perf_counter()
+        nenc = max(8, args.steps)
+        for _ in range(nenc):
+            enc_step()
+        enc_drain()
+        dt_ = (time.perf_counter() - t1) / nenc
+        with_encode = {"ms_per_step": dt_ * 1e3, "queries_per_s": len(queries) / dt_, "pairs_per_s": batch.stats()["n_pairs"] / dt_, "steps": nenc,
+                       "what": "raw packed input bytes resident in HBM -> device-side encoder (k_enc_strings, sort, k_enc_gather, tiles) -> scan -> score -> rank; "
+                               "a fresh batch per step (anx_batch_encode_packed_device + anx_batch_run_async), the run of step i waited for and freed after "
+                               "step i + 1 was enqueued"}
+        del dev_blob
     st = batch.stats()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(st["n_pairs"]), float(st["n_queries"]), float(st["n_class_tests"])],
@@ -1004,6 +1105,7 @@ def main():
             "pipelining": "2 resident copies of the batch alternate: anx_batch_run_async from ONE caller stream, each waited for a step later; the library runs "
                           "consecutive asynchronous runs on two streams of its own (the scan of one under the scoring tail / compaction / ranking of the other)",
             "serial_ms_per_step": serial_ms,
+            "ms_per_step_with_encode": with_encode["ms_per_step"] if with_encode else None, "with_encode": with_encode,
             "kernels_ms_in_timed_region": overlapped_kernel_ms,
             "sync_single_copy_ms_per_step": sync_ms,
             "parity": parity, "preroll_steps": preroll_steps,

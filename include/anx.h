@@ -195,6 +195,11 @@ anx_batch *anx_batch_encode(const anx_model *, const char *const *utf8, size_t n
  * is and the strings are found there (the first n NUL-terminated spans; anything behind them is ignored; fewer than n spans or
  * a buffer that does not end with a NUL byte: ANX_EINVAL).  An input may not contain a NUL byte itself (as in the char** form). */
 anx_batch *anx_batch_encode_packed(const anx_model *, const char *blob, size_t blob_len, size_t n, const anx_params *);
+/* the same for inputs that already sit in HBM: device_blob is memory of the model's (one) device, laid out like the packed buffer above
+ * (every input followed by a NUL byte).  Nothing crosses PCIe; the bytes are copied device to device, so the caller's buffer is free
+ * again when the call returns.  Models with several replicas and the host-side rescoring path (ANX_CONFUSABLES=host): ANX_EINVAL.
+ * A trailing NUL byte is the caller's responsibility (the host cannot look). */
+anx_batch *anx_batch_encode_packed_device(const anx_model *, const void *device_blob, size_t blob_len, size_t n, const anx_params *);
 /* `stream` is a hipStream_t (NULL = the default stream).  A model with several replicas runs every shard of the batch on its
  * replica's own stream: `stream` must then be NULL. */
 int anx_batch_run(const anx_model *, anx_batch *, void *stream);
