@@ -121,3 +121,47 @@ def search_round(seed, worlds):
             A.set_switch("ANX_SEARCH_PARTS_MIN", None)
             A.set_switch("ANX_SEARCH_PARTS", None)
     return with_lm, with_rules, max_seq, len(texts), n_multi, n_tagged
+
+
+def conf_round(seed):
+    """Device-vs-host round of the confusable weighting: a random pattern set over a golden lexicon, random parameters, late or early
+    mode; every ranked row (ids, order, f64 scores) of the device path (conf.hip) must equal the host path (ANX_CONFUSABLES=host);
+    both compile confusables_core.hpp, the device through its kernels' own memory layout.  Returns the ranked rows compared."""
+    import numpy as np
+    rng = random.Random(seed)
+    d = synth.materialize_golden(f"/tmp/anxdata_soak_{os.getuid()}")
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    lex = rng.choice(["eng", "nld"])
+    words = _state.setdefault("lexwords_" + lex, synth.load_lexicon_words(d[lex]))
+    g = A.VariantModel(d["alphabet"], A.Weights(), device=0)
+    g.read_lexicon(d[lex])
+    pats = []
+    for _ in range(rng.randrange(1, 14)):
+        ops = []
+        for _k in range(rng.randrange(1, 4)):
+            op = rng.choice("-+=")
+            opts = "|".join("".join(rng.choice(letters + "\u00eb\u00e9\u00ef") for _ in range(rng.choice([1, 1, 1, 2]))) for _ in range(rng.choice([1, 1, 2, 3])))
+            ops.append(f"{op}[{opts}]")
+        script = ("^" if rng.random() < 0.15 else "") + "".join(ops) + ("$" if rng.random() < 0.15 else "")
+        pats.append((script, rng.choice([0.8, 0.9, 0.95, 1.05, 1.1, 1.2])))
+        g.add_to_confusables(*pats[-1])
+    early = rng.random() < 0.4
+    if early:
+        g.set_confusables_before_pruning()
+    g.build()
+    qs = synth.make_queries(words, rng.choice([100_000, 300_000]), max_len=rng.choice([12, 16, 24, 30]), seed=rng.randrange(1 << 30))
+    p = A.SearchParameters(max_anagram_distance=rng.choice([2, 3]), max_edit_distance=rng.choice([1, 2, 3]), max_matches=rng.choice([0, 1, 3, 10, 20]),
+                           score_threshold=rng.choice([0.0, 0.25, 0.5]), cutoff_threshold=rng.choice([0.0, 1.5, 2.0]), freq_weight=rng.choice([0.0, 0.0, 0.5]))
+    out = {}
+    try:
+        for mode in ("device", "host"):
+            A.set_switch("ANX_CONFUSABLES", "host" if mode == "host" else None)
+            b = g.encode_batch(qs, p)
+            b.run()
+            out[mode] = b.fetch_arrays()
+            b.free()
+    finally:
+        A.set_switch("ANX_CONFUSABLES", None)
+    for x, y in zip(out["device"], out["host"]):
+        assert np.array_equal(x, y), (seed, lex, "early" if early else "late", pats)
+    return int(out["device"][0][-1])

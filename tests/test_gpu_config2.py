@@ -76,3 +76,30 @@ def test_oracle_spot_check_with_confusables(setup, data_dir):
             assert abs(d - d2) <= 1e-6 and f == f2, qs[i]  # north_star: float composite score within 1e-6
         fired += any(CO.confusable_weight(confs, qs[i], o.text(v)) != 1.0 for v, _d, _f in exp)
     assert fired > 100  # the patterns did fire on the sample
+
+
+def test_filters_and_adjacency_off_equal_default_with_confusables(setup):
+    """configs[2] at full size WITH its confusable patterns loaded (the device weights the ranked rows): the run with the scan's fused
+    band-match filter off (ANX_SCAN_FUSE=0), with no band-match bound at all (ANX_PREFILTER=0: every length-compatible pair goes
+    through damerau_levenshtein, /root/reference/src/distance.rs:101-179) and with the probe walk instead of the adjacency lists
+    (ANX_SCAN_ADJ=0) must agree with the default path on scored pairs, survivors and the checksum of the weighted rows."""
+    g, qs, p, b, arrays, st = setup
+    ref = (st["n_pairs"], st["n_survivors"], checksum(*arrays))
+    assert st["n_prefiltered_in_scan"] > 0.5 * st["n_pairs"] and st["n_conf_scripts"] > 0 and st["n_adj_tiles"] > 0.9 * st["n_scan_blocks"]
+    try:
+        for sw in ("ANX_SCAN_FUSE", "ANX_PREFILTER"):
+            A.set_switch(sw, "0")
+            b.run()
+            s2 = b.stats()
+            assert (s2["n_pairs"], s2["n_survivors"], checksum(*b.fetch_arrays())) == ref, sw
+            A.set_switch(sw, None)
+        A.set_switch("ANX_SCAN_ADJ", "0")
+        b2 = g.encode_batch(qs, p)   # read when the tiles are built
+        b2.run()
+        s3 = b2.stats()
+        got = (s3["n_pairs"], s3["n_survivors"], checksum(*b2.fetch_arrays()))
+        b2.free()
+        assert s3["n_adj_tiles"] == 0 and got == ref
+    finally:
+        for sw in ("ANX_SCAN_FUSE", "ANX_PREFILTER", "ANX_SCAN_ADJ"):
+            A.set_switch(sw, None)

@@ -116,3 +116,47 @@ def test_oracle_spot_check(setup, data_dir):
         exp = [(res[n * stride + j].vocab_id, res[n * stride + j].dist_score, res[n * stride + j].freq_score) for j in range(counts[n])]
         got = [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
         assert got == exp, qs[i]
+
+
+def test_whole_job_equals_its_length_split_shares(setup):
+    """The WHOLE configs[3] job shape on one GPU: 5 M of the 10 M length-bucketed queries (two device batches of 2.5 M), and the
+    same 5 M queries as the 8 shares the length-partitioned split of a multi-device model makes of them (anx_debug_length_split: what
+    anx_model_to_devices would give 8 GPUs), each share run on its own.  Rows of every query must agree -- a checksum of the whole
+    run against the shares' rows scattered back to input order; independent inputs in any order: src/bin/analiticcl.rs:416-448."""
+    g, path, _qs, p, _b, _arrays, _st = setup
+    lex = synth.load_lexicon_words(path)
+    NJ = 5_000_000
+    job = synth.make_queries(lex, NJ, max_len=32, min_len=4, seed=9)
+    whole_cnt = np.zeros(NJ, dtype=np.int64)
+    parts = []
+    for lo in range(0, NJ, 2_500_000):
+        b = g.encode_batch(job[lo:lo + 2_500_000], p)
+        b.run()
+        off, vid, dist, freq = b.fetch_arrays()
+        b.free()
+        whole_cnt[lo:lo + 2_500_000] = np.diff(off)
+        parts.append((vid, dist, freq))
+    w_off = np.concatenate([[0], np.cumsum(whole_cnt)])
+    w_vid, w_dist, w_freq = (np.concatenate([x[i] for x in parts]) for i in range(3))
+    assert w_off[-1] > NJ    # more than a row per query on average
+    gid = g.length_split(job, p, 8)
+    assert np.bincount(gid, minlength=8).min() > 0
+    s_cnt = np.zeros(NJ, dtype=np.int64)
+    s_vid, s_dist, s_freq = np.zeros_like(w_vid), np.zeros_like(w_dist), np.zeros_like(w_freq)
+    total_ms = []
+    for sh in range(8):
+        ix = np.nonzero(gid == sh)[0]
+        b = g.encode_batch([job[i] for i in ix], p)
+        b.run()
+        total_ms.append(b.stats()["ms_total"])
+        off, vid, dist, freq = b.fetch_arrays()
+        b.free()
+        cnt = np.diff(off)
+        s_cnt[ix] = cnt
+        assert np.array_equal(cnt, whole_cnt[ix])
+        dst = np.repeat(w_off[ix], cnt) + (np.arange(off[-1]) - np.repeat(off[:-1], cnt))   # the rows of query ix[j] at its place in the whole job's arrays
+        s_vid[dst], s_dist[dst], s_freq[dst] = vid, dist, freq
+    assert np.array_equal(s_cnt, whole_cnt)
+    assert checksum(w_off, s_vid, s_dist, s_freq) == checksum(w_off, w_vid, w_dist, w_freq)
+    assert np.array_equal(s_vid, w_vid) and np.array_equal(s_dist, w_dist)
+    print(f"whole job of {NJ} queries: shares' device times {[round(t, 2) for t in total_ms]} ms, balance {sum(total_ms) / 8 / max(total_ms):.2f}")
