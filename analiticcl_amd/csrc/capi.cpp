@@ -124,6 +124,8 @@ const anx::HostModel& anx_host_of(const anx_model* m) { return m->host; }
 const anx::DeviceLexicon* anx_replica_of(const anx_model* m, size_t i) { return i < m->replicas.size() ? m->replicas[i].dev : nullptr; }
 int anx_replica_device(const anx_model* m, size_t i) { return i < m->replicas.size() ? m->replicas[i].device : -1; }
 int anx_fail(int code, const std::string& msg) { return fail(code, msg); }
+// the device batch of a batch that lives on ONE replica (search.cpp's one-pass path reads its device-resident rows); nullptr otherwise
+anx::Batch* anx_batch_single(const anx_batch* b) { return (b && b->shards.size() == 1 && !b->rescore) ? b->shards[0].b : nullptr; }
 
 
 // Confusable rescoring of the ranked lists (src/lib.rs:1505-1508 early, :1591-1595 late) followed by the steps the device

@@ -109,4 +109,42 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& i
                    uint32_t* out_n, uint32_t* out_syms, std::string& err);
 void batch_free(Batch*);
 
+// ---- search mode in one device pass (lattice.hip): the lattices are built on the device from the rows of the part's batches --------------
+// What the host knows without any result: the segments ("matches") of every stretch, in the order of the stretch's match list
+// (order-major), the states they connect, and the layout of the arcs ("groups", listed per destination state in (source state,
+// insertion) order: a segment's variants | the epsilon arc of a state | an arc into the virtual end state).
+struct OnePassIn {
+  size_t nmatch = 0, ngroup = 0, nin = 0, nst = 0;
+  const uint32_t* m_q = nullptr;     // [nmatch] input index of the segment in its batch (order 1: the unigram batch, else the higher-order batch); 0xFFFFFFFF: none
+  const uint32_t* m_u0 = nullptr;    // [nmatch] order > 1: the unigram matches [u0, u1) (part-wide match indices) that lie inside the segment (redundant_match)
+  const uint32_t* m_u1 = nullptr;
+  const uint32_t* m_pack = nullptr;  // [nmatch] source state | destination state << 12 | order << 24 | (ends at no boundary) << 31
+  const uint32_t* m_lat = nullptr;   // [nmatch] lattice of its stretch (index into st), 0xFFFFFFFF: the stretch has no lattice
+  const uint32_t* g_ref = nullptr;   // [ngroup] kind << 30 | value: 0 match index, 1 epsilon arc (value = source state), 2 arc into the end state (value = source state)
+  const uint32_t* e_g0 = nullptr;    // [nin] first group of every (lattice, state) entry of in_off: nstates + 2 per lattice
+  const uint32_t* e_lat = nullptr;   // [nin] its lattice
+  const uint32_t* st_m0 = nullptr;   // [nst] first match of the lattice's stretch
+  const uint32_t* st_e0 = nullptr;   // [nst] first in_off entry of the lattice (= LatStretch::in_off0)
+  LatStretch* st = nullptr;          // [nst] nstates, in_off0, btok_off0, btok0, out0, best_cost_init, ring set; arc0 / sym0 are the device's
+  const uint32_t* maxdeg = nullptr;  // [nst] upper bound of the incoming arcs of a state
+  const uint32_t* btok_off = nullptr; size_t nboff = 0;
+  const int32_t* btok = nullptr; size_t nbtok = 0;
+  size_t out_total = 0;              // out slots (LatStretch::out0: nstates per lattice)
+};
+struct OnePassOut {   // host_result_alloc'd (block, rows): release with host_result_free
+  char* block = nullptr;
+  uint32_t* out_n = nullptr;    // [nst] symbols on the chosen path
+  uint32_t* e_match = nullptr;  // [out_total] per out slot: match index within its stretch
+  uint32_t* e_sel = nullptr;    // ... chosen variant, 0xFFFFFFFF = none (out of vocabulary)
+  uint32_t* e_row0 = nullptr;   // [out_total + 1] ... first of the match's rows in `rows`
+  anx_result* rows = nullptr;
+  size_t n_rows = 0;
+  bool handed_back = false;     // some lattice is beyond the device decoder's limits: nothing above is valid, take the classic path
+};
+struct OnePassState;
+int search_onepass_prepare(const DeviceLexicon* dl, const Batch* bu, Batch* bh, const OnePassIn& in, const anx_search_params& p, OnePassState** out, std::string& err);
+int search_onepass_finish(const HostModel& m, const DeviceLexicon* dl, OnePassState* s, const Batch* bu, const Batch* bh, OnePassIn& in, const anx_search_params& p,
+                          OnePassOut& out, std::string& err);
+void search_onepass_free(OnePassState*);
+
 }  // namespace anx

@@ -458,6 +458,7 @@ const SwitchDef kSwitches[] = {
     {"ANX_SHARD_MIN", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.shard_min = x > 0 ? x : 8192; }},
     {"ANX_CONFUSABLES", [](Switches& s, const char* v) { s.confusables_host = v && strcmp(v, "host") == 0; }},
     {"ANX_LATTICE", [](Switches& s, const char* v) { s.lattice_host = v && strcmp(v, "host") == 0; }},
+    {"ANX_SEARCH_ONEPASS", [](Switches& s, const char* v) { s.search_onepass = flag01(v, 1); }},
     {"ANX_ENCODE_TIMING", [](Switches& s, const char* v) { s.encode_timing = v != nullptr && v[0] != 0 && v[0] != '0'; }},
     {"ANX_SEARCH_TIMING", [](Switches& s, const char* v) { s.search_timing = v != nullptr && v[0] != 0 && v[0] != '0'; }},
     {"ANX_SEARCH_PARTS", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.search_parts = x >= 1 && x <= 8 ? x : 4; }},

@@ -86,6 +86,7 @@ struct Switches {
   long shard_min = 8192;     // ANX_SHARD_MIN: fewest inputs a replica of a multi-device model gets (smaller calls use fewer replicas)
   int confusables_host = 0;  // ANX_CONFUSABLES=host: confusable weighting on the host threads (A/B reference of the device kernel)
   int lattice_host = 0;      // ANX_LATTICE=host: lattice decoding on the host threads (A/B reference of the device kernel)
+  int search_onepass = 1;    // ANX_SEARCH_ONEPASS=0: search mode downloads every ranked row and builds the lattice input on the host (the path until round 4; A/B reference)
   int encode_timing = 0;     // ANX_ENCODE_TIMING, ANX_SEARCH_TIMING: host phase times on stderr
   int search_timing = 0;
   int search_parts = 4;      // ANX_SEARCH_PARTS: parts of a large find_all_matches call in flight at a time (search.cpp)

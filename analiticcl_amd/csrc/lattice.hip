@@ -18,10 +18,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <ctime>
+#include <functional>
 #include <mutex>
 #include <type_traits>
 #include <string>
 #include <vector>
+
+#include <memory>
+#include <rocprim/device/device_scan.hpp>
 
 #include "engine_internal.h"
 #include "portable_log.hpp"
@@ -433,56 +439,22 @@ static int lm_ensure(const HostModel& m, const DeviceLexicon* dl, std::string& e
   return ANX_OK;
 }
 
-// Decodes the stretches of `in` on the replica `dl`.  out_n[i] = symbols of the chosen path of stretch i (0xFFFFFFFF: not decoded,
-// the caller's host decoder takes it), out_syms[st[i].out0 ..] = their local symbol ids in path order.
-int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& whole, size_t first, size_t count, const anx_search_params& p,
-                   uint32_t* out_n, uint32_t* out_syms, std::string& err) {
-  if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
-  HIP_TRY(hipSetDevice(dl->device));
-  if (!count) return ANX_OK;
-  // the sub-range [first, first + count) of the call's lattices as a view of its own: the arrays of consecutive stretches are
-  // consecutive, so only their part is uploaded (a replica of a multi-device model decodes its share)
-  const LatStretch& s0 = whole.st[first];
-  const bool last = first + count == whole.nst;
-  const LatStretch* s1 = last ? nullptr : &whole.st[first + count];
-  LatView in;
-  in.st = whole.st + first; in.nst = count;
-  in.in_off = whole.in_off + s0.in_off0; in.nin = (last ? whole.nin : s1->in_off0) - s0.in_off0;
-  in.arcs = whole.arcs + s0.arc0; in.narcs = (last ? whole.narcs : s1->arc0) - s0.arc0;
-  in.syms = whole.syms + s0.sym0; in.nsyms = (last ? whole.nsyms : s1->sym0) - s0.sym0;
-  in.btok_off = whole.btok_off + s0.btok_off0; in.nboff = (last ? whole.nboff : s1->btok_off0) - s0.btok_off0;
-  in.btok = whole.btok + s0.btok0; in.nbtok = (last ? whole.nbtok : s1->btok0) - s0.btok0;
-  in.out_total = (last ? whole.out_total : s1->out0) - s0.out0;
-  out_n += first;
-  out_syms += s0.out0;
-  const size_t n = count;
-  int rc = lm_ensure(m, dl, err);
-  if (rc) return rc;
+// The launches of a set of n lattices whose arrays are (or are about to be) on the device: launch order, node pools, kernels.
+// hst: the stretches (indices relative to the device arrays; node0 is assigned here), maxdeg[j]: (an upper bound of) the most
+// incoming arcs of a state of stretch j.  The planned stretch array is uploaded to d_st, then after_stretch_upload (may be empty)
+// enqueues whatever still has to happen to the arrays on `st` before the kernels run.  Blocks allocated here go to `owned`.
+static int lattice_launch(const HostModel& m, const DeviceLexicon* dl, std::vector<LatStretch>& hst, const std::vector<uint32_t>& maxdeg, LatStretch* d_st,
+                          const uint32_t* d_inoff, const LatArc* d_arcs, const LatSym* d_syms, const uint32_t* d_boff, const int32_t* d_btok, uint32_t* d_outn,
+                          uint32_t* d_outs, const anx_search_params& p, hipStream_t st, const std::function<int()>& after_stretch_upload, std::vector<void*>& owned,
+                          std::string& err) {
+  const size_t n = hst.size();
   const DeviceLm* lm = dl->dlm;
   const uint32_t K = std::max<uint32_t>(1u, p.max_seq);
-  if (K > 4096u) {  // node pools of (states x K) and the LDS cost ring are sized for the reference's default of 250: the host decoder takes these
-    for (size_t i = 0; i < count; ++i) out_n[i] = 0xFFFFFFFFu;
-    return ANX_OK;
-  }
-  hipStream_t st = encoder_stream_acquire(dl->device);
-  struct Rel { hipStream_t s; int dev; ~Rel() { (void)hipStreamSynchronize(s); encoder_stream_release(dev, s); } } rel{st, dl->device};
-  LatStretch* d_st = nullptr; uint32_t* d_inoff = nullptr; LatArc* d_arcs = nullptr; LatSym* d_syms = nullptr; uint32_t* d_boff = nullptr;
-  int32_t* d_btok = nullptr; uint32_t *d_outn = nullptr, *d_outs = nullptr; LNode* d_nodes = nullptr;
-  std::vector<void*> owned;
+  LNode* d_nodes = nullptr;
+  int rc;
   auto dalloc_ = [&](void** p_, size_t bytes) -> int { HIP_TRY(pool_malloc(p_, std::max<size_t>(bytes, 16))); owned.push_back(*p_); return ANX_OK; };
-  struct Free { std::vector<void*>& v; hipStream_t s; ~Free() { (void)hipStreamSynchronize(s); for (void* q : v) pool_free(q); } } fr{owned, st};
-  const size_t nout = in.out_total;
-  if ((rc = dalloc_((void**)&d_st, n * sizeof(LatStretch))) || (rc = dalloc_((void**)&d_inoff, in.nin * 4)) ||
-      (rc = dalloc_((void**)&d_arcs, in.narcs * sizeof(LatArc))) || (rc = dalloc_((void**)&d_syms, in.nsyms * sizeof(LatSym))) ||
-      (rc = dalloc_((void**)&d_boff, in.nboff * 4)) || (rc = dalloc_((void**)&d_btok, in.nbtok * 4)) ||
-      (rc = dalloc_((void**)&d_outn, n * 4)) || (rc = dalloc_((void**)&d_outs, nout * 4)))
-    return rc;
   // node pool: (nstates + 1) * K nodes per stretch; launches of as many stretches as fit the budget
   const size_t budget_nodes = ((size_t)6 << 30) / sizeof(LNode);
-  std::vector<LatStretch> hst(in.st, in.st + n);
-  for (LatStretch& S : hst) {  // indices relative to the uploaded parts
-    S.in_off0 -= s0.in_off0; S.arc0 -= s0.arc0; S.sym0 -= s0.sym0; S.btok_off0 -= s0.btok_off0; S.btok0 -= s0.btok0; S.out0 -= s0.out0;
-  }
   // Launch order: the stretches none of whose states has more than 64 incoming arcs (and whose cost ring fits half the LDS budget)
   // first, by decreasing number of states -- k_lattice<32> decodes them two per wave, neighbours of this order side by side --,
   // then the others (k_lattice<64>: one per wave, up to 128 incoming arcs).
@@ -492,10 +464,7 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   order.reserve(n);
   std::vector<uint32_t> wide;
   for (size_t j = 0; j < n; ++j) {
-    const uint32_t* io = in.in_off + hst[j].in_off0;
-    uint32_t maxdeg = 0;
-    for (uint32_t d = 1; d <= hst[j].nstates; ++d) maxdeg = std::max(maxdeg, io[d + 1] - io[d]);
-    if (maxdeg <= 64u && hst[j].ring <= ring_cap32) order.push_back((uint32_t)j);
+    if (maxdeg[j] <= 64u && hst[j].ring <= ring_cap32) order.push_back((uint32_t)j);
     else wide.push_back((uint32_t)j);
   }
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return hst[x].nstates > hst[y].nstates; });
@@ -527,11 +496,7 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
   const bool lm_on = m.have_lm && p.lm_weight > 0.0f;
   if (lm_on && ((rc = dalloc_((void**)&d_lm, max_pool * sizeof(LmNode))) || (rc = dalloc_((void**)&d_marks, max_pool / K * ((K + 3u) & ~3u))))) return rc;
   HIP_TRY(hipMemcpyAsync(d_st, hst.data(), n * sizeof(LatStretch), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_inoff, in.in_off, in.nin * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_arcs, in.arcs, in.narcs * sizeof(LatArc), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_syms, in.syms, in.nsyms * sizeof(LatSym), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_boff, in.btok_off, in.nboff * 4, hipMemcpyHostToDevice, st));
-  if (in.nbtok) HIP_TRY(hipMemcpyAsync(d_btok, in.btok, in.nbtok * 4, hipMemcpyHostToDevice, st));
+  if (after_stretch_upload) { const int rcu = after_stretch_upload(); if (rcu) return rcu; }  // the caller's uploads / kernels that complete the lattice arrays
   LatArgs a;
   a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.lm = d_lm; a.marks = d_marks; a.K = K;
   a.use_lm = (m.have_lm && p.lm_weight > 0.0f) ? 1 : 0;
@@ -556,9 +521,446 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
     ktimer_end(kt, st);
   }
   HIP_TRY(hipGetLastError());
+  return ANX_OK;
+}
+
+// Decodes the stretches of `in` on the replica `dl`.  out_n[i] = symbols of the chosen path of stretch i (0xFFFFFFFF: not decoded,
+// the caller's host decoder takes it), out_syms[st[i].out0 ..] = their local symbol ids in path order.
+int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& whole, size_t first, size_t count, const anx_search_params& p,
+                   uint32_t* out_n, uint32_t* out_syms, std::string& err) {
+  if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
+  HIP_TRY(hipSetDevice(dl->device));
+  if (!count) return ANX_OK;
+  // the sub-range [first, first + count) of the call's lattices as a view of its own: the arrays of consecutive stretches are
+  // consecutive, so only their part is uploaded (a replica of a multi-device model decodes its share)
+  const LatStretch& s0 = whole.st[first];
+  const bool last = first + count == whole.nst;
+  const LatStretch* s1 = last ? nullptr : &whole.st[first + count];
+  LatView in;
+  in.st = whole.st + first; in.nst = count;
+  in.in_off = whole.in_off + s0.in_off0; in.nin = (last ? whole.nin : s1->in_off0) - s0.in_off0;
+  in.arcs = whole.arcs + s0.arc0; in.narcs = (last ? whole.narcs : s1->arc0) - s0.arc0;
+  in.syms = whole.syms + s0.sym0; in.nsyms = (last ? whole.nsyms : s1->sym0) - s0.sym0;
+  in.btok_off = whole.btok_off + s0.btok_off0; in.nboff = (last ? whole.nboff : s1->btok_off0) - s0.btok_off0;
+  in.btok = whole.btok + s0.btok0; in.nbtok = (last ? whole.nbtok : s1->btok0) - s0.btok0;
+  in.out_total = (last ? whole.out_total : s1->out0) - s0.out0;
+  out_n += first;
+  out_syms += s0.out0;
+  const size_t n = count;
+  int rc = lm_ensure(m, dl, err);
+  if (rc) return rc;
+  const uint32_t K = std::max<uint32_t>(1u, p.max_seq);
+  if (K > 4096u) {  // node pools of (states x K) and the LDS cost ring are sized for the reference's default of 250: the host decoder takes these
+    for (size_t i = 0; i < count; ++i) out_n[i] = 0xFFFFFFFFu;
+    return ANX_OK;
+  }
+  hipStream_t st = encoder_stream_acquire(dl->device);
+  struct Rel { hipStream_t s; int dev; ~Rel() { (void)hipStreamSynchronize(s); encoder_stream_release(dev, s); } } rel{st, dl->device};
+  LatStretch* d_st = nullptr; uint32_t* d_inoff = nullptr; LatArc* d_arcs = nullptr; LatSym* d_syms = nullptr; uint32_t* d_boff = nullptr;
+  int32_t* d_btok = nullptr; uint32_t *d_outn = nullptr, *d_outs = nullptr;
+  std::vector<void*> owned;
+  auto dalloc_ = [&](void** p_, size_t bytes) -> int { HIP_TRY(pool_malloc(p_, std::max<size_t>(bytes, 16))); owned.push_back(*p_); return ANX_OK; };
+  struct Free { std::vector<void*>& v; hipStream_t s; ~Free() { (void)hipStreamSynchronize(s); for (void* q : v) pool_free(q); } } fr{owned, st};
+  const size_t nout = in.out_total;
+  if ((rc = dalloc_((void**)&d_st, n * sizeof(LatStretch))) || (rc = dalloc_((void**)&d_inoff, in.nin * 4)) ||
+      (rc = dalloc_((void**)&d_arcs, in.narcs * sizeof(LatArc))) || (rc = dalloc_((void**)&d_syms, in.nsyms * sizeof(LatSym))) ||
+      (rc = dalloc_((void**)&d_boff, in.nboff * 4)) || (rc = dalloc_((void**)&d_btok, in.nbtok * 4)) ||
+      (rc = dalloc_((void**)&d_outn, n * 4)) || (rc = dalloc_((void**)&d_outs, nout * 4)))
+    return rc;
+  std::vector<LatStretch> hst(in.st, in.st + n);
+  std::vector<uint32_t> maxdeg(n, 0u);
+  for (size_t j = 0; j < n; ++j) {  // indices relative to the uploaded parts
+    LatStretch& S = hst[j];
+    S.in_off0 -= s0.in_off0; S.arc0 -= s0.arc0; S.sym0 -= s0.sym0; S.btok_off0 -= s0.btok_off0; S.btok0 -= s0.btok0; S.out0 -= s0.out0;
+    const uint32_t* io = in.in_off + S.in_off0;
+    for (uint32_t d = 1; d <= S.nstates; ++d) maxdeg[j] = std::max(maxdeg[j], io[d + 1] - io[d]);
+  }
+  auto uploads = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(d_inoff, in.in_off, in.nin * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_arcs, in.arcs, in.narcs * sizeof(LatArc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_syms, in.syms, in.nsyms * sizeof(LatSym), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_boff, in.btok_off, in.nboff * 4, hipMemcpyHostToDevice, st));
+    if (in.nbtok) HIP_TRY(hipMemcpyAsync(d_btok, in.btok, in.nbtok * 4, hipMemcpyHostToDevice, st));
+    return ANX_OK;
+  };
+  if ((rc = lattice_launch(m, dl, hst, maxdeg, d_st, d_inoff, d_arcs, d_syms, d_boff, d_btok, d_outn, d_outs, p, st, uploads, owned, err))) return rc;
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out_n, d_outn, n * 4, hipMemcpyDeviceToHost, st));
   if (nout) HIP_TRY(hipMemcpyAsync(out_syms, d_outs, nout * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return ANX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Search mode in ONE device pass (round 5).  Until round 4 a part of a find_all_matches call downloaded every ranked row of every
+// segment, built row views and the lattice input on the host threads (search.cpp build_lattice) and uploaded it again.  Here the
+// lattices are BUILT on the device from the device-resident rows of the part's two batches (unigram segments; segments of the higher
+// orders): the host only describes the structure that does not depend on the results -- which segment connects which boundaries
+// (states), in which order the arcs of a state are listed -- and the device fills in what does: redundant_match
+// (/root/reference/src/search.rs:317-336: a higher-order segment whose unigrams all have an exact match is not looked up), one arc and
+// one output symbol per variant with cost = n + (1 - score) (/root/reference/src/lib.rs:2104-2276), out-of-vocabulary arcs for
+// unigrams without variants, the fail-safe epsilon arcs and the arcs into the virtual end state.  k_lattice decodes as before; only
+// the matches ON the chosen paths come back, with their rows (a third of all ranked rows on BASELINE configs[4]).
+//   arcs of a lattice are listed per destination state in (source state, insertion) order: the host lays the "arc groups" (a
+//   segment's variants | the epsilon arc of a state | an arc into the end state) out in exactly that order, the device counts the
+//   arcs of every group and an exclusive scan over the groups IS the arc layout; symbols are numbered in segment order (a second scan).
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct OpArgs {
+  uint32_t nmatch, ngroup, nin, nst;
+  const uint32_t *m_q, *m_u0, *m_u1, *m_pack, *m_lat, *g_ref, *e_g0, *e_lat, *st_m0, *st_e0;
+  // the two batches: ranked rows per sorted query, input index -> sorted query
+  const uint32_t *inv_u, *inv_h, *soff_u, *soff_h, *cnt_u, *cnt_h;
+  const DevRow *rows_u, *rows_h;
+  uint32_t nin_u, nin_h;      // inputs of the batches
+  float freq_weight;
+  uint32_t *mc, *gc;          // symbols per match, arcs per group
+  uint8_t* mflag;             // bit 0: looked up (not redundant)
+  uint32_t *sym_off, *arc_off;
+  LatStretch* st;
+  uint32_t* in_off;
+  LatArc* arcs;
+  LatSym* syms;
+  uint2* refs;                // per symbol: (match index within its stretch, variant index | 0xFFFFFFFF)
+  uint32_t narc_cap, nsym_cap;
+  uint32_t* overflow;
+  // emit
+  const uint32_t *out_n, *out_syms;
+  uint32_t *e_match, *e_sel, *e_cnt, *e_row0;
+  anx_result* e_rows;
+  uint32_t out_total;
+};
+__global__ __launch_bounds__(256) void k_op_inv(uint32_t nq, const uint32_t* __restrict__ q_orig, uint32_t* __restrict__ inv) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s < nq) inv[q_orig[s]] = s;
+}
+__device__ inline uint32_t op_rows_of(const OpArgs& a, uint32_t order, uint32_t q, uint32_t* sorted) {
+  *sorted = 0xFFFFFFFFu;
+  if (q == 0xFFFFFFFFu) return 0u;
+  const bool uni = order == 1u;
+  if (q >= (uni ? a.nin_u : a.nin_h)) return 0u;
+  const uint32_t sq = (uni ? a.inv_u : a.inv_h)[q];
+  if (sq == 0xFFFFFFFFu) return 0u;  // not encodable (empty / too long): no variants
+  *sorted = sq;
+  return (uni ? a.cnt_u : a.cnt_h)[sq];
+}
+// symbols (= arcs) a segment contributes: its variants, or one out-of-vocabulary symbol for a unigram without variants; nothing for a
+// redundant higher-order segment (redundant_match, src/search.rs:317-336, decided from the unigrams' device-resident rows) and for a
+// segment that ends at no boundary of its stretch
+__global__ __launch_bounds__(256) void k_op_counts(OpArgs a) {
+  const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.nmatch) return;
+  const uint32_t pk = a.m_pack[m], order = (pk >> 24) & 0x7Fu;
+  bool looked = true;
+  if (order > 1u) {  // redundant <=> every unigram inside has variants and its best one is an exact match (dist_score >= 1.0)
+    bool red = true;
+    for (uint32_t u = a.m_u0[m]; u < a.m_u1[m] && red; ++u) {
+      uint32_t sq;
+      const uint32_t n = op_rows_of(a, 1u, a.m_q[u], &sq);
+      if (n == 0u || a.rows_u[a.soff_u[sq]].dist_score < 1.0) red = false;
+    }
+    looked = !red;
+  }
+  uint32_t sq;
+  const uint32_t rows = looked ? op_rows_of(a, order, a.m_q[m], &sq) : 0u;
+  uint32_t c = rows ? rows : ((looked && order == 1u) ? 1u : 0u);
+  if ((pk >> 31) || a.m_lat[m] == 0xFFFFFFFFu) c = 0u;  // no destination state / a stretch without a lattice
+  a.mc[m] = c;
+  a.mflag[m] = looked ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_op_gcount(OpArgs a) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.ngroup) return;
+  const uint32_t r = a.g_ref[g];
+  a.gc[g] = (r >> 30) == 0u ? a.mc[r & 0x3FFFFFFFu] : 1u;
+}
+__device__ inline double op_vr_score(const DevRow& r, float fw) {  // src/types.rs:335-341 (search.cpp vr_score)
+  if (fw == 0.0f) return r.dist_score;
+  return (r.dist_score + ((double)fw * r.freq_score)) / (1.0 + (double)fw);
+}
+__global__ __launch_bounds__(256) void k_op_fill(OpArgs a) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.ngroup) return;
+  const uint32_t r = a.g_ref[g], kind = r >> 30, v = r & 0x3FFFFFFFu;
+  const uint32_t ao = a.arc_off[g];
+  if (kind != 0u) {  // fail-safe epsilon transition (src/lib.rs: cost 100) / arc into the virtual end state (cost 0)
+    if (ao < a.narc_cap) a.arcs[ao] = LatArc{kind == 1u ? 100.0f : 0.0f, v, 0xFFFFFFFFu};
+    else atomicOr(a.overflow, 1u);
+    return;
+  }
+  const uint32_t m = v, c = a.mc[m];
+  if (!c) return;
+  const uint32_t pk = a.m_pack[m], src = pk & 0xFFFu, dst = (pk >> 12) & 0xFFFu, order = (pk >> 24) & 0x7Fu, lat = a.m_lat[m];
+  const uint32_t so = a.sym_off[m], s_base = a.sym_off[a.st_m0[lat]], mloc = m - a.st_m0[lat];
+  if (ao + c > a.narc_cap || so + c > a.nsym_cap) { atomicOr(a.overflow, 1u); return; }
+  uint32_t sq;
+  const uint32_t rows = op_rows_of(a, order, a.m_q[m], &sq);
+  if (!rows) {  // out of vocabulary: one symbol without a vocabulary id (unigrams only: k_op_counts)
+    a.arcs[ao] = LatArc{(float)order + 1.0f, src, so - s_base};
+    a.syms[so] = LatSym{0u, dst - 1u};
+    a.refs[so] = make_uint2(mloc, 0xFFFFFFFFu);
+    return;
+  }
+  const bool uni = order == 1u;
+  const DevRow* rr = (uni ? a.rows_u : a.rows_h) + (uni ? a.soff_u : a.soff_h)[sq];
+  for (uint32_t vi = 0; vi < c; ++vi) {
+    const DevRow d = rr[vi];
+    const float cost = (float)order + (1.0f - (float)op_vr_score(d, a.freq_weight));
+    a.arcs[ao + vi] = LatArc{cost, src, so + vi - s_base};
+    a.syms[so + vi] = LatSym{d.vocab_id, dst - 1u};
+    a.refs[so + vi] = make_uint2(mloc, vi);
+  }
+}
+__global__ __launch_bounds__(256) void k_op_inoff(OpArgs a) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.nin) return;
+  const uint32_t lat = a.e_lat[e];
+  a.in_off[e] = a.arc_off[a.e_g0[e]] - a.arc_off[a.e_g0[a.st_e0[lat]]];
+}
+__global__ __launch_bounds__(256) void k_op_stfix(OpArgs a) {
+  const uint32_t li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= a.nst) return;
+  a.st[li].arc0 = a.arc_off[a.e_g0[a.st_e0[li]]];
+  a.st[li].sym0 = a.sym_off[a.st_m0[li]];
+}
+// the chosen symbols of a lattice -> (match, variant) and the match's row count
+__global__ __launch_bounds__(256) void k_op_emit_count(OpArgs a) {
+  const uint32_t li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= a.nst) return;
+  const LatStretch S = a.st[li];
+  const uint32_t n = a.out_n[li];
+  const uint32_t m0 = a.st_m0[li];
+  for (uint32_t j = 0; j < S.nstates; ++j) {  // the lattice's out slots (a path has at most one symbol per state it enters)
+    uint32_t cnt = 0, ml = 0xFFFFFFFFu, sel = 0xFFFFFFFFu;
+    if (n != 0xFFFFFFFFu && j < n) {
+      const uint2 rf = a.refs[S.sym0 + a.out_syms[S.out0 + j]];
+      ml = rf.x; sel = rf.y;
+      const uint32_t m = m0 + rf.x;
+      uint32_t sq;
+      cnt = op_rows_of(a, (a.m_pack[m] >> 24) & 0x7Fu, a.m_q[m], &sq);
+    }
+    a.e_match[S.out0 + j] = ml;
+    a.e_sel[S.out0 + j] = sel;
+    a.e_cnt[S.out0 + j] = cnt;
+  }
+}
+__global__ __launch_bounds__(256) void k_op_emit_rows(OpArgs a) {
+  const uint32_t li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= a.nst) return;
+  const LatStretch S = a.st[li];
+  const uint32_t n = a.out_n[li];
+  if (n == 0xFFFFFFFFu) return;
+  const uint32_t m0 = a.st_m0[li];
+  for (uint32_t j = 0; j < n && j < S.nstates; ++j) {
+    const uint32_t m = m0 + a.e_match[S.out0 + j], order = (a.m_pack[m] >> 24) & 0x7Fu;
+    uint32_t sq;
+    const uint32_t cnt = op_rows_of(a, order, a.m_q[m], &sq);
+    if (!cnt) continue;
+    const bool uni = order == 1u;
+    const DevRow* rr = (uni ? a.rows_u : a.rows_h) + (uni ? a.soff_u : a.soff_h)[sq];
+    anx_result* out = a.e_rows + a.e_row0[S.out0 + j];
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const DevRow d = rr[i];
+      anx_result r;
+      r.vocab_id = d.vocab_id;
+      r.dist_score = d.dist_score;
+      r.freq_score = d.freq_score;
+      r.via = d.via == 0xFFFFFFFFu ? ANX_NO_VIA : (uint64_t)d.via;
+      out[i] = r;
+    }
+  }
+}
+// higher-order queries whose segment is redundant: their bit planes are cleared before the batch runs, so the scan finds nothing for
+// them (a clean text has few misspelt words: two thirds of its higher-order segments would be looked up for nothing)
+__global__ __launch_bounds__(256) void k_op_skip(OpArgs a, uint32_t* __restrict__ q_bits_h) {
+  const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.nmatch) return;
+  const uint32_t order = (a.m_pack[m] >> 24) & 0x7Fu;
+  if (order <= 1u) return;
+  for (uint32_t u = a.m_u0[m]; u < a.m_u1[m]; ++u) {
+    uint32_t sq;
+    const uint32_t n = op_rows_of(a, 1u, a.m_q[u], &sq);
+    if (n == 0u || a.rows_u[a.soff_u[sq]].dist_score < 1.0) return;  // not redundant
+  }
+  const uint32_t q = a.m_q[m];
+  if (q == 0xFFFFFFFFu || q >= a.nin_h) return;
+  const uint32_t sq = a.inv_h[q];
+  if (sq == 0xFFFFFFFFu) return;
+#pragma unroll
+  for (int p = 0; p < NBITPLANES; ++p) q_bits_h[(size_t)sq * NBITPLANES + p] = 0u;
+}
+
+namespace {
+template <typename T>
+int op_scan(const T* in, T* out, size_t n, hipStream_t st, std::vector<void*>& owned, std::string& err) {
+  size_t bytes = 0;
+  HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), st));
+  void* tmp = nullptr;
+  HIP_TRY(pool_malloc(&tmp, bytes + 16));
+  owned.push_back(tmp);
+  HIP_TRY(rocprim::exclusive_scan(tmp, bytes, in, out, T(0), n, rocprim::plus<T>(), st));
+  return ANX_OK;
+}
+}  // namespace
+
+struct OnePassState {  // between search_onepass_prepare and search_onepass_finish
+  hipStream_t st = nullptr;
+  int device = 0;
+  std::vector<void*> owned;
+  OpArgs a{};
+  uint32_t* d_inv_h = nullptr;
+  ~OnePassState() {
+    if (st) (void)hipStreamSynchronize(st);
+    for (void* q : owned) pool_free(q);
+    if (st) encoder_stream_release(device, st);
+  }
+};
+void search_onepass_free(OnePassState* s) { delete s; }
+
+// Phase 1 (after the unigram batch bu has run, before the higher-order batch bh runs): uploads the part's tables, maps the unigram
+// batch, and clears the bit planes of the redundant higher-order queries of bh (already encoded).  bh may be nullptr (max_ngram 1).
+int search_onepass_prepare(const DeviceLexicon* dl, const Batch* bu, Batch* bh, const OnePassIn& in, const anx_search_params& p, OnePassState** out, std::string& err) {
+  *out = nullptr;
+  if (!dl || !bu || !bu->ran) { err = "one-pass search: the unigram batch has not run"; return ANX_EINVAL; }
+  HIP_TRY(hipSetDevice(dl->device));
+  std::unique_ptr<OnePassState> S(new OnePassState());
+  S->device = dl->device;
+  S->st = encoder_stream_acquire(dl->device);
+  hipStream_t st = S->st;
+  OpArgs& a = S->a;
+  int rc;
+  auto dalloc_ = [&](void** p_, size_t bytes) -> int { HIP_TRY(pool_malloc(p_, std::max<size_t>(bytes, 16))); S->owned.push_back(*p_); return ANX_OK; };
+  auto up = [&](const uint32_t** dst, const uint32_t* src, size_t n) -> int {
+    void* q = nullptr;
+    int r = dalloc_(&q, n * 4);
+    if (r) return r;
+    if (n) HIP_TRY(hipMemcpyAsync(q, src, n * 4, hipMemcpyHostToDevice, st));
+    *dst = static_cast<const uint32_t*>(q);
+    return ANX_OK;
+  };
+  a.nmatch = (uint32_t)in.nmatch; a.ngroup = (uint32_t)in.ngroup; a.nin = (uint32_t)in.nin; a.nst = (uint32_t)in.nst;
+  if ((rc = up(&a.m_q, in.m_q, in.nmatch)) || (rc = up(&a.m_u0, in.m_u0, in.nmatch)) || (rc = up(&a.m_u1, in.m_u1, in.nmatch)) ||
+      (rc = up(&a.m_pack, in.m_pack, in.nmatch)) || (rc = up(&a.m_lat, in.m_lat, in.nmatch)) || (rc = up(&a.g_ref, in.g_ref, in.ngroup)) ||
+      (rc = up(&a.e_g0, in.e_g0, in.nin)) || (rc = up(&a.e_lat, in.e_lat, in.nin)) || (rc = up(&a.st_m0, in.st_m0, in.nst)) || (rc = up(&a.st_e0, in.st_e0, in.nst)))
+    return rc;
+  a.freq_weight = p.base.freq_weight;
+  // input index -> sorted query of both batches
+  uint32_t *inv_u = nullptr, *inv_h = nullptr;
+  a.nin_u = (uint32_t)bu->n_input;
+  a.nin_h = bh ? (uint32_t)bh->n_input : 0u;
+  if ((rc = dalloc_((void**)&inv_u, (size_t)a.nin_u * 4)) || (rc = dalloc_((void**)&inv_h, (size_t)a.nin_h * 4))) return rc;
+  HIP_TRY(hipMemsetAsync(inv_u, 0xFF, std::max<size_t>((size_t)a.nin_u * 4, 4), st));
+  HIP_TRY(hipMemsetAsync(inv_h, 0xFF, std::max<size_t>((size_t)a.nin_h * 4, 4), st));
+  if (bu->nq) hipLaunchKernelGGL(k_op_inv, dim3(((uint32_t)bu->nq + 255) / 256), dim3(256), 0, st, (uint32_t)bu->nq, bu->q_orig, inv_u);
+  if (bh && bh->nq) hipLaunchKernelGGL(k_op_inv, dim3(((uint32_t)bh->nq + 255) / 256), dim3(256), 0, st, (uint32_t)bh->nq, bh->q_orig, inv_h);
+  a.inv_u = inv_u; a.inv_h = inv_h;
+  S->d_inv_h = inv_h;
+  a.soff_u = bu->soff; a.cnt_u = bu->r_count; a.rows_u = bu->r_rows;
+  if (bh && bh->nq && a.nmatch) {  // the redundant higher-order queries find nothing
+    hipLaunchKernelGGL(k_op_skip, dim3((a.nmatch + 255) / 256), dim3(256), 0, st, a, bh->q_bits);
+    HIP_TRY(hipStreamSynchronize(st));  // the batch runs on another stream
+  }
+  HIP_TRY(hipGetLastError());
+  *out = S.release();
+  return ANX_OK;
+}
+
+// Phase 2 (both batches have run): builds the lattices, decodes them and brings the matches of the chosen paths back.
+int search_onepass_finish(const HostModel& m, const DeviceLexicon* dl, OnePassState* S, const Batch* bu, const Batch* bh, OnePassIn& in, const anx_search_params& p,
+                          OnePassOut& out, std::string& err) {
+  HIP_TRY(hipSetDevice(dl->device));
+  hipStream_t st = S->st;
+  OpArgs& a = S->a;
+  int rc = lm_ensure(m, dl, err);
+  if (rc) return rc;
+  const bool timing = switches().search_timing != 0;  // (the laps synchronise: timing runs only)
+  auto tnow = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+  double t_prev = timing ? tnow() : 0.0;
+  auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); const double t = tnow(); fprintf(stderr, "[anx search]     one pass / device: %-22s %8.2f ms\n", what, (t - t_prev) * 1e3); t_prev = t; } };
+  auto dalloc_ = [&](void** p_, size_t bytes) -> int { HIP_TRY(pool_malloc(p_, std::max<size_t>(bytes, 16))); S->owned.push_back(*p_); return ANX_OK; };
+  if (bh) {
+    if (!bh->ran) { err = "one-pass search: the higher-order batch has not run"; return ANX_EINVAL; }
+    a.soff_h = bh->soff; a.cnt_h = bh->r_count; a.rows_h = bh->r_rows;
+  } else { a.soff_h = a.soff_u; a.cnt_h = a.cnt_u; a.rows_h = a.rows_u; }
+  const size_t nres = bu->n_results + (bh ? bh->n_results : 0);
+  size_t n_uni = 0;
+  for (size_t i = 0; i < in.nmatch; ++i) n_uni += ((in.m_pack[i] >> 24) & 0x7Fu) == 1u;
+  const size_t nsym_cap = nres + n_uni + 16, narc_cap = nsym_cap + (in.ngroup - in.nmatch) + 16;
+  if (narc_cap >= ((size_t)1 << 32)) { err = "more than 2^32 lattice arcs in one part"; return ANX_ELIMIT; }
+  a.narc_cap = (uint32_t)narc_cap; a.nsym_cap = (uint32_t)nsym_cap;
+  uint32_t *d_outn = nullptr, *d_outs = nullptr, *d_boff = nullptr;
+  int32_t* d_btok = nullptr;
+  if ((rc = dalloc_((void**)&a.mc, ((size_t)a.nmatch + 1) * 4)) || (rc = dalloc_((void**)&a.gc, ((size_t)a.ngroup + 1) * 4)) || (rc = dalloc_((void**)&a.mflag, (size_t)a.nmatch + 4)) ||
+      (rc = dalloc_((void**)&a.sym_off, ((size_t)a.nmatch + 1) * 4)) || (rc = dalloc_((void**)&a.arc_off, ((size_t)a.ngroup + 1) * 4)) ||
+      (rc = dalloc_((void**)&a.st, (size_t)a.nst * sizeof(LatStretch))) || (rc = dalloc_((void**)&a.in_off, (size_t)a.nin * 4)) ||
+      (rc = dalloc_((void**)&a.arcs, narc_cap * sizeof(LatArc))) || (rc = dalloc_((void**)&a.syms, nsym_cap * sizeof(LatSym))) ||
+      (rc = dalloc_((void**)&a.refs, nsym_cap * sizeof(uint2))) || (rc = dalloc_((void**)&a.overflow, 16)) ||
+      (rc = dalloc_((void**)&d_outn, (size_t)a.nst * 4)) || (rc = dalloc_((void**)&d_outs, in.out_total * 4)) ||
+      (rc = dalloc_((void**)&d_boff, in.nboff * 4)) || (rc = dalloc_((void**)&d_btok, in.nbtok * 4)))
+    return rc;
+  HIP_TRY(hipMemsetAsync(a.overflow, 0, 16, st));
+  HIP_TRY(hipMemsetAsync(a.mc + a.nmatch, 0, 4, st));
+  HIP_TRY(hipMemsetAsync(a.gc + a.ngroup, 0, 4, st));
+  if (in.nboff) HIP_TRY(hipMemcpyAsync(d_boff, in.btok_off, in.nboff * 4, hipMemcpyHostToDevice, st));
+  if (in.nbtok) HIP_TRY(hipMemcpyAsync(d_btok, in.btok, in.nbtok * 4, hipMemcpyHostToDevice, st));
+  if (a.nmatch) hipLaunchKernelGGL(k_op_counts, dim3((a.nmatch + 255) / 256), dim3(256), 0, st, a);
+  if (a.ngroup) hipLaunchKernelGGL(k_op_gcount, dim3((a.ngroup + 255) / 256), dim3(256), 0, st, a);
+  if ((rc = op_scan(a.mc, a.sym_off, (size_t)a.nmatch + 1, st, S->owned, err)) || (rc = op_scan(a.gc, a.arc_off, (size_t)a.ngroup + 1, st, S->owned, err))) return rc;
+  if (a.ngroup) hipLaunchKernelGGL(k_op_fill, dim3((a.ngroup + 255) / 256), dim3(256), 0, st, a);
+  if (a.nin) hipLaunchKernelGGL(k_op_inoff, dim3((a.nin + 255) / 256), dim3(256), 0, st, a);
+  lap("build (counts, scans, fill)");
+  a.out_n = d_outn; a.out_syms = d_outs; a.out_total = (uint32_t)in.out_total;
+  std::vector<LatStretch> hst(in.st, in.st + in.nst);
+  std::vector<uint32_t> maxdeg(in.maxdeg, in.maxdeg + in.nst);
+  const uint32_t K = std::max<uint32_t>(1u, p.max_seq);
+  out.handed_back = false;
+  if (a.nst) {
+    if (K > 4096u) { out.handed_back = true; return ANX_OK; }
+    HIP_TRY(hipMemsetAsync(d_outn, 0, (size_t)a.nst * 4, st));
+    auto fix = [&]() -> int {
+      hipLaunchKernelGGL(k_op_stfix, dim3((a.nst + 255) / 256), dim3(256), 0, st, a);
+      return ANX_OK;
+    };
+    if ((rc = lattice_launch(m, dl, hst, maxdeg, a.st, a.in_off, a.arcs, a.syms, d_boff, d_btok, d_outn, d_outs, p, st, fix, S->owned, err))) return rc;
+  }
+  lap("k_lattice");
+  // the matches on the chosen paths and their rows
+  if ((rc = dalloc_((void**)&a.e_match, (in.out_total + 1) * 4)) || (rc = dalloc_((void**)&a.e_sel, (in.out_total + 1) * 4)) ||
+      (rc = dalloc_((void**)&a.e_cnt, (in.out_total + 1) * 4)) || (rc = dalloc_((void**)&a.e_row0, (in.out_total + 1) * 4)) ||
+      (rc = dalloc_((void**)&a.e_rows, std::max<size_t>(nres, 1) * sizeof(anx_result))))
+    return rc;
+  HIP_TRY(hipMemsetAsync(a.e_cnt, 0, (in.out_total + 1) * 4, st));
+  if (a.nst) hipLaunchKernelGGL(k_op_emit_count, dim3((a.nst + 255) / 256), dim3(256), 0, st, a);
+  if ((rc = op_scan(a.e_cnt, a.e_row0, in.out_total + 1, st, S->owned, err))) return rc;
+  if (a.nst) hipLaunchKernelGGL(k_op_emit_rows, dim3((a.nst + 255) / 256), dim3(256), 0, st, a);
+  // download: per lattice the symbols of its path; per out slot (match, variant, first row); then the rows themselves
+  const size_t o_n = 0, o_m = o_n + ((size_t)a.nst * 4 + 63) / 64 * 64, o_s = o_m + ((in.out_total + 1) * 4 + 63) / 64 * 64, o_r = o_s + ((in.out_total + 1) * 4 + 63) / 64 * 64,
+               o_end = o_r + ((in.out_total + 1) * 4 + 63) / 64 * 64 + 64;
+  char* blk = static_cast<char*>(host_result_alloc(o_end));
+  if (!blk) { err = "out of memory"; return ANX_EINVAL; }
+  out.block = blk;
+  out.out_n = reinterpret_cast<uint32_t*>(blk + o_n); out.e_match = reinterpret_cast<uint32_t*>(blk + o_m);
+  out.e_sel = reinterpret_cast<uint32_t*>(blk + o_s); out.e_row0 = reinterpret_cast<uint32_t*>(blk + o_r);
+  uint32_t* h_over = reinterpret_cast<uint32_t*>(blk + o_end - 64);
+  if (a.nst) HIP_TRY(hipMemcpyAsync(out.out_n, d_outn, (size_t)a.nst * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(out.e_match, a.e_match, (in.out_total + 1) * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(out.e_sel, a.e_sel, (in.out_total + 1) * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(out.e_row0, a.e_row0, (in.out_total + 1) * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_over, a.overflow, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  lap("emit + small downloads");
+  if (*h_over) { err = "internal error: a lattice outgrew the bounds of its part"; return ANX_ELIMIT; }
+  for (uint32_t li = 0; li < a.nst; ++li)
+    if (out.out_n[li] == 0xFFFFFFFFu) { out.handed_back = true; return ANX_OK; }  // a lattice beyond the kernel's limits: the caller takes the classic path
+  const size_t total_rows = out.e_row0[in.out_total];
+  if (total_rows > nres) { err = "internal error: more emitted rows than ranked rows"; return ANX_ELIMIT; }
+  out.n_rows = total_rows;
+  out.rows = static_cast<anx_result*>(host_result_alloc(std::max<size_t>(total_rows, 1) * sizeof(anx_result)));
+  if (!out.rows) { err = "out of memory"; return ANX_EINVAL; }
+  if (total_rows) HIP_TRY(hipMemcpyAsync(out.rows, a.e_rows, total_rows * sizeof(anx_result), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  lap("rows download");
   return ANX_OK;
 }
 

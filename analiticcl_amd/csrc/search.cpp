@@ -40,6 +40,7 @@ const anx::HostModel& anx_host_of(const anx_model* m);  // capi.cpp
 const anx::DeviceLexicon* anx_replica_of(const anx_model* m, size_t i);
 int anx_replica_device(const anx_model* m, size_t i);  // capi.cpp
 int anx_fail(int code, const std::string& msg);         // capi.cpp
+anx::Batch* anx_batch_single(const anx_batch* b);       // capi.cpp
 
 namespace {
 
@@ -226,8 +227,11 @@ size_t count_internal(const Span& m, const Span* bs, size_t nb) {
   return end - (size_t)begin;
 }
 // find_match_ngrams (src/search.rs:262-313)
+// states: optionally, per segment pushed, the lattice states it connects as source | destination << 12 (state i + 1 = behind boundary
+// i of the stretch, state 0 = its start: what build_lattice finds by comparing offsets) -- 0xFFFFFFFF for the rare tail segment,
+// whose states the caller looks up
 void find_match_ngrams(const char* text, const Span* bs, size_t nb, uint32_t order, size_t begin, size_t end,
-                       std::vector<Span>& out) {
+                       std::vector<Span>& out, std::vector<uint32_t>* states = nullptr) {
   size_t i = 0;
   while (i + order - 1 < nb) {
     const Span& boundary = bs[i + order - 1];
@@ -236,6 +240,9 @@ void find_match_ngrams(const char* text, const Span* bs, size_t nb, uint32_t ord
       Span s{begin, boundary.begin};
       s.n = order;
       out.push_back(s);
+      // the segment starts behind boundary i - 1 (or at the stretch's start) and ends at boundary i + order - 1; a zero-length
+      // boundary (only the one find_boundaries appends at the end of a text) could tie with those: then the caller looks it up
+      if (states) states->push_back((bs[nb - 1].begin == bs[nb - 1].end) ? 0xFFFFFFFFu : ((uint32_t)i | ((uint32_t)(i + order) << 12)));
     }
     begin = bs[i].end;
     ++i;
@@ -243,7 +250,7 @@ void find_match_ngrams(const char* text, const Span* bs, size_t nb, uint32_t ord
   if (begin < end && !(end - begin == 1 && text[begin] == ' ')) {
     Span s{begin, end};
     s.n = order;
-    if (count_internal(s, bs, nb) == order) out.push_back(s);
+    if (count_internal(s, bs, nb) == order) { out.push_back(s); if (states) states->push_back(0xFFFFFFFFu); }
   }
 }
 // redundant_match (src/search.rs:317-336)
@@ -875,6 +882,345 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   return ANX_OK;
 }
 
+
+// ---- the one-device-pass form of a part (round 5; lattice.hip search_onepass_*) ------------------------------------------------------
+// The host generates the segments of ALL n-gram orders at once (whether a higher-order segment is looked up no longer waits for
+// the unigrams' results on the host: redundant_match, src/search.rs:317-336, is decided on the device from the unigrams' rows),
+// describes the lattice structure that does not depend on results (states, arc order) and lets the device build and decode the
+// lattices; only the matches of the chosen paths come back, with their rows.  Fills decoded[] / done[] like the classic path and
+// leaves the rows in po.kept.  *fallback: the part needs the classic path (a lattice beyond the device decoder's limits, a stretch
+// with matches but no lattice): nothing was changed.
+static int onepass_part(const anx_model* model, const HostModel& m, const char* const* texts, const anx_search_params* sp, std::vector<std::vector<Span>>& bounds,
+                        std::vector<Stretch>& stretches, std::vector<std::vector<Span>>& decoded, std::vector<uint8_t>& done, PartOut& po, void* stream, bool* fallback,
+                        const std::function<void(const char*)>& lap) {
+  *fallback = false;
+  const size_t NS = stretches.size();
+  const bool use_lm = m.have_lm && sp->lm_weight > 0.0f;
+  const uint32_t max_ngram = sp->max_ngram;
+  const size_t SC = 64, nsc = (NS + SC - 1) / SC;
+  struct MRec { uint32_t pack, u0, u1; };   // u0 / u1 local to the stretch
+  struct Chunk {
+    std::vector<MRec> rec;                // per match of the chunk's stretches, in order
+    std::vector<int32_t> btok;            // LM tokens of the boundaries
+    std::vector<uint32_t> btok_off;       // per (stretch, boundary) + 1 per stretch, relative to the stretch's first token
+    bool odd = false;                     // a stretch with matches but no lattice
+  };
+  std::vector<Chunk> chunks(nsc);
+  std::vector<uint32_t> st_nu(NS + 1, 0), st_nm(NS + 1, 0);       // unigram matches / matches per stretch (prefix sums below)
+  std::vector<size_t> st_bu(NS + 1, 0), st_bh(NS + 1, 0);         // arena bytes per stretch
+  std::vector<uint8_t> has_lat(NS, 0);
+  std::vector<uint32_t> st_nfin(NS, 0), st_ntok(NS, 0);           // final states / LM tokens per stretch
+  auto state_of_end = [](const Span* bs, size_t nb, size_t off) -> long {  // last boundary whose END is off (build_lattice: prevb)
+    size_t lo = 0, hi = nb;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (bs[mid].end < off) lo = mid + 1; else hi = mid; }
+    long r = -1;
+    for (size_t i = lo; i < nb && bs[i].end == off; ++i) r = (long)i;
+    return r;
+  };
+  auto state_of_begin = [](const Span* bs, size_t nb, size_t off, size_t mbegin) -> long {  // last boundary whose BEGIN is off and whose end is not the match's begin (nextb)
+    size_t lo = 0, hi = nb;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (bs[mid].begin < off) lo = mid + 1; else hi = mid; }
+    long r = -1;
+    for (size_t i = lo; i < nb && bs[i].begin == off; ++i) if (bs[i].end != mbegin) r = (long)i;
+    return r;
+  };
+  pool_for(nsc, 4, 8, [&](size_t clo, size_t chi) {
+    std::vector<uint32_t> sd;  // states of the segments as find_match_ngrams knows them
+    for (size_t c = clo; c < chi; ++c) {
+      Chunk& C = chunks[c];
+      const size_t s_lo = c * SC, s_hi = std::min(NS, s_lo + SC);
+      for (size_t si = s_lo; si < s_hi; ++si) {
+        Stretch& st = stretches[si];
+        const char* text = texts[st.text_index];
+        const Span* bs = bounds[st.text_index].data() + st.b0;
+        const size_t nb = st.b1 - st.b0;
+        std::vector<Span>& mv = st.matches;
+        mv.clear();
+        mv.reserve((nb + 1) * max_ngram);
+        sd.clear();
+        for (uint32_t order = 1; order <= max_ngram; ++order) {
+          find_match_ngrams(text, bs, nb, order, st.begin, st.end, mv, &sd);
+          if (order == 1) st_nu[si + 1] = (uint32_t)mv.size();
+        }
+        st_nm[si + 1] = (uint32_t)mv.size();
+        const uint32_t nu = st_nu[si + 1];
+        bool any_sym = false;
+        uint32_t nfin = 0;
+        for (size_t i = 0; i < nb; ++i) nfin += (bs[i].begin == st.end || bs[i].end == st.end) ? 1u : 0u;
+        st_nfin[si] = nfin;
+        const bool any_final = nfin != 0;
+        uint32_t ulo = 0;
+        for (size_t mi = 0; mi < mv.size(); ++mi) {
+          const Span& mt = mv[mi];
+          MRec r{0u, 0u, 0u};
+          bool has_dst = true;
+          if (sd[mi] != 0xFFFFFFFFu) r.pack = sd[mi] | (mt.n << 24);
+          else {  // build_lattice's own search over the boundaries' offsets
+            const long prevb = state_of_end(bs, nb, mt.begin), nextb = state_of_begin(bs, nb, mt.end, mt.begin);
+            const uint32_t src = prevb >= 0 ? (uint32_t)prevb + 1u : 0u;
+            has_dst = nextb >= 0;
+            if (!has_dst) r.pack = src | (mt.n << 24) | 0x80000000u;
+            else r.pack = src | (((uint32_t)nextb + 1u) << 12) | (mt.n << 24);
+          }
+          if (mt.n == 1) { any_sym = any_sym || has_dst; st_bu[si + 1] += mt.end - mt.begin + 1; }
+          else {
+            if (mi == nu || mv[mi - 1].n != mt.n) ulo = 0;  // a new order: its segments ascend again
+            while (ulo < nu && mv[ulo].begin < mt.begin) ++ulo;
+            uint32_t uhi = ulo;
+            while (uhi < nu && mv[uhi].end <= mt.end) ++uhi;
+            r.u0 = ulo; r.u1 = uhi;
+            st_bh[si + 1] += mt.end - mt.begin + 1;
+          }
+          C.rec.push_back(r);
+        }
+        if (nb + 1 > 0xFFEu) C.odd = true;  // states beyond the packed 12 bits (the device decoder's limit is lower still)
+        has_lat[si] = any_sym && any_final;
+        if (!has_lat[si] && !mv.empty()) C.odd = true;
+        // LM tokens of the boundary texts (src/lib.rs:2606-2629), as build_lattice lays them out
+        if (has_lat[si]) {
+          const size_t t0 = C.btok.size();
+          for (size_t bi = 0; bi < nb; ++bi) {
+            C.btok_off.push_back((uint32_t)(C.btok.size() - t0));
+            if (!use_lm) continue;
+            const Span& nbs = bs[bi];
+            if (!(nbs.end - nbs.begin == 1 && text[nbs.begin] == ' ') && nbs.end > nbs.begin) {
+              const std::string bt = anx::trim_whitespace(std::string(text + nbs.begin, nbs.end - nbs.begin));
+              if (!bt.empty()) {
+                auto it = m.encoder.find(bt);
+                if (it != m.encoder.end()) for (uint32_t k = m.ngram_off[it->second]; k < m.ngram_off[it->second + 1]; ++k) C.btok.push_back((int32_t)m.ngram_ids[k]);
+                else C.btok.push_back(-1);
+              }
+            }
+          }
+          C.btok_off.push_back((uint32_t)(C.btok.size() - t0));
+          st_ntok[si] = (uint32_t)(C.btok.size() - t0);
+        }
+      }
+    }
+  });
+  for (const Chunk& C : chunks) if (C.odd) { *fallback = true; return ANX_OK; }
+  // prefix sums: matches, unigram / higher-order queries and arena bytes per stretch
+  std::vector<uint32_t> m0(NS + 1, 0), qu0(NS + 1, 0), qh0(NS + 1, 0);
+  for (size_t si = 0; si < NS; ++si) {
+    m0[si + 1] = m0[si] + st_nm[si + 1];
+    qu0[si + 1] = qu0[si] + st_nu[si + 1];
+    qh0[si + 1] = qh0[si] + (st_nm[si + 1] - st_nu[si + 1]);
+    st_bu[si + 1] += st_bu[si];
+    st_bh[si + 1] += st_bh[si];
+  }
+  const size_t M = m0[NS], NU = qu0[NS], NH = qh0[NS];
+  if (M >= (1u << 30) || st_bu[NS] >= ((size_t)1 << 32) || st_bh[NS] >= ((size_t)1 << 32) || NU > ((size_t)4 << 20) || NH > ((size_t)4 << 20)) { *fallback = true; return ANX_OK; }
+  // lattices: the stretches that have one, in stretch order; in_off entries, out slots, LM token offsets
+  std::vector<uint32_t> lat_of_st(NS, 0xFFFFFFFFu), st_of_lat;
+  for (size_t si = 0; si < NS; ++si) if (has_lat[si]) { lat_of_st[si] = (uint32_t)st_of_lat.size(); st_of_lat.push_back((uint32_t)si); }
+  const size_t NL = st_of_lat.size();
+  std::vector<anx::LatStretch> lst(NL);
+  std::vector<uint32_t> st_m0(NL), st_e0(NL), maxdeg(NL, 0), g0_of_lat(NL + 1, 0);
+  size_t nin = 0, nout = 0, nboff = 0, nbtok = 0;
+  {
+    std::vector<size_t> ch_btok0(nsc + 1, 0), ch_boff0(nsc + 1, 0);
+    for (size_t c = 0; c < nsc; ++c) { ch_btok0[c + 1] = ch_btok0[c] + chunks[c].btok.size(); ch_boff0[c + 1] = ch_boff0[c] + chunks[c].btok_off.size(); }
+    nbtok = ch_btok0[nsc]; nboff = ch_boff0[nsc];
+    size_t li = 0;
+    for (size_t c = 0; c < nsc; ++c) {
+      size_t boff = ch_boff0[c];
+      size_t tok_before = 0;  // tokens of the chunk's earlier lattices
+      for (size_t si = c * SC; si < std::min(NS, (c + 1) * SC); ++si) {
+        if (!has_lat[si]) continue;
+        const size_t nb = stretches[si].b1 - stretches[si].b0;
+        anx::LatStretch& S = lst[li];
+        S.nstates = (uint32_t)nb + 1u;
+        S.in_off0 = (uint32_t)nin;
+        S.arc0 = 0; S.sym0 = 0;
+        S.btok_off0 = (uint32_t)boff;
+        S.btok0 = (uint32_t)(ch_btok0[c] + tok_before);
+        tok_before += st_ntok[si];
+        S.out0 = (uint32_t)nout;
+        S.best_cost_init = (float)(nb - 1) * 2.0f;
+        S.ring = 2;
+        S.node0 = 0;
+        st_m0[li] = m0[si];
+        st_e0[li] = (uint32_t)nin;
+        nin += nb + 3;
+        nout += nb + 1;
+        boff += nb + 1;
+        ++li;
+      }
+    }
+  }
+  if (nin >= ((size_t)1 << 32) || nout >= ((size_t)1 << 32)) { *fallback = true; return ANX_OK; }
+  // per-match tables, arenas, arc groups (parallel over the chunks)
+  // (the tables and the arenas live in ONE pinned block of the result cache: they go to the device at PCIe speed; from pageable
+  // vectors the 35 MB per part took 6-10 ms)
+  // groups per lattice: one per match with a destination + one epsilon per boundary + the finals
+  std::vector<uint32_t> g_cnt(NL + 1, 0);
+  for (size_t li = 0; li < NL; ++li) {
+    const size_t si = st_of_lat[li];
+    const size_t nb = stretches[si].b1 - stretches[si].b0;
+    g_cnt[li + 1] = g_cnt[li] + st_nm[si + 1] + (uint32_t)nb + st_nfin[si];  // (matches without a destination get a group too: zero arcs)
+  }
+  const size_t G = g_cnt[NL];
+  auto al64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t o_q = 0, o_u0 = o_q + al64(M * 4), o_u1 = o_u0 + al64(M * 4), o_pk = o_u1 + al64(M * 4), o_lt = o_pk + al64(M * 4), o_g = o_lt + al64(M * 4),
+               o_e0 = o_g + al64(G * 4), o_el = o_e0 + al64(nin * 4), o_bo = o_el + al64(nin * 4), o_bt = o_bo + al64(std::max<size_t>(nboff, 1) * 4),
+               o_au = o_bt + al64(std::max<size_t>(nbtok, 1) * 4), o_ah = o_au + al64(st_bu[NS] + 16), o_end = o_ah + al64(st_bh[NS] + 16);
+  char* tblk = static_cast<char*>(anx::host_result_alloc(o_end));
+  if (!tblk) return anx_fail(ANX_EINVAL, "out of memory");
+  struct TblFree { char* p; ~TblFree() { anx::host_result_free(p); } } tbl_free{tblk};
+  uint32_t *t_q = reinterpret_cast<uint32_t*>(tblk + o_q), *t_u0 = reinterpret_cast<uint32_t*>(tblk + o_u0), *t_u1 = reinterpret_cast<uint32_t*>(tblk + o_u1),
+           *t_pack = reinterpret_cast<uint32_t*>(tblk + o_pk), *t_lat = reinterpret_cast<uint32_t*>(tblk + o_lt), *g_ref = reinterpret_cast<uint32_t*>(tblk + o_g),
+           *e_g0 = reinterpret_cast<uint32_t*>(tblk + o_e0), *e_lat = reinterpret_cast<uint32_t*>(tblk + o_el), *btok_off = reinterpret_cast<uint32_t*>(tblk + o_bo);
+  int32_t* btok = reinterpret_cast<int32_t*>(tblk + o_bt);
+  char *arena_u = tblk + o_au, *arena_h = tblk + o_ah;
+  const uint32_t rows_bound = sp->base.max_matches ? sp->base.max_matches + 1u : 200u;
+  pool_for(nsc, 4, 8, [&](size_t clo, size_t chi) {
+    std::vector<uint32_t> cnt, pos, ord;
+    for (size_t c = clo; c < chi; ++c) {
+      const Chunk& C = chunks[c];
+      size_t rpos = 0;
+      for (size_t si = c * SC; si < std::min(NS, (c + 1) * SC); ++si) {
+        const Stretch& st = stretches[si];
+        const char* text = texts[st.text_index];
+        const std::vector<Span>& mv = st.matches;
+        const uint32_t nu = st_nu[si + 1], li = lat_of_st[si];
+        char* wu = arena_u + st_bu[si];
+        char* wh = arena_h + st_bh[si];
+        uint32_t iu = qu0[si], ih = qh0[si];
+        for (size_t mi = 0; mi < mv.size(); ++mi, ++rpos) {
+          const size_t gm = (size_t)m0[si] + mi;
+          const MRec& r = C.rec[rpos];
+          const size_t l = mv[mi].end - mv[mi].begin;
+          char*& w = mi < nu ? wu : wh;
+          memcpy(w, text + mv[mi].begin, l);
+          w[l] = '\0';
+          w += l + 1;
+          t_q[gm] = mi < nu ? iu++ : ih++;
+          t_u0[gm] = m0[si] + r.u0; t_u1[gm] = m0[si] + r.u1;
+          t_pack[gm] = r.pack;
+          t_lat[gm] = li;
+        }
+        if (li == 0xFFFFFFFFu) continue;
+        // arc groups in (destination state, source state, match) order, the epsilon arc of a state behind its matches, then the finals
+        const Span* bs = bounds[st.text_index].data() + st.b0;
+        const size_t nb = st.b1 - st.b0, nstates = nb + 1;
+        cnt.assign(nstates + 2, 0u);
+        const size_t rbase = rpos - mv.size();
+        uint32_t nodst = 0;
+        for (size_t mi = 0; mi < mv.size(); ++mi) {
+          const uint32_t pk = C.rec[rbase + mi].pack;
+          if (pk >> 31) ++nodst; else ++cnt[((pk >> 12) & 0xFFFu) + 1];
+        }
+        for (size_t d = 1; d <= nstates + 1; ++d) cnt[d] += cnt[d - 1];
+        ord.assign(mv.size(), 0u);
+        pos.assign(cnt.begin(), cnt.end());
+        for (size_t mi = 0; mi < mv.size(); ++mi) {
+          const uint32_t pk = C.rec[rbase + mi].pack;
+          if (!(pk >> 31)) ord[pos[(pk >> 12) & 0xFFFu]++] = (uint32_t)mi;
+        }
+        uint32_t g = g_cnt[li], e = st_e0[li], span = 1, deg_max = 0;
+        // the matches that end at no boundary come first: zero arcs, any place will do
+        for (size_t mi = 0; mi < mv.size(); ++mi) if (C.rec[rbase + mi].pack >> 31) g_ref[g++] = (uint32_t)(m0[si] + mi);
+        e_g0[e] = g; e_lat[e] = li; ++e;                       // state 0: no incoming arcs
+        for (size_t d = 1; d < nstates; ++d) {
+          e_g0[e] = g; e_lat[e] = li; ++e;
+          const uint32_t a0 = cnt[d], a1 = cnt[d + 1];
+          // by source state ascending, then by match index (a handful of entries)
+          std::sort(ord.begin() + a0, ord.begin() + a1, [&](uint32_t x, uint32_t y) {
+            const uint32_t sx = C.rec[rbase + x].pack & 0xFFFu, sy = C.rec[rbase + y].pack & 0xFFFu;
+            return sx != sy ? sx < sy : x < y;
+          });
+          uint32_t deg = 1;
+          for (uint32_t k = a0; k < a1; ++k) {
+            g_ref[g++] = (uint32_t)(m0[si] + ord[k]);
+            span = std::max(span, (uint32_t)d - (C.rec[rbase + ord[k]].pack & 0xFFFu));
+            deg += rows_bound;
+          }
+          g_ref[g++] = (1u << 30) | (uint32_t)(d - 1);          // the fail-safe epsilon arc d - 1 -> d
+          deg_max = std::max(deg_max, deg);
+        }
+        e_g0[e] = g; e_lat[e] = li; ++e;                       // the virtual end state: the finals
+        uint32_t nfin = 0;
+        for (size_t i = 0; i < nb; ++i)
+          if (bs[i].begin == st.end || bs[i].end == st.end) { g_ref[g++] = (2u << 30) | (uint32_t)(i + 1); span = std::max(span, (uint32_t)nstates - (uint32_t)(i + 1)); ++nfin; }
+        deg_max = std::max(deg_max, nfin);
+        e_g0[e] = g; e_lat[e] = li; ++e;                       // end of the lattice's arcs
+        (void)nodst;
+        lst[li].ring = span + 1;
+        maxdeg[li] = deg_max;
+      }
+    }
+  });
+  {
+    size_t tb = 0, ob = 0;
+    for (const Chunk& C : chunks) {
+      if (!C.btok.empty()) memcpy(btok + tb, C.btok.data(), C.btok.size() * sizeof(int32_t));
+      if (!C.btok_off.empty()) memcpy(btok_off + ob, C.btok_off.data(), C.btok_off.size() * sizeof(uint32_t));
+      tb += C.btok.size(); ob += C.btok_off.size();
+    }
+  }
+  lap("one pass: segments + tables");
+  // ---- the device: both batches, the redundant higher-order queries cleared in between ------------------------------------------
+  struct BatchFree { anx_batch* b; ~BatchFree() { if (b) anx_batch_free(b); } };
+  BatchFree bu{nullptr}, bh{nullptr};
+  auto failed = [&]() { const int code = anx_last_error_code(); return code ? code : ANX_ENODEVICE; };
+  if (!NU) { *fallback = true; return ANX_OK; }  // no unigram at all: nothing to decode (the classic path passes the stretches through)
+  bu.b = anx_batch_encode_packed(model, arena_u, st_bu[NS], NU, &sp->base);
+  if (!bu.b) return failed();
+  anx::Batch* eu = anx_batch_single(bu.b);
+  if (!eu) { *fallback = true; return ANX_OK; }
+  // the unigrams run while the higher orders are encoded (the encoder waits for the device several times: that time is the run's)
+  int rc = anx_batch_run_async(model, bu.b, stream);
+  if (rc != ANX_OK) return rc;
+  if (NH) { bh.b = anx_batch_encode_packed(model, arena_h, st_bh[NS], NH, &sp->base); if (!bh.b) { (void)anx_batch_wait(model, bu.b); return failed(); } }
+  anx::Batch* eh = bh.b ? anx_batch_single(bh.b) : nullptr;
+  rc = anx_batch_wait(model, bu.b);
+  if (rc != ANX_OK) return rc;
+  if (bh.b && !eh) { *fallback = true; return ANX_OK; }
+  anx::OnePassIn in;
+  in.nmatch = M; in.ngroup = G; in.nin = nin; in.nst = NL;
+  in.m_q = t_q; in.m_u0 = t_u0; in.m_u1 = t_u1; in.m_pack = t_pack; in.m_lat = t_lat; in.g_ref = g_ref;
+  in.e_g0 = e_g0; in.e_lat = e_lat; in.st_m0 = st_m0.data(); in.st_e0 = st_e0.data(); in.st = lst.data(); in.maxdeg = maxdeg.data();
+  in.btok_off = btok_off; in.nboff = nboff; in.btok = btok; in.nbtok = nbtok; in.out_total = nout;
+  const anx::DeviceLexicon* dl = anx_replica_of(model, 0);
+  std::string err;
+  anx::OnePassState* stp = nullptr;
+  rc = anx::search_onepass_prepare(dl, eu, eh, in, *sp, &stp, err);
+  if (rc != ANX_OK) return anx_fail(rc, err);
+  struct StFree { anx::OnePassState* s; ~StFree() { anx::search_onepass_free(s); } } st_free{stp};
+  if (bh.b && (rc = anx_batch_run(model, bh.b, stream)) != ANX_OK) return rc;
+  lap("one pass: device batches");
+  anx::OnePassOut out;
+  rc = anx::search_onepass_finish(m, dl, stp, eu, eh, in, *sp, out, err);
+  struct OutFree { anx::OnePassOut& o; bool keep_rows = false; ~OutFree() { anx::host_result_free(o.block); if (!keep_rows) anx::host_result_free(o.rows); } } out_free{out};
+  if (rc != ANX_OK) return anx_fail(rc, err);
+  if (out.handed_back) { *fallback = true; return ANX_OK; }
+  lap("one pass: lattices on the device");
+  // the matches of the chosen paths; their variants are views of the part's row array
+  po.kept.push_back(OrderRows{out.rows, nullptr});
+  out_free.keep_rows = true;
+  pool_for(NL, 256, 512, [&](size_t lo, size_t hi) {
+    for (size_t li = lo; li < hi; ++li) {
+      const size_t si = st_of_lat[li];
+      const anx::LatStretch& S = lst[li];
+      std::vector<Span>& o = decoded[si];
+      const uint32_t n = out.out_n[li];
+      o.reserve(n);
+      for (uint32_t j = 0; j < n; ++j) {
+        const size_t slot = (size_t)S.out0 + j;
+        Span r = stretches[si].matches[out.e_match[slot]];
+        r.has_variants = true;
+        r.variants = RowView{out.rows + out.e_row0[slot], (size_t)(out.e_row0[slot + 1] - out.e_row0[slot])};
+        r.selected = out.e_sel[slot] == 0xFFFFFFFFu ? -1 : (int)out.e_sel[slot];
+        o.push_back(r);
+      }
+      done[si] = 1;
+    }
+  });
+  for (size_t si = 0; si < NS; ++si) if (!has_lat[si]) done[si] = 1;  // (no matches: checked above)
+  lap("one pass: output");
+  return ANX_OK;
+}
+
 static int find_all_part(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp, PartOut& po) {
   const bool timing = anx::switches().search_timing != 0;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -916,6 +1262,29 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
       for (Stretch& x : v) stretches.push_back(std::move(x));
   }
   lap("boundaries");
+  std::vector<std::vector<Span>> decoded(stretches.size());
+  std::vector<uint8_t> done(stretches.size(), 0);
+  bool onepass_done = false;
+  {
+    // round 5: the whole part in one device pass (onepass_part) where the device decodes the lattices anyway: one replica, no context
+    // rules (the host decoder applies them), rows final on the device (no host-side confusable rescoring), max_seq within the
+    // decoder's node pools
+    const bool lattice_needed = sp->max_ngram > 1 || m.have_lm;
+    const bool eligible = anx::switches().search_onepass && one_replica && lattice_needed && m.context_rules.empty() && !anx::switches().lattice_host &&
+                          !(anx::switches().confusables_host && !m.confusables.empty()) && sp->max_seq <= 4096u && sp->max_ngram >= 1 && sp->max_ngram <= 100u &&
+                          !stretches.empty();
+    if (eligible) {
+      bool fb = false;
+      const int rc1 = onepass_part(model, m, texts, sp, bounds, stretches, decoded, done, po, part_stream.s, &fb, lap);
+      if (rc1 != ANX_OK) { po.free_kept(); return rc1; }
+      onepass_done = !fb;
+      if (fb) {  // the classic path starts from clean stretches
+        for (Stretch& st : stretches) st.matches.clear();
+        for (auto& d : decoded) d.clear();
+        std::fill(done.begin(), done.end(), 0);
+      }
+    }
+  }
   // the result arrays of the device batches stay alive until the output has been written
   std::vector<OrderRows>& kept = po.kept;
   auto free_kept = [&]() { po.free_kept(); };
@@ -934,7 +1303,7 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   auto parallel_chunks = [&](const std::function<void(size_t)>& work) {
     parallel_for(nsc, 4, 8, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) work(c); });
   };
-  for (uint32_t o_lo = 1; o_lo <= sp->max_ngram; o_lo = (o_lo == 1 ? 2 : sp->max_ngram + 1)) {
+  for (uint32_t o_lo = 1; o_lo <= sp->max_ngram && !onepass_done; o_lo = (o_lo == 1 ? 2 : sp->max_ngram + 1)) {
     const uint32_t o_hi = o_lo == 1 ? 1 : sp->max_ngram, no = o_hi - o_lo + 1;
     seg_lap(4);
     std::vector<std::vector<ChunkSegs>> cs(no, std::vector<ChunkSegs>(nsc));
@@ -1068,14 +1437,12 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
   // consolidate per stretch: the lattices are independent.  Default: all of them in one go on the device (lattice.hip: one wave per
   // stretch); models with context rules, ANX_LATTICE=host, and the lattices the device hands back are decoded by the host threads
   // (the reference: rayon over the segments and a sequential loop over the stretches, src/lib.rs:1821-1940).
-  std::vector<std::vector<Span>> decoded(stretches.size());
   std::vector<TagPool>& tagpools = po.tagpools;
   tagpools.assign(m.context_rules.empty() ? 0 : stretches.size(), TagPool());
   TagPool no_tags;
   const bool need_lattice = sp->max_ngram > 1 || m.have_lm || !m.context_rules.empty();  // src/lib.rs:1912
   const anx::DeviceLexicon* lat_dev = anx_replica_of(model, 0);
-  const bool on_device = need_lattice && m.context_rules.empty() && !anx::switches().lattice_host && lat_dev && !stretches.empty();
-  std::vector<uint8_t> done(stretches.size(), 0);
+  const bool on_device = !onepass_done && need_lattice && m.context_rules.empty() && !anx::switches().lattice_host && lat_dev && !stretches.empty();
   if (on_device) {
     const bool use_lm = m.have_lm && sp->lm_weight > 0.0f;
     // Chunks of stretches build their lattices side by side, straight into the call's arrays: ONE pinned block (the result cache of
