@@ -542,3 +542,46 @@ def test_search_parts_equal_one_pass(data_dir):
     finally:
         A.set_switch("ANX_SEARCH_PARTS", None)
         A.set_switch("ANX_SEARCH_PARTS_MIN", None)
+
+
+@pytest.mark.gpu
+def test_one_device_pass_equals_the_classic_path(data_dir):
+    """Search mode in one device pass (round 5: the lattices are built on the device from the batches' device-resident rows, the
+    redundancy rule of /root/reference/src/search.rs:317-336 is applied there, only the chosen paths' matches come back) against the
+    path of rounds 1-4 (ANX_SEARCH_ONEPASS=0: every ranked row downloaded, lattice input built by the host threads): offsets, every
+    match field and every variant row identical -- on noisy text, on CLEAN text (nearly every higher-order segment redundant: their
+    queries are cleared before the second batch runs), with a language model, frequency weighting and confusable patterns."""
+    import random
+    import numpy as np
+    lex = os.path.join(data_dir, "eng.aspell.lexicon")
+    words = synth.load_lexicon_words(lex)
+    rng = random.Random(23)
+    common = [w for w in words if w.isalpha()][::23][:5000]
+    LM = A.VocabParams(vocabtype="LM")
+    for variant in ("lm", "plain", "confusables"):
+        g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+        g.read_lexicon(lex)
+        if variant == "lm":
+            for _ in range(8000):
+                g.add_to_vocabulary(f"{rng.choice(common)} {rng.choice(common)}", rng.randrange(1, 20), LM)
+            for w in common[:300]:
+                g.add_to_vocabulary(f"<bos> {w}", 5, LM)
+        if variant == "confusables":
+            g.add_to_confusables("-[e]+[a]", 1.1)
+            g.add_to_confusables("-[y]+[i]", 0.9)
+        g.build()
+        noisy = synth.make_running_text(common, 0.6, seed=41)
+        clean = [" ".join(rng.choice(common) for _ in range(rng.randrange(3, 30))) + rng.choice([". ", "\n", ""]) for _ in range(1500)]
+        texts = noisy + clean + ["", "x", "it's a well-known co-op", "a " * 200, "end"]
+        for kw in (dict(max_ngram=3), dict(max_ngram=2, max_seq=3, freq_weight=0.5), dict(max_ngram=3, max_matches=0), dict(max_ngram=4, max_matches=3, lm_weight=0.0)):
+            p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, **({"max_matches": 10} | kw))
+            out = {}
+            for mode in ("onepass", "classic"):
+                A.set_switch("ANX_SEARCH_ONEPASS", "0" if mode == "classic" else None)
+                try:
+                    out[mode] = g.find_all_matches_arrays(texts, p)
+                finally:
+                    A.set_switch("ANX_SEARCH_ONEPASS", None)
+            for x, y in zip(out["onepass"], out["classic"]):
+                assert np.array_equal(x, y), (variant, kw)
+            assert out["onepass"][1].size > 20_000
