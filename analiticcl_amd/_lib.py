@@ -165,6 +165,7 @@ def lib():
         "anx_model_tag_name": (cp, [vp, sz]),
         "anx_batch_encode": (vp, [vp, C.POINTER(cp), sz, C.POINTER(Params)]),
         "anx_batch_encode_packed": (vp, [vp, C.c_char_p, sz, sz, C.POINTER(Params)]),
+        "anx_batch_gather_compact": (C.c_int, [vp, C.c_int, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
         "anx_batch_encode_packed_device": (vp, [vp, vp, sz, sz, C.POINTER(Params)]),
         "anx_batch_run": (C.c_int, [vp, vp, vp]),
         "anx_batch_run_async": (C.c_int, [vp, vp, vp]),

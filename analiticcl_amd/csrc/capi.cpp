@@ -1474,6 +1474,25 @@ int anx_batch_export_compact(const anx_batch* b, void* dst, size_t capacity, voi
   int rc = anx::batch_export_compact(b->model->replicas[(size_t)b->shards[0].replica].dev, b->shards[0].b, dst, capacity, stream, used, err);
   return rc ? fail(rc, err) : ANX_OK;
 }
+int anx_batch_gather_compact(const anx_batch* b, int dst_device, void* device_dst, size_t capacity, size_t* shard_offsets, size_t* used) {
+  if (!b || !device_dst || !used) return fail(ANX_EINVAL, "NULL argument");
+  if (b->rescore) return fail(ANX_EINVAL, "host-rescored confusable batches have no device-side export: anx_batch_fetch");
+  const size_t S = b->shards.size();
+  std::vector<size_t> off(S + 1, 0);
+  for (size_t g = 0; g < S; ++g) {
+    if (!b->shards[g].b) return fail(ANX_EINVAL, "batch has not been run");
+    off[g + 1] = off[g] + ((anx::batch_compact_bytes(b->shards[g].b) + 255) & ~(size_t)255);
+  }
+  *used = off[S];
+  if (shard_offsets) for (size_t g = 0; g <= S; ++g) shard_offsets[g] = off[g];
+  if (capacity < off[S]) return fail(ANX_ELIMIT, "gather buffer too small: " + std::to_string(off[S]) + " bytes needed");
+  // every shard from its replica's own thread and stream: the exports run side by side, the copies use the links of their own devices
+  char* dst = static_cast<char*>(device_dst);
+  return on_shards(b, [&](size_t g, std::string& err) {
+    const Shard& s = b->shards[g];
+    return anx::batch_gather_compact(b->model->replicas[(size_t)s.replica].dev, s.b, dst_device, dst + off[g], off[g + 1] - off[g], shard_stream(b, s, nullptr), err);
+  });
+}
 int anx_batch_num_shards(const anx_batch* b) { return b ? (int)b->shards.size() : 0; }
 int anx_batch_shard_info(const anx_batch* b, int shard, int* device, size_t* first_input, size_t* n_inputs) {
   if (!b || shard < 0 || (size_t)shard >= b->shards.size()) return fail(ANX_EINVAL, "no such shard");

@@ -66,6 +66,11 @@ int batch_export_topk(const DeviceLexicon* dl, const Batch* b, void* dst, uint32
                       std::string& err);
 int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, size_t capacity, void* stream,
                          size_t* used, std::string& err);
+// the top-k gather behind the C ABI: the compact export of a batch (as batch_export_compact) placed at dst on device dst_device --
+// exported in place when the batch lives there, else exported on its own device and copied over (hipMemcpyPeerAsync: xGMI where the
+// devices see each other, staged through the host otherwise); returns when the bytes are at their destination
+size_t batch_compact_bytes(const Batch* b);
+int batch_gather_compact(const DeviceLexicon* dl, const Batch* b, int dst_device, void* dst, size_t capacity, void* stream, std::string& err);
 void batch_stats(const Batch* b, anx_batch_stats* s);
 
 // ---- search mode's lattice decoding on the device (lattice.hip) ------------------------------------------------------------------

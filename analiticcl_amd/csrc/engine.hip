@@ -1658,6 +1658,42 @@ int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, siz
   return ANX_OK;
 }
 
+size_t batch_compact_bytes(const Batch* b) {
+  return (((b->n_input + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + (b->ran ? (size_t)b->n_results : 0) * sizeof(anx_topk_record);
+}
+int batch_gather_compact(const DeviceLexicon* dl, const Batch* b, int dst_device, void* dst, size_t capacity, void* stream, std::string& err) {
+  if (!b->ran) { err = "batch has not been run"; return ANX_EINVAL; }
+  const size_t need = batch_compact_bytes(b);
+  if (capacity < need) { err = "gather buffer too small: " + std::to_string(need) + " bytes needed for this shard"; return ANX_ELIMIT; }
+  size_t used = 0;
+  if (b->device == dst_device) {  // already where the rows are wanted
+    const int rc = batch_export_compact(dl, b, dst, capacity, stream, &used, err);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    return ANX_OK;
+  }
+  HIP_TRY(hipSetDevice(b->device));
+  {  // direct access between the two devices where the topology has it (xGMI); without it the peer copy is staged by the runtime
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, b->device, dst_device) == hipSuccess && can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      else (void)hipGetLastError();
+    } else (void)hipGetLastError();
+  }
+  void* tmp = nullptr;
+  HIP_TRY(pool_malloc(&tmp, std::max<size_t>(need, 16)));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = batch_export_compact(dl, b, tmp, need, stream, &used, err);
+  if (rc == ANX_OK) {
+    const hipError_t e = hipMemcpyPeerAsync(dst, dst_device, tmp, b->device, used, st);
+    if (e != hipSuccess) { err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); rc = ANX_ENODEVICE; }
+  }
+  (void)hipStreamSynchronize(st);
+  pool_free(tmp);
+  return rc;
+}
+
 // Scored pairs per input query, counted by the scan of a PRODUCTION run (pairs that fail the DL's length test are only
 // counted there, never materialised): the batch is run once more with the per-query counters switched on.
 int batch_pair_counts(const HostModel& m, const DeviceLexicon* dl, Batch* b, uint32_t** out, std::string& err) {

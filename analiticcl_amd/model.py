@@ -320,6 +320,16 @@ class Batch:
         L.check(L.lib().anx_batch_export_compact(self.h, C.c_void_p(device_ptr), capacity, C.c_void_p(stream), C.byref(used)))
         return used.value
 
+    def gather_compact(self, dst_device: int, device_ptr: int, capacity: int):
+        """anx_batch_gather_compact: every shard's compact export in one buffer on device dst_device (the shards' own devices copy
+        their sections over) -> (section offsets [shards + 1], bytes used)."""
+        import numpy as np
+        ns = L.lib().anx_batch_num_shards(self.h)
+        offs = (C.c_size_t * (ns + 1))()
+        used = C.c_size_t(0)
+        L.check(L.lib().anx_batch_gather_compact(self.h, dst_device, C.c_void_p(device_ptr), capacity, offs, C.byref(used)))
+        return np.array(list(offs), dtype=np.int64), used.value
+
     def free(self):
         if getattr(self, "h", None):
             L.lib().anx_batch_free(self.h)

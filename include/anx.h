@@ -257,6 +257,16 @@ int anx_batch_export_topk(const anx_batch *, void *device_dst, uint32_t stride, 
  * the host without a device round trip), also set when the call fails with ANX_ELIMIT because capacity is too small;
  * the multi-GPU gather then moves the used bytes only. */
 int anx_batch_export_compact(const anx_batch *, void *device_dst, size_t capacity, void *stream, size_t *used);
+/* The final top-k gather of a query-sharded job behind the C ABI (what analiticcl_amd/shard.py does for one rank per GPU with RCCL):
+ * the compact export (as anx_batch_export_compact) of EVERY shard of a batch of a multi-device model, in ONE buffer on device
+ * dst_device.  Shard g's records start at shard_offsets[g] (shard_offsets[0 .. shards], 256-byte aligned sections; may be NULL);
+ * a section = u32 offsets[n_g + 1] padded to 16 bytes, then the 16-byte anx_topk_record rows of the shard's inputs IN THE SHARD'S
+ * ORDER (anx_batch_shard_info / anx_batch_shard_inputs map them to the call's input indices).  A shard that lives on dst_device is
+ * exported in place; the others are exported on their own device and copied device to device (hipMemcpyPeerAsync: over xGMI where
+ * the devices see each other, staged by the runtime otherwise), every shard from its replica's own host thread and stream.  Returns
+ * when all sections are in place; *used = bytes needed (also when ANX_ELIMIT says capacity is too small).  The reference's
+ * counterpart is the collect() of its rayon fan-out (src/bin/analiticcl.rs:445-448). */
+int anx_batch_gather_compact(const anx_batch *, int dst_device, void *device_dst, size_t capacity, size_t *shard_offsets, size_t *used);
 typedef struct anx_batch_stats {
   uint64_t n_queries;
   uint64_t n_pairs;          /* scored (query,candidate) pairs = DL invocations of the reference */

@@ -102,6 +102,32 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
         CHECK(anx_batch_run_async(m, b, nullptr) == ANX_OK && anx_batch_wait(m, b) == ANX_OK);
         if (nrep > 1) CHECK(anx_batch_run(m, b, (void*)0x10) == ANX_EINVAL);  // a caller stream with several replicas
         CHECK(anx_batch_fetch(b, &rows, &off) == ANX_OK);
+        if (nrep != 3) {  // the top-k gather behind the C ABI: every shard's compact section in one buffer, rows equal the fetched ones
+          const int S = anx_batch_num_shards(b);
+          std::vector<size_t> so((size_t)S + 1, 0);
+          size_t used = 0;
+          CHECK(anx_batch_gather_compact(b, 0, (void*)&used, 0, so.data(), &used) == ANX_ELIMIT && used > 0);   // too small: says what it needs
+          std::vector<char> buf(used);
+          size_t used2 = 0;
+          CHECK(anx_batch_gather_compact(b, 0, buf.data(), buf.size(), so.data(), &used2) == ANX_OK && used2 == used && so[(size_t)S] == used);
+          for (int g = 0; g < S; ++g) {
+            size_t lo2 = 0, cnt2 = 0;
+            const uint32_t* ix = nullptr;
+            CHECK(anx_batch_shard_info(b, g, nullptr, &lo2, &cnt2) == ANX_OK && anx_batch_shard_inputs(b, g, &ix) == ANX_OK);
+            const uint32_t* go = reinterpret_cast<const uint32_t*>(buf.data() + so[(size_t)g]);
+            const anx_topk_record* gr = reinterpret_cast<const anx_topk_record*>(buf.data() + so[(size_t)g] + (((cnt2 + 1) * 4 + 15) & ~(size_t)15));
+            for (size_t i = 0; i < cnt2; ++i) {
+              const size_t inp = ix ? ix[i] : lo2 + i;
+              CHECK(go[i + 1] - go[i] == off[inp + 1] - off[inp]);
+              for (uint32_t k = go[i]; k < go[i + 1]; ++k)
+                CHECK(gr[k].vocab_id == (uint32_t)rows[off[inp] + (k - go[i])].vocab_id && gr[k].dist_score == rows[off[inp] + (k - go[i])].dist_score);
+            }
+          }
+        } else {
+          size_t used = 0;
+          char dummy[16];
+          CHECK(anx_batch_gather_compact(b, 0, dummy, sizeof dummy, nullptr, &used) == ANX_EINVAL);  // host-rescored rows have no device export
+        }
         anx_batch_stats st;
         CHECK(anx_batch_get_stats(b, &st, sizeof st) == ANX_OK && st.n_queries == in.size() && (nrep == 3 || st.n_results == off[in.size()]));
         uint32_t* counts = nullptr;

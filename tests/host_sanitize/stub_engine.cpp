@@ -48,7 +48,7 @@ Batch* batch_encode(const HostModel&, const DeviceLexicon* dl, const char* const
   for (size_t i = 0; i < n; ++i) b->in.emplace_back(utf8[i] ? utf8[i] : "");
   return b;
 }
-Batch* batch_encode_spans(const HostModel&, const DeviceLexicon* dl, const char* blob, size_t bytes, const uint32_t* off, size_t n, const anx_params&, std::string& err, int* code, bool) {
+Batch* batch_encode_spans(const HostModel&, const DeviceLexicon* dl, const char* blob, size_t bytes, const uint32_t* off, size_t n, const anx_params&, std::string& err, int* code, bool, bool) {
   if (!dl) { err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr; }
   Batch* b = new Batch();
   if (off) {
@@ -117,6 +117,26 @@ int batch_pair_counts(const HostModel&, const DeviceLexicon*, Batch* b, uint32_t
 }
 int batch_export_topk(const DeviceLexicon*, const Batch*, void*, uint32_t, void*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 int batch_export_compact(const DeviceLexicon*, const Batch*, void*, size_t, void*, size_t*, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
+// the gather behind the C ABI: the fake devices' "device memory" is host memory, the section has the real layout
+size_t batch_compact_bytes(const Batch* b) { return (((b->in.size() + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + (b->ran ? b->rows.size() : 0) * sizeof(anx_topk_record); }
+int batch_gather_compact(const DeviceLexicon* dl, const Batch* b, int, void* dst, size_t capacity, void*, std::string& err) {
+  if (!dl || !b || !b->ran) { err = "stub"; return ANX_ENODEVICE; }
+  if (capacity < batch_compact_bytes(b)) { err = "gather buffer too small"; return ANX_ELIMIT; }
+  const size_t off_bytes = ((b->in.size() + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+  return batch_fetch_compact_into(b, reinterpret_cast<anx_topk_record*>(static_cast<char*>(dst) + off_bytes), static_cast<uint32_t*>(dst), 0, err);
+}
+// search mode's one-pass path: the fake device hands every part back to the classic path (after the host has built its tables)
+struct OnePassState { int unused; };
+int search_onepass_prepare(const DeviceLexicon* dl, const Batch*, Batch*, const OnePassIn&, const anx_search_params&, OnePassState** out, std::string& err) {
+  if (!dl) { err = "stub"; return ANX_ENODEVICE; }
+  *out = new OnePassState{0};
+  return ANX_OK;
+}
+int search_onepass_finish(const HostModel&, const DeviceLexicon*, OnePassState*, const Batch*, const Batch*, OnePassIn&, const anx_search_params&, OnePassOut& out, std::string&) {
+  out.handed_back = true;
+  return ANX_OK;
+}
+void search_onepass_free(OnePassState* s) { delete s; }
 // the fake device hands every lattice back (out_n = 0xFFFFFFFF): search.cpp's host decoder takes them -- the fallback path
 int lattice_decode(const HostModel&, const DeviceLexicon* dl, const LatView&, size_t first, size_t count, const anx_search_params&, uint32_t* out_n, uint32_t*, std::string& err) {
   if (!dl) { err = "stub"; return ANX_ENODEVICE; }

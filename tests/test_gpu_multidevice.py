@@ -221,3 +221,47 @@ def test_conf_fallback_with_an_empty_shard(data_dir):
             for x, y in zip(one["arrays"], got["arrays"]):
                 assert np.array_equal(x, y)
     A.set_switch("ANX_SHARD_POLICY", None)
+
+
+@pytest.mark.parametrize("policy", ["length", "range"])
+def test_gather_compact_behind_the_c_abi(data_dir, policy):
+    """anx_batch_gather_compact: the compact top-k export of every shard of a three-replica batch (replicas on device 0: the pool's boxes
+    have one GPU; a shard on another device would come over by hipMemcpyPeerAsync) in ONE device buffer -- what analiticcl_amd/shard.py
+    gathers with RCCL for one rank per GPU.  Every section (u32 offsets + 16-byte records, in the shard's input order) must hold the rows
+    anx_batch_fetch_compact returns for those inputs; a buffer that is too small is refused with the size it needs."""
+    import torch
+    from analiticcl_amd import shard as SH
+    A.set_switch("ANX_SHARD_MIN", "1")
+    A.set_switch("ANX_SHARD_POLICY", policy)
+    try:
+        g = _model(data_dir, "eng", [0, 0, 0])
+        p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10)
+        words = synth.load_lexicon_words(os.path.join(data_dir, "eng.aspell.lexicon"))
+        qs = synth.make_queries(words, 60_000, max_len=16, seed=19)
+        b = g.encode_batch(qs, p)
+        assert len(b.shards()) == 3
+        b.run()
+        off, rows = b.fetch_compact()
+        small = torch.empty(1024, dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(A.AnxError, match="too small"):
+            b.gather_compact(0, small.data_ptr(), small.numel())
+        buf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda:0")
+        so, used = b.gather_compact(0, buf.data_ptr(), buf.numel())
+        torch.cuda.synchronize()
+        raw = buf[:used].cpu().numpy().tobytes()
+        assert so[-1] == used and len(so) == 4
+        seen = np.zeros(len(qs), dtype=bool)
+        for s, (_dev, lo, cnt) in enumerate(b.shards()):
+            ix = b.shard_inputs(s)
+            ix = np.arange(lo, lo + cnt) if ix is None else ix
+            o = np.frombuffer(raw, dtype="<u4", count=cnt + 1, offset=int(so[s]))
+            r = np.frombuffer(raw, dtype=SH.TOPK_DTYPE, count=int(o[cnt]), offset=int(so[s]) + SH.compact_offsets_bytes(cnt))
+            assert np.array_equal(np.diff(o).astype(np.int64), (off[ix + 1].astype(np.int64) - off[ix].astype(np.int64)))
+            want = np.concatenate([rows[off[i]:off[i + 1]] for i in ix]) if len(ix) else rows[:0]
+            assert np.array_equal(r["vocab_id"], want["vocab_id"]) and np.array_equal(r["dist_score"], want["dist_score"])
+            seen[ix] = True
+        assert seen.all()
+        b.free()
+    finally:
+        A.set_switch("ANX_SHARD_MIN", None)
+        A.set_switch("ANX_SHARD_POLICY", None)
