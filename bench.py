@@ -775,7 +775,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the export + gather code at N=1 too (testing)")
     ap.add_argument("--timed-only", action="store_true", help="skip the passes after the timed region (two-stream overlap, end to end, CPU baseline): for rocprofv3 runs")
-    ap.add_argument("--check-gather", action="store_true", help="rank 0: compare every rank's gathered export of the last step with that rank's fetch()")
+    ap.add_argument("--check-gather", action="store_true", default=True, help="rank 0: compare every rank's gathered export of the last step with that rank's fetch() (default whenever results are gathered)")
+    ap.add_argument("--no-check-gather", dest="check_gather", action="store_false")
     ap.add_argument("--single-process", action="store_true", help="one process, --gpus N replicas behind the C ABI (anx_model_to_devices)")
     ap.add_argument("--replicas-on-one-gpu", action="store_true", help="with --single-process: all replicas on device 0")
     ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="N", help="N ranks, all on device 0 (dry run of the N-rank control flow)")
@@ -1031,6 +1032,10 @@ def main():
                                "step i + 1 was enqueued"}
         del dev_blob
     st = batch.stats()
+    per_rank_ms = [elapsed / max(args.steps, 1) * 1e3]
+    if use_dist and world > 1:  # every rank's own time per step: a first real N-GPU run shows at once which rank is the slow one
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, elapsed / max(args.steps, 1) * 1e3)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(st["n_pairs"]), float(st["n_queries"]), float(st["n_class_tests"])],
                        dtype=torch.float64, device="cuda")
@@ -1120,7 +1125,7 @@ def main():
                             "what": "the same steps with the two resident copies of the batch on two HIP streams (compaction + ranking of one run "
                                     "under the scan of the next), measured after the timed region"} if overlapped else None),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_by_rank": per_rank_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.lexicon}.aspell lexicon + simple.alphabet, {args.queries} synthetic queries "
                                    f"len<={args.max_len} per GPU, k={args.anagram_distance} d={args.edit_distance} n=10 score-threshold 0.25 cutoff 2.0"
