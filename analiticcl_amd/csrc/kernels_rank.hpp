@@ -72,16 +72,34 @@ __global__ __launch_bounds__(COMPACT_B) void k_compact_grouped(const SurvRec* __
     SurvRec sr{0u, 0u, 0.0};
     uint32_t slot = 0, rank = 0;
     bool owner = false;
-    if (live) {
-      sr = surv[(size_t)region * region_cap + i];
-      slot = (sr.q * 2654435761u) >> 21;  // 11 bits
-      for (;;) {
-        const uint32_t prev = atomicCAS(&h_key[slot], 0xFFFFFFFFu, sr.q);
-        if (prev == 0xFFFFFFFFu) { owner = true; break; }
-        if (prev == sr.q) break;
-        slot = (slot + 1u) & (COMPACT_H - 1u);
+    if (live) sr = surv[(size_t)region * region_cap + i];
+    {
+      // The survivors of a query sit next to each other (k_filter_score appends them in pair-list order, a scan tile's queries
+      // one after the other): a RUN of equal queries among neighbouring lanes is inserted by its first lane alone, with the run's
+      // length -- until round 4 every lane did its own compare-and-swap and increment on the run's ONE table word (10 same-address
+      // LDS atomics in a row on BASELINE configs[1]: 56 % of the kernel's LDS cycles were conflicts).
+      const uint32_t lane = threadIdx.x & 63u;
+      const uint32_t qprev = (uint32_t)__shfl_up((int)sr.q, 1);
+      const bool head = live && (lane == 0u || qprev != sr.q);
+      const unsigned long long hm = __ballot(head), lm = __ballot(live);
+      const unsigned long long below = hm & ((2ull << lane) - 1ull);                     // heads at or below this lane
+      const uint32_t start = live ? 63u - (uint32_t)__clzll((long long)below) : 0u;    // (a live lane has a head at or below it)
+      const unsigned long long above = hm & ~((2ull << lane) - 1ull);                    // the next run's head
+      const uint32_t nlive = (uint32_t)__popcll(lm);
+      const uint32_t end = above ? (uint32_t)__ffsll((long long)above) - 1u : nlive;    // (the live lanes are a prefix of the wave)
+      uint32_t base_rank = 0;
+      if (head) {
+        slot = (sr.q * 2654435761u) >> 21;  // 11 bits
+        for (;;) {
+          const uint32_t prev = atomicCAS(&h_key[slot], 0xFFFFFFFFu, sr.q);
+          if (prev == 0xFFFFFFFFu) { owner = true; break; }
+          if (prev == sr.q) break;
+          slot = (slot + 1u) & (COMPACT_H - 1u);
+        }
+        base_rank = atomicAdd(&h_cnt[slot], end - lane);
       }
-      rank = atomicAdd(&h_cnt[slot], 1u);
+      slot = (uint32_t)__shfl((int)slot, (int)start);
+      rank = (uint32_t)__shfl((int)base_rank, (int)start) + (lane - start);
     }
     __syncthreads();
     if (owner) h_base[slot] = atomicAdd(&qcur[sr.q], h_cnt[slot]);  // qcur starts as a copy of soff

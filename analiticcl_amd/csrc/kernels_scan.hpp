@@ -649,13 +649,16 @@ template <int NP, bool BITS, bool GEN, bool ADJ = false>
 __device__ inline void scan_wave(const ScanArgs& A) {
   constexpr int QWORDS = SCAN_TQ * (BITS ? NBITPLANES : NP);
   __shared__ uint32_t s_qlds[4][QWORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][SCAN_STAGE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][ADJ ? 64 * 4 : SCAN_STAGE];  // (tiles that stream a list only keep the chunk's ids)
   // per wave, entries awaiting expansion: bit-plane tiles hit mask u32[SCAN_HITS] + (position in the chunk | pass | flag) u16[SCAN_HITS];
   // count-vector tiles (class | pass << 27, hit mask) pairs
   __shared__ uint32_t s_hits[4][BITS ? SCAN_HITS + SCAN_HITS / 2 : 2 * SCAN_HITS];
   __shared__ uint4 s_qsym[BITS ? 4 : 1][BITS ? SCAN_TQ : 1];     // first 16 symbols of the tile's queries (fused prefilter)
   __shared__ uint32_t s_pbuf[BITS ? 4 : 1][BITS ? SCAN_PBUF : 1];      // dense (entry | query << 26) pairs awaiting the filter / the write
   const uint32_t wid = threadIdx.x >> 6;
+  // (round 5, measured and dropped: persistent waves that stride over the tiles -- 256 x 6 blocks, each wave taking every 6144th tile
+  // of the cost-sorted list -- 1.12 -> 1.42 ms: the hardware's dispatch of one wave per tile in cost order balances the waves, a
+  // static stride does not)
   const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wid));
   if (item >= A.ntiles) return;
   const cptr_u32 tp = (cptr_u32)(A.tiles + item);
@@ -671,7 +674,7 @@ template <bool GEN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_bits(ScanArgs A) { scan_wave<8, true, GEN>(A); }
 // the tiles whose signature has an adjacency list (adjacency.h): a kernel of their own, so that neither path carries the other's registers
 template <bool GEN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_adj(ScanArgs A) { scan_wave<8, true, GEN, true>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scan_adj(ScanArgs A) { scan_wave<8, true, GEN, true>(A); }
 template <int NP>
 __global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false, true>(A); }
 
