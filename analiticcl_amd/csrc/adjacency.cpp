@@ -213,6 +213,7 @@ void build_adjacency(const LexiconImage& img, int closure, size_t budget_bytes, 
   {  // expected records per query of every length (queries drawn like lexicon entries)
     double num[256] = {}, den[256] = {};
     std::vector<double> cnum(64 * 1024, 0.0), cden(64 * 1024, 0.0);
+    out.class_nsig.assign(64 * 1024, 0.0f);
     for (size_t x = 0; x < nk; ++x) {
       if (keys[x].tier != 0) continue;
       const int i = lexsig.find(keys[x].sig);
@@ -226,6 +227,7 @@ void build_adjacency(const LexiconImage& img, int closure, size_t budget_bytes, 
         const size_t c = (size_t)len * 1024 + std::min<size_t>(keys[x].sig & 0xFFu, 31) * 32 + std::min<size_t>((keys[x].sig >> 8) & 0xFFu, 31);
         cnum[c] += e * (double)nrec[x];
         cden[c] += e;
+        out.class_nsig[c] += 1.0f;
       }
     }
     for (int L = 0; L < 256; ++L) out.len_records[L] = den[L] > 0.0 ? num[L] / den[L] : 0.0;

@@ -50,6 +50,7 @@ struct AdjIndex {
   // the same by (length, group sum 0, group sum 1) for lengths < 64, sums clipped to 31: index length * 1024 + sum0 * 32 + sum1 -- the
   // classes the split orders the inputs by; within one length the dense signatures (common letters) meet several times the records
   std::vector<float> class_records;
+  std::vector<float> class_nsig;   // lexicon signatures per class: with the inputs of a class in a batch, how full its scan tiles get
   double build_ms = 0.0;
   AdjIndex() = default;
   AdjIndex(const AdjIndex&) = delete;

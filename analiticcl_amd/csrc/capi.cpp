@@ -83,6 +83,7 @@ struct LengthCost {
   // prior from the signature adjacency lists (anx_model_to_devices): records the scan tests per query of every length, averaged over
   // the lexicon's entries of that length; have_records = false: the window-size prior below
   double records[LMAX] = {};
+  std::vector<float> class_nsig;      // lexicon signatures per split class (tile fill of a batch's class)
   std::vector<float> class_records;   // by split class (length < 64: length * 1024 + group sum 0 * 32 + group sum 1); 0 = no entry there
   bool have_records = false;
   unsigned updates = 0;   // learning steps since the corrections started over
@@ -338,6 +339,7 @@ int anx_model_to_devices(anx_model* m, const int* devices, int n) {
       std::lock_guard<std::mutex> lk(lc.mu);
       for (uint32_t L = 0; L < LengthCost::LMAX; ++L) lc.records[L] = adj->len_records[L];
       lc.class_records = adj->class_records;
+      lc.class_nsig = adj->class_nsig;
       lc.have_records = !adj->hash.empty();
       lc.init = false;  // the corrections were learned against another prior
     }
@@ -925,8 +927,16 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
       if (lc.have_records && c < lc.class_records.size() && lc.class_records[c] > 0.0f && lc.records[L] > 0.0) {
         const int k = anx::clamp_threshold(p.max_anagram_distance, (int)L, anx::kMaxAnagramDistance);
         if (k <= anx::kAdjRadius) {
+          // the class's own records, and how full its scan tiles get in THIS batch: m inputs over the signatures its queries fall on
+          // (about three closure signatures per lexicon signature) -- a tile of few queries pays its set-up (rows x 8 query-tests'
+          // worth, 48 queries share it in a full tile) and its launch (~3.5 ns of device time, 11 600 record tests' worth) alone
+          uint32_t m_c = 0;
+          for (unsigned t = 0; t < T; ++t) m_c += hist[t][c];
+          const double sigs = 3.0 * std::max(1.0, (double)lc.class_nsig[c]);
+          const double fill = std::min(48.0, std::max(1.0, (double)m_c / sigs));
           const double x = std::min(L ? (double)k / (double)L : 0.0, 0.5), f = 0.35 + 15.2 * x * x * x;
-          wc[c] = w[L] * (6500.0 + (double)lc.class_records[c] * f) / (6500.0 + lc.records[L] * f);
+          const double mine = 4300.0 + 11600.0 / fill + (double)lc.class_records[c] * f * (1.0 + 8.0 / fill) / (1.0 + 8.0 / 48.0);
+          wc[c] = w[L] * mine / (6500.0 + lc.records[L] * f);
         }
       }
     }

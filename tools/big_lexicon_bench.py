@@ -29,7 +29,7 @@ tr = (time.time() - t) / 5
 st = b.stats()
 print("encode %.2f s; run %.2f ms per batch of %d queries = %.2f ms per 1M; %.1f G pairs/s; pairs/query %.1f, class tests/query %.0f, slots %d, survivors %d, results %d"
       % (te, tr * 1e3, NQ, tr * 1e3 * 1e6 / NQ, st["n_pairs"] / tr / 1e9, st["n_pairs"] / NQ, st["n_class_tests"] / NQ, st["n_pair_slots"], st["n_survivors"], st["n_results"]))
-print({k: round(st[k], 3) for k in ("ms_scan", "ms_score", "ms_group", "ms_rank", "ms_total", "ms_scan_kernel", "ms_filter_score_kernel")})
+print({k: round(st[k], 3) for k in ("ms_scan", "ms_score", "ms_group", "ms_rank", "ms_total", "ms_scan_kernel", "ms_filter_score_kernel")}, "tiles", st["n_scan_blocks"], "adj tiles", st["n_adj_tiles"], "adj records", st["n_adj_records"], "first", st["n_adj_records_first"])
 if len(sys.argv) > 3 and sys.argv[3] == "nocheck":
     sys.exit(0)
 res = b.fetch()
