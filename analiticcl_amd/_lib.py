@@ -193,6 +193,7 @@ def lib():
         "anx_debug_signature": (C.c_int, [vp, cp, C.POINTER(C.c_uint64)]),
         "anx_debug_entries": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]),
         "anx_debug_adjacency": (C.c_int, [vp, C.c_int, C.c_uint64, vp, C.c_size_t, vp, C.POINTER(C.POINTER(C.c_uint32)), vp]),
+        "anx_debug_adjacency_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.POINTER(C.POINTER(C.c_uint32))]),
         "anx_debug_band_bound": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
         "anx_batch_free": (None, [vp]),
         "anx_device_pool_trim": (None, [C.c_int]),

@@ -330,27 +330,35 @@ int anx_model_to_devices(anx_model* m, const int* devices, int n) {
   anx::EncodeTables et;
   anx::build_encode_tables(m->host.alphabet, et);
   // the signature adjacency lists (adjacency.h): built once per call, uploaded to every replica, not kept on the host
-  std::unique_ptr<anx::AdjIndex> adj;
-  if (anx::switches().scan_adj && m->host.lex.nsym <= 32) {
+  // Default: every replica builds them ON ITS DEVICE from the lexicon tables it has just received (adjacency.hip: milliseconds);
+  // ANX_ADJ_BUILD=host: the host threads build them once (adjacency.cpp, seconds for a large lexicon) and every replica gets a copy.
+  std::unique_ptr<anx::AdjIndex> adj, stats;
+  const bool want_adj = anx::switches().scan_adj && m->host.lex.nsym <= 32;
+  const bool on_device = want_adj && !anx::switches().adj_build_host;
+  if (want_adj && !on_device) {
     adj.reset(new anx::AdjIndex());
     anx::build_adjacency(m->host.lex, anx::switches().adj_closure, (size_t)anx::switches().adj_budget_mb << 20, anx::usable_hw_threads(), *adj);
-    {
-      LengthCost& lc = m->len_cost;
-      std::lock_guard<std::mutex> lk(lc.mu);
-      for (uint32_t L = 0; L < LengthCost::LMAX; ++L) lc.records[L] = adj->len_records[L];
-      lc.class_records = adj->class_records;
-      lc.class_nsig = adj->class_nsig;
-      lc.have_records = !adj->hash.empty();
-      lc.init = false;  // the corrections were learned against another prior
-    }
-    if (getenv("ANX_ADJ_TIMING"))
-      fprintf(stderr, "[anx adjacency] %u lexicon signatures, %u in the closure, %u lists, %llu records in %llu rows (%.1f MB), %.1f ms\n", adj->nsig_lexicon,
-              adj->nsig_closure, adj->nsig_kept, (unsigned long long)adj->records, (unsigned long long)adj->rows, adj->rows * 64.0 * 12.0 / 1e6, adj->build_ms);
   }
+  auto publish = [&](const anx::AdjIndex& a, bool have) {
+    LengthCost& lc = m->len_cost;
+    std::lock_guard<std::mutex> lk(lc.mu);
+    for (uint32_t L = 0; L < LengthCost::LMAX; ++L) lc.records[L] = a.len_records[L];
+    lc.class_records = a.class_records;
+    lc.class_nsig = a.class_nsig;
+    lc.have_records = have;
+    lc.init = false;  // the corrections were learned against another prior
+    if (getenv("ANX_ADJ_TIMING"))
+      fprintf(stderr, "[anx adjacency] %s: %u lexicon signatures, %u in the closure, %u lists, %llu records in %llu rows (%.1f MB), %.1f ms\n", on_device ? "device" : "host",
+              a.nsig_lexicon, a.nsig_closure, a.nsig_kept, (unsigned long long)a.records, (unsigned long long)a.rows, a.rows * 64.0 * 12.0 / 1e6, a.build_ms);
+  };
+  if (adj) publish(*adj, !adj->hash.empty());
   for (int i = 0; i < n; ++i) {
     Replica r;
     r.device = devices[i];
-    r.dev = anx::lexicon_upload(m->host.lex, et, adj.get(), devices[i], err);
+    if (on_device && i == 0) stats.reset(new anx::AdjIndex());
+    r.dev = anx::lexicon_upload(m->host.lex, et, adj.get(), devices[i], err, on_device ? anx::switches().adj_closure : -1, (size_t)anx::switches().adj_budget_mb << 20,
+                                (on_device && i == 0) ? stats.get() : nullptr);
+    if (r.dev && on_device && i == 0) publish(*stats, stats->nsig_kept != 0);
     if (r.dev && n > 1 && !(r.stream = anx::stream_create(devices[i], err))) { anx::lexicon_free(r.dev); r.dev = nullptr; }
     if (!r.dev) { drop_replicas(m); return fail(ANX_ENODEVICE, err); }
     if (n > 1) r.worker.reset(new Worker());
@@ -410,6 +418,13 @@ int anx_debug_adjacency(const anx_model* m, int closure, uint64_t budget_bytes, 
   }
   *out_ids = ids;
   return ANX_OK;
+}
+int anx_debug_adjacency_device(const anx_model* m, const uint64_t* sigs, size_t n, uint32_t* out_cum, uint32_t** out_ids) {
+  if (!m || (!sigs && n) || (!out_cum && n) || !out_ids) return fail(ANX_EINVAL, "NULL argument");
+  if (m->replicas.empty()) return fail(ANX_ENODEVICE, "model is not resident on a device");
+  std::string err;
+  const int rc = anx::adjacency_debug_lists(m->replicas[0].dev, sigs, n, out_cum, out_ids, err);
+  return rc ? fail(rc, err) : ANX_OK;
 }
 int anx_debug_set_switch(const char* name, const char* value) {
   return anx::set_switch(name, value) ? ANX_OK : fail(ANX_EINVAL, "unknown switch");

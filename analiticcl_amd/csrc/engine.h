@@ -14,7 +14,10 @@ struct Batch;          // encoded queries + pipeline buffers + results, HBM-resi
 
 int device_count(std::string& err);
 // adj: the signature adjacency lists of the image (adjacency.h; nullptr = none: every scan tile probes its ball itself)
-DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, const AdjIndex* adj, int device, std::string& err);
+// dev_closure >= 0 (and adj == nullptr): the lists are built ON THE DEVICE (adjacency.hip) for that closure within dev_budget bytes;
+// *dev_stats (may be nullptr) receives what the host builder reports (counts and the statistics of the length split)
+DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, const AdjIndex* adj, int device, std::string& err, int dev_closure = -1,
+                              size_t dev_budget = 0, AdjIndex* dev_stats = nullptr);
 void lexicon_free(DeviceLexicon*);
 // test hook: the band-match bound of the scan / scoring kernels on n (query row, candidate row) pairs (engine.hip k_debug_band_bound)
 int debug_band_bound(int device, const uint8_t* q_rows, const uint8_t* c_rows, const uint8_t* lq, const uint8_t* lc, size_t n, int d, int form,
@@ -71,6 +74,8 @@ int batch_export_compact(const DeviceLexicon* dl, const Batch* b, void* dst, siz
 // devices see each other, staged through the host otherwise); returns when the bytes are at their destination
 size_t batch_compact_bytes(const Batch* b);
 int batch_gather_compact(const DeviceLexicon* dl, const Batch* b, int dst_device, void* dst, size_t capacity, void* stream, std::string& err);
+// test hook (adjacency.hip): the adjacency lists of the given signatures as the replica holds them
+int adjacency_debug_lists(const DeviceLexicon* d, const uint64_t* sigs, size_t n, uint32_t* out_cum, uint32_t** out_ids, std::string& err);
 void batch_stats(const Batch* b, anx_batch_stats* s);
 
 // ---- search mode's lattice decoding on the device (lattice.hip) ------------------------------------------------------------------
@@ -150,6 +155,7 @@ struct OnePassState;
 int search_onepass_prepare(const DeviceLexicon* dl, const Batch* bu, Batch* bh, const OnePassIn& in, const anx_search_params& p, OnePassState** out, std::string& err);
 int search_onepass_finish(const HostModel& m, const DeviceLexicon* dl, OnePassState* s, const Batch* bu, const Batch* bh, OnePassIn& in, const anx_search_params& p,
                           OnePassOut& out, std::string& err);
+int search_onepass_rows_wait(OnePassState* s, std::string& err);  // the row array of search_onepass_finish is complete
 void search_onepass_free(OnePassState*);
 
 }  // namespace anx

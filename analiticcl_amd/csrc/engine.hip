@@ -332,7 +332,8 @@ static int dalloc(T** dst, size_t count, std::string& err) {
   return ANX_OK;
 }
 
-DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, const AdjIndex* adj, int device, std::string& err) {
+DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, const AdjIndex* adj, int device, std::string& err, int dev_closure, size_t dev_budget,
+                              AdjIndex* dev_stats) {
   DeviceGuard guard;
   int n = device_count(err);
   if (n <= 0) {
@@ -478,8 +479,15 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, c
       return nullptr;
     }
     d->adj_mask = adj->hash_mask;
+    d->adj_nhdr = (uint32_t)adj->hdr.size();
     d->adj_hash_host = adj->hash;
     d->adj_hdr_host = adj->hdr;
+  } else if (!adj && dev_closure >= 0 && img.nsym <= 32) {  // built here, on the device, from the tables just uploaded (adjacency.hip)
+    AdjIndex local;
+    if ((rc = adjacency_build_device(d, img, dev_closure, dev_budget, dev_stats ? *dev_stats : local, err))) {
+      lexicon_free(d);
+      return nullptr;
+    }
   }
   return d;
 }
@@ -735,6 +743,10 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
     const uint32_t nsplit = (sad && !balln) ? 8u : 1u;
     const uint32_t step = (((s1 - s0) + nsplit - 1) / nsplit + 63u) & ~63u;
     uint32_t adj = 0;  // the signature's adjacency list (adjacency.h), as the device encoder's adj_lookup finds it
+    if (!sad && k <= (uint32_t)kAdjRadius && switches().scan_adj && dl->adj_mask && dl->adj_hash_host.empty()) {
+      const int rca = adjacency_host_copies(dl, err);  // (lists built on the device: the table comes down once)
+      if (rca) return rca;
+    }
     if (!sad && k <= (uint32_t)kAdjRadius && switches().scan_adj && !dl->adj_hash_host.empty()) {
       uint32_t h = sig_hash((uint32_t)h_sig[i], (uint32_t)(h_sig[i] >> 32)) & dl->adj_mask;
       for (int pr = 0; pr < 17; ++pr) {

@@ -32,6 +32,9 @@ void encoder_stream_release(int device, hipStream_t s);
 struct DeviceConf;
 void conf_free(DeviceConf*);
 int conf_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, hipStream_t st, bool early, uint32_t row_cap, std::string& err);
+// the signature adjacency lists built on the device (adjacency.hip); host copies of its table and headers for the host encoder
+int adjacency_build_device(DeviceLexicon* d, const LexiconImage& img, int closure, size_t budget_bytes, AdjIndex& stats, std::string& err);
+int adjacency_host_copies(const DeviceLexicon* d, std::string& err);
 // search mode's LM tables of a replica (lattice.hip)
 struct DeviceLm;
 void lm_free(DeviceLm*);

@@ -71,6 +71,7 @@ struct Switches {
   int scan_walk_flat = 0;    // ANX_SCAN_WALK=flat: window walk instead of the hash-probed ball
   int scan_tq = 0;           // ANX_SCAN_TQ=1..64: queries per scan tile (0 = default)
   int scan_adj = 1;          // ANX_SCAN_ADJ=0: no signature adjacency lists (adjacency.h): every tile walks / probes its ball itself (A/B reference)
+  int adj_build_host = 0;    // ANX_ADJ_BUILD=host: the lists are built by the host threads and uploaded (adjacency.cpp: the reference of the device builder)
   int adj_closure = 2;       // ANX_ADJ_CLOSURE=0..2: lists for the signatures within this distance of a lexicon signature (models put on a device afterwards)
   long adj_budget_mb = 16384; // ANX_ADJ_MB: most HBM the lists may take per replica (16 GB of 288: every list of the closure of a 1 M-entry lexicon, 12.8 GB)
   int sig_groups = 0;        // ANX_SIG_GROUPS=1..8: signature groups of a model built afterwards (0 = default)

@@ -76,8 +76,9 @@ struct DeviceLexicon {
   uint32_t* adj_hdr = nullptr;     // [lists][8] {first row, cumulative rows of the 7 length sections}
   uint2* adj_planes = nullptr;     // [rows * 64] {plane 1, plane 2}
   uint32_t* adj_ids = nullptr;     // [rows * 64] entry ids (padding: nentries)
-  std::vector<AdjSlot> adj_hash_host;  // host copies for the host encoder (ANX_ENCODE=host)
-  std::vector<AdjHdr> adj_hdr_host;
+  uint32_t adj_nhdr = 0;           // lists
+  mutable std::vector<AdjSlot> adj_hash_host;  // host copies for the host encoder (ANX_ENCODE=host): adjacency_host_copies, on first use
+  mutable std::vector<AdjHdr> adj_hdr_host;
   uint4* sig = nullptr;            // [nsig_pad] signature table (see LexiconImage): {groups 0-3, groups 4-7, first class of the run, classes}
   uint32_t* sig_cbeg = nullptr;    // [nsig_pad+1]
   uint32_t* ent_vocab = nullptr;

@@ -958,9 +958,14 @@ int search_onepass_finish(const HostModel& m, const DeviceLexicon* dl, OnePassSt
   out.n_rows = total_rows;
   out.rows = static_cast<anx_result*>(host_result_alloc(std::max<size_t>(total_rows, 1) * sizeof(anx_result)));
   if (!out.rows) { err = "out of memory"; return ANX_EINVAL; }
+  // the rows are on their way when this returns: the caller builds its matches from the small arrays meanwhile and calls
+  // search_onepass_rows_wait before it reads a row
   if (total_rows) HIP_TRY(hipMemcpyAsync(out.rows, a.e_rows, total_rows * sizeof(anx_result), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  lap("rows download");
+  if (timing) { HIP_TRY(hipStreamSynchronize(st)); lap("rows download"); }
+  return ANX_OK;
+}
+int search_onepass_rows_wait(OnePassState* S, std::string& err) {
+  HIP_TRY(hipStreamSynchronize(S->st));
   return ANX_OK;
 }
 

@@ -1217,6 +1217,8 @@ static int onepass_part(const anx_model* model, const HostModel& m, const char* 
     }
   });
   for (size_t si = 0; si < NS; ++si) if (!has_lat[si]) done[si] = 1;  // (no matches: checked above)
+  rc = anx::search_onepass_rows_wait(stp, err);  // the rows came down under the loop above (the views only point at them)
+  if (rc != ANX_OK) return anx_fail(rc, err);
   lap("one pass: output");
   return ANX_OK;
 }

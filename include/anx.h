@@ -346,6 +346,9 @@ int anx_debug_signature(const anx_model *, const char *utf8, uint64_t *out_sig);
 int anx_debug_entries(const anx_model *, uint32_t **out_vocab_ids, size_t *n);
 int anx_debug_adjacency(const anx_model *, int closure, uint64_t budget_bytes, const uint64_t *sigs, size_t n, uint32_t *out_cum,
                         uint32_t **out_ids, uint64_t *out_stats);
+/* The same lists as the model's first replica HOLDS them (built on the device by default, analiticcl_amd/csrc/adjacency.hip): out_cum /
+ * out_ids as anx_debug_adjacency (the order of the ids inside a section is the builder's own). */
+int anx_debug_adjacency_device(const anx_model *, const uint64_t *sigs, size_t n, uint32_t *out_cum, uint32_t **out_ids);
 /* Test hook: the band-match bound the scan's fused filter and k_filter_score apply before damerau_levenshtein (src/distance.rs:101-179)
  * on n (query, candidate) pairs of <= 16 symbols: rows of 16 bytes (alphabet-indexed symbols, the query padded with 0xFE, the
  * candidate with 0xFF), lengths, d <= 3.  form: 0 the scan's (7-bit symbols, wave-uniform d), 1 k_filter_score's (7-bit symbols),

@@ -21,7 +21,7 @@ static bool fake() { const char* e = getenv("ANX_STUB_FAKE"); return e && e[0] =
 static uint64_t fnv(const std::string& s) { uint64_t h = 1469598103934665603ull; for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; } return h; }
 
 int device_count(std::string& err) { if (fake()) return 4; err = "stub: no device"; return 0; }
-DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, const AdjIndex*, int device, std::string& err) {
+DeviceLexicon* lexicon_upload(const LexiconImage&, const EncodeTables&, const AdjIndex*, int device, std::string& err, int, size_t, AdjIndex*) {
   if (!fake()) { err = "stub: no device"; return nullptr; }
   if (device < 0 || device >= 4) { err = "stub: invalid device ordinal"; return nullptr; }
   return new DeviceLexicon{device};
@@ -136,6 +136,7 @@ int search_onepass_finish(const HostModel&, const DeviceLexicon*, OnePassState*,
   out.handed_back = true;
   return ANX_OK;
 }
+int search_onepass_rows_wait(OnePassState*, std::string&) { return ANX_OK; }
 void search_onepass_free(OnePassState* s) { delete s; }
 // the fake device hands every lattice back (out_n = 0xFFFFFFFF): search.cpp's host decoder takes them -- the fallback path
 int lattice_decode(const HostModel&, const DeviceLexicon* dl, const LatView&, size_t first, size_t count, const anx_search_params&, uint32_t* out_n, uint32_t*, std::string& err) {
@@ -143,6 +144,7 @@ int lattice_decode(const HostModel&, const DeviceLexicon* dl, const LatView&, si
   for (size_t i = first; i < first + count; ++i) out_n[i] = 0xFFFFFFFFu;
   return ANX_OK;
 }
+int adjacency_debug_lists(const DeviceLexicon*, const uint64_t*, size_t, uint32_t*, uint32_t**, std::string& err) { err = "stub"; return ANX_ENODEVICE; }
 void batch_stats(const Batch* b, anx_batch_stats* s) { memset(s, 0, sizeof *s); if (b) { s->n_queries = b->in.size(); s->n_results = b->rows.size(); s->ms_total = 1.0f; } }
 void batch_free(Batch* b) { delete b; }
 }  // namespace anx
