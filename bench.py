@@ -519,59 +519,40 @@ def extra_configs(args, paths, device, ncores):
         om.build()
         chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
         b.free()
-        # The same job cut the way a multi-device model cuts it (anx_model_to_devices: length-partitioned split, cost-balanced): ONE of
-        # the 8 shares of the 10 M-query job -- every query of the lengths that share owns -- run on this GPU.  The lengths come from
-        # the library's own split of a 1 M sample of the job (anx_debug_length_split, 8 shards), scaled by 10; the queries from the
-        # job's generator conditioned on their length (synth.make_queries_with_quota).
+        # The WHOLE 10 M-query job cut the way a multi-device model cuts it (anx_model_to_devices: length-partitioned split into 8
+        # cost-balanced shares, anx_debug_length_split), every share run on this one GPU one after the other: the longest share is
+        # what an 8-GPU job takes.  Round 0 = the FIRST call (the split's prior alone: records per query of every (length, signature
+        # class) from the adjacency lists, fill of the scan tiles); round 1 = the next call, after the split's cost model has seen
+        # the shares' device times.  Same methodology as tools/length_shares.py (which runs more rounds and prints every share).
         import numpy as np
-        sample = synth.make_queries(lex, 1_000_000, max_len=32, min_len=4, seed=6)
-        # the split learns what a query of every length costs from the device times of its shards (capi.cpp LengthCost): three
-        # rounds on the sample's own 8 shares, run one after the other on this GPU, stand in for the first calls of an 8-GPU job
-        share_ms = []
-        balance_by_round, longest_by_round = [], []
-        for _round in range(4):
-            gid = m.length_split(sample, p, 8)
-            share_ms = []
+        job = synth.make_queries(lex, 10_000_000, max_len=32, min_len=4, seed=6)
+        rounds = []
+        for _round in range(2):
+            gid = m.length_split(job, p, 8)
+            share_ms, share_n = [], []
             for g_ in range(8):
-                bs = m.encode_batch([q for q, s_ in zip(sample, gid) if s_ == g_], p)
+                ix = np.nonzero(gid == g_)[0]
+                bs = m.encode_batch([job[i] for i in ix], p)
                 share_ms.append(_time_runs(bs, reps=2) * 1e3)
+                share_n.append(int(ix.size))
                 bs.free()
-            balance_by_round.append(sum(share_ms) / 8 / max(share_ms))
-            longest_by_round.append(max(share_ms))
-            if _round < 3:
-                m.length_split(sample, p, 8, learn_ms=share_ms)
-        share = int(np.argmax(share_ms))   # the share that takes longest decides the job's time
-        quota = {}
-        for q, g_ in zip(sample, gid):
-            if g_ == share:
-                quota[len(q)] = quota.get(len(q), 0) + 10
-        qs2 = synth.make_queries_with_quota(lex, quota, max_len=32, min_len=4, seed=7)
-        qs2.sort(key=len)
-        b2 = m.encode_batch(qs2, p)
-        dt2 = _time_runs(b2, reps=3)
-        st2 = b2.stats()
-        chk2 = _spot_check(m, om, qs2, b2.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
-        b2.free()
+            rounds.append({"share_ms": share_ms, "share_queries": share_n, "sum_ms": sum(share_ms), "longest_share_ms": max(share_ms),
+                           "balance": sum(share_ms) / 8 / max(share_ms)})
+            if _round == 0:
+                m.length_split(job, p, 8, learn_ms=share_ms)
+        del job
         os.unlink(path)
-        shares = [int((gid == g_).sum()) for g_ in range(8)]
         return {"workload": "BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon, 1.25 M of the 10 M length-bucketed queries len 4-32, k=3 d=2 n=10",
                 "ms_per_batch": dt * 1e3, "ms_per_1M_queries": dt * 1e3 / 1.25, "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt,
                 "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "scan_tiles": st["n_scan_blocks"], "parity": chk,
                 "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000, profile_key="big"),
                 "what": "ms_per_1M_queries = a RANDOM eighth of the job (what consecutive input ranges give a GPU: an eighth of every (length, signature) group); "
-                        "by_length = one share of the length-partitioned split the library uses for multi-device models",
-                "by_length": {"workload": f"the longest of the 8 shares of the 10 M-query job under the length-partitioned split (share {share}: the queries of lengths {min(quota)}-{max(quota)} it owns), "
-                                          "after three learning rounds of the split's cost model on a 1 M-query sample of the job",
-                              "sample_share_ms": share_ms, "sample_balance": sum(share_ms) / 8 / max(share_ms),
-                              # round 0 = the FIRST call of a job: the split's prior alone (records per query of every length, from the
-                              # adjacency lists), no measured correction yet; the later rounds have learned from the shards' device times
-                              "first_call_balance": balance_by_round[0], "balance_by_round": balance_by_round, "longest_share_ms_by_round": longest_by_round,
-                              "job_speedup_vs_consecutive_ranges": dt / dt2,
-                              "queries": len(qs2), "ms_per_batch": dt2 * 1e3, "ms_per_1M_queries": dt2 * 1e3 / (len(qs2) / 1e6), "pairs_per_s": st2["n_pairs"] / dt2,
-                              "scan_kernel_ms": st2["ms_scan_kernel"], "filter_score_kernel_ms": st2["ms_filter_score_kernel"], "scan_tiles": st2["n_scan_blocks"],
-                              "queries_per_tile": len(qs2) / max(st2["n_scan_blocks"], 1), "parity": chk2,
-                              "shares_of_1M_sample": shares,
-                              "roofline": _config_roofline(m, qs2, st2, dt2 * 1e3, "big", 32, 2, len(qs2))}}
+                        "by_length = the 8 shares of the whole job under the length-partitioned split the library uses for multi-device models",
+                "by_length": {"workload": "the whole 10 M-query job as the 8 shares of the length-partitioned split, run one after the other on this GPU (tools/length_shares.py's methodology)",
+                              "first_call_balance": rounds[0]["balance"], "first_call_longest_share_ms": rounds[0]["longest_share_ms"],
+                              "second_call_balance": rounds[1]["balance"], "second_call_longest_share_ms": rounds[1]["longest_share_ms"],
+                              "whole_job_sum_ms": rounds[1]["sum_ms"], "job_speedup_vs_consecutive_ranges": dt * 1e3 / rounds[1]["longest_share_ms"],
+                              "rounds": rounds}}
 
     def configs4_share():  # search mode: one GPU's 12.5 MB of the 100 MB running text, n-gram windows + bigram LM
         import random

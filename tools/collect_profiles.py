@@ -16,7 +16,7 @@ for name, blk in blocks():
     f, w, va, g, vi, si = (val(blk, c) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"))
     if f is not None and w is not None:
         kern[name] = {"fetch_kb": f, "write_kb": w, "traffic_bytes": int((2 * f + w) * 1024)}
-    if va and g and name in ("k_scan_bits", "k_filter_score", "k_rank", "k_compact", "k_compact_grouped"):
+    if va and g and name in ("k_scan_adj", "k_scan_bits", "k_filter_score", "k_rank", "k_compact", "k_compact_grouped"):
         lines.append(f"# {name}: VALU-active = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = {va*4/(g/8*1024)*100:.0f} %; "
                      f"{vi/1e6:.0f} M VALU + {si/1e6:.0f} M SALU wave-instructions; HBM traffic 2*{f/1024:.0f} MiB + {w/1024:.0f} MiB = {(2*f+w)*1024/1e9:.2f} GB per launch")
 hdr = (f"# Round {int(TAG[1:])} final -- rocprofv3 --pmc passes (separate runs, --kernel-trace only), python3 bench.py --steps 2 --warmup 1 --timed-only --no-overlap (every kernel alone on the GPU)\n"
@@ -27,9 +27,22 @@ open(os.path.join(R, "profiles", f"{TAG}_final_pmc.md"), "w").write(hdr + pmc)
 sha = hashlib.sha256()
 for f in sorted(glob.glob(os.path.join(R, "analiticcl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(R, "analiticcl_amd", "csrc", "*.hpp"))):
     sha.update(open(f, "rb").read())
-json.dump({"kernel_src_sha256": sha.hexdigest(), "source": f"profiles/{TAG}_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py config 2, 1M queries)",
+# the other configurations: HBM bytes per launch of every kernel of their PMC passes (tools/measure_configs.sh), keyed as bench.py asks
+cfg = {}
+for name in ("conf", "big", "search"):
+    src = os.path.join(M, f"{name}_pmc.md")
+    if not os.path.exists(src):
+        continue
+    body = open(src).read()
+    ent = {}
+    for kname, blk in re.findall(r"## (k_[a-z_0-9]+):.*?\n(.*?)\n\n", body + "\n\n", re.S):
+        f, w = val(blk, "FETCH_SIZE"), val(blk, "WRITE_SIZE")
+        if f is not None and w is not None:
+            ent[kname] = {"fetch_kb": f, "write_kb": w, "traffic_bytes": int((2 * f + w) * 1024)}
+    cfg[name] = ent
+json.dump({"kernel_src_sha256": sha.hexdigest(), "source": f"profiles/{TAG}_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py configs[1], 1M queries); configs: profiles/{TAG}_{{conf,big,search}}_pmc.md",
            "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024; the x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (calibrated there for 16 B/lane streams; narrower loads make the read side an upper bound)",
-           "kernels": kern}, open(os.path.join(R, "profiles", f"{TAG}_pmc_traffic.json"), "w"), indent=1)
+           "kernels": kern, "configs": cfg}, open(os.path.join(R, "profiles", f"{TAG}_pmc_traffic.json"), "w"), indent=1)
 kt = open(os.path.join(M, "kernel_trace.md")).read()
 open(os.path.join(R, "profiles", f"{TAG}_final_kernel_trace.md"), "w").write(
     f"# Round {int(TAG[1:])} final -- rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --timed-only --no-overlap (7 runs of the pipeline, every kernel alone on the GPU; tools/measure_round.sh)\n"
@@ -48,7 +61,14 @@ for name, what in (("conf", "BASELINE configs[2]: tools/conf_probe.py 1000000 (n
             if kind == "pmc":   # lanes active per vector instruction of the kernels that matter
                 for kname, blk in re.findall(r"## (k_[a-z_0-9]+):.*?\n(.*?)\n\n", body + "\n\n", re.S):
                     tc, vi = val(blk, "SQ_THREAD_CYCLES_VALU"), val(blk, "SQ_INSTS_VALU")
-                    if tc and vi and kname in ("k_conf_script", "k_lattice", "k_scan_bits", "k_filter_score"):
+                    if tc and vi and kname in ("k_conf_script", "k_lattice", "k_scan_adj", "k_scan_bits", "k_filter_score"):
                         body = f"# {kname}: SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = {tc / vi:.1f} (lanes active per vector instruction; a kernel with every lane busy reads ~64)\n" + body
             open(os.path.join(R, "profiles", f"{TAG}_{name}_{kind}.md"), "w").write(
                 f"# Round {int(TAG[1:])} -- {hdr2} -- {what}; ANX_RUN_OVERLAP=0 (tools/measure_configs.sh)\n\n" + body)
+
+# the single-part search trace (tools/trace_cmd.sh lat1 with ANX_SEARCH_PARTS=1): k_lattice alone on the device
+src = os.path.join(M, "trace_lat1.md")
+if os.path.exists(src) and os.path.getsize(src) > 0:
+    open(os.path.join(R, "profiles", f"{TAG}_search_single_part_kernel_trace.md"), "w").write(
+        f"# Round {int(TAG[1:])} -- rocprofv3 --kernel-trace --stats -- tools/search_bench.py 12.5 with ANX_SEARCH_PARTS=1 (the whole 12.5 MB as ONE part: every kernel of the call alone "
+        "on the device; k_lattice: total ms / calls = ms per 12.5 MB call, the bench makes 5 calls incl. the Python-level one)\n\n" + open(src).read())
