@@ -78,6 +78,10 @@ def test_occupancy_of_the_dominant_kernels(kernels):
     # registers: 28 SGPRs spilled into VGPR lanes cost the hot loops 0.05 ms of the kernel's 1.60 (v_readlane / v_writelane + hazards)
     prod = [r for n, r in kernels.items() if "k_scan_bitsILb0" in n]
     assert prod and all(r["sgpr_spill_count"] <= 8 for r in prod), prod
+    # round 5: k_scan_adj (the tiles that stream an adjacency list: 99 % of them) runs at 6 waves per SIMD -- <= 80 VGPRs (and 26.6 KB
+    # of LDS per block) -- and keeps its scalar state in registers in BOTH instances (the StopAtExactMatch / pair-count one too)
+    adj = [r for n, r in kernels.items() if "k_scan_adj" in n]
+    assert len(adj) == 2 and all(r["vgpr_count"] <= 80 and r["sgpr_spill_count"] == 0 for r in adj), adj
     # round 4: the instance of k_rank for models without variant lists at freq_weight 0 (what every BASELINE configuration runs)
     simple = [r for n, r in kernels.items() if "k_rankILb1" in n]
     assert simple and all(r["sgpr_spill_count"] == 0 and r["vgpr_count"] <= 72 for r in simple), simple
