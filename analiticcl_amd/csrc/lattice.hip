@@ -133,6 +133,21 @@ __device__ inline uint32_t group_min_u32(uint32_t v) {
   return v;
 }
 
+template <uint32_t G>
+__device__ inline uint32_t group_sum_u32(uint32_t v) {  // the same butterfly with adds: after the four rotations every lane of a row holds the row's sum
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+  const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = (uint32_t)r16[0] + (uint32_t)r16[1];
+  if (G == 64) {
+    const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = (uint32_t)r32[0] + (uint32_t)r32[1];
+  }
+  return v;
+}
+
 // G lanes per stretch: G = 64 one stretch per wave (states with up to 128 incoming arcs, two candidate heads per lane); G = 32 two
 // stretches per wave, side by side in its halves (up to 64 incoming arcs per state: the common case -- ~30 on the bench's text): the
 // wave-wide minimum, the ballot and the bookkeeping of a pop then serve two lattices.  The host pairs stretches of similar size.
@@ -178,10 +193,6 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     s_ring[0] = 0.0f;
   }
   __syncthreads();
-  // the lanes of this lane's group below it, as masks over the two halves of a wave-wide ballot
-  const uint32_t below = gl >= 32u ? 0xFFFFFFFFu : ((1u << (gl & 31u)) - 1u);
-  const uint32_t blo = G == 64 ? below : (grp ? 0u : below);
-  const uint32_t bhi = G == 64 ? (gl >= 32u ? (1u << (gl - 32u)) - 1u : 0u) : (grp ? below : 0u);
   for (uint32_t d = 1; d < nsmax; ++d) {
     const bool act = alive && d < ns;
     const uint32_t a0 = act ? ioff[d] : 0u, indeg = act ? ioff[d + 1] - a0 : 0u;
@@ -201,51 +212,65 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         ac[w] = arc.cost;
         hn[w] = s_cnt[arc.src];
         ho[w] = (arc.src % ring) * K;
-        if (hn[w]) { hc[w] = __float_as_uint(s_ring[ho[w]] + arc.cost); hx[w] = s_ring[ho[w] + (hn[w] > 1u ? 1u : 0u)]; }
+        // (hx of a one-element list is the word behind it -- the next list, or the (arc, rank) array behind the rings: inside the
+        // wave's LDS either way, and never used)
+        if (hn[w]) { hc[w] = __float_as_uint(s_ring[ho[w]] + arc.cost); hx[w] = s_ring[ho[w] + 1u]; }
       }
     }
-    uint32_t count = 0;       // group-uniform
+    // Pops of this state: K, or every candidate when the lists hold fewer -- known up front (group-uniform), so the loop counts in a
+    // scalar register and the pop number is the place in the state's list.
+    const uint32_t count = min(K, group_sum_u32<G>(hn[0] + hn[1]));
+    uint32_t itmax_v = count;
+#pragma unroll
+    for (int o = 32; o >= (int)G && o < 64; o >>= 1) itmax_v = max(itmax_v, (uint32_t)__shfl_xor((int)itmax_v, o));
+    const uint32_t itmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)itmax_v);
     const bool two = __any(indeg > G);  // wave-uniform: some group of the wave uses its second heads
-    // K pops (or until every list of the group is exhausted).  A pop: the smallest cost (bit pattern of a non-negative float) over
-    // the group's heads, then the smallest arc among the heads that have it -- arcs 0 .. G-1 (first heads, by lane) precede arcs
-    // G .. 2G-1 (second heads); the winning lane notes (arc, rank) and the cost, and moves its head up.  TWO = false (no state of
-    // the wave has more than G incoming arcs: the common case) compiles the loop without the second heads; its winner is the lane
-    // that has the minimum and no such lane below it in its group (blo / bhi: the lanes of the group below this one).
-    // The minimum of the NEXT pop is taken at the end of the loop body, behind the winner's LDS read: the read is waited for after
-    // that minimum, not before it.
-    auto move_up = [&](int w, uint32_t arc_index) {
-      s_par[count] = (arc_index << 16) | hr[w];
-      if (++hr[w] < hn[w]) { hc[w] = __float_as_uint(hx[w] + ac[w]); hx[w] = s_ring[ho[w] + (hr[w] + 1u < hn[w] ? hr[w] + 1u : hr[w])]; }
-      else hc[w] = 0xFFFFFFFFu;
+    // A pop: the smallest cost (bit pattern of a non-negative float) over the group's heads, then the smallest arc among the heads
+    // that have it -- arcs 0 .. G-1 (first heads, by lane) precede arcs G .. 2G-1 (second heads); the winning lane notes (arc, rank)
+    // and the cost, and moves its head up.  TWO = false (no state of the wave has more than G incoming arcs: the common case)
+    // compiles the loop without the second heads.
+    // The kernel is bound by the instructions of this loop (a wave-wide vector instruction occupies its SIMD for 4 cycles; the 3-4
+    // waves of a SIMD keep it busy): round 5 took it from ~33 vector instructions per pop to ~17 --
+    //   * the winner is found in SCALAR registers: the compare writes a lane mask, the lowest set bit of each group's part of it
+    //     (x & -x) IS the winner's lane, and that mask becomes EXEC (no per-lane "is a lane below me equal" arithmetic, no ballot
+    //     round trip through a vector register);
+    //   * the minimum is clamped to 0xFFFFFFFE: an exhausted head (0xFFFFFFFF) never equals it, so there is no "anything left" test;
+    //   * the winner's update is branch-free (the new head cost is selected, the read of the cost after it runs one word past a
+    //     list's end at worst), and the pop number is the loop counter.
+    const uint32_t arcw[2] = {gl << 16, (gl + G) << 16};
+    auto move_up = [&](int w, uint32_t it, uint32_t best) {
+      const uint32_t rank = hr[w];
+      // the sum first ("memory": the read below may not move above it): the read then lands in hx's own register -- scheduled ahead of
+      // the sum it went to a temporary, and the copy into hx waited for it in the same pop
+      float nx;
+      asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(nx) : "v"(hx[w]), "v"(ac[w]) : "memory");
+      hx[w] = s_ring[ho[w] + rank + 2u];
+      s_par[it] = arcw[w] | rank;
+      mine[it] = __uint_as_float(best);
+      hr[w] = rank + 1u;
+      hc[w] = rank + 1u < hn[w] ? __float_as_uint(nx) : 0xFFFFFFFFu;
     };
+    auto lowbit = [](uint32_t x) { return x & (0u - x); };
     auto pops = [&](auto two_c) {
       constexpr bool TWO = decltype(two_c)::value;
-      uint32_t best = group_min_u32<G>(TWO ? min(hc[0], hc[1]) : hc[0]);
-      for (;;) {
-        const bool live = best != 0xFFFFFFFFu && count < K;  // group-uniform (groups without an active state have no heads)
-        const bool eq0 = live && hc[0] == best;
-        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(eq0);
-        if (!TWO) {
-          if (m0 == 0ull) break;  // wave-uniform: no group has anything left to pop
-          if (eq0 && (((uint32_t)m0 & blo) | ((uint32_t)(m0 >> 32) & bhi)) == 0u) {
-            move_up(0, gl);
-            mine[count] = __uint_as_float(best);
-          }
+      for (uint32_t it = 0; it < itmax; ++it) {
+        const uint32_t best = min(group_min_u32<G>(TWO ? min(hc[0], hc[1]) : hc[0]), 0xFFFFFFFEu);
+        const unsigned long long m0 = __builtin_amdgcn_uicmp(hc[0], best, 32 /* == */);
+        unsigned long long w0, w1 = 0ull;
+        if (G == 64) {
+          w0 = m0 & (0ull - m0);
+          if (TWO) { const unsigned long long m1 = __builtin_amdgcn_uicmp(hc[1], best, 32); w1 = m0 ? 0ull : (m1 & (0ull - m1)); }
         } else {
-          const bool eq1 = live && hc[1] == best;
-          const unsigned long long m1 = __builtin_amdgcn_ballot_w64(eq1);
-          if ((m0 | m1) == 0ull) break;
-          const bool none0 = (G == 64 ? m0 : (unsigned long long)(grp ? (uint32_t)(m0 >> 32) : (uint32_t)m0)) == 0ull;  // no first head of the group has it
-          if (eq0 && (((uint32_t)m0 & blo) | ((uint32_t)(m0 >> 32) & bhi)) == 0u) {
-            move_up(0, gl);
-            mine[count] = __uint_as_float(best);
-          } else if (none0 && eq1 && (((uint32_t)m1 & blo) | ((uint32_t)(m1 >> 32) & bhi)) == 0u) {
-            move_up(1, gl + G);
-            mine[count] = __uint_as_float(best);
+          const uint32_t l0 = (uint32_t)m0, h0 = (uint32_t)(m0 >> 32);
+          w0 = (unsigned long long)lowbit(l0) | ((unsigned long long)lowbit(h0) << 32);
+          if (TWO) {
+            const unsigned long long m1 = __builtin_amdgcn_uicmp(hc[1], best, 32);
+            const uint32_t l1 = l0 ? 0u : (uint32_t)m1, h1 = h0 ? 0u : (uint32_t)(m1 >> 32);  // a group's second heads only when none of its first heads has it
+            w1 = (unsigned long long)lowbit(l1) | ((unsigned long long)lowbit(h1) << 32);
           }
         }
-        if (live) ++count;
-        best = group_min_u32<G>(TWO ? min(hc[0], hc[1]) : hc[0]);
+        if (__builtin_amdgcn_inverse_ballot_w64(w0)) move_up(0, it, best);
+        if (TWO && __builtin_amdgcn_inverse_ballot_w64(w1)) move_up(1, it, best);
       }
     };
     if (two) pops(std::true_type{}); else pops(std::false_type{});

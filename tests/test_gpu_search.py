@@ -585,3 +585,45 @@ def test_one_device_pass_equals_the_classic_path(data_dir):
             for x, y in zip(out["onepass"], out["classic"]):
                 assert np.array_equal(x, y), (variant, kw)
             assert out["onepass"][1].size > 20_000
+
+
+@pytest.mark.gpu
+def test_lattice_kernel_equals_the_host_decoder_for_every_k(data_dir):
+    """k_lattice's K best paths into a state (rustfst shortest_path(nshortest = max_seq), /root/reference/src/lib.rs:2288-2317) against
+    the host decoder (ANX_LATTICE=host): every output array identical, for K below / at / above the number of candidate paths and
+    around the number of list costs a head keeps in registers (max_seq 1, 2, 3, 7, 8, 9, 10, 17, 64, 250, 1000), with and without a
+    language model, on text with long and short stretches."""
+    import random
+    import numpy as np
+    lex = os.path.join(data_dir, "eng.aspell.lexicon")
+    words = synth.load_lexicon_words(lex)
+    rng = random.Random(5)
+    common = [w for w in words if w.isalpha()][::23][:5000]
+    LM = A.VocabParams(vocabtype="LM")
+    g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
+    g.read_lexicon(lex)
+    for _ in range(8000):
+        g.add_to_vocabulary(f"{rng.choice(common)} {rng.choice(common)}", rng.randrange(1, 20), LM)
+    for w in common[:300]:
+        g.add_to_vocabulary(f"<bos> {w}", 5, LM)
+    g.build()
+    noisy = synth.make_running_text(common, 0.6, seed=43)
+    long_ones = [" ".join(rng.choice(common) for _ in range(rng.randrange(40, 120))) for _ in range(60)]   # stretches of up to 120 tokens
+    texts = noisy + long_ones + ["", "x", "a b", "a " * 300, "it's a well-known co-op"]
+    total = 0
+    for kw in (dict(max_seq=1), dict(max_seq=2), dict(max_seq=3), dict(max_seq=7, max_ngram=2), dict(max_seq=8), dict(max_seq=9), dict(max_seq=10),
+               dict(max_seq=17, max_ngram=2), dict(max_seq=64), dict(max_seq=250), dict(max_seq=250, lm_weight=0.0),
+               dict(max_seq=1000, max_matches=3), dict(max_seq=250, max_ngram=4, max_matches=20)):
+        p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, **({"max_matches": 10, "max_ngram": 3} | kw))
+        out = {}
+        for mode in ("device", "host"):
+            if mode == "host":
+                A.set_switch("ANX_LATTICE", "host")
+            try:
+                out[mode] = g.find_all_matches_arrays(texts, p)
+            finally:
+                A.set_switch("ANX_LATTICE", None)
+        for x, y in zip(out["device"], out["host"]):
+            assert np.array_equal(x, y), kw
+        total += out["device"][1].size
+    assert total > 100_000
