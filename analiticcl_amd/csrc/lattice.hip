@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
     auto lowbit = [](uint32_t x) { return x & (0u - x); };
     auto pops = [&](auto two_c) {
       constexpr bool TWO = decltype(two_c)::value;
-      for (uint32_t it = 0; it < itmax; ++it) {
+      auto pop = [&](uint32_t it) {
         const uint32_t best = min(group_min_u32<G>(TWO ? min(hc[0], hc[1]) : hc[0]), 0xFFFFFFFEu);
         const unsigned long long m0 = __builtin_amdgcn_uicmp(hc[0], best, 32 /* == */);
         unsigned long long w0, w1 = 0ull;
@@ -271,7 +271,10 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         }
         if (__builtin_amdgcn_inverse_ballot_w64(w0)) move_up(0, it, best);
         if (TWO && __builtin_amdgcn_inverse_ballot_w64(w1)) move_up(1, it, best);
-      }
+      };
+      uint32_t it = 0;
+      for (; it + 4u <= itmax; it += 4u) { pop(it); pop(it + 1u); pop(it + 2u); pop(it + 3u); }  // (four per trip: one taken branch and one pair of LDS address updates per four pops)
+      for (; it < itmax; ++it) pop(it);
     };
     if (two) pops(std::true_type{}); else pops(std::false_type{});
     if (act && gl == 0) s_cnt[d] = (uint16_t)count;
