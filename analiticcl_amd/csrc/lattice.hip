@@ -79,6 +79,7 @@ struct LatArgs {
   LNode* nodes;              // node pool of this launch
   LmNode* lm;                // [same index]: LM sums of the marked nodes
   uint8_t* marks;            // a byte per node ((K + 3) & ~3 per state): the node lies on one of the final paths
+  uint16_t* cnts;            // nodes per state, [node0 / K + state]: from k_lattice to k_lattice_lm
   uint32_t K;
   uint32_t ring_max;         // cost lists the LDS ring of this launch holds (LatStretch::ring above it: host fallback)
   uint32_t cnt_cap;          // states (virtual end state included) of the launch's longest stretch: size of the per-state counts in LDS
@@ -179,8 +180,6 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
   if (have && !alive && gl == 0) a.out_n[si] = 0xFFFFFFFFu;  // not decoded here: the host decoder takes it
   LNode* __restrict__ nodes = a.nodes + (size_t)(S.node0);
   LmNode* __restrict__ lmn = a.lm + (size_t)(S.node0);
-  const uint32_t MK = (K + 3u) & ~3u;  // mark bytes per state
-  uint8_t* __restrict__ marks = a.marks + (size_t)(S.node0 / K) * MK;
   const uint32_t ring = S.ring ? S.ring : 1u;
   uint32_t nsmax = alive ? ns : 0u;  // the wave's states loop runs as long as its longest stretch
 #pragma unroll
@@ -286,6 +285,37 @@ __global__ __launch_bounds__(64) void k_lattice(LatArgs a) {
         nodes[(size_t)d * K + r] = LNode{mine[r], (arc.src << 16) | (pk & 0xFFFFu), arc.sym};
       }
   }
+  // the nodes per state and "decoded so far" for the second kernel (the language model and the choice of the path need no LDS: with
+  // the cost rings out of the way twice as many waves are in flight for that latency-bound part, and this kernel's waves make room
+  // for the next ones as soon as their merges are done)
+  if (alive) {
+    uint16_t* __restrict__ c = a.cnts + (size_t)(S.node0 / K);
+    for (uint32_t d = gl; d < ns; d += G) c[d] = s_cnt[d];
+    if (gl == 0) a.out_n[si] = 0u;
+  }
+}
+
+// The second half of a stretch's decoding: LM sums of the nodes on the final paths, rerank, the chosen path's symbols.  Same launch
+// geometry as k_lattice (G lanes per stretch), no LDS.
+template <uint32_t G>
+__global__ __launch_bounds__(64) void k_lattice_lm(LatArgs a) {
+  constexpr uint32_t NG = 64u / G;
+  const uint32_t lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const uint32_t slot = blockIdx.x * NG + grp;
+  const bool have = slot < a.count;
+  const uint32_t si = a.index[a.first + (have ? slot : 0u)];
+  const LatStretch S = a.st[si];
+  const uint32_t K = a.K;
+  const uint32_t ns = S.nstates + 1u;  // with the virtual end state
+  bool alive = have && a.out_n[si] != 0xFFFFFFFFu;   // (k_lattice leaves 0xFFFFFFFF for what it hands to the host decoder)
+  LNode* __restrict__ nodes = a.nodes + (size_t)(S.node0);
+  LmNode* __restrict__ lmn = a.lm + (size_t)(S.node0);
+  const uint32_t MK = (K + 3u) & ~3u;  // mark bytes per state
+  uint8_t* __restrict__ marks = a.marks + (size_t)(S.node0 / K) * MK;
+  const uint16_t* __restrict__ s_cnt = a.cnts + (size_t)(S.node0 / K);
+  uint32_t nsmax = alive ? ns : 0u;  // the wave's states loops run as long as its longest stretch
+#pragma unroll
+  for (int o = 32; o >= (int)G && o < 64; o >>= 1) nsmax = max(nsmax, (uint32_t)__shfl_xor((int)nsmax, o));
   const uint32_t end = ns - 1u;
   uint32_t npaths = alive ? s_cnt[end] : 0u;
   if (alive && npaths == 0) { if (gl == 0) a.out_n[si] = 0xFFFFFFFFu; alive = false; }  // no complete path (cannot happen: the epsilon chain): host
@@ -523,10 +553,12 @@ static int lattice_launch(const HostModel& m, const DeviceLexicon* dl, std::vect
   uint8_t* d_marks = nullptr;
   const bool lm_on = m.have_lm && p.lm_weight > 0.0f;
   if (lm_on && ((rc = dalloc_((void**)&d_lm, max_pool * sizeof(LmNode))) || (rc = dalloc_((void**)&d_marks, max_pool / K * ((K + 3u) & ~3u))))) return rc;
+  uint16_t* d_cnts = nullptr;
+  if ((rc = dalloc_((void**)&d_cnts, (max_pool / K + 1) * sizeof(uint16_t)))) return rc;
   HIP_TRY(hipMemcpyAsync(d_st, hst.data(), n * sizeof(LatStretch), hipMemcpyHostToDevice, st));
   if (after_stretch_upload) { const int rcu = after_stretch_upload(); if (rcu) return rcu; }  // the caller's uploads / kernels that complete the lattice arrays
   LatArgs a;
-  a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.lm = d_lm; a.marks = d_marks; a.K = K;
+  a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.lm = d_lm; a.marks = d_marks; a.cnts = d_cnts; a.K = K;
   a.use_lm = (m.have_lm && p.lm_weight > 0.0f) ? 1 : 0;
   a.lm_weight = p.lm_weight; a.variantmodel_weight = p.variantmodel_weight; a.contextrules_weight = p.contextrules_weight;
   a.bg_key = lm->bg_key; a.bg_val = lm->bg_val; a.bg_mask = lm->bg_mask; a.ngram_off = lm->ngram_off; a.ngram_ids = lm->ngram_ids; a.nvocab = lm->nvocab;
@@ -547,6 +579,10 @@ static int lattice_launch(const HostModel& m, const DeviceLexicon* dl, std::vect
     if (l.lanes == 32u) hipLaunchKernelGGL(k_lattice<32>, dim3((l.count + 1u) / 2u), dim3(64), lds, st, a);
     else hipLaunchKernelGGL(k_lattice<64>, dim3(l.count), dim3(64), lds, st, a);
     ktimer_end(kt, st);
+    const int kt2 = ktimer_begin("k_lattice_lm", st);
+    if (l.lanes == 32u) hipLaunchKernelGGL(k_lattice_lm<32>, dim3((l.count + 1u) / 2u), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_lattice_lm<64>, dim3(l.count), dim3(64), 0, st, a);
+    ktimer_end(kt2, st);
   }
   HIP_TRY(hipGetLastError());
   return ANX_OK;
