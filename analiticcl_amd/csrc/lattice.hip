@@ -67,6 +67,13 @@ struct LmNode {  // the LM side of a node, only written for the nodes that lie o
   int32_t prev;  // last token (-1 = out of vocabulary)
 };
 
+struct LmSym {   // what a symbol adds to a path's LM sum, as far as it does not depend on the path (k_lattice_lm): 32 B
+  int32_t first, last;   // its first / last token (-1 = out of vocabulary)
+  uint32_t ntok;         // tokens (n-gram parts, then the boundary text behind it); above LMSYM_TERMS + 1: terms[] is not used
+  float terms[5];        // the bigram terms BETWEEN its tokens, in order: term(tok[i - 1], tok[i]), i = 1 .. ntok - 1
+};
+constexpr uint32_t LMSYM_TERMS = 5;
+
 struct LatArgs {
   const LatStretch* st;
   uint32_t first, count;     // stretches index[first .. first + count) of the batch run in this launch
@@ -80,6 +87,7 @@ struct LatArgs {
   LmNode* lm;                // [same index]: LM sums of the marked nodes
   uint8_t* marks;            // a byte per node ((K + 3) & ~3 per state): the node lies on one of the final paths
   uint16_t* cnts;            // nodes per state, [node0 / K + state]: from k_lattice to k_lattice_lm
+  LmSym* lmsym;              // [symbol]: filled and used by k_lattice_lm
   uint32_t K;
   uint32_t ring_max;         // cost lists the LDS ring of this launch holds (LatStretch::ring above it: host fallback)
   uint32_t cnt_cap;          // states (virtual end state included) of the launch's longest stretch: size of the per-state counts in LDS
@@ -346,6 +354,40 @@ __global__ __launch_bounds__(64) void k_lattice_lm(LatArgs a) {
       __syncthreads();
     }
     const uint32_t* __restrict__ boff = a.btok_off + S.btok_off0;
+    // Per SYMBOL, once (a lane per arc of the stretch): its tokens' first / last / count and the bigram terms between them -- none of
+    // that depends on the path.  A node then adds term(parent's last token, first) and the stored terms, in the same order as the
+    // token walk below (the same float additions), with one hash look-up instead of one per token: the walk's chain of dependent
+    // loads (symbol -> n-gram offsets -> ids -> key -> value, per token) is what this kernel's time was.
+    if (alive) {
+      const uint32_t* __restrict__ ioff = a.in_off + S.in_off0;
+      const uint32_t narcs = ioff[ns];
+      for (uint32_t ai = gl; ai < narcs; ai += G) {
+        const uint32_t sym = a.arcs[S.arc0 + ai].sym;
+        if (sym == 0xFFFFFFFFu) continue;
+        const LatSym sy = a.syms[S.sym0 + sym];
+        LmSym rec;
+        rec.first = -1; rec.last = -1; rec.ntok = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < LMSYM_TERMS; ++i) rec.terms[i] = 0.0f;
+        auto push = [&](int32_t t) {
+          if (rec.ntok == 0u) rec.first = t;
+          else {
+            const float tm = rec.ntok <= LMSYM_TERMS ? lat_term(a, rec.last, t) : 0.0f;
+#pragma unroll
+            for (uint32_t i = 0; i < LMSYM_TERMS; ++i)   // (no run-time index into a register array)
+              if (rec.ntok == i + 1u) rec.terms[i] = tm;
+          }
+          rec.last = t;
+          ++rec.ntok;
+        };
+        if (sy.vocab_id == 0u) push(-1);
+        else if (sy.vocab_id < a.nvocab)
+          for (uint32_t k = a.ngram_off[sy.vocab_id]; k < a.ngram_off[sy.vocab_id + 1]; ++k) push((int32_t)a.ngram_ids[k]);
+        for (uint32_t k = boff[sy.boundary]; k < boff[sy.boundary + 1]; ++k) push(a.btok[S.btok0 + k]);
+        a.lmsym[S.sym0 + sym] = rec;
+      }
+    }
+    __syncthreads();
     for (uint32_t d = 1; d < nsmax; ++d) {
       const uint32_t cnt = (alive && d < ns) ? s_cnt[d] : 0u;
       for (uint32_t r = gl; r < cnt; r += G) {
@@ -355,7 +397,17 @@ __global__ __launch_bounds__(64) void k_lattice_lm(LatArgs a) {
         float lp = pa.lp;
         uint32_t n = pa.n;
         int32_t prev = pa.prev;
-        if (nd.sym != 0xFFFFFFFFu) {  // the tokens of the symbol: its n-gram parts, then the boundary text behind it (src/lib.rs:2580-2629)
+        const LmSym rec = nd.sym != 0xFFFFFFFFu ? a.lmsym[S.sym0 + nd.sym] : LmSym{-1, -1, 0u, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
+        if (nd.sym != 0xFFFFFFFFu && rec.ntok <= LMSYM_TERMS + 1u) {
+          if (rec.ntok) {
+            lp += lat_term(a, prev, rec.first);
+#pragma unroll
+            for (uint32_t i = 0; i < LMSYM_TERMS; ++i)
+              if (i + 1u < rec.ntok) lp += rec.terms[i];
+            n += rec.ntok;
+            prev = rec.last;
+          }
+        } else if (nd.sym != 0xFFFFFFFFu) {  // the tokens of the symbol: its n-gram parts, then the boundary text behind it (src/lib.rs:2580-2629)
           const LatSym sy = a.syms[S.sym0 + nd.sym];
           if (sy.vocab_id == 0u) { lp += lat_term(a, prev, -1); ++n; prev = -1; }
           else if (sy.vocab_id < a.nvocab)
@@ -502,7 +554,7 @@ static int lm_ensure(const HostModel& m, const DeviceLexicon* dl, std::string& e
 // incoming arcs of a state of stretch j.  The planned stretch array is uploaded to d_st, then after_stretch_upload (may be empty)
 // enqueues whatever still has to happen to the arrays on `st` before the kernels run.  Blocks allocated here go to `owned`.
 static int lattice_launch(const HostModel& m, const DeviceLexicon* dl, std::vector<LatStretch>& hst, const std::vector<uint32_t>& maxdeg, LatStretch* d_st,
-                          const uint32_t* d_inoff, const LatArc* d_arcs, const LatSym* d_syms, const uint32_t* d_boff, const int32_t* d_btok, uint32_t* d_outn,
+                          const uint32_t* d_inoff, const LatArc* d_arcs, const LatSym* d_syms, size_t nsyms_cap, const uint32_t* d_boff, const int32_t* d_btok, uint32_t* d_outn,
                           uint32_t* d_outs, const anx_search_params& p, hipStream_t st, const std::function<int()>& after_stretch_upload, std::vector<void*>& owned,
                           std::string& err) {
   const size_t n = hst.size();
@@ -555,10 +607,12 @@ static int lattice_launch(const HostModel& m, const DeviceLexicon* dl, std::vect
   if (lm_on && ((rc = dalloc_((void**)&d_lm, max_pool * sizeof(LmNode))) || (rc = dalloc_((void**)&d_marks, max_pool / K * ((K + 3u) & ~3u))))) return rc;
   uint16_t* d_cnts = nullptr;
   if ((rc = dalloc_((void**)&d_cnts, (max_pool / K + 1) * sizeof(uint16_t)))) return rc;
+  LmSym* d_lmsym = nullptr;
+  if (lm_on && (rc = dalloc_((void**)&d_lmsym, (nsyms_cap + 1) * sizeof(LmSym)))) return rc;
   HIP_TRY(hipMemcpyAsync(d_st, hst.data(), n * sizeof(LatStretch), hipMemcpyHostToDevice, st));
   if (after_stretch_upload) { const int rcu = after_stretch_upload(); if (rcu) return rcu; }  // the caller's uploads / kernels that complete the lattice arrays
   LatArgs a;
-  a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.lm = d_lm; a.marks = d_marks; a.cnts = d_cnts; a.K = K;
+  a.st = d_st; a.in_off = d_inoff; a.arcs = d_arcs; a.syms = d_syms; a.btok_off = d_boff; a.btok = d_btok; a.nodes = d_nodes; a.lm = d_lm; a.marks = d_marks; a.cnts = d_cnts; a.lmsym = d_lmsym; a.K = K;
   a.use_lm = (m.have_lm && p.lm_weight > 0.0f) ? 1 : 0;
   a.lm_weight = p.lm_weight; a.variantmodel_weight = p.variantmodel_weight; a.contextrules_weight = p.contextrules_weight;
   a.bg_key = lm->bg_key; a.bg_val = lm->bg_val; a.bg_mask = lm->bg_mask; a.ngram_off = lm->ngram_off; a.ngram_ids = lm->ngram_ids; a.nvocab = lm->nvocab;
@@ -647,7 +701,7 @@ int lattice_decode(const HostModel& m, const DeviceLexicon* dl, const LatView& w
     if (in.nbtok) HIP_TRY(hipMemcpyAsync(d_btok, in.btok, in.nbtok * 4, hipMemcpyHostToDevice, st));
     return ANX_OK;
   };
-  if ((rc = lattice_launch(m, dl, hst, maxdeg, d_st, d_inoff, d_arcs, d_syms, d_boff, d_btok, d_outn, d_outs, p, st, uploads, owned, err))) return rc;
+  if ((rc = lattice_launch(m, dl, hst, maxdeg, d_st, d_inoff, d_arcs, d_syms, in.nsyms, d_boff, d_btok, d_outn, d_outs, p, st, uploads, owned, err))) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out_n, d_outn, n * 4, hipMemcpyDeviceToHost, st));
   if (nout) HIP_TRY(hipMemcpyAsync(out_syms, d_outs, nout * 4, hipMemcpyDeviceToHost, st));
@@ -985,7 +1039,7 @@ int search_onepass_finish(const HostModel& m, const DeviceLexicon* dl, OnePassSt
       hipLaunchKernelGGL(k_op_stfix, dim3((a.nst + 255) / 256), dim3(256), 0, st, a);
       return ANX_OK;
     };
-    if ((rc = lattice_launch(m, dl, hst, maxdeg, a.st, a.in_off, a.arcs, a.syms, d_boff, d_btok, d_outn, d_outs, p, st, fix, S->owned, err))) return rc;
+    if ((rc = lattice_launch(m, dl, hst, maxdeg, a.st, a.in_off, a.arcs, a.syms, nsym_cap, d_boff, d_btok, d_outn, d_outs, p, st, fix, S->owned, err))) return rc;
   }
   lap("k_lattice");
   // the matches on the chosen paths and their rows
