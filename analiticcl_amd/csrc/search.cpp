@@ -809,9 +809,15 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   parts = std::max<size_t>(parts, 1);
   std::vector<size_t> cut(parts + 1, n);
   cut[0] = 0;
-  for (size_t r = 1, t = 0; r < parts; ++r) {
-    while (t < n && len_upto[t] * parts < len_upto[n] * r) ++t;
-    cut[r] = t;
+  {
+    // part r ends where the text reaches its share: even shares, except that the first part may be smaller (ANX_SEARCH_FIRST_PCT)
+    const double first = parts > 1 ? (double)anx::switches().search_first_pct / 100.0 : 1.0;
+    const double total_w = first + (double)(parts - 1);
+    for (size_t r = 1, t = 0; r < parts; ++r) {
+      const double share = (first + (double)(r - 1)) / total_w;
+      while (t < n && (double)len_upto[t] < (double)len_upto[n] * share) ++t;
+      cut[r] = t;
+    }
   }
   std::vector<std::unique_ptr<PartOut>> P(parts);
   for (auto& p : P) p.reset(new PartOut());
