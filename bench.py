@@ -590,6 +590,7 @@ def extra_configs(args, paths, device, ncores):
             L.lib().anx_matches_free(ms, offs, rows, None)
             best = dt if best is None else min(best, dt)
         lat_ms, lat_n = L_.kernel_time("k_lattice")
+        lm_ms, _lm_n = L_.kernel_time("k_lattice_lm")
         L_.kernel_timer(False)
         off, ma, ra = m.find_all_matches_arrays(texts, sp)
         # parity: sampled texts through the oracle twin's segmentation / lattice / LM code, per-segment find_variants by the C oracle
@@ -619,13 +620,16 @@ def extra_configs(args, paths, device, ncores):
                 "MB_per_s": nbytes / 1e6 / best, "seconds": best, "matches": int(off[-1]), "variant_rows": int(ra.shape[0]),
                 # k_lattice per call (all its launches): algorithmic bytes = the lattice input (16 B per arc: one arc per variant row, plus
                 # one out-of-vocabulary / epsilon arc per match) + the chosen symbols out (8 B per match)
-                "roofline": (lambda ms, nb: {"bound": "latency", "kernel": "k_lattice", "avg_kernel_ms": ms, "algorithmic_bytes": nb, "compulsory_bytes": nb, "access_bytes": nb,
+                "roofline": (lambda ms, nb: {"bound": "valu_issue", "kernel": "k_lattice", "avg_kernel_ms": ms, "algorithmic_bytes": nb, "compulsory_bytes": nb, "access_bytes": nb,
                                              "achieved": (nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": (nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0), "valu_issue_frac": None,
                                              "traffic": _profile_traffic("search", "k_lattice")[0], "traffic_source": _profile_traffic("search", "k_lattice")[1],
                                              "launches_per_call": lat_n / 5.0,
-                                             "note": "ms = all k_lattice launches of one call; two stretches per wave, K <= 250 serial pops of a group-wide minimum each: "
-                                                     "latency-bound, and the call as a whole is bound by its host phases (MB_per_s)"})(
+                                             "k_lattice_lm_ms": lm_ms / 5.0,
+                                             "note": "ms = all k_lattice launches of one call (the four parts' launches overlap on the device: each takes longer than alone; "
+                                                     "12.5 MB as ONE part: profiles/r*_search_single_part_kernel_trace.md); two stretches per wave, K <= 250 pops of a "
+                                                     "group-wide minimum each, ~17 vector instructions per pop: bound by vector-instruction issue (DESIGN.md section 5 K6); "
+                                                     "k_lattice_lm (LM sums, rerank, chosen path): dependent loads, latency"})(
                     lat_ms / 5.0, int(ra.shape[0]) * 16 + int(off[-1]) * (16 + 8)),
                 "parity": f"ok ({nchk} texts = {8 * nchk} sentences vs the oracle twin)"}
 
