@@ -728,6 +728,13 @@ struct PartOut {
   size_t total = 0, total_rows = 0, total_tags = 0;
   int rc = ANX_OK;
   std::string err;
+  // progress, for the call's thread that writes the output while later parts are still on the device (anx_find_all_matches_batch):
+  // an upper bound of the part's matches once its boundaries are known (a path has at most one match per token), and "done"
+  std::atomic<size_t> ub_matches{(size_t)-1};
+  std::atomic<int> done{0};
+  std::mutex* sig_mu = nullptr;
+  std::condition_variable* sig_cv = nullptr;
+  void signal() { if (sig_mu) { { std::lock_guard<std::mutex> g(*sig_mu); } sig_cv->notify_all(); } }
   void free_kept() { for (OrderRows& o : kept) anx_results_free(o.rows, o.offs); kept.clear(); }
   ~PartOut() { free_kept(); }
 };
@@ -821,12 +828,16 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   }
   std::vector<std::unique_ptr<PartOut>> P(parts);
   for (auto& p : P) p.reset(new PartOut());
+  struct Early { bool on = false; anx_match* om = nullptr; size_t* oo = nullptr; anx_result* orows = nullptr; size_t m_cap = 0, r_cap = 0, m_total = 0, r_total = 0, parts_written = 0; double write_s = 0.0; } early;
   if (parts == 1) {
     P[0]->rc = find_all_part(model, texts, n, sp, *P[0]);
     if (P[0]->rc != ANX_OK) return P[0]->rc;  // (the message is this thread's)
   } else {
     std::atomic<size_t> next_part{0};
     std::atomic<bool> failed{false};
+    std::mutex sig_mu;
+    std::condition_variable sig_cv;
+    for (auto& p : P) { p->sig_mu = &sig_mu; p->sig_cv = &sig_cv; }
     std::vector<std::thread> th;
     for (size_t w = 0; w < workers; ++w)
       th.emplace_back([&]() {
@@ -834,14 +845,58 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
           const size_t r = next_part.fetch_add(1);
           if (r >= parts) break;
           PartOut& p = *P[r];
-          if (failed.load()) { p.rc = ANX_EINVAL; continue; }
-          const auto tp = std::chrono::steady_clock::now();
-          p.rc = find_all_part(model, texts + cut[r], cut[r + 1] - cut[r], sp, p);
-          if (anx::switches().search_timing) fprintf(stderr, "[anx search] part %zu, all of it          %8.2f ms\n", r, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count() * 1e3);
-          if (p.rc != ANX_OK) { p.err = anx_last_error(); failed.store(true); }  // (the message is the worker thread's)
+          if (!failed.load()) {
+            const auto tp = std::chrono::steady_clock::now();
+            p.rc = find_all_part(model, texts + cut[r], cut[r + 1] - cut[r], sp, p);
+            if (anx::switches().search_timing) fprintf(stderr, "[anx search] part %zu, all of it          %8.2f ms\n", r, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count() * 1e3);
+            if (p.rc != ANX_OK) { p.err = anx_last_error(); failed.store(true); }  // (the message is the worker thread's)
+          } else p.rc = ANX_EINVAL;
+          p.ub_matches.store(0, std::memory_order_release);  // (a part that failed before its boundaries: nobody waits for the bound)
+          p.done.store(1, std::memory_order_release);
+          p.signal();
         }
       });
+    // The output while the later parts are still at work (round 5: the middle of a call is bound by the device, the host threads wait;
+    // written at the end, the 256 MB of a 12.5 MB call were 6-7 ms with the device idle).  The arrays are sized by upper bounds
+    // -- matches: one per token, known after every part's boundaries; rows: max_matches + 2 per match -- and cut back to what was
+    // written at the end.  Not with unlimited lists (max_matches = 0), tags, or when a bound does not hold: those write at the end.
+    early.on = anx::switches().search_early_output && sp->base.max_matches > 0 && !out_tags;
+    if (early.on) {
+      size_t ub = 0;
+      {
+        std::unique_lock<std::mutex> l(sig_mu);
+        sig_cv.wait(l, [&]() { for (auto& p : P) if (p->ub_matches.load(std::memory_order_acquire) == (size_t)-1) return false; return true; });
+      }
+      for (auto& p : P) ub += p->ub_matches.load(std::memory_order_acquire);
+      early.m_cap = std::max<size_t>(1, ub);
+      early.r_cap = std::max<size_t>(1, ub * ((size_t)sp->base.max_matches + 2));
+      early.om = static_cast<anx_match*>(malloc(early.m_cap * sizeof(anx_match)));
+      early.oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
+      early.orows = static_cast<anx_result*>(malloc(early.r_cap * sizeof(anx_result)));
+      if (!early.om || !early.oo || !early.orows) { free(early.om); free(early.oo); free(early.orows); early = Early(); }
+      else { advise_huge(early.om, early.m_cap * sizeof(anx_match)); advise_huge(early.orows, early.r_cap * sizeof(anx_result)); }
+    }
+    if (early.on) {
+      size_t mb = 0, rb = 0;
+      for (size_t r = 0; r < parts && early.on; ++r) {
+        {
+          std::unique_lock<std::mutex> l(sig_mu);
+          sig_cv.wait(l, [&]() { return P[r]->done.load(std::memory_order_acquire) != 0; });
+        }
+        if (P[r]->rc != ANX_OK) break;  // (reported below)
+        if (mb + P[r]->total > early.m_cap || rb + P[r]->total_rows > early.r_cap) { early.on = false; break; }  // a bound did not hold: at the end, exactly
+        const auto tw0 = std::chrono::steady_clock::now();
+        write_part(*P[r], texts + cut[r], cut[r + 1] - cut[r], sp, early.om, early.oo + cut[r], early.orows, nullptr, mb, rb, 0);
+        early.write_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+        mb += P[r]->total;
+        rb += P[r]->total_rows;
+        early.parts_written = r + 1;
+      }
+      early.m_total = mb;
+      early.r_total = rb;
+    }
     for (auto& x : th) x.join();
+    if (early.om && (!early.on || early.parts_written != parts)) { free(early.om); free(early.oo); free(early.orows); early = Early(); }
     for (auto& p : P)
       if (p->rc != ANX_OK && !p->err.empty()) return anx_fail(p->rc, p->err);
     for (auto& p : P)
@@ -851,6 +906,20 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   // copied here: twice the fresh pages, and 38 ms of copying per 12.5 MB of text)
   const bool timing = anx::switches().search_timing != 0;
   const auto t_out = std::chrono::steady_clock::now();
+  if (early.on && early.om && early.parts_written == parts) {  // everything is written: the arrays shrink to what was used
+    anx_match* om2 = static_cast<anx_match*>(realloc(early.om, std::max<size_t>(1, early.m_total) * sizeof(anx_match)));
+    anx_result* or2 = static_cast<anx_result*>(realloc(early.orows, std::max<size_t>(1, early.r_total) * sizeof(anx_result)));
+    for (size_t r = 0; r < parts; ++r) P[r]->free_kept();
+    auto garbage = std::make_shared<std::vector<std::unique_ptr<PartOut>>>(std::move(P));
+    HostPool::get().post([garbage]() { garbage->clear(); });
+    if (timing) fprintf(stderr, "[anx search] output (%zu parts), written as the parts finished: %.2f ms of writing, %.2f ms behind the last part\n", parts, early.write_s * 1e3,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count() * 1e3);
+    *out_matches = om2 ? om2 : early.om;
+    *out_offsets = early.oo;
+    *out_rows = or2 ? or2 : early.orows;
+    *out_n_rows = early.r_total;
+    return ANX_OK;
+  }
   std::vector<size_t> m0(parts + 1, 0), r0(parts + 1, 0), t0(parts + 1, 0);
   for (size_t r = 0; r < parts; ++r) {
     m0[r + 1] = m0[r] + P[r]->total;
@@ -1268,6 +1337,12 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
     stretches.reserve(ns);
     for (auto& v : per_text_stretches)
       for (Stretch& x : v) stretches.push_back(std::move(x));
+  }
+  {
+    size_t ub = n;
+    for (size_t t = 0; t < n; ++t) ub += bounds[t].size();
+    po.ub_matches.store(ub, std::memory_order_release);
+    po.signal();
   }
   lap("boundaries");
   std::vector<std::vector<Span>> decoded(stretches.size());

@@ -253,6 +253,22 @@ static int shards_mode(const std::string& alphabet, const std::string& lexicon) 
           same = rr[k].vocab_id == ref_r[k].vocab_id && rr[k].dist_score == ref_r[k].dist_score && rr[k].freq_score == ref_r[k].freq_score && rr[k].via == ref_r[k].via;
         CHECK(same);
         anx_matches_free(ms, mo, rr, tg);
+        // without a tag array the output is written while later parts are still at work (arrays sized by upper bounds, cut back at the
+        // end), with ANX_SEARCH_EARLY_OUTPUT=0 when the last part is done: the same arrays either way
+        for (const char* early : {"1", "0"}) {
+          CHECK(anx_debug_set_switch("ANX_SEARCH_EARLY_OUTPUT", early) == ANX_OK);
+          CHECK(anx_find_all_matches_batch(m, mp.data(), mp.size(), &sp, &ms, &mo, &rr, &nr, nullptr) == ANX_OK);
+          CHECK(nr == ref_nr && memcmp(mo, ref_o, (mp.size() + 1) * sizeof(size_t)) == 0);
+          same = true;
+          for (size_t k = 0; k < nm && same; ++k)
+            same = ms[k].begin == ref_m[k].begin && ms[k].end == ref_m[k].end && ms[k].n == ref_m[k].n && ms[k].selected == ref_m[k].selected &&
+                   ms[k].var_begin == ref_m[k].var_begin && ms[k].var_end == ref_m[k].var_end && ms[k].tag_begin == 0 && ms[k].tag_end == 0;
+          for (size_t k = 0; k < nr && same; ++k)
+            same = rr[k].vocab_id == ref_r[k].vocab_id && rr[k].dist_score == ref_r[k].dist_score && rr[k].freq_score == ref_r[k].freq_score && rr[k].via == ref_r[k].via;
+          CHECK(same);
+          anx_matches_free(ms, mo, rr, nullptr);
+        }
+        CHECK(anx_debug_set_switch("ANX_SEARCH_EARLY_OUTPUT", nullptr) == ANX_OK);
       }
       // anx_shutdown joins the pool's threads; the next call starts a fresh pool and gives the same answer
       anx_shutdown();

@@ -539,7 +539,21 @@ def test_search_parts_equal_one_pass(data_dir):
                 continue
             assert np.array_equal(off, ref[0]) and np.array_equal(ma, ref[1]) and np.array_equal(ra, ref[2]), parts
             assert ids == ref[3], parts
+            # (the array form has no tag array: its output is written while later parts are still at work; written at the end instead:)
+            A.set_switch("ANX_SEARCH_EARLY_OUTPUT", "0")
+            off2, ma2, ra2 = g.find_all_matches_arrays(texts, p)
+            A.set_switch("ANX_SEARCH_EARLY_OUTPUT", None)
+            assert np.array_equal(off2, ref[0]) and np.array_equal(ma2, ref[1]) and np.array_equal(ra2, ref[2]), parts
+            # unlimited lists (max_matches = 0: no bound for the rows, the output waits for the last part)
+            if parts == "3":
+                p0 = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=0, max_ngram=2)
+                a3 = g.find_all_matches_arrays(texts[:300], p0)
+                A.set_switch("ANX_SEARCH_PARTS", "1")
+                a1 = g.find_all_matches_arrays(texts[:300], p0)
+                for x, y in zip(a3, a1):
+                    assert np.array_equal(x, y)
     finally:
+        A.set_switch("ANX_SEARCH_EARLY_OUTPUT", None)
         A.set_switch("ANX_SEARCH_PARTS", None)
         A.set_switch("ANX_SEARCH_PARTS_MIN", None)
 
