@@ -882,6 +882,11 @@ void split_classes(const anx_model* m, size_t n, const std::function<void(size_t
     }
   });
 }
+// the prior of the length split (split_by_length): record tests' worth of per-query work that does not depend on the records, and what
+// a record test goes on to cost as a function of x = k / length
+static inline double split_fixed_cost(uint32_t L) { return 6500.0 * (1.0 + 0.012 * (double)(L > 6u ? L - 6u : 0u)); }
+static inline double split_record_factor(double x) { const double x2 = x * x; return 0.2 + 38.0 * x2 * x2; }
+
 void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const anx_params& p, std::vector<Shard>& shards) {
   const size_t S = shards.size();
   constexpr uint32_t LMAX = LengthCost::LMAX;
@@ -930,8 +935,11 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
         // DL: large for short strings (k / L large: most of a short string's neighbourhood is within reach), small for long ones.
         // Fitted on the 10 M-query configs[3] job (ns per query by length: 21.7 at 6 symbols, 10.5 at 8, 5 at 10, 3 at 12, 2.3 from 16 on:
         // 6500 record tests ~ the per-query work that does not depend on the records -- encoder, tile set-up at 5 queries per tile, ranking)
+        // (refitted at the end of round 5 on the corrections the learner converges to on that job -- 1.13 at 6 symbols, 0.78 at 10-12,
+        // 1.19 from 13 on: the share of the record tests that go on to cost something falls faster with k / L than a cube, and the
+        // per-query work grows with the length: rows, the DL's band, the wide path above 16 symbols)
         const double x = std::min(rel, 0.5);
-        w[L] = (6500.0 + r * (0.35 + 15.2 * x * x * x)) * lc.scale[L];
+        w[L] = (split_fixed_cost(L) + r * split_record_factor(x)) * lc.scale[L];
       } else {
         w[L] = (1024.0 + window / 16.0) * (1.0 + 30.0 * rel * rel * rel) * lc.scale[L];
       }
@@ -949,9 +957,9 @@ void split_by_length(const anx_model* m, const uint32_t* cls, size_t n, const an
           for (unsigned t = 0; t < T; ++t) m_c += hist[t][c];
           const double sigs = 3.0 * std::max(1.0, (double)lc.class_nsig[c]);
           const double fill = std::min(48.0, std::max(1.0, (double)m_c / sigs));
-          const double x = std::min(L ? (double)k / (double)L : 0.0, 0.5), f = 0.35 + 15.2 * x * x * x;
-          const double mine = 4300.0 + 11600.0 / fill + (double)lc.class_records[c] * f * (1.0 + 8.0 / fill) / (1.0 + 8.0 / 48.0);
-          wc[c] = w[L] * mine / (6500.0 + lc.records[L] * f);
+          const double x = std::min(L ? (double)k / (double)L : 0.0, 0.5), f = split_record_factor(x), g = split_fixed_cost(L) / 6500.0;
+          const double mine = (4300.0 + 11600.0 / fill) * g + (double)lc.class_records[c] * f * (1.0 + 8.0 / fill) / (1.0 + 8.0 / 48.0);
+          wc[c] = w[L] * mine / (split_fixed_cost(L) + lc.records[L] * f);
         }
       }
     }
