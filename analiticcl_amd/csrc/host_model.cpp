@@ -464,6 +464,7 @@ const SwitchDef kSwitches[] = {
     {"ANX_SEARCH_TIMING", [](Switches& s, const char* v) { s.search_timing = v != nullptr && v[0] != 0 && v[0] != '0'; }},
     {"ANX_SEARCH_PARTS", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.search_parts = x >= 1 && x <= 8 ? x : 4; }},
     {"ANX_SEARCH_PART_BYTES", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.search_part_bytes = x > 0 ? x : (4l << 20); }},
+    {"ANX_SEARCH_PRIO", [](Switches& s, const char* v) { s.search_prio = flag01(v, 1); }},
     {"ANX_SEARCH_EARLY_OUTPUT", [](Switches& s, const char* v) { s.search_early_output = flag01(v, 1); }},
     {"ANX_SEARCH_FIRST_PCT", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.search_first_pct = x >= 10 && x <= 100 ? x : 50; }},
     {"ANX_SEARCH_PARTS_MIN", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.search_parts_min = x > 0 ? x : (2l << 20); }},

@@ -93,6 +93,7 @@ struct Switches {
   int search_parts = 4;      // ANX_SEARCH_PARTS: parts of a large find_all_matches call in flight at a time (search.cpp)
   long search_parts_min = 2l << 20;  // ANX_SEARCH_PARTS_MIN: bytes of text from which a call is split
   long search_part_bytes = 4l << 20;  // ANX_SEARCH_PART_BYTES: text per part
+  int search_prio = 1;               // ANX_SEARCH_PRIO=0: the host pool serves the loops of a call's parts first come, first served; 1: the earlier part first
   int search_early_output = 1;       // ANX_SEARCH_EARLY_OUTPUT=0: a call's output arrays are written when its last part is done (until round 5)
   int search_first_pct = 50;         // ANX_SEARCH_FIRST_PCT: size of a call's FIRST part in percent of an even share: the device idles until the first part's host phase
                                      // is done (same-box best calls 226-247 MB/s with even parts, 246-263 / 243-273 with 40 / 60 %; medians 222 -> 226 / 232)

@@ -58,6 +58,10 @@ struct LatLap { uint64_t t; LatLap() : t(g_lat_timing ? lat_now() : 0) {} void l
 // exist in the child), so the child's first call builds its own.
 class HostPool;
 std::atomic<HostPool*> g_pool{nullptr};
+// The loops of a call's parts queue up with the part's number: a pool thread takes the waiting task of the EARLIEST part (first come,
+// first served inside one part), so that the first part -- whose host phase the device waits for -- gets the threads first.  A task
+// carries its number to the thread that runs it (loops started from inside a loop body).
+thread_local int tl_pool_prio = 0;
 std::mutex g_pool_mu;
 class HostPool {
  public:
@@ -111,12 +115,18 @@ class HostPool {
     st->remaining.store(helpers);
     if (helpers) {
       {
+        const int prio = tl_pool_prio;
         std::lock_guard<std::mutex> g(mu_);
+        auto at = q_.end();
+        while (at != q_.begin() && std::prev(at)->prio > prio) --at;   // behind the waiting tasks of this and of earlier parts
         for (unsigned i = 0; i < helpers; ++i)
-          q_.push_back([st, &body]() {
+          at = std::next(q_.insert(at, Task{prio, [st, &body, prio]() {
+            const int saved = tl_pool_prio;
+            tl_pool_prio = prio;
             body();
+            tl_pool_prio = saved;
             if (st->remaining.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g2(st->m); st->cv.notify_all(); }
-          });
+          }}));
       }
       cv_.notify_all();
     }
@@ -125,7 +135,7 @@ class HostPool {
       std::function<void()> f;
       {
         std::lock_guard<std::mutex> g(mu_);
-        if (!q_.empty()) { f = std::move(q_.front()); q_.pop_front(); }
+        if (!q_.empty()) { f = std::move(q_.front().f); q_.pop_front(); }
       }
       if (f) { f(); continue; }
       std::unique_lock<std::mutex> l(st->m);
@@ -142,7 +152,7 @@ class HostPool {
           {
             std::unique_lock<std::mutex> l(mu_);
             cv_.wait(l, [&]() { return stop_ || !q_.empty() || !bg_.empty(); });
-            if (!q_.empty()) { f = std::move(q_.front()); q_.pop_front(); }
+            if (!q_.empty()) { f = std::move(q_.front().f); q_.pop_front(); }
             else if (!bg_.empty()) { f = std::move(bg_.front()); bg_.pop_front(); }
             else return;  // stop_ and nothing left to do
           }
@@ -155,7 +165,8 @@ class HostPool {
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;
-  std::deque<std::function<void()>> q_;
+  struct Task { int prio; std::function<void()> f; };
+  std::deque<Task> q_;                    // loop tasks, ordered by (part number, arrival)
   std::deque<std::function<void()>> bg_;  // post(): run when no loop task waits
 };
 
@@ -846,6 +857,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
           if (r >= parts) break;
           PartOut& p = *P[r];
           if (!failed.load()) {
+            tl_pool_prio = anx::switches().search_prio ? (int)r + 1 : 0;   // (the call's own thread, which writes the output, keeps 0)
             const auto tp = std::chrono::steady_clock::now();
             p.rc = find_all_part(model, texts + cut[r], cut[r + 1] - cut[r], sp, p);
             if (anx::switches().search_timing) fprintf(stderr, "[anx search] part %zu, all of it          %8.2f ms\n", r, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count() * 1e3);
