@@ -41,9 +41,9 @@ def test_row_kernels_do_not_spill(tmp_path_factory):
             for r in hit:
                 assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (frag, r)
             if frag == "k_lattice":
-                # round 4: 8.5 KB of LDS per wave gives 18 waves per CU; the registers must not become the limit (<= 64 -> 8 per SIMD),
-                # and the pop loop keeps its scalar state in SGPRs
-                assert all(r["vgpr_count"] <= 64 and r["sgpr_spill_count"] == 0 for r in hit), hit
+                # k_lattice (merges: ~10 KB of LDS per wave bound its waves) and k_lattice_lm (no LDS: 8 waves per SIMD as long as it stays
+                # within 64 registers); the pop loop keeps its scalar state (winner masks, pop counter) in SGPRs
+                assert len(hit) == 4 and all(r["vgpr_count"] <= 64 and r["sgpr_spill_count"] == 0 for r in hit), hit
 
 
 @pytest.fixture(scope="module")
