@@ -68,6 +68,8 @@ struct DevPool {
   std::multimap<size_t, void*> free_blocks;        // size -> block
   std::unordered_map<void*, size_t> size_of;       // every live or cached block of this pool
   size_t cached = 0;
+  std::unordered_map<void*, uint64_t> freed_at;   // cached blocks: when they came back (a full cache lets its oldest blocks go)
+  uint64_t clock = 0;
   int lexicons = 0;
   std::vector<hipStream_t> idle_streams;           // non-blocking streams of the device-side encoder, handed out per call
   hipStream_t run_streams[2] = {nullptr, nullptr}; // the library's own streams for asynchronous runs (batch_run_async)
@@ -162,6 +164,7 @@ hipError_t pool_malloc(void** p, size_t bytes) {
       *p = it->second;
       pl.cached -= it->first;
       pl.free_blocks.erase(it);
+      pl.freed_at.erase(*p);
       return hipSuccess;
     }
   }
@@ -172,6 +175,7 @@ hipError_t pool_malloc(void** p, size_t bytes) {
       std::lock_guard<std::mutex> g(pl.mu);
       for (auto& kv : pl.free_blocks) { drop.push_back(kv.second); pl.size_of.erase(kv.second); }
       pl.free_blocks.clear();
+      pl.freed_at.clear();
       pl.cached = 0;
     }
     for (void* d : drop) (void)hipFree(d);
@@ -188,17 +192,35 @@ void pool_free(void* p) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   DevPool& pl = pool_of(dev);
+  std::vector<void*> evicted;
+  bool kept = false;
   {
     std::lock_guard<std::mutex> g(pl.mu);
     auto it = pl.size_of.find(p);
-    if (it != pl.size_of.end() && pl.cached + it->second <= pool_cache_limit()) {
+    if (it != pl.size_of.end() && it->second <= pool_cache_limit()) {
+      // A full cache makes room by letting its OLDEST blocks go.  (Until the end of round 5 the block that came back was handed to
+      // hipFree instead -- a call that waits for the device: after a workload that had filled the cache -- bench.py's 1 M-entry
+      // lexicon -- every call of the next one paid its frees and mallocs in full: 18-22 ms per part of a search-mode call.)
+      while (pl.cached + it->second > pool_cache_limit() && !pl.free_blocks.empty()) {
+        auto old = pl.free_blocks.begin();
+        for (auto jt = pl.free_blocks.begin(); jt != pl.free_blocks.end(); ++jt)
+          if (pl.freed_at[jt->second] < pl.freed_at[old->second]) old = jt;
+        pl.cached -= old->first;
+        evicted.push_back(old->second);
+        pl.freed_at.erase(old->second);
+        pl.size_of.erase(old->second);
+        pl.free_blocks.erase(old);
+      }
       pl.free_blocks.emplace(it->second, p);
+      pl.freed_at[p] = ++pl.clock;
       pl.cached += it->second;
-      return;
+      kept = true;
+    } else if (it != pl.size_of.end()) {
+      pl.size_of.erase(it);
     }
-    if (it != pl.size_of.end()) pl.size_of.erase(it);
   }
-  (void)hipFree(p);
+  for (void* q : evicted) (void)hipFree(q);
+  if (!kept) (void)hipFree(p);
 }
 static void pool_trim(int device) {
   DevPool& pl = pool_of(device);
@@ -207,6 +229,7 @@ static void pool_trim(int device) {
     std::lock_guard<std::mutex> g(pl.mu);
     for (auto& kv : pl.free_blocks) { drop.push_back(kv.second); pl.size_of.erase(kv.second); }
     pl.free_blocks.clear();
+    pl.freed_at.clear();
     pl.cached = 0;
   }
   for (void* d : drop) (void)hipFree(d);
@@ -221,6 +244,8 @@ struct HostCache {
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks;
   std::unordered_map<void*, std::pair<size_t, bool>> live;  // every block handed out or cached: (bytes, pinned)
+  std::unordered_map<void*, uint64_t> freed_at;             // cached blocks: when they came back (the oldest leave first)
+  uint64_t clock = 0;
   size_t cached = 0;
 };
 HostCache& host_cache() { static HostCache c; return c; }
@@ -241,6 +266,7 @@ void* host_result_alloc(size_t bytes) {
       void* p = it->second;
       hc.cached -= it->first;
       hc.free_blocks.erase(it);
+      hc.freed_at.erase(p);
       ++g_host_hits;
       return p;
     }
@@ -263,6 +289,7 @@ void host_result_free(void* p) {
   HostCache& hc = host_cache();
   size_t bytes = 0;
   bool pinned = false, known = false;
+  std::vector<void*> evicted;
   {
     std::lock_guard<std::mutex> g(hc.mu);
     auto it = hc.live.find(p);
@@ -270,14 +297,32 @@ void host_result_free(void* p) {
       known = true;
       bytes = it->second.first;
       pinned = it->second.second;
-      if (pinned && hc.cached + bytes <= host_cache_limit()) {
+      if (pinned && bytes <= host_cache_limit()) {
+        // A full cache makes room by letting its OLDEST blocks go.  (Until the end of round 5 the block that came back was dropped
+        // instead: a process that had filled the cache with the buffers of one workload -- bench.py after its 1 M-entry lexicon --
+        // then pinned and unpinned the buffers of the next one on every call: search mode 225-240 instead of 250-280 MB/s.)
+        while (hc.cached + bytes > host_cache_limit() && !hc.free_blocks.empty()) {
+          auto old = hc.free_blocks.begin();
+          for (auto jt = hc.free_blocks.begin(); jt != hc.free_blocks.end(); ++jt)
+            if (hc.freed_at[jt->second] < hc.freed_at[old->second]) old = jt;
+          hc.cached -= old->first;
+          evicted.push_back(old->second);
+          hc.freed_at.erase(old->second);
+          hc.live.erase(old->second);
+          hc.free_blocks.erase(old);
+        }
         hc.free_blocks.emplace(bytes, p);
+        hc.freed_at[p] = ++hc.clock;
         hc.cached += bytes;
-        return;
+        known = false;  // (cached: nothing to release below)
+        p = nullptr;
+      } else {
+        hc.live.erase(it);
       }
-      hc.live.erase(it);
     }
   }
+  for (void* q : evicted) (void)hipHostFree(q);
+  if (!p) return;
   if (known && pinned) (void)hipHostFree(p);
   else free(p);  // a malloc block (also: rows assembled by anx_find_variants_batch from several device batches)
 }
@@ -288,6 +333,7 @@ static void host_cache_trim() {
     std::lock_guard<std::mutex> g(hc.mu);
     for (auto& kv : hc.free_blocks) { drop.push_back(kv.second); hc.live.erase(kv.second); }
     hc.free_blocks.clear();
+    hc.freed_at.clear();
     hc.cached = 0;
   }
   for (void* p : drop) (void)hipHostFree(p);
