@@ -139,7 +139,7 @@ void build_adjacency(const LexiconImage& img, int closure, size_t budget_bytes, 
   out.rows = 0; out.records = 0; out.nsig_closure = out.nsig_kept = 0;
   out.nsig_lexicon = img.nsigs;
   if (img.nsym > 32 || img.nsigs == 0 || img.cls_bits.empty()) return;  // the bit-plane scan only
-  closure = std::max(0, std::min(closure, 2));
+  closure = std::max(0, std::min(closure, kAdjMaxClosure));
   threads = std::max(1u, threads);
   int ng = 1;
   for (uint8_t g : img.sym_group) ng = std::max(ng, (int)g + 1);

@@ -20,6 +20,8 @@ struct LexiconImage;
 
 constexpr int kAdjRadius = 3;             // lists hold the ball of this radius; tiles with k <= kAdjRadius use the sections |lc - lq| <= k
 constexpr int kAdjSections = 2 * kAdjRadius + 1;
+constexpr int kAdjMaxClosure = 2;         // lists are built for signatures within 0..kAdjMaxClosure of a lexicon signature: ONE clamp for the switch parser,
+                                          // the host builder (the device builder's test reference) and the device builder
 constexpr uint32_t kAdjRow = 64;          // records per row (one wave)
 
 struct AdjHdr {        // 32 bytes, read with scalar loads

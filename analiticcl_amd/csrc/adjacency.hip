@@ -227,7 +227,7 @@ int adjacency_build_device(DeviceLexicon* d, const LexiconImage& img, int closur
   stats.nsig_closure = stats.nsig_kept = 0;
   stats.records = stats.rows = stats.rows_wanted = 0;
   if (img.nsym > 32 || img.nsigs == 0 || !d->sighash_e) return ANX_OK;
-  closure = std::max(0, std::min(closure, 3));
+  closure = std::max(0, std::min(closure, kAdjMaxClosure));
   if (!d->ball_n[kAdjRadius] || !d->ball_n[closure] || !d->ball_n[1]) return ANX_OK;  // (a ball too large to enumerate: no lists)
   HIP_TRY(hipSetDevice(d->device));
   hipStream_t st = nullptr;  // the NULL stream: model set-up, nothing else runs

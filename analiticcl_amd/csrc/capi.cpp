@@ -1637,7 +1637,8 @@ struct anx_pipeline {
   bool stop = false;
   uint64_t next_seq = 0;
   void* streams[2] = {nullptr, nullptr};
-  void* enc_stream = nullptr;  // the encode thread's own stream (single-replica models)
+  void* enc_stream = nullptr;  // the encode thread's own stream (single-replica models; highest stream priority)
+  int running = 0;             // runs launched and not yet waited for (at most 2: the scan of one under the tail of the other)
   std::thread th[3];
 };
 static void pipeline_stage(anx_pipeline* pl, int stage) {
@@ -1658,9 +1659,26 @@ static void pipeline_stage(anx_pipeline* pl, int stage) {
       if (stage == 0) {
         job->b = anx_batch_encode_packed(pl->m, job->blob, job->blob_len, job->n, &job->p);
         if (!job->b) { job->rc = g_code ? g_code : ANX_EINVAL; job->err = g_err; }
+        else {
+          // The run is ENQUEUED by this thread, as soon as the batch is encoded and fewer than two runs are in flight; the run thread
+          // only waits (round 5: the run thread launched job i + 1 after it had waited for job i -- the device idled for the length
+          // of a launch sequence and a wake-up between any two runs).
+          {
+            std::unique_lock<std::mutex> lk(pl->mu);
+            pl->cv.wait(lk, [&]() { return pl->stop || pl->running < 2; });
+            ++pl->running;
+          }
+          job->rc = anx_batch_run_async(pl->m, job->b, pl->streams[job->seq & 1]);
+          if (job->rc) {
+            job->err = g_err;
+            std::lock_guard<std::mutex> lk(pl->mu);
+            --pl->running;
+          }
+        }
       } else if (stage == 1) {
-        job->rc = anx_batch_run(pl->m, job->b, pl->streams[job->seq & 1]);
+        job->rc = anx_batch_wait(pl->m, job->b);
         if (job->rc) job->err = g_err;
+        { std::lock_guard<std::mutex> lk(pl->mu); --pl->running; }
       } else {
         job->rc = anx_batch_fetch_compact(job->b, &job->rows, &job->offs);
         if (job->rc) job->err = g_err;
@@ -1688,7 +1706,7 @@ anx_pipeline* anx_pipeline_new(const anx_model* m, int depth) {
   pl->depth = depth > 0 ? (size_t)depth : 6;
   if (m->replicas.size() == 1) {  // a multi-replica model runs every shard on its replica's own stream
     std::string err;
-    pl->enc_stream = anx::stream_create(m->replicas[0].device, err);  // (nullptr: the encoder's pooled streams)
+    pl->enc_stream = anx::stream_create(m->replicas[0].device, err, true);  // (nullptr: the encoder's pooled streams)
     for (void*& st : pl->streams)
       if (!(st = anx::stream_create(m->replicas[0].device, err))) {
         for (void* x : pl->streams) if (x) anx::stream_destroy(m->replicas[0].device, x);

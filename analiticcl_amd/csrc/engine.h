@@ -27,7 +27,7 @@ bool kernel_timer_read(const char* name, double* total_ms, uint64_t* launches); 
 void device_pool_trim(int device);  // hands the cached scratch blocks of the device (and the pinned result buffers) back to the driver
 // result rows of batch_fetch live in cached pinned host buffers: release them with host_result_free (falls back to free())
 // a non-blocking stream on `device` for a replica of a multi-device model (hipStream_t behind void*)
-void* stream_create(int device, std::string& err);
+void* stream_create(int device, std::string& err, bool high_priority = false);  // high_priority: see engine.hip make_stream
 void stream_destroy(int device, void* stream);
 void* host_result_alloc(size_t bytes);
 void host_result_free(void* p);

@@ -48,6 +48,12 @@ namespace anx {
 // ------------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------------
+// layout of the pinned block a run reads back into (Batch::h_read), in uint32 words
+enum { HR_RCTR = 0, HR_SCTR = SCAN_REGIONS * RC_STRIDE, HR_LCTR = 2 * SCAN_REGIONS * RC_STRIDE, HR_CTR = 5 * SCAN_REGIONS * RC_STRIDE,
+       HR_TOTAL_SURV = HR_CTR + CTR_N, HR_TOTAL_RESULTS = HR_TOTAL_SURV + 1, HR_CONF = HR_TOTAL_RESULTS + 1 /* 2 words */, HR_N = HR_CONF + 2 };
+constexpr size_t HR_COLD_OFF = (HR_N * sizeof(uint32_t) + 63) & ~(size_t)63;  // byte offset of the FsCold staging copy in Batch::h_read
+static void shells_destroy(int device);
+
 int device_count(std::string& err) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -74,6 +80,7 @@ struct DevPool {
   std::vector<hipStream_t> idle_streams;           // non-blocking streams of the device-side encoder, handed out per call
   hipStream_t run_streams[2] = {nullptr, nullptr}; // the library's own streams for asynchronous runs (batch_run_async)
   unsigned run_counter = 0;
+  std::vector<BatchShell> shells;                  // events + pinned read-back blocks of freed batches (batch_free), handed to the next batch
 };
 // bytes of freed blocks kept per device (MI355X: 288 GB HBM; a 1 M-query batch holds 3-6 GB of scratch).  ANX_POOL_CACHE_MB
 // overrides the default; anx_device_pool_trim() hands the cache back to the driver at any time.
@@ -95,6 +102,21 @@ DevPool& pool_of(int device) {
 // A thread may bring its own encoder stream (anx_pipeline's encode thread: created together with the pipeline's run streams, so that
 // the runtime's least-used-hardware-queue rule puts the three on different queues -- see anx_pipeline_new).
 static thread_local hipStream_t t_encoder_stream = nullptr;
+// A non-blocking stream on the current device.  high = the device's highest stream priority: the encoder of batch i + 1 (and search
+// mode's lattice-build kernels) are chains of ~45 short dependent launches that run beside the scan / scoring kernels of batch i --
+// tens of thousands of waves queued on streams of normal priority; at equal priority every launch of the chain waits its turn behind
+// them (round 5: the encoder "under" a run took the run's length), at high priority the dispatcher serves its few workgroups first.
+// ANX_ENC_PRIORITY=0: normal priority (A/B).
+void* make_stream(bool high) {
+  hipStream_t s = nullptr;
+  int least = 0, greatest = 0;
+  if (high && switches().enc_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least) {
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) == hipSuccess) return s;
+    (void)hipGetLastError();
+  }
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return s;
+}
 void encoder_stream_set_override(void* s) { t_encoder_stream = reinterpret_cast<hipStream_t>(s); }
 hipStream_t encoder_stream_acquire(int device) {
   if (t_encoder_stream) return t_encoder_stream;
@@ -103,9 +125,7 @@ hipStream_t encoder_stream_acquire(int device) {
     std::lock_guard<std::mutex> g(pl.mu);
     if (!pl.idle_streams.empty()) { hipStream_t s = pl.idle_streams.back(); pl.idle_streams.pop_back(); return s; }
   }
-  hipStream_t s = nullptr;
-  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }  // NULL stream: still correct
-  return s;
+  return static_cast<hipStream_t>(make_stream(true));  // nullptr = the NULL stream: still correct
 }
 void encoder_stream_release(int device, hipStream_t s) {
   if (!s || s == t_encoder_stream) return;
@@ -136,11 +156,11 @@ void thread_stream_end(int device, void* s) {
   encoder_stream_release(device, reinterpret_cast<hipStream_t>(s));
 }
 // streams of the replicas of a multi-device model (capi.cpp owns them; HIP stays behind this file)
-void* stream_create(int device, std::string& err) {
+void* stream_create(int device, std::string& err, bool high_priority) {
   DeviceGuard guard;
-  hipStream_t s = nullptr;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
-    err = std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(hipGetLastError());
+  void* s = nullptr;
+  if (hipSetDevice(device) != hipSuccess || !(s = make_stream(high_priority))) {
+    err = std::string("hipStreamCreate: ") + hipGetErrorString(hipGetLastError());
     return nullptr;
   }
   return s;
@@ -233,6 +253,7 @@ static void pool_trim(int device) {
     pl.cached = 0;
   }
   for (void* d : drop) (void)hipFree(d);
+  shells_destroy(device);
 }
 // Pinned host buffers for the downloaded results.  A fresh malloc'd buffer of 141 MB (1 M queries of config 2) is pageable and
 // untouched: the D2H copy is staged and page-faults its way through it (~20 ms); a pinned buffer takes the rows at PCIe speed.
@@ -515,6 +536,15 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, c
     return nullptr;
   }
   d->alpha.nlower = (uint32_t)(et.lower.size() / 2);
+  {  // x / L for x, L <= 32 as the host's IEEE division computes it (ScoreArgs::quot; until round 5 uploaded again with every batch)
+    std::vector<double> quot(33 * 33, 0.0);
+    for (int x = 0; x <= 32; ++x)
+      for (int L = 1; L <= 32; ++L) {
+        volatile double num = (double)x, den = (double)L;  // a real division at run time, as the reference does
+        quot[(size_t)x * 33 + L] = num / den;
+      }
+    if ((rc = upload(&d->quot, quot.data(), quot.size(), err, &d->bytes))) { lexicon_free(d); return nullptr; }
+  }
   if (adj && !adj->hash.empty() && img.nsym <= 32) {  // signature adjacency lists (adjacency.h): streamed by the bit-plane scan
     static_assert(sizeof(AdjSlot) == sizeof(uint4) && sizeof(AdjHdr) == 32 && sizeof(AdjPlanes) == sizeof(uint2), "adjacency records");
     if ((rc = upload(reinterpret_cast<AdjSlot**>(&d->adj_hash), adj->hash.data(), adj->hash.size(), err, &d->bytes)) ||
@@ -546,7 +576,7 @@ void lexicon_free(DeviceLexicon* d) {
                   (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin,
-                  (void*)d->adj_hash, (void*)d->adj_hdr, (void*)d->adj_planes, (void*)d->adj_ids})
+                  (void*)d->adj_hash, (void*)d->adj_hdr, (void*)d->adj_planes, (void*)d->adj_ids, (void*)d->quot})
     if (p) pool_free(p);
   conf_free(d->dconf);
   lm_free(d->dlm);
@@ -863,30 +893,61 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
   return ANX_OK;
 }
 
-// what every batch needs besides its query arrays: counters, per-query accumulators, the quotient table, events
+// events + pinned read-back block of a batch: from the device's pool of shells (freed batches), created when the pool is empty
+static int shell_acquire(Batch* b, std::string& err) {
+  DevPool& pl = pool_of(b->device);
+  BatchShell sh;
+  bool have = false;
+  {
+    std::lock_guard<std::mutex> g(pl.mu);
+    if (!pl.shells.empty()) { sh = pl.shells.back(); pl.shells.pop_back(); have = true; }
+  }
+  if (!have) {
+    for (auto& e : sh.ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreate(&sh.ev_fs0));
+    HIP_TRY(hipEventCreate(&sh.ev_fs1));
+    HIP_TRY(hipEventCreate(&sh.ev_scan0));
+    HIP_TRY(hipEventCreate(&sh.ev_done));
+    HIP_TRY(hipEventCreateWithFlags(&sh.ev_in, hipEventDisableTiming));
+    // pinned: the counters the run reads back, and behind them the staging copy of FsCold (a pageable source would make the host
+    // wait, in stream order behind the scan just enqueued, until the copy has been staged)
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_read), HR_COLD_OFF + sizeof(FsCold), hipHostMallocDefault));
+  }
+  for (int i = 0; i < 6; ++i) b->ev[i] = sh.ev[i];
+  b->ev_fs0 = sh.ev_fs0; b->ev_fs1 = sh.ev_fs1; b->ev_scan0 = sh.ev_scan0; b->ev_done = sh.ev_done; b->ev_in = sh.ev_in; b->h_read = sh.h_read;
+  return ANX_OK;
+}
+static void shell_release(Batch* b) {
+  if (!b->ev_done) return;  // never acquired (an encode that failed early)
+  BatchShell sh;
+  for (int i = 0; i < 6; ++i) { sh.ev[i] = b->ev[i]; b->ev[i] = nullptr; }
+  sh.ev_fs0 = b->ev_fs0; sh.ev_fs1 = b->ev_fs1; sh.ev_scan0 = b->ev_scan0; sh.ev_done = b->ev_done; sh.ev_in = b->ev_in; sh.h_read = b->h_read;
+  b->ev_fs0 = b->ev_fs1 = b->ev_scan0 = b->ev_done = b->ev_in = nullptr; b->h_read = nullptr;
+  DevPool& pl = pool_of(b->device);
+  std::lock_guard<std::mutex> g(pl.mu);
+  pl.shells.push_back(sh);
+}
+static void shells_destroy(int device) {  // (the current device is `device`)
+  DevPool& pl = pool_of(device);
+  std::vector<BatchShell> drop;
+  { std::lock_guard<std::mutex> g(pl.mu); drop.swap(pl.shells); }
+  for (BatchShell& sh : drop) {
+    for (auto& e : sh.ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {sh.ev_fs0, sh.ev_fs1, sh.ev_scan0, sh.ev_done, sh.ev_in}) if (e) (void)hipEventDestroy(e);
+    if (sh.h_read) (void)hipHostFree(sh.h_read);
+  }
+}
+
+// what every batch needs besides its query arrays: counters, per-query accumulators, events
 static int encode_tail(Batch* b, std::string& err) {
   const size_t nq = b->nq;
   int rc;
   const size_t nblk = (nq + SCAN_TILE - 1) / SCAN_TILE + 2;
-  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->lctr, 3 * SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->quot, 33 * 33, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
+  if ((rc = dalloc(&b->counters, CTR_N, err)) || (rc = dalloc(&b->rctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->sctr, SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->lctr, 3 * SCAN_REGIONS * RC_STRIDE, err)) || (rc = dalloc(&b->qexpand, nq, err)) || (rc = dalloc(&b->qsurv, nq, err)) ||
       (rc = dalloc(&b->soff, nq + 1, err)) || (rc = dalloc(&b->qcur, nq, err)) || (rc = dalloc(&b->qmaxfreq, nq, err)) ||
       (rc = dalloc(&b->scan_tmp, nblk, err)) || (rc = dalloc(&b->r_count, nq, err)) || (rc = dalloc(&b->r_off, nq + 1, err)))
     return rc;
-  {
-    std::vector<double> quot(33 * 33, 0.0);
-    for (int x = 0; x <= 32; ++x)
-      for (int L = 1; L <= 32; ++L) {
-        volatile double num = (double)x, den = (double)L;  // a real division at run time, as the reference does
-        quot[(size_t)x * 33 + L] = num / den;
-      }
-    HIP_TRY(hipMemcpy(b->quot, quot.data(), quot.size() * sizeof(double), hipMemcpyHostToDevice));
-  }
-  for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
-  HIP_TRY(hipEventCreate(&b->ev_fs0));
-  HIP_TRY(hipEventCreate(&b->ev_fs1));
-  HIP_TRY(hipEventCreate(&b->ev_scan0));
-  HIP_TRY(hipEventCreate(&b->ev_done));
-  return ANX_OK;
+  return shell_acquire(b, err);
 }
 
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
@@ -1113,15 +1174,52 @@ static int ensure_surv(Batch* b, size_t cap, std::string& err) {
 // (wait for the read-back, check the capacities the launch assumed, statistics).  The launch sizes its grids and buffers from the
 // previous run of the batch (first run: estimates); every kernel bounds-checks its appends, the fills come back with the one
 // read-back at the end, and a run whose assumptions did not hold is repeated with the measured sizes.
-enum { HR_RCTR = 0, HR_SCTR = SCAN_REGIONS * RC_STRIDE, HR_LCTR = 2 * SCAN_REGIONS * RC_STRIDE, HR_CTR = 5 * SCAN_REGIONS * RC_STRIDE,
-       HR_TOTAL_SURV = HR_CTR + CTR_N, HR_TOTAL_RESULTS = HR_TOTAL_SURV + 1, HR_CONF = HR_TOTAL_RESULTS + 1 /* 2 words */, HR_N = HR_CONF + 2 };
-constexpr size_t HR_COLD_OFF = (HR_N * sizeof(uint32_t) + 63) & ~(size_t)63;  // byte offset of the FsCold staging copy in Batch::h_read
 
 // ANX_CAP_DIV=n (tests): the first-run capacity ESTIMATES are divided by n, so that the overflow -> regrow -> repeat path runs
 static size_t cap_div() { return (size_t)switches().cap_div; }
 
 // k_rank<true> for models without variant lists at freq_weight == 0, k_rank<false> otherwise (ra = the RankArgs of the launch)
 #define ANX_RANK_LAUNCH(...) do { if (!ra.any_variants && ra.freq_weight == 0.0f) hipLaunchKernelGGL(k_rank<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_rank<false>, __VA_ARGS__); } while (0)
+// ---- sizes carried from batch to batch (RunHints, kernels_common.hpp) ----------------------------------------------------------------
+static bool same_threshold(const anx_threshold& a, const anx_threshold& b) { return a.kind == b.kind && a.value == b.value && a.ratio == b.ratio; }
+static bool hints_match(const RunHints& h, const Batch* b) {
+  return h.valid && same_threshold(h.kth, b->params.max_anagram_distance) && same_threshold(h.dth, b->params.max_edit_distance) &&
+         h.score_threshold == b->params.score_threshold && h.stop == (b->params.stop_at_exact_match ? 1 : 0);
+}
+// first launch of a batch: fills per region / rows per query of the last finished batch of the same parameters, scaled to this batch's
+// queries, + 25 %.  Only ever SHRINKS what the worst-case estimates would take.
+static void hints_apply(const DeviceLexicon* dl, Batch* b) {
+  if (b->runs_finished || b->hinted || b->prev_maxfill || !switches().hints || switches().cap_div != 1 || b->nq < 4096) return;
+  RunHints& h = dl->hints;
+  std::lock_guard<std::mutex> g(h.mu);
+  if (!hints_match(h, b)) return;
+  const double nq = (double)b->nq, m = 1.25;
+  const double worst_fill = (nq * 140.0 + (double)b->ntiles * SCAN_CHUNK) / SCAN_REGIONS + 4096.0;
+  const double fill = h.maxfill * nq * m + 8192.0;
+  if (fill >= worst_fill) return;
+  b->prev_maxfill = (uint32_t)fill;
+  b->prev_surv_fill = (uint32_t)(h.surv_fill * nq * m + 1024.0);
+  b->prev_list_fill = h.list_fill > 0 ? (uint32_t)(h.list_fill * nq * m + 1024.0) : 0u;
+  b->hint_rows = (size_t)std::min(nq * 16.0 + 1024.0, h.total_surv * nq * m + 4096.0);
+  b->hinted = true;
+}
+// a first run that stood: what it measured, per query (a running maximum that decays: alternating kinds of batches -- search mode's
+// unigram and higher-order batches -- keep the larger one's sizes)
+static void hints_record(const DeviceLexicon* dl, const Batch* b, uint32_t maxfill, uint32_t surv_fill, uint32_t list_fill, uint32_t total_surv) {
+  if (b->nq < 4096 || !switches().hints) return;
+  RunHints& h = dl->hints;
+  std::lock_guard<std::mutex> g(h.mu);
+  const double nq = (double)b->nq, decay = hints_match(h, b) ? 0.9 : 0.0;
+  h.maxfill = std::max(maxfill / nq, h.maxfill * decay);
+  h.surv_fill = std::max(surv_fill / nq, h.surv_fill * decay);
+  h.list_fill = std::max(list_fill / nq, h.list_fill * decay);
+  h.total_surv = std::max(total_surv / nq, h.total_surv * decay);
+  h.kth = b->params.max_anagram_distance; h.dth = b->params.max_edit_distance; h.score_threshold = b->params.score_threshold;
+  h.stop = b->params.stop_at_exact_match ? 1 : 0;
+  h.nq = nq;
+  h.valid = true;
+}
+
 static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, std::string& err) {
   if (!dl) { err = "model is not resident on a device"; return ANX_ENODEVICE; }
   if (b->nq >= (1u << 27) || dl->nentries >= (1u << 26)) { err = "more than 2^27 queries per batch or 2^26 lexicon entries (32-bit record offsets, packed pair records)"; return ANX_ELIMIT; }
@@ -1140,11 +1238,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   if (nq == 0) { b->ran = true; return ANX_OK; }
   const int stop = b->params.stop_at_exact_match ? 1 : 0;
   int rc;
+  hints_apply(dl, b);
+  if (b->raw_cap == 0 && b->hinted && (rc = ensure_raw(b, (size_t)b->prev_maxfill + (b->prev_maxfill >> 3) + 4096, err))) return rc;
   if (b->raw_cap == 0 && (rc = ensure_raw(b, (nq * (size_t)140 + (size_t)b->ntiles * SCAN_CHUNK) / SCAN_REGIONS / cap_div() + 4096, err)))
     return rc;
-  // pinned: the counters the run reads back, and behind them the staging copy of FsCold (a pageable source would make the host
-  // wait, in stream order behind the scan just enqueued, until the copy has been staged)
-  if (!b->h_read) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_read), HR_COLD_OFF + sizeof(FsCold), hipHostMallocDefault));
   const uint32_t region_cap = 1u << b->region_shift;
   // slots per region the scoring grid covers: the previous fill + 1/8 (first run: the whole region; blocks beyond a region's
   // fill return at once)
@@ -1203,7 +1300,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
 #ifdef ANX_DEBUG_SWITCHES
   { const char* e = getenv("ANX_SCORE_DBG"); sa.dbg = e ? atoi(e) : 0; }
 #endif
-  sa.quot = b->quot;
+  sa.quot = dl->quot;
   sa.store_pairs = b->keep_all_pairs ? 1 : 0;
   if (sa.store_pairs && (rc = ensure_pair_outputs(b, err))) return rc;
   sa.w_ld = m.weights.ld; sa.w_lcs = m.weights.lcs; sa.w_prefix = m.weights.prefix; sa.w_suffix = m.weights.suffix;
@@ -1349,7 +1446,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
   } else {
     // No host round trip between scoring and ranking: the row buffers keep the size of the previous run (first run:
     // an estimate), the kernels check the total on the device, and batch_finish repeats the run if it did not fit.
-    if (b->surv_cap == 0 && (rc = ensure_surv(b, (size_t)nq * 16 / cap_div() + 1024, err))) return rc;
+    if (b->surv_cap == 0 && (rc = ensure_surv(b, b->hint_rows ? b->hint_rows : (size_t)nq * 16 / cap_div() + 1024, err))) return rc;
     const uint32_t row_cap = (uint32_t)std::min<size_t>(b->surv_cap, 0xFFFFFFFFu);
     hipLaunchKernelGGL(k_compact_grouped, dim3(COMPACT_P * SCAN_REGIONS), dim3(COMPACT_B), 0, st, b->surv, b->sctr,
                        (uint32_t)b->surv_region_cap, m.have_freq ? 1 : 0, b->qcur, dl->ent_rec, b->c_rows, b->soff + nq, row_cap,
@@ -1431,7 +1528,8 @@ static int batch_finish(const HostModel& m, const DeviceLexicon* dl, Batch* b, b
   b->prev_maxfill = std::max(b->prev_maxfill, maxfill);
   b->prev_surv_fill = std::max(b->prev_surv_fill, surv_fill);
   b->prev_list_fill = std::max(b->prev_list_fill, list_fill);
-  if (again) { *retry = true; return ANX_OK; }
+  if (again) { *retry = true; b->runs_finished++; return ANX_OK; }
+  if (b->runs_finished++ == 0) hints_record(dl, b, maxfill, surv_fill, list_fill, total_surv);
   if (maxfill == 0) b->n_raw = 0;
   b->n_pairs = n_valid - h[HR_CTR + CTR_SKIPPED];
   b->n_surv = total_surv;
@@ -1483,7 +1581,6 @@ int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void*
       s = slot;
     }
     if (s) {
-      if (!b->ev_in) HIP_TRY(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
       HIP_TRY(hipEventRecord(b->ev_in, reinterpret_cast<hipStream_t>(stream)));
       HIP_TRY(hipStreamWaitEvent(s, b->ev_in, 0));
       use = s;
@@ -1805,20 +1902,13 @@ void batch_free(Batch* b) {
   // before the blocks go back to the pool, where another batch / thread / stream may take them at once
   if (b->async_pending) (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(b->async_stream));
   if (b->launched) (void)hipEventSynchronize(b->ev_done);  // a run enqueued with batch_run_async and never waited for
-  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv, (void*)b->quot,
+  for (void* p : {(void*)b->q_cv, (void*)b->q_bits, (void*)b->q_rows, (void*)b->q_rec, (void*)b->q_meta, (void*)b->q_orig, (void*)b->d_tiles, (void*)b->rctr, (void*)b->sctr, (void*)b->surv,
                   (void*)b->counters, (void*)b->qexact, (void*)b->qsurv, (void*)b->soff, (void*)b->qcur,
                   (void*)b->qmaxfreq, (void*)b->d_cold, (void*)b->qpairs, (void*)b->x_cnt, (void*)b->x_tmp, (void*)b->scan_tmp, (void*)b->raw, (void*)b->p_score, (void*)b->p_meta, (void*)b->list8, (void*)b->listg, (void*)b->listw, (void*)b->lctr,
                   (void*)b->c_rows, (void*)b->qexpand, (void*)b->r_rows, (void*)b->t_key, (void*)b->r_count, (void*)b->r_off,
                   (void*)b->d_text, (void*)b->d_textoff, (void*)b->cf_weight, (void*)b->cf_need, (void*)b->cf_ctr, b->cf_work, (void*)b->cf_sort, b->cf_sort_tmp})
     if (p) pool_free(p);
-  for (auto& e : b->ev)
-    if (e) (void)hipEventDestroy(e);
-  if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
-  if (b->ev_done) (void)hipEventDestroy(b->ev_done);
-  if (b->ev_in) (void)hipEventDestroy(b->ev_in);
-  if (b->h_read) (void)hipHostFree(b->h_read);
-  if (b->ev_fs0) (void)hipEventDestroy(b->ev_fs0);
-  if (b->ev_fs1) (void)hipEventDestroy(b->ev_fs1);
+  shell_release(b);  // events + pinned read-back block: to the device's pool (hipHostFree / hipEventDestroy here would wait for the device)
   delete b;
 }
 

@@ -1,5 +1,6 @@
 // host_model.cpp -- see host_model.h.  Host-only code (no HIP here).
 #include "host_model.h"
+#include "adjacency.h"
 
 #include <sched.h>
 
@@ -444,7 +445,9 @@ const SwitchDef kSwitches[] = {
     {"ANX_SCAN_TQ", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.scan_tq = x >= 1 && x <= 64 ? x : 0; }},
     {"ANX_SCAN_ADJ", [](Switches& s, const char* v) { s.scan_adj = flag01(v, 1); }},
     {"ANX_ADJ_BUILD", [](Switches& s, const char* v) { s.adj_build_host = v && strcmp(v, "host") == 0; }},
-    {"ANX_ADJ_CLOSURE", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 2; s.adj_closure = x >= 0 && x <= 3 ? x : 2; }},
+    {"ANX_ADJ_CLOSURE", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 2; s.adj_closure = x >= 0 && x <= kAdjMaxClosure ? x : kAdjMaxClosure; }},
+    {"ANX_ENC_PRIORITY", [](Switches& s, const char* v) { s.enc_priority = flag01(v, 1); }},
+    {"ANX_HINTS", [](Switches& s, const char* v) { s.hints = flag01(v, 1); }},
     {"ANX_ADJ_MB", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.adj_budget_mb = x > 0 ? x : 16384; }},
     {"ANX_SIG_GROUPS", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.sig_groups = x >= 1 && x <= 8 ? x : 0; }},
     {"ANX_PREFILTER", [](Switches& s, const char* v) { s.prefilter = flag01(v, 1); }},

@@ -53,6 +53,26 @@ struct DevAlphabet {  // tables of the device-side query encoder (encode.hip), d
   uint32_t* siglen_begin = nullptr;  // [kMaxSymbols + 2] signature range per charcount
 };
 
+// What a batch needs from the runtime besides device memory: its events and the pinned block its run reads back into.  Creating and
+// destroying them per batch costs more than it looks -- hipHostFree waits for the DEVICE to go idle: a batch freed while the next one
+// was running serialised the two (round 5: the step with the encoder inside, 3.56 ms, was encode + run back to back, never
+// overlapped).  Freed batches hand theirs to the device's pool (engine.hip DevPool::shells); device_pool_trim releases them.
+struct BatchShell {
+  hipEvent_t ev[6] = {};
+  hipEvent_t ev_scan0 = nullptr, ev_fs0 = nullptr, ev_fs1 = nullptr, ev_done = nullptr, ev_in = nullptr;
+  uint32_t* h_read = nullptr;
+};
+// Sizes of the last finished first run on this replica, per query: the next batch of the same parameters sizes its pair list, its
+// scoring grid and its survivor buffers from them (with a margin) instead of from worst-case estimates.  A wrong guess costs what a
+// wrong estimate always cost: the run is repeated with the measured sizes (batch_finish).
+struct RunHints {
+  std::mutex mu;
+  bool valid = false;
+  anx_threshold kth = {}, dth = {};
+  double score_threshold = 0.0;
+  int stop = 0;
+  double nq = 0, maxfill = 0, surv_fill = 0, list_fill = 0, total_surv = 0;
+};
 struct DeviceLexicon {
   int device = 0;
   int nplanes = 0;      // count-vector dwords (SAD path)
@@ -96,6 +116,8 @@ struct DeviceLexicon {
   uint4* rows = nullptr;
   DevAlphabet alpha;
   size_t bytes = 0;
+  double* quot = nullptr;              // [33][33] IEEE quotients x / L computed on the host (ScoreArgs::quot)
+  mutable RunHints hints;
   mutable struct DeviceLm* dlm = nullptr;      // bigram terms + token lists of the vocabulary (lattice.hip), built on first use
   mutable struct DeviceConf* dconf = nullptr;  // confusable patterns + vocabulary texts of this replica (conf.hip), built on first use
 };
@@ -181,7 +203,6 @@ struct Batch {
   uint32_t* lctr = nullptr;        // [3][SCAN_REGIONS][RC_STRIDE] their fills
   size_t list_cap = 0;             // slots per region in list8 / listg
   size_t raw_cap = 0;
-  double* quot = nullptr;          // table of IEEE quotients x / L (ScoreArgs::quot)
   SurvRec* surv = nullptr;         // survivor records in SCAN_REGIONS regions of surv_region_cap (order arbitrary)
   uint32_t* sctr = nullptr;        // [SCAN_REGIONS][RC_STRIDE] fill of every survivor region
   size_t surv_region_cap = 0;
@@ -212,6 +233,9 @@ struct Batch {
   bool launched = false;           // a run is enqueued and not yet finished
   uint32_t fill_cap_launched = 0;  // slots per region the scoring grid of the launched run covers
   uint32_t prev_maxfill = 0, prev_surv_fill = 0, prev_list_fill = 0;  // largest fills seen by earlier runs of this batch
+  bool hinted = false;             // ... or taken from the replica's RunHints (first run)
+  size_t hint_rows = 0;            // candidate rows of the whole batch the hints expect (0: none)
+  int runs_finished = 0;
   anx_batch_stats stats = {};
 };
 
