@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("ANX_LIB") or os.path.join(HERE, "libanx.so")  # ANX_L
 
 ANX_OK, ANX_EINVAL, ANX_EIO, ANX_ENOTBUILT, ANX_ENODEVICE, ANX_ELIMIT, ANX_EEMPTY = 0, -1, -2, -3, -4, -5, -6
 ANX_NO_VIA = 0xFFFFFFFFFFFFFFFF
-ABI_VERSION = 2  # include/anx.h ANX_ABI_VERSION these ctypes signatures were written against (checked when the library is loaded)
+ABI_VERSION = 3  # include/anx.h ANX_ABI_VERSION these ctypes signatures were written against (checked when the library is loaded)
 
 
 class AnxError(RuntimeError):
@@ -167,6 +167,8 @@ def lib():
         "anx_batch_encode_packed": (vp, [vp, C.c_char_p, sz, sz, C.POINTER(Params)]),
         "anx_batch_gather_compact": (C.c_int, [vp, C.c_int, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
         "anx_batch_encode_packed_device": (vp, [vp, vp, sz, sz, C.POINTER(Params)]),
+        "anx_batch_encode_packed_device_on": (vp, [vp, vp, sz, sz, C.POINTER(Params), vp]),
+        "anx_debug_search_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
         "anx_batch_run": (C.c_int, [vp, vp, vp]),
         "anx_batch_run_async": (C.c_int, [vp, vp, vp]),
         "anx_batch_wait": (C.c_int, [vp, vp]),

@@ -282,6 +282,13 @@ int adjacency_build_device(DeviceLexicon* d, const LexiconImage& img, int closur
   for (uint32_t k = 0; k < nk; ++k) want += hcum[(size_t)k * 8 + kAdjSections];
   stats.rows_wanted = want;
   std::vector<uint8_t> keep(nk, 1);
+  {  // the lists are an accelerator, not a requirement: never more than 60 % of what the device has free right now (the build's own
+     // transient buffers above are allocated already, so they are counted), whatever ANX_ADJ_MB says -- a busier or smaller device,
+     // or many replicas on one device, get fewer lists instead of a failed model load
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget_bytes = std::min<size_t>(budget_bytes, free_b / 10 * 6);
+    else (void)hipGetLastError();
+  }
   if (want * row_bytes > budget_bytes) {
     std::vector<uint32_t> ord(nk);
     for (uint32_t k = 0; k < nk; ++k) ord[k] = k;
@@ -350,6 +357,7 @@ int adjacency_build_device(DeviceLexicon* d, const LexiconImage& img, int closur
   if ((rc = own((void**)&d->adj_planes, rows * kAdjRow * sizeof(uint2))) || (rc = own((void**)&d->adj_ids, rows * kAdjRow * 4)) ||
       (rc = own((void**)&d->adj_hdr, (size_t)std::max<uint32_t>(nkept, 1) * 32)))
     return rc;
+  if (switches().adj_fail) { err = "injected failure (ANX_ADJ_FAIL)"; return ANX_ENODEVICE; }
   a.planes = d->adj_planes; a.ids = d->adj_ids;
   hipLaunchKernelGGL(k_adjb_fill, dim3((nk + 3) / 4), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_adjb_hdr, dim3((nk + 255) / 256), dim3(256), 0, st, a, d_hidx, d->adj_hdr);

@@ -1131,7 +1131,14 @@ anx_batch* anx_batch_encode(const anx_model* m, const char* const* utf8, size_t 
   }
   return h;
 }
+static anx_batch* encode_packed_device(const anx_model* m, const void* device_blob, size_t blob_len, size_t n, const anx_params* p, bool ordered, void* stream);
 anx_batch* anx_batch_encode_packed_device(const anx_model* m, const void* device_blob, size_t blob_len, size_t n, const anx_params* p) {
+  return encode_packed_device(m, device_blob, blob_len, n, p, false, nullptr);
+}
+anx_batch* anx_batch_encode_packed_device_on(const anx_model* m, const void* device_blob, size_t blob_len, size_t n, const anx_params* p, void* stream) {
+  return encode_packed_device(m, device_blob, blob_len, n, p, true, stream);
+}
+static anx_batch* encode_packed_device(const anx_model* m, const void* device_blob, size_t blob_len, size_t n, const anx_params* p, bool ordered, void* stream) {
   if (!m || (!device_blob && n) || !p) { fail(ANX_EINVAL, "NULL argument"); return nullptr; }
   if (!m->host.built) { fail(ANX_ENOTBUILT, "Model has not been built yet! Call build() first"); return nullptr; }
   if (blob_len >= ((size_t)1 << 32)) { fail(ANX_ELIMIT, "inputs exceed 4 GB per batch: split the batch"); return nullptr; }
@@ -1152,7 +1159,7 @@ anx_batch* anx_batch_encode_packed_device(const anx_model* m, const void* device
   s.replica = 0; s.lo = 0; s.n = n;
   std::string err;
   int code = ANX_OK;
-  s.b = anx::batch_encode_spans(m->host, m->replicas[0].dev, static_cast<const char*>(device_blob), blob_len, nullptr, n, dp, err, &code, dev_conf, true);
+  s.b = anx::batch_encode_spans(m->host, m->replicas[0].dev, static_cast<const char*>(device_blob), blob_len, nullptr, n, dp, err, &code, dev_conf, true, ordered, stream);
   if (!s.b) { fail(code ? code : ANX_ENODEVICE, err); delete h; return nullptr; }
   if (dev_conf) anx::batch_set_run_mode(s.b, dp, m->host.confusables_before_pruning ? 2 : 1);
   return h;

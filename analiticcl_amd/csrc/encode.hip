@@ -556,7 +556,7 @@ int balloc(T** dst, size_t count, std::string& err) {
 // Fills the query and tile arrays of `b` (device) from the packed inputs.  Returns ANX_OK or an error code.
 // off == nullptr: the n strings are the first n NUL-terminated spans of blob[0, blob_len); their offsets are found on the device.
 int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off,
-                        size_t n, const anx_params& p, std::string& err, bool blob_on_device) {
+                        size_t n, const anx_params& p, std::string& err, bool blob_on_device, bool after_stream, void* src_stream) {
   const bool timing = switches().encode_timing != 0;
   double t_prev = 0.0;
   auto tnow = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
@@ -591,6 +591,14 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
       (rc = sc.get(&d_cv, n * (size_t)NP, err)) || (rc = sc.get(&d_key, n, err)) || (rc = sc.get(&d_sig, n, err)) || (rc = sc.get(&d_ctr, 8, err)) ||
       (rc = sc.get(&d_blk, 3 * ((n + 255) / 256), err)))
     return rc;
+  if (after_stream) {  // the caller's stream produced the buffer: this stream reads it behind that work (anx_batch_encode_packed_device_on)
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e1 = hipEventRecord(ev, reinterpret_cast<hipStream_t>(src_stream));
+    if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, ev, 0);
+    (void)hipEventDestroy(ev);  // (released by the runtime once the wait has been satisfied)
+    HIP_TRY(e1);
+  }
   HIP_TRY(hipMemcpyAsync(d_blob, blob, blob_len, blob_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   const int bits_ok = (dl->nsym <= 32 && !switches().scan_sad) ? 1 : 0;
   if (!bits_ok) HIP_TRY(hipMemsetAsync(d_cv, 0, n * (size_t)NP * 4, st));

@@ -43,7 +43,8 @@ Batch* batch_encode(const HostModel& m, const DeviceLexicon* dl, const char* con
 // inputs are the first n NUL-terminated spans of blob[0, blob_bytes) and the device finds their offsets itself
 // blob_on_device: `blob` is device memory of the replica's device (off must be nullptr then): the encoder copies it device to device
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
-                          const anx_params& p, std::string& err, int* code, bool keep_text = false, bool blob_on_device = false);
+                          const anx_params& p, std::string& err, int* code, bool keep_text = false, bool blob_on_device = false,
+                          bool after_stream = false, void* src_stream = nullptr);  // after_stream: the encoder's stream first waits for what src_stream holds now
 // how the following runs treat confusables: conf_mode 0 = not on the device (the caller rescored / has none), 1 = late, 2 = early
 // (src/lib.rs:1591-1595 / :1505-1508); `p` = the parameters those runs use
 void batch_set_run_mode(Batch* b, const anx_params& p, int conf_mode);

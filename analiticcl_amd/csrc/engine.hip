@@ -561,8 +561,16 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, c
   } else if (!adj && dev_closure >= 0 && img.nsym <= 32) {  // built here, on the device, from the tables just uploaded (adjacency.hip)
     AdjIndex local;
     if ((rc = adjacency_build_device(d, img, dev_closure, dev_budget, dev_stats ? *dev_stats : local, err))) {
-      lexicon_free(d);
-      return nullptr;
+      // the lists only accelerate the scan (k_scan_bits probes the ball of a tile without a list): a build that failed -- out of
+      // memory on a busy device, as a rule -- leaves a working replica without lists
+      fprintf(stderr, "[anx] device %d: signature adjacency lists not built (%s): the scan probes every tile's ball itself\n", device, err.c_str());
+      (void)hipGetLastError();
+      for (void** p : {(void**)&d->adj_hash, (void**)&d->adj_hdr, (void**)&d->adj_planes, (void**)&d->adj_ids})
+        if (*p) { pool_free(*p); *p = nullptr; }
+      d->adj_mask = 0;
+      d->adj_nhdr = 0;
+      if (dev_stats) { dev_stats->nsig_kept = 0; dev_stats->rows = 0; dev_stats->records = 0; }
+      err.clear();
     }
   }
   return d;
@@ -951,7 +959,7 @@ static int encode_tail(Batch* b, std::string& err) {
 }
 
 Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
-                          const anx_params& p, std::string& err, int* code, bool keep_text, bool blob_on_device) {
+                          const anx_params& p, std::string& err, int* code, bool keep_text, bool blob_on_device, bool after_stream, void* src_stream) {
   *code = ANX_OK;
   if (blob_on_device && (off || switches().encode_host)) { err = "inputs in device memory need the device-side encoder and no host offsets"; *code = ANX_EINVAL; return nullptr; }
   if (!dl) { err = "model is not resident on a device (no HIP device / anx_model_to_device not called)"; *code = ANX_ENODEVICE; return nullptr; }
@@ -980,7 +988,7 @@ Batch* batch_encode_spans(const HostModel& m, const DeviceLexicon* dl, const cha
       b->text_bytes = bytes;
     }
   } else {
-    rc = batch_encode_device(m, dl, b, blob, blob_bytes, off, n, p, err, blob_on_device);
+    rc = batch_encode_device(m, dl, b, blob, blob_bytes, off, n, p, err, blob_on_device, after_stream, src_stream);
   }
   if (!rc) rc = encode_tail(b, err);
   if (rc) { *code = rc; batch_free(b); return nullptr; }

@@ -40,6 +40,6 @@ struct DeviceLm;
 void lm_free(DeviceLm*);
 // device-side query encoder (encode.hip): fills the query and tile arrays of `b` from the packed inputs
 int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
-                        const anx_params& p, std::string& err, bool blob_on_device = false);
+                        const anx_params& p, std::string& err, bool blob_on_device = false, bool after_stream = false, void* src_stream = nullptr);
 
 }  // namespace anx

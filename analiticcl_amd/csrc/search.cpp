@@ -805,6 +805,10 @@ static void write_part(const PartOut& po, const char* const* texts, size_t n, co
 // for two thirds of the call and the host threads for the rest).
 // When all parts are done their sizes are known: the call's arrays are allocated once and every part writes its matches, rows
 // and tags at its base (write_part).
+// diagnosis (anx_debug_search_stats): multi-part calls, and how many of them wrote their output while later parts were still at work /
+// had to fall back to writing it at the end although early output was eligible
+static std::atomic<uint64_t> g_search_multi_calls{0}, g_search_early_kept{0}, g_search_early_dropped{0};
+int anx_debug_search_stats(uint64_t* out) { if (!out) return ANX_EINVAL; out[0] = g_search_multi_calls.load(); out[1] = g_search_early_kept.load(); out[2] = g_search_early_dropped.load(); out[3] = 0; return ANX_OK; }
 int anx_find_all_matches_batch(const anx_model* model, const char* const* texts, size_t n, const anx_search_params* sp,
                                anx_match** out_matches, size_t** out_offsets, anx_result** out_rows, size_t* out_n_rows,
                                anx_match_tag** out_tags) {
@@ -863,7 +867,11 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
             if (anx::switches().search_timing) fprintf(stderr, "[anx search] part %zu, all of it          %8.2f ms\n", r, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count() * 1e3);
             if (p.rc != ANX_OK) { p.err = anx_last_error(); failed.store(true); }  // (the message is the worker thread's)
           } else p.rc = ANX_EINVAL;
-          p.ub_matches.store(0, std::memory_order_release);  // (a part that failed before its boundaries: nobody waits for the bound)
+          {  // a part that failed before its boundaries: nobody waits for its bound.  Only if the part never published one: a finished
+             // part keeps its real bound (calls with more parts than workers sum the bounds after the first round of parts is done)
+            size_t unset = (size_t)-1;
+            p.ub_matches.compare_exchange_strong(unset, 0, std::memory_order_acq_rel);
+          }
           p.done.store(1, std::memory_order_release);
           p.signal();
         }
@@ -908,6 +916,9 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
       early.r_total = rb;
     }
     for (auto& x : th) x.join();
+    g_search_multi_calls.fetch_add(1, std::memory_order_relaxed);
+    if (early.on && early.om && early.parts_written == parts) g_search_early_kept.fetch_add(1, std::memory_order_relaxed);
+    else if (anx::switches().search_early_output && sp->base.max_matches > 0 && !out_tags) g_search_early_dropped.fetch_add(1, std::memory_order_relaxed);
     if (early.om && (!early.on || early.parts_written != parts)) { free(early.om); free(early.oo); free(early.orows); early = Early(); }
     for (auto& p : P)
       if (p->rc != ANX_OK && !p->err.empty()) return anx_fail(p->rc, p->err);

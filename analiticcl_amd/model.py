@@ -183,7 +183,7 @@ class Batch:
     """A batch of queries encoded and resident in HBM (anx_batch_*): encode once, run many times."""
 
     def __init__(self, model: "VariantModel", inputs: Sequence[str], params: SearchParameters, packed: Optional[bytes] = None,
-                 n: Optional[int] = None, device_ptr: Optional[int] = None, nbytes: int = 0):
+                 n: Optional[int] = None, device_ptr: Optional[int] = None, nbytes: int = 0, src_stream: Optional[int] = None):
         """inputs: the query strings; or packed + n: the same as ONE bytes object, every input followed by a NUL byte (what a
         caller that reads its queries from a file or a socket already has: the buffer goes to the device as it is)."""
         self.model = model
@@ -191,7 +191,10 @@ class Batch:
         # one NUL-terminated buffer instead of a pointer array (anx_batch_encode_packed)
         if device_ptr is not None:   # the packed buffer already sits in HBM (anx_batch_encode_packed_device)
             self.n = int(n)
-            self.h = L.lib().anx_batch_encode_packed_device(model.h, C.c_void_p(device_ptr), int(nbytes), self.n, C.byref(cp))
+            if src_stream is None:   # the buffer is complete (its producer has been waited for)
+                self.h = L.lib().anx_batch_encode_packed_device(model.h, C.c_void_p(device_ptr), int(nbytes), self.n, C.byref(cp))
+            else:                    # ordered behind what the stream holds now (anx_batch_encode_packed_device_on)
+                self.h = L.lib().anx_batch_encode_packed_device_on(model.h, C.c_void_p(device_ptr), int(nbytes), self.n, C.byref(cp), C.c_void_p(src_stream))
         else:
             blob = _pack(inputs) if packed is None else packed
             self.n = len(inputs) if packed is None else int(n)
@@ -548,9 +551,11 @@ class VariantModel:
         """encode_batch for n inputs already packed into one bytes object, each followed by a NUL byte."""
         return Batch(self, (), params, packed=packed, n=n)
 
-    def encode_packed_device(self, device_ptr: int, nbytes: int, n: int, params: SearchParameters) -> Batch:
-        """encode_packed for a packed buffer in device memory (e.g. a torch uint8 tensor's data_ptr()): nothing crosses PCIe."""
-        return Batch(self, (), params, n=n, device_ptr=device_ptr, nbytes=nbytes)
+    def encode_packed_device(self, device_ptr: int, nbytes: int, n: int, params: SearchParameters, stream: Optional[int] = None) -> Batch:
+        """encode_packed for a packed buffer in device memory (e.g. a torch uint8 tensor's data_ptr()): nothing crosses PCIe.
+        stream = None: the buffer must be complete (synchronised) when the call is made; stream = a hipStream_t handle (0 = the default
+        stream): the encoder is ordered behind what that stream holds now (the kernel or copy that fills the buffer)."""
+        return Batch(self, (), params, n=n, device_ptr=device_ptr, nbytes=nbytes, src_stream=stream)
 
     def encode_batch(self, inputs: Sequence[str], params: SearchParameters) -> Batch:
         return Batch(self, inputs, params)

@@ -24,8 +24,12 @@ extern "C" {
  * 2: anx_batch_stats grew (n_prefiltered_in_scan, ...) and anx_batch_get_stats(batch, out, struct_size) takes the caller's struct
  *    size as its third argument (the struct only grows at its end; a size below the version-2 struct's first 152 bytes is refused
  *    with ANX_EINVAL: a caller built against ABI 1 passes no size at all), anx_shutdown, asynchronous fetch, length-partitioned
- *    sharding.  A binding compares anx_abi_version() with the ANX_ABI_VERSION it was compiled against before it calls anything else. */
-#define ANX_ABI_VERSION 2
+ *    sharding.  A binding compares anx_abi_version() with the ANX_ABI_VERSION it was compiled against before it calls anything else.
+ * 3: anx_pipeline_submit_packed NEVER blocks: with `depth` jobs in flight it returns ANX_ELIMIT and submits nothing (until the middle
+ *    of ABI 2's life it waited instead -- a binding written against the blocking contract sees failing submits, hence the new
+ *    version); anx_batch_encode_packed_device_on (the caller's stream orders the encoder behind the producer of the buffer);
+ *    anx_debug_search_stats; ANX_ADJ_CLOSURE is 0..2 for every builder.  Nothing was removed; every struct of version 2 is unchanged. */
+#define ANX_ABI_VERSION 3
 
 enum {
   ANX_OK = 0,
@@ -198,8 +202,14 @@ anx_batch *anx_batch_encode_packed(const anx_model *, const char *blob, size_t b
 /* the same for inputs that already sit in HBM: device_blob is memory of the model's (one) device, laid out like the packed buffer above
  * (every input followed by a NUL byte).  Nothing crosses PCIe; the bytes are copied device to device, so the caller's buffer is free
  * again when the call returns.  Models with several replicas and the host-side rescoring path (ANX_CONFUSABLES=host): ANX_EINVAL.
- * A trailing NUL byte is the caller's responsibility (the host cannot look). */
+ * A trailing NUL byte is the caller's responsibility (the host cannot look).
+ * Ordering: the encoder reads the buffer on a stream of its own.  anx_batch_encode_packed_device takes no stream, so the buffer must
+ * be COMPLETE and visible to the device when the call is made (the work that produced it -- a kernel, an asynchronous copy -- has been
+ * waited for: hipStreamSynchronize / hipDeviceSynchronize).  anx_batch_encode_packed_device_on(..., stream) instead orders the
+ * encoder behind everything `stream` (a hipStream_t; NULL = the default stream) holds at the time of the call (an event recorded on it
+ * that the encoder's stream waits for): the producer needs no host synchronisation. */
 anx_batch *anx_batch_encode_packed_device(const anx_model *, const void *device_blob, size_t blob_len, size_t n, const anx_params *);
+anx_batch *anx_batch_encode_packed_device_on(const anx_model *, const void *device_blob, size_t blob_len, size_t n, const anx_params *, void *stream);
 /* `stream` is a hipStream_t (NULL = the default stream).  A model with several replicas runs every shard of the batch on its
  * replica's own stream: `stream` must then be NULL. */
 int anx_batch_run(const anx_model *, anx_batch *, void *stream);
@@ -327,6 +337,10 @@ int anx_debug_set_switch(const char *name, const char *value);
  * and returns their summed duration and count (ANX_EINVAL: none recorded).  k_scan_bits / k_filter_score are always timed: anx_batch_stats. */
 void anx_debug_kernel_timer(int enable);
 int anx_debug_kernel_time(const char *name, double *total_ms, uint64_t *launches);
+/* Diagnosis of search mode's output path since the library was loaded: out[0] = calls that ran as several parts, out[1] = of those, the
+ * calls whose output arrays were written while later parts were still on the device, out[2] = calls that were eligible for that but
+ * had to write at the end (an upper bound did not hold), out[3] = 0 (reserved). */
+int anx_debug_search_stats(uint64_t out[4]);
 /* The length-partitioned split by itself (no device needed): which of n_shards replicas each of the n inputs
  * would go to (out_shard[i] in 0 .. n_shards - 1; see anx_batch_shard_info).  bench.py and the tests use it to build one GPU's share of
  * a larger job (BASELINE configs[3]) on a one-GPU box.  learn_ms (may be NULL): the device times of THOSE shares, measured by the caller

@@ -253,6 +253,43 @@ class OracleModel:
         return rc, res, counts, tp.value, tc.value
 
 
+def batch_rows(model: "OracleModel", texts: Sequence[str], params: Params, nthreads: int = 0, stride: int = 16):
+    """orc_find_variants_batch as numpy arrays: (counts int32[n], vocab_id uint64[n, stride], dist f64[n, stride], freq f64[n, stride],
+    scored pairs, anagram classes).  Rows beyond counts[i] are unspecified.  Raises if a list did not fit the stride."""
+    import numpy as np
+    rc, res, counts, tp, tc = model.find_variants_batch(texts, params, nthreads=nthreads, stride=stride)
+    if rc != 0:
+        raise RuntimeError(f"orc_find_variants_batch: {rc}")
+    n = len(texts)
+    dt = np.dtype([("vocab_id", "<u8"), ("dist", "<f8"), ("freq", "<f8"), ("via", "<u8")])
+    a = np.frombuffer(res, dtype=dt).reshape(n, stride)
+    c = np.frombuffer(counts, dtype=np.int32)
+    if n and (c.min() < 0 or c.max() > stride):
+        raise RuntimeError("a result list did not fit the stride")
+    return c, a["vocab_id"], a["dist"], a["freq"], tp, tc
+
+
+def assert_rows_equal(off, vid, dist, freq, idx, counts, ovid, odist, ofreq, what=lambda i: i, tol=0.0):
+    """The ranked rows of the queries idx of a device result (CSR arrays off / vid / dist / freq) against batch_rows' arrays (row n =
+    query idx[n]): list lengths, vocabulary ids in order, scores (== when tol is 0)."""
+    import numpy as np
+    idx = np.asarray(idx, dtype=np.int64)
+    cnt = (off[idx + 1] - off[idx]).astype(np.int64)
+    bad = np.nonzero(cnt != counts)[0]
+    assert bad.size == 0, (what(int(idx[bad[0]])), int(cnt[bad[0]]), int(counts[bad[0]]))
+    if cnt.sum() == 0:
+        return 0
+    src = np.repeat(off[idx], cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))   # device rows
+    row = np.repeat(np.arange(len(idx)), cnt)
+    col = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    for name, g, o in (("vocab_id", vid[src].astype(np.uint64), ovid[row, col]), ("dist_score", dist[src], odist[row, col]), ("freq_score", freq[src], ofreq[row, col])):
+        ne = (g != o) if (tol == 0.0 or name == "vocab_id") else (np.abs(g - o) > tol)
+        if ne.any():
+            k = int(np.nonzero(ne)[0][0])
+            raise AssertionError((name, what(int(idx[row[k]])), int(col[k]), g[k], o[k]))
+    return int(cnt.sum())
+
+
 def dl(s: Sequence[int], t: Sequence[int], maxd: int) -> Optional[int]:
     r = lib().orc_damerau_levenshtein(bytes(s), len(s), bytes(t), len(t), maxd)
     return None if r < 0 else r

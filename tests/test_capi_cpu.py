@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol():
     lib = ctypes.CDLL(L.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert L.lib().anx_abi_version() == L.ABI_VERSION == 2
+    assert L.lib().anx_abi_version() == L.ABI_VERSION == 3
 
 
 def test_defaults_match_reference():

@@ -17,7 +17,7 @@ from analiticcl_amd import synth
 from oracle import cwrap as O
 from oracle import twin as T
 
-from search_common import TwinOverOracle
+from search_common import twin_matches_parallel
 
 MB = 12.5
 LM = A.VocabParams(vocabtype="LM")
@@ -92,31 +92,23 @@ def test_shard_equals_whole(setup):
 
 def test_twin_spot_check(setup, data_dir):
     g, lex, lm, texts, p, (off, ma, ra) = setup
-    tw = TwinOverOracle(T.read_alphabet(os.path.join(data_dir, "simple.alphabet.tsv")))
-    tw.read_vocabulary(lex)
-    for t, f in lm:
-        tw.add_lm(t, f)
-    tw.build()
-    orc = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
-    orc.read_lexicon(lex)
-    orc.build()
-    tw.attach(orc)
-    tp = T.SearchParams(("abs", 3), ("abs", 2), 10, 0.25, 2.0, False, 0.0, max_ngram=3)
+    # 400 sampled texts (3 200 sentences; round 5: 40 texts) through the oracle twin's search mode, spread over 16 child processes
+    idx = random.Random(5).sample(range(len(texts)), 400)
+    exp_all, _secs = twin_matches_parallel(os.path.join(data_dir, "simple.alphabet.tsv"), lex, lm, [texts[i] for i in idx], workers=16)
     n_multi = n_sent = 0
-    for i in random.Random(5).sample(range(len(texts)), 40):
-        exp = tw.find_all_matches(texts[i], tp)
+    for i, exp in zip(idx, exp_all):
         got = ma[off[i]:off[i + 1]]
         raw = texts[i].encode("utf-8")
         n_sent += 8
         assert [(raw[int(m["begin"]):int(m["end"])].decode(), int(m["begin"]), int(m["end"])) for m in got] == \
-            [(e.text, e.begin, e.end) for e in exp], texts[i]
+            [(e[0], e[1], e[2]) for e in exp], texts[i]
         for m, e in zip(got, exp):
-            ev = e.variants or []
+            ev = e[5]
             rows = ra[int(m["vb"]):int(m["ve"])]
-            assert [int(v) for v in rows["vocab_id"]] == [v.vocab_id for v in ev], (texts[i], e.text)
+            assert [int(v) for v in rows["vocab_id"]] == [v[0] for v in ev], (texts[i], e[0])
             for r, w in zip(rows, ev):
-                assert abs(float(r["dist"]) - w.dist_score) <= 1e-6 and abs(float(r["freq"]) - w.freq_score) <= 1e-6
+                assert abs(float(r["dist"]) - w[1]) <= 1e-6 and abs(float(r["freq"]) - w[2]) <= 1e-6
             if ev:
-                assert int(m["selected"]) == e.selected, (texts[i], e.text)
-            n_multi += e.n > 1
-    assert n_sent >= 200
+                assert int(m["selected"]) == e[4], (texts[i], e[0])
+            n_multi += e[3] > 1
+    assert n_sent >= 3000 and n_multi > 0

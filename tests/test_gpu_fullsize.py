@@ -103,3 +103,9 @@ def test_oracle_spot_check(setup, data_dir):
         got = [(int(vid[j]), float(dist[j]), float(freq[j])) for j in range(off[i], off[i + 1])]
         assert got == exp, qs[i]
         assert int(counts[i]) == npairs, qs[i]
+    # 100 000 of the million queries (10 %: the tail of the ONE distribution the headline is quoted on) through the oracle's OpenMP
+    # batch entry: ranked ids in order, f64 scores with ==, and the sample's scored pairs against the scan's per-query counts
+    idx = np.sort(rng.choice(N, 100_000, replace=False))
+    c, ov, od, of, tp, _tc = O.batch_rows(o, [qs[i] for i in idx], op, nthreads=16, stride=16)
+    rows = O.assert_rows_equal(off, vid, dist, freq, idx, c, ov, od, of, what=lambda i: qs[i])
+    assert rows > 300_000 and int(counts[idx].sum()) == tp
