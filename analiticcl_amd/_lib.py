@@ -169,6 +169,7 @@ def lib():
         "anx_batch_encode_packed_device": (vp, [vp, vp, sz, sz, C.POINTER(Params)]),
         "anx_batch_encode_packed_device_on": (vp, [vp, vp, sz, sz, C.POINTER(Params), vp]),
         "anx_debug_search_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
+        "anx_debug_small_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
         "anx_batch_run": (C.c_int, [vp, vp, vp]),
         "anx_batch_run_async": (C.c_int, [vp, vp, vp]),
         "anx_batch_wait": (C.c_int, [vp, vp]),

@@ -430,6 +430,7 @@ int anx_debug_set_switch(const char* name, const char* value) {
   return anx::set_switch(name, value) ? ANX_OK : fail(ANX_EINVAL, "unknown switch");
 }
 void anx_debug_kernel_timer(int enable) { anx::kernel_timer_enable(enable != 0); }
+int anx_debug_small_stats(uint64_t* out) { if (!out) return fail(ANX_EINVAL, "NULL argument"); anx::small_stats(out); return ANX_OK; }
 int anx_debug_kernel_time(const char* name, double* total_ms, uint64_t* launches) {
   return anx::kernel_timer_read(name, total_ms, launches) ? ANX_OK : fail(ANX_EINVAL, "no launch of that kernel was timed");
 }
@@ -1583,6 +1584,18 @@ int anx_find_variants_batch(const anx_model* m, const char* const* utf8, size_t 
   // One device batch holds at most 2^31 pair-list slots (~10 M queries of BASELINE config 2): larger calls are run as
   // consecutive rounds of ANX_MAX_BATCH inputs per replica and their CSR results concatenated.
   const size_t per_round = (size_t)anx::switches().max_batch * std::max<size_t>(1, m ? m->replicas.size() : 1);
+  // the small call (engine small_path.hpp): the reference's own granularity -- one string per call, 1 000 per batch
+  // (src/lib.rs:972, src/bin/analiticcl.rs:416) -- in eleven launches and one host wait instead of the batch pipeline
+  if (m && utf8 && p && n >= 1 && n <= 4096 && m->host.built && m->replicas.size() == 1 && m->replicas[0].dev && anx::switches().small_path) {
+    bool rescore = false;
+    const anx_params dp = device_params(m, p, &rescore);
+    if (!rescore) {   // (confusables: weighted by the batch path)
+      std::string err;
+      const int rc = anx::small_find(m->host, m->replicas[0].dev, utf8, n, dp, out_rows, out_offsets, err);
+      if (rc == ANX_OK) return ANX_OK;
+      if (rc < 0) return fail(rc, err);
+    }
+  }
   if (n <= per_round) {
     anx_batch* b = anx_batch_encode(m, utf8, n, p);
     if (!b) return g_code ? g_code : ANX_EINVAL;

@@ -60,6 +60,7 @@ struct EncArgs {
   int ngroups;              // signature groups in use (1..8)
   uint32_t* blk;            // [blocks][3] per block: max len, max d, encodable inputs (k_enc_totals -> ctr[0..2])
   int dbg;                  // ANX_ENC_DBG (debug builds, timing only, results WRONG): 1 no count-vector writes, 2 no code stores, 4 no walk, 8 no record stores
+  int zero_cv;              // !bits_ok: every lane clears its own count-vector row first (the small path: no memset launch before the kernel)
 };
 
 // Where the codes of string i start: the bytes of string i and its separator are >= symbols + 1, and rounding every start up to a
@@ -101,6 +102,11 @@ __device__ inline int dev_clamp_threshold(const anx_threshold& t, int len, int a
   return (int)t.value < half ? (int)t.value : half;
 }
 
+// STAGE (the small call): the blob is pinned HOST memory; the block first copies the bytes of its 256 strings into LDS with coalesced
+// 16-byte loads (one burst over PCIe instead of a dword read per lane and window) and the lanes walk them there.  Strings of at most
+// ENC_STAGE_BYTES bytes each.
+constexpr uint32_t ENC_STAGE_BYTES = 64;
+template <bool STAGE>
 __global__ __launch_bounds__(256) void k_enc_strings(EncArgs a) {
   // the per-byte tables of the walk in LDS: one lane walks one string, every step is a chain of dependent loads -- from LDS they
   // cost ~64 cycles instead of a trip to L1 / L2
@@ -111,12 +117,23 @@ __global__ __launch_bounds__(256) void k_enc_strings(EncArgs a) {
   __syncthreads();
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   uint32_t len = 0, d = 0, ok = 0;
+  __shared__ uint4 s_stage[STAGE ? (256 * (ENC_STAGE_BYTES + 1) + 48) / 16 : 1];
+  uint32_t stage0 = 0;
+  if (STAGE) {
+    const uint32_t first = blockIdx.x * 256u, last = min(a.n, first + 256u);
+    const uint32_t b0 = a.off[first] & ~15u, b1 = a.off[last] + 16u;   // (the window of the last string may read 16 bytes past it)
+    for (uint32_t x = threadIdx.x; x < (b1 - b0 + 15u) / 16u; x += 256u) s_stage[x] = reinterpret_cast<const uint4*>(a.blob + b0)[x];
+    stage0 = b0;
+    __syncthreads();
+  }
   if (i < a.n) {
     const uint32_t begin = a.off[i], end = a.off[i + 1] - 1u;
-    const uint8_t* __restrict__ s = a.blob;
+    const uint8_t* __restrict__ s = STAGE ? reinterpret_cast<const uint8_t*>(s_stage) - stage0 : a.blob;
     uint32_t n = 0, skip = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, over = 0;
     unsigned long long sig = 0;
     uint8_t* cvb = reinterpret_cast<uint8_t*>(a.cv) + (size_t)i * (size_t)a.NP * 4u;
+    if (!a.bits_ok && a.zero_cv)
+      for (uint32_t w = 0; w < (uint32_t)a.NP; ++w) a.cv[(size_t)i * (size_t)a.NP + w] = 0u;
     uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(a.codes + code_off(begin, i));
     uint32_t cword = 0;
     bool too_long = false;
@@ -514,6 +531,96 @@ __global__ __launch_bounds__(256) void k_tile_adj_count(const Tile* tiles, uint3
   if (i < n && tiles[i].adj && (i + 1 == n || !tiles[i + 1].adj)) ctr[5] = i + 1u;
 }
 
+// ---- the small call (engine.hip small_find): queries stay in INPUT order, one tile per query -----------------------------------------
+// Tile slot of (query s, part) = part * n + s: the bit-plane tiles (part 0) of consecutive queries take consecutive pair-list regions;
+// a count-vector tile that walks its window is split over up to 8 slots (as in k_tile_emit); unused slots get nq = 0 and are skipped
+// by k_scan_small.  The kernel also clears what the run accumulates into (counters, per-query sums): no memset launches.
+__global__ __launch_bounds__(256) void k_small_tiles(TileArgs t, SmallZero z, uint32_t slots, const uint32_t* __restrict__ adj_hdr) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256u;
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+    for (uint32_t i = s; i < z.n[a]; i += nthreads) z.p[a][i] = 0u;
+  if (s >= t.nq) return;
+  const uint32_t meta = t.q_meta[s], lq = meta & 0xFFu, k = (meta >> 8) & 0xFFu, d = (meta >> 16) & 0xFFu;
+  Tile nul{};
+  nul.kind = 1u;
+  uint32_t nparts = 0;
+  if (meta) {
+    const uint32_t kind = t.s_kind[s];
+    const bool sad = kind == 0;
+    uint32_t s0, s1, step, ball0, balln;
+    tile_window(t, s, s0, s1, step, nparts, ball0, balln);
+    const unsigned long long sig = t.s_sig[s];
+    uint32_t adj_rows = 0;
+    const uint32_t adj = (!sad && k <= (uint32_t)kAdjRadius) ? adj_lookup(t.adj_hash, t.adj_mask, (uint32_t)sig, (uint32_t)(sig >> 32), &adj_rows) : 0u;
+    // A tile that streams an adjacency list is ONE wave waiting for its own loads chunk after chunk (~2 us per chunk of 4 rows, 100 us
+    // for a list of 200 rows): in a batch sixty thousand other waves fill the gaps, in a small call nothing does.  The rows of the list
+    // are therefore shared out over up to `slots` tiles of at least 8 rows (two chunks) each.
+    uint32_t rbeg = 0, rend = 0;
+    if (adj) {
+      const uint32_t* hp = adj_hdr + (size_t)(adj - 1u) * 8u;   // {first row, cumulative rows of the 7 length sections} -- as scan_tile reads it
+      rbeg = k >= 3u ? 0u : k == 2u ? hp[1] : k == 1u ? hp[2] : hp[3];
+      rend = k >= 3u ? hp[7] : k == 2u ? hp[6] : k == 1u ? hp[5] : hp[4];
+      const uint32_t rows = rend > rbeg ? rend - rbeg : 0u;
+      nparts = min(slots, max(1u, rows / 8u));
+      step = ((rows + nparts - 1u) / nparts + 3u) & ~3u;      // whole chunks
+    }
+    for (uint32_t part = 0; part < nparts; ++part) {
+      const uint32_t a0 = s0 + part * step, a1 = min(s1, a0 + step);
+      Tile tl;
+      tl.q0 = s; tl.nq = 1u; tl.s0 = a0; tl.s1 = a1; tl.k = k; tl.lq = lq; tl.sig_lo = (uint32_t)sig; tl.sig_hi = (uint32_t)(sig >> 32);
+      tl.kind = sad ? 0u : 1u; tl.d = d;
+      tl.kend = sad ? 0u : ((kind <= 1u ? 1u : 0u) | (kind <= 2u ? 1u : 0u) << 8 | (kind <= 3u ? 1u : 0u) << 16);  // ends of the kind-1 / -2 / -3 queries
+      tl.ball0 = ball0; tl.balln = balln; tl.adj = adj; tl.flags = part == 0u ? 1u : 0u;
+      if (adj) {
+        tl.s0 = min(rend, rbeg + part * step);
+        tl.s1 = min(rend, tl.s0 + step);
+        tl.flags |= 2u;
+        if (tl.s0 >= tl.s1 && part) tl.nq = 0u;  // (nothing left for this part)
+      }
+      t.tiles[(size_t)part * t.nq + s] = tl;
+    }
+  }
+  (void)nul;
+  for (uint32_t part = nparts; part < slots; ++part) t.tiles[(size_t)part * t.nq + s].nq = 0u;  // an unused slot: k_scan_small only looks at nq
+}
+
+int small_encode_launch(const HostModel& m, const DeviceLexicon* dl, const SmallEnc& e, const uint8_t* blob, const uint32_t* off, uint32_t n, uint32_t qw,
+                        const anx_params& p, const SmallZero& z, uint32_t slots, bool stage_lds, hipStream_t st, std::string& err) {
+  const int NP = dl->nplanes;
+  EncArgs ea;
+  ea.blob = blob; ea.off = off; ea.n = n; ea.al = dl->alpha; ea.A = m.alphabet.size(); ea.NP = NP;
+  ea.bits_ok = (dl->nsym <= 32 && !switches().scan_sad) ? 1 : 0;
+  ea.ngroups = 1;
+  for (uint8_t g : m.lex.sym_group) ea.ngroups = std::max(ea.ngroups, (int)g + 1);
+  ea.kth = p.max_anagram_distance; ea.dth = p.max_edit_distance;
+  ea.codes = e.codes; ea.meta = e.meta; ea.bits = e.bits; ea.sig = e.sig; ea.kind = e.kind; ea.cv = e.cv; ea.key = e.key; ea.blk = e.blk;
+  ea.dbg = 0;
+  ea.zero_cv = 1;
+  const dim3 gn((n + 255) / 256);
+  if (stage_lds) hipLaunchKernelGGL(k_enc_strings<true>, gn, dim3(256), 0, st, ea);
+  else hipLaunchKernelGGL(k_enc_strings<false>, gn, dim3(256), 0, st, ea);
+  GatherArgs ga;
+  ga.nq = n; ga.qw = qw; ga.NP = NP; ga.want_exact = 0;
+  ga.perm = e.perm; ga.off = off; ga.codes = e.codes; ga.meta = e.meta; ga.bits = e.bits; ga.kind = e.kind; ga.cv = e.cv; ga.sig = e.sig;
+  ga.q_rec = e.q_rec; ga.q_rows = e.q_rows; ga.q_bits = e.q_bits; ga.q_cv = e.q_cv; ga.q_meta = e.q_meta; ga.q_orig = e.q_orig;
+  ga.qexact = e.qexact; ga.s_kind = e.s_kind; ga.s_sig = e.s_sig;
+  ga.sigtab = dl->sig; ga.siglen_begin = dl->alpha.siglen_begin; ga.cls_planes = dl->cls_planes; ga.cstride = dl->cstride;
+  hipLaunchKernelGGL(k_enc_gather, gn, dim3(256), 0, st, ga);
+  TileArgs ta;
+  ta.tq = 1; ta.nq = n; ta.q_meta = e.q_meta; ta.s_kind = e.s_kind; ta.s_sig = e.s_sig; ta.siglen_begin = dl->alpha.siglen_begin; ta.ctr = nullptr;
+  ta.ball_tab = dl->ball_tab; ta.probe = probe_enabled() ? 1 : 0;
+  ta.adj_hash = dl->adj_hash; ta.adj_mask = switches().scan_adj ? dl->adj_mask : 0u;
+  ta.head = nullptr; ta.tcount = nullptr; ta.tiles = e.tiles; ta.tkey = nullptr;
+  hipLaunchKernelGGL(k_small_tiles, gn, dim3(256), 0, st, ta, z, slots, dl->adj_hdr);
+  HIP_TRY(hipGetLastError());
+  return ANX_OK;
+}
+int small_iota(uint32_t* perm, uint32_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, st, perm, n);
+  return hipGetLastError() == hipSuccess ? ANX_OK : ANX_ENODEVICE;
+}
+
 // ---- host driver --------------------------------------------------------------------------------------------------------
 namespace {
 struct Scratch {  // pool blocks released together, and the private stream of the call
@@ -629,12 +736,13 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   ea.kth = p.max_anagram_distance; ea.dth = p.max_edit_distance;
   ea.codes = d_codes; ea.meta = d_meta; ea.bits = d_bits; ea.sig = d_sig; ea.kind = d_kind; ea.cv = d_cv; ea.key = d_key; ea.blk = d_blk;
   ea.dbg = 0;
+  ea.zero_cv = 0;
 #ifdef ANX_DEBUG_SWITCHES
   { const char* e = getenv("ANX_ENC_DBG"); ea.dbg = e ? atoi(e) : 0; }
 #endif
   const dim3 gn((n32 + 255) / 256);
   lap("alloc + H2D");
-  hipLaunchKernelGGL(k_enc_strings, gn, dim3(256), 0, st, ea);
+  hipLaunchKernelGGL(k_enc_strings<false>, gn, dim3(256), 0, st, ea);
   hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(256), 0, st, d_blk, gn.x, d_ctr);
   lap("k_enc_strings");
   // ---- (scan kernel, length, signature, kind) order: one sort of a packed key (until round 3: three stable passes over kind, the

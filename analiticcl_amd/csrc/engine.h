@@ -30,6 +30,7 @@ void device_pool_trim(int device);  // hands the cached scratch blocks of the de
 void* stream_create(int device, std::string& err, bool high_priority = false);  // high_priority: see engine.hip make_stream
 void stream_destroy(int device, void* stream);
 void* host_result_alloc(size_t bytes);
+bool host_result_is_pinned(void* p);  // a block of host_result_alloc that is pinned (device-visible) host memory
 void host_result_free(void* p);
 void* thread_stream_begin(int device);            // see engine.hip; nullptr = nothing to end
 void thread_stream_end(int device, void* stream);
@@ -59,6 +60,11 @@ int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::strin
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err);
 // the same into caller-provided storage: rows[0 .. batch_n_results) and offs[0 .. batch_n_input] = base + CSR offsets
+// The small call (small_path.hpp): find_variants for at most 4096 inputs of at most 64 bytes in eleven launches and one host wait,
+// no allocation.  0: done (*rows: a block of the pinned result cache, *offs: malloc'd, as batch_fetch returns them); 1: not taken
+// (too many / too long inputs, variant lists, StopAtExactMatch, a fixed capacity exceeded): use the batch path; negative: device error.
+int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* utf8, size_t n, const anx_params& p, anx_result** rows, size_t** offs, std::string& err);
+void small_stats(uint64_t* out);  // out[0] = calls the small path answered, out[1] = calls it handed to the batch path after a capacity overflow
 size_t batch_n_results(const Batch* b);
 size_t batch_n_input(const Batch* b);
 int batch_fetch_into(const Batch* b, anx_result* rows, size_t* offs, size_t base, std::string& err);

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <numeric>
@@ -53,6 +54,7 @@ enum { HR_RCTR = 0, HR_SCTR = SCAN_REGIONS * RC_STRIDE, HR_LCTR = 2 * SCAN_REGIO
        HR_TOTAL_SURV = HR_CTR + CTR_N, HR_TOTAL_RESULTS = HR_TOTAL_SURV + 1, HR_CONF = HR_TOTAL_RESULTS + 1 /* 2 words */, HR_N = HR_CONF + 2 };
 constexpr size_t HR_COLD_OFF = (HR_N * sizeof(uint32_t) + 63) & ~(size_t)63;  // byte offset of the FsCold staging copy in Batch::h_read
 static void shells_destroy(int device);
+static void small_ctxs_destroy(int device);
 
 int device_count(std::string& err) {
   int n = 0;
@@ -68,6 +70,7 @@ int device_count(std::string& err) {
 // hipFree of that size cost 100-300 ms per call, far more than the 6 ms the kernels take for a million queries, and
 // search mode issues one batch per n-gram order.  Freed blocks are kept per device and handed out again (best fit,
 // at most 2x the request); lexicon_free() of the last lexicon on a device returns them to the driver.
+struct SmallCtx;  // small_path.hpp
 namespace {
 struct DevPool {
   std::mutex mu;
@@ -81,6 +84,7 @@ struct DevPool {
   hipStream_t run_streams[2] = {nullptr, nullptr}; // the library's own streams for asynchronous runs (batch_run_async)
   unsigned run_counter = 0;
   std::vector<BatchShell> shells;                  // events + pinned read-back blocks of freed batches (batch_free), handed to the next batch
+  std::vector<SmallCtx*> small_idle;               // contexts of the small call (small_path.hpp), checked out per call
 };
 // bytes of freed blocks kept per device (MI355X: 288 GB HBM; a 1 M-query batch holds 3-6 GB of scratch).  ANX_POOL_CACHE_MB
 // overrides the default; anx_device_pool_trim() hands the cache back to the driver at any time.
@@ -244,6 +248,7 @@ void pool_free(void* p) {
 }
 static void pool_trim(int device) {
   DevPool& pl = pool_of(device);
+  small_ctxs_destroy(device);  // (first: their blocks go back to the pool that is emptied below)
   std::vector<void*> drop;
   {
     std::lock_guard<std::mutex> g(pl.mu);
@@ -304,6 +309,12 @@ void* host_result_alloc(size_t bytes) {
   std::lock_guard<std::mutex> g(hc.mu);
   hc.live[p] = std::make_pair(bytes, pinned);
   return p;
+}
+bool host_result_is_pinned(void* p) {
+  HostCache& hc = host_cache();
+  std::lock_guard<std::mutex> g(hc.mu);
+  auto it = hc.live.find(p);
+  return it != hc.live.end() && it->second.second;
 }
 void host_result_free(void* p) {
   if (!p) return;
@@ -1374,7 +1385,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand};
     FilterArgs fa;
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
-    fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap;
+    fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap; fa.blk = FS_BLK;
     const dim3 fgrid(((fill_cap + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
     {
       FsCold* cold = reinterpret_cast<FsCold*>(reinterpret_cast<char*>(b->h_read) + HR_COLD_OFF);  // pinned: a truly asynchronous copy
@@ -1919,6 +1930,8 @@ void batch_free(Batch* b) {
   shell_release(b);  // events + pinned read-back block: to the device's pool (hipHostFree / hipEventDestroy here would wait for the device)
   delete b;
 }
+
+#include "small_path.hpp"
 
 // ---- test hook: the band-match bound alone (anx_debug_band_bound; tests/test_gpu_switches.py) ------------------------------------
 // One lane per pair, rows as the kernels see them (first 16 symbols, query padded with 0xFE, candidate with 0xFF); the three forms

@@ -42,4 +42,22 @@ void lm_free(DeviceLm*);
 int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, const char* blob, size_t blob_bytes, const uint32_t* off, size_t n,
                         const anx_params& p, std::string& err, bool blob_on_device = false, bool after_stream = false, void* src_stream = nullptr);
 
+// ---- the small call: device buffers of its encoder (engine.hip small_find owns them; encode.hip launches the kernels) -----------------
+struct Tile;
+struct SmallEnc {
+  uint8_t* codes = nullptr;
+  uint32_t *meta = nullptr, *bits = nullptr, *kind = nullptr, *cv = nullptr, *blk = nullptr, *perm = nullptr;
+  unsigned long long *key = nullptr, *sig = nullptr;
+  uint4 *q_rec = nullptr, *q_rows = nullptr;
+  uint32_t *q_bits = nullptr, *q_cv = nullptr, *q_meta = nullptr, *q_orig = nullptr, *qexact = nullptr, *s_kind = nullptr;
+  unsigned long long* s_sig = nullptr;
+  Tile* tiles = nullptr;  // [slots * inputs] (8 * SMALL_MAX in all): slot of (query s, part) = part * n + s
+};
+struct SmallZero { uint32_t* p[8]; uint32_t n[8]; };  // arrays k_small_tiles clears before the run (unused entries: n = 0)
+// k_enc_strings -> k_enc_gather (identity order) -> k_small_tiles on `st`: no allocation, no host wait.  blob / off may be pinned host
+// memory (read over PCIe; stage_lds: every block of k_enc_strings first copies its strings into LDS, inputs of <= 64 bytes).  qw: 16-byte words per query row (from the host's bound of the longest input)
+int small_encode_launch(const HostModel& m, const DeviceLexicon* dl, const SmallEnc& e, const uint8_t* blob, const uint32_t* off, uint32_t n, uint32_t qw,
+                        const anx_params& p, const SmallZero& z, uint32_t slots, bool stage_lds, hipStream_t st, std::string& err);  // slots: tile slots per query (>= 8)
+int small_iota(uint32_t* perm, uint32_t n, hipStream_t st);
+
 }  // namespace anx

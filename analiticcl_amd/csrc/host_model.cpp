@@ -447,6 +447,7 @@ const SwitchDef kSwitches[] = {
     {"ANX_ADJ_BUILD", [](Switches& s, const char* v) { s.adj_build_host = v && strcmp(v, "host") == 0; }},
     {"ANX_ADJ_CLOSURE", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 2; s.adj_closure = x >= 0 && x <= kAdjMaxClosure ? x : kAdjMaxClosure; }},
     {"ANX_ADJ_FAIL", [](Switches& s, const char* v) { s.adj_fail = flag01(v, 0); }},
+    {"ANX_SMALL", [](Switches& s, const char* v) { s.small_path = flag01(v, 1); }},
     {"ANX_ENC_PRIORITY", [](Switches& s, const char* v) { s.enc_priority = flag01(v, 1); }},
     {"ANX_HINTS", [](Switches& s, const char* v) { s.hints = flag01(v, 1); }},
     {"ANX_ADJ_MB", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.adj_budget_mb = x > 0 ? x : 16384; }},

@@ -89,6 +89,7 @@ struct Switches {
   int lattice_host = 0;      // ANX_LATTICE=host: lattice decoding on the host threads (A/B reference of the device kernel)
   int search_onepass = 1;    // ANX_SEARCH_ONEPASS=0: search mode downloads every ranked row and builds the lattice input on the host (the path until round 4; A/B reference)
   int adj_fail = 0;          // ANX_ADJ_FAIL=1 (test hook): the device build of the adjacency lists fails after its allocations: the replica must load without lists
+  int small_path = 1;        // ANX_SMALL=0: calls of a few inputs take the batch pipeline like the large ones (A/B reference of small_path.hpp)
   int enc_priority = 1;      // ANX_ENC_PRIORITY=0: the encoder's streams get normal instead of the highest stream priority (A/B)
   int hints = 1;             // ANX_HINTS=0: a batch's first run sizes its grids and buffers from worst-case estimates instead of the last finished batch of the same parameters
   int encode_timing = 0;     // ANX_ENCODE_TIMING, ANX_SEARCH_TIMING: host phase times on stderr

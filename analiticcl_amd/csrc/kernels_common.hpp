@@ -16,7 +16,8 @@ struct Tile {           // <= SCAN_TQ queries of one length and one signature (b
   uint32_t kend;        // bit-plane tiles: end (within the tile) of the queries of kind 1 | kind 2 << 8 | kind 3 << 16; the rest are kind 4
   uint32_t ball0, balln;  // balln > 0: probe the signature hash table with the balln offsets ball[ball0 ..] instead of walking [s0, s1)
   uint32_t adj;           // > 0: header index + 1 of the signature's adjacency list (adjacency.h): the tile streams it (bit-plane tiles, k <= kAdjRadius)
-  uint32_t flags;         // bit 0: the first tile of its (length, signature) group (statistics: list bytes a batch has to read at least once)
+  uint32_t flags;         // bit 0: the first tile of its (length, signature) group (statistics: list bytes a batch has to read at least once);
+                          // bit 1: the tile streams only rows [s0, s1) of its adjacency list (relative to the list's first row; the small call)
 };
 constexpr uint32_t BALL_MAX = 4096;   // largest L1 ball of signature offsets enumerated (per k; larger k walk the window)
 constexpr uint32_t SIG_BYTE_MAX = 120;  // group sums above this take the walk (byte-wise SWAR add of an offset must not overflow)

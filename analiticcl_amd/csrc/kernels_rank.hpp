@@ -64,7 +64,7 @@ __global__ __launch_bounds__(COMPACT_B) void k_compact_grouped(const SurvRec* __
     fill = region_cap;      // the host repeats the run with a larger survivor list
     if (threadIdx.x == 0) *overflow = 1u;
   }
-  for (uint32_t i0 = (blockIdx.x / SCAN_REGIONS) * COMPACT_B; i0 < fill; i0 += COMPACT_P * COMPACT_B) {  // block-uniform
+  for (uint32_t i0 = (blockIdx.x / SCAN_REGIONS) * COMPACT_B; i0 < fill; i0 += (gridDim.x / SCAN_REGIONS) * COMPACT_B) {  // block-uniform (COMPACT_P blocks per region; the small path launches fewer)
     for (uint32_t h = threadIdx.x; h < COMPACT_H; h += COMPACT_B) { h_key[h] = 0xFFFFFFFFu; h_cnt[h] = 0; }
     __syncthreads();
     const uint32_t i = i0 + threadIdx.x;
@@ -638,5 +638,118 @@ __global__ __launch_bounds__(256) void k_export_rows(uint32_t nq, const uint32_t
     r.freq_score = (float)d.freq_score;
     r.dist_score = d.dist_score;
     out[dst + i] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The small call (engine.hip small_find): at most SMALL_MAX queries in INPUT order (no sort: query s = input s), one
+// scan tile per query.  Two single-block kernels replace the prefix-sum launches, the cursor copy, the order scatter and
+// the downloads of the batch path: the whole call is eleven launches and ONE host wait.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SMALL_MAX = 4096;     // inputs per small call
+constexpr uint32_t SMALL_T = 1024;       // threads of the single-block kernels (4 queries per thread)
+__device__ inline uint32_t small_block_exscan(uint32_t v, uint32_t* s_w, uint32_t* total) {  // exclusive scan over SMALL_T threads
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+    if ((int)lane >= o) inc += u;
+  }
+  if (lane == 63u) s_w[wid] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t i = 0; i < SMALL_T / 64u; ++i) {
+    if (i < wid) base += s_w[i];
+    tot += s_w[i];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+// soff = exclusive scan of qsurv (n + 1 entries), qcur = soff (the cursors of k_compact_grouped)
+__global__ __launch_bounds__(SMALL_T) void k_small_offsets(const uint32_t* __restrict__ qsurv, uint32_t n, uint32_t* __restrict__ soff, uint32_t* __restrict__ qcur) {
+  __shared__ uint32_t s_w[SMALL_T / 64];
+  uint32_t v[4], s = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4u; ++i) {
+    const uint32_t q = threadIdx.x * 4u + i;
+    v[i] = q < n ? qsurv[q] : 0u;
+    s += v[i];
+  }
+  uint32_t tot;
+  uint32_t ex = small_block_exscan(s, s_w, &tot);
+#pragma unroll
+  for (uint32_t i = 0; i < 4u; ++i) {
+    const uint32_t q = threadIdx.x * 4u + i;
+    if (q < n) { soff[q] = ex; qcur[q] = ex; }
+    ex += v[i];
+  }
+  if (threadIdx.x == 0) soff[n] = tot;
+}
+// The ranked rows straight into the caller's (pinned, device-visible) result block, in input order: off[n + 1] (u64) and the
+// anx_result rows; behind them the counters the host checks the run's capacities with.  ctl[0] = rows written (0xFFFFFFFF: they
+// did not fit row_cap), ctl[1 ..]: largest pair-list / survivor / slot-list fill, candidate rows, the overflow flag.
+struct SmallCtl { uint32_t rows, maxfill, surv_fill, list_fill, total_surv, overflow, pad0, pad1; };
+__global__ __launch_bounds__(SMALL_T) void k_small_fetch(uint32_t n, const uint32_t* __restrict__ soff, const uint32_t* __restrict__ r_count, const DevRow* __restrict__ r_rows,
+                                                         const uint32_t* __restrict__ rctr, const uint32_t* __restrict__ sctr, const uint32_t* __restrict__ lctr,
+                                                         const uint32_t* __restrict__ counters, unsigned long long* __restrict__ off, anx_result* __restrict__ out, uint32_t row_cap,
+                                                         uint32_t crow_cap, SmallCtl* __restrict__ ctl) {
+  __shared__ uint32_t s_w[SMALL_T / 64];
+  __shared__ uint32_t s_max[3];
+  if (threadIdx.x < 3u) s_max[threadIdx.x] = 0u;
+  // k_compact_grouped / k_rank did nothing when the candidate rows did not fit or survivor records were dropped (r_count is stale then)
+  const bool ranked = soff[n] <= crow_cap && counters[CTR_OVERFLOW] == 0u;
+  uint32_t v[4], s = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4u; ++i) {
+    const uint32_t q = threadIdx.x * 4u + i;
+    v[i] = (ranked && q < n) ? r_count[q] : 0u;
+    s += v[i];
+  }
+  __shared__ uint32_t s_off[SMALL_MAX + 1];
+  uint32_t tot;
+  uint32_t ex = small_block_exscan(s, s_w, &tot);  // (its barriers also publish s_max = 0)
+  const bool fits = tot <= row_cap;
+#pragma unroll
+  for (uint32_t i = 0; i < 4u; ++i) {
+    const uint32_t q = threadIdx.x * 4u + i;
+    if (q < n) { if (blockIdx.x == 0) off[q] = ex; s_off[q] = ex; }
+    ex += v[i];
+  }
+  if (threadIdx.x == 0) s_off[n] = tot;
+  __syncthreads();
+  // The rows go to HOST memory (the caller's pinned block, over PCIe): consecutive lanes write consecutive rows, so that a wave's store
+  // is 2 KB of contiguous bytes (per-query loops wrote scattered 32-byte pieces: a thousand queries took 0.2 ms to leave the device).
+  // Output row r belongs to the query q with off[q] <= r < off[q + 1]: a binary search of the offsets in LDS.
+  if (fits)
+    for (uint32_t r = blockIdx.x * SMALL_T + threadIdx.x; r < tot; r += gridDim.x * SMALL_T) {  // (every block has the offsets; the rows are shared out)
+      uint32_t lo = 0, hi = n;  // the last q with s_off[q] <= r
+      while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_off[mid] <= r) lo = mid; else hi = mid;
+      }
+      const DevRow d = r_rows[soff[lo] + (r - s_off[lo])];
+      anx_result o;
+      o.vocab_id = d.vocab_id;
+      o.dist_score = d.dist_score;
+      o.freq_score = d.freq_score;
+      o.via = d.via == 0xFFFFFFFFu ? ANX_NO_VIA : (uint64_t)d.via;
+      out[r] = o;
+    }
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x < SCAN_REGIONS) {
+    atomicMax(&s_max[0], rctr[threadIdx.x * RC_STRIDE + RC_RAW]);
+    atomicMax(&s_max[1], sctr[threadIdx.x * RC_STRIDE]);
+    atomicMax(&s_max[2], max(max(lctr[threadIdx.x * RC_STRIDE], lctr[(SCAN_REGIONS + threadIdx.x) * RC_STRIDE]), lctr[(2u * SCAN_REGIONS + threadIdx.x) * RC_STRIDE]));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    off[n] = tot;
+    SmallCtl c;
+    c.rows = (fits && ranked) ? tot : 0xFFFFFFFFu;
+    c.maxfill = s_max[0]; c.surv_fill = s_max[1]; c.list_fill = s_max[2];
+    c.total_surv = soff[n]; c.overflow = counters[CTR_OVERFLOW]; c.pad0 = c.pad1 = 0u;
+    *ctl = c;
   }
 }

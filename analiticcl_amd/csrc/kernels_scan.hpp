@@ -556,8 +556,9 @@ __device__ inline void scan_tile(const ScanArgs& AA, const Tile& t, uint32_t ite
     // list = length lq - 3 + i; a list holds the ball of radius 3, a tile with a smaller k tests a few records more than it has to)
     const cptr_u32 hp = (cptr_u32)(A.adj_hdr + (size_t)(t.adj - 1u) * 8u);
     const uint32_t row0 = hp[0], c0 = hp[1], c1 = hp[2], c2 = hp[3], c3 = hp[4], c4 = hp[5], c5 = hp[6], c6 = hp[7];
-    const uint32_t rbeg = t.k >= 3u ? 0u : t.k == 2u ? c0 : t.k == 1u ? c1 : c2;
-    const uint32_t rend = t.k >= 3u ? c6 : t.k == 2u ? c5 : t.k == 1u ? c4 : c3;
+    uint32_t rbeg = t.k >= 3u ? 0u : t.k == 2u ? c0 : t.k == 1u ? c1 : c2;
+    uint32_t rend = t.k >= 3u ? c6 : t.k == 2u ? c5 : t.k == 1u ? c4 : c3;
+    if (t.flags & 2u) { rbeg = t.s0; rend = t.s1; }  // the small call splits a query's list over several waves (k_small_tiles): this tile's share of the rows
     arend = row0 + rend;
     if (lane == 0 && rend > rbeg) {  // statistics: rows streamed (bench.py: access bytes / bytes that have to be read at least once)
       atomicAdd(&wo.ctr[RC_ADJ], rend - rbeg);
@@ -678,3 +679,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 template <int NP>
 __global__ __launch_bounds__(256) void k_scan_sad(ScanArgs A) { scan_wave<NP, false, true>(A); }
 
+
+// The small call's scan: ONE launch over all tile slots of the call (engine.hip small_find: a tile per query and part, unused slots
+// have nq = 0), each wave taking the body its tile needs.  The three bodies share one kernel here -- occupancy does not matter for a
+// few thousand waves, the launches do (a small call is launch-bound).  Tiles hold ONE query.
+template <int NP>
+__global__ __launch_bounds__(256) void k_scan_small(ScanArgs A) {
+  constexpr int QW = NP > NBITPLANES ? NP : NBITPLANES;
+  __shared__ uint32_t s_qlds[4][QW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][SCAN_STAGE];
+  __shared__ uint32_t s_hits[4][2 * SCAN_HITS];
+  __shared__ uint4 s_qsym[4][1];
+  __shared__ uint32_t s_pbuf[4][SCAN_PBUF];
+  const uint32_t wid = threadIdx.x >> 6;
+  const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wid));
+  if (item >= A.ntiles) return;
+  const cptr_u32 tp = (cptr_u32)(A.tiles + item);
+  Tile t;
+  t.q0 = tp[0]; t.nq = tp[1]; t.s0 = tp[2]; t.s1 = tp[3]; t.k = tp[4]; t.lq = tp[5]; t.sig_lo = tp[6]; t.sig_hi = tp[7]; t.kind = tp[8]; t.d = tp[9]; t.kend = tp[10]; t.ball0 = tp[11]; t.balln = tp[12]; t.adj = tp[13]; t.flags = tp[14];
+  if (t.nq == 0u) return;  // an unused slot
+  if (t.kind == 0u) scan_tile<false, NP, true>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[wid], s_pbuf[wid]);
+  else if (t.adj) scan_tile<true, 8, false, true>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[wid], s_pbuf[wid]);
+  else scan_tile<true, 8, false>(A, t, item, s_stage[wid], s_hits[wid], s_qlds[wid], s_qsym[wid], s_pbuf[wid]);
+}

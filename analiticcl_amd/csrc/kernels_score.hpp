@@ -352,6 +352,7 @@ struct FilterArgs {
   uint32_t* counters;
   uint32_t* stat_ctr;       // [SCAN_REGIONS][RC_STRIDE], word 1: selected pairs
   uint32_t fill_cap;        // slots per region the grid covers (a region filled beyond it makes batch_finish repeat the run)
+  uint32_t blk;             // slots per block: FS_BLK in the batch path; the small call takes smaller blocks (a multiple of 256, <= FS_BLK): more blocks share its few pairs
 };
 // WIDE = true: the 8-word prefilter of pairs with a string of 17..32 symbols runs inline (batches with such queries: many
 // wide pairs).  WIDE = false (every query <= 16 symbols, so only the few pairs with a 17..19-symbol candidate are wide):
@@ -375,13 +376,13 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   __shared__ uint32_t s_str[256 * 9];
   // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
   // counter word sustains only ~88 M atomics/s)
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * FS_BLK;
+  const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * f.blk;
   if (base >= fill) return;  // block-uniform
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   uint32_t nselected = 0;  // wave-uniform
-  for (uint32_t r = 0; r < FS_BLK / 256; ++r) {
+  for (uint32_t r = 0; r < f.blk / 256; ++r) {
     const uint32_t idx = base + r * 256 + threadIdx.x;
     if (base + r * 256 >= fill) break;  // block-uniform
     const uint32_t p = (region << f.region_shift) + idx;
@@ -509,13 +510,13 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   }
 }
 
-constexpr uint32_t LIST_P = 64;  // blocks per region of the slot-list kernels
+constexpr uint32_t LIST_P = 64;  // blocks per region of the slot-list kernels (the kernels stride by gridDim.x / SCAN_REGIONS: the small path launches fewer)
 // The 8-word band-match prefilter of the wide pairs k_filter_score<D, false> deferred (listw): survivors go to the slot
 // list of the 8-word kernel (fastD > 0 and the batch uses it) or of the general kernel.
 __global__ __launch_bounds__(256) void k_filter_wide(SlotList in, FilterArgs f, PairArgs A, ScoreArgs a, int fastD, SlotList list8, SlotList listg) {
   const uint32_t region = blockIdx.x % SCAN_REGIONS, n = min(in.ctr[region * RC_STRIDE], in.region_cap), lane = threadIdx.x & 63;  // (a list filled beyond its capacity makes the host repeat the run)
   uint32_t nselected = 0;  // wave-uniform
-  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += LIST_P) {  // block-uniform
+  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += gridDim.x / SCAN_REGIONS) {  // block-uniform
     const uint32_t i = blk * 256 + threadIdx.x;
     const bool active = i < n;
     const uint32_t p = active ? in.list[(size_t)region * in.region_cap + i] : 0u;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, Sc
   // LIST_P blocks per region walk the region's slot list in strides: the list fills are only known on the device, and a
   // grid sized for the fullest possible list would consist of ~400 k empty blocks (0.08 ms of dispatch on config 2)
   const uint32_t region = blockIdx.x % SCAN_REGIONS, n = min(in.ctr[region * RC_STRIDE], in.region_cap);
-  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += LIST_P) {  // block-uniform
+  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += gridDim.x / SCAN_REGIONS) {  // block-uniform
     const uint32_t i = blk * 256 + threadIdx.x;
     const bool active = i < n;
     score_fast_pair<D, 8>(active ? in.list[(size_t)region * in.region_cap + i] : 0u, active, A, a, so, region, s_str);
@@ -570,7 +571,7 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
   uint32_t* __restrict__ qsurv = A.qsurv;
   uint32_t* __restrict__ qexpand = A.qexpand;
   const uint32_t region = blockIdx.x % SCAN_REGIONS, nsel = min(in.ctr[region * RC_STRIDE], in.region_cap);
-  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * blockDim.x < nsel; blk += LIST_P) {  // block-uniform; see k_score_fast8
+  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * blockDim.x < nsel; blk += gridDim.x / SCAN_REGIONS) {  // block-uniform; see k_score_fast8
   const uint32_t i_sel = blk * blockDim.x + threadIdx.x;
   bool keep = false;
   uint32_t kq = 0, ke = 0;

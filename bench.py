@@ -292,7 +292,9 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
                     got_ok = digest(last) == want and got_ok
             dt = time.perf_counter() - t
             got_ok = digest(last) == want and got_ok
+            pipe_last[0] = (last[0].copy(), last[1].copy())
             return njobs * args.queries / dt
+        pipe_last = [None]
         pipe_pass(8, True)   # every batch of this pass is checked (and the pools of the extra buffers warm up); hashing 70 MB per
         passes = sorted(pipe_pass(40, False) for _ in range(5))  # best and median of five passes of 40 jobs (filling and draining the
         pipelined, pipelined_median = passes[-1], passes[2]     # pipeline is inside the timed pass: ~6 % at this length)
@@ -300,10 +302,81 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
         pl.close()
         e2e = {"queries_per_s": args.queries / best[0], "two_threads_queries_per_s": piped,
                "pipelined_queries_per_s": pipelined, "pipelined_median_queries_per_s": pipelined_median, "pipelined_parity": "ok (every batch's rows equal the synchronous path's)" if got_ok else "MISMATCH", "s_per_batch": best[0], "encode_upload_s": best[1], "run_s": best[2],
-               "download_s": best[3], "rows": best[4],
+               "download_s": best[3], "rows": best[4], "pipelined_last": pipe_last[0],
                "what": "host buffer of NUL-terminated UTF-8 strings -> anx_batch_encode_packed (H2D + device-side encoder) -> anx_batch_run -> "
                        "anx_batch_fetch_compact (ranked rows in input order as 16-byte records + u32 offsets, pinned host memory), best of 3, one batch at a time, no overlap between batches"}
     return e2e
+
+
+def by_batch_size_of(model, om, queries, params, op, sizes=(1, 64, 1000, 32768, 1_000_000), threads=8):
+    """The call at the reference's own granularity (find_variants takes ONE string, src/lib.rs:972; the CLI and the Python binding fan out
+    in batches of 1 000, src/bin/analiticcl.rs:416, bindings/python/src/lib.rs:704-749): anx_find_variants_batch (char** in, anx_result
+    rows + offsets out) host to host for n = 1 .. 1 M inputs -- best / median microseconds per call, the rows of every size against the
+    oracle -- and `threads` host threads each issuing calls of 1 000 inputs on the one model.  Calls of <= 4096 short inputs take the
+    small path (analiticcl_amd/csrc/small_path.hpp: eleven launches, one host wait); larger ones the batch pipeline."""
+    import ctypes as C
+    import random
+    import statistics
+    import threading
+
+    import analiticcl_amd as A
+    from analiticcl_amd import _lib as LL
+    L = A.lib()
+    cp = params._c()
+    enc = [q.encode("utf-8") for q in queries]
+    res = {}
+
+    def small_taken():
+        out = (C.c_uint64 * 2)()
+        L.anx_debug_small_stats(out)
+        return out[0]
+    for n in sizes:
+        n = min(n, len(enc))
+        arr = (C.c_char_p * n)(*enc[:n])
+        reps = 200 if n <= 1000 else 30 if n <= 32768 else 5
+        ts = []
+        t_small = small_taken()
+        for r in range(reps + 3):
+            rows = C.POINTER(LL.Result)()
+            offs = C.POINTER(C.c_size_t)()
+            t = time.perf_counter()
+            rc = L.anx_find_variants_batch(model.h, arr, n, C.byref(cp), C.byref(rows), C.byref(offs))
+            dt = time.perf_counter() - t
+            if rc != 0:
+                raise RuntimeError(LL.last_error())
+            if r == reps + 2:   # the last call's rows against the oracle (a sample of the larger sizes)
+                idx = list(range(n)) if n <= 64 else random.Random(n).sample(range(n), 200)
+                for i in idx:
+                    got = [(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score) for j in range(offs[i], offs[i + 1])]
+                    if got != om.find_variants(queries[i], op):
+                        raise RuntimeError(f"by_batch_size n={n}: rows of {queries[i]!r} differ from the oracle's")
+            L.anx_results_free(rows, offs)
+            if r >= 3:
+                ts.append(dt)
+        res[str(n)] = {"best_us": min(ts) * 1e6, "median_us": statistics.median(ts) * 1e6, "queries_per_s_best": n / min(ts), "calls": reps,
+                       "path": "small" if small_taken() - t_small == reps + 3 else "batch", "parity": f"ok ({min(n, 200) if n > 64 else n} queries vs the oracle)"}
+    n, per = min(1000, len(enc) // threads), 100
+    arrs = [(C.c_char_p * n)(*enc[i * n:(i + 1) * n]) for i in range(threads)]
+
+    def worker(a):
+        for _ in range(per):
+            rows = C.POINTER(LL.Result)()
+            offs = C.POINTER(C.c_size_t)()
+            if L.anx_find_variants_batch(model.h, a, n, C.byref(cp), C.byref(rows), C.byref(offs)) != 0:
+                raise RuntimeError("threads: call failed")
+            L.anx_results_free(rows, offs)
+    best = 0.0
+    for _pass in range(3):
+        th = [threading.Thread(target=worker, args=(a,)) for a in arrs]
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        best = max(best, threads * per * n / (time.perf_counter() - t))
+    res[f"threads{threads}_n{n}"] = {"queries_per_s": best, "calls_per_pass": threads * per,
+                                     "what": f"{threads} host threads, each {per} calls of {n} inputs on the one model (ctypes releases the GIL for the call), best of 3 passes"}
+    return res
 
 
 def cpu_baseline_of(args, paths, queries, ncores, seconds=15.0):
@@ -989,6 +1062,7 @@ def main():
     # encoder (anx_batch_encode_packed_device: no PCIe) + anx_batch_run_async, the run waited for a step later -- the encoder of
     # step i + 1 works while the GPU runs step i.  Never `value`: reported next to it.
     with_encode = None
+    with_encode_rows = None
     if world == 1 and not do_gather and not args.timed_only:
         packed_ = ("\0".join(queries) + "\0").encode("utf-8")
         dev_blob = torch.frombuffer(bytearray(packed_), dtype=torch.uint8).cuda()
@@ -1003,12 +1077,16 @@ def main():
                 o_.wait()
                 o_.free()
 
-        def enc_drain():
+        def enc_drain(keep_last=False):
+            last_ = None
             while live:
                 o_ = live.pop(0)
                 o_.wait()
+                if keep_last and not live:
+                    last_ = o_.fetch_arrays()   # the rows of the last fresh batch: checked against the oracle below
                 o_.free()
             torch.cuda.synchronize()
+            return last_
         for _ in range(3):
             enc_step()
         enc_drain()
@@ -1018,6 +1096,8 @@ def main():
             enc_step()
         enc_drain()
         dt_ = (time.perf_counter() - t1) / nenc
+        enc_step()   # one more fresh batch, outside the timed loop: its rows are checked against the oracle below
+        with_encode_rows = enc_drain(keep_last=True)
         with_encode = {"ms_per_step": dt_ * 1e3, "queries_per_s": len(queries) / dt_, "pairs_per_s": batch.stats()["n_pairs"] / dt_, "steps": nenc,
                        "what": "raw packed input bytes resident in HBM -> device-side encoder (k_enc_strings, sort, k_enc_gather, tiles) -> scan -> score -> rank; "
                                "a fresh batch per step (anx_batch_encode_packed_device + anx_batch_run_async), the run of step i waited for and freed after "
@@ -1078,14 +1158,27 @@ def main():
         # parity of the TIMED batch itself: sampled queries of the rows the last timed step left on the device against the oracle
         # (ranked ids, f64 scores) -- after the timed region, never inside it
         parity = None
+        by_batch_size = None
         if args.spot_check > 0 and not args.timed_only:
             from oracle import cwrap as O
             om_ = O.OracleModel(alphabet_path=paths["alphabet"])
             om_.read_lexicon(paths[args.lexicon])
             om_.build()
-            parity = _spot_check(model, om_, queries, batches[(args.steps - 1) & 1].fetch_arrays(),
-                                 O.make_params(("abs", args.anagram_distance), ("abs", args.edit_distance), 10, 0.25, 2.0), min(args.spot_check, len(queries)))
+            op_ = O.make_params(("abs", args.anagram_distance), ("abs", args.edit_distance), 10, 0.25, 2.0)
+            parity = _spot_check(model, om_, queries, batches[(args.steps - 1) & 1].fetch_arrays(), op_, min(args.spot_check, len(queries)))
+            # the paths a caller uses, each against the ORACLE (not against the synchronous path): a fresh batch of the with_encode loop
+            # (device-resident inputs) and a batch that went through anx_pipeline
+            if with_encode is not None and with_encode_rows is not None:
+                with_encode["parity"] = _spot_check(model, om_, queries, with_encode_rows, op_, min(args.spot_check, len(queries)))
+            if e2e is not None and e2e.get("pipelined_last") is not None:
+                off_, rows_ = e2e.pop("pipelined_last")
+                e2e["pipelined_oracle_parity"] = _spot_check(model, om_, queries, (off_, rows_["vocab_id"], rows_["dist_score"], rows_["freq_score"]), op_,
+                                                             min(args.spot_check, len(queries)))
+            if world == 1 and not do_gather:
+                by_batch_size = by_batch_size_of(model, om_, queries, params, op_)
             del om_
+        if e2e is not None:
+            e2e.pop("pipelined_last", None)
         # the CPU baseline is reported from rank 0; at N > 1 on a shorter sample (the other ranks wait at the final barrier)
         cpu = cpu_baseline_of(args, paths, queries, ncores, 15.0 if world == 1 else 6.0) if (args.cpu_sample != 0 and not args.timed_only) else None
         # one resident copy, one run at a time (anx_batch_run: launch, wait, launch ...): the like-for-like figure of round 1's records
@@ -1102,7 +1195,10 @@ def main():
             "pipelining": "2 resident copies of the batch alternate: anx_batch_run_async from ONE caller stream, each waited for a step later; the library runs "
                           "consecutive asynchronous runs on two streams of its own (the scan of one under the scoring tail / compaction / ranking of the other)",
             "serial_ms_per_step": serial_ms,
-            "ms_per_step_with_encode": with_encode["ms_per_step"] if with_encode else None, "with_encode": with_encode,
+            "ms_per_step_with_encode": with_encode["ms_per_step"] if with_encode else None,
+            "pairs_per_s_with_encode": with_encode["pairs_per_s"] if with_encode else None,   # the fresh-batch step: what a caller executes
+            "queries_per_s_with_encode": with_encode["queries_per_s"] if with_encode else None,
+            "with_encode": with_encode, "by_batch_size": by_batch_size,
             "kernels_ms_in_timed_region": overlapped_kernel_ms,
             "sync_single_copy_ms_per_step": sync_ms,
             "parity": parity, "preroll_steps": preroll_steps,

@@ -28,7 +28,7 @@ extern "C" {
  * 3: anx_pipeline_submit_packed NEVER blocks: with `depth` jobs in flight it returns ANX_ELIMIT and submits nothing (until the middle
  *    of ABI 2's life it waited instead -- a binding written against the blocking contract sees failing submits, hence the new
  *    version); anx_batch_encode_packed_device_on (the caller's stream orders the encoder behind the producer of the buffer);
- *    anx_debug_search_stats; ANX_ADJ_CLOSURE is 0..2 for every builder.  Nothing was removed; every struct of version 2 is unchanged. */
+ *    anx_debug_search_stats, anx_debug_small_stats (anx_find_variants_batch's path for small calls); ANX_ADJ_CLOSURE is 0..2 for every builder.  Nothing was removed; every struct of version 2 is unchanged. */
 #define ANX_ABI_VERSION 3
 
 enum {
@@ -341,6 +341,12 @@ int anx_debug_kernel_time(const char *name, double *total_ms, uint64_t *launches
  * calls whose output arrays were written while later parts were still on the device, out[2] = calls that were eligible for that but
  * had to write at the end (an upper bound did not hold), out[3] = 0 (reserved). */
 int anx_debug_search_stats(uint64_t out[4]);
+/* The small call: anx_find_variants_batch answers calls of at most 4096 inputs of at most 64 bytes each (single-device models without
+ * variant lists, confusables or StopAtExactMatch) through a path of eleven launches and one host wait with preallocated buffers (the
+ * reference's own granularity: one string per call, src/lib.rs:972; 1 000 per batch, src/bin/analiticcl.rs:416) instead of the batch
+ * pipeline; results are identical.  ANX_SMALL=0 switches it off (A/B).  out[0] = calls it answered since the library was loaded,
+ * out[1] = calls it handed to the batch pipeline because a fixed capacity did not hold. */
+int anx_debug_small_stats(uint64_t out[2]);
 /* The length-partitioned split by itself (no device needed): which of n_shards replicas each of the n inputs
  * would go to (out_shard[i] in 0 .. n_shards - 1; see anx_batch_shard_info).  bench.py and the tests use it to build one GPU's share of
  * a larger job (BASELINE configs[3]) on a one-GPU box.  learn_ms (may be NULL): the device times of THOSE shares, measured by the caller

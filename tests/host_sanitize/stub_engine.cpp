@@ -31,9 +31,13 @@ void device_pool_trim(int) {}
 void kernel_timer_enable(bool) {}
 bool kernel_timer_read(const char*, double* ms, uint64_t* n) { if (ms) *ms = 0.0; if (n) *n = 0; return false; }
 int debug_band_bound(int, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, int, int, uint8_t*, std::string& err) { err = "stub: no device"; return ANX_ENODEVICE; }
-void* stream_create(int, std::string&) { return malloc(1); }
+void* stream_create(int, std::string&, bool) { return malloc(1); }
 void stream_destroy(int, void* s) { free(s); }
 void* host_result_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+bool host_result_is_pinned(void*) { return false; }
+void small_stats(uint64_t* out) { out[0] = out[1] = 0; }
+// the small call needs the device: the stub never takes it (the batch entry points run on the fake devices)
+int small_find(const HostModel&, const DeviceLexicon*, const char* const*, size_t, const anx_params&, anx_result**, size_t**, std::string&) { return 1; }
 void encoder_stream_set_override(void*) {}
 void* thread_stream_begin(int) { return nullptr; }
 void thread_stream_end(int, void*) {}
@@ -48,7 +52,7 @@ Batch* batch_encode(const HostModel&, const DeviceLexicon* dl, const char* const
   for (size_t i = 0; i < n; ++i) b->in.emplace_back(utf8[i] ? utf8[i] : "");
   return b;
 }
-Batch* batch_encode_spans(const HostModel&, const DeviceLexicon* dl, const char* blob, size_t bytes, const uint32_t* off, size_t n, const anx_params&, std::string& err, int* code, bool, bool) {
+Batch* batch_encode_spans(const HostModel&, const DeviceLexicon* dl, const char* blob, size_t bytes, const uint32_t* off, size_t n, const anx_params&, std::string& err, int* code, bool, bool, bool, void*) {
   if (!dl) { err = "stub: no device"; if (code) *code = ANX_ENODEVICE; return nullptr; }
   Batch* b = new Batch();
   if (off) {
