@@ -788,7 +788,7 @@ int batch_encode_device(const HostModel& m, const DeviceLexicon* dl, Batch* b, c
   lap("k_enc_gather");
   // ---- tiles --------------------------------------------------------------------------------------------------------------
   TileArgs ta;
-  ta.tq = switches().scan_tq ? (uint32_t)switches().scan_tq : SCAN_TQ_DEFAULT;
+  ta.tq = switches().scan_tq ? (uint32_t)switches().scan_tq : default_scan_tq(ea.ngroups);
   ta.nq = nq; ta.q_meta = b->q_meta; ta.s_kind = s_kind; ta.s_sig = s_sig; ta.siglen_begin = dl->alpha.siglen_begin; ta.ctr = d_ctr;
   ta.ball_tab = dl->ball_tab; ta.probe = probe_enabled() ? 1 : 0;
   ta.adj_hash = dl->adj_hash; ta.adj_mask = switches().scan_adj ? dl->adj_mask : 0u;

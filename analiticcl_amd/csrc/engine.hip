@@ -828,7 +828,9 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
     const int lo = std::max<int>(1, (int)lq - (int)k), hi = std::min<int>(kMaxSymbols, (int)lq + (int)k);
     // aligned to whole 64-signature blocks (the neighbours inside the edge blocks belong to charcounts outside the window)
     const uint32_t s0 = m.lex.siglen_begin[lo] & ~63u, s1 = (m.lex.siglen_begin[hi + 1] + 63u) & ~63u;
-    const uint32_t tq = switches().scan_tq ? (uint32_t)switches().scan_tq : SCAN_TQ_DEFAULT;
+    uint32_t ngroups_ = 1;
+    for (uint8_t g_ : m.lex.sym_group) ngroups_ = std::max<uint32_t>(ngroups_, (uint32_t)g_ + 1u);
+    const uint32_t tq = switches().scan_tq ? (uint32_t)switches().scan_tq : default_scan_tq((int)ngroups_);
     // The count-vector (SAD) tiles are rare (queries with a symbol more than NBITPLANES times) and run as a launch of
     // their own: a handful of waves whose time is the latency of ONE wave walking the whole signature window.  Their
     // windows are therefore split over several waves (disjoint signature ranges = disjoint classes: same pairs).
@@ -1278,7 +1280,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     A.cls_len = dl->cls_len; A.cls_off = dl->cls_off; A.sig = dl->sig; A.sig_e = dl->sig_e; A.sig_cbeg = dl->sig_cbeg; A.sighash = dl->sighash; A.sighash_e = dl->sighash_e; A.hash_mask = dl->hash_mask; A.ball = dl->ball;
     A.adj_hdr = dl->adj_hdr; A.adj_planes = dl->adj_planes; A.adj_ids = dl->adj_ids;
     A.chunk = SCAN_CHUNK;
-    A.chunk_fused = SCAN_CHUNK_FUSED;
+    A.chunk_fused = switches().scan_chunk_fused ? (uint32_t)switches().scan_chunk_fused : SCAN_CHUNK_FUSED;
 #ifdef ANX_DEBUG_SWITCHES
     { const char* e = getenv("ANX_SCAN_CHUNK"); const int v = e ? atoi(e) : 0; if (v >= 32 && v <= 1024) A.chunk = (uint32_t)v; }
 #endif

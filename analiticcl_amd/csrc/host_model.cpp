@@ -446,6 +446,7 @@ const SwitchDef kSwitches[] = {
     {"ANX_SCAN_ADJ", [](Switches& s, const char* v) { s.scan_adj = flag01(v, 1); }},
     {"ANX_ADJ_BUILD", [](Switches& s, const char* v) { s.adj_build_host = v && strcmp(v, "host") == 0; }},
     {"ANX_ADJ_CLOSURE", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 2; s.adj_closure = x >= 0 && x <= kAdjMaxClosure ? x : kAdjMaxClosure; }},
+    {"ANX_SCAN_CHUNK_FUSED", [](Switches& s, const char* v) { const int x = v ? atoi(v) : 0; s.scan_chunk_fused = x >= 32 && x <= 1024 ? x : 0; }},
     {"ANX_ADJ_FAIL", [](Switches& s, const char* v) { s.adj_fail = flag01(v, 0); }},
     {"ANX_SMALL", [](Switches& s, const char* v) { s.small_path = flag01(v, 1); }},
     {"ANX_ENC_PRIORITY", [](Switches& s, const char* v) { s.enc_priority = flag01(v, 1); }},
@@ -568,7 +569,7 @@ int HostModel::build_index(std::string& err) {
     std::vector<uint32_t> slots(cvbytes);
     std::iota(slots.begin(), slots.end(), 0u);
     std::stable_sort(slots.begin(), slots.end(), [&](uint32_t a, uint32_t b) { return slot_freq[a] > slot_freq[b]; });
-    const int ngroups = switches().sig_groups ? switches().sig_groups : kSigGroups;
+    const int ngroups = switches().sig_groups ? switches().sig_groups : (decoder.size() <= kSigGroupsWideMax ? kSigGroupsWide : kSigGroups);
     uint64_t weight[8] = {};
     lex.sym_group.assign(cvbytes, 0);
     for (uint32_t sl : slots) {

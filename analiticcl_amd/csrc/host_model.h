@@ -88,6 +88,7 @@ struct Switches {
   int confusables_host = 0;  // ANX_CONFUSABLES=host: confusable weighting on the host threads (A/B reference of the device kernel)
   int lattice_host = 0;      // ANX_LATTICE=host: lattice decoding on the host threads (A/B reference of the device kernel)
   int search_onepass = 1;    // ANX_SEARCH_ONEPASS=0: search mode downloads every ranked row and builds the lattice input on the host (the path until round 4; A/B reference)
+  int scan_chunk_fused = 0;  // ANX_SCAN_CHUNK_FUSED=32..1024: pair-list slots a wave of a fused-filter tile reserves per atomic (0 = default)
   int adj_fail = 0;          // ANX_ADJ_FAIL=1 (test hook): the device build of the adjacency lists fails after its allocations: the replica must load without lists
   int small_path = 1;        // ANX_SMALL=0: calls of a few inputs take the batch pipeline like the large ones (A/B reference of small_path.hpp)
   int enc_priority = 1;      // ANX_ENC_PRIORITY=0: the encoder's streams get normal instead of the highest stream priority (A/B)
@@ -170,6 +171,14 @@ struct LexiconImage {
   std::vector<uint32_t> sig_cbeg;       // [nsig_pad+1] first class of the run (padding: nclasses)
   uint32_t siglen_begin[kMaxSymbols + 2];  // signature range per charcount
 };
+// Round 6, with the signature adjacency lists (no ball walk per tile any more; every kernel alone on the GPU, ms: scan / filter+score /
+// device pass): eng.aspell k=3 d=2 1 M queries, 7 groups 1.105 / 0.824 / 2.59 (4.65 G record tests, 60.6 k tiles of <= 48 queries),
+// 8 groups 0.913 / 0.812 / 2.39 (2.78 G tests, 106 k tiles of <= 32); nld.aspell d=3: 1.431 / 2.56 / 4.89 -> 1.277 / 2.58 / 4.80;
+// the 1 M-entry lexicon of BASELINE configs[3]: 4.39 / 2.96 / 9.32 -> 4.03 / 3.16 / 9.38 (its emptier tiles cost the scoring kernel
+// what the scan gains).  So: 8 groups up to kSigGroupsWideMax entries, kSigGroups above.  ANX_SIG_GROUPS overrides.
+constexpr int kSigGroupsWide = 8;
+constexpr size_t kSigGroupsWideMax = 500000;
+inline uint32_t default_scan_tq(int ngroups) { return ngroups >= 8 ? 32u : 48u; }  // queries per scan tile the encoders cut groups into (ANX_SCAN_TQ overrides)
 constexpr int kSigGroups = 7;  // measured (round 2, hash-probe walk): eng.aspell k=3 d=2, 1 M queries: 6 groups 5.45 k record tests per
                                // query, 37.8 k tiles, 3.33 ms per step; 7: 4.14 k tests, 56.6 k tiles, 3.22 ms; 8: 2.35 k tests,
                                // 96 k tiles, 3.48 ms.  1 M-entry lexicon, 1.25 M queries: 13.5 / 12.2 / 13.8 ms

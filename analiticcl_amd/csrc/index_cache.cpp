@@ -61,7 +61,11 @@ int HostModel::save_index(const std::string& path, std::string& err) const {
   if (!f) { err = "cannot create " + path; return ANX_EIO; }
   Writer w{f};
   w.raw(kMagic, sizeof kMagic);
-  w.pod<uint32_t>(kSigGroups);
+  {
+    uint32_t ng = 1;
+    for (uint8_t g : lex.sym_group) ng = std::max<uint32_t>(ng, (uint32_t)g + 1u);
+    w.pod<uint32_t>(ng);  // signature groups in use (7 or 8 by the size of the lexicon; the per-slot groups follow in the image)
+  }
   w.str(alphabet_fingerprint(alphabet));
   w.str(index_tag);  // the caller's description of what the image was built from (anx_model_set_index_tag)
   w.pod<uint8_t>(have_freq ? 1 : 0);
@@ -101,7 +105,7 @@ int HostModel::load_index(const std::string& path, std::string& err) {
   r.pod(groups);
   std::string fp;
   r.str(fp);
-  if (!r.ok || memcmp(magic, kMagic, sizeof kMagic) != 0 || groups != (uint32_t)kSigGroups) {
+  if (!r.ok || memcmp(magic, kMagic, sizeof kMagic) != 0 || groups < 1u || groups > 8u) {
     fclose(f);
     err = path + " is not an index image of this library version";
     return ANX_EINVAL;

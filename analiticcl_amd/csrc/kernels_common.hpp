@@ -24,7 +24,7 @@ constexpr uint32_t SIG_BYTE_MAX = 120;  // group sums above this take the walk (
 
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
 constexpr uint32_t SCAN_TQ = 64;         // most queries a tile (= a wave) can hold, compared in passes of 32 (one hit-mask bit each)
-constexpr uint32_t SCAN_TQ_DEFAULT = 48; // queries per tile the encoders cut groups into (ANX_SCAN_TQ overrides).  Measured on BASELINE configs[1], three interleaved
+constexpr uint32_t SCAN_TQ_DEFAULT = 48; // (until round 6; now host_model.h default_scan_tq: 48 with 7 signature groups, 32 with 8) queries per tile the encoders cut groups into (ANX_SCAN_TQ overrides).  Measured on BASELINE configs[1], three interleaved
                                          // runs each: 64 -> k_scan_bits 1.55-1.57 ms, 56 -> 1.51-1.55, 48 -> 1.51-1.52, 40 -> 1.52 (more, smaller tiles of
                                          // the large groups balance the waves better than the longest-first order alone; configs[3] shares: 32 slightly ahead of 64)
 constexpr uint32_t SCAN_HITS = 512;      // per-wave LDS hit list of the scan (entries); expanded when fewer than 256 are free

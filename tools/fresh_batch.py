@@ -21,7 +21,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
-def setup(nq=1_000_000, lexicon="eng", max_len=16):
+def setup(nq=1_000_000, lexicon=os.environ.get("FB_LEX", "eng"), max_len=int(os.environ.get("FB_MAXLEN", "16"))):
     import torch
 
     import analiticcl_amd as A
@@ -33,7 +33,7 @@ def setup(nq=1_000_000, lexicon="eng", max_len=16):
     model.build()
     words = synth.load_lexicon_words(paths[lexicon])
     queries = synth.make_queries(words, nq, max_len=max_len, seed=synth.SEED)
-    params = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+    params = A.SearchParameters(max_anagram_distance=3, max_edit_distance=int(os.environ.get("FB_D", "2")), max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
     return torch, A, model, queries, params, paths
 
 
@@ -120,6 +120,23 @@ def main():
         out["ms_per_step"] = (time.perf_counter() - t) / steps * 1e3
         st = bs[0].stats()
         out["stage_ms_last"] = {k: st[k] for k in ("ms_scan", "ms_score", "ms_group", "ms_rank", "ms_total", "ms_scan_kernel", "ms_filter_score_kernel")}
+    elif mode == "kernels":
+        # every kernel alone on the GPU (ANX_RUN_OVERLAP=0, one stream): HIP-event times of the run's stages, averaged
+        A.set_switch("ANX_RUN_OVERLAP", "0")
+        b = model.encode_packed_device(dev_blob.data_ptr(), dev_blob.numel(), len(queries), params)
+        for _ in range(10):
+            b.run(stream)
+        acc = {}
+        t = time.perf_counter()
+        for _ in range(steps):
+            b.run(stream)
+            st = b.stats()
+            for k in ("ms_scan", "ms_score", "ms_group", "ms_rank", "ms_total", "ms_scan_kernel", "ms_filter_score_kernel"):
+                acc[k] = acc.get(k, 0.0) + st[k] / steps
+        out["ms_per_step"] = (time.perf_counter() - t) / steps * 1e3
+        out["stage_ms"] = {k: round(v, 4) for k, v in acc.items()}
+        out["tiles"] = st["n_scan_blocks"]; out["class_tests"] = st["n_class_tests"]; out["pairs"] = st["n_pairs"]; out["slots"] = st["n_pair_slots"]
+        out["adj_records"] = st["n_adj_records"]; out["adj_tiles"] = st["n_adj_tiles"]
     elif mode == "small":
         out["by_batch_size"] = small_calls(A, model, queries, params)
     print(json.dumps(out))
