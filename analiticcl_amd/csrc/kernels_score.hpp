@@ -121,6 +121,10 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
 template <int NW>
 __device__ inline uint32_t byte_of(const uint32_t (&w)[NW], int idx) { return (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; }
 
+// (round 6, measured and dropped: taking the transposition term's "an earlier query symbol equals t[j-1]" tests from the match bits of
+// the D rows above -- column c of row i and column c+1+a of row i-1-a are the same candidate symbol -- instead of comparing again:
+// v_cmp 415 -> 368 in the ISA of k_filter_score<2>, but the masks kept across the exec-masked rows cost more in merges than the
+// compares saved: 2028 -> 2094 VALU, 1138 -> 1573 SALU instructions)
 template <int D, int NW>
 __device__ inline uint32_t dl_band(const uint32_t (&S)[NW], const uint32_t (&T)[NW], int lq, int lc, int lqmax) {
   constexpr int BW = 2 * D + 1, NR = D + 2, MAXLEN = 4 * NW;

@@ -495,6 +495,31 @@ def _e2e_packed(model, queries, params, reps=3):
     return len(queries) / best
 
 
+def _cpu_baseline_config(om, qs, op, ncores, st, seconds=8.0, post=None, post_what=""):
+    """The C oracle (a "port" of the reference algorithm; oracle/anx_oracle.c, OpenMP batch entry) over a bounded prefix of an extra
+    configuration's queries on this box's host cores.  post(rows of query i, query) -> rows: what the configuration does on top
+    (configs[2]: the confusable weighting of oracle/confusable_oracle.py, Python), timed with it.  st: the GPU run's statistics (pairs per query)."""
+    from oracle import cwrap as O
+    ncal = min(len(qs), 16 * ncores)
+    t = time.perf_counter()
+    O.batch_rows(om, qs[:ncal], op, nthreads=ncores, stride=32)
+    rate = ncal / max(time.perf_counter() - t, 1e-3)
+    n = int(max(ncal, min(len(qs), rate * seconds)))
+    t = time.perf_counter()
+    c, ov, od, of, tp, _tc = O.batch_rows(om, qs[:n], op, nthreads=ncores, stride=32)
+    dt_c = time.perf_counter() - t
+    dt_post = 0.0
+    if post is not None:
+        t = time.perf_counter()
+        for i in range(n):
+            post([(int(ov[i, j]), float(od[i, j]), float(of[i, j])) for j in range(c[i])], qs[i])
+        dt_post = time.perf_counter() - t
+    dt = dt_c + dt_post
+    return {"value": tp / dt, "unit": "pairs/s", "queries_per_s": n / dt, "cores": ncores, "kind": "port",
+            "sample": f"first {n} of the configuration's {len(qs)} queries, C oracle (oracle/anx_oracle.c, OpenMP, {ncores} threads) {dt_c:.1f} s"
+                      + (f" + {post_what} {dt_post:.1f} s (one Python thread)" if post is not None else "")}
+
+
 def extra_configs(args, paths, device, ncores):
     """BASELINE.json's other configurations and the literal metric configuration on this one GPU, each behind a parity spot check.
     Every entry carries its own wall time ("took_s"); an entry that fails says why instead of stopping the bench."""
@@ -532,7 +557,8 @@ def extra_configs(args, paths, device, ncores):
         om.build()
         chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
         b.free()
-        return {"workload": "nld.aspell (222 908 entries) + simple.alphabet, 1 M queries len<=16, k=3 d=2 n=10", "ms_per_step": dt * 1e3,
+        cpu1 = _cpu_baseline_config(om, qs, O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), ncores, st, seconds=6.0)
+        return {"workload": "nld.aspell (222 908 entries) + simple.alphabet, 1 M queries len<=16, k=3 d=2 n=10", "ms_per_step": dt * 1e3, "cpu_baseline": cpu1,
                 "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt, "pairs_per_query": st["n_pairs"] / max(st["n_queries"], 1),
                 "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "parity": chk,
                 "roofline": _config_roofline(m, qs, st, dt * 1e3, "nld", 16, 2, 1_000_000)}
@@ -564,7 +590,9 @@ def extra_configs(args, paths, device, ncores):
                           rescore=lambda exp, q: CO.late_rescore(exp, q, confs, om.text, 0.0, 2.0))
         b.free()
         e2e = _e2e_packed(m, qs, p)
-        return {"workload": "BASELINE.json configs[2]: nld.aspell, 1 M queries len<=24, k=3 d=3 n=10, 10 confusable patterns", "device_ms": dt * 1e3,
+        cpu2 = _cpu_baseline_config(om, qs, O.make_params(("abs", 3), ("abs", 3), 10, 0.25, 0.0), ncores, st,
+                                    post=lambda rows_, q_: CO.late_rescore(rows_, q_, confs, om.text, 0.0, 2.0), post_what="confusable weighting (oracle/confusable_oracle.py)")
+        return {"workload": "BASELINE.json configs[2]: nld.aspell, 1 M queries len<=24, k=3 d=3 n=10, 10 confusable patterns", "device_ms": dt * 1e3, "cpu_baseline": cpu2,
                 "pairs_per_s": st["n_pairs"] / dt, "e2e_queries_per_s": e2e, "parity": chk, "conf_scripts": st["n_conf_scripts"],
                 "roofline": _config_roofline(m, qs, st, dt * 1e3, "nld", 24, 3, 1_000_000,
                                              extra=("k_conf_script", conf_ms / max(conf_n, 1), conf_bytes,
@@ -592,6 +620,9 @@ def extra_configs(args, paths, device, ncores):
         om.build()
         chk = _spot_check(m, om, qs, b.fetch_arrays(), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), nspot)
         b.free()
+        import random as _random
+        cpu3 = _cpu_baseline_config(om, _random.Random(3).sample(qs, 60_000), O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), ncores, st)   # (a random sample: the queries are sorted by length)
+        del om
         # The WHOLE 10 M-query job cut the way a multi-device model cuts it (anx_model_to_devices: length-partitioned split into 8
         # cost-balanced shares, anx_debug_length_split), every share run on this one GPU one after the other: the longest share is
         # what an 8-GPU job takes.  Round 0 = the FIRST call (the split's prior alone: records per query of every (length, signature
@@ -616,7 +647,7 @@ def extra_configs(args, paths, device, ncores):
         del job
         os.unlink(path)
         return {"workload": "BASELINE.json configs[3], one GPU's share: merged 1 M-entry synthetic lexicon, 1.25 M of the 10 M length-bucketed queries len 4-32, k=3 d=2 n=10",
-                "ms_per_batch": dt * 1e3, "ms_per_1M_queries": dt * 1e3 / 1.25, "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt,
+                "ms_per_batch": dt * 1e3, "ms_per_1M_queries": dt * 1e3 / 1.25, "pairs_per_s": st["n_pairs"] / dt, "queries_per_s": st["n_queries"] / dt, "cpu_baseline": cpu3,
                 "scan_kernel_ms": st["ms_scan_kernel"], "filter_score_kernel_ms": st["ms_filter_score_kernel"], "scan_tiles": st["n_scan_blocks"], "parity": chk,
                 "roofline": _config_roofline(m, qs, st, dt * 1e3, "big", 32, 2, 1_250_000, profile_key="big"),
                 "what": "ms_per_1M_queries = a RANDOM eighth of the job (what consecutive input ranges give a GPU: an eighth of every (length, signature) group); "
@@ -632,7 +663,6 @@ def extra_configs(args, paths, device, ncores):
         from oracle import twin as T
         if os.path.join(REPO, "tests") not in sys.path:
             sys.path.insert(0, os.path.join(REPO, "tests"))
-        from search_common import TwinOverOracle   # the checker of tests/test_gpu_config4.py
         eng_words = synth.load_lexicon_words(paths["eng"])
         m = A.VariantModel(paths["alphabet"], A.Weights(), device=device)
         m.read_lexicon(paths["eng"])
@@ -672,31 +702,28 @@ def extra_configs(args, paths, device, ncores):
         lm_ms, _lm_n = L_.kernel_time("k_lattice_lm")
         L_.kernel_timer(False)
         off, ma, ra = m.find_all_matches_arrays(texts, sp)
-        # parity: sampled texts through the oracle twin's segmentation / lattice / LM code, per-segment find_variants by the C oracle
-        tw = TwinOverOracle(T.read_alphabet(paths["alphabet"]))
-        tw.read_vocabulary(paths["eng"])
-        for t_, f_ in lm:
-            tw.add_lm(t_, f_)
-        tw.build()
-        om = O.OracleModel(alphabet_path=paths["alphabet"])
-        om.read_lexicon(paths["eng"])
-        om.build()
-        tw.attach(om)
-        tp = T.SearchParams(("abs", 3), ("abs", 2), 10, 0.25, 2.0, False, 0.0, max_ngram=3)
-        nchk = 16
-        for i in random.Random(5).sample(range(len(texts)), nchk):
-            exp = tw.find_all_matches(texts[i], tp)
+        # parity AND the CPU side of this configuration: sampled texts through the oracle twin's search mode (segmentation / lattice / LM of
+        # oracle/twin.py, pure Python; per-segment find_variants by the C oracle), one worker process per host core
+        from search_common import twin_matches_parallel
+        nchk = 8 * ncores
+        idx = random.Random(5).sample(range(len(texts)), nchk)
+        exp_all, twin_s = twin_matches_parallel(paths["alphabet"], paths["eng"], lm, [texts[i] for i in idx], workers=ncores)
+        for i, exp in zip(idx, exp_all):
             got = ma[off[i]:off[i + 1]]
-            if [(int(g_["begin"]), int(g_["end"])) for g_ in got] != [(e.begin, e.end) for e in exp]:
+            if [(int(g_["begin"]), int(g_["end"])) for g_ in got] != [(e[1], e[2]) for e in exp]:
                 raise RuntimeError(f"parity spot check failed: segmentation of text {i}")
             for g_, e in zip(got, exp):
-                ev = e.variants or []
+                ev = e[5]
                 rows = ra[int(g_["vb"]):int(g_["ve"])]
-                if [int(v) for v in rows["vocab_id"]] != [v.vocab_id for v in ev] or (ev and int(g_["selected"]) != e.selected) \
-                        or any(abs(float(r["dist"]) - w.dist_score) > 1e-6 for r, w in zip(rows, ev)):
-                    raise RuntimeError(f"parity spot check failed: text {i}, match {e.text!r}")
+                if [int(v) for v in rows["vocab_id"]] != [v[0] for v in ev] or (ev and int(g_["selected"]) != e[4]) \
+                        or any(abs(float(r["dist"]) - w[1]) > 1e-6 for r, w in zip(rows, ev)):
+                    raise RuntimeError(f"parity spot check failed: text {i}, match {e[0]!r}")
+        chk_bytes = sum(len(texts[i].encode("utf-8")) for i in idx)
+        cpu4 = {"value": chk_bytes / 1e6 / twin_s, "unit": "MB/s", "cores": ncores, "kind": "port",
+                "sample": f"{nchk} of the {len(texts)} texts ({chk_bytes} bytes), oracle twin's find_all_matches (oracle/twin.py: segmentation, lattice, LM in Python; "
+                          f"per-segment find_variants by the C oracle), {ncores} worker processes, slowest worker {twin_s:.1f} s (model builds not counted)"}
         return {"workload": "BASELINE.json configs[4], one GPU's share: 12.5 MB of synthetic running text (sentences of 5-25 perturbed words), max_ngram 3, bigram LM, anx_find_all_matches_batch",
-                "MB_per_s": nbytes / 1e6 / best, "seconds": best, "median_MB_per_s": nbytes / 1e6 / sorted(call_s)[len(call_s) // 2], "calls": "4 untimed + 5 timed, best / median of the timed ones",
+                "MB_per_s": nbytes / 1e6 / best, "seconds": best, "cpu_baseline": cpu4, "median_MB_per_s": nbytes / 1e6 / sorted(call_s)[len(call_s) // 2], "calls": "4 untimed + 5 timed, best / median of the timed ones",
                 "matches": int(off[-1]), "variant_rows": int(ra.shape[0]),
                 # k_lattice per call (all its launches): algorithmic bytes = the lattice input (16 B per arc: one arc per variant row, plus
                 # one out-of-vocabulary / epsilon arc per match) + the chosen symbols out (8 B per match)
@@ -826,6 +853,77 @@ def single_process(args):
     print(json.dumps(out))
 
 
+def strong_scaling_job(args):
+    """--strong (with --single-process --gpus N): BASELINE configs[3]'s job SHAPE as a strong-scaling measurement behind the C ABI -- ONE
+    process, the merged 1 M-entry lexicon replicated on N devices (anx_model_to_devices), `--strong-queries` length-bucketed queries of
+    4-32 symbols split by the length-partitioned policy, every replica's top-k records gathered into one buffer on device 0
+    (anx_batch_gather_compact: in place / hipMemcpyPeerAsync over xGMI).  The same job is first run on ONE replica: the ratio of the two
+    times is the speed-up the driver can turn into an efficiency.  Prints one JSON line."""
+    import numpy as np
+    import torch
+    import analiticcl_amd as A
+    from analiticcl_amd import synth
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    devices = [0] * n if args.replicas_on_one_gpu else list(range(n))
+    if max(devices) >= ndev:
+        raise SystemExit(f"--strong --gpus {n}: only {ndev} device(s) visible (use --replicas-on-one-gpu for a dry run)")
+    paths = synth.materialize_golden(os.path.join(tempfile.gettempdir(), f"anx_bench_data_{os.getuid()}_strong"))
+    words = list(dict.fromkeys(synth.load_lexicon_words(paths["eng"]) + synth.load_lexicon_words(paths["nld"])))
+    lex = synth.make_lexicon(words, args.strong_entries, seed=11)
+    path = os.path.join(tempfile.gettempdir(), f"anx_bench_strong_{os.getuid()}.lexicon")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lex) + "\n")
+    qs = synth.make_queries(lex, args.strong_queries, max_len=32, min_len=4, seed=6)
+    p = A.SearchParameters(max_anagram_distance=3, max_edit_distance=2, max_matches=10, score_threshold=0.25, cutoff_threshold=2.0)
+    # peer access between device 0 (the gather's destination) and every other device in use
+    peers = {f"{d}->0": bool(torch.cuda.can_device_access_peer(d, 0)) for d in sorted(set(devices)) if d != 0}
+
+    def timed(model, reps):
+        b = model.encode_batch(qs, p)
+        b.run()
+        b.run()   # (the second call's split has learned from the first one's shard times)
+        t = time.perf_counter()
+        for _ in range(reps):
+            b.run()
+        dt = (time.perf_counter() - t) / reps
+        return b, dt
+    one = A.VariantModel(paths["alphabet"], A.Weights(), device=devices[0])
+    one.read_lexicon(path)
+    one.build()
+    b1, t1 = timed(one, 3)
+    o1, v1, d1, _f1 = b1.fetch_arrays()
+    ref = (o1.copy(), v1.copy(), d1.copy())
+    st1 = b1.stats()
+    b1.free()
+    del one
+    A.set_switch("ANX_SHARD_MIN", 1024)
+    many = A.VariantModel(paths["alphabet"], A.Weights(), devices=devices)
+    many.read_lexicon(path)
+    many.build()
+    bn, tn = timed(many, 3)
+    shards = bn.shards()
+    on, vn, dn, _fn = bn.fetch_arrays()
+    same = bool(np.array_equal(on, ref[0]) and np.array_equal(vn, ref[1]) and np.array_equal(dn, ref[2]))
+    # the gather: every shard's compact records into one buffer on device 0
+    cap = int(16 * (len(qs) + 64 * n) + 16 * int(on[-1]) + 4096 * n + (1 << 20))
+    with torch.cuda.device(devices[0]):
+        buf = torch.empty(cap, dtype=torch.uint8, device=f"cuda:{devices[0]}")
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        offs, used = bn.gather_compact(devices[0], buf.data_ptr(), buf.numel())
+        gather_s = time.perf_counter() - t
+    bn.free()
+    os.unlink(path)
+    print(json.dumps({"what": "strong scaling behind the C ABI: the same job on 1 replica and on N (anx_model_to_devices + length-partitioned split + anx_batch_gather_compact)",
+                      "workload": f"merged {len(lex)}-entry synthetic lexicon, {len(qs)} queries len 4-32, k=3 d=2 n=10 (BASELINE configs[3]'s shape)",
+                      "devices": devices, "n_replicas": n, "ms_one_replica": t1 * 1e3, "ms_n_replicas": tn * 1e3, "speedup": t1 / tn,
+                      "pairs_per_s_n_replicas": st1["n_pairs"] / tn, "rows_equal_one_replica_run": same,
+                      "shards": [{"device": d_, "first_input": lo_, "inputs": c_} for d_, lo_, c_ in shards],
+                      "gather": {"bytes": int(used), "seconds": gather_s, "GB_per_s": used / 1e9 / max(gather_s, 1e-9), "section_offsets": [int(x) for x in offs]},
+                      "peer_access_to_device0": peers, "all_peers_reachable": all(peers.values()) if peers else None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -844,6 +942,10 @@ def main():
     ap.add_argument("--no-check-gather", dest="check_gather", action="store_false")
     ap.add_argument("--single-process", action="store_true", help="one process, --gpus N replicas behind the C ABI (anx_model_to_devices)")
     ap.add_argument("--replicas-on-one-gpu", action="store_true", help="with --single-process: all replicas on device 0")
+    ap.add_argument("--strong", action="store_true", help="with --single-process: the strong-scaling job (configs[3]'s shape on 1 and on N replicas + the gather) instead of the weak-scaling steps")
+    ap.add_argument("--strong-entries", type=int, default=1_000_000)
+    ap.add_argument("--strong-queries", type=int, default=4_000_000)
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the single-process strong-scaling leg rank 0 runs after the timed region")
     ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="N", help="N ranks, all on device 0 (dry run of the N-rank control flow)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the result gather")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config numbers measured after the timed region")
@@ -856,7 +958,7 @@ def main():
     if args.ranks_on_one_gpu:
         args.gpus = args.ranks_on_one_gpu
     if args.single_process:
-        return single_process(args)
+        return strong_scaling_job(args) if args.strong else single_process(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # (also --ranks-on-one-gpu N)
         # `python bench.py --gpus N` without a launcher: start the N ranks as a fresh child (nothing here has touched the
@@ -1228,6 +1330,17 @@ def main():
             "gather_error": gather_error[0], "gather_check": gather_check, "process_group": (args.backend if use_dist else None), "ranks_on_one_gpu": bool(args.ranks_on_one_gpu),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if world > 1 and not args.no_strong and not args.ranks_on_one_gpu:
+            # The other way to use the node: ONE process with N replicas behind the C ABI, the strong-scaling job of BASELINE configs[3]'s
+            # shape (the ranks idle at the barrier below meanwhile; a child process: this one has initialised the GPU).  Its JSON line goes
+            # into this line; a failure is reported, never fatal.
+            import subprocess
+            try:
+                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process", "--strong", "--gpus", str(world)],
+                                    capture_output=True, text=True, timeout=1500)
+                out["single_process_strong"] = json.loads(r_.stdout.strip().splitlines()[-1]) if r_.returncode == 0 else {"error": (r_.stderr or r_.stdout)[-600:]}
+            except Exception as e_:  # noqa: BLE001
+                out["single_process_strong"] = {"error": repr(e_)[:300]}
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
