@@ -382,15 +382,16 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   // counter word sustains only ~88 M atomics/s)
   const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * f.blk;
   if (base >= fill) return;  // block-uniform
+  const uint32_t lim = min(fill, base + f.blk);  // this block's slots: [base, lim)
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   uint32_t nselected = 0;  // wave-uniform
-  for (uint32_t r = 0; r < f.blk / 256; ++r) {
+  for (uint32_t r = 0; r < FS_BLK / 256; ++r) {
     const uint32_t idx = base + r * 256 + threadIdx.x;
-    if (base + r * 256 >= fill) break;  // block-uniform
+    if (base + r * 256 >= lim) break;  // block-uniform
     const uint32_t p = (region << f.region_shift) + idx;
-    const bool live = idx < fill;
+    const bool live = idx < lim;
     // Straight-line loads: a lane without a pair (beyond the region's fill, unused chunk tail, StopAtExactMatch drop) reads
     // slot / query / entry 0 instead of being masked off -- 98 % of the lanes have a pair, and the exec-mask bookkeeping of
     // nested branches around the loads cost more than the few wasted gathers; its verdict is masked by `selected`.
