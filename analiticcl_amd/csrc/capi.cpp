@@ -1260,11 +1260,18 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
   }
   return h;
 }
+// anx_pipeline's launching thread: its runs stay on the pipeline's own two streams (alternating per job) instead of moving to the
+// library's pair of run streams.  The pipeline then needs two normal-priority streams in all -- runs and downloads of a job on one of
+// them, the next job's on the other -- where runs on the library's streams + downloads on the pipeline's needed four: the runtime maps
+// streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a 70 MB download that shared a queue with a run
+// stream held up that run's kernels (bench.py's end-to-end section inside the full run: 272 M queries/s; the same section in a fresh
+// process, where the streams happened to land on other queues: 355 M).
+static thread_local bool t_runs_on_caller_stream = false;
 int anx_batch_run_async(const anx_model* m, anx_batch* b, void* stream) {
   if (int rc = check_batch(m, b, stream)) return rc;
   return on_shards(b, [&](size_t g, std::string& err) {
     const Shard& s = b->shards[g];
-    return anx::batch_run_async(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), m->replicas.size() == 1, err);
+    return anx::batch_run_async(m->host, m->replicas[(size_t)s.replica].dev, s.b, shard_stream(b, s, stream), m->replicas.size() == 1 && !t_runs_on_caller_stream, err);
   });
 }
 // A device-weighted run met a row the device could not weight (a string beyond the fixed working memory of conf.hip): the whole
@@ -1663,6 +1670,7 @@ struct anx_pipeline {
 };
 static void pipeline_stage(anx_pipeline* pl, int stage) {
   if (stage == 0 && pl->enc_stream) anx::encoder_stream_set_override(pl->enc_stream);
+  if (stage == 0 && pl->streams[0]) t_runs_on_caller_stream = true;  // (single-replica models: the pipeline's two streams carry the runs)
   for (;;) {
     std::shared_ptr<PipeJob> job;
     {

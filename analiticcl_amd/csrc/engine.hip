@@ -85,6 +85,8 @@ struct DevPool {
   unsigned run_counter = 0;
   std::vector<BatchShell> shells;                  // events + pinned read-back blocks of freed batches (batch_free), handed to the next batch
   std::vector<SmallCtx*> small_idle;               // contexts of the small call (small_path.hpp), checked out per call
+  std::vector<std::pair<void*, size_t>> doomed;    // blocks evicted from the cache, not yet handed to hipFree (pool_free: hipFree waits for the device)
+  size_t doomed_bytes = 0;
 };
 // bytes of freed blocks kept per device (MI355X: 288 GB HBM; a 1 M-query batch holds 3-6 GB of scratch).  ANX_POOL_CACHE_MB
 // overrides the default; anx_device_pool_trim() hands the cache back to the driver at any time.
@@ -92,7 +94,7 @@ static size_t pool_cache_limit() {
   static const size_t lim = []() {
     const char* e = getenv("ANX_POOL_CACHE_MB");
     const long long v = e ? atoll(e) : -1;
-    return v >= 0 ? (size_t)v << 20 : (size_t)32 << 30;
+    return v >= 0 ? (size_t)v << 20 : (size_t)96 << 30;   // (32 GB until round 6: six un-hinted first runs of a million queries, 7 GB each, outgrew it)
   }();
   return lim;
 }
@@ -176,6 +178,14 @@ void stream_destroy(int device, void* s) {
   (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(s));
 }
 
+// Blocks the cache let go (pool_free) wait here for a call that can afford hipFree -- it waits for the whole device, and pool_free runs
+// on the hot path: a pipeline of fresh batches whose (un-hinted, 7 GB) first runs had filled the cache freed a block per batch and stalled
+// its fetch thread behind the runs in flight: 273 instead of 355 M queries/s in bench.py's end-to-end section (round 6).
+static void pool_reap(DevPool& pl) {
+  std::vector<std::pair<void*, size_t>> drop;
+  { std::lock_guard<std::mutex> g(pl.mu); drop.swap(pl.doomed); pl.doomed_bytes = 0; }
+  for (auto& d : drop) (void)hipFree(d.first);
+}
 hipError_t pool_malloc(void** p, size_t bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -192,6 +202,7 @@ hipError_t pool_malloc(void** p, size_t bytes) {
       return hipSuccess;
     }
   }
+  pool_reap(pl);  // (a cache miss pays a hipMalloc anyway: the evicted blocks go to the driver here)
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {  // out of memory: give the cache back and retry once
     std::vector<void*> drop;
@@ -230,11 +241,13 @@ void pool_free(void* p) {
         for (auto jt = pl.free_blocks.begin(); jt != pl.free_blocks.end(); ++jt)
           if (pl.freed_at[jt->second] < pl.freed_at[old->second]) old = jt;
         pl.cached -= old->first;
-        evicted.push_back(old->second);
+        pl.doomed.emplace_back(old->second, old->first);   // freed by the next cache miss / trim (pool_reap), not here
+        pl.doomed_bytes += old->first;
         pl.freed_at.erase(old->second);
         pl.size_of.erase(old->second);
         pl.free_blocks.erase(old);
       }
+      if (pl.doomed_bytes > pool_cache_limit() / 2) { evicted.reserve(pl.doomed.size()); for (auto& d : pl.doomed) evicted.push_back(d.first); pl.doomed.clear(); pl.doomed_bytes = 0; }  // (a bound all the same)
       pl.free_blocks.emplace(it->second, p);
       pl.freed_at[p] = ++pl.clock;
       pl.cached += it->second;
@@ -249,6 +262,7 @@ void pool_free(void* p) {
 static void pool_trim(int device) {
   DevPool& pl = pool_of(device);
   small_ctxs_destroy(device);  // (first: their blocks go back to the pool that is emptied below)
+  pool_reap(pl);
   std::vector<void*> drop;
   {
     std::lock_guard<std::mutex> g(pl.mu);
@@ -273,6 +287,8 @@ struct HostCache {
   std::unordered_map<void*, uint64_t> freed_at;             // cached blocks: when they came back (the oldest leave first)
   uint64_t clock = 0;
   size_t cached = 0;
+  std::vector<void*> doomed;   // evicted pinned blocks awaiting hipHostFree (which waits for the device: done on a cache miss, not on the hot path)
+  size_t doomed_bytes = 0;
 };
 HostCache& host_cache() { static HostCache c; return c; }
 size_t host_cache_limit() {
@@ -299,6 +315,11 @@ void* host_result_alloc(size_t bytes) {
   }
   ++g_host_misses;
   g_host_miss_bytes += bytes;
+  {  // a miss pins a fresh block anyway: the evicted ones are released here
+    std::vector<void*> drop;
+    { std::lock_guard<std::mutex> g(hc.mu); drop.swap(hc.doomed); hc.doomed_bytes = 0; }
+    for (void* q : drop) (void)hipHostFree(q);
+  }
   void* p = nullptr;
   bool pinned = hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p;  // portable: the replicas of a multi-device model download into one buffer
   if (!pinned) {
@@ -338,11 +359,13 @@ void host_result_free(void* p) {
           for (auto jt = hc.free_blocks.begin(); jt != hc.free_blocks.end(); ++jt)
             if (hc.freed_at[jt->second] < hc.freed_at[old->second]) old = jt;
           hc.cached -= old->first;
-          evicted.push_back(old->second);
+          hc.doomed.push_back(old->second);
+          hc.doomed_bytes += old->first;
           hc.freed_at.erase(old->second);
           hc.live.erase(old->second);
           hc.free_blocks.erase(old);
         }
+        if (hc.doomed_bytes > host_cache_limit()) { evicted.swap(hc.doomed); hc.doomed_bytes = 0; }  // (a bound all the same)
         hc.free_blocks.emplace(bytes, p);
         hc.freed_at[p] = ++hc.clock;
         hc.cached += bytes;
@@ -364,6 +387,9 @@ static void host_cache_trim() {
   {
     std::lock_guard<std::mutex> g(hc.mu);
     for (auto& kv : hc.free_blocks) { drop.push_back(kv.second); hc.live.erase(kv.second); }
+    for (void* q : hc.doomed) drop.push_back(q);
+    hc.doomed.clear();
+    hc.doomed_bytes = 0;
     hc.free_blocks.clear();
     hc.freed_at.clear();
     hc.cached = 0;

@@ -1018,6 +1018,10 @@ def main():
                                 score_threshold=0.25, cutoff_threshold=2.0)
     if args.no_overlap:
         A.set_switch("ANX_RUN_OVERLAP", "0")
+    if os.environ.get("ANX_BENCH_E2E_FIRST"):  # diagnosis: the end-to-end section in a fresh process state
+        e_ = e2e_of(args, model, queries, params, torch.cuda.current_stream().cuda_stream, torch)
+        e_.pop("pipelined_last", None)
+        sys.stderr.write("[bench] e2e first: " + json.dumps({k: v for k, v in e_.items() if k != "what"}) + "\n")
     t_enc = time.time()
     batch = model.encode_batch(queries, params)  # encode + H2D, outside the timed region
     t_enc = time.time() - t_enc

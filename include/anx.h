@@ -316,7 +316,7 @@ int anx_batch_shard_inputs(const anx_batch *, int shard, const uint32_t **indice
 /* Waits for asynchronous exports of the batch (anx_batch_export_topk / _compact on the caller's stream), then releases it. */
 void anx_batch_free(anx_batch *);
 /* Device scratch (pair lists, survivor rows: several GB per million queries) comes from a per-device pool that keeps freed
- * blocks for the next batch (up to 32 GB, ANX_POOL_CACHE_MB overrides; the reference has no counterpart: its scratch is
+ * blocks for the next batch (up to 96 GB, ANX_POOL_CACHE_MB overrides; the reference has no counterpart: its scratch is
  * Vec storage inside find_variants, src/lib.rs:1311-1402).  This hands the cached blocks back to the driver, e.g. before
  * another library needs the memory. */
 void anx_device_pool_trim(int device);
