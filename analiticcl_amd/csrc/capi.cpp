@@ -1260,12 +1260,8 @@ anx_batch* anx_batch_encode_packed(const anx_model* m, const char* blob, size_t 
   }
   return h;
 }
-// anx_pipeline's launching thread: its runs stay on the pipeline's own two streams (alternating per job) instead of moving to the
-// library's pair of run streams.  The pipeline then needs two normal-priority streams in all -- runs and downloads of a job on one of
-// them, the next job's on the other -- where runs on the library's streams + downloads on the pipeline's needed four: the runtime maps
-// streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a 70 MB download that shared a queue with a run
-// stream held up that run's kernels (bench.py's end-to-end section inside the full run: 272 M queries/s; the same section in a fresh
-// process, where the streams happened to land on other queues: 355 M).
+// anx_pipeline's launching thread: its runs go to the pipeline's own two normal-priority streams (alternating per job), not to the
+// library's pair of run streams (anx_pipeline_new)
 static thread_local bool t_runs_on_caller_stream = false;
 int anx_batch_run_async(const anx_model* m, anx_batch* b, void* stream) {
   if (int rc = check_batch(m, b, stream)) return rc;
@@ -1665,12 +1661,13 @@ struct anx_pipeline {
   uint64_t next_seq = 0;
   void* streams[2] = {nullptr, nullptr};
   void* enc_stream = nullptr;  // the encode thread's own stream (single-replica models; highest stream priority)
+  void* fetch_stream = nullptr;  // the downloads' stream (highest stream priority as well)
   int running = 0;             // runs launched and not yet waited for (at most 2: the scan of one under the tail of the other)
   std::thread th[3];
 };
 static void pipeline_stage(anx_pipeline* pl, int stage) {
   if (stage == 0 && pl->enc_stream) anx::encoder_stream_set_override(pl->enc_stream);
-  if (stage == 0 && pl->streams[0]) t_runs_on_caller_stream = true;  // (single-replica models: the pipeline's two streams carry the runs)
+  if (stage == 0 && pl->streams[0]) t_runs_on_caller_stream = true;
   for (;;) {
     std::shared_ptr<PipeJob> job;
     {
@@ -1708,6 +1705,8 @@ static void pipeline_stage(anx_pipeline* pl, int stage) {
         if (job->rc) job->err = g_err;
         { std::lock_guard<std::mutex> lk(pl->mu); --pl->running; }
       } else {
+        if (pl->fetch_stream)  // the run has been waited for: its rows are downloaded on the pipeline's download stream
+          for (Shard& s_ : job->b->shards) anx::batch_set_last_stream(s_.b, pl->fetch_stream);
         job->rc = anx_batch_fetch_compact(job->b, &job->rows, &job->offs);
         if (job->rc) job->err = g_err;
       }
@@ -1735,10 +1734,19 @@ anx_pipeline* anx_pipeline_new(const anx_model* m, int depth) {
   if (m->replicas.size() == 1) {  // a multi-replica model runs every shard on its replica's own stream
     std::string err;
     pl->enc_stream = anx::stream_create(m->replicas[0].device, err, true);  // (nullptr: the encoder's pooled streams)
+    // Streams of a pipeline: the encoder's and the downloads' at the highest stream priority, two of normal priority that carry the
+    // runs, alternating per job (the scan of one job under the tail of the other).  The runtime maps streams onto a handful of hardware
+    // queues per priority level (GPU_MAX_HW_QUEUES, 4 by default): with the runs on the library's pair of run streams AND two normal-
+    // priority download streams, a 70 MB download could share a hardware queue with a run stream and hold up that run's kernels --
+    // depending on which streams the process had created before (bench.py's end-to-end section: 272 M queries/s inside the full
+    // run, 355 M in a fresh process).  High-priority streams never share a queue with normal ones, and a download on a stream of its
+    // own is never enqueued behind the run after next (runs AND downloads on the two run streams: 234 M in a fresh process).
+    pl->fetch_stream = anx::stream_create(m->replicas[0].device, err, true);
     for (void*& st : pl->streams)
       if (!(st = anx::stream_create(m->replicas[0].device, err))) {
         for (void* x : pl->streams) if (x) anx::stream_destroy(m->replicas[0].device, x);
         if (pl->enc_stream) anx::stream_destroy(m->replicas[0].device, pl->enc_stream);
+        if (pl->fetch_stream) anx::stream_destroy(m->replicas[0].device, pl->fetch_stream);
         delete pl;
         fail(ANX_ENODEVICE, err);
         return nullptr;
@@ -1804,6 +1812,7 @@ void anx_pipeline_free(anx_pipeline* pl) {
   pl->cv.notify_all();
   for (std::thread& t : pl->th) t.join();
   for (void* st : pl->streams) if (st) anx::stream_destroy(pl->m->replicas[0].device, st);
+  if (pl->fetch_stream) anx::stream_destroy(pl->m->replicas[0].device, pl->fetch_stream);
   if (pl->enc_stream) anx::stream_destroy(pl->m->replicas[0].device, pl->enc_stream);
   delete pl;
 }

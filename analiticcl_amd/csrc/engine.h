@@ -57,6 +57,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
 // the same in two halves: enqueue on `stream` and return / wait for it (statistics, results usable afterwards)
 int batch_run_async(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* stream, bool own_streams, std::string& err);
 int batch_wait(const HostModel& m, const DeviceLexicon* dl, Batch* b, std::string& err);
+void batch_set_last_stream(Batch* b, void* stream);  // where the fetches / exports of a FINISHED run are enqueued from now on
 int batch_fetch(const HostModel& m, const DeviceLexicon* dl, const Batch* b, anx_result** rows, size_t** offs,
                 std::string& err);
 // the same into caller-provided storage: rows[0 .. batch_n_results) and offs[0 .. batch_n_input] = base + CSR offsets

@@ -1653,6 +1653,7 @@ int batch_run(const HostModel& m, const DeviceLexicon* dl, Batch* b, void* strea
   return rc ? rc : batch_wait(m, dl, b, err);
 }
 
+void batch_set_last_stream(Batch* b, void* stream) { if (b && !b->launched) b->last_stream = stream; }
 size_t batch_n_results(const Batch* b) { return b->ran ? (size_t)b->n_results : 0; }
 size_t batch_n_input(const Batch* b) { return b->n_input; }
 

@@ -35,6 +35,7 @@ void* stream_create(int, std::string&, bool) { return malloc(1); }
 void stream_destroy(int, void* s) { free(s); }
 void* host_result_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 bool host_result_is_pinned(void*) { return false; }
+void batch_set_last_stream(Batch*, void*) {}
 void small_stats(uint64_t* out) { out[0] = out[1] = 0; }
 // the small call needs the device: the stub never takes it (the batch entry points run on the fake devices)
 int small_find(const HostModel&, const DeviceLexicon*, const char* const*, size_t, const anx_params&, anx_result**, size_t**, std::string&) { return 1; }
