@@ -359,9 +359,7 @@ struct GatherArgs {
   // exact-class lookup (StopAtExactMatch)
   const uint4* sigtab; const uint32_t* siglen_begin; const uint32_t* cls_planes; uint32_t cstride;
 };
-__global__ __launch_bounds__(256) void k_enc_gather(GatherArgs g) {
-  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= g.nq) return;
+__device__ inline void enc_gather_body(const GatherArgs& g, uint32_t s) {   // sorted position s (s < g.nq)
   const uint32_t i = g.perm[s];
   const uint32_t meta = g.meta[i], len = meta & 0xFFu;
   const unsigned long long sig = g.sig[i];
@@ -412,6 +410,10 @@ __global__ __launch_bounds__(256) void k_enc_gather(GatherArgs g) {
     }
   }
   g.qexact[s] = xc;
+}
+__global__ __launch_bounds__(256) void k_enc_gather(GatherArgs g) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s < g.nq) enc_gather_body(g, s);
 }
 
 // ---- tiles ------------------------------------------------------------------------------------------------------------
@@ -535,12 +537,13 @@ __global__ __launch_bounds__(256) void k_tile_adj_count(const Tile* tiles, uint3
 // Tile slot of (query s, part) = part * n + s: the bit-plane tiles (part 0) of consecutive queries take consecutive pair-list regions;
 // a count-vector tile that walks its window is split over up to 8 slots (as in k_tile_emit); unused slots get nq = 0 and are skipped
 // by k_scan_small.  The kernel also clears what the run accumulates into (counters, per-query sums): no memset launches.
-__global__ __launch_bounds__(256) void k_small_tiles(TileArgs t, SmallZero z, uint32_t slots, const uint32_t* __restrict__ adj_hdr) {
+__global__ __launch_bounds__(256) void k_small_tiles(GatherArgs g, TileArgs t, SmallZero z, uint32_t slots, const uint32_t* __restrict__ adj_hdr) {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256u;
 #pragma unroll
   for (int a = 0; a < 8; ++a)
     for (uint32_t i = s; i < z.n[a]; i += nthreads) z.p[a][i] = 0u;
   if (s >= t.nq) return;
+  enc_gather_body(g, s);  // the query's arrays (k_enc_gather's work, input order: g.perm is the identity) -- one launch less
   const uint32_t meta = t.q_meta[s], lq = meta & 0xFFu, k = (meta >> 8) & 0xFFu, d = (meta >> 16) & 0xFFu;
   Tile nul{};
   nul.kind = 1u;
@@ -606,13 +609,12 @@ int small_encode_launch(const HostModel& m, const DeviceLexicon* dl, const Small
   ga.q_rec = e.q_rec; ga.q_rows = e.q_rows; ga.q_bits = e.q_bits; ga.q_cv = e.q_cv; ga.q_meta = e.q_meta; ga.q_orig = e.q_orig;
   ga.qexact = e.qexact; ga.s_kind = e.s_kind; ga.s_sig = e.s_sig;
   ga.sigtab = dl->sig; ga.siglen_begin = dl->alpha.siglen_begin; ga.cls_planes = dl->cls_planes; ga.cstride = dl->cstride;
-  hipLaunchKernelGGL(k_enc_gather, gn, dim3(256), 0, st, ga);
   TileArgs ta;
   ta.tq = 1; ta.nq = n; ta.q_meta = e.q_meta; ta.s_kind = e.s_kind; ta.s_sig = e.s_sig; ta.siglen_begin = dl->alpha.siglen_begin; ta.ctr = nullptr;
   ta.ball_tab = dl->ball_tab; ta.probe = probe_enabled() ? 1 : 0;
   ta.adj_hash = dl->adj_hash; ta.adj_mask = switches().scan_adj ? dl->adj_mask : 0u;
   ta.head = nullptr; ta.tcount = nullptr; ta.tiles = e.tiles; ta.tkey = nullptr;
-  hipLaunchKernelGGL(k_small_tiles, gn, dim3(256), 0, st, ta, z, slots, dl->adj_hdr);
+  hipLaunchKernelGGL(k_small_tiles, gn, dim3(256), 0, st, ga, ta, z, slots, dl->adj_hdr);
   HIP_TRY(hipGetLastError());
   return ANX_OK;
 }

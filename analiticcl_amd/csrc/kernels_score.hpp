@@ -518,10 +518,13 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
 constexpr uint32_t LIST_P = 64;  // blocks per region of the slot-list kernels (the kernels stride by gridDim.x / SCAN_REGIONS: the small path launches fewer)
 // The 8-word band-match prefilter of the wide pairs k_filter_score<D, false> deferred (listw): survivors go to the slot
 // list of the 8-word kernel (fastD > 0 and the batch uses it) or of the general kernel.
-__global__ __launch_bounds__(256) void k_filter_wide(SlotList in, FilterArgs f, PairArgs A, ScoreArgs a, int fastD, SlotList list8, SlotList listg) {
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = min(in.ctr[region * RC_STRIDE], in.region_cap), lane = threadIdx.x & 63;  // (a list filled beyond its capacity makes the host repeat the run)
+// (body + launch wrapper: the small call runs the three slot-list kernels as ONE launch, k_small_lists; region = the list's region, the
+// block takes rounds blk0, blk0 + blkstep, ... of 256 entries)
+__device__ inline void filter_wide_body(const SlotList& in, const FilterArgs& f, const PairArgs& A, const ScoreArgs& a, int fastD, const SlotList& list8, const SlotList& listg,
+                                        uint32_t region, uint32_t blk0, uint32_t blkstep) {
+  const uint32_t n = min(in.ctr[region * RC_STRIDE], in.region_cap), lane = threadIdx.x & 63;  // (a list filled beyond its capacity makes the host repeat the run)
   uint32_t nselected = 0;  // wave-uniform
-  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += gridDim.x / SCAN_REGIONS) {  // block-uniform
+  for (uint32_t blk = blk0; blk * 256 < n; blk += blkstep) {  // block-uniform
     const uint32_t i = blk * 256 + threadIdx.x;
     const bool active = i < n;
     const uint32_t p = active ? in.list[(size_t)region * in.region_cap + i] : 0u;
@@ -547,23 +550,29 @@ __global__ __launch_bounds__(256) void k_filter_wide(SlotList in, FilterArgs f, 
   }
   if (lane == 0 && nselected) atomicAdd(&f.stat_ctr[region * RC_STRIDE + 1], nselected);
 }
+__global__ __launch_bounds__(256) void k_filter_wide(SlotList in, FilterArgs f, PairArgs A, ScoreArgs a, int fastD, SlotList list8, SlotList listg) {
+  filter_wide_body(in, f, A, a, fastD, list8, listg, blockIdx.x % SCAN_REGIONS, blockIdx.x / SCAN_REGIONS, gridDim.x / SCAN_REGIONS);
+}
 // the selected pairs with a string of 17..32 symbols (list8 of k_filter_score)
 template <int D>
-__global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
-  __shared__ uint32_t s_str[256 * 17];
+__device__ inline void score_fast8_body(const SlotList& in, const PairArgs& A, const ScoreArgs& a, const SurvOut& so, uint32_t* __restrict__ s_str, uint32_t region, uint32_t blk0, uint32_t blkstep) {
   // LIST_P blocks per region walk the region's slot list in strides: the list fills are only known on the device, and a
   // grid sized for the fullest possible list would consist of ~400 k empty blocks (0.08 ms of dispatch on config 2)
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, n = min(in.ctr[region * RC_STRIDE], in.region_cap);
-  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * 256 < n; blk += gridDim.x / SCAN_REGIONS) {  // block-uniform
+  const uint32_t n = min(in.ctr[region * RC_STRIDE], in.region_cap);
+  for (uint32_t blk = blk0; blk * 256 < n; blk += blkstep) {  // block-uniform
     const uint32_t i = blk * 256 + threadIdx.x;
     const bool active = i < n;
     score_fast_pair<D, 8>(active ? in.list[(size_t)region * in.region_cap + i] : 0u, active, A, a, so, region, s_str);
     __syncthreads();  // s_str is reused by the next round
   }
 }
+template <int D>
+__global__ __launch_bounds__(256) void k_score_fast8(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
+  __shared__ uint32_t s_str[256 * 17];
+  score_fast8_body<D>(in, A, a, so, s_str, blockIdx.x % SCAN_REGIONS, blockIdx.x / SCAN_REGIONS, gridDim.x / SCAN_REGIONS);
+}
 
-__global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
-  extern __shared__ uint32_t lds32[];
+__device__ inline void score_pairs_body(const SlotList& in, const PairArgs& A, const ScoreArgs& a, const SurvOut& so, uint32_t* __restrict__ lds32, uint32_t region, uint32_t blk0, uint32_t blkstep) {
   const uint2* __restrict__ raw = A.raw;
   const uint32_t* __restrict__ q_meta = A.q_meta;
   const uint4* __restrict__ q_rows = A.q_rows;
@@ -575,8 +584,8 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
   uint32_t* __restrict__ qmaxfreq = A.qmaxfreq;
   uint32_t* __restrict__ qsurv = A.qsurv;
   uint32_t* __restrict__ qexpand = A.qexpand;
-  const uint32_t region = blockIdx.x % SCAN_REGIONS, nsel = min(in.ctr[region * RC_STRIDE], in.region_cap);
-  for (uint32_t blk = blockIdx.x / SCAN_REGIONS; blk * blockDim.x < nsel; blk += gridDim.x / SCAN_REGIONS) {  // block-uniform; see k_score_fast8
+  const uint32_t nsel = min(in.ctr[region * RC_STRIDE], in.region_cap);
+  for (uint32_t blk = blk0; blk * blockDim.x < nsel; blk += blkstep) {  // block-uniform; see k_score_fast8
   const uint32_t i_sel = blk * blockDim.x + threadIdx.x;
   bool keep = false;
   uint32_t kq = 0, ke = 0;
@@ -671,4 +680,28 @@ __global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) 
   surv_append(so, region, keep, kq, ke, kscore);
   }
 }
+__global__ void k_score_pairs(SlotList in, PairArgs A, ScoreArgs a, SurvOut so) {
+  extern __shared__ uint32_t lds32[];
+  score_pairs_body(in, A, a, so, lds32, blockIdx.x % SCAN_REGIONS, blockIdx.x / SCAN_REGIONS, gridDim.x / SCAN_REGIONS);
+}
 
+// The small call (small_path.hpp): the three slot-list kernels as ONE launch, one block of 256 threads per pair-list region.  The lists of
+// a region are appended to by that region's blocks only, and k_filter_wide's output (list8 / listg entries of the block's own region) is
+// consumed by the same block after a barrier -- so no second launch is needed between them (a small call is launch-bound).
+struct SmallListArgs {
+  SlotList lw, l8, lg;
+  int do_wide, do_fast8, fastD;
+};
+template <int D>
+__global__ __launch_bounds__(256) void k_small_lists(SmallListArgs L, FilterArgs f, PairArgs A, ScoreArgs a, SurvOut so) {
+  extern __shared__ uint32_t lds32[];
+  __shared__ uint32_t s_str[D > 0 ? 256 * 17 : 1];
+  const uint32_t region = blockIdx.x;
+  if (L.do_wide) {
+    filter_wide_body(L.lw, f, A, a, L.fastD, L.l8, L.lg, region, 0u, 1u);
+    __threadfence();     // (the entries this block appended to list8 / listg, and their counters, before anybody of the block reads them)
+    __syncthreads();
+  }
+  if (D > 0 && L.do_fast8) score_fast8_body<(D > 0 ? D : 1)>(L.l8, A, a, so, s_str, region, 0u, 1u);
+  score_pairs_body(L.lg, A, a, so, lds32, region, 0u, 1u);
+}

@@ -10,9 +10,10 @@
 //     no event, no memset command per call;
 //   * the inputs are packed into pinned memory the encoder kernels read over PCIe; queries stay in INPUT order (no sort, no
 //     permutation), one scan tile per query (k_small_tiles), capacities are fixed and every append is bounds-checked as always;
-//   * eleven launches -- k_enc_strings, k_enc_gather, k_small_tiles | k_scan_small (all three scan bodies in one launch) |
-//     k_filter_score, k_filter_wide, k_score_pairs (k_score_fast8) | k_small_offsets, k_compact_grouped, k_rank | k_small_fetch (rows
-//     and offsets straight into pinned host memory, with the run's fills) -- and ONE host wait;
+//   * nine launches -- k_enc_strings, k_small_tiles (with k_enc_gather's work) | k_scan_small (all three scan bodies in one launch) |
+//     k_filter_score, k_small_lists (k_filter_wide + k_score_fast8 + k_score_pairs, a block per region) | k_small_offsets,
+//     k_compact_grouped, k_rank | k_small_fetch (rows and offsets straight into pinned host memory, with the run's fills) -- and ONE host wait
+//     (eleven in the first version: 66 us for one input);
 //   * a run whose fills exceeded a fixed capacity (a handful of very short queries can) is discarded and the call takes the batch path.
 // Same kernels, same arithmetic as the batch path: the results are identical (tests/test_gpu_small.py: against the batch path and the oracle).
 #pragma once
@@ -225,9 +226,13 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
   const SlotList l8{c->list8, c->lctr, SMALL_SURV_CAP}, lg{c->listg, c->lctr + SCAN_REGIONS * RC_STRIDE, SMALL_SURV_CAP}, lw{c->listw, c->lctr + 2 * SCAN_REGIONS * RC_STRIDE, SMALL_SURV_CAP};
   const PairArgs pa{c->raw, c->enc.q_meta, c->enc.q_rows, c->enc.q_rec, dl->e_rec, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, dl->ent_var_off,
                     nullptr, nullptr, c->qmaxfreq, c->qsurv, c->qexpand};
+  // slots per region the scoring grid covers: the whole region from a few hundred inputs on, less for the smallest calls (a region filled
+  // beyond it hands the call to the batch path, like every other capacity)
+  uint32_t fs_cap = 2048;
+  while (fs_cap < region_cap && fs_cap < n32 * 32u + 1024u) fs_cap *= 2u;
   FilterArgs fa;
   fa.region_shift = SMALL_SHIFT; fa.rctr = c->rctr; fa.qexact = c->enc.qexact; fa.stop = 0; fa.enable = enable_filter;
-  fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = c->counters; fa.stat_ctr = c->sctr; fa.fill_cap = region_cap; fa.blk = SMALL_FS_BLK;
+  fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = c->counters; fa.stat_ctr = c->sctr; fa.fill_cap = fs_cap; fa.blk = SMALL_FS_BLK;
   {
     // k_filter_score's rarely used arguments live in device memory (FsCold): uploaded again only when they change (another model,
     // other weights / thresholds / row width) -- compared field by field (struct padding is not)
@@ -244,7 +249,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
       c->cold_valid = true;
     }
   }
-  const dim3 fgrid(((region_cap + SMALL_FS_BLK - 1) / SMALL_FS_BLK) * SCAN_REGIONS);
+  const dim3 fgrid(((fs_cap + SMALL_FS_BLK - 1) / SMALL_FS_BLK) * SCAN_REGIONS);
   const bool split_wide = !have_long_q && switches().fs_split;
   const bool b7 = switches().fs_b7 && m.alphabet.size() + 1 < 0x7E;
 #define ANX_FS_LAUNCH(DD, WW, BB) hipLaunchKernelGGL((k_filter_score<DD, WW, BB>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(c->d_cold))
@@ -259,7 +264,15 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
   else { if (b7) ANX_FS_PICK(true, true); else ANX_FS_PICK(true, false); }
 #undef ANX_FS_PICK
 #undef ANX_FS_LAUNCH
-  {
+  if (threads == 256) {  // the slot-list kernels as one launch, a block per region (k_small_lists)
+    SmallListArgs L{lw, l8, lg, (split_wide && enable_filter) ? 1 : 0, (fastD && have_long_q) ? 1 : 0, fastD};
+    const dim3 lgrid(SCAN_REGIONS);
+    const size_t dyn = (size_t)threads * sa.stride;
+    if (fastD == 1) hipLaunchKernelGGL(k_small_lists<1>, lgrid, dim3(256), dyn, st, L, fa, pa, sa, so);
+    else if (fastD == 2) hipLaunchKernelGGL(k_small_lists<2>, lgrid, dim3(256), dyn, st, L, fa, pa, sa, so);
+    else if (fastD == 3) hipLaunchKernelGGL(k_small_lists<3>, lgrid, dim3(256), dyn, st, L, fa, pa, sa, so);
+    else hipLaunchKernelGGL(k_small_lists<0>, lgrid, dim3(256), dyn, st, L, fa, pa, sa, so);
+  } else {
     const dim3 lgrid(SMALL_LIST_BLOCKS * SCAN_REGIONS);
     if (split_wide && enable_filter) hipLaunchKernelGGL(k_filter_wide, lgrid, dim3(256), 0, st, lw, fa, pa, sa, fastD, l8, lg);
     if (fastD && have_long_q) {
@@ -290,7 +303,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
   }
   // ---- did the run fit the fixed capacities? -----------------------------------------------------------------------------------------------
   const SmallCtl ctl = *h_ctl;
-  if (ctl.rows > row_cap || ctl.maxfill > region_cap || ctl.surv_fill > SMALL_SURV_CAP || ctl.list_fill > SMALL_SURV_CAP || ctl.total_surv > crow_cap || ctl.overflow) {
+  if (ctl.rows > row_cap || ctl.maxfill > fs_cap || ctl.surv_fill > SMALL_SURV_CAP || ctl.list_fill > SMALL_SURV_CAP || ctl.total_surv > crow_cap || ctl.overflow) {
     host_result_free(rows);
     g_small_overflow.fetch_add(1, std::memory_order_relaxed);
     return 1;  // the batch path sizes its buffers from what it measures
