@@ -279,7 +279,15 @@ typedef struct {
   uint32_t ninst, capinst;
 } klass;
 
+/* the language model of search mode (anx_oracle_search.inc): LM vocabulary ids and the n-gram counts built from them */
+typedef struct { uint32_t a, b; uint64_t count; uint8_t used; } ngslot;
+typedef struct {
+  uint64_t *lm_ids; size_t nlm, caplm;
+  ngslot *tab; size_t cap, n;
+  int have_lm;
+} orc_lm;
 struct orc_model {
+  orc_lm lm;
   aclass *alpha;
   int nalpha;
   double w_ld, w_lcs, w_prefix, w_suffix, w_case;
@@ -425,6 +433,8 @@ void orc_model_free(orc_model *m) {
   free(m->cls);
   free(m->ctab);
   for (int i = 0; i < 256; i++) { free(m->bucket[i]); free(m->bflat[i]); free(m->bflat_n[i]); }
+  free(m->lm.lm_ids);
+  free(m->lm.tab);
   free(m);
 }
 void orc_set_weights(orc_model *m, double ld, double lcs, double prefix, double suffix, double casew) {
@@ -669,6 +679,7 @@ static int cmp_cls(const void *a, const void *b) {
   const klass *x = &g_sort_model->cls[*(const uint32_t *)a], *y = &g_sort_model->cls[*(const uint32_t *)b];
   return big_cmp(x->w, x->n, y->w, y->n);
 }
+static void lm_build(orc_model *m);
 void orc_build(orc_model *m) {
   for (uint64_t i = 0; i < m->ncls; i++) { free(m->cls[i].w); free(m->cls[i].inst); }
   m->ncls = 0;
@@ -732,6 +743,7 @@ void orc_build(orc_model *m) {
       m->bflat_n[c][i] = (uint8_t)k->n;
     }
   }
+  lm_build(m);  /* the n-gram counts of the LM vocabulary (src/lib.rs:252-277) */
 }
 uint64_t orc_n_classes(const orc_model *m) { return m->ncls; }
 uint64_t orc_n_instances(const orc_model *m) { return m->ninstances; }
@@ -1382,3 +1394,5 @@ int orc_find_variants_batch(const orc_model *m, const char *const *texts, size_t
   if (total_classes) *total_classes = tc;
   return err ? -1 : 0;
 }
+
+#include "anx_oracle_search.inc"

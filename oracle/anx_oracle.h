@@ -100,6 +100,28 @@ int orc_find_nearest(const orc_model *, const char *text, int max_distance, int 
 int orc_find_variants_batch(const orc_model *, const char *const *texts, size_t n, const orc_params *,
                             int nthreads, orc_result *out, int stride, int32_t *counts,
                             uint64_t *total_pairs, uint64_t *total_classes);
+/* ---- search mode (anx_oracle_search.inc): find_all_matches, src/lib.rs:1790-1957 (no context rules) -------------------------------- */
+typedef struct {
+  orc_params base;
+  uint8_t max_ngram;
+  uint32_t max_seq;
+  float lm_weight, variantmodel_weight, contextrules_weight;
+} orc_search_params;
+typedef struct {
+  uint64_t begin, end;          /* byte offsets of the matched text */
+  uint32_t n;                   /* tokens spanned */
+  int32_t selected;             /* index of the chosen variant, -1 = none */
+  uint64_t var_begin, var_end;  /* its variants: rows [var_begin, var_end) */
+  int32_t has_variants;         /* 0: variants == None */
+} orc_match;
+/* add_to_vocabulary(text, freq, VocabParams{vocab_type: LM}), src/lib.rs:900-967 */
+uint64_t orc_add_lm(orc_model *, const char *text, int has_freq, uint32_t freq);
+/* returns the number of matches (-1: a capacity did not hold); *n_pairs (optional): scored pairs of all find_variants calls made */
+int orc_find_all_matches(const orc_model *, const char *text, const orc_search_params *, orc_match *out, int cap, orc_result *rows, int rows_cap, int *n_rows,
+                         uint64_t *n_pairs);
+/* one OpenMP task per text (the reference's rayon fan-out, src/bin/analiticcl.rs:445-448): the CPU baseline of search mode */
+int orc_find_all_matches_batch(const orc_model *, const char *const *texts, size_t n, const orc_search_params *, int nthreads, int32_t *counts, uint64_t *total_matches,
+                               uint64_t *total_rows, uint64_t *total_pairs);
 const char *orc_last_error(void);
 
 #ifdef __cplusplus

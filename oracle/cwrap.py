@@ -28,14 +28,24 @@ class Result(C.Structure):
     _fields_ = [("vocab_id", C.c_uint64), ("dist_score", C.c_double), ("freq_score", C.c_double), ("via", C.c_uint64)]
 
 
+class SearchParams(C.Structure):   # orc_search_params (anx_oracle.h): search mode of the C oracle (anx_oracle_search.inc)
+    _fields_ = [("base", Params), ("max_ngram", C.c_uint8), ("max_seq", C.c_uint32), ("lm_weight", C.c_float),
+                ("variantmodel_weight", C.c_float), ("contextrules_weight", C.c_float)]
+
+
+class Match(C.Structure):          # orc_match
+    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("n", C.c_uint32), ("selected", C.c_int32),
+                ("var_begin", C.c_uint64), ("var_end", C.c_uint64), ("has_variants", C.c_int32)]
+
+
 class Pair(C.Structure):
     _fields_ = [("vocab_id", C.c_uint64), ("ld", C.c_int16), ("lcs", C.c_uint16),
                 ("prefixlen", C.c_uint16), ("suffixlen", C.c_uint16), ("samecase", C.c_uint8)]
 
 
 def build_lib(force: bool = False) -> str:
-    src = os.path.join(HERE, "anx_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("anx_oracle.c", "anx_oracle_search.inc", "anx_oracle.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "-s"])
     return LIB_PATH
 
@@ -91,6 +101,12 @@ def lib():
         L.orc_find_variants_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(Params), C.c_int,
                                               C.POINTER(Result), C.c_int, C.POINTER(C.c_int32),
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_add_lm.restype = C.c_uint64
+        L.orc_add_lm.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint32]
+        L.orc_find_all_matches.argtypes = [vp, C.c_char_p, C.POINTER(SearchParams), C.POINTER(Match), C.c_int, C.POINTER(Result), C.c_int,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+        L.orc_find_all_matches_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(SearchParams), C.c_int, C.POINTER(C.c_int32),
+                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -110,6 +126,11 @@ def make_params(max_anagram_distance=("abs", 3), max_edit_distance=("abs", 3), m
                 freq_weight=0.0) -> Params:
     return Params(threshold(max_anagram_distance), threshold(max_edit_distance), max_matches,
                   score_threshold, cutoff_threshold, 1 if stop_at_exact_match else 0, freq_weight)
+
+
+def make_search_params(base: Params, max_ngram=3, max_seq=250, lm_weight=1.0, variantmodel_weight=3.0, contextrules_weight=1.0) -> SearchParams:
+    """SearchParameters' search-mode fields (src/types.rs:132-168; defaults as the reference's)"""
+    return SearchParams(base, max_ngram, max_seq, lm_weight, variantmodel_weight, contextrules_weight)
 
 
 def _b(s) -> bytes:
@@ -241,6 +262,35 @@ class OracleModel:
                    pairs[i].samecase) for i in range(min(npairs.value, pair_cap))]
             return results, pl, npairs.value, ncls.value
         return results
+
+    def add_lm(self, text: str, freq: Optional[int] = None) -> int:
+        """add_to_vocabulary(text, freq, VocabParams{vocab_type: LM})"""
+        return lib().orc_add_lm(self.h, _b(text), 0 if freq is None else 1, 0 if freq is None else int(freq))
+
+    def find_all_matches(self, text: str, sp: SearchParams):
+        """-> [(matched text, begin, end, n, selected | None, variants [(vocab_id, dist, freq)] | None)] (byte offsets), scored pairs"""
+        raw = _b(text)
+        cap, rcap = len(raw) + 16, 32 * (len(raw) + 16)
+        ms, rs = (Match * cap)(), (Result * rcap)()
+        nr, npairs = C.c_int(0), C.c_uint64(0)
+        n = lib().orc_find_all_matches(self.h, raw, C.byref(sp), ms, cap, rs, rcap, C.byref(nr), C.byref(npairs))
+        if n < 0:
+            raise RuntimeError("orc_find_all_matches: capacity")
+        out = []
+        for i in range(n):
+            m = ms[i]
+            var = [(rs[j].vocab_id, rs[j].dist_score, rs[j].freq_score) for j in range(m.var_begin, m.var_end)] if m.has_variants else None
+            out.append((raw[m.begin:m.end].decode("utf-8"), m.begin, m.end, m.n, None if m.selected < 0 else m.selected, var))
+        return out, npairs.value
+
+    def find_all_matches_batch(self, texts: Sequence[str], sp: SearchParams, nthreads: int = 0):
+        """the timed form (one OpenMP task per text) -> (rc, matches per text, total matches, total variant rows, scored pairs)"""
+        n = len(texts)
+        arr = (C.c_char_p * n)(*[_b(t) for t in texts])
+        counts = (C.c_int32 * n)()
+        tm, tr, tp = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = lib().orc_find_all_matches_batch(self.h, arr, n, C.byref(sp), nthreads, counts, C.byref(tm), C.byref(tr), C.byref(tp))
+        return rc, list(counts), tm.value, tr.value, tp.value
 
     def find_variants_batch(self, texts: Sequence[str], params: Params, nthreads: int = 0, stride: int = 64):
         n = len(texts)
