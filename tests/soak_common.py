@@ -91,7 +91,34 @@ def parity_round(seed, max_words=30000):
         assert int(counts[i]) == npairs, (seed, text, int(counts[i]), npairs)
         assert [(v, ds, fs) for v, ds, fs in res[i]] == [tuple(x) for x in ores], (seed, text, res[i][:4], ores[:4])
     assert st["n_pairs"] == total, (seed, st["n_pairs"], total)
+    # the same configuration through the call at the reference's granularity (anx_find_variants_batch, char**): a random handful of
+    # the queries -- the small path (small_path.hpp) answers when the model has no variant lists and the round no StopAtExactMatch, the
+    # batch pipeline otherwise (and for the subset that keeps an input beyond 64 bytes): the rows must be the batch's either way
+    sub = rng.sample(range(len(qs)), min(len(qs), rng.choice((1, 3, 40, 700))))
+    if rng.random() < 0.7:
+        sub = [i for i in sub if len(qs[i].encode("utf-8")) <= 64] or [1]
+    got = small_call(g, [qs[i] for i in sub], gp)
+    for i, r in zip(sub, got):
+        exp = [] if (qs[i] == "" or len(qs[i]) > 255) else [(v, ds, fs) for v, ds, fs in res[i]]
+        assert r == exp, (seed, "small call", qs[i], r[:3], exp[:3])
     return nwords, with_freq, nvar, len(qs), total, (k, dd, n, thr, cutoff, stop, fw)
+
+
+def small_call(model, qs, params):
+    """anx_find_variants_batch(char**) -> [[(vocab_id, dist, freq)]]"""
+    import ctypes as C
+    from analiticcl_amd import _lib as L
+    lib = L.lib()
+    arr = (C.c_char_p * len(qs))(*[q.encode("utf-8") for q in qs])
+    rows = C.POINTER(L.Result)()
+    offs = C.POINTER(C.c_size_t)()
+    cp = params._c()
+    L.check(lib.anx_find_variants_batch(model.h, arr, len(qs), C.byref(cp), C.byref(rows), C.byref(offs)))
+    try:
+        off = [offs[i] for i in range(len(qs) + 1)]
+        return [[(rows[j].vocab_id, rows[j].dist_score, rows[j].freq_score) for j in range(off[i], off[i + 1])] for i in range(len(qs))]
+    finally:
+        lib.anx_results_free(rows, offs)
 
 
 
