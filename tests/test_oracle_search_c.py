@@ -64,32 +64,40 @@ def test0707_byte_offsets():  # :1454-1481
     assert (res[1][1], res[1][2]) == (2, 8) and _sel(m, res)[4] == ("rihgt", "right")
 
 
-@pytest.mark.parametrize("max_ngram,with_lm", [(1, False), (2, True), (3, True), (3, False)])
-def test_equals_the_twin_on_running_text(data_dir, max_ngram, with_lm):
-    """eng.aspell, sentences of perturbed words (the generator of BASELINE configs[4]'s workload), a bigram LM: segmentation, variants, the
-    chosen sequence -- everything the twin returns -- equal, text by text."""
-    lex = os.path.join(data_dir, "eng.aspell.lexicon")
-    words = synth.load_lexicon_words(lex)
-    common = [w for w in words if w.isalpha()][::23][:5000]
-    rng = random.Random(7)
-    lm = [(f"{rng.choice(common)} {rng.choice(common)}", rng.randrange(1, 20)) for _ in range(20000)] + [(f"<bos> {w}", 5) for w in common[:500]] if with_lm else []
-    texts = synth.make_running_text(common, 0.03, seed=11 + max_ngram)[:14] + ["", "one", "the cat and the dgo", "a-b c_d e'f", "x\n\ny  z.", "Ünïcödé wörds hëre"]
-    tw = T.SearchModel(T.read_alphabet(os.path.join(data_dir, "simple.alphabet.tsv")))
-    tw.read_vocabulary(lex)
-    for t, f in lm:
-        tw.add_lm(t, f)
-    tw.build()
-    om = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
-    om.read_lexicon(lex)
-    for t, f in lm:
-        om.add_lm(t, f)
-    om.build()
-    # the twin's own find_variants takes seconds per query on a 119 k-entry lexicon: answered by the C oracle (same results: tests/test_oracle_c.py)
+@pytest.fixture(scope="module")
+def worlds(data_dir):
+    """twin + C oracle over eng.aspell, once without and once with a bigram LM (the twin's vocabulary build takes ~20 s each)"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from search_common import TwinOverOracle
-    tw.__class__ = TwinOverOracle
-    tw.attach(om)
+    lex = os.path.join(data_dir, "eng.aspell.lexicon")
+    words = synth.load_lexicon_words(lex)
+    common = [w for w in words if w.isalpha()][::23][:5000]
+    out = {}
+    for with_lm in (False, True):
+        rng = random.Random(7)
+        lm = [(f"{rng.choice(common)} {rng.choice(common)}", rng.randrange(1, 20)) for _ in range(20000)] + [(f"<bos> {w}", 5) for w in common[:500]] if with_lm else []
+        tw = TwinOverOracle(T.read_alphabet(os.path.join(data_dir, "simple.alphabet.tsv")))
+        tw.read_vocabulary(lex)
+        for t, f in lm:
+            tw.add_lm(t, f)
+        tw.build()
+        om = O.OracleModel(alphabet_path=os.path.join(data_dir, "simple.alphabet.tsv"))
+        om.read_lexicon(lex)
+        for t, f in lm:
+            om.add_lm(t, f)
+        om.build()
+        tw.attach(om)   # the twin's own find_variants takes seconds per query on a 119 k-entry lexicon: answered by the C oracle (same results: tests/test_oracle_c.py)
+        out[with_lm] = (tw, om, common)
+    return out
+
+
+@pytest.mark.parametrize("max_ngram,with_lm", [(1, False), (2, True), (3, True), (3, False)])
+def test_equals_the_twin_on_running_text(worlds, max_ngram, with_lm):
+    """eng.aspell, sentences of perturbed words (the generator of BASELINE configs[4]'s workload), a bigram LM: segmentation, variants, the
+    chosen sequence -- everything the twin returns -- equal, text by text."""
+    tw, om, common = worlds[with_lm]
+    texts = synth.make_running_text(common, 0.03, seed=11 + max_ngram)[:7] + ["", "one", "the cat and the dgo", "a-b c_d e'f", "x\n\ny  z.", "Ünïcödé wörds hëre"]
     tp = T.SearchParams(("abs", 3), ("abs", 2), 10, 0.25, 2.0, False, 0.0, max_ngram=max_ngram)
     sp = O.make_search_params(O.make_params(("abs", 3), ("abs", 2), 10, 0.25, 2.0), max_ngram=max_ngram)
     nsel = 0
@@ -102,6 +110,6 @@ def test_equals_the_twin_on_running_text(data_dir, max_ngram, with_lm):
             assert g[5] == ev, (text, e.text)
             assert g[4] == e.selected, (text, e.text, g[4], e.selected)
             nsel += e.selected is not None
-    assert nsel > 50
+    assert nsel > 25
     rc, counts, tm, _tr, _tp = om.find_all_matches_batch(texts, sp, nthreads=4)
-    assert rc == 0 and tm == sum(counts) > 100
+    assert rc == 0 and tm == sum(counts) > 50
