@@ -61,6 +61,7 @@ struct EncArgs {
   uint32_t* blk;            // [blocks][3] per block: max len, max d, encodable inputs (k_enc_totals -> ctr[0..2])
   int dbg;                  // ANX_ENC_DBG (debug builds, timing only, results WRONG): 1 no count-vector writes, 2 no code stores, 4 no walk, 8 no record stores
   int zero_cv;              // !bits_ok: every lane clears its own count-vector row first (the small path: no memset launch before the kernel)
+  uint32_t stage_off[17];   // k_enc_strings<true> (<= 4096 strings): off[256 b] for every block b and off[n]: the block's byte range without a read of the (host) offsets
 };
 
 // Where the codes of string i start: the bytes of string i and its separator are >= symbols + 1, and rounding every start up to a
@@ -119,15 +120,16 @@ __global__ __launch_bounds__(256) void k_enc_strings(EncArgs a) {
   uint32_t len = 0, d = 0, ok = 0;
   __shared__ uint4 s_stage[STAGE ? (256 * (ENC_STAGE_BYTES + 1) + 48) / 16 : 1];
   uint32_t stage0 = 0;
+  // (STAGE: the lane's own offsets are requested first, so that they travel over PCIe together with the block's bytes, not after them)
+  const uint32_t off_i = i < a.n ? a.off[i] : 0u, off_i1 = i < a.n ? a.off[i + 1] : 1u;
   if (STAGE) {
-    const uint32_t first = blockIdx.x * 256u, last = min(a.n, first + 256u);
-    const uint32_t b0 = a.off[first] & ~15u, b1 = a.off[last] + 16u;   // (the window of the last string may read 16 bytes past it)
+    const uint32_t b0 = a.stage_off[blockIdx.x] & ~15u, b1 = a.stage_off[blockIdx.x + 1u] + 16u;   // (the window of the last string may read 16 bytes past it)
     for (uint32_t x = threadIdx.x; x < (b1 - b0 + 15u) / 16u; x += 256u) s_stage[x] = reinterpret_cast<const uint4*>(a.blob + b0)[x];
     stage0 = b0;
     __syncthreads();
   }
   if (i < a.n) {
-    const uint32_t begin = a.off[i], end = a.off[i + 1] - 1u;
+    const uint32_t begin = off_i, end = off_i1 - 1u;
     const uint8_t* __restrict__ s = STAGE ? reinterpret_cast<const uint8_t*>(s_stage) - stage0 : a.blob;
     uint32_t n = 0, skip = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, over = 0;
     unsigned long long sig = 0;
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256) void k_small_tiles(GatherArgs g, TileArgs t, S
 }
 
 int small_encode_launch(const HostModel& m, const DeviceLexicon* dl, const SmallEnc& e, const uint8_t* blob, const uint32_t* off, uint32_t n, uint32_t qw,
-                        const anx_params& p, const SmallZero& z, uint32_t slots, bool stage_lds, hipStream_t st, std::string& err) {
+                        const anx_params& p, const SmallZero& z, uint32_t slots, bool stage_lds, const uint32_t* host_off, hipStream_t st, std::string& err) {
   const int NP = dl->nplanes;
   EncArgs ea;
   ea.blob = blob; ea.off = off; ea.n = n; ea.al = dl->alpha; ea.A = m.alphabet.size(); ea.NP = NP;
@@ -600,8 +602,9 @@ int small_encode_launch(const HostModel& m, const DeviceLexicon* dl, const Small
   ea.codes = e.codes; ea.meta = e.meta; ea.bits = e.bits; ea.sig = e.sig; ea.kind = e.kind; ea.cv = e.cv; ea.key = e.key; ea.blk = e.blk;
   ea.dbg = 0;
   ea.zero_cv = 1;
+  for (uint32_t bk = 0; bk <= 16u; ++bk) ea.stage_off[bk] = host_off ? host_off[std::min<uint32_t>(bk * 256u, n)] : 0u;
   const dim3 gn((n + 255) / 256);
-  if (stage_lds) hipLaunchKernelGGL(k_enc_strings<true>, gn, dim3(256), 0, st, ea);
+  if (stage_lds && host_off && n <= 4096u) hipLaunchKernelGGL(k_enc_strings<true>, gn, dim3(256), 0, st, ea);
   else hipLaunchKernelGGL(k_enc_strings<false>, gn, dim3(256), 0, st, ea);
   GatherArgs ga;
   ga.nq = n; ga.qw = qw; ga.NP = NP; ga.want_exact = 0;

@@ -57,7 +57,7 @@ struct SmallZero { uint32_t* p[8]; uint32_t n[8]; };  // arrays k_small_tiles cl
 // k_enc_strings -> k_enc_gather (identity order) -> k_small_tiles on `st`: no allocation, no host wait.  blob / off may be pinned host
 // memory (read over PCIe; stage_lds: every block of k_enc_strings first copies its strings into LDS, inputs of <= 64 bytes).  qw: 16-byte words per query row (from the host's bound of the longest input)
 int small_encode_launch(const HostModel& m, const DeviceLexicon* dl, const SmallEnc& e, const uint8_t* blob, const uint32_t* off, uint32_t n, uint32_t qw,
-                        const anx_params& p, const SmallZero& z, uint32_t slots, bool stage_lds, hipStream_t st, std::string& err);  // slots: tile slots per query (>= 8)
+                        const anx_params& p, const SmallZero& z, uint32_t slots, bool stage_lds, const uint32_t* host_off, hipStream_t st, std::string& err);  // host_off: the offsets as the HOST reads them (stage_lds: the blocks' byte ranges go into the kernel arguments)  // slots: tile slots per query (>= 8)
 int small_iota(uint32_t* perm, uint32_t n, hipStream_t st);
 
 }  // namespace anx

@@ -175,7 +175,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
   // tile slots per query: 8 at 4096 inputs, up to 32 for the smallest calls (the rows of a query's adjacency list are shared out over them)
   uint32_t slots = 8;
   while (slots < 32u && 2u * slots * n32 <= 8u * SMALL_MAX) slots *= 2u;
-  int rc = small_encode_launch(m, dl, c->enc, in_blob, in_off, n32, qw, p, z, slots, true, st, err);
+  int rc = small_encode_launch(m, dl, c->enc, in_blob, in_off, n32, qw, p, z, slots, true, h_off, st, err);
   if (rc) { host_result_free(rows); return rc; }
   // ---- scan -----------------------------------------------------------------------------------------------------------------------------
   const uint32_t region_cap = 1u << SMALL_SHIFT;
@@ -232,7 +232,11 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
   while (fs_cap < region_cap && fs_cap < n32 * 32u + 1024u) fs_cap *= 2u;
   FilterArgs fa;
   fa.region_shift = SMALL_SHIFT; fa.rctr = c->rctr; fa.qexact = c->enc.qexact; fa.stop = 0; fa.enable = enable_filter;
-  fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = c->counters; fa.stat_ctr = c->sctr; fa.fill_cap = fs_cap; fa.blk = SMALL_FS_BLK;
+  // pairs with a string of 17..32 symbols go to the 8-word register DL also when no QUERY is that long (the batch path leaves a short-query
+  // batch's few long candidates to the general LDS kernel: there its extra launch costs more than it saves; here both run inside k_small_lists and
+  // one round of the general kernel is 25 us of a 170 us call)
+  const bool use8 = fastD > 0 && threads == 256;
+  fa.use_nw8 = (have_long_q || use8) ? 1 : 0; fa.counters = c->counters; fa.stat_ctr = c->sctr; fa.fill_cap = fs_cap; fa.blk = SMALL_FS_BLK;
   {
     // k_filter_score's rarely used arguments live in device memory (FsCold): uploaded again only when they change (another model,
     // other weights / thresholds / row width) -- compared field by field (struct padding is not)
@@ -265,7 +269,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
 #undef ANX_FS_PICK
 #undef ANX_FS_LAUNCH
   if (threads == 256) {  // the slot-list kernels as one launch, a block per region (k_small_lists)
-    SmallListArgs L{lw, l8, lg, (split_wide && enable_filter) ? 1 : 0, (fastD && have_long_q) ? 1 : 0, fastD};
+    SmallListArgs L{lw, l8, lg, (split_wide && enable_filter) ? 1 : 0, (fastD && (have_long_q || use8)) ? 1 : 0, fastD};
     const dim3 lgrid(SCAN_REGIONS);
     const size_t dyn = (size_t)threads * sa.stride;
     if (fastD == 1) hipLaunchKernelGGL(k_small_lists<1>, lgrid, dim3(256), dyn, st, L, fa, pa, sa, so);
