@@ -308,7 +308,7 @@ def e2e_of(args, model, queries, params, stream_handle, torch):
     return e2e
 
 
-def by_batch_size_of(model, om, queries, params, op, sizes=(1, 64, 1000, 32768, 1_000_000), threads=8):
+def by_batch_size_of(model, om, queries, params, op, sizes=(1, 64, 1000, 32768, 1_000_000), threads=8, alphabet_path=None, lexicon_path=None):
     """The call at the reference's own granularity (find_variants takes ONE string, src/lib.rs:972; the CLI and the Python binding fan out
     in batches of 1 000, src/bin/analiticcl.rs:416, bindings/python/src/lib.rs:704-749): anx_find_variants_batch (char** in, anx_result
     rows + offsets out) host to host for n = 1 .. 1 M inputs -- best / median microseconds per call, the rows of every size against the
@@ -375,7 +375,29 @@ def by_batch_size_of(model, om, queries, params, op, sizes=(1, 64, 1000, 32768, 
             x.join()
         best = max(best, threads * per * n / (time.perf_counter() - t))
     res[f"threads{threads}_n{n}"] = {"queries_per_s": best, "calls_per_pass": threads * per,
-                                     "what": f"{threads} host threads, each {per} calls of {n} inputs on the one model (ctypes releases the GIL for the call), best of 3 passes"}
+                                     "what": f"{threads} PYTHON host threads, each {per} calls of {n} inputs on the one model (ctypes releases the GIL for the call, the "
+                                             "interpreter's own work per call is serialised by it), best of 3 passes"}
+    # the same with NATIVE host threads: tools/small_threads.cpp against libanx.so, as a child process with a model of its own
+    if alphabet_path is None or lexicon_path is None:
+        return res
+    try:
+        import subprocess
+        import tempfile as _tf
+        d_ = _tf.mkdtemp(prefix="anx_small_threads_")
+        exe = os.path.join(d_, "small_threads")
+        libdir = os.path.join(REPO, "analiticcl_amd")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tools", "small_threads.cpp"), "-o", exe,
+                               "-L", libdir, "-lanx", f"-Wl,-rpath,{libdir}"], stderr=subprocess.DEVNULL)
+        qf = os.path.join(d_, "queries.txt")
+        with open(qf, "w", encoding="utf-8") as f:
+            f.write("\n".join(queries[:threads * n]) + "\n")
+        r_ = subprocess.run([exe, alphabet_path, lexicon_path, qf, str(threads), str(n), "200"], capture_output=True, text=True, timeout=300)
+        if r_.returncode == 0:
+            res[f"native_threads{threads}_n{n}"] = json.loads(r_.stdout.strip().splitlines()[-1])
+        else:
+            res[f"native_threads{threads}_n{n}"] = {"error": (r_.stderr or r_.stdout)[-300:]}
+    except Exception as e_:  # noqa: BLE001
+        res[f"native_threads{threads}_n{n}"] = {"error": repr(e_)[:300]}
     return res
 
 
@@ -1298,7 +1320,7 @@ def main():
                 e2e["pipelined_oracle_parity"] = _spot_check(model, om_, queries, (off_, rows_["vocab_id"], rows_["dist_score"], rows_["freq_score"]), op_,
                                                              min(args.spot_check, len(queries)))
             if world == 1 and not do_gather:
-                by_batch_size = by_batch_size_of(model, om_, queries, params, op_)
+                by_batch_size = by_batch_size_of(model, om_, queries, params, op_, alphabet_path=paths["alphabet"], lexicon_path=paths[args.lexicon])
             del om_
         if e2e is not None:
             e2e.pop("pipelined_last", None)
