@@ -42,7 +42,12 @@ __device__ inline void surv_append(const SurvOut& o, uint32_t region, bool keep,
 }
 
 // The part of gather_instances / score_and_rank that follows a successful Damerau-Levenshtein (ld <= d):
-// LCS, prefix, suffix, case (src/lib.rs:1352-1377), the f64 score (:1433-1452), max_freq and the survivor count.
+// LCS, prefix, suffix (src/lib.rs:1352-1366; score_tail: byte-wise from LDS rows) and case (:1367-1377), the f64 score (:1433-1452),
+// max_freq and the survivor count (score_finish).
+__device__ inline double score_finish(int lq, uint32_t ld, uint32_t lcs, uint32_t pre, uint32_t suf, uint32_t qm, uint32_t em, uint32_t q, uint32_t e,
+                                      const ScoreArgs& a, const uint32_t* __restrict__ ent_freq, const uint32_t* __restrict__ ent_var_off,
+                                      uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand,
+                                      uint32_t& samecase, bool& keep);
 __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, int lc, uint32_t ld, uint32_t qm, uint32_t em,
                                     uint32_t q, uint32_t e, const ScoreArgs& a, const uint32_t* __restrict__ ent_freq,
                                     const uint32_t* __restrict__ ent_var_off, uint32_t* __restrict__ qmaxfreq,
@@ -82,6 +87,12 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
     while (n < m && S[lq - 1 - n] == T[lc - 1 - n]) ++n;
     suf = n;
   }
+  return score_finish(lq, ld, lcs, pre, suf, qm, em, q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, samecase, keep);
+}
+__device__ inline double score_finish(int lq, uint32_t ld, uint32_t lcs, uint32_t pre, uint32_t suf, uint32_t qm, uint32_t em, uint32_t q, uint32_t e,
+                                      const ScoreArgs& a, const uint32_t* __restrict__ ent_freq, const uint32_t* __restrict__ ent_var_off,
+                                      uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand,
+                                      uint32_t& samecase, bool& keep) {
   if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
   // x / L for integers x <= L <= 32 comes from a table of host-computed IEEE quotients (identical bits, no f64 divide)
   const double L = (double)lq;
@@ -227,6 +238,167 @@ __device__ inline uint32_t dl_band(const uint32_t (&S)[NW], const uint32_t (&T)[
   return res;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3, round 6: the same distance by DIAGONALS (Ukkonen / Landau-Vishkin furthest-reaching form) for pairs of <= 16 symbols.
+//   L[e][k] = the furthest row i on diagonal k (column j = i + k) with D[i][j] <= e.  D is non-decreasing along a diagonal, so
+//   L[e][k] = slide(max(L[e-1][k-1], L[e-1][k] + 1, L[e-1][k+1] + 1, transposition terms)) where slide() follows the equal symbols.
+//   The transposition term of src/distance.rs:157-162 (cost (i-l-1) + 1 + (j-db-1): a symbols of s deleted and b symbols of t inserted
+//   between the two swapped ones, x = 1 + a + b) only has to be tried at the FURTHEST point r = L[e-x][k'] of its source diagonal
+//   k' = k - b + a: from any earlier point of that diagonal the landing row r' + 2 + a is reached by one substitution + a deletions +
+//   b insertions from the furthest point as well (r + 1 + a >= r' + 2 + a), at the same cost.  It applies iff s[r] == t[c + 1 + b] and
+//   s[r + 1 + a] == t[c] (c = r + k'), and lands on row r + 2 + a; every term so formed is a real edit sequence of the unrestricted
+//   distance, so the minimum is the reference's value for every outcome <= D (the reference keeps the LAST matching row / column only,
+//   which Lowrance-Wagner prove sufficient).  Result = the smallest e with L[e][lc - lq] >= lq.
+//   All of it runs on 16-bit MISMATCH MASKS, one per diagonal of the band: bit i of M[k] = (s[i] != t[i + k]), built from the register
+//   words by XOR, a zero-byte test and a 4 x 8-bit dot product that gathers the four flags of a word (v_dot4_u32_u8 with the weights
+//   1, 2, 4, 8 / 16, 32, 64, 128); slide(r, k) = r + ctz(M[k] >> r), the symbol tests are single bits of ~M.  No row loop: (D+1)^2 cells
+//   instead of (2D+1) x lq, the same instruction count for every length, no exec masks.  Rows beyond a string's end need no clamp:
+//   the paddings equal nothing (bits set), every step off a diagonal costs 1 whatever the row, and the final test is ">= lq".
+//   Python model + 720 k random pairs against the twin's damerau_levenshtein (alphabets of 2..26 symbols, D = 1..3): HISTORY.md section 15.
+// ------------------------------------------------------------------------------------------------
+template <bool B7>
+__device__ __forceinline__ uint32_t nonzero_byte_flags(uint32_t x) {  // 0x80 in every byte of x that is not zero (B7: every byte of x < 0x80)
+  if (B7) return (x + 0x7F7F7F7Fu) & 0x80808080u;
+  return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+// bit i (i < 16) = s[i] != t[i + K]; bits 16..31 set.  pad = four bytes that equal nothing of s
+template <int K, bool B7>
+__device__ __forceinline__ uint32_t diag_mismatch_mask(const uint32_t (&S)[4], const uint32_t (&T)[4], uint32_t pad) {
+  static_assert(K >= -15 && K <= 15, "16 symbols");
+  constexpr int KM = (K + 16) / 4 - 4, KS = (K + 16) % 4;   // K = 4 * KM + KS, KS in 0..3
+  auto word = [&](int i) { return i >= 0 && i < 4 ? T[i >= 0 && i < 4 ? i : 0] : pad; };
+  uint32_t tw[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) tw[w] = KS == 0 ? word(w + KM) : __builtin_amdgcn_alignbyte(word(w + KM + 1), word(w + KM), KS);
+  const uint32_t lo = __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(S[1] ^ tw[1]), 0x80402010u,
+                                             __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(S[0] ^ tw[0]), 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(S[3] ^ tw[3]), 0x80402010u,
+                                             __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(S[2] ^ tw[2]), 0x08040201u, 0u, false), false);
+  return (lo >> 7) | (hi << 1) | 0xFFFF0000u;   // (the flags are 0x80: the sums come out shifted by 7)
+}
+template <int D, bool B7>
+struct DiagMasks {
+  static constexpr uint32_t PM = B7 ? 0x7F7F7F7Fu : 0xFFFFFFFFu;  // B7: symbols < 0x7E, the paddings become 0x7E / 0x7F
+  uint32_t M[2 * D + 1];   // [k + D]
+  uint32_t S[4], T[4];     // the words the masks are made from
+  template <int K>
+  __device__ __forceinline__ void fill() {
+    M[K + D] = diag_mismatch_mask<K, B7>(S, T, PM);
+    if constexpr (K < D) fill<K + 1>();
+  }
+  // S0: query words padded 0xFE, T0: candidate words padded 0xFF (load_pair)
+  __device__ __forceinline__ void build(const uint32_t (&S0)[4], const uint32_t (&T0)[4]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { S[w] = S0[w] & PM; T[w] = T0[w] & PM; }
+    fill<-D>();
+  }
+};
+// ------------------------------------------------------------------------------------------------
+// The tail's string measures from the same masks (pairs of <= 16 symbols, |lq - lc| <= D):
+//   common_prefix_length (src/distance.rs:207-218) = the first set bit of M[0];
+//   common_suffix_length (:220-231) = the clear bits of M[lc - lq] downwards from bit lq - 1;
+//   longest_common_substring_length (:181-205) = the longest run of clear bits on ANY diagonal: the band's 2D + 1 masks two to a
+//   register (z & z >> 1 until nothing is left; the upper half holds a negative diagonal, whose bit 0 is never a match, so nothing
+//   leaks into the lower half), then the diagonals +-r beyond the band, r = D + 1, ... while some lane of the wave has an overlap
+//   min(lq, lc - r) or min(lq - r, lc) above its best run so far (the overlaps only shrink with r: same walk and same stop as
+//   score_tail's byte loop).  On configs[1]'s survivors a lane needs r = 3 in 24 %, r = 4 in 7 %, r >= 5 in 2 % of the cases, and a far
+//   diagonal holds the longest run 4 times in 28 644.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t runs_of_packed(uint32_t p) {  // longest run of set bits in either half of p (see above), wave-uniform loop
+  uint32_t n = 0;
+  while (__any(p != 0u)) {
+    n += p != 0u;
+    p &= p >> 1;
+  }
+  return n;
+}
+template <int R, int D, bool B7>
+__device__ __forceinline__ void lcs_far_diagonals(const DiagMasks<D, B7>& dm, int lq, int lc, uint32_t& best) {
+  const int ov = max(min(lq, lc - R), min(lq - R, lc));
+  if (!__any(ov > (int)best)) return;   // wave-uniform
+  const uint32_t zp = ~diag_mismatch_mask<R, B7>(dm.S, dm.T, DiagMasks<D, B7>::PM), zm = ~diag_mismatch_mask<-R, B7>(dm.S, dm.T, DiagMasks<D, B7>::PM);
+  best = max(best, runs_of_packed(zp | (zm << 16)));
+  if constexpr (R < 15) lcs_far_diagonals<R + 1, D, B7>(dm, lq, lc, best);
+}
+template <int D, bool B7>
+__device__ __forceinline__ void measures16(const DiagMasks<D, B7>& dm, int lq, int lc, const ScoreArgs& a, uint32_t& lcs, uint32_t& pre, uint32_t& suf) {
+  if (a.w_prefix > 0.0) pre = (uint32_t)__builtin_ctz(dm.M[D]);
+  if (a.w_suffix > 0.0) {
+    const int kf = lc - lq;
+    uint32_t sel = dm.M[0];
+#pragma unroll
+    for (int k = -D + 1; k <= D; ++k) {
+      sel = kf == k ? dm.M[k + D] : sel;
+      asm("" : "+v"(sel));   // (keeps the selects: the compiler otherwise turns the chain into an indexed load of M[] from scratch memory)
+    }
+    suf = (uint32_t)__builtin_clz(~(~sel << (32 - lq)));   // (1 <= lq <= 16: the low bits of the shifted word are clear)
+  }
+  if (a.w_lcs > 0.0 && !(ANX_DBG(a.dbg) & 1)) {
+    uint32_t best = 0;
+    {
+      uint32_t p[D + 1];
+#pragma unroll
+      for (int k = 0; k <= D; ++k) p[k] = ~dm.M[k + D] | (k + 1 <= D ? ~dm.M[D - (k + 1)] << 16 : 0u);
+      while (true) {   // wave-uniform
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k <= D; ++k) any |= p[k];
+        if (!__any(any != 0u)) break;
+        best += any != 0u;
+#pragma unroll
+        for (int k = 0; k <= D; ++k) p[k] &= p[k] >> 1;
+      }
+    }
+    lcs_far_diagonals<D + 1, D, B7>(dm, lq, lc, best);
+    lcs = best;
+  }
+}
+
+template <int D, bool B7>
+__device__ __forceinline__ uint32_t dl_diag(const DiagMasks<D, B7>& dm, int lq, int lc) {
+  constexpr int BW = 2 * D + 1;
+  uint32_t N[BW];
+#pragma unroll
+  for (int c = 0; c < BW; ++c) N[c] = ~dm.M[c];
+  auto slide = [&](uint32_t r, int k) { return r + (uint32_t)__builtin_ctz(dm.M[k + D] >> r); };  // (r <= 16 + D; bits 16.. are set)
+  uint32_t L[D + 1][BW];
+#pragma unroll
+  for (int e = 0; e <= D; ++e)
+#pragma unroll
+    for (int c = 0; c < BW; ++c) L[e][c] = 0;
+  L[0][D] = slide(0u, 0);
+#pragma unroll
+  for (int e = 1; e <= D; ++e) {
+#pragma unroll
+    for (int k = -e; k <= e; ++k) {
+      uint32_t v = 0;
+      if (k - 1 >= -(e - 1) && k - 1 <= e - 1) v = max(v, L[e - 1][k - 1 + D]);          // insertion: same row, next column
+      if (k + 1 >= -(e - 1) && k + 1 <= e - 1) v = max(v, L[e - 1][k + 1 + D] + 1u);     // deletion
+#pragma unroll
+      for (int a = 0; a < e; ++a) {
+#pragma unroll
+        for (int b = 0; a + b < e; ++b) {
+          const int x = 1 + a + b, kp = k - b + a, lim = e - x;
+          if (kp < -lim || kp > lim) continue;
+          // substitution + a deletions + b insertions from the furthest point of (e - x, kp), one row more if the transposition applies
+          // (a = b = 0: the plain substitution term)
+          const uint32_t r = L[e - x][kp + D];
+          const uint32_t both = N[kp + 1 + b + D] & (N[kp - 1 - a + D] >> (1 + a));
+          v = max(v, r + (uint32_t)(1 + a) + ((both >> r) & 1u));
+        }
+      }
+      L[e][k + D] = slide(v, k);
+    }
+  }
+  const int kf = lc - lq;
+  uint32_t res = D + 1;
+#pragma unroll
+  for (int e = D; e >= 0; --e)
+#pragma unroll
+    for (int k = -e; k <= e; ++k) res = (kf == k && L[e][k + D] >= (uint32_t)lq) ? (uint32_t)e : res;
+  return res;
+}
+
 // A list of pair-list slots per region (the selected pairs a later kernel has to score), appended per wave.
 struct SlotList {
   uint32_t* list;      // [SCAN_REGIONS][region_cap]
@@ -294,6 +466,17 @@ __device__ inline void load_pair(uint32_t p, bool active, const PairArgs& A, con
   }
 }
 // DL of the loaded pair (all lanes of the wave call this); PAIR_NONE if above the pair's d
+#ifndef ANX_DL_BAND   // (A/B builds: -DANX_DL_BAND=1 keeps the row form for every pair)
+#define ANX_DL_BAND 0
+#endif
+template <int D, bool B7>
+__device__ __forceinline__ uint32_t dl_of_pair16(const PairRegs<4>& r, bool active) {
+  DiagMasks<D, B7> dm;
+  dm.build(r.S, r.T);
+  const uint32_t res = dl_diag<D, B7>(dm, r.lq, r.lc);
+  const int diff = r.lq > r.lc ? r.lq - r.lc : r.lc - r.lq;
+  return (active && diff <= r.d && res <= (uint32_t)r.d) ? res : PAIR_NONE;  // src/distance.rs:109-130, 173-178
+}
 template <int D, int NW>
 __device__ inline uint32_t dl_of_pair(const PairRegs<NW>& r, bool active) {
   int lqmax = active ? r.lq : 0;
@@ -324,6 +507,26 @@ __device__ inline void tail_of_pair(uint32_t p, bool has, uint32_t ld, const Pai
       A.p_score[p] = score;
       A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
     }
+  }
+}
+
+// tail_of_pair for pairs of <= 16 symbols whose |lq - lc| <= D: the measures from the diagonal masks, no LDS rows
+template <int D, bool B7>
+__device__ __forceinline__ void tail_of_pair16(uint32_t p, bool has, uint32_t ld, const PairRegs<4>& r, const PairArgs& A, const ScoreArgs& a, const SurvOut& so,
+                                      uint32_t surv_region) {
+  uint32_t lcs = 0, pre = 0, suf = 0, samecase = 1;
+  double score = __builtin_nan("");
+  bool keep = false;
+  if (__any(has) && !(ANX_DBG(a.dbg) & 2)) {   // (the measures' loops are wave-wide: lanes without a pair hold paddings, which match nothing)
+    DiagMasks<D, B7> dm;
+    dm.build(r.S, r.T);
+    measures16<D, B7>(dm, has ? r.lq : 1, has ? r.lc : 1, a, lcs, pre, suf);
+    if (has) score = score_finish(r.lq, ld, lcs, pre, suf, r.qm, r.em, r.q, r.e, a, A.ent_freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, samecase, keep);
+  }
+  surv_append(so, surv_region, keep, r.q, r.e, score);
+  if (has && a.store_pairs) {
+    A.p_score[p] = score;
+    A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
 }
 
@@ -377,7 +580,7 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   const SlotList &list8 = cold->list8, &listg = cold->listg, &listw = cold->listw;
   __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
   __shared__ uint32_t s_n;
-  __shared__ uint32_t s_str[256 * 9];
+  __shared__ uint32_t s_str[ANX_DL_BAND ? 256 * 9 : 1];
   // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
   // counter word sustains only ~88 M atomics/s)
   const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * f.blk;
@@ -489,7 +692,7 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       const uint32_t p = (region << f.region_shift) + base + off;
       PairRegs<4> r;
       load_pair<4>(p, active, A, a, r);
-      const uint32_t ld = dl_of_pair<DD, 4>(r, active);
+      const uint32_t ld = ANX_DL_BAND ? dl_of_pair<DD, 4>(r, active) : dl_of_pair16<DD, B7>(r, active);
       if (a.store_pairs && active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
       const bool surv = ld != PAIR_NONE;
       const unsigned long long ms = __ballot(surv);
@@ -510,7 +713,8 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       const uint32_t p = (region << f.region_shift) + base + (ent & 0xFFFu);
       PairRegs<4> r;
       load_pair<4>(p, active, A, a, r);
-      tail_of_pair<4>(p, active, ent >> 12, r, A, a, so, region, s_str);
+      if (ANX_DL_BAND) tail_of_pair<4>(p, active, ent >> 12, r, A, a, so, region, s_str);
+      else tail_of_pair16<DD, B7>(p, active, ent >> 12, r, A, a, so, region);
     }
   }
 }

@@ -36,6 +36,16 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed) {
       if (OP == 17) asm volatile("v_and_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]), "=&v"(f[i]) : "v"(x), "v"(y));
       if (OP == 18) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
       if (OP == 19) asm volatile("v_max_i32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
+      if (OP == 20) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
+      if (OP == 21) asm volatile("v_ffbl_b32 %0, %0" : "+v"(a[i]));
+      if (OP == 22) asm volatile("v_alignbyte_b32 %0, %1, %0, 1" : "+v"(a[i]) : "v"(x));
+      if (OP == 23) asm volatile("v_bfe_u32 %0, %1, %0, 1" : "+v"(a[i]) : "v"(x));
+      if (OP == 24) asm volatile("v_xad_u32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(x), "s"(seed));
+      if (OP == 25) asm volatile("v_cmp_eq_u32_sdwa s[10:11], %0, %1 src0_sel:BYTE_1 src1_sel:BYTE_0" :: "v"(a[i]), "v"(x) : "s10", "s11");
+      if (OP == 26) asm volatile("v_cndmask_b32 %0, %1, %0, vcc" : "+v"(a[i]) : "v"(x) : "vcc");
+      if (OP == 27) asm volatile("v_max3_u32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+      if (OP == 28) asm volatile("v_bitop3_b32 %0, %1, %2, %0 bitop3:0x10" : "+v"(a[i]) : "v"(x), "v"(y));
+      if (OP == 29) asm volatile("v_min_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
     }
   }
   uint32_t r = 0;
@@ -81,6 +91,16 @@ int main() {
   run<15>("v_dot4_u32_u8", 1, d);
   run<18>("v_and_b32 (sgpr src)", 1, d);
   run<19>("v_max_i32", 1, d);
+  run<20>("v_lshrrev_b32", 1, d);
+  run<21>("v_ffbl_b32", 1, d);
+  run<22>("v_alignbyte_b32", 1, d);
+  run<23>("v_bfe_u32", 1, d);
+  run<24>("v_xad_u32", 1, d);
+  run<25>("v_cmp_eq_u32_sdwa sgpr", 1, d);
+  run<26>("v_cndmask_b32 vcc", 1, d);
+  run<27>("v_max3_u32", 1, d);
+  run<28>("v_bitop3_b32", 1, d);
+  run<29>("v_min_u32", 1, d);
   run<16>("and(sgpr)+bcnt pair", 2, d);
   run<17>("and(vgpr)+bcnt pair", 2, d);
   return 0;
