@@ -13,7 +13,7 @@
 // ------------------------------------------------------------------------------------------------
 struct ScoreArgs {
   const double* quot;  // [33][33] quot[x*33+L] = (double)x / (double)L computed on the host, or nullptr
-  int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL
+  int dbg;  // ANX_SCORE_DBG (timing experiments only): 1 skip LCS, 2 skip everything after DL, 4 skip the DL, 8 skip the short round's row gathers
   int store_pairs;  // write the per-slot outputs p_meta / p_score (only the debug view anx_batch_fetch_pairs reads them)
   double w_ld, w_lcs, w_prefix, w_suffix, w_case, w_sum;
   double score_threshold;
@@ -44,10 +44,11 @@ __device__ inline void surv_append(const SurvOut& o, uint32_t region, bool keep,
 // The part of gather_instances / score_and_rank that follows a successful Damerau-Levenshtein (ld <= d):
 // LCS, prefix, suffix (src/lib.rs:1352-1366; score_tail: byte-wise from LDS rows) and case (:1367-1377), the f64 score (:1433-1452),
 // max_freq and the survivor count (score_finish).
+// freq: the entry's frequency (ent_freq[e]); quot17: nullptr, or the part of a.quot for x, L <= 16 as an LDS table [17][17]
 __device__ inline double score_finish(int lq, uint32_t ld, uint32_t lcs, uint32_t pre, uint32_t suf, uint32_t qm, uint32_t em, uint32_t q, uint32_t e,
-                                      const ScoreArgs& a, const uint32_t* __restrict__ ent_freq, const uint32_t* __restrict__ ent_var_off,
+                                      const ScoreArgs& a, uint32_t freq, const uint32_t* __restrict__ ent_var_off,
                                       uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand,
-                                      uint32_t& samecase, bool& keep);
+                                      uint32_t& samecase, bool& keep, const double* quot17 = nullptr, uint32_t* rows_out = nullptr);
 __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, int lc, uint32_t ld, uint32_t qm, uint32_t em,
                                     uint32_t q, uint32_t e, const ScoreArgs& a, const uint32_t* __restrict__ ent_freq,
                                     const uint32_t* __restrict__ ent_var_off, uint32_t* __restrict__ qmaxfreq,
@@ -87,17 +88,20 @@ __device__ inline double score_tail(const uint8_t* S, const uint8_t* T, int lq, 
     while (n < m && S[lq - 1 - n] == T[lc - 1 - n]) ++n;
     suf = n;
   }
-  return score_finish(lq, ld, lcs, pre, suf, qm, em, q, e, a, ent_freq, ent_var_off, qmaxfreq, qsurv, qexpand, samecase, keep);
+  return score_finish(lq, ld, lcs, pre, suf, qm, em, q, e, a, a.have_freq ? ent_freq[e] : 1u, ent_var_off, qmaxfreq, qsurv, qexpand, samecase, keep);
 }
 __device__ inline double score_finish(int lq, uint32_t ld, uint32_t lcs, uint32_t pre, uint32_t suf, uint32_t qm, uint32_t em, uint32_t q, uint32_t e,
-                                      const ScoreArgs& a, const uint32_t* __restrict__ ent_freq, const uint32_t* __restrict__ ent_var_off,
+                                      const ScoreArgs& a, uint32_t freq, const uint32_t* __restrict__ ent_var_off,
                                       uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv, uint32_t* __restrict__ qexpand,
-                                      uint32_t& samecase, bool& keep) {
+                                      uint32_t& samecase, bool& keep, const double* quot17, uint32_t* rows_out) {
   if (a.w_case > 0.0) samecase = ((qm >> 24) & 1u) == ((em >> 8) & 1u);  // src/lib.rs:1367-1377
   // x / L for integers x <= L <= 32 comes from a table of host-computed IEEE quotients (identical bits, no f64 divide)
   const double L = (double)lq;
   const bool tab = a.quot && lq <= 32;
-  auto over_L = [&](uint32_t x) { return (tab && x <= 32u) ? a.quot[x * 33u + (uint32_t)lq] : (double)x / L; };
+  auto over_L = [&](uint32_t x) {
+    if (quot17 && lq <= 16 && x <= 16u) return quot17[x * 17u + (uint32_t)lq];
+    return (tab && x <= 32u) ? a.quot[x * 33u + (uint32_t)lq] : (double)x / L;
+  };
   const double distance_score = (int)ld > lq ? 0.0 : 1.0 - over_L(ld);
   const double lcs_score = over_L(lcs);
   const double prefix_score = over_L(pre);
@@ -106,15 +110,52 @@ __device__ inline double score_finish(int lq, uint32_t ld, uint32_t lcs, uint32_
                      a.w_suffix * suffix_score + (samecase ? a.w_case : 0.0);
   const double score = a.w_sum == 1.0 ? num : num / a.w_sum;  // x / 1.0 == x
   // max_freq over every DL-surviving instance, before the threshold test (src/lib.rs:1454-1462)
-  atomicMax(&qmaxfreq[q], a.have_freq ? ent_freq[e] : 1u);
+  // (rows_out: the caller adds the two per-query counters itself, see survivor_counts)
+  if (!rows_out && !(ANX_DBG(a.dbg) & 16)) atomicMax(&qmaxfreq[q], freq);
   uint32_t nrows = 1;
   if (a.any_variants) {  // variant lists loaded (src/lib.rs:1464-1466, 1510, 1677-1727)
     if (em & 0x200u) qexpand[q] = 1;  // benign race: every writer stores 1
     nrows = (ent_var_off[e + 1] - ent_var_off[e]) + ((em & 0x400u) ? 0u : 1u);  // transparent: references only
   }
   keep = score >= a.score_threshold && nrows;  // src/lib.rs:1475
-  if (keep) atomicAdd(&qsurv[q], nrows);
+  if (rows_out) *rows_out = keep ? nrows : 0u;
+  else if (keep && !(ANX_DBG(a.dbg) & 16)) atomicAdd(&qsurv[q], nrows);
   return score;
+}
+// The per-query counters of score_finish for a whole wave (all lanes call this): the DL survivors of a query are neighbours in the
+// pair list and in k_filter_score's queue, so ONE lane per run of equal queries adds the run's rows and its largest frequency --
+// 64 lanes' atomics on a few words of one cache line were 0.14 of the kernel's 0.63 ms.
+__device__ __forceinline__ void survivor_counts(bool has, uint32_t q, uint32_t freq, uint32_t nrows, const ScoreArgs& a,
+                                                uint32_t* __restrict__ qmaxfreq, uint32_t* __restrict__ qsurv) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t key = has ? q : 0xFFFFFFFFu;
+  const uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
+  const bool head = lane == 0u || kprev != key;
+  const unsigned long long hm = __ballot(head);
+  const uint32_t start = 63u - (uint32_t)__clzll((long long)(hm & ((2ull << lane) - 1ull)));   // (lane 0 is a head)
+  const unsigned long long above = lane == 63u ? 0ull : hm & ~((2ull << lane) - 1ull);
+  const bool last = above ? (uint32_t)__ffsll((long long)above) - 1u == lane + 1u : lane == 63u;   // the run's last lane
+  // inclusive segmented scans over the run: rows (sum), frequency (max)
+  uint32_t rows = has ? nrows : 0u, mf = has ? freq : 0u;
+  const bool scan_rows = a.any_variants != 0, scan_freq = a.have_freq != 0;   // (else: one row per kept lane, frequency 1)
+  if (!scan_rows) {
+    const unsigned long long km = __ballot(rows != 0u);
+    const unsigned long long upto = (2ull << lane) - 1ull, from = ~((1ull << start) - 1ull);
+    rows = (uint32_t)__popcll(km & upto & from);
+  }
+  if (scan_rows || scan_freq) {
+#pragma unroll
+    for (uint32_t off = 1; off < 64u; off <<= 1) {
+      const uint32_t ur = (uint32_t)__shfl_up((int)rows, off), uf = (uint32_t)__shfl_up((int)mf, off);
+      const bool in = lane >= start + off;
+      if (scan_rows) rows += in ? ur : 0u;
+      if (scan_freq) mf = in ? max(mf, uf) : mf;
+    }
+  }
+  if (last && has && !(ANX_DBG(a.dbg) & 16)) {
+    atomicMax(&qmaxfreq[q], mf);
+    if (rows) atomicAdd(&qsurv[q], rows);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,22 +479,30 @@ struct PairArgs {  // what every scoring kernel reads / writes
 // Loads the pair of slot p into registers (NW words per string); returns false for !active.
 template <int NW>
 struct PairRegs {
-  uint32_t q = 0, e = 0, qm = 0, em = 0;
+  uint32_t q = 0, e = 0, qm = 0, em = 0, freq = 1;
   int lq = 0, lc = 0, d = 0;
   uint32_t S[NW], T[NW];
 };
 template <int NW>
+__device__ inline void load_pair_qe(uint32_t q, uint32_t e, bool active, const PairArgs& A, const ScoreArgs& a, PairRegs<NW>& r);
+template <int NW>
 __device__ inline void load_pair(uint32_t p, bool active, const PairArgs& A, const ScoreArgs& a, PairRegs<NW>& r) {
+  uint2 rp = make_uint2(0u, 0u);
+  if (active) rp = A.raw[p];
+  load_pair_qe<NW>(rp.x, rp.y & RAW_ENTRY_MASK, active, A, a, r);
+}
+template <int NW>
+__device__ inline void load_pair_qe(uint32_t q, uint32_t e, bool active, const PairArgs& A, const ScoreArgs& a, PairRegs<NW>& r) {
 #pragma unroll
   for (int w = 0; w < NW; ++w) { r.S[w] = 0xFEFEFEFEu; r.T[w] = 0xFFFFFFFFu; }
   if (!active) return;
-  const uint2 rp = A.raw[p];
-  r.q = rp.x;
-  r.e = rp.y & RAW_ENTRY_MASK;
+  r.q = q;
+  r.e = e;
   const uint4 Q0 = rec32(A.q_rec, r.q)[0], QM = rec32(A.q_rec, r.q)[1];
   const uint4 C0 = rec32(A.e_rec, r.e)[0], CM = rec32(A.e_rec, r.e)[1];
   r.qm = QM.x;
   r.em = CM.x;
+  r.freq = a.have_freq ? CM.z : 1u;   // (e_rec[e][1] = {meta, row offset, ent_freq[e], -})
   r.lq = r.qm & 0xFF; r.d = (r.qm >> 16) & 0xFF; r.lc = r.em & 0xFF;
   r.S[0] = Q0.x; r.S[1] = Q0.y; r.S[2] = Q0.z; r.S[3] = Q0.w;
   r.T[0] = C0.x; r.T[1] = C0.y; r.T[2] = C0.z; r.T[3] = C0.w;
@@ -513,7 +562,7 @@ __device__ inline void tail_of_pair(uint32_t p, bool has, uint32_t ld, const Pai
 // tail_of_pair for pairs of <= 16 symbols whose |lq - lc| <= D: the measures from the diagonal masks, no LDS rows
 template <int D, bool B7>
 __device__ __forceinline__ void tail_of_pair16(uint32_t p, bool has, uint32_t ld, const PairRegs<4>& r, const PairArgs& A, const ScoreArgs& a, const SurvOut& so,
-                                      uint32_t surv_region) {
+                                      uint32_t surv_region, const double* quot17) {
   uint32_t lcs = 0, pre = 0, suf = 0, samecase = 1;
   double score = __builtin_nan("");
   bool keep = false;
@@ -521,9 +570,12 @@ __device__ __forceinline__ void tail_of_pair16(uint32_t p, bool has, uint32_t ld
     DiagMasks<D, B7> dm;
     dm.build(r.S, r.T);
     measures16<D, B7>(dm, has ? r.lq : 1, has ? r.lc : 1, a, lcs, pre, suf);
-    if (has) score = score_finish(r.lq, ld, lcs, pre, suf, r.qm, r.em, r.q, r.e, a, A.ent_freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, samecase, keep);
+    uint32_t nrows = 0;
+    if (has) score = score_finish(r.lq, ld, lcs, pre, suf, r.qm, r.em, r.q, r.e, a, r.freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, samecase, keep, quot17, &nrows);
+    survivor_counts(has, r.q, r.freq, nrows, a, A.qmaxfreq, A.qsurv);
   }
-  surv_append(so, surv_region, keep, r.q, r.e, score);
+  if (!(ANX_DBG(a.dbg) & 32)) surv_append(so, surv_region, keep, r.q, r.e, score);
+  else asm volatile("" :: "v"(score), "v"(keep));
   if (has && a.store_pairs) {
     A.p_score[p] = score;
     A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
@@ -542,14 +594,23 @@ __device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& 
   tail_of_pair<NW>(p, ld != PAIR_NONE, ld, r, A, a, so, surv_region, lds);
 }
 
-// K2+K3 fused: prefilter of every pair-list slot and register-resident DL of the selected pairs, one block per
-// FS_BLK consecutive slots of a region.  Phase 1 (FS_BLK / 256 rounds): length test |lq - lc| <= d
-// (src/distance.rs:109-130), StopAtExactMatch drop (src/lib.rs:1164-1173) and the SWAR band-match bound; selected
-// pairs of <= 16 symbols with d <= D are queued in LDS, longer ones go to the slot lists of the 8-word / general
-// kernels.  Phase 2: the queue is scored 256 pairs at a time, so the DL lanes are dense although only ~1/3 of the
-// slots survive phase 1 (no global compaction pass, no index list).  D = 0: no inline DL (d > 3), everything selected
-// goes to the general kernel's list.
+// K2+K3 fused: prefilter of every pair-list slot, the DL of the selected pairs of <= 16 symbols and the tail of its survivors, one
+// block per FS_BLK consecutive slots of a region, 256 slots per round (the next round's slots are requested a round ahead).
+//   A wave whose slots all carry RAW_PREFILTERED (the scan applied the length test and the band-match bound; both strings <= 16 symbols,
+//   d <= the batch's largest d = D) gathers 16 + 16 bytes per pair -- the two symbol rows -- and nothing else: the lengths are read off
+//   the rows' paddings, and the query's own d is tested with the survivors.  Any other wave takes the general round: length test
+//   |lq - lc| <= d (src/distance.rs:109-130), StopAtExactMatch drop (src/lib.rs:1164-1173), the SWAR band-match bound; selected pairs
+//   of <= 16 symbols with d <= D join the inline DL, longer ones go to the slot lists of the 8-word / general kernels.
+//   The DL runs on the slots as they lie (dl_diag: ~185 instructions a wave whatever the lengths; 3/4 of a fused tile's slots hold a
+//   pair).  Its survivors (~29 %) are queued in LDS -- (query, entry | ld << 26) -- and the queue is drained in dense rounds of 256
+//   whenever another round could overflow it: both records of the pair, the query's d, LCS / prefix / suffix from the diagonal masks,
+//   the f64 score with the x / L quotients from an LDS copy of the host's table, survivor record.
+//   Round 6: until then every selected pair was queued first (a u16 slot offset), gathered through raw[] + two 32-byte records for the
+//   DL in dense rounds and gathered AGAIN the same way for the tail: 5 + 5 vector loads with 64 different lines each per pair-wave,
+//   which is what the kernel's time was once the DL itself had become cheap (the texture path takes about a cycle per line).
+//   D = 0: no inline DL (d > 3), everything selected goes to the general kernel's list.
 constexpr uint32_t FS_BLK = 4096;
+constexpr uint32_t FS_SURV = 1024;   // entries of the LDS survivor queue
 struct FilterArgs {
   uint32_t region_shift;
   const uint32_t* rctr;     // region fills of the pair list
@@ -564,106 +625,140 @@ struct FilterArgs {
 // WIDE = true: the 8-word prefilter of pairs with a string of 17..32 symbols runs inline (batches with such queries: many
 // wide pairs).  WIDE = false (every query <= 16 symbols, so only the few pairs with a 17..19-symbol candidate are wide):
 // wide pairs are appended unfiltered to listw and k_filter_wide prefilters them -- the 8-word SWAR state is what sets the
-// register count of this kernel (72 VGPRs with it, 43 / 52 / 69 for D = 1 / 2 / 3 without: 8 waves per SIMD instead of 7).
+// register count of this kernel.
 // arguments the prefilter rounds hardly touch (score weights, survivor / slot lists) live in device memory and are read where
-// they are used: as by-value kernel arguments they stayed in SGPRs over the 16 unrolled rounds and pushed 20 SGPRs into VGPR
+// they are used: as by-value kernel arguments they stayed in SGPRs over the unrolled rounds and pushed 20 SGPRs into VGPR
 // lanes (a v_readlane per use)
 struct FsCold {
   ScoreArgs a;
   SurvOut so;
   SlotList list8, listg, listw;
 };
+// number of symbols of a row of 16 whose unused bytes hold `pad` (x = the row's words XOR pad: zero bytes = unused)
+template <bool B7>
+__device__ __forceinline__ int row_length16(const uint32_t (&x)[4]) {
+  const uint32_t lo = __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(x[1]), 0x80402010u, __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(x[0]), 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(x[3]), 0x80402010u, __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(x[2]), 0x08040201u, 0u, false), false);
+  return __builtin_ctz(~((lo >> 7) | (hi << 1)));   // (bits 16.. of the sum are clear: at most 16)
+}
 template <int D, bool WIDE, bool B7>
 __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, const FsCold* __restrict__ cold) {
   const ScoreArgs& a = cold->a;
   const SurvOut& so = cold->so;
   const SlotList &list8 = cold->list8, &listg = cold->listg, &listw = cold->listw;
-  __shared__ uint16_t s_q[FS_BLK];  // queued pairs as offsets from the block's first slot
-  __shared__ uint32_t s_n;
-  __shared__ uint32_t s_str[ANX_DL_BAND ? 256 * 9 : 1];
+  constexpr int DD = D > 0 ? D : 1;
+  __shared__ uint2 s_sv[D > 0 ? FS_SURV : 1];         // survivors of the inline DL: (query, entry | ld << 26)
+  __shared__ uint16_t s_svoff[D > 0 ? FS_SURV : 1];   // their slots as offsets from the block's first one (the per-slot debug outputs)
+  __shared__ double s_quot[D > 0 ? 17 * 17 : 1];      // a.quot for x, L <= 16
+  __shared__ uint32_t s_m;
   // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
   // counter word sustains only ~88 M atomics/s)
   const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * f.blk;
   if (base >= fill) return;  // block-uniform
   const uint32_t lim = min(fill, base + f.blk);  // this block's slots: [base, lim)
-  if (threadIdx.x == 0) s_n = 0;
+  const uint32_t p0 = (region << f.region_shift) + base;
+  if (threadIdx.x == 0) s_m = 0;
+  const bool have_quot = D > 0 && a.quot != nullptr;
+  if (have_quot)
+    for (uint32_t i = threadIdx.x; i < 17u * 17u; i += 256u) s_quot[i] = a.quot[(i / 17u) * 33u + i % 17u];
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
+  // the queue's entries in dense rounds: records, the query's own d, tail
+  auto drain = [&]() {
+    const uint32_t m = s_m;   // (read by every thread between two barriers)
+    for (uint32_t r0 = 0; r0 < m; r0 += 256) {
+      const uint32_t i = r0 + threadIdx.x;
+      const bool active = i < m;
+      const uint2 ent = active ? s_sv[i] : make_uint2(0u, 0u);
+      const uint32_t p = p0 + (active ? (uint32_t)s_svoff[i] : 0u), ld = (ent.y >> 26) & 3u;
+      PairRegs<4> r;
+      load_pair_qe<4>(ent.x, ent.y & 0x3FFFFFFu, active && !(ANX_DBG(a.dbg) & 64), A, a, r);
+      if (ANX_DBG(a.dbg) & 64) { r.lq = 8; r.lc = 8; r.d = 2; r.q = ent.x; r.e = ent.y & 0x3FFFFFFu; }
+      const bool has = active && ld <= (uint32_t)r.d;   // (|lq - lc| <= ld)
+      if (a.store_pairs && active && !has) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+      tail_of_pair16<DD, B7>(p, has, ld, r, A, a, so, region, have_quot ? s_quot : nullptr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_m = 0;
+    __syncthreads();
+  };
   uint32_t nselected = 0;  // wave-uniform
+  // Straight-line loads: a lane without a pair (beyond the region's fill, unused chunk tail) reads the block's first slot
+  uint2 rp_next = A.raw[base + threadIdx.x < lim ? p0 + threadIdx.x : p0];
   for (uint32_t r = 0; r < FS_BLK / 256; ++r) {
-    const uint32_t idx = base + r * 256 + threadIdx.x;
     if (base + r * 256 >= lim) break;  // block-uniform
-    const uint32_t p = (region << f.region_shift) + idx;
+    const uint32_t idx = base + r * 256 + threadIdx.x;
+    const uint32_t p = p0 + r * 256 + threadIdx.x;
     const bool live = idx < lim;
-    // Straight-line loads: a lane without a pair (beyond the region's fill, unused chunk tail, StopAtExactMatch drop) reads
-    // slot / query / entry 0 instead of being masked off -- 98 % of the lanes have a pair, and the exec-mask bookkeeping of
-    // nested branches around the loads cost more than the few wasted gathers; its verdict is masked by `selected`.
-    const uint2 rp = A.raw[live ? p : (region << f.region_shift)];
+    const uint2 rp = rp_next;
+    if (base + (r + 1) * 256 < lim) rp_next = A.raw[idx + 256 < lim ? p + 256 : p0];
     const bool invalid = !live || rp.x == RAW_INVALID;  // unused chunk tail
-    // RAW_PREFILTERED: the scan's fused expansion applied the length test and the band-match bound already, and the pair has
-    // both strings <= 16 symbols and d <= 3 -- it goes straight to the inline queue, nothing is gathered for it here.  A chunk
-    // comes from one tile, so whole waves take this path (wave-uniform test).
+    // RAW_PREFILTERED: a chunk comes from one tile, so whole waves take the short round (wave-uniform test)
     const bool pre = !invalid && (rp.y & RAW_PREFILTERED);
-    bool selected = pre, wide = false;
-    int lq = 0, lc = 0, d = 0;
+    bool selected = pre, wide = false, inl = false;
+    int lq = 0, lc = 0, d = D;
+    uint32_t S[4] = {0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu}, T[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     bool stop_skipped = false;
     if (__any(!invalid && !pre)) {
-    bool skip = invalid || pre;
-    if (f.stop)  // StopAtExactMatch: a non-exact class of a query that has an exact one (wave-uniform branch)
-      skip = skip || (!(rp.y & 0x80000000u) && f.qexact[skip ? 0u : rp.x] != 0xFFFFFFFFu);
-    stop_skipped = skip && !invalid && !pre;
-    const uint32_t q = skip ? 0u : rp.x, e = skip ? 0u : (rp.y & RAW_ENTRY_MASK);
-    // the first 16 symbols of both strings come with the records (rows are padded with bytes that equal nothing:
-    // query 0xFE, candidate 0xFF)
-    const uint4 Q = rec32(A.q_rec, q)[0];  // 32-B records: one line each
-    const uint4 QM = rec32(A.q_rec, q)[1];
-    const uint4 C = rec32(A.e_rec, e)[0];
-    const uint4 CM = rec32(A.e_rec, e)[1];
-    const uint32_t crow = CM.y;
-    lq = QM.x & 0xFF; d = (QM.x >> 16) & 0xFF; lc = CM.x & 0xFF;
-    const int diff = lq > lc ? lq - lc : lc - lq;
-    selected = pre || (!skip && diff <= d);
-    const bool filt = selected && !pre && f.enable && d <= 3 && lq <= 32 && lc <= 32;
-    wide = filt && (lq > 16 || lc > 16);
-    if (WIDE && __any(wide)) {  // wave-uniform, rare: some pair of the wave has a string of 17..32 symbols
-      uint32_t q8[8] = {Q.x, Q.y, Q.z, Q.w, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
-      uint32_t c10[10] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-      if (wide && lq > 16) { const uint4 Q1 = A.q_rows[(size_t)q * a.qw + 1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
-      if (wide && lc > 16) { const uint4 C1 = A.rows[crow + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
-      if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
-    } else if (__any(filt && !wide)) {
-      // as many 4-symbol words as the longest string of the WAVE needs (its 64 slots come from one scan chunk, i.e. one tile
-      // and one query length: 23 % of the bench queries fit 2 words with their candidates, 54 % more fit 3)
-      const bool f4 = filt && !wide;
-      const int ml = lq > lc ? lq : lc;
-      // B7 (alphabets of <= 124 classes): symbols < 0x7E, the paddings 0xFE / 0xFF masked down to 0x7E / 0x7F
-      constexpr uint32_t M = B7 ? 0x7F7F7F7Fu : 0xFFFFFFFFu;
-      if (__any(f4 && ml > 12)) {
-        const uint32_t q4[4] = {Q.x & M, Q.y & M, Q.z & M, Q.w & M}, c6[6] = {M, C.x & M, C.y & M, C.z & M, C.w & M, M};
-        if (band_bound_rejects<4, B7>(q4, c6, f4, d, lq, lc)) selected = false;
-      } else if (__any(f4 && ml > 8)) {
-        const uint32_t q3[3] = {Q.x & M, Q.y & M, Q.z & M}, c5[5] = {M, C.x & M, C.y & M, C.z & M, M};
-        if (band_bound_rejects<3, B7>(q3, c5, f4, d, lq, lc)) selected = false;
-      } else {
-        const uint32_t q2[2] = {Q.x & M, Q.y & M}, c4[4] = {M, C.x & M, C.y & M, M};
-        if (band_bound_rejects<2, B7>(q2, c4, f4, d, lq, lc)) selected = false;
+      bool skip = invalid;
+      if (f.stop)  // StopAtExactMatch: a non-exact class of a query that has an exact one (wave-uniform branch)
+        skip = skip || (!pre && !(rp.y & 0x80000000u) && f.qexact[skip ? 0u : rp.x] != 0xFFFFFFFFu);
+      stop_skipped = skip && !invalid;
+      const uint32_t q = skip ? 0u : rp.x, e = skip ? 0u : (rp.y & RAW_ENTRY_MASK);
+      // the first 16 symbols of both strings come with the records (rows are padded with bytes that equal nothing:
+      // query 0xFE, candidate 0xFF); a lane without a pair reads record 0, its verdict is masked by `selected`
+      const uint4 Q = rec32(A.q_rec, q)[0];  // 32-B records: one line each
+      const uint4 QM = rec32(A.q_rec, q)[1];
+      const uint4 C = rec32(A.e_rec, e)[0];
+      const uint4 CM = rec32(A.e_rec, e)[1];
+      const uint32_t crow = CM.y;
+      lq = QM.x & 0xFF; d = (QM.x >> 16) & 0xFF; lc = CM.x & 0xFF;
+      const int diff = lq > lc ? lq - lc : lc - lq;
+      selected = pre || (!skip && diff <= d);
+      const bool filt = selected && !pre && f.enable && d <= 3 && lq <= 32 && lc <= 32;
+      wide = filt && (lq > 16 || lc > 16);
+      if (WIDE && __any(wide)) {  // wave-uniform, rare: some pair of the wave has a string of 17..32 symbols
+        uint32_t q8[8] = {Q.x, Q.y, Q.z, Q.w, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
+        uint32_t c10[10] = {0xFFFFFFFFu, C.x, C.y, C.z, C.w, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (wide && lq > 16) { const uint4 Q1 = A.q_rows[(size_t)q * a.qw + 1]; q8[4] = Q1.x; q8[5] = Q1.y; q8[6] = Q1.z; q8[7] = Q1.w; }
+        if (wide && lc > 16) { const uint4 C1 = A.rows[crow + 1]; c10[5] = C1.x; c10[6] = C1.y; c10[7] = C1.z; c10[8] = C1.w; }
+        if (band_bound_rejects<8>(q8, c10, filt, d, lq, lc)) selected = false;
+      } else if (__any(filt && !wide)) {
+        // as many 4-symbol words as the longest string of the WAVE needs (its 64 slots come from one scan chunk, i.e. one tile
+        // and one query length)
+        const bool f4 = filt && !wide;
+        const int ml = lq > lc ? lq : lc;
+        // B7 (alphabets of <= 124 classes): symbols < 0x7E, the paddings 0xFE / 0xFF masked down to 0x7E / 0x7F
+        constexpr uint32_t M = B7 ? 0x7F7F7F7Fu : 0xFFFFFFFFu;
+        if (__any(f4 && ml > 12)) {
+          const uint32_t q4[4] = {Q.x & M, Q.y & M, Q.z & M, Q.w & M}, c6[6] = {M, C.x & M, C.y & M, C.z & M, C.w & M, M};
+          if (band_bound_rejects<4, B7>(q4, c6, f4, d, lq, lc)) selected = false;
+        } else if (__any(f4 && ml > 8)) {
+          const uint32_t q3[3] = {Q.x & M, Q.y & M, Q.z & M}, c5[5] = {M, C.x & M, C.y & M, C.z & M, M};
+          if (band_bound_rejects<3, B7>(q3, c5, f4, d, lq, lc)) selected = false;
+        } else {
+          const uint32_t q2[2] = {Q.x & M, Q.y & M}, c4[4] = {M, C.x & M, C.y & M, M};
+          if (band_bound_rejects<2, B7>(q2, c4, f4, d, lq, lc)) selected = false;
+        }
       }
-    }
+      inl = selected && D > 0 && (pre || (lq <= 16 && lc <= 16 && d <= D));   // (pre: d <= the batch's largest d = D)
+      if (inl) { S[0] = Q.x; S[1] = Q.y; S[2] = Q.z; S[3] = Q.w; T[0] = C.x; T[1] = C.y; T[2] = C.z; T[3] = C.w; }
+    } else if (D > 0 && __any(pre)) {
+      inl = pre;
+      if (pre && !(ANX_DBG(a.dbg) & 8)) {
+        const uint4 Q = rec32(A.q_rec, rp.x)[0], C = rec32(A.e_rec, rp.y & 0x3FFFFFFu)[0];
+        S[0] = Q.x; S[1] = Q.y; S[2] = Q.z; S[3] = Q.w; T[0] = C.x; T[1] = C.y; T[2] = C.z; T[3] = C.w;
+      }
+      const uint32_t xs[4] = {(S[0] ^ 0xFEFEFEFEu), (S[1] ^ 0xFEFEFEFEu), (S[2] ^ 0xFEFEFEFEu), (S[3] ^ 0xFEFEFEFEu)};
+      const uint32_t xt[4] = {~T[0], ~T[1], ~T[2], ~T[3]};
+      lq = row_length16<false>(xs);   // (lanes without a pair: 0)
+      lc = row_length16<false>(xt);
     }
     const bool tow = !WIDE && wide;  // prefiltered later by k_filter_wide (which also counts it as selected if it passes)
     if (a.store_pairs && live && !selected && !tow)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
       A.p_meta[p] = (invalid || stop_skipped) ? META_SKIPPED : (PAIR_NONE | (1u << 7));
-    const bool inl = selected && D > 0 && (pre || (lq <= 16 && lc <= 16 && d <= D));   // (pre: d <= the batch's largest d = D)
     const bool to8 = selected && !inl && !tow && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
     const bool tog = selected && !inl && !tow && !to8;
-    const unsigned long long mi = __ballot(inl);
-    if (mi) {  // wave-uniform: queue the inline pairs
-      const int first = __ffsll((long long)mi) - 1;
-      uint32_t qb = 0;
-      if ((int)lane == first) qb = atomicAdd(&s_n, (uint32_t)__popcll(mi));
-      qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
-      if (inl) s_q[qb + (uint32_t)__popcll(mi & ((1ull << lane) - 1ull))] = (uint16_t)(r * 256 + threadIdx.x);
-    }
     slot_append(list8, region, to8, p);
     slot_append(listg, region, tog, p);
     if (!WIDE) slot_append(listw, region, tow, p);
@@ -672,50 +767,38 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       const unsigned long long ms = __ballot(stop_skipped);
       if (lane == 0 && ms) atomicAdd(&f.counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
     }
+    if (D > 0) {
+      if (ANX_DBG(a.dbg) & 4) {   // timing: the rows are consumed, no DL
+        asm volatile("" :: "v"(S[0]), "v"(S[1]), "v"(S[2]), "v"(S[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(lq), "v"(lc));
+      } else if (__any(inl)) {  // wave-uniform
+        DiagMasks<DD, B7> dm;
+        dm.build(S, T);
+        const uint32_t res = dl_diag<DD, B7>(dm, lq, lc);
+        const int diff = lq > lc ? lq - lc : lc - lq;
+        // src/distance.rs:109-130, 173-178 (short round: d = D here, the query's own d is tested when the queue is drained)
+        const bool surv = inl && diff <= d && res <= (uint32_t)d && !(ANX_DBG(a.dbg) & 2);
+        if (a.store_pairs && inl && !surv) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+        const unsigned long long ms = __ballot(surv);
+        if (ms) {  // wave-uniform
+          const int first = __ffsll((long long)ms) - 1;
+          uint32_t qb = 0;
+          if ((int)lane == first) qb = atomicAdd(&s_m, (uint32_t)__popcll(ms));
+          qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
+          if (surv) {
+            const uint32_t pos = qb + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+            s_sv[pos] = make_uint2(rp.x, (rp.y & 0x3FFFFFFu) | (res << 26));
+            s_svoff[pos] = (uint16_t)(r * 256 + threadIdx.x);
+          }
+        }
+      }
+      __syncthreads();
+      if (s_m > FS_SURV - 256u) drain();  // block-uniform: another round could overflow the queue
+    }
   }
   if (lane == 0 && nselected) atomicAdd(&f.stat_ctr[region * RC_STRIDE + 1], nselected);
-  __syncthreads();
   if (D > 0) {
-    // Phase 2a: DL of the queued pairs, 256 per round.  Survivors (ld <= d, ~30 % of the queue) are queued again, in
-    // place: entries [0, s_m) of s_q = slot offset | ld << 12 (s_m never overtakes the read position; a barrier
-    // separates a round's reads from its writes).  Phase 2b: LCS / prefix / suffix / score of the survivors in dense
-    // rounds -- the tail costs as much as the DL itself and would otherwise run with a third of its lanes.
-    constexpr int DD = D > 0 ? D : 1;
-    const uint32_t n = s_n;
-    __shared__ uint32_t s_m;
-    if (threadIdx.x == 0) s_m = 0;
-    for (uint32_t r0 = 0; r0 < n; r0 += 256) {  // block-uniform trip count
-      const uint32_t i = r0 + threadIdx.x;
-      const bool active = i < n;
-      const uint32_t off = active ? s_q[i] : 0u;
-      __syncthreads();
-      const uint32_t p = (region << f.region_shift) + base + off;
-      PairRegs<4> r;
-      load_pair<4>(p, active, A, a, r);
-      const uint32_t ld = ANX_DL_BAND ? dl_of_pair<DD, 4>(r, active) : dl_of_pair16<DD, B7>(r, active);
-      if (a.store_pairs && active && ld == PAIR_NONE) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
-      const bool surv = ld != PAIR_NONE;
-      const unsigned long long ms = __ballot(surv);
-      if (ms) {  // wave-uniform
-        const int first = __ffsll((long long)ms) - 1;
-        uint32_t qb = 0;
-        if ((int)lane == first) qb = atomicAdd(&s_m, (uint32_t)__popcll(ms));
-        qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
-        if (surv) s_q[qb + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))] = (uint16_t)(off | (ld << 12));
-      }
-    }
     __syncthreads();
-    const uint32_t m = s_m;
-    for (uint32_t r0 = 0; r0 < m; r0 += 256) {
-      const uint32_t i = r0 + threadIdx.x;
-      const bool active = i < m;
-      const uint32_t ent = active ? s_q[i] : 0u;
-      const uint32_t p = (region << f.region_shift) + base + (ent & 0xFFFu);
-      PairRegs<4> r;
-      load_pair<4>(p, active, A, a, r);
-      if (ANX_DL_BAND) tail_of_pair<4>(p, active, ent >> 12, r, A, a, so, region, s_str);
-      else tail_of_pair16<DD, B7>(p, active, ent >> 12, r, A, a, so, region);
-    }
+    drain();
   }
 }
 
