@@ -602,15 +602,16 @@ __device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& 
 //   |lq - lc| <= d (src/distance.rs:109-130), StopAtExactMatch drop (src/lib.rs:1164-1173), the SWAR band-match bound; selected pairs
 //   of <= 16 symbols with d <= D join the inline DL, longer ones go to the slot lists of the 8-word / general kernels.
 //   The DL runs on the slots as they lie (dl_diag: ~185 instructions a wave whatever the lengths; 3/4 of a fused tile's slots hold a
-//   pair).  Its survivors (~29 %) are queued in LDS -- (query, entry | ld << 26) -- and the queue is drained in dense rounds of 256
-//   whenever another round could overflow it: both records of the pair, the query's d, LCS / prefix / suffix from the diagonal masks,
-//   the f64 score with the x / L quotients from an LDS copy of the host's table, survivor record.
+//   pair).  Its survivors (~29 %) are queued in LDS -- (query, entry | ld << 26), a queue per WAVE -- and a wave drains its queue in dense
+//   rounds of 64 whenever another round could overflow it: both records of the pair, the query's d, LCS / prefix / suffix from the
+//   diagonal masks, the f64 score with the x / L quotients from an LDS copy of the host's table, survivor record.  No barrier after
+//   the table is loaded: the waves of a block drift apart, one's gathers under another's DL.
 //   Round 6: until then every selected pair was queued first (a u16 slot offset), gathered through raw[] + two 32-byte records for the
 //   DL in dense rounds and gathered AGAIN the same way for the tail: 5 + 5 vector loads with 64 different lines each per pair-wave,
 //   which is what the kernel's time was once the DL itself had become cheap (the texture path takes about a cycle per line).
 //   D = 0: no inline DL (d > 3), everything selected goes to the general kernel's list.
 constexpr uint32_t FS_BLK = 4096;
-constexpr uint32_t FS_SURV = 1024;   // entries of the LDS survivor queue
+constexpr uint32_t FS_SURV = 256;    // entries of a wave's LDS survivor queue
 struct FilterArgs {
   uint32_t region_shift;
   const uint32_t* rctr;     // region fills of the pair list
@@ -647,27 +648,29 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   const SurvOut& so = cold->so;
   const SlotList &list8 = cold->list8, &listg = cold->listg, &listw = cold->listw;
   constexpr int DD = D > 0 ? D : 1;
-  __shared__ uint2 s_sv[D > 0 ? FS_SURV : 1];         // survivors of the inline DL: (query, entry | ld << 26)
-  __shared__ uint16_t s_svoff[D > 0 ? FS_SURV : 1];   // their slots as offsets from the block's first one (the per-slot debug outputs)
-  __shared__ double s_quot[D > 0 ? 17 * 17 : 1];      // a.quot for x, L <= 16
-  __shared__ uint32_t s_m;
+  __shared__ uint2 s_sv_all[D > 0 ? 4 * FS_SURV : 1];         // survivors of the inline DL: (query, entry | ld << 26)
+  __shared__ uint16_t s_svoff_all[D > 0 ? 4 * FS_SURV : 1];   // their slots as offsets from the block's first one (the per-slot debug outputs)
+  __shared__ double s_quot[D > 0 ? 17 * 17 : 1];              // a.quot for x, L <= 16
+  uint2* const s_sv = s_sv_all + (D > 0 ? (threadIdx.x >> 6) * FS_SURV : 0u);
+  uint16_t* const s_svoff = s_svoff_all + (D > 0 ? (threadIdx.x >> 6) * FS_SURV : 0u);
+  uint32_t nsv = 0;   // entries in this wave's queue (wave-uniform)
   // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
   // counter word sustains only ~88 M atomics/s)
   const uint32_t region = blockIdx.x % SCAN_REGIONS, fill = f.rctr[region * RC_STRIDE + RC_RAW], base = (blockIdx.x / SCAN_REGIONS) * f.blk;
   if (base >= fill) return;  // block-uniform
   const uint32_t lim = min(fill, base + f.blk);  // this block's slots: [base, lim)
   const uint32_t p0 = (region << f.region_shift) + base;
-  if (threadIdx.x == 0) s_m = 0;
   const bool have_quot = D > 0 && a.quot != nullptr;
   if (have_quot)
     for (uint32_t i = threadIdx.x; i < 17u * 17u; i += 256u) s_quot[i] = a.quot[(i / 17u) * 33u + i % 17u];
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
-  // the queue's entries in dense rounds: records, the query's own d, tail
+  // the wave's queue in dense rounds: records, the query's own d, tail
   auto drain = [&]() {
-    const uint32_t m = s_m;   // (read by every thread between two barriers)
-    for (uint32_t r0 = 0; r0 < m; r0 += 256) {
-      const uint32_t i = r0 + threadIdx.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own LDS writes; LDS operations of a wave complete in order)
+    const uint32_t m = nsv;
+    for (uint32_t r0 = 0; r0 < m; r0 += 64) {
+      const uint32_t i = r0 + lane;
       const bool active = i < m;
       const uint2 ent = active ? s_sv[i] : make_uint2(0u, 0u);
       const uint32_t p = p0 + (active ? (uint32_t)s_svoff[i] : 0u), ld = (ent.y >> 26) & 3u;
@@ -678,9 +681,7 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       if (a.store_pairs && active && !has) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
       tail_of_pair16<DD, B7>(p, has, ld, r, A, a, so, region, have_quot ? s_quot : nullptr);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) s_m = 0;
-    __syncthreads();
+    nsv = 0;
   };
   uint32_t nselected = 0;  // wave-uniform
   // Straight-line loads: a lane without a pair (beyond the region's fill, unused chunk tail) reads the block's first slot
@@ -780,26 +781,18 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
         if (a.store_pairs && inl && !surv) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
         const unsigned long long ms = __ballot(surv);
         if (ms) {  // wave-uniform
-          const int first = __ffsll((long long)ms) - 1;
-          uint32_t qb = 0;
-          if ((int)lane == first) qb = atomicAdd(&s_m, (uint32_t)__popcll(ms));
-          qb = (uint32_t)__builtin_amdgcn_readlane((int)qb, first);
           if (surv) {
-            const uint32_t pos = qb + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+            const uint32_t pos = nsv + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
             s_sv[pos] = make_uint2(rp.x, (rp.y & 0x3FFFFFFu) | (res << 26));
             s_svoff[pos] = (uint16_t)(r * 256 + threadIdx.x);
           }
+          nsv += (uint32_t)__popcll(ms);
         }
       }
-      __syncthreads();
-      if (s_m > FS_SURV - 256u) drain();  // block-uniform: another round could overflow the queue
+      if (nsv > FS_SURV - 64u || base + (r + 1) * 256 >= lim) drain();  // wave-uniform: another round could overflow the queue / the last round
     }
   }
   if (lane == 0 && nselected) atomicAdd(&f.stat_ctr[region * RC_STRIDE + 1], nselected);
-  if (D > 0) {
-    __syncthreads();
-    drain();
-  }
 }
 
 constexpr uint32_t LIST_P = 64;  // blocks per region of the slot-list kernels (the kernels stride by gridDim.x / SCAN_REGIONS: the small path launches fewer)
