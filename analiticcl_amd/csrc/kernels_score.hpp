@@ -561,10 +561,11 @@ __device__ inline void tail_of_pair(uint32_t p, bool has, uint32_t ld, const Pai
 
 // tail_of_pair for pairs of <= 16 symbols whose |lq - lc| <= D: the measures from the diagonal masks, no LDS rows
 template <int D, bool B7>
-__device__ __forceinline__ void tail_of_pair16(uint32_t p, bool has, uint32_t ld, const PairRegs<4>& r, const PairArgs& A, const ScoreArgs& a, const SurvOut& so,
-                                      uint32_t surv_region, const double* quot17) {
+// (returns keep: the pair goes to the survivor list with `score`; the caller appends it)
+__device__ __forceinline__ bool tail_of_pair16(uint32_t p, bool has, uint32_t ld, const PairRegs<4>& r, const PairArgs& A, const ScoreArgs& a,
+                                      const double* quot17, double& score) {
   uint32_t lcs = 0, pre = 0, suf = 0, samecase = 1;
-  double score = __builtin_nan("");
+  score = __builtin_nan("");
   bool keep = false;
   if (__any(has) && !(ANX_DBG(a.dbg) & 2)) {   // (the measures' loops are wave-wide: lanes without a pair hold paddings, which match nothing)
     DiagMasks<D, B7> dm;
@@ -574,12 +575,11 @@ __device__ __forceinline__ void tail_of_pair16(uint32_t p, bool has, uint32_t ld
     if (has) score = score_finish(r.lq, ld, lcs, pre, suf, r.qm, r.em, r.q, r.e, a, r.freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, samecase, keep, quot17, &nrows);
     survivor_counts(has, r.q, r.freq, nrows, a, A.qmaxfreq, A.qsurv);
   }
-  if (!(ANX_DBG(a.dbg) & 32)) surv_append(so, surv_region, keep, r.q, r.e, score);
-  else asm volatile("" :: "v"(score), "v"(keep));
   if (has && a.store_pairs) {
     A.p_score[p] = score;
     A.p_meta[p] = ld | (samecase << 7) | (lcs << 8) | (pre << 16) | (suf << 24);
   }
+  return keep;
 }
 
 // Scores the pair in slot p with the register-resident DL of NW words (all lanes of the wave call this; lanes with
@@ -648,10 +648,10 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   const SurvOut& so = cold->so;
   const SlotList &list8 = cold->list8, &listg = cold->listg, &listw = cold->listw;
   constexpr int DD = D > 0 ? D : 1;
-  __shared__ uint2 s_sv_all[D > 0 ? 4 * FS_SURV : 1];         // survivors of the inline DL: (query, entry | ld << 26)
+  __shared__ uint4 s_sv_all[D > 0 ? 4 * FS_SURV : 1];         // survivors of the inline DL: (query, entry | ld << 26, -, -), after their tail: (query, entry, f64 score) = SurvRec
   __shared__ uint16_t s_svoff_all[D > 0 ? 4 * FS_SURV : 1];   // their slots as offsets from the block's first one (the per-slot debug outputs)
   __shared__ double s_quot[D > 0 ? 17 * 17 : 1];              // a.quot for x, L <= 16
-  uint2* const s_sv = s_sv_all + (D > 0 ? (threadIdx.x >> 6) * FS_SURV : 0u);
+  uint4* const s_sv = s_sv_all + (D > 0 ? (threadIdx.x >> 6) * FS_SURV : 0u);
   uint16_t* const s_svoff = s_svoff_all + (D > 0 ? (threadIdx.x >> 6) * FS_SURV : 0u);
   uint32_t nsv = 0;   // entries in this wave's queue (wave-uniform)
   // 1-D grid, region fastest: blocks that run at the same time append to different regions' counters (a single
@@ -669,19 +669,38 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
   auto drain = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own LDS writes; LDS operations of a wave complete in order)
     const uint32_t m = nsv;
+    uint32_t nk = 0;   // entries that go to the survivor list: written back to the head of the queue (never beyond the entry just read)
     for (uint32_t r0 = 0; r0 < m; r0 += 64) {
       const uint32_t i = r0 + lane;
       const bool active = i < m;
-      const uint2 ent = active ? s_sv[i] : make_uint2(0u, 0u);
+      const uint2 ent = active ? *reinterpret_cast<const uint2*>(&s_sv[i]) : make_uint2(0u, 0u);
       const uint32_t p = p0 + (active ? (uint32_t)s_svoff[i] : 0u), ld = (ent.y >> 26) & 3u;
       PairRegs<4> r;
       load_pair_qe<4>(ent.x, ent.y & 0x3FFFFFFu, active && !(ANX_DBG(a.dbg) & 64), A, a, r);
       if (ANX_DBG(a.dbg) & 64) { r.lq = 8; r.lc = 8; r.d = 2; r.q = ent.x; r.e = ent.y & 0x3FFFFFFu; }
       const bool has = active && ld <= (uint32_t)r.d;   // (|lq - lc| <= ld)
       if (a.store_pairs && active && !has) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
-      tail_of_pair16<DD, B7>(p, has, ld, r, A, a, so, region, have_quot ? s_quot : nullptr);
+      double score;
+      const bool keep = tail_of_pair16<DD, B7>(p, has, ld, r, A, a, have_quot ? s_quot : nullptr, score);
+      const unsigned long long km = __ballot(keep);
+      if (keep) {
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(score);
+        s_sv[nk + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = make_uint4(r.q, r.e, (uint32_t)sb, (uint32_t)(sb >> 32));
+      }
+      nk += (uint32_t)__popcll(km);
     }
     nsv = 0;
+    // one reservation in the region's survivor list for the whole queue (a returning atomic: one wait per drain, not per round),
+    // and the records leave as consecutive 16-byte pieces
+    if (nk && !(ANX_DBG(a.dbg) & 32)) {  // wave-uniform
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      uint32_t sbase = 0;
+      if (lane == 0) sbase = atomicAdd(&so.ctr[region * RC_STRIDE], nk);
+      sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sbase);
+      uint4* const out = reinterpret_cast<uint4*>(so.list) + (size_t)region * so.region_cap;
+      for (uint32_t i = lane; i < nk; i += 64)
+        if (sbase + i < so.region_cap) out[sbase + i] = s_sv[i];
+    }
   };
   uint32_t nselected = 0;  // wave-uniform
   // Straight-line loads: a lane without a pair (beyond the region's fill, unused chunk tail) reads the block's first slot
@@ -783,7 +802,7 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
         if (ms) {  // wave-uniform
           if (surv) {
             const uint32_t pos = nsv + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-            s_sv[pos] = make_uint2(rp.x, (rp.y & 0x3FFFFFFu) | (res << 26));
+            *reinterpret_cast<uint2*>(&s_sv[pos]) = make_uint2(rp.x, (rp.y & 0x3FFFFFFu) | (res << 26));
             s_svoff[pos] = (uint16_t)(r * 256 + threadIdx.x);
           }
           nsv += (uint32_t)__popcll(ms);
