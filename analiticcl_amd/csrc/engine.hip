@@ -1422,10 +1422,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
       HIP_TRY(hipMemcpyAsync(b->d_cold, cold, sizeof(FsCold), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipEventRecord(b->ev_fs0, st));  // ev_fs0 .. ev_fs1 = k_filter_score alone (anx_batch_stats.ms_filter_score_kernel)
-    // batches without long queries defer the 8-word prefilter of their few wide pairs (a 17..19-symbol candidate) to
-    // k_filter_wide: without that state the fused kernel fits 8 waves per SIMD
-    const int enable_split = switches().fs_split;
-    const bool split_wide = !have_long_q && enable_split;
+    // the 8-word prefilter of the wide pairs (a string of 17..32 symbols) runs in k_filter_wide: its state inline costs the fused
+    // kernel 105 instead of 70 VGPRs.  Round 6: for batches with long queries as well (BASELINE configs[2]: 9.68 -> 9.52 ms per pass,
+    // configs[3]'s share: 6.73 -> 6.42 ms per 1 M queries)
+    const bool split_wide = switches().fs_split != 0;
     // the one-add zero test of the prefilter needs every symbol code (classes, unknown = A + 1) below the masked paddings 0x7E / 0x7F
     const int enable_b7 = switches().fs_b7;
     const bool b7 = enable_b7 && m.alphabet.size() + 1 < 0x7E;
