@@ -255,7 +255,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
     }
   }
   const dim3 fgrid(((fs_cap + SMALL_FS_BLK - 1) / SMALL_FS_BLK) * SCAN_REGIONS);
-  const bool split_wide = !have_long_q && switches().fs_split;
+  const bool split_wide = switches().fs_split != 0;
   const bool b7 = switches().fs_b7 && m.alphabet.size() + 1 < 0x7E;
 #define ANX_FS_LAUNCH(DD, WW, BB) hipLaunchKernelGGL((k_filter_score<DD, WW, BB>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(c->d_cold))
 #define ANX_FS_PICK(WW, BB)                        \
