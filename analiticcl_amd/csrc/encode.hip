@@ -389,7 +389,22 @@ __device__ inline void enc_gather_body(const GatherArgs& g, uint32_t s) {   // s
     }
     const uint4 row = make_uint4(v[0], v[1], v[2], v[3]);
     g.q_rows[(size_t)s * g.qw + w] = row;
-    if (w == 0) { g.q_rec[2 * (size_t)s] = row; g.q_rec[2 * (size_t)s + 1] = make_uint4(meta, 0u, 0u, 0u); }
+    if (w == 0) {
+      uint32_t pw[3] = {0u, 0u, 0u};
+      {  // symbol planes of the first 16 symbols (kernels_common.hpp symbol_planes16; bytes from len on are padding)
+        uint32_t p[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+          const uint32_t c = ((v[i >> 2] >> (8u * (i & 3u))) & 0xFFu) + 1u;
+          const uint32_t on = i < len ? 1u : 0u;
+#pragma unroll
+          for (uint32_t b = 0; b < 6u; ++b) p[b] |= (((c >> b) & on)) << i;
+        }
+        pw[0] = p[0] | p[1] << 16; pw[1] = p[2] | p[3] << 16; pw[2] = p[4] | p[5] << 16;
+      }
+      g.q_rec[2 * (size_t)s] = row;
+      g.q_rec[2 * (size_t)s + 1] = make_uint4(meta, pw[0], pw[1], pw[2]);
+    }
   }
   uint32_t xc = 0xFFFFFFFFu;
   if (g.want_exact) {  // the exact anagram class: the run of this signature in its charcount range, then the count vectors

@@ -466,6 +466,12 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, c
     memcpy(&erec[2 * e], &img.rows[(size_t)img.ent_rowoff[e] * 16], 16);
     erec[2 * e + 1] = make_uint4(img.ent_meta[e], img.ent_rowoff[e], img.ent_freq[e], 0u);
   }
+  std::vector<uint4> eplanes(img.ent_vocab.size());   // {meta, symbol planes of the first 16 symbols}
+  for (size_t e = 0; e < img.ent_vocab.size(); ++e) {
+    uint32_t pw[3];
+    symbol_planes16(&img.rows[(size_t)img.ent_rowoff[e] * 16], img.ent_meta[e] & 0xFFu, pw);
+    eplanes[e] = make_uint4(img.ent_meta[e], pw[0], pw[1], pw[2]);
+  }
   // scan records of the bit-plane kernel: one per ENTRY (class-major, the order of the entry ids) carrying the planes of its
   // class, so that a scan hit is a (query, entry) pair -- classes with several entries (8 % of eng.aspell) are tested once per
   // entry, and the hit expansion has no entries-per-class loop (it ran as long as the largest class among 64 hits)
@@ -557,6 +563,7 @@ DeviceLexicon* lexicon_upload(const LexiconImage& img, const EncodeTables& et, c
       (rc = upload(&d->ent_order, img.ent_order.data(), img.ent_order.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_rec, rec.data(), rec.size(), err, &d->bytes)) ||
       (rc = upload(&d->e_rec, erec.data(), erec.size(), err, &d->bytes)) ||
+      (rc = upload(&d->e_planes, eplanes.data(), eplanes.size(), err, &d->bytes)) ||
       (rc = upload(&d->ent_var_off, img.ent_var_off.data(), img.ent_var_off.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_target, img.var_target.data(), img.var_target.size(), err, &d->bytes)) ||
       (rc = upload(&d->var_target_freq, img.var_target_freq.data(), img.var_target_freq.size(), err, &d->bytes)) ||
@@ -618,7 +625,7 @@ void lexicon_free(DeviceLexicon* d) {
   DeviceGuard guard;
   (void)hipSetDevice(d->device);
   for (void* p : {(void*)d->cls_planes, (void*)d->cls_bits, (void*)d->cls_len, (void*)d->cls_off, (void*)d->scan_rec, (void*)d->scan_rec34, (void*)d->sig_e, (void*)d->sighash, (void*)d->sighash_e, (void*)d->ball, (void*)d->ball_tab, (void*)d->sig, (void*)d->sig_cbeg, (void*)d->ent_vocab,
-                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->ent_var_off,
+                  (void*)d->ent_freq, (void*)d->ent_meta, (void*)d->ent_rowoff, (void*)d->ent_order, (void*)d->ent_rec, (void*)d->e_rec, (void*)d->e_planes, (void*)d->ent_var_off,
                   (void*)d->var_target, (void*)d->var_target_freq, (void*)d->var_score, (void*)d->rows, (void*)d->alpha.fast, (void*)d->alpha.coff,
                   (void*)d->alpha.cand, (void*)d->alpha.bytes, (void*)d->alpha.sym_group, (void*)d->alpha.lower, (void*)d->alpha.siglen_begin,
                   (void*)d->adj_hash, (void*)d->adj_hdr, (void*)d->adj_planes, (void*)d->adj_ids, (void*)d->quot})
@@ -828,7 +835,11 @@ static int encode_host(const HostModel& m, const DeviceLexicon* dl, Batch* b, co
       memset(row, 0xFE, (size_t)b->qw * 16);  // padding that equals nothing (kernels_score.hpp)
       memcpy(row, &arena[e.thread][e.off], e.meta & 0xFF);
       memcpy(&h_qrec[2 * s], row, 16);  // 32-B query record: first 16 symbols + meta
-      h_qrec[2 * s + 1] = make_uint4(e.meta, 0u, 0u, 0u);
+      {
+        uint32_t pw[3];
+        symbol_planes16(reinterpret_cast<const uint8_t*>(row), e.meta & 0xFFu, pw);
+        h_qrec[2 * s + 1] = make_uint4(e.meta, pw[0], pw[1], pw[2]);
+      }
       h_meta[s] = e.meta;
       h_orig[s] = (uint32_t)i;
       h_kind[s] = e.kind;
@@ -1410,7 +1421,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     const SlotList l8{b->list8, b->lctr, (uint32_t)b->list_cap}, lg{b->listg, b->lctr + SCAN_REGIONS * RC_STRIDE, (uint32_t)b->list_cap},
                    lw{b->listw, b->lctr + 2 * SCAN_REGIONS * RC_STRIDE, (uint32_t)b->list_cap};
     const PairArgs pa{b->raw, b->q_meta, b->q_rows, b->q_rec, dl->e_rec, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, dl->ent_var_off,
-                      b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand};
+                      b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand, dl->e_planes};
     FilterArgs fa;
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
     fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap; fa.blk = FS_BLK;
@@ -1429,6 +1440,8 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     // the one-add zero test of the prefilter needs every symbol code (classes, unknown = A + 1) below the masked paddings 0x7E / 0x7F
     const int enable_b7 = switches().fs_b7;
     const bool b7 = enable_b7 && m.alphabet.size() + 1 < 0x7E;
+    // symbol planes instead of byte rows for the inline DL and its tail (codes + 1 in six bits)
+    const bool planes = b7 && switches().fs_planes && (int)m.alphabet.size() <= kSymbolPlanesMaxA;
 #define ANX_FS_LAUNCH(DD, WW, BB) hipLaunchKernelGGL((k_filter_score<DD, WW, BB>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(b->d_cold))
 #define ANX_FS_PICK(WW, BB)                      \
   do {                                           \
@@ -1437,8 +1450,8 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     else if (fastD == 3) ANX_FS_LAUNCH(3, WW, BB); \
     else ANX_FS_LAUNCH(0, WW, BB);               \
   } while (0)
-    if (split_wide) { if (b7) ANX_FS_PICK(false, true); else ANX_FS_PICK(false, false); }
-    else { if (b7) ANX_FS_PICK(true, true); else ANX_FS_PICK(true, false); }
+    if (split_wide) { if (planes) ANX_FS_PICK(false, 2); else if (b7) ANX_FS_PICK(false, 1); else ANX_FS_PICK(false, 0); }
+    else { if (b7) ANX_FS_PICK(true, 1); else ANX_FS_PICK(true, 0); }   // (ANX_FS_SPLIT=0, A/B: byte rows)
 #undef ANX_FS_PICK
 #undef ANX_FS_LAUNCH
     HIP_TRY(hipEventRecord(b->ev_fs1, st));

@@ -456,6 +456,7 @@ const SwitchDef kSwitches[] = {
     {"ANX_PREFILTER", [](Switches& s, const char* v) { s.prefilter = flag01(v, 1); }},
     {"ANX_SCORE_FAST", [](Switches& s, const char* v) { s.score_fast = flag01(v, 1); }},
     {"ANX_FS_SPLIT", [](Switches& s, const char* v) { s.fs_split = flag01(v, 1); }},
+    {"ANX_FS_PLANES", [](Switches& s, const char* v) { s.fs_planes = flag01(v, 1); }},
     {"ANX_FS_B7", [](Switches& s, const char* v) { s.fs_b7 = flag01(v, 1); }},
     {"ANX_SCAN_FUSE", [](Switches& s, const char* v) { s.fuse_prefilter = flag01(v, 1); }},
     {"ANX_CAP_DIV", [](Switches& s, const char* v) { const long x = v ? atol(v) : 0; s.cap_div = x > 1 ? x : 1; }},

@@ -77,6 +77,7 @@ struct Switches {
   int sig_groups = 0;        // ANX_SIG_GROUPS=1..8: signature groups of a model built afterwards (0 = default)
   int prefilter = 1;         // ANX_PREFILTER=0: no SWAR bound, every length-compatible pair goes through the DL
   int score_fast = 1;        // ANX_SCORE_FAST=0: general k_score_pairs for every pair
+  int fs_planes = 1;         // ANX_FS_PLANES=0: byte rows instead of symbol planes in k_filter_score (A/B; alphabets beyond 61 classes always take the rows)
   int fs_split = 1;          // ANX_FS_SPLIT=0: the 8-word prefilter of the wide pairs inline in k_filter_score (A/B; until round 6 what batches with long queries ran)
   int fs_b7 = 1;             // ANX_FS_B7=0: general zero test in the prefilter
   int fuse_prefilter = 1;    // ANX_SCAN_FUSE=0: the scan's expansion does not apply the SWAR bound (k_filter_score's phase 1 does)

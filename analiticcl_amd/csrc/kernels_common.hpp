@@ -22,6 +22,21 @@ struct Tile {           // <= SCAN_TQ queries of one length and one signature (b
 constexpr uint32_t BALL_MAX = 4096;   // largest L1 ball of signature offsets enumerated (per k; larger k walk the window)
 constexpr uint32_t SIG_BYTE_MAX = 120;  // group sums above this take the walk (byte-wise SWAR add of an offset must not overflow)
 
+// Symbol PLANES of a string's first 16 symbols (round 6): plane b, bit i = bit b of (code of symbol i) + 1, zero from the string's end on --
+// six planes, two to a word, for alphabets whose codes + 1 fit six bits (classes + the unknown code A + 1: A <= 61; kSymbolPlanesMaxA).
+// The mismatch masks of kernels_score.hpp (bit i = s[i] != t[i + k]) are OR_b (S_b ^ T_b >> k): shifts and bit operations at the
+// full issue rate, where the byte rows need v_alignbyte + a zero-byte test + v_dot4 per word and diagonal.
+// Query: q_rec[q][1] = {meta, planes}.  Entry: e_planes[e] = {ent_meta, planes}.
+constexpr int kSymbolPlanesMaxA = 61;
+__host__ __device__ inline void symbol_planes16(const uint8_t* row, uint32_t len, uint32_t (&w)[3]) {
+  uint32_t p[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  for (uint32_t i = 0; i < 16u && i < len; ++i) {
+    const uint32_t v = (uint32_t)row[i] + 1u;
+    for (uint32_t b = 0; b < 6u; ++b) p[b] |= ((v >> b) & 1u) << i;
+  }
+  w[0] = p[0] | p[1] << 16; w[1] = p[2] | p[3] << 16; w[2] = p[4] | p[5] << 16;
+}
+
 constexpr int NBITPLANES = 4;            // thermometer planes stored per class / query
 constexpr uint32_t SCAN_TQ = 64;         // most queries a tile (= a wave) can hold, compared in passes of 32 (one hit-mask bit each)
 constexpr uint32_t SCAN_TQ_DEFAULT = 48; // (until round 6; now host_model.h default_scan_tq: 48 with 7 signature groups, 32 with 8) queries per tile the encoders cut groups into (ANX_SCAN_TQ overrides).  Measured on BASELINE configs[1], three interleaved
@@ -109,6 +124,7 @@ struct DeviceLexicon {
   uint32_t* ent_order = nullptr;
   EntRec* ent_rec = nullptr;           // {vocab, freq, order, meta} per entry
   uint4* e_rec = nullptr;              // [E][2] {first 16 symbols} {meta, row offset, freq, 0}: PairArgs::e_rec
+  uint4* e_planes = nullptr;           // [E] {meta, symbol planes of the first 16 symbols (symbol_planes16)}: PairArgs::e_planes
   uint32_t* ent_var_off = nullptr;     // CSR entry -> VariantOf references (variant lists, src/lib.rs:1677-1727)
   uint32_t* var_target = nullptr;      // vocab id of the reference item
   uint32_t* var_target_freq = nullptr;

@@ -333,6 +333,26 @@ struct DiagMasks {
     for (int w = 0; w < 4; ++w) { S[w] = S0[w] & PM; T[w] = T0[w] & PM; }
     fill<-D>();
   }
+  template <int K>
+  __device__ __forceinline__ uint32_t far() const { return diag_mismatch_mask<K, B7>(S, T, PM); }   // a diagonal beyond the band
+};
+// The same masks from the strings' symbol PLANES (kernels_common.hpp symbol_planes16: plane b, bit i = bit b of code + 1, zero from the
+// string's end on): M[k] = OR_b (S_b ^ T_b >> k) | (all positions from lq on).  A position of s inside the string against one outside t
+// (shifted-in zeros or t's own) differs in some plane, because code + 1 is never zero.  2 x 6 + 1 instructions a diagonal, all at the
+// full issue rate (v_lshrrev / v_bitop3): ~30 cycles where the byte rows take ~68 (4 v_alignbyte + 4 v_xad + 4 v_and + 4 v_dot4 + 3).
+template <int D>
+struct PlaneMasks : PlaneRows {   // (kernels_swar.hpp)
+  uint32_t M[2 * D + 1];   // [k + D]
+  template <int K>
+  __device__ __forceinline__ void fill() {
+    M[K + D] = this->template far<K>();
+    if constexpr (K < D) fill<K + 1>();
+  }
+  // qp = q_rec[q][1], cp = e_planes[e]; lq = 0 for a lane without a pair (nothing matches)
+  __device__ __forceinline__ void build(const uint4& qp, const uint4& cp, int lq) {
+    this->load(qp, cp, lq);
+    fill<-D>();
+  }
 };
 // ------------------------------------------------------------------------------------------------
 // The tail's string measures from the same masks (pairs of <= 16 symbols, |lq - lc| <= D):
@@ -353,16 +373,16 @@ __device__ __forceinline__ uint32_t runs_of_packed(uint32_t p) {  // longest run
   }
   return n;
 }
-template <int R, int D, bool B7>
-__device__ __forceinline__ void lcs_far_diagonals(const DiagMasks<D, B7>& dm, int lq, int lc, uint32_t& best) {
+template <int R, int D, class MT>
+__device__ __forceinline__ void lcs_far_diagonals(const MT& dm, int lq, int lc, uint32_t& best) {
   const int ov = max(min(lq, lc - R), min(lq - R, lc));
   if (!__any(ov > (int)best)) return;   // wave-uniform
-  const uint32_t zp = ~diag_mismatch_mask<R, B7>(dm.S, dm.T, DiagMasks<D, B7>::PM), zm = ~diag_mismatch_mask<-R, B7>(dm.S, dm.T, DiagMasks<D, B7>::PM);
+  const uint32_t zp = ~dm.template far<R>(), zm = ~dm.template far<-R>();
   best = max(best, runs_of_packed(zp | (zm << 16)));
-  if constexpr (R < 15) lcs_far_diagonals<R + 1, D, B7>(dm, lq, lc, best);
+  if constexpr (R < 15) lcs_far_diagonals<R + 1, D, MT>(dm, lq, lc, best);
 }
-template <int D, bool B7>
-__device__ __forceinline__ void measures16(const DiagMasks<D, B7>& dm, int lq, int lc, const ScoreArgs& a, uint32_t& lcs, uint32_t& pre, uint32_t& suf) {
+template <int D, class MT>
+__device__ __forceinline__ void measures16(const MT& dm, int lq, int lc, const ScoreArgs& a, uint32_t& lcs, uint32_t& pre, uint32_t& suf) {
   if (a.w_prefix > 0.0) pre = (uint32_t)__builtin_ctz(dm.M[D]);
   if (a.w_suffix > 0.0) {
     const int kf = lc - lq;
@@ -390,13 +410,13 @@ __device__ __forceinline__ void measures16(const DiagMasks<D, B7>& dm, int lq, i
         for (int k = 0; k <= D; ++k) p[k] &= p[k] >> 1;
       }
     }
-    lcs_far_diagonals<D + 1, D, B7>(dm, lq, lc, best);
+    lcs_far_diagonals<D + 1, D, MT>(dm, lq, lc, best);
     lcs = best;
   }
 }
 
-template <int D, bool B7>
-__device__ __forceinline__ uint32_t dl_diag(const DiagMasks<D, B7>& dm, int lq, int lc) {
+template <int D, class MT>
+__device__ __forceinline__ uint32_t dl_diag(const MT& dm, int lq, int lc) {
   constexpr int BW = 2 * D + 1;
   uint32_t N[BW];
 #pragma unroll
@@ -474,6 +494,7 @@ struct PairArgs {  // what every scoring kernel reads / writes
   uint32_t* qmaxfreq;
   uint32_t* qsurv;
   uint32_t* qexpand;
+  const uint4* e_planes;    // [E] {meta, symbol planes}; the queries' planes are q_rec[q][1].yzw
 };
 
 // Loads the pair of slot p into registers (NW words per string); returns false for !active.
@@ -522,7 +543,7 @@ template <int D, bool B7>
 __device__ __forceinline__ uint32_t dl_of_pair16(const PairRegs<4>& r, bool active) {
   DiagMasks<D, B7> dm;
   dm.build(r.S, r.T);
-  const uint32_t res = dl_diag<D, B7>(dm, r.lq, r.lc);
+  const uint32_t res = dl_diag<D>(dm, r.lq, r.lc);
   const int diff = r.lq > r.lc ? r.lq - r.lc : r.lc - r.lq;
   return (active && diff <= r.d && res <= (uint32_t)r.d) ? res : PAIR_NONE;  // src/distance.rs:109-130, 173-178
 }
@@ -560,20 +581,19 @@ __device__ inline void tail_of_pair(uint32_t p, bool has, uint32_t ld, const Pai
 }
 
 // tail_of_pair for pairs of <= 16 symbols whose |lq - lc| <= D: the measures from the diagonal masks, no LDS rows
-template <int D, bool B7>
-// (returns keep: the pair goes to the survivor list with `score`; the caller appends it)
-__device__ __forceinline__ bool tail_of_pair16(uint32_t p, bool has, uint32_t ld, const PairRegs<4>& r, const PairArgs& A, const ScoreArgs& a,
-                                      const double* quot17, double& score) {
+// (returns keep: the pair goes to the survivor list with `score`; the caller appends it.  Wave-wide: lanes without a pair (has = false)
+// hold masks in which nothing matches.  dm: the pair's band masks, DiagMasks or PlaneMasks)
+template <int D, class MT>
+__device__ __forceinline__ bool tail16(uint32_t p, bool has, uint32_t ld, const MT& dm, int lq, int lc, uint32_t qm, uint32_t em, uint32_t q, uint32_t e, uint32_t freq,
+                                       const PairArgs& A, const ScoreArgs& a, const double* quot17, double& score) {
   uint32_t lcs = 0, pre = 0, suf = 0, samecase = 1;
   score = __builtin_nan("");
   bool keep = false;
-  if (__any(has) && !(ANX_DBG(a.dbg) & 2)) {   // (the measures' loops are wave-wide: lanes without a pair hold paddings, which match nothing)
-    DiagMasks<D, B7> dm;
-    dm.build(r.S, r.T);
-    measures16<D, B7>(dm, has ? r.lq : 1, has ? r.lc : 1, a, lcs, pre, suf);
+  if (!(ANX_DBG(a.dbg) & 2)) {
+    measures16<D>(dm, has ? lq : 1, has ? lc : 1, a, lcs, pre, suf);
     uint32_t nrows = 0;
-    if (has) score = score_finish(r.lq, ld, lcs, pre, suf, r.qm, r.em, r.q, r.e, a, r.freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, samecase, keep, quot17, &nrows);
-    survivor_counts(has, r.q, r.freq, nrows, a, A.qmaxfreq, A.qsurv);
+    if (has) score = score_finish(lq, ld, lcs, pre, suf, qm, em, q, e, a, freq, A.ent_var_off, A.qmaxfreq, A.qsurv, A.qexpand, samecase, keep, quot17, &nrows);
+    survivor_counts(has, q, freq, nrows, a, A.qmaxfreq, A.qsurv);
   }
   if (has && a.store_pairs) {
     A.p_score[p] = score;
@@ -642,8 +662,11 @@ __device__ __forceinline__ int row_length16(const uint32_t (&x)[4]) {
   const uint32_t hi = __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(x[3]), 0x80402010u, __builtin_amdgcn_udot4(nonzero_byte_flags<B7>(x[2]), 0x08040201u, 0u, false), false);
   return __builtin_ctz(~((lo >> 7) | (hi << 1)));   // (bits 16.. of the sum are clear: at most 16)
 }
-template <int D, bool WIDE, bool B7>
+// MODE: 0 = byte rows, any alphabet; 1 = byte rows, B7 (symbol codes below 0x7E: the one-add zero-byte test); 2 = symbol planes (B7 and
+// A <= kSymbolPlanesMaxA): the short round gathers q_rec[q][1] + e_planes[e], the lengths and d come with them
+template <int D, bool WIDE, int MODE>
 __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, const FsCold* __restrict__ cold) {
+  constexpr bool B7 = MODE >= 1, PL = MODE == 2;
   const ScoreArgs& a = cold->a;
   const SurvOut& so = cold->so;
   const SlotList &list8 = cold->list8, &listg = cold->listg, &listw = cold->listw;
@@ -675,17 +698,37 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       const bool active = i < m;
       const uint2 ent = active ? *reinterpret_cast<const uint2*>(&s_sv[i]) : make_uint2(0u, 0u);
       const uint32_t p = p0 + (active ? (uint32_t)s_svoff[i] : 0u), ld = (ent.y >> 26) & 3u;
-      PairRegs<4> r;
-      load_pair_qe<4>(ent.x, ent.y & 0x3FFFFFFu, active && !(ANX_DBG(a.dbg) & 64), A, a, r);
-      if (ANX_DBG(a.dbg) & 64) { r.lq = 8; r.lc = 8; r.d = 2; r.q = ent.x; r.e = ent.y & 0x3FFFFFFu; }
-      const bool has = active && ld <= (uint32_t)r.d;   // (|lq - lc| <= ld)
-      if (a.store_pairs && active && !has) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+      const uint32_t q = ent.x, e = ent.y & 0x3FFFFFFu;
       double score;
-      const bool keep = tail_of_pair16<DD, B7>(p, has, ld, r, A, a, have_quot ? s_quot : nullptr, score);
+      bool keep;
+      if (PL) {
+        uint4 qp = make_uint4(0u, 0u, 0u, 0u), cp = qp;
+        uint32_t freq = 1u;
+        if (active) {
+          qp = rec32(A.q_rec, q)[1];
+          cp = A.e_planes[e];
+          if (a.have_freq) freq = A.ent_freq[e];
+        }
+        const int lq = qp.x & 0xFF, d = (qp.x >> 16) & 0xFF, lc = cp.x & 0xFF;
+        const bool has = active && ld <= (uint32_t)d;   // (|lq - lc| <= ld)
+        if (a.store_pairs && active && !has) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+        PlaneMasks<DD> dm;
+        dm.build(qp, cp, has ? lq : 0);
+        keep = tail16<DD>(p, has, ld, dm, lq, lc, qp.x, cp.x, q, e, freq, A, a, have_quot ? s_quot : nullptr, score);
+      } else {
+        PairRegs<4> r;
+        load_pair_qe<4>(q, e, active && !(ANX_DBG(a.dbg) & 64), A, a, r);
+        if (ANX_DBG(a.dbg) & 64) { r.lq = 8; r.lc = 8; r.d = 2; }
+        const bool has = active && ld <= (uint32_t)r.d;   // (|lq - lc| <= ld)
+        if (a.store_pairs && active && !has) A.p_meta[p] = PAIR_NONE | (1u << 7);  // ld = None, samecase = true
+        DiagMasks<DD, B7> dm;
+        dm.build(r.S, r.T);   // (a lane without a pair holds paddings: nothing matches)
+        keep = tail16<DD>(p, has, ld, dm, r.lq, r.lc, r.qm, r.em, q, e, r.freq, A, a, have_quot ? s_quot : nullptr, score);
+      }
       const unsigned long long km = __ballot(keep);
       if (keep) {
         const unsigned long long sb = (unsigned long long)__double_as_longlong(score);
-        s_sv[nk + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = make_uint4(r.q, r.e, (uint32_t)sb, (uint32_t)(sb >> 32));
+        s_sv[nk + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = make_uint4(q, e, (uint32_t)sb, (uint32_t)(sb >> 32));
       }
       nk += (uint32_t)__popcll(km);
     }
@@ -717,7 +760,8 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     const bool pre = !invalid && (rp.y & RAW_PREFILTERED);
     bool selected = pre, wide = false, inl = false;
     int lq = 0, lc = 0, d = D;
-    uint32_t S[4] = {0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu}, T[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t S[4] = {0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu}, T[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // MODE 0 / 1
+    uint4 qpl = make_uint4(0u, 0u, 0u, 0u), cpl = qpl;   // MODE 2: the pair's plane records
     bool stop_skipped = false;
     if (__any(!invalid && !pre)) {
       bool skip = invalid;
@@ -762,17 +806,23 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
         }
       }
       inl = selected && D > 0 && (pre || (lq <= 16 && lc <= 16 && d <= D));   // (pre: d <= the batch's largest d = D)
-      if (inl) { S[0] = Q.x; S[1] = Q.y; S[2] = Q.z; S[3] = Q.w; T[0] = C.x; T[1] = C.y; T[2] = C.z; T[3] = C.w; }
+      if (inl && !PL) { S[0] = Q.x; S[1] = Q.y; S[2] = Q.z; S[3] = Q.w; T[0] = C.x; T[1] = C.y; T[2] = C.z; T[3] = C.w; }
+      if (inl && PL) { qpl = QM; cpl = A.e_planes[e]; }
     } else if (D > 0 && __any(pre)) {
       inl = pre;
-      if (pre && !(ANX_DBG(a.dbg) & 8)) {
-        const uint4 Q = rec32(A.q_rec, rp.x)[0], C = rec32(A.e_rec, rp.y & 0x3FFFFFFu)[0];
-        S[0] = Q.x; S[1] = Q.y; S[2] = Q.z; S[3] = Q.w; T[0] = C.x; T[1] = C.y; T[2] = C.z; T[3] = C.w;
+      if (PL) {
+        if (pre && !(ANX_DBG(a.dbg) & 8)) { qpl = rec32(A.q_rec, rp.x)[1]; cpl = A.e_planes[rp.y & 0x3FFFFFFu]; }
+        lq = qpl.x & 0xFF; d = pre ? (int)((qpl.x >> 16) & 0xFF) : D; lc = cpl.x & 0xFF;
+      } else {
+        if (pre && !(ANX_DBG(a.dbg) & 8)) {
+          const uint4 Q = rec32(A.q_rec, rp.x)[0], C = rec32(A.e_rec, rp.y & 0x3FFFFFFu)[0];
+          S[0] = Q.x; S[1] = Q.y; S[2] = Q.z; S[3] = Q.w; T[0] = C.x; T[1] = C.y; T[2] = C.z; T[3] = C.w;
+        }
+        const uint32_t xs[4] = {(S[0] ^ 0xFEFEFEFEu), (S[1] ^ 0xFEFEFEFEu), (S[2] ^ 0xFEFEFEFEu), (S[3] ^ 0xFEFEFEFEu)};
+        const uint32_t xt[4] = {~T[0], ~T[1], ~T[2], ~T[3]};
+        lq = row_length16<false>(xs);   // (lanes without a pair: 0)
+        lc = row_length16<false>(xt);
       }
-      const uint32_t xs[4] = {(S[0] ^ 0xFEFEFEFEu), (S[1] ^ 0xFEFEFEFEu), (S[2] ^ 0xFEFEFEFEu), (S[3] ^ 0xFEFEFEFEu)};
-      const uint32_t xt[4] = {~T[0], ~T[1], ~T[2], ~T[3]};
-      lq = row_length16<false>(xs);   // (lanes without a pair: 0)
-      lc = row_length16<false>(xt);
     }
     const bool tow = !WIDE && wide;  // prefiltered later by k_filter_wide (which also counts it as selected if it passes)
     if (a.store_pairs && live && !selected && !tow)  // skipped (tail / StopAtExactMatch) or rejected: ld = None, samecase = true
@@ -789,11 +839,18 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     }
     if (D > 0) {
       if (ANX_DBG(a.dbg) & 4) {   // timing: the rows are consumed, no DL
-        asm volatile("" :: "v"(S[0]), "v"(S[1]), "v"(S[2]), "v"(S[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(lq), "v"(lc));
+        asm volatile("" :: "v"(S[0]), "v"(S[1]), "v"(S[2]), "v"(S[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(lq), "v"(lc), "v"(qpl.y), "v"(qpl.z), "v"(qpl.w), "v"(cpl.y), "v"(cpl.z), "v"(cpl.w));
       } else if (__any(inl)) {  // wave-uniform
-        DiagMasks<DD, B7> dm;
-        dm.build(S, T);
-        const uint32_t res = dl_diag<DD, B7>(dm, lq, lc);
+        uint32_t res;
+        if (PL) {
+          PlaneMasks<DD> dm;
+          dm.build(qpl, cpl, inl ? lq : 0);
+          res = dl_diag<DD>(dm, lq, lc);
+        } else {
+          DiagMasks<DD, B7> dm;
+          dm.build(S, T);
+          res = dl_diag<DD>(dm, lq, lc);
+        }
         const int diff = lq > lc ? lq - lc : lc - lq;
         // src/distance.rs:109-130, 173-178 (short round: d = D here, the query's own d is tested when the queue is drained)
         const bool surv = inl && diff <= d && res <= (uint32_t)d && !(ANX_DBG(a.dbg) & 2);

@@ -85,3 +85,29 @@ __device__ inline bool band_bound_rejects(const uint32_t (&q)[NW], const uint32_
 __device__ inline const uint4* rec32(const uint4* base, uint32_t i) {
   return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (i << 5));
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: mismatch masks from SYMBOL PLANES (kernels_common.hpp symbol_planes16; alphabets of <= 61 classes): M_k bit i = (s[i] != t[i + k])
+// = OR over the six planes of S_b ^ (T_b >> k); k_filter_score's DL and tail run on them (kernels_score.hpp PlaneMasks).
+// (Measured and dropped: the scan's band-match bound on the same masks -- positions of q without a partner = AND_k M_k, of c the masks
+// moved back by k, two popcounts -- with the candidate's planes and length as ONE 16-byte gather: identical verdicts, but k_scan_adj
+// 0.916 -> 0.95 ms: seven diagonals x 13 instructions + the unpacking are no fewer issue cycles than the byte-wise bound over the 2-4
+// words a tile's strings need.)
+// ------------------------------------------------------------------------------------------------
+struct PlaneRows {
+  uint32_t S[6], T[6];
+  uint32_t inv;            // bits lq .. 31: positions beyond the query match nothing
+  // qp = q_rec[q][1], cp = e_planes[e]: {meta, planes 0|1, 2|3, 4|5}; lq = 0 for a lane without a pair
+  __device__ __forceinline__ void load(const uint4& qp, const uint4& cp, int lq) {
+    S[0] = qp.y & 0xFFFFu; S[1] = qp.y >> 16; S[2] = qp.z & 0xFFFFu; S[3] = qp.z >> 16; S[4] = qp.w & 0xFFFFu; S[5] = qp.w >> 16;
+    T[0] = cp.y & 0xFFFFu; T[1] = cp.y >> 16; T[2] = cp.z & 0xFFFFu; T[3] = cp.z >> 16; T[4] = cp.w & 0xFFFFu; T[5] = cp.w >> 16;
+    inv = 0xFFFFFFFFu << lq;   // (lq <= 16)
+  }
+  template <int K>
+  __device__ __forceinline__ uint32_t far() const {   // mismatch mask of diagonal K, |K| <= 15
+    uint32_t acc = inv;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) acc |= S[b] ^ (K >= 0 ? T[b] >> (K >= 0 ? K : 0) : T[b] << (K < 0 ? -K : 0));
+    return acc;
+  }
+};

@@ -189,6 +189,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
     A.chunk = 64; A.chunk_fused = 32;  // (SCAN_CHUNK / SCAN_CHUNK_FUSED of the batch path: 256 / 128 -- a wave here holds a share of ONE query's pairs)
     A.raw = c->raw; A.region_cap = region_cap; A.rctr = c->rctr; A.qexact = c->enc.qexact; A.want_exact = 0; A.drop_len = 1;
     A.q_rec = c->enc.q_rec; A.e_rec = dl->e_rec;
+
     A.fuse = (switches().fuse_prefilter && switches().prefilter) ? 1 : 0;
     A.qpairs = nullptr; A.dbg = 0;
     const dim3 grid((A.ntiles + 3) / 4);
@@ -226,7 +227,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
   const int fastD = (enable_fast && d >= 1 && d <= 3) ? (int)d : 0;
   const SlotList l8{c->list8, c->lctr, SMALL_SURV_CAP}, lg{c->listg, c->lctr + SCAN_REGIONS * RC_STRIDE, SMALL_SURV_CAP}, lw{c->listw, c->lctr + 2 * SCAN_REGIONS * RC_STRIDE, SMALL_SURV_CAP};
   const PairArgs pa{c->raw, c->enc.q_meta, c->enc.q_rows, c->enc.q_rec, dl->e_rec, dl->ent_meta, dl->ent_rowoff, dl->rows, dl->ent_freq, dl->ent_var_off,
-                    nullptr, nullptr, c->qmaxfreq, c->qsurv, c->qexpand};
+                    nullptr, nullptr, c->qmaxfreq, c->qsurv, c->qexpand, dl->e_planes};
   // slots per region the scoring grid covers: the whole region from a few hundred inputs on, less for the smallest calls (a region filled
   // beyond it hands the call to the batch path, like every other capacity)
   uint32_t fs_cap = 2048;
@@ -257,6 +258,7 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
   const dim3 fgrid(((fs_cap + SMALL_FS_BLK - 1) / SMALL_FS_BLK) * SCAN_REGIONS);
   const bool split_wide = switches().fs_split != 0;
   const bool b7 = switches().fs_b7 && m.alphabet.size() + 1 < 0x7E;
+  const bool planes = b7 && switches().fs_planes && (int)m.alphabet.size() <= kSymbolPlanesMaxA;
 #define ANX_FS_LAUNCH(DD, WW, BB) hipLaunchKernelGGL((k_filter_score<DD, WW, BB>), fgrid, dim3(256), 0, st, fa, pa, static_cast<const FsCold*>(c->d_cold))
 #define ANX_FS_PICK(WW, BB)                        \
   do {                                             \
@@ -265,8 +267,8 @@ int small_find(const HostModel& m, const DeviceLexicon* dl, const char* const* u
     else if (fastD == 3) ANX_FS_LAUNCH(3, WW, BB); \
     else ANX_FS_LAUNCH(0, WW, BB);                 \
   } while (0)
-  if (split_wide) { if (b7) ANX_FS_PICK(false, true); else ANX_FS_PICK(false, false); }
-  else { if (b7) ANX_FS_PICK(true, true); else ANX_FS_PICK(true, false); }
+  if (split_wide) { if (planes) ANX_FS_PICK(false, 2); else if (b7) ANX_FS_PICK(false, 1); else ANX_FS_PICK(false, 0); }
+  else { if (b7) ANX_FS_PICK(true, 1); else ANX_FS_PICK(true, 0); }
 #undef ANX_FS_PICK
 #undef ANX_FS_LAUNCH
   if (threads == 256) {  // the slot-list kernels as one launch, a block per region (k_small_lists)
