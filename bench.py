@@ -134,8 +134,14 @@ def roofline_of(args, model, queries, st, scan_ms, fs_ms, total_ms):
     #  symbol codes, the kernel's B7 instances): 2 mask ands, unshifted (xor, add, and, and) = 8.8 cycles, shifted
     #  (alignbyte, xor, add, and | alignbyte, and) = 17.4; otherwise unshifted (xor, and, add, or, and, and) = 15.4, shifted
     #  (alignbyte, xor, and, add, or3, and | alignbyte, and) = 24.0.
-    #  band DL of every selected pair: rows x (2d+1) cells x (2 min, 2 add, cmp, cndmask = 16 cycles), rows ~ mean query length;
-    #  tail of every DL survivor (LCS diagonal walk, prefix, suffix, f64 score) ~ 300 instructions = 900 cycles.
+    #  DL of every selected pair, round 6: by diagonals on mismatch masks (kernels_score.hpp dl_diag): 2d + 1 masks from the symbol
+    #  planes (6 x (shift, xor-or) + 1 at 2.3 cycles = 30) + (d + 1)^2 furthest-reaching cells (slide = shift 2.3 + ffbl 4.2 + add 2.3,
+    #  max3 4.3, two adds 4.6 = 17.7) + one transposition test per (e, a, b, k') (bfe 4.1 + add 2.3 = 6.4; 1 / 6 / 20 of them for
+    #  d = 1 / 2 / 3) + the final select (2 x 4.2 per cell) -- no row loop: the same for every length (until round 6: rows x (2d+1)
+    #  cells x 16 cycles, ~720 a wave at d = 2);
+    #  tail of every DL survivor: the masks again (30 x (2d + 1)), prefix / suffix (ffbl, ffbh + shifts: 20), the band's runs
+    #  (mean query length x 3 registers x 2 x 2.3), the f64 score (5 quotients from LDS, 9 f64 operations at 4.3, compare: 80) = ~350 cycles
+    #  at d = 2 (until round 6: byte loops through LDS, ~900).
     dd = args.edit_distance
     nw = 4 if args.max_len <= 16 else 8
     sample_q = queries[:20000]
@@ -149,8 +155,10 @@ def roofline_of(args, model, queries, st, scan_ms, fs_ms, total_ms):
     # round 3: with the filter fused into the scan's expansion the band bound of those pairs is the SCAN's work (uniform d per
     # tile: one OR per shifted word less); k_filter_score only filters the few pairs the scan left unflagged (wide candidates)
     fs_filter_waves = 0.0 if fused else st["n_pair_slots"] / 64.0
-    fs_cycles = fs_filter_waves * band_cycles_per_wave \
-        + (st["n_selected"] / 64.0) * (mean_len * (2 * dd + 1) * 16.0) + (st["n_survivors"] / 64.0) * 900.0
+    ntrans = {0: 0, 1: 1, 2: 6, 3: 20}.get(dd, 20)
+    dl_cycles = (2 * dd + 1) * 30.0 + (dd + 1) ** 2 * (17.7 + 8.4) + ntrans * 6.4
+    tail_cycles = (2 * dd + 1) * 30.0 + 20.0 + mean_len * 3 * 2 * 2.3 + 80.0
+    fs_cycles = fs_filter_waves * band_cycles_per_wave + (st["n_selected"] / 64.0) * dl_cycles + (st["n_survivors"] / 64.0) * tail_cycles
     fs_valu_floor_ms = fs_cycles / SIMD_HZ * 1e3
     valu_floor_ms += (fused / 64.0) * ((c_mask + c_unshifted + 2 * dd * (c_shifted - 2.2) + 2 * 6.5) * words) / SIMD_HZ * 1e3
     # HBM bytes per launch of that kernel from the committed PMC passes: only for the same workload AND the same kernel

@@ -8,7 +8,7 @@ and of every A/B switch of the hot path (DESIGN.md "Switches").
    ANX_SCAN_FUSE=0 (the scan leaves the bound to k_filter_score) and with ANX_PREFILTER=0 (no bound anywhere: every
    length-compatible pair goes through the DL) must agree on the scored-pair count, the survivor count and the result checksum
    -- a false reject anywhere, also of a pair that would not have made the top n, changes n_survivors.
-3. The remaining result-neutral switches (ANX_SCAN=sad, ANX_SCORE_FAST=0, ANX_FS_SPLIT=0, ANX_FS_B7=0) on a mid-size batch."""
+3. The remaining result-neutral switches (ANX_SCAN=sad, ANX_SCORE_FAST=0, ANX_FS_SPLIT=0, ANX_FS_B7=0, ANX_FS_PLANES=0) on a mid-size batch."""
 import ctypes as C
 import os
 
@@ -126,7 +126,7 @@ def test_filters_off_equal_default_at_full_size(data_dir, lex, maxlen, d, nq):
         b.free()
 
 
-@pytest.mark.parametrize("switch,value", [("ANX_SCAN_ADJ", "0"), ("ANX_SCAN", "sad"), ("ANX_SCORE_FAST", "0"), ("ANX_FS_SPLIT", "0"), ("ANX_FS_B7", "0")])
+@pytest.mark.parametrize("switch,value", [("ANX_SCAN_ADJ", "0"), ("ANX_SCAN", "sad"), ("ANX_SCORE_FAST", "0"), ("ANX_FS_SPLIT", "0"), ("ANX_FS_B7", "0"), ("ANX_FS_PLANES", "0")])
 def test_result_neutral_switches(data_dir, switch, value):
     g = A.VariantModel(os.path.join(data_dir, "simple.alphabet.tsv"), A.Weights(), device=0)
     g.read_lexicon(os.path.join(data_dir, "eng.aspell.lexicon"))

@@ -85,9 +85,10 @@ def test_occupancy_of_the_dominant_kernels(kernels):
     # round 4: the instance of k_rank for models without variant lists at freq_weight 0 (what every BASELINE configuration runs)
     simple = [r for n, r in kernels.items() if "k_rankILb1" in n]
     assert simple and all(r["sgpr_spill_count"] == 0 and r["vgpr_count"] <= 72 for r in simple), simple
-    # round 6: one pass (DL by diagonals on the slots as they lie, a survivor queue per wave, the tail from the same masks): 7 waves per
-    # SIMD; the instances with the inline 8-word prefilter only run under ANX_FS_SPLIT=0 (A/B)
-    assert vgprs("k_filter_scoreILi2ELb0") <= 72
-    assert vgprs("k_filter_scoreILi1ELb0") <= 72
-    assert vgprs("k_filter_scoreILi3ELb0") <= 72
+    # round 6: one pass (DL by diagonals on the slots as they lie, a survivor queue per wave, the tail from the same masks): 6 waves per
+    # SIMD on symbol planes (twelve plane registers), 7 on byte rows -- measured: no difference between 6, 7 and 8 (HISTORY.md section 15);
+    # the instances with the inline 8-word prefilter only run under ANX_FS_SPLIT=0 (A/B)
+    assert vgprs("k_filter_scoreILi2ELb0") <= 80
+    assert vgprs("k_filter_scoreILi1ELb0") <= 80
+    assert vgprs("k_filter_scoreILi3ELb0") <= 80
     assert vgprs("k_filter_score") <= 112
