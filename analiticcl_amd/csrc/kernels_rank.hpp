@@ -365,17 +365,24 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
                             r_rows, r_count);
     return;
   }
+  // (wave-uniform) every row of the list is some lane's `mine`: the ranked row then comes out of the registers of the lane that loaded
+  // it (shuffles inside the group) instead of a second gather of c_rows -- one dependent memory round trip less per wave.  The loop
+  // below therefore runs with every lane (trip count nloop / G, lanes without a row masked by `have`).
+  const bool one_row_per_lane = nloop <= (uint32_t)G;
   n = kept;
   if (valid && n == 0 && gl == 0) r_count[q] = 0;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // ---- rank by counting -------------------------------------------------------------------------------
   const bool full = score_weighted || a.max_matches == 0 || expanded;
   const uint32_t M = full ? n : (uint32_t)min((uint64_t)n, a.max_matches + 1);
-  for (uint32_t i = gl; i < n; i += G) {
-    const double ki = s_key[i];
-    const uint32_t fi = s_freq[i];
-    const unsigned long long oi = s_ord[i];
-    uint32_t rank = 0;
+  for (uint32_t base = 0; base < nloop; base += G) {
+    const uint32_t i = base + (uint32_t)gl;
+    const bool have = i < n;
+    const double ki = have ? s_key[i] : 0.0;
+    const uint32_t fi = have ? s_freq[i] : 0u;
+    const unsigned long long oi = have ? s_ord[i] : 0ull;
+    uint32_t rank = have ? 0u : 0xFFFFFFFFu;
+    if (have) {
     // every comparison is evaluated and the flags combined with bit operations: short-circuit && / || compiled to nested
     // exec-masked branches, four per candidate; the wave-uniform choice of the order is taken outside the loop
     if (sort_weighted) {
@@ -392,12 +399,25 @@ __device__ inline void rank_query(uint32_t q, bool valid, int gl, int gshift, ui
         rank += (uint32_t)((kj > ki) | ((kj == ki) & ((fj > fi) | ((fj == fi) & (oj < oi)))));
       }
     }
-    if (rank < M) {
+    }
+    uint32_t r_vocab = 0, r_via = 0;
+    double r_score = 0.0;
+    if (one_row_per_lane) {
+      const int from = gshift + (have ? (int)s_src[i] : gl);   // the lane whose `mine` is this slot's source row
+      const unsigned long long sbits = (unsigned long long)__double_as_longlong(mine.score);
+      r_vocab = (uint32_t)__shfl((int)mine.vocab, from);
+      r_via = (uint32_t)__shfl((int)mine.via, from);
+      const uint32_t s_lo = (uint32_t)__shfl((int)(uint32_t)sbits, from), s_hi = (uint32_t)__shfl((int)(uint32_t)(sbits >> 32), from);
+      r_score = __longlong_as_double((long long)((unsigned long long)s_lo | (unsigned long long)s_hi << 32));
+    } else if (have && rank < M) {
       const SurvRow r = c_rows[seg0 + s_src[i]];
+      r_vocab = r.vocab; r_via = r.via; r_score = r.score;
+    }
+    if (have && rank < M) {
       // (without frequency information max_freq is 1 or 0: x / 1.0 == x, no f64 division)
       const double ff = (a.have_freq && max_freq > 0.0) ? (double)fi / max_freq : (double)fi;
-      r_rows[seg0 + rank] = DevRow{r.vocab, a.any_variants ? r.via : 0xFFFFFFFFu, r.score, ff};
-      if (rank < (uint32_t)G) { s_sdist[rank] = r.score; s_sfreq[rank] = ff; }
+      r_rows[seg0 + rank] = DevRow{r_vocab, a.any_variants ? r_via : 0xFFFFFFFFu, r_score, ff};
+      if (rank < (uint32_t)G) { s_sdist[rank] = r_score; s_sfreq[rank] = ff; }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
