@@ -73,6 +73,9 @@ __global__ __launch_bounds__(COMPACT_B) void k_compact_grouped(const SurvRec* __
     uint32_t slot = 0, rank = 0;
     bool owner = false;
     if (live) sr = surv[(size_t)region * region_cap + i];
+    // (requested here: the gather travels while the block groups its survivors and waits for the cursors' returning atomics)
+    EntRec er{};
+    if (live) er = ent_rec[sr.e];
     {
       // The survivors of a query sit next to each other (k_filter_score appends them in pair-list order, a scan tile's queries
       // one after the other): a RUN of equal queries among neighbouring lanes is inserted by its first lane alone, with the run's
@@ -105,7 +108,6 @@ __global__ __launch_bounds__(COMPACT_B) void k_compact_grouped(const SurvRec* __
     if (owner) h_base[slot] = atomicAdd(&qcur[sr.q], h_cnt[slot]);  // qcur starts as a copy of soff
     __syncthreads();
     if (live) {
-      const EntRec er = ent_rec[sr.e];
       c_rows[h_base[slot] + rank] = SurvRow{sr.score, (unsigned long long)er.order << 20, er.vocab, have_freq ? er.freq : 1u, 0xFFFFFFFFu, 0u};
     }
     __syncthreads();  // the table is cleared for the next chunk
