@@ -675,3 +675,58 @@ def test_pipeline_equals_staged_calls(eng, data_dir):
     assert np.array_equal(o, want[0][0]) and np.array_equal(r, want[0][1])
     pl.submit(blobs[3], len(sets[3]), p)         # jobs still in flight when the pipeline is freed
     pl.close()
+
+
+@pytest.mark.parametrize("nclasses", [26, 61, 62])
+def test_dl_by_diagonals_edge_cases(nclasses):
+    """k_filter_score's Damerau-Levenshtein runs by diagonals on mismatch masks (kernels_score.hpp dl_diag), the masks from symbol planes
+    for alphabets of <= 61 classes (26, 61) and from the byte rows beyond (62).  Words of 13..17 symbols (16 = the last length of the
+    inline path, 17 = the first one of the 8-word kernel) over few letters, among them the alphabet's last ones (the highest symbol
+    codes); queries made of them by transpositions with and without a gap, edits at the very start / end, repeated symbols; d = 1, 2, 3.
+    Every scored pair's (ld, lcs, prefix, suffix) and the ranked lists against the oracle (src/distance.rs:101-231)."""
+    rng = random.Random(900 + nclasses)
+    letters = [chr(c) for c in range(ord("a"), ord("z") + 1)] + [chr(c) for c in range(0x3B1, 0x3B1 + 25)] + [chr(c) for c in range(0x430, 0x430 + 32)]
+    letters = letters[:nclasses]
+    assert len(letters) == nclasses
+    tsv = "\n".join(letters) + "\n"
+    few = letters[:5] + letters[-3:]
+    words = set()
+    while len(words) < 1200:
+        words.add("".join(rng.choice(few) for _ in range(rng.choice([13, 14, 15, 16, 16, 16, 17]))))
+    words = sorted(words)
+
+    def mutate(w):
+        w = list(w)
+        for _ in range(rng.randint(1, 3)):
+            op = rng.randrange(6)
+            if op == 0 and len(w) > 2:      # adjacent transposition, often at an end
+                i = rng.choice([0, len(w) - 2, rng.randrange(len(w) - 1)])
+                w[i], w[i + 1] = w[i + 1], w[i]
+            elif op == 1 and len(w) > 3:    # transposition around a deleted symbol
+                i = rng.randrange(len(w) - 2)
+                w[i], w[i + 2] = w[i + 2], w[i]
+                del w[i + 1]
+            elif op == 2 and len(w) > 2:    # transposition around an inserted symbol
+                i = rng.randrange(len(w) - 1)
+                w[i], w[i + 1] = w[i + 1], w[i]
+                w.insert(i + 1, rng.choice(few))
+            elif op == 3 and len(w) > 1:
+                del w[rng.choice([0, len(w) - 1])]
+            elif op == 4:
+                w.insert(rng.choice([0, len(w)]), rng.choice(few))
+            else:
+                w[rng.randrange(len(w))] = rng.choice(few)
+        return "".join(w)
+    queries = [mutate(rng.choice(words)) for _ in range(500)] + words[:100]
+    g = A.VariantModel("", alphabet_text=tsv, device=0)
+    o = O.OracleModel(alphabet_text=tsv)
+    for w in words:
+        g.add_to_vocabulary(w)
+        o.add(w)
+    g.build()
+    o.build()
+    for d in (1, 2, 3):
+        gp, op = params_pair(("abs", 3), ("abs", d), 50, 0.0, 0.0)
+        st = compare_batch(g, o, queries, gp, op)
+        assert st["n_survivors"] > 0
+

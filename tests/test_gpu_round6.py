@@ -143,3 +143,4 @@ def test_early_output_stays_on_with_more_parts_than_workers(data_dir):
     finally:
         for sw in ("ANX_SEARCH_PARTS_MIN", "ANX_SEARCH_PART_BYTES", "ANX_SEARCH_PARTS"):
             A.set_switch(sw, None)
+
