@@ -321,7 +321,7 @@ def by_batch_size_of(model, om, queries, params, op, sizes=(1, 64, 1000, 32768, 
     in batches of 1 000, src/bin/analiticcl.rs:416, bindings/python/src/lib.rs:704-749): anx_find_variants_batch (char** in, anx_result
     rows + offsets out) host to host for n = 1 .. 1 M inputs -- best / median microseconds per call, the rows of every size against the
     oracle -- and `threads` host threads each issuing calls of 1 000 inputs on the one model.  Calls of <= 4096 short inputs take the
-    small path (analiticcl_amd/csrc/small_path.hpp: eleven launches, one host wait); larger ones the batch pipeline."""
+    small path (analiticcl_amd/csrc/small_path.hpp: nine launches, one host wait); larger ones the batch pipeline."""
     import ctypes as C
     import random
     import statistics

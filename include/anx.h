@@ -342,7 +342,7 @@ int anx_debug_kernel_time(const char *name, double *total_ms, uint64_t *launches
  * had to write at the end (an upper bound did not hold), out[3] = 0 (reserved). */
 int anx_debug_search_stats(uint64_t out[4]);
 /* The small call: anx_find_variants_batch answers calls of at most 4096 inputs of at most 64 bytes each (single-device models without
- * variant lists, confusables or StopAtExactMatch) through a path of eleven launches and one host wait with preallocated buffers (the
+ * variant lists, confusables or StopAtExactMatch) through a path of nine launches and one host wait with preallocated buffers (the
  * reference's own granularity: one string per call, src/lib.rs:972; 1 000 per batch, src/bin/analiticcl.rs:416) instead of the batch
  * pipeline; results are identical.  ANX_SMALL=0 switches it off (A/B).  out[0] = calls it answered since the library was loaded,
  * out[1] = calls it handed to the batch pipeline because a fixed capacity did not hold. */
