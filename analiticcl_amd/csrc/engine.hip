@@ -1399,9 +1399,8 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     }
     so.list = b->surv;
     so.region_cap = (uint32_t)b->surv_region_cap;
-    // slot lists for the pairs the fused kernel cannot score inline: strings of 17..32 symbols (8-word kernel, when the
-    // batch has such queries) and everything else (longer strings, d > 3, or the few long candidates of a short-query
-    // batch: for those the general kernel is cheaper than the 8-word one, measured 0.10 vs 0.22 ms on config 2)
+    // slot lists for the pairs the fused kernel cannot score inline: strings of 17..32 symbols (8-word kernel) and everything
+    // else (longer strings, d > 3)
     const bool need_lists = !fastD || have_long_q || dl->max_len > 16;
     if (need_lists) {
       // without the inline DL (d > 3) every length-compatible pair goes to the general list; else the prefilter passes ~1/3
@@ -1424,7 +1423,10 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
                       b->p_score, b->p_meta, b->qmaxfreq, b->qsurv, b->qexpand, dl->e_planes};
     FilterArgs fa;
     fa.region_shift = b->region_shift; fa.rctr = b->rctr; fa.qexact = b->qexact; fa.stop = stop; fa.enable = enable_filter;
-    fa.use_nw8 = have_long_q ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap; fa.blk = FS_BLK;
+    // pairs with a string of 17..32 symbols go to the 8-word register DL also when no QUERY is that long (the few 17..19-symbol candidates
+    // of a short-query batch): until round 6 those went to the general LDS kernel, whose one round cost 0.05 ms (scoring stage of BASELINE
+    // configs[1] 0.555 -> 0.53 ms; the three slot-list kernels as ONE launch, k_small_lists, on top of that: 0.527, not kept)
+    fa.use_nw8 = (have_long_q || fastD > 0) ? 1 : 0; fa.counters = b->counters; fa.stat_ctr = b->sctr; fa.fill_cap = fill_cap; fa.blk = FS_BLK;
     const dim3 fgrid(((fill_cap + FS_BLK - 1) / FS_BLK) * SCAN_REGIONS);
     {
       FsCold* cold = reinterpret_cast<FsCold*>(reinterpret_cast<char*>(b->h_read) + HR_COLD_OFF);  // pinned: a truly asynchronous copy
@@ -1458,7 +1460,7 @@ static int batch_launch(const HostModel& m, const DeviceLexicon* dl, Batch* b, v
     if (need_lists) {  // the list fills are only known on the device: fixed grids walk the lists in strides
       const dim3 lgrid(LIST_P * SCAN_REGIONS);
       if (split_wide && enable_filter) hipLaunchKernelGGL(k_filter_wide, lgrid, dim3(256), 0, st, lw, fa, pa, sa, fastD, l8, lg);
-      if (fastD && have_long_q) {
+      if (fastD) {
         if (fastD == 1) hipLaunchKernelGGL(k_score_fast8<1>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
         else if (fastD == 2) hipLaunchKernelGGL(k_score_fast8<2>, lgrid, dim3(256), 0, st, l8, pa, sa, so);
         else hipLaunchKernelGGL(k_score_fast8<3>, lgrid, dim3(256), 0, st, l8, pa, sa, so);

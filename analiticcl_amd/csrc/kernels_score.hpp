@@ -763,7 +763,8 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
     uint32_t S[4] = {0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu}, T[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // MODE 0 / 1
     uint4 qpl = make_uint4(0u, 0u, 0u, 0u), cpl = qpl;   // MODE 2: the pair's plane records
     bool stop_skipped = false;
-    if (__any(!invalid && !pre)) {
+    const bool general = __any(!invalid && !pre);   // wave-uniform
+    if (general) {
       bool skip = invalid;
       if (f.stop)  // StopAtExactMatch: a non-exact class of a query that has an exact one (wave-uniform branch)
         skip = skip || (!pre && !(rp.y & 0x80000000u) && f.qexact[skip ? 0u : rp.x] != 0xFFFFFFFFu);
@@ -829,14 +830,16 @@ __global__ __launch_bounds__(256) void k_filter_score(FilterArgs f, PairArgs A, 
       A.p_meta[p] = (invalid || stop_skipped) ? META_SKIPPED : (PAIR_NONE | (1u << 7));
     const bool to8 = selected && !inl && !tow && f.use_nw8 && D > 0 && lq <= 32 && lc <= 32 && d <= D;
     const bool tog = selected && !inl && !tow && !to8;
-    slot_append(list8, region, to8, p);
-    slot_append(listg, region, tog, p);
-    if (!WIDE) slot_append(listw, region, tow, p);
-    nselected += (uint32_t)__popcll(__ballot(selected && !tow));
-    if (f.stop) {  // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops
-      const unsigned long long ms = __ballot(stop_skipped);
-      if (lane == 0 && ms) atomicAdd(&f.counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
+    if (general || D == 0) {   // (a short round with the inline DL lists nothing: every pair it has is inline)
+      slot_append(list8, region, to8, p);
+      slot_append(listg, region, tog, p);
+      if (!WIDE) slot_append(listw, region, tow, p);
+      if (f.stop) {  // scored pairs = pairs emitted by the scan minus the ones StopAtExactMatch drops
+        const unsigned long long ms = __ballot(stop_skipped);
+        if (lane == 0 && ms) atomicAdd(&f.counters[CTR_SKIPPED], (uint32_t)__popcll(ms));
+      }
     }
+    nselected += (uint32_t)__popcll(__ballot(selected && !tow));
     if (D > 0) {
       if (ANX_DBG(a.dbg) & 4) {   // timing: the rows are consumed, no DL
         asm volatile("" :: "v"(S[0]), "v"(S[1]), "v"(S[2]), "v"(S[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(lq), "v"(lc), "v"(qpl.y), "v"(qpl.z), "v"(qpl.w), "v"(cpl.y), "v"(cpl.z), "v"(cpl.w));
