@@ -715,11 +715,23 @@ def extra_configs(args, paths, device, ncores):
         spc = sp._c_search()
         best = None
         call_s = []
+
+        def _throttled():  # CFS quota: periods in which the cgroup ran out of CPU time (a search call keeps ~10 host cores busy; a
+            for path_ in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):   # throttled period stalls it for tens of ms)
+                try:
+                    for line_ in open(path_):
+                        if line_.startswith("nr_throttled"):
+                            return int(line_.split()[1])
+                except OSError:
+                    pass
+            return 0
+        thr0 = 0
         # a stream of calls: the first ones of a process still grow the pinned result cache and the device pool (a same-box series:
         # best of calls 1-5 256 MB/s, of 6-10 274, of 11-15 284); four untimed calls, then five timed ones (kernel timer on)
         for i_ in range(9):
             if i_ == 4:
                 L_.kernel_timer(True)
+                thr0 = _throttled()
             ms, offs, rows, nrows = C.POINTER(L.Match)(), C.POINTER(C.c_size_t)(), C.POINTER(L.Result)(), C.c_size_t(0)
             t = time.perf_counter()
             L.check(L.lib().anx_find_all_matches_batch(m.h, arr, len(texts), C.byref(spc), C.byref(ms), C.byref(offs), C.byref(rows), C.byref(nrows), None))
@@ -728,6 +740,7 @@ def extra_configs(args, paths, device, ncores):
             if i_ >= 4:
                 call_s.append(dt)
                 best = dt if best is None else min(best, dt)
+        thr_timed = _throttled() - thr0
         lat_ms, lat_n = L_.kernel_time("k_lattice")
         lm_ms, _lm_n = L_.kernel_time("k_lattice_lm")
         L_.kernel_timer(False)
@@ -771,6 +784,7 @@ def extra_configs(args, paths, device, ncores):
         del om
         return {"workload": "BASELINE.json configs[4], one GPU's share: 12.5 MB of synthetic running text (sentences of 5-25 perturbed words), max_ngram 3, bigram LM, anx_find_all_matches_batch",
                 "MB_per_s": nbytes / 1e6 / best, "seconds": best, "cpu_baseline": cpu4, "median_MB_per_s": nbytes / 1e6 / sorted(call_s)[len(call_s) // 2], "calls": "4 untimed + 5 timed, best / median of the timed ones",
+                "call_seconds": [round(x, 5) for x in call_s], "cgroup_throttled_periods_during_timed_calls": thr_timed,
                 "matches": int(off[-1]), "variant_rows": int(ra.shape[0]),
                 # k_lattice per call (all its launches): algorithmic bytes = the lattice input (16 B per arc: one arc per variant row, plus
                 # one out-of-vocabulary / epsilon arc per match) + the chosen symbols out (8 B per match)
