@@ -535,18 +535,7 @@ __device__ inline void load_pair_qe(uint32_t q, uint32_t e, bool active, const P
     if (w * 16 < r.lc) { const uint4 C = cr[w]; r.T[4 * w] = C.x; r.T[4 * w + 1] = C.y; r.T[4 * w + 2] = C.z; r.T[4 * w + 3] = C.w; }
   }
 }
-// DL of the loaded pair (all lanes of the wave call this); PAIR_NONE if above the pair's d
-#ifndef ANX_DL_BAND   // (A/B builds: -DANX_DL_BAND=1 keeps the row form for every pair)
-#define ANX_DL_BAND 0
-#endif
-template <int D, bool B7>
-__device__ __forceinline__ uint32_t dl_of_pair16(const PairRegs<4>& r, bool active) {
-  DiagMasks<D, B7> dm;
-  dm.build(r.S, r.T);
-  const uint32_t res = dl_diag<D>(dm, r.lq, r.lc);
-  const int diff = r.lq > r.lc ? r.lq - r.lc : r.lc - r.lq;
-  return (active && diff <= r.d && res <= (uint32_t)r.d) ? res : PAIR_NONE;  // src/distance.rs:109-130, 173-178
-}
+// DL of the loaded pair in the row form (the 8-word kernel; all lanes of the wave call this); PAIR_NONE if above the pair's d
 template <int D, int NW>
 __device__ inline uint32_t dl_of_pair(const PairRegs<NW>& r, bool active) {
   int lqmax = active ? r.lq : 0;
