@@ -986,6 +986,9 @@ def strong_scaling_job(args):
 
 
 def main():
+    if os.environ.get("ANX_BENCH_WATCHDOG"):   # diagnosis: every thread's Python stack to stderr after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ANX_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -1175,11 +1178,23 @@ def main():
     # region starts and runs at its steady-state clocks
     preroll_steps = 0
     if args.preroll_s > 0 and not args.timed_only:
+        # The SAME number of steps on every rank: a step posts a collective (the size exchange of the result gather), and a loop that
+        # each rank ends by its own clock left ranks with different counts -- one rank in the barrier, the others waiting for its
+        # gather (seen as an intermittent hang of the 3-ranks-on-one-GPU job, 3 in 24 runs, once the steps had become shorter).
+        # One chunk of 8 steps is timed, the slowest rank's time decides how many more chunks everybody runs.
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.preroll_s:
+        for k in range(8):
+            step(k, stream.cuda_stream, False)
+        barrier()
+        t8 = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(t8, op=dist.ReduceOp.MAX)
+        t8 = max(float(t8.item()), 1e-4)
+        nchunks = max(0, min(100000, int((args.preroll_s - t8) / t8)))
+        for _ in range(nchunks):
             for k in range(8):
                 step(k, stream.cuda_stream, False)
-            preroll_steps += 8
+        preroll_steps = 8 * (1 + nchunks)
         barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
