@@ -14,6 +14,7 @@
 #include <deque>
 #include <functional>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <new>
 #include <iterator>
@@ -680,9 +681,10 @@ struct Stretch {  // one hard-boundary "batch" of the reference (src/lib.rs:1821
 
 }  // namespace
 
+static void search_out_cache_trim();   // (the cache of output blocks, below)
 extern "C" {
-// joins the library's host threads (the pool of search mode); see include/anx.h
-void anx_shutdown(void) { HostPool::shutdown(); }
+// joins the library's host threads (the pool of search mode) and releases the cached output blocks; see include/anx.h
+void anx_shutdown(void) { HostPool::shutdown(); search_out_cache_trim(); }
 }
 // the library is unloaded (dlclose) or the process exits through exit(): no thread of ours may be left running code that is about to be unmapped
 __attribute__((destructor)) static void anx_on_unload() { HostPool::shutdown(); }
@@ -728,6 +730,81 @@ static void advise_huge(void* p, size_t bytes) {
   (void)p; (void)bytes;
 #endif
 }
+// Round 6: the big output arrays of a call (matches, variant rows: 190 MB for 12.5 MB of text) come from a small cache of blocks that
+// anx_matches_free hands back, instead of fresh memory every time.  Fresh memory means page faults and zeroing inside the output loops
+// (with transparent huge pages: 2 MB pieces that the kernel has to find contiguous), and in a long-lived process that had churned through
+// a hundred GB of host memory two calls of a series of five took 80 instead of 41-50 ms (bench.py's search line, no cgroup throttling;
+// a fresh process: 37-46 ms).  Blocks below 1 MB are plain malloc blocks; the cache keeps at most ANX_SEARCH_OUT_CACHE_MB (default 1024).
+extern "C++" {
+namespace {
+struct OutCache {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;   // blocks handed out (capacity in bytes)
+  std::multimap<size_t, void*> idle;        // blocks that came back
+  size_t idle_bytes = 0;
+};
+OutCache& out_cache() { static OutCache* c = new OutCache(); return *c; }   // (never destroyed: anx_matches_free may run at exit)
+size_t out_cache_limit() {
+  static const size_t lim = []() { const char* e = getenv("ANX_SEARCH_OUT_CACHE_MB"); return (size_t)(e ? strtoull(e, nullptr, 10) : 1024ull) << 20; }();
+  return lim;
+}
+void* out_alloc(size_t bytes) {
+  bytes = std::max<size_t>(bytes, 1);
+  if (bytes < ((size_t)1 << 20) || out_cache_limit() == 0) return malloc(bytes);
+  OutCache& c = out_cache();
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.idle.lower_bound(bytes);
+    if (it != c.idle.end() && it->first <= 2 * bytes) {
+      void* p = it->second;
+      c.idle_bytes -= it->first;
+      c.live[p] = it->first;
+      c.idle.erase(it);
+      return p;
+    }
+  }
+  void* p = malloc(bytes);
+  if (!p) return nullptr;
+  advise_huge(p, bytes);
+  std::lock_guard<std::mutex> g(c.mu);
+  c.live[p] = bytes;
+  return p;
+}
+// true: p was a cached block (kept or released); false: not one of ours, the caller frees it
+bool out_release(void* p) {
+  if (!p) return true;
+  OutCache& c = out_cache();
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.live.find(p);
+    if (it == c.live.end()) return false;
+    cap = it->second;
+    c.live.erase(it);
+    if (c.idle_bytes + cap <= out_cache_limit()) {
+      c.idle.emplace(cap, p);
+      c.idle_bytes += cap;
+      return true;
+    }
+  }
+  free(p);
+  return true;
+}
+void out_cache_trim() {
+  OutCache& c = out_cache();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    for (auto& kv : c.idle) drop.push_back(kv.second);
+    c.idle.clear();
+    c.idle_bytes = 0;
+  }
+  for (void* p : drop) free(p);
+}
+}  // namespace
+static void search_out_cache_trim() { out_cache_trim(); }
+}  // extern "C++"
+
 // What the pipeline leaves for a part of a call: the matches of every text (their variants are views of the kept result arrays of
 // the n-gram orders), the tags, and the sizes of the part's share of the output arrays.
 struct OrderRows { anx_result* rows; size_t* offs; };
@@ -890,11 +967,10 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
       for (auto& p : P) ub += p->ub_matches.load(std::memory_order_acquire);
       early.m_cap = std::max<size_t>(1, ub);
       early.r_cap = std::max<size_t>(1, ub * ((size_t)sp->base.max_matches + 2));
-      early.om = static_cast<anx_match*>(malloc(early.m_cap * sizeof(anx_match)));
+      early.om = static_cast<anx_match*>(out_alloc(early.m_cap * sizeof(anx_match)));
       early.oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
-      early.orows = static_cast<anx_result*>(malloc(early.r_cap * sizeof(anx_result)));
-      if (!early.om || !early.oo || !early.orows) { free(early.om); free(early.oo); free(early.orows); early = Early(); }
-      else { advise_huge(early.om, early.m_cap * sizeof(anx_match)); advise_huge(early.orows, early.r_cap * sizeof(anx_result)); }
+      early.orows = static_cast<anx_result*>(out_alloc(early.r_cap * sizeof(anx_result)));
+      if (!early.om || !early.oo || !early.orows) { if (!out_release(early.om)) free(early.om); free(early.oo); if (!out_release(early.orows)) free(early.orows); early = Early(); }
     }
     if (early.on) {
       size_t mb = 0, rb = 0;
@@ -919,7 +995,7 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     g_search_multi_calls.fetch_add(1, std::memory_order_relaxed);
     if (early.on && early.om && early.parts_written == parts) g_search_early_kept.fetch_add(1, std::memory_order_relaxed);
     else if (anx::switches().search_early_output && sp->base.max_matches > 0 && !out_tags) g_search_early_dropped.fetch_add(1, std::memory_order_relaxed);
-    if (early.om && (!early.on || early.parts_written != parts)) { free(early.om); free(early.oo); free(early.orows); early = Early(); }
+    if (early.om && (!early.on || early.parts_written != parts)) { if (!out_release(early.om)) free(early.om); free(early.oo); if (!out_release(early.orows)) free(early.orows); early = Early(); }
     for (auto& p : P)
       if (p->rc != ANX_OK && !p->err.empty()) return anx_fail(p->rc, p->err);
     for (auto& p : P)
@@ -929,9 +1005,9 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
   // copied here: twice the fresh pages, and 38 ms of copying per 12.5 MB of text)
   const bool timing = anx::switches().search_timing != 0;
   const auto t_out = std::chrono::steady_clock::now();
-  if (early.on && early.om && early.parts_written == parts) {  // everything is written: the arrays shrink to what was used
-    anx_match* om2 = static_cast<anx_match*>(realloc(early.om, std::max<size_t>(1, early.m_total) * sizeof(anx_match)));
-    anx_result* or2 = static_cast<anx_result*>(realloc(early.orows, std::max<size_t>(1, early.r_total) * sizeof(anx_result)));
+  if (early.on && early.om && early.parts_written == parts) {  // everything is written (the arrays keep their capacity: cached blocks)
+    anx_match* om2 = early.om;
+    anx_result* or2 = early.orows;
     for (size_t r = 0; r < parts; ++r) P[r]->free_kept();
     auto garbage = std::make_shared<std::vector<std::unique_ptr<PartOut>>>(std::move(P));
     HostPool::get().post([garbage]() { garbage->clear(); });
@@ -949,13 +1025,11 @@ int anx_find_all_matches_batch(const anx_model* model, const char* const* texts,
     r0[r + 1] = r0[r] + P[r]->total_rows;
     t0[r + 1] = t0[r] + P[r]->total_tags;
   }
-  anx_match* om = static_cast<anx_match*>(malloc(std::max<size_t>(1, m0[parts]) * sizeof(anx_match)));
+  anx_match* om = static_cast<anx_match*>(out_alloc(std::max<size_t>(1, m0[parts]) * sizeof(anx_match)));
   size_t* oo = static_cast<size_t*>(calloc(n + 1, sizeof(size_t)));
-  anx_result* orows = static_cast<anx_result*>(malloc(std::max<size_t>(1, r0[parts]) * sizeof(anx_result)));
+  anx_result* orows = static_cast<anx_result*>(out_alloc(std::max<size_t>(1, r0[parts]) * sizeof(anx_result)));
   anx_match_tag* otags = out_tags ? static_cast<anx_match_tag*>(malloc(std::max<size_t>(1, t0[parts]) * sizeof(anx_match_tag))) : nullptr;
-  if (!om || !oo || !orows || (out_tags && !otags)) { free(om); free(oo); free(orows); free(otags); return anx_fail(ANX_EINVAL, "out of memory"); }
-  advise_huge(om, m0[parts] * sizeof(anx_match));
-  advise_huge(orows, r0[parts] * sizeof(anx_result));
+  if (!om || !oo || !orows || (out_tags && !otags)) { if (!out_release(om)) free(om); free(oo); if (!out_release(orows)) free(orows); free(otags); return anx_fail(ANX_EINVAL, "out of memory"); }
   double t_write = 0.0, t_reset = 0.0;
   {
     const auto ta = std::chrono::steady_clock::now();
@@ -1737,9 +1811,9 @@ static int find_all_part(const anx_model* model, const char* const* texts, size_
 }
 
 void anx_matches_free(anx_match* matches, size_t* offsets, anx_result* rows, anx_match_tag* tags) {
-  free(matches);
+  if (!out_release(matches)) free(matches);   // (the two big arrays go back to the cache of output blocks)
   free(offsets);
-  free(rows);
+  if (!out_release(rows)) free(rows);
   free(tags);
 }
 

@@ -321,7 +321,8 @@ void anx_batch_free(anx_batch *);
  * another library needs the memory. */
 void anx_device_pool_trim(int device);
 /* Joins the host threads the library keeps between calls (the pool search mode's parallel loops run on; a model's replica threads
- * end with anx_model_free).  Call it with no library call in flight -- before dlclose() or at the end of main(); the library also
+ * end with anx_model_free) and releases the output blocks anx_matches_free keeps for the next search call (at most
+ * ANX_SEARCH_OUT_CACHE_MB, default 1024).  Call it with no library call in flight -- before dlclose() or at the end of main(); the library also
  * does it from a destructor function when it is unloaded.  The next call that needs the pool starts a fresh one.  After fork() the
  * child starts with no pool (a pthread_atfork handler forgets the parent's), so forked workers may use the library independently;
  * device state (models, batches) is NOT usable across fork(): create models in the child. */
@@ -438,7 +439,7 @@ void anx_default_search_params(anx_search_params *);
 int anx_find_all_matches_batch(const anx_model *, const char *const *utf8_texts, size_t n, const anx_search_params *,
                                anx_match **out_matches, size_t **out_offsets, anx_result **out_rows, size_t *out_n_rows,
                                anx_match_tag **out_tags);
-void anx_matches_free(anx_match *matches, size_t *offsets, anx_result *rows, anx_match_tag *tags);
+void anx_matches_free(anx_match *matches, size_t *offsets, anx_result *rows, anx_match_tag *tags);   /* (the two large arrays are kept for the next call: see anx_shutdown) */
 /* the text `analiticcl search` prints for the matches of n texts (src/bin/analiticcl.rs:21-187, 600-630): per match the
  * input slice, its offsets, tags, and the variants with the selected one first.  Needs byte offsets (unicodeoffsets
  * = 0).  *n_matches = matches formatted (JSON items are numbered from first_seqnr). */
