@@ -621,6 +621,8 @@ __device__ inline void score_fast_pair(uint32_t p, bool active, const PairArgs& 
 //   D = 0: no inline DL (d > 3), everything selected goes to the general kernel's list.
 constexpr uint32_t FS_BLK = 4096;
 constexpr uint32_t FS_SURV = 256;    // entries of a wave's LDS survivor queue
+static_assert(FS_BLK <= 65536 && FS_BLK % 256 == 0, "slot offsets inside a block are 16-bit, a round is 256 slots");
+static_assert(FS_SURV >= 128 && FS_SURV % 64 == 0, "a round adds at most 64 entries to a queue that is drained above FS_SURV - 64");
 struct FilterArgs {
   uint32_t region_shift;
   const uint32_t* rctr;     // region fills of the pair list
